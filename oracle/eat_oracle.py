@@ -1,0 +1,249 @@
+"""Functional fp32 CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY).
+
+Everything here works on a plain ``state_dict`` in the reference key layout and on
+CPU tensors; there are no nn.Modules and nothing from the product package.
+
+Reference anchors (paths relative to /root/reference):
+  * mel front-end ......... models/preprocess.py:40-67
+  * kaldi mel banks ....... torchaudio 0.13 compliance.kaldi.get_mel_banks (third party,
+                            pinned in requirements.txt:7; restated from the published algorithm)
+  * MobileNetV3 config .... models/mn/model.py:237-271, models/mn/block_types.py:86-117
+  * MN forward ............ models/mn/model.py:212-231, models/mn/block_types.py:72-83,177-181
+  * DyMN config/forward ... models/dymn/model.py:157-183,209-254, models/dymn/dy_block.py:103-131,
+                            172-188,195-201,235-254,390-409
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3  # models/mn/model.py:114-115, models/dymn/dy_block.py:284
+
+
+# --------------------------------------------------------------------------- mel
+def kaldi_mel_banks(n_mels, n_fft, sr, fmin, fmax):
+    """(n_mels, n_fft//2+1) fp32 basis, last column zero (preprocess.py:52-55)."""
+    nfb = n_fft / 2
+    width = sr / n_fft
+    lo = 1127.0 * math.log(1.0 + fmin / 700.0)
+    hi = 1127.0 * math.log(1.0 + fmax / 700.0)
+    d = (hi - lo) / (n_mels + 1)
+    b = torch.arange(n_mels).unsqueeze(1)
+    left, center, right = lo + b * d, lo + (b + 1.0) * d, lo + (b + 2.0) * d
+    mel = (1127.0 * (1.0 + (width * torch.arange(nfb)) / 700.0).log()).unsqueeze(0)
+    up = (mel - left) / (center - left)
+    down = (right - mel) / (right - center)
+    bins = torch.max(torch.zeros(1), torch.min(up, down))
+    return F.pad(bins, (0, 1))
+
+
+def mel_forward(x, n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024,
+                fmin=0.0, fmax=15000.0, freq_mask=None, time_mask=None):
+    """x (B, L) fp32 -> (B, n_mels, T).  Explicit framing restatement of
+    preprocess.py:41-65 (conv1d pre-emphasis, centred reflect-padded STFT with a
+    non-periodic hann window zero-padded to n_fft, power, mel matmul, log, normalise).
+    ``freq_mask``/``time_mask`` = (start, end) index ranges zeroed after the log
+    (train-mode masking, preprocess.py:61-63); the caller draws them."""
+    x = x.float()
+    pre = x[:, 1:] - 0.97 * x[:, :-1]                                  # :41
+    pad = n_fft // 2
+    p = F.pad(pre.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)  # stft(center=True)
+    frames = p.unfold(1, n_fft, hopsize)                                # (B, T, n_fft)
+    win = torch.hann_window(win_length, periodic=False)
+    lpad = (n_fft - win_length) // 2
+    win = F.pad(win, (lpad, n_fft - win_length - lpad))
+    spec = torch.fft.rfft(frames * win, dim=-1)                         # (B, T, n_fft/2+1)
+    power = (spec.real ** 2 + spec.imag ** 2).transpose(1, 2)           # :44
+    basis = kaldi_mel_banks(n_mels, n_fft, sr, fmin, fmax)
+    mel = torch.matmul(basis, power)                                    # :57
+    mel = (mel + 0.00001).log()                                         # :59
+    if freq_mask is not None:
+        mel[:, freq_mask[0]:freq_mask[1], :] = 0.0
+    if time_mask is not None:
+        mel[:, :, time_mask[0]:time_mask[1]] = 0.0
+    return (mel + 4.5) / 5.0                                            # :65
+
+
+# ------------------------------------------------------------------- config math
+def make_divisible(v, divisor=8):
+    """models/mn/utils.py:8-21."""
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+# (in, kernel, expanded, out, use_se, use_hs, stride index or None)   mn/model.py:252-268
+_ROWS = [
+    (16, 3, 16, 16, False, False, None), (16, 3, 64, 24, False, False, 0), (24, 3, 72, 24, False, False, None),
+    (24, 5, 72, 40, True, False, 1), (40, 5, 120, 40, True, False, None), (40, 5, 120, 40, True, False, None),
+    (40, 3, 240, 80, False, True, 2), (80, 3, 200, 80, False, True, None), (80, 3, 184, 80, False, True, None),
+    (80, 3, 184, 80, False, True, None), (80, 3, 480, 112, True, True, None), (112, 3, 672, 112, True, True, None),
+    (112, 5, 672, 160, True, True, 3), (160, 5, 960, 160, True, True, None), (160, 5, 960, 160, True, True, None),
+]
+
+
+def block_table(width_mult=1.0, strides=(2, 2, 2, 2)):
+    """List of dicts (cin, k, cexp, cout, se, hs, stride) per inverted-residual block."""
+    adj = lambda c: make_divisible(c * width_mult, 8)
+    out = []
+    for cin, k, cexp, cout, se, hs, si in _ROWS:
+        out.append(dict(cin=adj(cin), k=k, cexp=adj(cexp), cout=adj(cout), se=se, hs=hs,
+                        stride=1 if si is None else strides[si]))
+    return out, adj(1280)
+
+
+def _act(x, hs):
+    return F.hardswish(x) if hs else F.relu(x)
+
+
+def _bn(sd, prefix, x, train, stats=None):
+    """BatchNorm2d(eps=1e-3, momentum=0.01).  In train mode uses batch statistics and,
+    if ``stats`` is a dict, records the updated running buffers there."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if not train:
+        return F.batch_norm(x, rm, rv, w, b, False, 0.0, BN_EPS)
+    rm2, rv2 = rm.clone(), rv.clone()
+    mom = 0.01 if stats is None else stats.get("__momentum__", 0.01)
+    y = F.batch_norm(x, rm2, rv2, w, b, True, mom, BN_EPS)
+    if stats is not None:
+        stats[prefix + ".running_mean"], stats[prefix + ".running_var"] = rm2, rv2
+    return y
+
+
+def _cna(sd, prefix, x, train, stats, k, stride, groups, act):
+    """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2) + BN + act."""
+    x = F.conv2d(x, sd[prefix + ".0.weight"], None, stride, (k - 1) // 2, 1, groups)
+    x = _bn(sd, prefix + ".1", x, train, stats)
+    if act == "hs":
+        x = F.hardswish(x)
+    elif act == "re":
+        x = F.relu(x)
+    return x
+
+
+def _se(sd, prefix, x):
+    """SqueezeExcitation over channels, Linear/ReLU/Linear/Sigmoid (block_types.py:72-83)."""
+    z = x.mean(dim=(2, 3))
+    z = F.relu(F.linear(z, sd[prefix + ".fc1.weight"], sd[prefix + ".fc1.bias"]))
+    s = torch.sigmoid(F.linear(z, sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"]))
+    return x * s[:, :, None, None]
+
+
+def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True):
+    """block_types.py:120-181: [expand] -> depthwise -> [SE] -> project (+ residual)."""
+    inp, j = x, 0
+    a = "hs" if c["hs"] else "re"
+    if c["cexp"] != c["cin"]:
+        x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, a)
+        j += 1
+    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, c["k"], c["stride"], c["cexp"], a)
+    j += 1
+    if c["se"] and use_se:
+        x = _se(sd, f"{prefix}.block.{j}.conc_se_layers.0", x)
+        j += 1
+    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, None)
+    if c["stride"] == 1 and c["cin"] == c["cout"]:
+        x = x + inp
+    return x
+
+
+def _mlp_head(sd, x, train, drop_mask):
+    """mn/model.py:186-194 (Dropout replayed from an explicit keep-mask in train mode)."""
+    pooled = x.mean(dim=(2, 3))
+    h = F.hardswish(F.linear(pooled, sd["classifier.2.weight"], sd["classifier.2.bias"]))
+    if train and drop_mask is not None:
+        h = h * drop_mask / 0.8
+    return F.linear(h, sd["classifier.5.weight"], sd["classifier.5.bias"]), pooled
+
+
+def mn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), train=False, stats=None,
+               drop_mask=None, return_fmaps=False):
+    """x (B,1,F,T) -> (logits, pooled features) or (logits, fmaps)   (mn/model.py:212-231)."""
+    blocks, _ = block_table(width_mult, strides)
+    fmaps = []
+    x = _cna(sd, "features.0", x, train, stats, 3, 2, 1, "hs")
+    fmaps.append(x)
+    for i, c in enumerate(blocks):
+        x = _inverted_residual(sd, f"features.{i + 1}", x, c, train, stats)
+        fmaps.append(x)
+    x = _cna(sd, "features.16", x, train, stats, 1, 1, 1, "hs")
+    fmaps.append(x)
+    logits, pooled = _mlp_head(sd, x, train, drop_mask)
+    return (logits, fmaps) if return_fmaps else (logits, pooled)
+
+
+# --------------------------------------------------------------------------- DyMN
+def context_dim(cexp, width_mult, ratio=4, lo=32, hi=128):
+    """dy_block.py:278-281."""
+    v = make_divisible(cexp // ratio, 8)
+    return int(min(max(v, make_divisible(lo * width_mult, 8)), make_divisible(hi * width_mult, 8)))
+
+
+def _dyconv(sd, prefix, x, h_c, cin, cout, k, stride, groups, temperature):
+    """DynamicConv (dy_block.py:103-131): per-sample kernel = softmax-weighted sum of K=4."""
+    b = x.shape[0]
+    a = F.softmax(F.linear(h_c, sd[prefix + ".residuals.0.weight"], sd[prefix + ".residuals.0.bias"])
+                  / temperature, dim=-1)                                    # (B,K)
+    bank = sd[prefix + ".weight"][0, 0]                                      # (K, N)
+    w = (a @ bank).reshape(b * cout, cin // groups, k, k)
+    y = F.conv2d(x.reshape(1, b * cin, *x.shape[2:]), w, None, stride, (k - 1) // 2, 1, groups * b)
+    return y.reshape(b, cout, *y.shape[2:])
+
+
+def _dy_block(sd, prefix, x, c, H, train, stats, temperature):
+    """DY_Block.forward (dy_block.py:390-409)."""
+    inp = x
+    B, C, Fq, T = x.shape
+    # ContextGen (dy_block.py:235-254)
+    cf, ct = x.mean(dim=3, keepdim=True), x.mean(dim=2, keepdim=True).permute(0, 1, 3, 2)
+    g = F.conv2d(torch.cat([cf, ct], dim=2), sd[prefix + ".context_gen.joint_conv.weight"])
+    g = F.hardswish(_bn(sd, prefix + ".context_gen.joint_norm", g, train, stats))
+    h_cf, h_ct = g[:, :, :Fq], g[:, :, Fq:].permute(0, 1, 3, 2)
+    h_c = g.mean(dim=2).reshape(B, H)
+    if c["stride"] > 1:
+        h_cf = F.avg_pool2d(h_cf, (3, 1), (c["stride"], 1), (1, 0))
+        h_ct = F.avg_pool2d(h_ct, (1, 3), (1, c["stride"]), (0, 1))
+    g_cf = F.conv2d(h_cf, sd[prefix + ".context_gen.conv_f.weight"], sd[prefix + ".context_gen.conv_f.bias"])
+    g_ct = F.conv2d(h_ct, sd[prefix + ".context_gen.conv_t.weight"], sd[prefix + ".context_gen.conv_t.bias"])
+    # expand
+    if c["cexp"] != c["cin"]:
+        x = _dyconv(sd, prefix + ".exp_conv", x, h_c, c["cin"], c["cexp"], 1, 1, 1, temperature)
+        x = _act(_bn(sd, prefix + ".exp_norm", x, train, stats), c["hs"])
+    # depthwise + DyReLU-B (dy_block.py:172-188) + CoordAtt (195-201)
+    x = _dyconv(sd, prefix + ".depth_conv", x, h_c, c["cexp"], c["cexp"], c["k"], c["stride"], c["cexp"], temperature)
+    x = _bn(sd, prefix + ".depth_norm", x, train, stats)
+    theta = 2 * torch.sigmoid(F.linear(h_c, sd[prefix + ".depth_act.coef_net.0.weight"],
+                                       sd[prefix + ".depth_act.coef_net.0.bias"])) - 1
+    co = theta.view(B, c["cexp"], 1, 1, 4) * sd[prefix + ".depth_act.lambdas"] + sd[prefix + ".depth_act.init_v"]
+    x = torch.maximum(x * co[..., 0] + co[..., 2], x * co[..., 1] + co[..., 3])
+    x = x * torch.sigmoid(g_cf) * torch.sigmoid(g_ct)
+    # project
+    x = _dyconv(sd, prefix + ".proj_conv", x, h_c, c["cexp"], c["cout"], 1, 1, 1, temperature)
+    x = _bn(sd, prefix + ".proj_norm", x, train, stats)
+    if c["stride"] == 1 and c["cin"] == c["cout"]:
+        x = x + inp
+    return x
+
+
+def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, train=False,
+                 stats=None, drop_mask=None, return_fmaps=False):
+    """DyMN with use_dy_blocks='all' (dymn/model.py:157-200)."""
+    blocks, _ = block_table(width_mult, strides)
+    fmaps = []
+    x = _cna(sd, "in_c", x, train, stats, 3, 2, 1, "hs")
+    fmaps.append(x)
+    for i, c in enumerate(blocks):
+        H = context_dim(c["cexp"], width_mult)
+        x = _dy_block(sd, f"layers.{i}", x, c, H, train, stats, temperature)
+        fmaps.append(x)
+    x = _cna(sd, "out_c", x, train, stats, 1, 1, 1, "hs")
+    fmaps.append(x)
+    logits, pooled = _mlp_head(sd, x, train, drop_mask)
+    return (logits, fmaps) if return_fmaps else (logits, pooled)
+
+
+def dyconv_temperature(epoch, T_max=30.0, T_min=1.0, T0_slope=1.0, T1_slope=0.02):
+    """dy_block.py:133-139."""
+    return max(T_max - T0_slope * epoch, 1 + T1_slope * (T_max - 1) / T0_slope - T1_slope * epoch, T_min)

@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference).
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python oracle/make_golden.py
+
+The reference's own modules (models/preprocess.py, models/mn/model.py, models/dymn/model.py)
+are imported with the three third-party stand-ins of oracle/ref_shims on sys.path and
+driven on CPU in fp32 on the seeded inputs / weights of oracle/synth.py.  The stored
+vectors pin oracle/eat_oracle.py (tests/test_oracle_golden.py) and, through it, the HIP
+path.  TEST INFRASTRUCTURE ONLY.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(HERE, "ref_shims"), REF, ROOT]
+os.chdir(REF)  # helpers/utils.py:38 opens metadata/class_labels_indices.csv relative to CWD
+
+from oracle import synth  # noqa: E402
+from models.preprocess import AugmentMelSTFT  # noqa: E402
+with contextlib.redirect_stdout(io.StringIO()):
+    from models.mn.model import get_model as get_mn  # noqa: E402
+    from models.dymn.model import get_model as get_dymn  # noqa: E402
+    from models.dymn.dy_block import DynamicConv  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+T_EDGE = [0, 1, 2, 3, 499, 996, 997, 998, 999]
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def fmap_summary(fmaps, rng):
+    """mean / std / 16 sampled entries per fmap (the full maps are tens of MB)."""
+    out = {}
+    for i, f in enumerate(fmaps):
+        flat = f.reshape(-1)
+        idx = rng.integers(0, flat.numel(), 16)
+        out[f"fmap{i}_shape"] = np.array(f.shape)
+        out[f"fmap{i}_mean"] = np.float64(f.double().mean())
+        out[f"fmap{i}_std"] = np.float64(f.double().std())
+        out[f"fmap{i}_idx"] = idx
+        out[f"fmap{i}_val"] = flat[idx].numpy()
+    return out
+
+
+def grad_summary(model, rng):
+    out = {}
+    for name, p in model.named_parameters():
+        g = p.grad.reshape(-1)
+        idx = rng.integers(0, g.numel(), 8)
+        out["gnorm/" + name] = np.float64(g.double().norm())
+        out["gidx/" + name] = idx
+        out["gval/" + name] = g[idx].numpy()
+    return out
+
+
+def golden_mel():
+    mel = quiet(AugmentMelSTFT, freqm=0, timem=0)
+    mel.eval()
+    short = synth.parity_clips(32000, seed=77)
+    full = synth.parity_clips(320000, seed=1234)
+    with torch.no_grad():
+        m_short = mel(short)
+        m_full = mel(full)
+    res = dict(short=m_short.numpy(), full_edge=m_full[:, :, T_EDGE].numpy(), t_edge=np.array(T_EDGE),
+               full_mean=m_full.double().mean(dim=(1, 2)).numpy(),
+               full_rowsum=m_full.double().sum(dim=2).numpy())
+    # train mode: fmin/fmax jitter + freq/time masking, torch CPU RNG seeded
+    mel_t = quiet(AugmentMelSTFT, freqm=48, timem=192)
+    mel_t.train()
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        res["train_short_seed2024"] = mel_t(synth.parity_clips(64000, seed=78)).numpy()
+    np.savez_compressed(os.path.join(OUT, "mel_ref.npz"), **res)
+    print("mel_ref.npz", m_short.shape, m_full.shape)
+    return mel
+
+
+def bn_buffers(model):
+    return {k: v.clone() for k, v in model.state_dict().items()
+            if k.endswith(("running_mean", "running_var"))}
+
+
+def calibrate_reference(model, x):
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    with torch.no_grad():
+        model(x)
+    for m in bns:
+        m.momentum = 0.01
+        m.num_batches_tracked.zero_()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.2
+
+
+def golden_model(kind, mel, width, tag, temp_eval=1.0, temp_train=30.0):
+    get = get_mn if kind == "mn" else get_dymn
+    shapes = (synth.mn_shapes if kind == "mn" else synth.dymn_shapes)(width)
+    model = quiet(get, width_mult=width)
+    sd = synth.synth_state(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)          # pins key names + shapes of oracle/synth.py
+
+    def set_temp(t):
+        for m in model.modules():
+            if isinstance(m, DynamicConv):
+                m.temperature = t
+
+    with torch.no_grad():
+        x_cal = mel(synth.calibration_clips()).unsqueeze(1)
+        x = mel(synth.parity_clips(320000, seed=1234)).unsqueeze(1)
+    set_temp(temp_eval)
+    calibrate_reference(model, x_cal)
+    res = {"bn/" + k: v.numpy() for k, v in bn_buffers(model).items()}
+    res["n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+    res["n_state"] = np.int64(len(model.state_dict()))
+    rng = np.random.Generator(np.random.PCG64(5))
+
+    model.eval()
+    with torch.no_grad():
+        logits, feats = model(x)
+        if kind == "mn":
+            _, fmaps = model._forward_impl(x, return_fmaps=True)
+        else:
+            _, fmaps = model(x, return_fmaps=True)
+    res.update(eval_logits=logits.numpy(), eval_features=feats.numpy(), temp_eval=np.float64(temp_eval))
+    res.update(fmap_summary(fmaps, rng))
+
+    # one train-mode step: BCE-with-logits vs seeded labels, gradients of every parameter
+    set_temp(temp_train)
+    model.train()
+    drop = [m for m in model.modules() if isinstance(m, torch.nn.Dropout)][0]
+    rec = {}
+    drop.register_forward_pre_hook(lambda m, inp: rec.__setitem__("in", inp[0].detach().clone()))
+    drop.register_forward_hook(lambda m, inp, out: rec.__setitem__("out", out.detach().clone()))
+    y = torch.from_numpy((np.random.Generator(np.random.PCG64(9)).random((x.shape[0], 527)) < 0.01)
+                         .astype(np.float32))
+    torch.manual_seed(11)
+    logits_t, _ = model(x)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits_t, y)
+    loss.backward()
+    keep = torch.where(rec["in"] != 0, (rec["out"] != 0).float(), torch.ones_like(rec["in"]))
+    res.update(train_logits=logits_t.detach().numpy(), train_loss=np.float64(loss.item()),
+               train_labels=y.numpy(), drop_keep=keep.numpy().astype(np.uint8),
+               temp_train=np.float64(temp_train))
+    res.update(grad_summary(model, rng))
+    res.update({"bn_after/" + k: v.numpy() for k, v in bn_buffers(model).items()})
+    np.savez_compressed(os.path.join(OUT, f"{tag}_ref.npz"), **res)
+    print(tag, "params", int(res["n_params"]), "logits std", float(logits.std()),
+          "absmax", float(logits.abs().max()), "train loss", loss.item())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    mel = golden_mel()
+    golden_model("mn", mel, 1.0, "mn10")
+    golden_model("dymn", mel, 1.0, "dymn10")

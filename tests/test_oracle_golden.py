@@ -1,0 +1,141 @@
+"""Pins oracle/eat_oracle.py (the CPU restatement) against vectors produced by the
+unmodified reference (oracle/make_golden.py -> tests/golden/*.npz).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eat_oracle as O
+from oracle import synth
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_param_counts_match_readme():
+    # README.md:94-113 (4.88 M / 68.43 M); DyMN counts as reproduced in SURVEY.md section 4
+    assert synth.n_params(synth.mn_shapes(1.0)) == 4876831
+    assert synth.n_params(synth.mn_shapes(4.0)) == 68427303
+    assert synth.n_params(synth.dymn_shapes(1.0)) == 10548479
+    assert synth.n_params(synth.dymn_shapes(2.0)) == 39966143
+    assert len(synth.mn_shapes(1.0)) == 312 and len(synth.dymn_shapes(1.0)) == 578
+
+
+def test_mel_basis_support_and_hf_crosscheck():
+    basis = O.kaldi_mel_banks(128, 1024, 32000, 0.0, 15000.0)
+    assert basis.shape == (128, 513)
+    assert int((basis != 0).sum()) == 948
+    assert float(basis[127, 480]) > 0              # the fp32 "bin 480" non-zero (hard parts)
+    assert float(basis[:, 512].abs().max()) == 0
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    hf = audio_utils.mel_filter_bank(num_frequency_bins=513, num_mel_filters=128, min_frequency=0.0,
+                                     max_frequency=15000.0, sampling_rate=32000, norm=None,
+                                     mel_scale="kaldi", triangularize_in_mel_space=True)
+    hf = torch.from_numpy(np.asarray(hf, dtype=np.float64)).T[:, :513]
+    assert float((basis.double() - hf).abs().max()) < 5e-5
+
+
+def test_mel_matches_reference(golden_dir):
+    g = _load(golden_dir, "mel_ref.npz")
+    m = O.mel_forward(synth.parity_clips(32000, seed=77))
+    assert m.shape == (5, 128, 100)
+    assert np.abs(m.numpy() - g["short"]).max() < 2e-5
+    full = O.mel_forward(synth.parity_clips(320000, seed=1234))
+    assert full.shape == (5, 128, 1000)
+    assert np.abs(full[:, :, g["t_edge"]].numpy() - g["full_edge"]).max() < 2e-5
+    assert np.abs(full.double().sum(dim=2).numpy() - g["full_rowsum"]).max() < 2e-2
+
+
+def test_mel_train_mode_matches_reference(golden_dir):
+    """Train mode: replay the reference's host RNG draws (preprocess.py:45-46, masking)."""
+    g = _load(golden_dir, "mel_ref.npz")
+    torch.manual_seed(2024)
+    fmin = 0.0 + torch.randint(10, (1,)).item()
+    fmax = 15000 + 2000 // 2 - torch.randint(2000, (1,)).item()
+
+    def draw(param, size):
+        value = torch.rand(1) * param
+        mn = torch.rand(1) * (size - value)
+        return int(mn.long()), int(mn.long()) + int(value.long())
+
+    fm = draw(48, 128)
+    tm = draw(192, 200)
+    m = O.mel_forward(synth.parity_clips(64000, seed=78), fmin=fmin, fmax=fmax, freq_mask=fm, time_mask=tm)
+    assert np.abs(m.numpy() - g["train_short_seed2024"]).max() < 2e-5
+
+
+def _calibrated(kind, g):
+    shapes = (synth.mn_shapes if kind == "mn" else synth.dymn_shapes)(1.0)
+    sd = synth.synth_state(shapes, seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    return sd
+
+
+def _check_model(kind, g, fwd, rel):
+    sd = _calibrated(kind, g)
+    x = O.mel_forward(synth.parity_clips(320000, seed=1234)).unsqueeze(1)
+    with torch.no_grad():
+        logits, fmaps = fwd(sd, x, return_fmaps=True)
+        _, feats = fwd(sd, x)
+    scale = np.abs(g["eval_logits"]).max(axis=1, keepdims=True)
+    assert (np.abs(logits.numpy() - g["eval_logits"]) / scale).max() < rel
+    assert np.abs(feats.numpy() - g["eval_features"]).max() < rel * max(1.0, np.abs(g["eval_features"]).max())
+    assert len(fmaps) == 17
+    for i, f in enumerate(fmaps):
+        assert tuple(f.shape) == tuple(g[f"fmap{i}_shape"])
+        v = f.reshape(-1)[g[f"fmap{i}_idx"]].numpy()
+        assert np.abs(v - g[f"fmap{i}_val"]).max() < rel * 10 * max(1.0, float(g[f"fmap{i}_std"]))
+        assert abs(float(f.double().std()) - float(g[f"fmap{i}_std"])) < 1e-3 * float(g[f"fmap{i}_std"])
+    return sd, x
+
+
+def _check_train(kind, g, sd, x, fwd, gtol=1e-2):
+    for k in sd:
+        if not k.endswith(("running_mean", "running_var", "num_batches_tracked", "lambdas", "init_v")):
+            sd[k] = sd[k].clone().requires_grad_(True)
+    stats = {}
+    keep = torch.from_numpy(g["drop_keep"].astype(np.float32))
+    logits, _ = fwd(sd, x, train=True, stats=stats, drop_mask=keep)
+    y = torch.from_numpy(g["train_labels"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y)
+    loss.backward()
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-5
+    assert np.abs(logits.detach().numpy() - g["train_logits"]).max() < 2e-4 * max(1.0, np.abs(g["train_logits"]).max())
+    bad = []
+    gmax = max(float(g[k]) for k in g.files if k.startswith("gnorm/"))
+    for k in g.files:
+        if not k.startswith("gnorm/"):
+            continue
+        name = k[6:]
+        ref = float(g[k])
+        got = float(sd[name].grad.double().norm())
+        # project-BN biases have an exactly-zero true gradient in train mode: skip tiny norms
+        if ref < 1e-5 * gmax:
+            continue
+        if abs(got - ref) > gtol * ref:
+            bad.append((name, ref, got))
+    assert not bad, bad[:5]
+    for k, v in stats.items():
+        assert np.abs(v.numpy() - g["bn_after/" + k]).max() < 1e-4 * max(1.0, np.abs(g["bn_after/" + k]).max())
+
+
+def test_mn10_oracle_matches_reference(golden_dir):
+    g = _load(golden_dir, "mn10_ref.npz")
+    assert int(g["n_params"]) == 4876831 and int(g["n_state"]) == 312
+    sd, x = _check_model("mn", g, O.mn_forward, 2e-5)
+    _check_train("mn", g, sd, x, O.mn_forward)
+
+
+def test_dymn10_oracle_matches_reference(golden_dir):
+    g = _load(golden_dir, "dymn10_ref.npz")
+    assert int(g["n_params"]) == 10548479 and int(g["n_state"]) == 578
+    te, tt = float(g["temp_eval"]), float(g["temp_train"])
+    fwd_e = lambda sd, x, **k: O.dymn_forward(sd, x, temperature=te, **k)
+    fwd_t = lambda sd, x, **k: O.dymn_forward(sd, x, temperature=tt, **k)
+    sd, x = _check_model("dymn", g, fwd_e, 2e-4)
+    # attention-logit grads at T=30 are cancellation-dominated (norm 1e-4): looser bound
+    _check_train("dymn", g, sd, x, fwd_t, gtol=3e-2)
