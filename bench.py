@@ -1,0 +1,264 @@
+"""bench.py -- hot-path throughput on MI355X.
+
+One "step" = one pass of the hot path (fused log-mel front-end + mn10_as forward, eval, fp32)
+over one batch of synthetic 10 s @ 32 kHz clips already resident in HBM (BASELINE.json configs[1]:
+"mn10_as forward-only, batch 256 synthetic 10 s clips, 1xMI355X, fp32").  With --gpus N every rank
+processes its own batch of the same size (clips are independent: no data-path collective), so
+value = N * batch * steps / max-over-ranks time and scaling is "weak".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel's algorithmic HBM bytes per launch / its mean launch duration
+                (HIP events on the launch stream), against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU oracle (a port of the reference's torch-CPU path) timed on this host
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12                      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+CLIP_SAMPLES = 320000                  # 10 s @ 32 kHz
+ALG_BYTES_PER_CLIP = 96.37e6           # mn10 fwd 94.50 MB + weights/B + mel 1.79 MB
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build_model(dev):
+    from efficientat_amd.mn import get_model
+    from efficientat_amd.preprocess import AugmentMelSTFT
+    torch.manual_seed(0)
+    mel = quiet(AugmentMelSTFT, freqm=0, timem=0).to(dev).eval()
+    model = quiet(get_model, width_mult=1.0)
+    # random init that keeps activations O(1) through 46 un-trained BN layers (fan-in scaling),
+    # so the kernels see realistic (non-collapsed, non-zero) data
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
+            elif isinstance(m, torch.nn.Linear):
+                m.weight.normal_(0, (1.0 / m.weight.shape[1]) ** 0.5)
+    return mel, model.to(dev).eval()
+
+
+# ------------------------------------------------------------------ per-kernel event profile
+def _alg_bytes(name, a):
+    """Algorithmic HBM bytes of one launch (activations in + out once, weights once)."""
+    if name == "eat_pw_conv_fwd":
+        x, wp, bias, sc, res, y, pool, B, Ci, Co, S, act = a[:12]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + 4 * Co * Ci
+        return f"pw_conv_kernel<{mtw}>", nbytes
+    if name == "eat_dw_conv_fwd":
+        x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
+        return f"dw_conv_kernel<{k},{s}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k
+    if name == "eat_stem_conv_fwd":
+        x, w, bias, y, B, C, F, T, Fo, To = a[:10]
+        return "stem_conv_kernel", 4 * B * (F * T + C * Fo * To)
+    if name == "eat_mel_fwd":
+        B, L, n_mels, T = a[1], a[2], a[10], a[13]
+        return "mel_fwd_kernel", 4 * B * (L + n_mels * T)
+    if name == "eat_linear_fwd":
+        x, w, bias, y, B, K, N = a[:7]
+        return "linear_kernel", 4 * (B * K + N * K + B * N)
+    return name, 0
+
+
+def kernel_profile(step, iters=3):
+    """Run `step` eagerly with a HIP event pair around every C-ABI launch (same stream)."""
+    from efficientat_amd import _lib
+    real_call = _lib.call
+    rec = []
+
+    def traced(name, *args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_call(name, *args)
+        e1.record()
+        rec.append((name, args, e0, e1))
+
+    _lib.call = traced
+    try:
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        _lib.call = real_call
+    agg = {}
+    for name, args, e0, e1 in rec:
+        sym, nbytes = _alg_bytes(name, args)
+        d = agg.setdefault(sym, [0, 0.0, 0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += nbytes
+    return {k: dict(launches=v[0] // iters, total_ms=v[1] / iters * 1e3, bytes=v[2] / iters,
+                    gbps=(v[2] / v[1] / 1e9) if v[1] > 0 else 0.0) for k, v in agg.items()}
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(budget_s=12.0, batch=16):
+    """The CPU oracle (port of the reference torch-CPU path: mel + mn10 eval forward) on host cores."""
+    from oracle import eat_oracle as O
+    from oracle import synth
+    sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
+    g = torch.Generator().manual_seed(1234)
+    x = (0.1 * torch.randn(batch, CLIP_SAMPLES, generator=g)).clamp_(-1, 1)
+
+    def once():
+        with torch.no_grad():
+            O.mn_forward(sd, O.mel_forward(x).unsqueeze(1))
+
+    once()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        once()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": round(batch * n / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} iters x batch {batch} of the same workload (mel + mn10 fwd, fp32, torch CPU)"}
+
+
+def parity_probe(mel, model, dev):
+    """logit max-abs-err of the HIP path vs the CPU oracle on 4 synthetic clips (same weights)."""
+    from oracle import eat_oracle as O
+    g = torch.Generator().manual_seed(7)
+    x = (0.1 * torch.randn(4, CLIP_SAMPLES, generator=g)).clamp_(-1, 1)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref, _ = O.mn_forward(sd, O.mel_forward(x).unsqueeze(1))
+        got, _ = model(mel(x.to(dev)).unsqueeze(1))
+    return float((got.cpu() - ref).abs().max()), float(ref.abs().max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event profile to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    mel, model = build_model(dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    wave = (0.1 * torch.randn(args.batch, CLIP_SAMPLES, device=dev, generator=g)).clamp_(-1, 1)
+
+    out = {}
+
+    def step():
+        with torch.no_grad():
+            out["logits"], out["feat"] = model(mel(wave).unsqueeze(1))
+
+    step()                               # folds / packs weights, builds mel tables
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as e:  # pragma: no cover - report, then measure eagerly
+            print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
+            graph = None
+    run = graph.replay if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    clips_per_s = world * args.batch * args.steps / elapsed
+    result = {
+        "metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": round(clips_per_s, 1), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 synthetic "
+                               "10 s @ 32 kHz clips per GPU, fp32 [BASELINE.json configs[1]]",
+                   "batch_per_gpu": args.batch, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "parallelism": f"dp{world} (independent clips, no collective)"},
+        "roofline_e2e": {"bound": "hbm", "achieved": round(clips_per_s / world * ALG_BYTES_PER_CLIP / 1e9, 1),
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(clips_per_s / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
+                         "note": "whole forward: clips/s per GPU x 96.37 MB algorithmic bytes per clip (SURVEY 8d)"},
+    }
+
+    if rank == 0:
+        prof = kernel_profile(step)
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        name, d = dom
+        per_launch_bytes = d["bytes"] / d["launches"]
+        per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
+        result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(per_launch_bytes / per_launch_s / 1e9, 1),
+                              "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                              "frac": round(per_launch_bytes / per_launch_s / HBM_PEAK, 4), "traffic": None,
+                              "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
+                              "alg_bytes_per_launch": int(per_launch_bytes),
+                              "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
+        if args.kernel_table:
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
+                print(f"[bench] {k:28s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "
+                      f"{v['bytes'] / 1e9:7.3f} GB  {v['gbps']:8.1f} GB/s", file=sys.stderr)
+        err, scale = parity_probe(mel, model, dev)
+        result["parity"] = {"logit_max_abs_err": err, "logit_abs_max": scale, "vs": "CPU oracle, 4 clips, same weights"}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""ctypes binding of libeat_hip.so (the C ABI declared in include/eat_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  Build it with ``python -m efficientat_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must be imported BEFORE libeat_hip.so is loaded: the kernels have to run on
+#                torch's own HIP runtime (libamdhip64 bundled with the wheel) to share its streams.
+#                Loading our library first binds it to /opt/rocm's copy, which sees no device.
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeat_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes (restype is always int unless noted); must mirror include/eat_hip.h
+SIGNATURES = {
+    "eat_mel_fwd": [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P],
+    "eat_stem_conv_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_dw_conv_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_pw_prepack": [_P, _P, _P, _I, _I, _P],
+    "eat_pw_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eat_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+}
+
+_lib = None
+
+
+class EatHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EatHipError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). "
+                "Build it with `python -m efficientat_amd.build`.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = argtypes
+            fn.restype = _I
+        h.eat_version.restype = _I
+        h.eat_last_error_string.restype = ctypes.c_char_p
+        _lib = h
+    return _lib
+
+
+def call(name, *args):
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise EatHipError(f"{name} failed ({rc}): {h.eat_last_error_string().decode()}")
+
+
+def exported_symbols():
+    return list(SIGNATURES) + ["eat_version", "eat_last_error_string"]

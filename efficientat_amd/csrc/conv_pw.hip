@@ -1,0 +1,329 @@
+// Pointwise (1x1) convolution and Linear layers as fp32 MFMA GEMMs for gfx950.
+//   reference: models/mn/block_types.py:138-147 (expand), :167-171 (project), :83 (SE scale),
+//              :177-181 (residual); models/mn/model.py:159-167 (last conv), :186-194 (head)
+//
+// y (Co, N) = W (Co, Ci) . x (Ci, N) with N = B*S the flattened (sample, position) axis: NCHW keeps
+// S = F*T contiguous per channel, so a k-row of a 256-column tile is (pieces of) contiguous
+// memory.  The activations are the MFMA B operand, the weights the A operand, pre-packed once
+// (BatchNorm scale folded in) into fragment order.
+//
+// Block = 4 waves = (MTW*16 rows) x 256 columns; wave w owns columns [64w, 64w+64).  K is walked
+// in chunks of 32 through a 2-stage LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane:
+// one wave instruction moves one k-row of the tile = 1 KiB, coalesced along time); the chunk
+// c+1 loads fly while chunk c is multiplied.  B fragments are read with ds_read_b128 (row stride
+// 256 floats: conflict-free for the b128 lane groups), A fragments with ds_read_b32.
+// v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain - what the 1e-3 logit-parity budget assumes.
+//
+// Column permutation: lane l holds x[k][n0 + 4*(l&15) + j] in element j of its float4 and feeds
+// it to MFMA n-tile j, so in the C/D layout lane l holds, for a fixed row, 4 consecutive columns:
+// the epilogue (bias, activation, residual, pooled sums) loads/stores float4.
+#include "eat_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int kKC = 32;          // k rows per LDS stage
+constexpr int kTileN = 256;      // columns per block
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// 16 B per lane global -> LDS (dst = wave-uniform base + lane*16)
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// Pack W (Co, Ci) [* row_scale] into wp[(ks * MT + mt) * 64 + lane] = W[mt*16 + (lane&15)][ks*4 + (lane>>4)]
+__global__ void pw_prepack_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,
+                                  float* __restrict__ wp, int Co, int Ci, int MT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = (Ci / 4) * MT * 64;
+  if (i >= total) return;
+  const int lane = i & 63, mt = (i >> 6) % MT, ks = (i >> 6) / MT;
+  const int m = mt * 16 + (lane & 15), k = ks * 4 + (lane >> 4);
+  float v = 0.0f;
+  if (m < Co) v = w[(size_t)m * Ci + k] * (row_scale ? row_scale[m] : 1.0f);
+  wp[i] = v;
+}
+
+__host__ __device__ constexpr int a_stage_floats(int mtw) { return 512 * mtw; }  // 8 ksteps * mtw * 64
+__host__ __device__ inline int stage_floats(int mtw, int ns) { return a_stage_floats(mtw) + kKC * kTileN + kKC * ns; }
+
+template <int MTW>
+__global__ __launch_bounds__(256) void pw_conv_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
+    float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // XCD-aware mapping: the MC row-chunks that share one column tile sit on the same XCD (ids
+  // congruent mod 8) so the tile's re-reads hit that XCD's L2.
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+  const int mchunk = jj % MC, tile = (jj / MC) * 8 + xcd;
+  if (tile >= n_tiles) return;
+  const int mt0 = mchunk * MTW;
+  const int mtw_eff = (MT - mt0) < MTW ? (MT - mt0) : MTW;
+  const long long N = (long long)B * S;
+  const long long n_base = (long long)tile * kTileN;
+  const int b_first = (int)(n_base / S);
+
+  // loader role: this lane's 4 columns of every k-row
+  long long nl = n_base + 4 * lane;
+  if (nl > N - 4) nl = N - 4;                       // clamp: garbage columns are never stored
+  const int bl = (int)(nl / S), sl = (int)(nl - (long long)bl * S);
+  const float* xsrc = x + ((size_t)bl * Ci) * S + sl;
+  // compute role
+  const long long nc = n_base + 64 * wv + 4 * (lane & 15);
+  const bool col_ok = nc < N;
+  const long long ncc = col_ok ? nc : N - 4;
+  const int bc = (int)(ncc / S), sc_ = (int)(ncc - (long long)bc * S);
+  const int kq = lane >> 4;
+
+  const int stage_sz = stage_floats(MTW, NS);
+  const int n_chunks = (Ci + kKC - 1) / kKC;
+
+  auto issue = [&](int c) {
+    float* st = smem + (c & 1) * stage_sz;
+    const int k0 = c * kKC;
+    const int klen = (Ci - k0) < kKC ? (Ci - k0) : kKC;
+    float* Xs = st + a_stage_floats(MTW);
+    for (int r = wv; r < klen; r += 4) glds16(xsrc + (size_t)(k0 + r) * S, Xs + r * kTileN);
+    // A: (klen/4) * MTW rows of 64 floats, fragment order; 256 floats per wave instruction
+    const int rows = (klen >> 2) * MTW;
+    const int n_inst = (rows + 3) >> 2;
+    for (int q = wv; q < n_inst; q += 4) {
+      int row = q * 4 + (lane >> 4);
+      if (row >= rows) row = rows - 1;
+      const int ksl = row / MTW, i = row - ksl * MTW;
+      int mt = mt0 + i;
+      if (mt >= MT) mt = MT - 1;
+      glds16(wp + ((size_t)((k0 >> 2) + ksl) * MT + mt) * 64 + 4 * (lane & 15), st + q * 256);
+    }
+    if (in_scale) {
+      float* SCs = Xs + kKC * kTileN;
+      for (int e = tid; e < klen * NS; e += 256) {
+        const int r = e / NS, j = e - r * NS;
+        int bb = b_first + j;
+        if (bb >= B) bb = B - 1;
+        SCs[e] = in_scale[(size_t)bb * Ci + k0 + r];
+      }
+    }
+  };
+
+  f32x4 acc[MTW][4];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int c = 0; c < n_chunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < n_chunks) issue(c + 1);
+    const float* st = smem + (c & 1) * stage_sz;
+    const float* Xw = st + a_stage_floats(MTW) + 64 * wv + 4 * (lane & 15) + kq * kTileN;
+    const float* SCs = st + a_stage_floats(MTW) + kKC * kTileN + kq * NS + (bc - b_first);
+    const float* Aw = st + lane;
+    const int k0 = c * kKC;
+    const int ksteps = ((Ci - k0) < kKC ? (Ci - k0) : kKC) >> 2;
+    auto kstep = [&](int ks) {
+      float4 xv = *reinterpret_cast<const float4*>(Xw + ks * 4 * kTileN);
+      if (in_scale) {
+        const float s = SCs[ks * 4 * NS];
+        xv.x *= s; xv.y *= s; xv.z *= s; xv.w *= s;
+      }
+      float a[MTW];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) a[i] = Aw[(ks * MTW + i) * 64];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        acc[i][0] = mfma16(a[i], xv.x, acc[i][0]);
+        acc[i][1] = mfma16(a[i], xv.y, acc[i][1]);
+        acc[i][2] = mfma16(a[i], xv.z, acc[i][2]);
+        acc[i][3] = mfma16(a[i], xv.w, acc[i][3]);
+      }
+    };
+    if (ksteps == 8) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kstep(ks);
+    } else {
+      for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
+    }
+  }
+
+  // epilogue: row m = (mt0+i)*16 + kq*4 + r, columns nc .. nc+3 of sample bc
+  bool group_one_sample = true;
+  if (pool) {
+    const int b_lo = __shfl(bc, lane & ~15, 64), b_hi = __shfl(bc, lane | 15, 64);
+    group_one_sample = (b_lo == b_hi);
+  }
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    if (i >= mtw_eff) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (mt0 + i) * 16 + kq * 4 + r;
+      const bool ok = col_ok && m < Co;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float bm = bias[m];
+        v = make_float4(eat::activate_rt(acc[i][0][r] + bm, act), eat::activate_rt(acc[i][1][r] + bm, act),
+                        eat::activate_rt(acc[i][2][r] + bm, act), eat::activate_rt(acc[i][3][r] + bm, act));
+        const size_t off = ((size_t)bc * Co + m) * S + sc_;
+        if (res) {
+          const float4 rv = *reinterpret_cast<const float4*>(res + off);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (y) *reinterpret_cast<float4*>(y + off) = v;
+      }
+      if (pool) {
+        float ps = v.x + v.y + v.z + v.w;
+        if (group_one_sample) {
+          ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
+          ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
+          if ((lane & 15) == 0 && m < Co) atomicAdd(pool + (size_t)bc * Co + m, ps);
+        } else if (ok) {
+          atomicAdd(pool + (size_t)bc * Co + m, ps);
+        }
+      }
+    }
+  }
+}
+
+// y (M,N) = act((x (M,K) * xs) . w (N,K)^T + bias): both operands K-contiguous; each lane loads 4
+// consecutive k as one float4 and the 4 MFMAs of a 16-k step consume a consistent k permutation.
+// Block = 4 waves on ONE 16 x 32 output tile with K split 4 ways (these GEMMs are tiny and
+// latency-bound: M = batch, K,N <= a few thousand), partial sums combined through LDS.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     int M, int K, int N, float xs, int act) {
+  __shared__ float s_red[3][2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
+  const int row = lane & 15, kq = lane >> 4;
+  const int mrow = m0 + row;
+  const int kslice = (((K + 3) / 4 + 15) / 16) * 16;       // per-wave K range, multiple of 16
+  const int kb = wv * kslice, ke = (kb + kslice) < K ? (kb + kslice) : K;
+  const bool vec = (K & 3) == 0;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+  auto load4 = [&](const float* base, int r, int rmax, int k, float (&o)[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.f;
+    if (r >= rmax || k >= ke) return;
+    if (vec) {
+      const float4 t = *reinterpret_cast<const float4*>(base + (size_t)r * K + k);
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (k + e < ke) o[e] = base[(size_t)r * K + k + e];
+    }
+  };
+
+  for (int k0 = kb; k0 < ke; k0 += 64) {
+    float xa[4][4], wb[4][2][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {           // issue every load of 4 k-steps before the first MFMA
+      const int k = k0 + 16 * u + 4 * kq;
+      load4(x, mrow, M, k, xa[u]);
+      load4(w, n0 + row, N, k, wb[u][0]);
+      load4(w, n0 + 16 + row, N, k, wb[u][1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = mfma16(xa[u][e] * xs, wb[u][0][e], acc[0]);
+        acc[1] = mfma16(xa[u][e] * xs, wb[u][1][e], acc[1]);
+      }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_red[wv - 1][j][r][lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (wv != 0) return;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 16 * j + row;          // C/D: col = lane&15, row = kq*4 + r
+    const float bn = (bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + kq * 4 + r;
+      float v = acc[j][r] + s_red[0][j][r][lane] + s_red[1][j][r][lane] + s_red[2][j][r][lane] + bn;
+      if (act == EAT_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+      else v = eat::activate_rt(v, act);
+      if (n < N && m < M) y[(size_t)m * N + n] = v;
+    }
+  }
+}
+
+template <int MTW>
+int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias, const float* in_scale,
+              const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act) {
+  const long long N = (long long)B * S;
+  const int n_tiles = (int)((N + kTileN - 1) / kTileN);
+  int NS = kTileN / S + 2;
+  if (NS > B) NS = B;
+  if (!in_scale) NS = 0;
+  const size_t smem = 2 * (size_t)stage_floats(MTW, NS) * sizeof(float);
+  if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: LDS stage too large (%zu B)", smem);
+  auto kern = pw_conv_kernel<MTW>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_pw_conv_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+  }
+  const int tiles8 = (n_tiles + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
+                     MC, n_tiles, NS, act);
+  return eat::check_launch("eat_pw_conv_fwd");
+}
+
+}  // namespace
+
+extern "C" int eat_pw_prepack(const float* w, const float* row_scale, float* wp, int Co, int Ci,
+                              eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_prepack: Ci=%d must be a multiple of 4", Ci);
+  const int MT = (Co + 15) / 16;
+  const int total = (Ci / 4) * MT * 64;
+  hipLaunchKernelGGL(pw_prepack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, row_scale,
+                     wp, Co, Ci, MT);
+  return eat::check_launch("eat_pw_prepack");
+}
+
+extern "C" int eat_pw_conv_fwd(const float* x, const float* wp, const float* bias, const float* in_scale,
+                               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
+                               eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Ci % 4 != 0 || S % 4 != 0)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
+  if (B < 1 || Ci < 4 || Co < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
+  const int MT = (Co + 15) / 16;
+  const int MC = (MT + 7) / 8;                    // row chunks
+  const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block, 1..8
+  hipStream_t s = (hipStream_t)stream;
+#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act);
+  switch (mtw) {
+    EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4)
+    EAT_PW_CASE(5) EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
+    default: return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: internal tiling error");
+  }
+#undef EAT_PW_CASE
+}
+
+extern "C" int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
+                              float x_scale, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 3) return eat::fail(EAT_EINVAL, "eat_linear_fwd: bad act %d", act);
+  dim3 grid((N + 31) / 32, (B + 15) / 16);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, K, N, x_scale, act);
+  return eat::check_launch("eat_linear_fwd");
+}

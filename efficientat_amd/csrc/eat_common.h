@@ -1,0 +1,53 @@
+// Shared helpers for the gfx950 kernels of libeat_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/eat_hip.h"
+
+namespace eat {
+
+// thread-local last-error text behind eat_last_error_string()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+// hipGetLastError is sticky per thread: drop whatever an earlier, unrelated runtime call left behind
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(EAT_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return EAT_OK;
+}
+
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+  if constexpr (ACT == EAT_ACT_RELU) return fmaxf(v, 0.0f);
+  if constexpr (ACT == EAT_ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+  return v;
+}
+
+__device__ __forceinline__ float activate_rt(float v, int act) {
+  if (act == EAT_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == EAT_ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+  return v;
+}
+
+// 64-lane wavefront sum (all lanes receive the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+constexpr int kWave = 64;
+
+}  // namespace eat
+
+#define EAT_DISPATCH_ACT(act, ...)                                    \
+  do {                                                                \
+    if ((act) == EAT_ACT_NONE) { constexpr int ACT = EAT_ACT_NONE; __VA_ARGS__; }        \
+    else if ((act) == EAT_ACT_RELU) { constexpr int ACT = EAT_ACT_RELU; __VA_ARGS__; }   \
+    else { constexpr int ACT = EAT_ACT_HSWISH; __VA_ARGS__; }                            \
+  } while (0)

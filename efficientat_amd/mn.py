@@ -1,0 +1,350 @@
+"""Drop-in for the reference's ``models.mn.model`` (get_model / MN) on the HIP hot path.
+
+Same public API and the same state_dict key layout as the reference
+(models/mn/model.py:73-234, 326-367; models/mn/block_types.py:45-181), so released checkpoints
+load with ``strict=True``.  The module tree only HOLDS parameters (nn.Conv2d / nn.BatchNorm2d /
+nn.Linear leaves under the reference's names); ``MN.forward`` does not call the leaves but runs
+a fused launch plan over libeat_hip.so:
+
+    stem conv3x3/s2+BN+hswish  ->  15 x [ pw expand+BN+act -> dw kxk+BN+act (+SE squeeze sums)
+    -> SE gate (2 small GEMMs) -> pw project+BN (*SE scale on the input, +residual) ]
+    ->  last 1x1 conv+BN+hswish with the global average pool fused  ->  2 Linear layers.
+
+Eval-mode BatchNorm is folded into the conv weights (cached, re-folded when a parameter or
+buffer changes).  There is no CPU path: CPU tensors raise.
+"""
+from functools import partial
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils import make_divisible, cnn_out_size, NAME_TO_WIDTH  # noqa: F401
+
+BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
+model_url = "https://github.com/fschmid56/EfficientAT/releases/download/v0.0.1/"
+model_dir = "resources"
+
+# checkpoint file names published by the reference (models/mn/model.py:24-70)
+_CKPT = {
+    "mn10_im_pytorch": "mn10_im_pytorch.pt",
+    **{f"mn{w}_im": f"mn{w}_im.pt" for w in ("01", "02", "04", "05", "10", "20", "30", "40")},
+    "mn01_as": "mn01_as_mAP_298.pt", "mn02_as": "mn02_as_mAP_378.pt", "mn04_as": "mn04_as_mAP_432.pt",
+    "mn05_as": "mn05_as_mAP_443.pt", "mn10_as": "mn10_as_mAP_471.pt", "mn20_as": "mn20_as_mAP_478.pt",
+    "mn30_as": "mn30_as_mAP_482.pt", "mn40_as": "mn40_as_mAP_484.pt", "mn40_as(2)": "mn40_as_mAP_483.pt",
+    "mn40_as(3)": "mn40_as_mAP_483(2).pt", "mn40_as_no_im_pre": "mn40_as_no_im_pre_mAP_483.pt",
+    "mn40_as_no_im_pre(2)": "mn40_as_no_im_pre_mAP_483(2).pt", "mn40_as_no_im_pre(3)": "mn40_as_no_im_pre_mAP_482.pt",
+    "mn40_as_ext": "mn40_as_ext_mAP_487.pt", "mn40_as_ext(2)": "mn40_as_ext_mAP_486.pt",
+    "mn40_as_ext(3)": "mn40_as_ext_mAP_485.pt", "mn10_as_hop_5": "mn10_as_hop_5_mAP_475.pt",
+    "mn10_as_hop_15": "mn10_as_hop_15_mAP_463.pt", "mn10_as_hop_20": "mn10_as_hop_20_mAP_456.pt",
+    "mn10_as_hop_25": "mn10_as_hop_25_mAP_447.pt", "mn10_as_mels_40": "mn10_as_mels_40_mAP_453.pt",
+    "mn10_as_mels_64": "mn10_as_mels_64_mAP_461.pt", "mn10_as_mels_256": "mn10_as_mels_256_mAP_474.pt",
+    "mn10_as_fc": "mn10_as_fc_mAP_465.pt", "mn10_as_fc_s2221": "mn10_as_fc_s2221_mAP_466.pt",
+    "mn10_as_fc_s2211": "mn10_as_fc_s2211_mAP_466.pt",
+}
+pretrained_models = {k: model_url + v for k, v in _CKPT.items()}
+
+
+class InvertedResidualConfig:
+    """Row of the MobileNetV3 table (models/mn/block_types.py:86-117)."""
+
+    def __init__(self, input_channels, kernel, expanded_channels, out_channels, use_se, activation, stride,
+                 dilation, width_mult):
+        adj = self.adjust_channels
+        self.input_channels = adj(input_channels, width_mult)
+        self.kernel = kernel
+        self.expanded_channels = adj(expanded_channels, width_mult)
+        self.out_channels = adj(out_channels, width_mult)
+        self.use_se, self.use_hs = use_se, activation == "HS"
+        self.stride, self.dilation = stride, dilation
+        self.f_dim = self.t_dim = None
+
+    @staticmethod
+    def adjust_channels(channels, width_mult):
+        return make_divisible(channels * width_mult, 8)
+
+    def out_size(self, in_size):
+        return cnn_out_size(in_size, (self.kernel - 1) // 2 * self.dilation, self.dilation, self.kernel, self.stride)
+
+
+def _conv_bn_act(cin, cout, k, stride=1, groups=1, act=None):
+    """Parameter holder with torchvision-0.14 ConvNormActivation key names (.0 conv, .1 BN, .2 act)."""
+    mods = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
+            nn.BatchNorm2d(cout, eps=BN_EPS, momentum=BN_MOMENTUM)]
+    if act is not None:
+        mods.append(act(inplace=True))
+    seq = nn.Sequential(*mods)
+    seq.out_channels = cout
+    return seq
+
+
+class SqueezeExcitation(nn.Module):
+    """fc1 / ReLU / fc2 / Sigmoid gate over channels (models/mn/block_types.py:45-83)."""
+
+    def __init__(self, input_dim, squeeze_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim, squeeze_dim)
+        self.fc2 = nn.Linear(squeeze_dim, input_dim)
+
+
+class ConcurrentSEBlock(nn.Module):
+    """Holder for ``conc_se_layers.0`` (models/mn/block_types.py:10-42); only channel SE is on the HIP path."""
+
+    def __init__(self, c_dim, se_cnf):
+        super().__init__()
+        if list(se_cnf["se_dims"]) != [1]:
+            raise NotImplementedError("HIP path implements squeeze-excitation over channels only (se_dims='c')")
+        if se_cnf["se_agg"] not in ("max", "avg", "add", "min"):
+            raise NotImplementedError(f"SE aggregation operation '{se_cnf['se_agg']}' not implemented")
+        self.sum_factor = 1.0  # a single SE layer: max/avg/min/add of one element is the identity
+        self.conc_se_layers = nn.ModuleList(
+            [SqueezeExcitation(c_dim, make_divisible(c_dim // se_cnf["se_r"], 8))])
+
+
+class InvertedResidual(nn.Module):
+    """expand 1x1 -> depthwise kxk -> [SE] -> project 1x1 (+ residual); models/mn/block_types.py:120-181."""
+
+    def __init__(self, cnf: InvertedResidualConfig, se_cnf):
+        super().__init__()
+        if not (1 <= cnf.stride <= 2):
+            raise ValueError("illegal stride value")
+        if cnf.dilation != 1:
+            raise NotImplementedError("dilated depthwise convs are not on the HIP path yet")
+        self.cnf = cnf
+        self.use_res_connect = cnf.stride == 1 and cnf.input_channels == cnf.out_channels
+        act = nn.Hardswish if cnf.use_hs else nn.ReLU
+        layers: List[nn.Module] = []
+        self.i_expand = self.i_se = None
+        if cnf.expanded_channels != cnf.input_channels:
+            self.i_expand = len(layers)
+            layers.append(_conv_bn_act(cnf.input_channels, cnf.expanded_channels, 1, act=act))
+        self.i_dw = len(layers)
+        layers.append(_conv_bn_act(cnf.expanded_channels, cnf.expanded_channels, cnf.kernel, cnf.stride,
+                                   cnf.expanded_channels, act))
+        if cnf.use_se and se_cnf["se_dims"] is not None:
+            self.i_se = len(layers)
+            layers.append(ConcurrentSEBlock(cnf.expanded_channels, se_cnf))
+        self.i_proj = len(layers)
+        layers.append(_conv_bn_act(cnf.expanded_channels, cnf.out_channels, 1, act=None))
+        self.block = nn.Sequential(*layers)
+        self.out_channels = cnf.out_channels
+        self._is_cn = cnf.stride > 1
+
+
+def _fold(conv, bn):
+    """Eval-mode BN as per-output-channel (scale, bias): y = conv(x)*scale + bias."""
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    return scale, bn.bias - bn.running_mean * scale
+
+
+class _FoldCache:
+    """Folded / packed weights keyed on the version counters of their source tensors."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self.key:
+            with torch.no_grad():
+                self.val = build()
+            self.key = key
+        return self.val
+
+
+class MN(nn.Module):
+    def __init__(self, inverted_residual_setting, last_channel, num_classes=1000, dropout=0.2,
+                 in_conv_kernel=3, in_conv_stride=2, in_channels=1, **kwargs):
+        super().__init__()
+        if not inverted_residual_setting:
+            raise ValueError("The inverted_residual_setting should not be empty")
+        if not all(isinstance(s, InvertedResidualConfig) for s in inverted_residual_setting):
+            raise TypeError("The inverted_residual_setting should be List[InvertedResidualConfig]")
+        if (in_conv_kernel, in_conv_stride, in_channels) != (3, 2, 1):
+            raise NotImplementedError("HIP stem kernel is 3x3 / stride 2 / 1 input channel")
+        se_cnf = kwargs.get("se_conf", dict(se_dims=[1], se_agg="max", se_r=4))
+        f_dim, t_dim = kwargs.get("input_dims", (128, 1000))
+        f_dim, t_dim = cnn_out_size(f_dim, 1, 1, 3, 2), cnn_out_size(t_dim, 1, 1, 3, 2)
+        c0 = inverted_residual_setting[0].input_channels
+        layers = [_conv_bn_act(in_channels, c0, 3, 2, act=nn.Hardswish)]
+        for cnf in inverted_residual_setting:
+            f_dim, t_dim = cnf.out_size(f_dim), cnf.out_size(t_dim)
+            cnf.f_dim, cnf.t_dim = f_dim, t_dim
+            layers.append(InvertedResidual(cnf, se_cnf))
+        c_last = inverted_residual_setting[-1].out_channels
+        layers.append(_conv_bn_act(c_last, 6 * c_last, 1, act=nn.Hardswish))
+        self.features = nn.Sequential(*layers)
+        self.head_type = kwargs.get("head_type", False)
+        if self.head_type == "mlp":
+            self.classifier = nn.Sequential(
+                nn.AdaptiveAvgPool2d(1), nn.Flatten(start_dim=1), nn.Linear(6 * c_last, last_channel),
+                nn.Hardswish(inplace=True), nn.Dropout(p=dropout, inplace=True), nn.Linear(last_channel, num_classes))
+        elif self.head_type in ("fully_convolutional", "multihead_attention_pooling"):
+            raise NotImplementedError(f"Head '{self.head_type}' is not on the HIP path yet (only 'mlp')")
+        else:
+            raise NotImplementedError(f"Head '{self.head_type}' unknown. Must be one of: 'mlp', "
+                                      f"'fully_convolutional', 'multihead_attention_pooling'")
+        for m in self.modules():  # models/mn/model.py:199-210
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+        self._cache = _FoldCache()
+
+    # ------------------------------------------------------------------ folded weights
+    def _fold_sources(self):
+        return [t for m in self.features.modules() if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))
+                for t in ([m.weight] if isinstance(m, nn.Conv2d) else
+                          [m.weight, m.bias, m.running_mean, m.running_var])]
+
+    def _build_folded(self):
+        out = {}
+        stem = self.features[0]
+        s, b = _fold(stem[0], stem[1])
+        out["stem"] = ((stem[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, 9).contiguous(), b.contiguous())
+        for i, blk in enumerate(self.features[1:-1]):
+            d = {}
+            if blk.i_expand is not None:
+                cna = blk.block[blk.i_expand]
+                s, b = _fold(cna[0], cna[1])
+                d["exp"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
+            cna = blk.block[blk.i_dw]
+            s, b = _fold(cna[0], cna[1])
+            k = blk.cnf.kernel
+            d["dw"] = ((cna[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, k * k).contiguous(), b.contiguous())
+            cna = blk.block[blk.i_proj]
+            s, b = _fold(cna[0], cna[1])
+            d["proj"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
+            out[i] = d
+        last = self.features[-1]
+        s, b = _fold(last[0], last[1])
+        out["last"] = (ops.pw_prepack(last[0].weight.flatten(1), s.contiguous()), b.contiguous())
+        return out
+
+    # --------------------------------------------------------------------------- forward
+    def _forward_impl(self, x, return_fmaps: bool = False):
+        if self.training:
+            raise NotImplementedError("train-mode forward/backward kernels are not wired up yet")
+        if not x.is_cuda:
+            raise ops._lib.EatHipError("MN.forward needs a GPU tensor: efficientat_amd has no CPU path")
+        W = self._cache.get(self._fold_sources(), self._build_folded)
+        x = x.contiguous().float()
+        B = x.shape[0]
+        fmaps = []
+        blocks = list(self.features[1:-1])
+        se_sizes = [b.cnf.expanded_channels for b in blocks if b.i_se is not None]
+        c_feat = self.features[-1].out_channels
+        # one zeroed arena for every fused-pool accumulator of this forward (SE squeezes + head pool)
+        arena = torch.zeros((B * (sum(se_sizes) + c_feat),), device=x.device, dtype=torch.float32)
+        off = 0
+
+        def take(c):
+            nonlocal off
+            t = arena[off:off + B * c].view(B, c)
+            off += B * c
+            return t
+
+        x = ops.stem_conv(x, *W["stem"], ops.ACT_HSWISH)
+        if return_fmaps:
+            fmaps.append(x)
+        for i, blk in enumerate(blocks):
+            cnf, w = blk.cnf, W[i]
+            act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
+            inp = x
+            if blk.i_expand is not None:
+                x = ops.pw_conv(x, w["exp"][0], w["exp"][1], cnf.expanded_channels, act)
+            pool = scale = None
+            if blk.i_se is not None:
+                pool = take(cnf.expanded_channels)
+            x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
+            if pool is not None:
+                se = blk.block[blk.i_se].conc_se_layers[0]
+                inv_s = 1.0 / (x.shape[2] * x.shape[3])
+                h = ops.linear(pool, se.fc1.weight, se.fc1.bias, ops.ACT_RELU, inv_s)
+                scale = ops.linear(h, se.fc2.weight, se.fc2.bias, ops.ACT_SIGMOID)
+            x = ops.pw_conv(x, w["proj"][0], w["proj"][1], cnf.out_channels, ops.ACT_NONE, in_scale=scale,
+                            res=inp if blk.use_res_connect else None)
+            if return_fmaps:
+                fmaps.append(x)
+        pooled = take(c_feat)
+        S = x.shape[2] * x.shape[3]
+        y = ops.pw_conv(x, W["last"][0], W["last"][1], c_feat, ops.ACT_HSWISH, pool=pooled, write=return_fmaps)
+        if return_fmaps:
+            fmaps.append(y)
+        fc1, fc2 = self.classifier[2], self.classifier[5]
+        h = ops.linear(pooled, fc1.weight, fc1.bias, ops.ACT_HSWISH, 1.0 / S)
+        logits = ops.linear(h, fc2.weight, fc2.bias, ops.ACT_NONE)
+        if return_fmaps:
+            return logits, fmaps
+        return logits, pooled * (1.0 / S)
+
+    def forward(self, x):
+        return self._forward_impl(x)
+
+
+def _mobilenet_v3_conf(width_mult=1.0, reduced_tail=False, dilated=False, strides=(2, 2, 2, 2), **kwargs):
+    """The 15-row MobileNetV3-large table scaled by width_mult (models/mn/model.py:237-271)."""
+    div = 2 if reduced_tail else 1
+    dil = 2 if dilated else 1
+    row = partial(InvertedResidualConfig, width_mult=width_mult)
+    c160, c960 = 160 // div, 960 // div
+    spec = [
+        (16, 3, 16, 16, False, "RE", 1, 1), (16, 3, 64, 24, False, "RE", strides[0], 1),
+        (24, 3, 72, 24, False, "RE", 1, 1), (24, 5, 72, 40, True, "RE", strides[1], 1),
+        (40, 5, 120, 40, True, "RE", 1, 1), (40, 5, 120, 40, True, "RE", 1, 1),
+        (40, 3, 240, 80, False, "HS", strides[2], 1), (80, 3, 200, 80, False, "HS", 1, 1),
+        (80, 3, 184, 80, False, "HS", 1, 1), (80, 3, 184, 80, False, "HS", 1, 1),
+        (80, 3, 480, 112, True, "HS", 1, 1), (112, 3, 672, 112, True, "HS", 1, 1),
+        (112, 5, 672, c160, True, "HS", strides[3], dil), (c160, 5, c960, c160, True, "HS", 1, dil),
+        (c160, 5, c960, c160, True, "HS", 1, dil),
+    ]
+    return [row(*r) for r in spec], InvertedResidualConfig.adjust_channels(1280 // div, width_mult)
+
+
+def _mobilenet_v3(inverted_residual_setting, last_channel, pretrained_name, **kwargs):
+    """Build + optional checkpoint load with class-count surgery (models/mn/model.py:274-313)."""
+    model = MN(inverted_residual_setting, last_channel, **kwargs)
+    if pretrained_name in pretrained_models:
+        from torch.hub import load_state_dict_from_url
+        state_dict = load_state_dict_from_url(pretrained_models[pretrained_name], model_dir=model_dir,
+                                              map_location="cpu")
+        n_ckpt = state_dict["classifier.5.bias"].size(0)
+        if kwargs["num_classes"] != n_ckpt:
+            print(f"Number of classes defined: {kwargs['num_classes']}, "
+                  f"but try to load pre-trained layer with logits: {n_ckpt}\nDropping last layer.")
+            del state_dict["classifier.5.weight"], state_dict["classifier.5.bias"]
+        try:
+            model.load_state_dict(state_dict)
+        except RuntimeError as e:
+            print(str(e))
+            print("Loading weights pre-trained weights in a non-strict manner.")
+            model.load_state_dict(state_dict, strict=False)
+    elif pretrained_name:
+        raise NotImplementedError(f"Model name '{pretrained_name}' unknown.")
+    return model
+
+
+def mobilenet_v3(pretrained_name: Optional[str] = None, **kwargs) -> MN:
+    setting, last_channel = _mobilenet_v3_conf(**kwargs)
+    return _mobilenet_v3(setting, last_channel, pretrained_name, **kwargs)
+
+
+def get_model(num_classes: int = 527, pretrained_name: str = None, width_mult: float = 1.0,
+              reduced_tail: bool = False, dilated: bool = False, strides=(2, 2, 2, 2),
+              head_type: str = "mlp", multihead_attention_heads: int = 4, input_dim_f: int = 128,
+              input_dim_t: int = 1000, se_dims: str = "c", se_agg: str = "max", se_r: int = 4):
+    """Same signature as models/mn/model.py:326-329."""
+    dim_map = {"c": 1, "f": 2, "t": 3}
+    assert len(se_dims) <= 3 and all(s in dim_map for s in se_dims) or se_dims == "none"
+    se_conf = dict(se_dims=None if se_dims == "none" else [dim_map[s] for s in se_dims], se_agg=se_agg, se_r=se_r)
+    m = mobilenet_v3(pretrained_name=pretrained_name, num_classes=num_classes, width_mult=width_mult,
+                     reduced_tail=reduced_tail, dilated=dilated, strides=strides, head_type=head_type,
+                     multihead_attention_heads=multihead_attention_heads,
+                     input_dims=(input_dim_f, input_dim_t), se_conf=se_conf)
+    print(m)
+    return m

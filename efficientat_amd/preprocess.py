@@ -1,0 +1,120 @@
+"""Drop-in for the reference's ``models.preprocess.AugmentMelSTFT`` (models/preprocess.py:6-67)
+backed by the fused HIP kernel ``eat_mel_fwd``.
+
+Same constructor signature, buffers (``window`` and ``preemphasis_coefficient``, both
+non-persistent so the state_dict stays empty), host RNG draw sequence and output
+``(B, n_mels, T)``.  The kaldi mel basis is built on the host with the reference's exact fp32
+op order (so the set of non-zero (mel, bin) pairs is identical, incl. the fp32-only entry at
+bin 480 / filter 127) and shipped to the kernel as a banded table.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def kaldi_mel_basis(n_mels, n_fft, sr, fmin, fmax):
+    """torchaudio 0.13 ``compliance.kaldi.get_mel_banks(n_mels, n_fft, sr, fmin, fmax, 100, -500, 1.0)``
+    restated op-for-op in fp32 torch CPU arithmetic (call site models/preprocess.py:52-53)."""
+    nyquist = 0.5 * sr
+    if fmax <= 0.0:
+        fmax += nyquist
+    if not (0.0 <= fmin < nyquist and 0.0 < fmax <= nyquist and fmin < fmax):
+        raise ValueError(f"Bad values in options: low-freq {fmin} and high-freq {fmax} vs. nyquist {nyquist}")
+    bin_width = sr / n_fft
+    m_lo = 1127.0 * math.log(1.0 + fmin / 700.0)
+    m_hi = 1127.0 * math.log(1.0 + fmax / 700.0)
+    delta = (m_hi - m_lo) / (n_mels + 1)
+    idx = torch.arange(n_mels).unsqueeze(1)
+    left = m_lo + idx * delta
+    center = m_lo + (idx + 1.0) * delta
+    right = m_lo + (idx + 2.0) * delta
+    mel = (1127.0 * (1.0 + (bin_width * torch.arange(n_fft / 2)) / 700.0).log()).unsqueeze(0)
+    up = (mel - left) / (center - left)
+    down = (right - mel) / (right - center)
+    return torch.max(torch.zeros(1), torch.min(up, down))          # (n_mels, n_fft/2)
+
+
+def band_table(basis):
+    """Dense (n_mels, n_fft/2) basis -> (band_w (n_mels, band_len) fp32, band_start (n_mels) int32).
+    Every non-zero of row m lies in [start[m], start[m]+band_len); start+band_len <= n_fft/2."""
+    nz = basis != 0
+    n_mels, nb = basis.shape
+    cols = torch.arange(nb)
+    first = torch.where(nz, cols, nb).min(dim=1).values
+    last = torch.where(nz, cols, -1).max(dim=1).values
+    first = torch.where(last < 0, torch.zeros_like(first), first)   # empty rows
+    band_len = int(max(1, (last - first + 1).max().item()))
+    start = torch.minimum(first, torch.full_like(first, nb - band_len)).clamp_(min=0)
+    gather = start.unsqueeze(1) + torch.arange(band_len).unsqueeze(0)
+    return basis.gather(1, gather).contiguous(), start.to(torch.int32).contiguous()
+
+
+def fft_twiddles(n_fft):
+    j = np.arange(n_fft, dtype=np.float64)
+    ang = -2.0 * np.pi * j / n_fft
+    return torch.from_numpy(np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32))
+
+
+class AugmentMelSTFT(nn.Module):
+    def __init__(self, n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, freqm=48, timem=192,
+                 fmin=0.0, fmax=None, fmin_aug_range=10, fmax_aug_range=2000):
+        super().__init__()
+        self.win_length, self.n_mels, self.n_fft, self.sr = win_length, n_mels, n_fft, sr
+        self.fmin = fmin
+        if fmax is None:
+            fmax = sr // 2 - fmax_aug_range // 2
+            print(f"Warning: FMAX is None setting to {fmax} ")
+        self.fmax = fmax
+        self.hopsize = hopsize
+        self.register_buffer("window", torch.hann_window(win_length, periodic=False), persistent=False)
+        assert fmin_aug_range >= 1, f"fmin_aug_range={fmin_aug_range} should be >=1; 1 means no augmentation"
+        assert fmax_aug_range >= 1, f"fmax_aug_range={fmax_aug_range} should be >=1; 1 means no augmentation"
+        self.fmin_aug_range, self.fmax_aug_range = fmin_aug_range, fmax_aug_range
+        self.register_buffer("preemphasis_coefficient", torch.as_tensor([[[-.97, 1]]]), persistent=False)
+        self.freqm, self.timem = freqm, timem          # mask parameters (0 = off), fused into the kernel
+        self._twiddle = None
+        self._tables = {}                              # (fmin, fmax, device) -> (band_w, band_start)
+
+    # -- host helpers -------------------------------------------------------------------
+    def _device_tables(self, fmin, fmax, device):
+        key = (float(fmin), float(fmax), str(device))
+        hit = self._tables.get(key)
+        if hit is None:
+            bw, bs = band_table(kaldi_mel_basis(self.n_mels, self.n_fft, self.sr, fmin, fmax))
+            hit = (bw.to(device, non_blocking=True), bs.to(device, non_blocking=True))
+            if len(self._tables) > 64:
+                self._tables.clear()
+            self._tables[key] = hit
+        if self._twiddle is None or self._twiddle.device != device:
+            self._twiddle = fft_twiddles(self.n_fft).to(device)
+        return hit
+
+    @staticmethod
+    def _draw_mask(param, size):
+        """torchaudio 0.13 mask_along_axis on a 3-D (B,F,T) input: one mask for the batch."""
+        value = torch.rand(1) * param
+        min_value = torch.rand(1) * (size - value)
+        start = int(min_value.long())
+        return start, start + int(value.long())
+
+    def forward(self, x):
+        # host RNG draws happen in the reference's order, also in eval (preprocess.py:45-46)
+        fmin = self.fmin + torch.randint(self.fmin_aug_range, (1,)).item()
+        fmax = self.fmax + self.fmax_aug_range // 2 - torch.randint(self.fmax_aug_range, (1,)).item()
+        if not self.training:
+            fmin, fmax = self.fmin, self.fmax
+        x = x.contiguous().float()
+        T = 1 + (x.shape[1] - 1) // self.hopsize
+        fmask = tmask = (0, 0)
+        if self.training:
+            if self.freqm:
+                fmask = self._draw_mask(self.freqm, self.n_mels)
+            if self.timem:
+                tmask = self._draw_mask(self.timem, T)
+        band_w, band_start = self._device_tables(fmin, fmax, x.device)
+        return ops.mel_fwd(x, self.window, self._twiddle, band_w, band_start, self.n_fft, self.hopsize,
+                           self.n_mels, fmask, tmask)

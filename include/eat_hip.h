@@ -1,0 +1,101 @@
+/* eat_hip.h -- C ABI of libeat_hip.so: the MI355X (gfx950) hot path of EfficientAT.
+ *
+ * The reference (fschmid56/EfficientAT) is pure Python on PyTorch: its "FFI" for this path
+ * is the set of torch ops its modules call.  Each entry point below replaces the torch-op
+ * sequence of one reference call site (cited per function, paths relative to the reference
+ * root).  A maintainer binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name starts with h_; fp32 unless noted
+ *   - tensors are contiguous NCHW = (B, C, F, T), T fastest; S = F*T is the plane size
+ *   - the caller owns every buffer; the library allocates nothing and keeps no mutable
+ *     global state, so calls may be issued concurrently on different streams
+ *   - work is enqueued on `stream` (a hipStream_t) asynchronously; no hidden synchronisation
+ *   - return 0 on success, a negative EAT_E* code otherwise (never throws, never exits);
+ *     eat_last_error_string() returns the message of the calling thread's last failure
+ */
+#ifndef EAT_HIP_H
+#define EAT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* eat_stream_t; /* hipStream_t */
+
+#define EAT_OK 0
+#define EAT_EINVAL (-1)   /* unsupported shape / bad argument            */
+#define EAT_ELAUNCH (-2)  /* HIP reported an error at kernel launch      */
+
+/* activation codes shared by all conv entry points */
+#define EAT_ACT_NONE 0
+#define EAT_ACT_RELU 1
+#define EAT_ACT_HSWISH 2   /* x * clamp(x + 3, 0, 6) / 6 (nn.Hardswish) */
+#define EAT_ACT_SIGMOID 3  /* eat_linear_fwd only (SqueezeExcitation gate)  */
+
+int eat_version(void);
+const char* eat_last_error_string(void);
+
+/* ---- mel front-end: models/preprocess.py:40-67 (AugmentMelSTFT.forward) -----------------
+ * wave (B, L) -> out (B, n_mels, T), T = 1 + (L - 1) / hop  [centre-padded STFT of the
+ * pre-emphasised signal, which has L-1 samples].
+ * One fused kernel: pre-emphasis conv1d [-0.97, 1] (:41), reflect pad n_fft/2 + hann window
+ * + rFFT (:42-43), power (:44), mel filterbank matmul (:56-57), log(x + 1e-5) (:59),
+ * optional frequency / time masking (:61-63), (x + 4.5) / 5 (:65).
+ *   window      (win_length)   the reference's torch.hann_window(win_length, periodic=False)
+ *   twiddle     (n_fft, 2)     exp(-2*pi*i*j/n_fft) as (cos, -sin) pairs, fp32 from fp64
+ *   band_w      (n_mels, band_len)  non-zero band of each row of the kaldi mel basis (:52-55),
+ *                              built on the host with the reference's fp32 op order
+ *   band_start  (n_mels)       first FFT bin of each band; band_start[m]+band_len <= n_fft/2
+ *   mask_f0..mask_t1           [f0,f1) mel rows and [t0,t1) frames set to 0.0 after the log
+ *                              (train-mode masking); pass f0==f1 / t0==t1 for none
+ * Only n_fft == 1024 is implemented (every reference config); others return EAT_EINVAL. */
+int eat_mel_fwd(const float* wave, int B, int L, const float* window, int win_length, int n_fft,
+                int hop, const float* twiddle, const float* band_w, const int* band_start,
+                int n_mels, int band_len, float* out, int T, int mask_f0, int mask_f1,
+                int mask_t0, int mask_t1, eat_stream_t stream);
+
+/* ---- stem: models/mn/model.py:124-133 (ConvNormActivation 3x3 stride 2, 1 -> C) ----------
+ * x (B,1,F,T) -> y (B,C,Fo,To), Fo=(F+1)/2-ish per cnn_out_size; w (C,1,3,3) with the eval-mode
+ * BatchNorm already folded in (w' = w*g/sqrt(rv+eps)), bias (C) = b - rm*g/sqrt(rv+eps). */
+int eat_stem_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
+                      int F, int T, int Fo, int To, int act, eat_stream_t stream);
+
+/* ---- depthwise k x k conv: models/mn/block_types.py:150-162 ------------------------------
+ * x (B,C,F,T) -> y (B,C,Fo,To); k in {3,5}, stride in {1,2}, pad (k-1)/2; w (C,k,k) BN-folded,
+ * bias (C).  If pool != NULL, the per-(b,c) sum over the output plane of the ACTIVATED output
+ * is atomically accumulated into pool (B,C) (zeroed by the caller): the squeeze of
+ * SqueezeExcitation (block_types.py:72-73) fused into the producer. */
+int eat_dw_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* pool,
+                    int B, int C, int F, int T, int Fo, int To, int k, int stride, int act,
+                    eat_stream_t stream);
+
+/* ---- pointwise 1x1 conv (GEMM): models/mn/block_types.py:138-147,167-171; mn/model.py:159-167
+ * y[b] (Co,S) = act( W (Co,Ci) . (x[b] (Ci,S) * in_scale[b,:,None]) + bias[:,None] ) + res[b]
+ * wp = W packed by eat_pw_prepack (BN scale folded in via row_scale), bias (Co);
+ * in_scale (B,Ci) or NULL (SE scale, block_types.py:83);
+ * res (B,Co,S) or NULL (block_types.py:179-180, added after the activation-free project conv);
+ * pool (B,Co) or NULL: per-(b,co) sums of the final output (global average pool of
+ * mn/model.py:220 fused; y may then be NULL to skip materialising the last feature map).
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products and accumulation.
+ * Requires Ci % 4 == 0 and S % 4 == 0 (true for every reference configuration). */
+int eat_pw_conv_fwd(const float* x, const float* wp, const float* bias, const float* in_scale,
+                    const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
+                    eat_stream_t stream);
+
+/* Pack w (Co,Ci) * row_scale[:,None] (row_scale may be NULL) into MFMA A-fragment order:
+ * wp has (Ci/4) * ceil(Co/16) * 64 floats.  Done once per weight update, not per step. */
+int eat_pw_prepack(const float* w, const float* row_scale, float* wp, int Co, int Ci,
+                   eat_stream_t stream);
+
+/* ---- linear: models/mn/model.py:189-193 (classifier Linear layers) and the two Linear layers
+ * of SqueezeExcitation (models/mn/block_types.py:64-65,74-79: fc1+ReLU, fc2+Sigmoid) ---------
+ * y (B,N) = act( (x (B,K) * x_scale) . W^T (N,K) + bias ); x_scale multiplies x (1/S turns
+ * pooled sums into the mean of mn/model.py:220). */
+int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
+                   float x_scale, int act, eat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAT_HIP_H */

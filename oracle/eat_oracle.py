@@ -38,23 +38,23 @@ def kaldi_mel_banks(n_mels, n_fft, sr, fmin, fmax):
 
 
 def mel_forward(x, n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024,
-                fmin=0.0, fmax=15000.0, freq_mask=None, time_mask=None):
+                fmin=0.0, fmax=15000.0, freq_mask=None, time_mask=None, dtype=torch.float32):
     """x (B, L) fp32 -> (B, n_mels, T).  Explicit framing restatement of
     preprocess.py:41-65 (conv1d pre-emphasis, centred reflect-padded STFT with a
     non-periodic hann window zero-padded to n_fft, power, mel matmul, log, normalise).
     ``freq_mask``/``time_mask`` = (start, end) index ranges zeroed after the log
     (train-mode masking, preprocess.py:61-63); the caller draws them."""
-    x = x.float()
+    x = x.to(dtype)
     pre = x[:, 1:] - 0.97 * x[:, :-1]                                  # :41
     pad = n_fft // 2
     p = F.pad(pre.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)  # stft(center=True)
     frames = p.unfold(1, n_fft, hopsize)                                # (B, T, n_fft)
-    win = torch.hann_window(win_length, periodic=False)
+    win = torch.hann_window(win_length, periodic=False).to(dtype)   # the fp32 window, as the reference holds it
     lpad = (n_fft - win_length) // 2
     win = F.pad(win, (lpad, n_fft - win_length - lpad))
     spec = torch.fft.rfft(frames * win, dim=-1)                         # (B, T, n_fft/2+1)
     power = (spec.real ** 2 + spec.imag ** 2).transpose(1, 2)           # :44
-    basis = kaldi_mel_banks(n_mels, n_fft, sr, fmin, fmax)
+    basis = kaldi_mel_banks(n_mels, n_fft, sr, fmin, fmax).to(dtype)   # always the fp32-built basis
     mel = torch.matmul(basis, power)                                    # :57
     mel = (mel + 0.00001).log()                                         # :59
     if freq_mask is not None:

@@ -1,0 +1,225 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle / golden vectors.
+
+Tolerances: fp32 everywhere.  Log-mel <= 1e-4 max-abs; per-op kernels <= 2e-5
+relative to the output scale; mn10 logits <= 1e-3 abs (BASELINE north_star), fmaps <= 1e-4
+relative to the fmap std.
+"""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import eat_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():  # collected but skipped on the CPU-only build container
+    pytest.skip("no GPU", allow_module_level=True)
+
+from efficientat_amd import ops  # noqa: E402
+from efficientat_amd.mn import get_model  # noqa: E402
+from efficientat_amd.preprocess import AugmentMelSTFT  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _close(got, ref, rel, what):
+    got = got.detach().cpu()
+    scale = max(1e-6, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= rel * scale, f"{what}: max-abs err {err:.3e} vs scale {scale:.3e} (rel tol {rel})"
+
+
+# ----------------------------------------------------------------------------------- mel
+@pytest.mark.parametrize("n_samples,seed", [(32000, 77), (320000, 1234), (33333, 5)])
+def test_mel_matches_oracle(n_samples, seed):
+    wave = synth.parity_clips(n_samples, seed=seed)
+    mel = _quiet(AugmentMelSTFT, freqm=0, timem=0).to(DEV).eval()
+    got = mel(wave.to(DEV)).cpu()
+    ref = O.mel_forward(wave)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().amax(dim=(1, 2))
+    # T1: <= 1e-4 on the noise / tone clips; the silence+chirp clip sits on the log(1e-5)
+    # floor where fp32 FFT round-off dominates (the reference itself is 1.5e-4 away from fp64 there)
+    assert float(err[[0, 1, 2, 4]].max()) < 1e-4, err.tolist()
+    assert float(err[0]) < 6e-5 and float(err[3]) < 5e-4, err.tolist()
+    # principled bound: the HIP result is as close to the exact (fp64) value as the reference-order
+    # fp32 evaluation is, up to a small factor
+    exact = O.mel_forward(wave, dtype=torch.float64)
+    e_hip = (got.double() - exact).abs().amax(dim=(1, 2))
+    e_ref = (ref.double() - exact).abs().amax(dim=(1, 2))
+    assert torch.all(e_hip <= 3.0 * e_ref + 2e-5), (e_hip.tolist(), e_ref.tolist())
+
+
+def test_mel_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel_ref.npz"))
+    mel = _quiet(AugmentMelSTFT, freqm=0, timem=0).to(DEV).eval()
+    got = mel(synth.parity_clips(32000, seed=77).to(DEV)).cpu().numpy()
+    e = np.abs(got - g["short"]).max(axis=(1, 2))
+    assert e[[0, 1, 2, 4]].max() < 1e-4 and e[3] < 5e-4, e
+    full = mel(synth.parity_clips(320000, seed=1234).to(DEV)).cpu()
+    assert np.abs(full[:, :, g["t_edge"]].numpy() - g["full_edge"]).max() < 5e-4
+    assert np.abs(full.double().sum(dim=2).numpy() - g["full_rowsum"]).max() < 5e-2
+
+
+def test_mel_train_mode_replays_reference_rng(golden_dir):
+    """fmin/fmax jitter + freq/time masks drawn from the torch CPU RNG in the reference's order."""
+    g = np.load(os.path.join(golden_dir, "mel_ref.npz"))
+    mel = _quiet(AugmentMelSTFT, freqm=48, timem=192).to(DEV).train()
+    torch.manual_seed(2024)
+    got = mel(synth.parity_clips(64000, seed=78).to(DEV)).cpu().numpy()
+    e = np.abs(got - g["train_short_seed2024"]).max(axis=(1, 2))
+    assert e[[0, 1, 2, 4]].max() < 1e-4 and e[3] < 5e-4, e
+    assert (got == 0.9).any()                      # masked cells: (0 + 4.5) / 5
+
+
+def test_mel_silence_and_linearity_property():
+    """Size-independent properties at full clip length: all-zero clip hits the log floor exactly;
+    scaling the waveform by a shifts the un-normalised log-mel by 2*log(a) away from the floor."""
+    mel = _quiet(AugmentMelSTFT, freqm=0, timem=0).to(DEV).eval()
+    z = mel(torch.zeros(2, 320000, device=DEV))
+    floor = (float(np.log(np.float32(1e-5))) + 4.5) / 5.0
+    assert float((z - floor).abs().max()) < 1e-6 and float(z.max() - z.min()) == 0.0
+    w = (0.1 * _rand(1, 320000, seed=3)).to(DEV)
+    a, b = mel(w), mel(2.0 * w)
+    d = ((b - a) * 5.0).cpu()
+    loud = (a.cpu() * 5.0 - 4.5) > -6.0           # cells whose energy is far above the 1e-5 floor
+    assert int(loud.sum()) > 10000
+    assert float((d[loud] - 2 * np.log(2.0)).abs().max()) < 2e-2
+
+
+# --------------------------------------------------------------------------- single ops
+@pytest.mark.parametrize("B,C,F_,T", [(2, 16, 128, 1000), (3, 8, 17, 33), (1, 24, 2, 5)])
+def test_stem_conv(B, C, F_, T):
+    x, w, b = _rand(B, 1, F_, T, seed=1), _rand(C, 1, 3, 3, seed=2, scale=0.3), _rand(C, seed=3, scale=0.1)
+    ref = F.hardswish(F.conv2d(x, w, b, 2, 1))
+    got = ops.stem_conv(x.to(DEV), w.reshape(C, 9).contiguous().to(DEV), b.to(DEV), ops.ACT_HSWISH)
+    _close(got, ref, 2e-6, "stem")
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s,act", [
+    (2, 16, 64, 500, 3, 1, 1), (2, 64, 64, 500, 3, 2, 1), (2, 72, 32, 250, 5, 2, 1), (2, 120, 16, 125, 5, 1, 1),
+    (2, 240, 16, 125, 3, 2, 2), (3, 200, 8, 63, 3, 1, 2), (3, 672, 8, 63, 5, 2, 2), (5, 960, 4, 32, 5, 1, 2),
+    (1, 8, 7, 9, 3, 2, 0), (2, 5, 1, 3, 5, 1, 2), (1, 3, 33, 700, 5, 2, 1)])
+def test_dw_conv(B, C, F_, T, k, s, act):
+    x, w, b = _rand(B, C, F_, T, seed=1), _rand(C, 1, k, k, seed=2, scale=0.3), _rand(C, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, s, (k - 1) // 2, 1, C)
+    ref = [ref, F.relu(ref), F.hardswish(ref)][act]
+    pool = torch.zeros(B, C, device=DEV)
+    got = ops.dw_conv(x.to(DEV), w.reshape(C, k * k).contiguous().to(DEV), b.to(DEV), k, s, act, pool)
+    _close(got, ref, 2e-6, "dw")
+    _close(pool, ref.sum(dim=(2, 3)), 2e-5, "dw pool")
+
+
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act,se,res", [
+    (2, 16, 64, 64, 500, 1, False, False), (2, 16, 16, 64, 500, 0, False, True), (2, 64, 24, 32, 250, 0, False, False),
+    (2, 72, 40, 16, 125, 0, True, False), (3, 80, 200, 8, 63, 2, False, False), (3, 184, 80, 8, 63, 0, False, True),
+    (3, 112, 672, 8, 63, 2, False, False), (4, 672, 160, 4, 32, 0, True, False), (4, 160, 960, 4, 32, 2, False, False),
+    (5, 960, 160, 4, 32, 0, True, True), (1, 8, 8, 1, 4, 2, False, False), (2, 12, 20, 3, 12, 1, True, True)])
+def test_pw_conv(B, Ci, Co, F_, T, act, se, res):
+    x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
+    bias, rs = _rand(Co, seed=3, scale=0.1), torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5
+    sc = torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) if se else None
+    r = _rand(B, Co, F_, T, seed=6) if res else None
+    xs = x * sc[:, :, None, None] if se else x
+    ref = F.conv2d(xs, (w * rs[:, None]).view(Co, Ci, 1, 1), bias)
+    ref = [ref, F.relu(ref), F.hardswish(ref)][act]
+    if res:
+        ref = ref + r
+    wp = ops.pw_prepack(w.to(DEV), rs.to(DEV))
+    pool = torch.zeros(B, Co, device=DEV)
+    got = ops.pw_conv(x.to(DEV), wp, bias.to(DEV), Co, act, in_scale=None if sc is None else sc.to(DEV),
+                      res=None if r is None else r.to(DEV), pool=pool)
+    _close(got, ref, 5e-6, "pw")
+    _close(pool, ref.sum(dim=(2, 3)), 5e-5, "pw pool")
+
+
+@pytest.mark.parametrize("B,K,N,act", [(256, 960, 1280, 2), (5, 1280, 527, 0), (3, 72, 24, 1), (7, 24, 72, 3),
+                                       (1, 10, 3, 0), (17, 6, 33, 2)])
+def test_linear(B, K, N, act):
+    x, w, b = _rand(B, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1)
+    ref = F.linear(x * 0.5, w, b)
+    ref = [ref, F.relu(ref), F.hardswish(ref), torch.sigmoid(ref)][act]
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act, 0.5)
+    _close(got, ref, 5e-6, "linear")
+
+
+# ------------------------------------------------------------------------- whole network
+def _calibrated_state(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
+    sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    return sd, g
+
+
+def test_mn10_eval_logits_and_fmaps(golden_dir):
+    sd, g = _calibrated_state(golden_dir)
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    wave = synth.parity_clips(320000, seed=1234)
+    x_ref = O.mel_forward(wave).unsqueeze(1)
+    with torch.no_grad():
+        ref_logits, ref_fmaps = O.mn_forward(sd, x_ref, return_fmaps=True)
+        _, ref_feat = O.mn_forward(sd, x_ref)
+        # T2: model kernels on the oracle's mel
+        logits, fmaps = model._forward_impl(x_ref.to(DEV), return_fmaps=True)
+        logits2, feat = model(x_ref.to(DEV))
+    assert len(fmaps) == 17
+    for i, (a, b) in enumerate(zip(fmaps, ref_fmaps)):
+        assert a.shape == b.shape
+        err = float((a.cpu() - b).abs().max())
+        assert err < 1e-4 * max(1.0, float(b.std())) * 10, f"fmap {i}: {err}"
+    assert float((logits.cpu() - ref_logits).abs().max()) < 1e-3
+    assert float((logits2.cpu() - ref_logits).abs().max()) < 1e-3
+    assert float((feat.cpu() - ref_feat).abs().max()) < 1e-4
+    # and against the stored output of the unmodified reference
+    assert np.abs(logits.cpu().numpy() - g["eval_logits"]).max() < 1e-3
+    # T3: waveform -> logits through the HIP mel
+    mel = _quiet(AugmentMelSTFT, freqm=0, timem=0).to(DEV).eval()
+    with torch.no_grad():
+        logits3, _ = model(mel(wave.to(DEV)).unsqueeze(1))
+    assert float((logits3.cpu() - ref_logits).abs().max()) < 1e-3
+    assert np.abs(logits3.cpu().numpy() - g["eval_logits"]).max() < 1e-3
+
+
+def test_refold_after_weight_update(golden_dir):
+    """Folded/packed weights must follow in-place parameter updates (optimizer steps, load_state_dict)."""
+    sd, _ = _calibrated_state(golden_dir)
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd)
+    model.to(DEV).eval()
+    x = _rand(2, 1, 128, 1000, seed=8).to(DEV)
+    with torch.no_grad():
+        a, _ = model(x)
+        model.features[3].block[0][0].weight.mul_(1.5)
+        b, _ = model(x)
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        model.load_state_dict(sd2)
+        c, _ = model(x)
+    assert float((a - b).abs().max()) > 1e-4
+    # atomics in the fused pools: not bit-reproducible, so compare relative to the logit scale
+    assert float((a - c).abs().max()) < 1e-5 * float(a.abs().max())
+
+
+def test_cpu_tensor_fails_loudly():
+    model = _quiet(get_model, width_mult=0.1).eval()
+    with pytest.raises(Exception):
+        model(torch.zeros(1, 1, 128, 100))

@@ -1,0 +1,100 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every declared symbol, and the host
+logic of the drop-in mirrors (mel basis table, config math, state-dict layout, error behaviour)."""
+import contextlib
+import ctypes
+import io
+import os
+import re
+
+import pytest
+import torch
+
+from efficientat_amd import _lib, build, utils
+from efficientat_amd.mn import get_model, _mobilenet_v3_conf
+from efficientat_amd.preprocess import AugmentMelSTFT, band_table, kaldi_mel_basis
+from oracle import eat_oracle as O
+from oracle import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+@pytest.fixture(scope="session")
+def libpath():
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    header = open(os.path.join(ROOT, "include", "eat_hip.h")).read()
+    declared = set(re.findall(r"\b(eat_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    import torch  # noqa: F401  (load order: see efficientat_amd/_lib.py)
+    h = ctypes.CDLL(libpath)
+    for name in sorted(declared):
+        assert hasattr(h, name), f"{name} declared in include/eat_hip.h but not exported"
+    assert declared == set(_lib.exported_symbols())
+    assert h.eat_version() >= 100
+
+
+def test_mel_basis_is_bit_identical_to_oracle_and_banded():
+    for fmin, fmax in [(0.0, 15000), (3, 14500), (9, 16000), (0.0, 14001)]:
+        b = kaldi_mel_basis(128, 1024, 32000, fmin, fmax)
+        ref = O.kaldi_mel_banks(128, 1024, 32000, fmin, float(fmax))
+        assert torch.equal(b, ref[:, :512])                       # same fp32 values => same bin indices
+        bw, bs = band_table(b)
+        dense = torch.zeros_like(b)
+        for m in range(128):
+            dense[m, bs[m]:bs[m] + bw.shape[1]] = bw[m]
+        assert torch.equal(dense, b)
+        assert int(bs.max()) + bw.shape[1] <= 512
+    b = kaldi_mel_basis(128, 1024, 32000, 0.0, 15000)
+    assert int((b != 0).sum()) == 948 and float(b[127, 480]) > 0
+
+
+def test_mel_module_mirrors_reference_surface():
+    m = _quiet(AugmentMelSTFT)
+    assert m.fmax == 15000 and len(m.state_dict()) == 0
+    assert m.window.shape == (800,) and m.preemphasis_coefficient.shape == (1, 1, 2)
+    with pytest.raises(AssertionError):
+        AugmentMelSTFT(fmin_aug_range=0, fmax=1)
+    with pytest.raises(_lib.EatHipError):
+        m.eval()(torch.zeros(1, 32000))          # CPU tensor: no fallback
+
+
+def test_config_math():
+    assert [utils.NAME_TO_WIDTH(n) for n in ("mn10_as", "mn40_as_ext(2)", "dymn20_as", "foo")] == [1.0, 4.0, 2.0, 1.0]
+    for v in (8, 12, 17.6, 64 * 0.4, 960 * 4.0, 23):
+        assert utils.make_divisible(v, 8) == O.make_divisible(v, 8)
+    setting, last = _mobilenet_v3_conf(width_mult=1.0)
+    assert last == 1280 and [c.out_channels for c in setting][-1] == 160
+    ref, _ = O.block_table(2.0)
+    got, _ = _mobilenet_v3_conf(width_mult=2.0)
+    assert [(c.input_channels, c.expanded_channels, c.out_channels, c.kernel, c.stride) for c in got] == \
+           [(r["cin"], r["cexp"], r["cout"], r["k"], r["stride"]) for r in ref]
+
+
+@pytest.mark.parametrize("width,n_params", [(1.0, 4876831), (0.4, None), (4.0, 68427303)])
+def test_state_dict_layout_matches_reference(width, n_params):
+    model = _quiet(get_model, width_mult=width)
+    shapes = synth.mn_shapes(width)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    if n_params:
+        assert sum(p.numel() for p in model.parameters()) == n_params
+
+
+def test_error_behaviour_matches_reference():
+    with pytest.raises(NotImplementedError):
+        _quiet(get_model, pretrained_name="no_such_model")
+    with pytest.raises(NotImplementedError):
+        _quiet(get_model, head_type="bogus")
+    with pytest.raises(AssertionError):
+        _quiet(get_model, se_dims="x")
+    with pytest.raises(ValueError):
+        from efficientat_amd.mn import MN
+        MN([], 1280)
