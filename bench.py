@@ -99,6 +99,12 @@ def kernel_profile(step, iters=3):
     finally:
         _lib.call = real_call
     agg = {}
+    if os.environ.get("EAT_BENCH_LAUNCHES"):      # debug: one line per launch of the last iteration
+        for name, args, e0, e1 in rec[-(len(rec) // iters):]:
+            sym, nbytes = _alg_bytes(name, args)
+            us = e0.elapsed_time(e1) * 1e3
+            ints = [a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < 10 ** 7]
+            print(f"[launch] {sym:24s} {us:9.1f} us {nbytes / us / 1e3:8.1f} GB/s  {ints}", file=sys.stderr)
     for name, args, e0, e1 in rec:
         sym, nbytes = _alg_bytes(name, args)
         d = agg.setdefault(sym, [0, 0.0, 0])

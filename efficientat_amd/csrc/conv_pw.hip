@@ -25,7 +25,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-constexpr int kKC = 32;          // k rows per LDS stage
+constexpr int kKC = 32;          // max k rows per LDS stage
 constexpr int kTileN = 256;      // columns per block
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -50,15 +50,47 @@ __global__ void pw_prepack_kernel(const float* __restrict__ w, const float* __re
   wp[i] = v;
 }
 
-__host__ __device__ constexpr int a_stage_floats(int mtw) { return 512 * mtw; }  // 8 ksteps * mtw * 64
-__host__ __device__ inline int stage_floats(int mtw, int ns) { return a_stage_floats(mtw) + kKC * kTileN + kKC * ns; }
+// LDS stage = [A: (kc/4)*MTW fragment rows of 64 floats, padded to 256][X: kc rows x 256][scale: kc x NS]
+__host__ __device__ inline int a_stage_floats(int mtw, int kc) { return (((kc >> 2) * mtw * 64) + 255) & ~255; }
+__host__ __device__ inline int stage_floats(int mtw, int kc, int ns) {
+  return a_stage_floats(mtw, kc) + kc * kTileN + ((kc * ns + 3) & ~3);
+}
 
-template <int MTW>
-__global__ __launch_bounds__(256) void pw_conv_kernel(
+// The same LDS-DMA issued from inline asm.  hipcc tracks a builtin-issued LDS-DMA as a pending LDS
+// write and puts "s_waitcnt vmcnt(0)" in front of the next ds_read of the same array, which drains
+// the chunks that are supposed to stay in flight.  An asm-issued DMA is invisible to that pass; the
+// kernel counts the VM queue by hand (wait_vmcnt) and orders LDS visibility with its own barrier.
+__device__ __forceinline__ unsigned lds_addr_uniform(float* lds_wave_base) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)lds_wave_base);
+}
+__device__ __forceinline__ void glds16_raw(const float* g, float* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds_addr_uniform(lds_wave_base)), "v"(g) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4_raw(const float* g, float* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+               :: "s"(lds_addr_uniform(lds_wave_base)), "v"(g) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// PIPE = true : 16-row chunks, ring of up to 3 LDS stages, chunk c+2 is issued while chunk c is
+//               multiplied; every wave issues a FIXED number of LDS-DMA instructions per chunk
+//               (kPipeKC/4 x-rows + ceil(MTW/4) A pieces [+1 scale piece]) so the wait for chunk c
+//               is a counted s_waitcnt that leaves chunk c+1 in flight across the raw s_barrier.
+//               Requires 16*NS <= 64.
+// PIPE = false: generic fallback (any kc, any NS): 2 stages, vmcnt(0) + __syncthreads per chunk.
+constexpr int kPipeKC = 16;
+
+template <int MTW, bool PIPE>
+__global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
-    float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act) {
+    float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int kc_arg,
+    int n_stages, int act) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int kc = PIPE ? kPipeKC : kc_arg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // XCD-aware mapping: the MC row-chunks that share one column tile sit on the same XCD (ids
   // congruent mod 8) so the tile's re-reads hit that XCD's L2.
@@ -83,33 +115,61 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
   const int bc = (int)(ncc / S), sc_ = (int)(ncc - (long long)bc * S);
   const int kq = lane >> 4;
 
-  const int stage_sz = stage_floats(MTW, NS);
-  const int n_chunks = (Ci + kKC - 1) / kKC;
+  const int a_sz = a_stage_floats(MTW, kc);
+  const int stage_sz = PIPE ? a_sz + kc * kTileN + (in_scale ? 64 : 0) : stage_floats(MTW, kc, NS);
+  const int n_chunks = (Ci + kc - 1) / kc;
 
   auto issue = [&](int c) {
-    float* st = smem + (c & 1) * stage_sz;
-    const int k0 = c * kKC;
-    const int klen = (Ci - k0) < kKC ? (Ci - k0) : kKC;
-    float* Xs = st + a_stage_floats(MTW);
-    for (int r = wv; r < klen; r += 4) glds16(xsrc + (size_t)(k0 + r) * S, Xs + r * kTileN);
-    // A: (klen/4) * MTW rows of 64 floats, fragment order; 256 floats per wave instruction
-    const int rows = (klen >> 2) * MTW;
-    const int n_inst = (rows + 3) >> 2;
-    for (int q = wv; q < n_inst; q += 4) {
-      int row = q * 4 + (lane >> 4);
-      if (row >= rows) row = rows - 1;
-      const int ksl = row / MTW, i = row - ksl * MTW;
-      int mt = mt0 + i;
-      if (mt >= MT) mt = MT - 1;
-      glds16(wp + ((size_t)((k0 >> 2) + ksl) * MT + mt) * 64 + 4 * (lane & 15), st + q * 256);
-    }
-    if (in_scale) {
-      float* SCs = Xs + kKC * kTileN;
-      for (int e = tid; e < klen * NS; e += 256) {
+    float* st = smem + (PIPE ? (c % n_stages) : (c & 1)) * stage_sz;
+    const int k0 = c * kc;
+    const int klen = (Ci - k0) < kc ? (Ci - k0) : kc;
+    float* Xs = st + a_sz;
+    const int rows = (klen >> 2) * MTW;     // A: fragment rows of 64 floats; 256 floats per wave instruction
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int i = 0; i < kPipeKC / 4; ++i) {
+        const int r = wv + 4 * i;
+        const int rc = r < klen ? r : klen - 1;          // tail chunk: re-load a valid row into an unused slot
+        glds16_raw(xsrc + (size_t)(k0 + rc) * S, Xs + r * kTileN);
+      }
+#pragma unroll
+      for (int i = 0; i < (MTW + 3) / 4; ++i) {
+        int q = wv + 4 * i;
+        if (q * 256 >= a_sz) q = 0;                        // keep the per-wave count fixed: re-load piece 0
+        int row = q * 4 + (lane >> 4);
+        if (row >= rows) row = rows - 1;
+        const int ksl = row / MTW, ii = row - ksl * MTW;
+        int mt = mt0 + ii;
+        if (mt >= MT) mt = MT - 1;
+        glds16_raw(wp + ((size_t)((k0 >> 2) + ksl) * MT + mt) * 64 + 4 * (lane & 15), st + q * 256);
+      }
+      if (in_scale) {
+        int e = lane < kPipeKC * NS ? lane : kPipeKC * NS - 1;
         const int r = e / NS, j = e - r * NS;
         int bb = b_first + j;
         if (bb >= B) bb = B - 1;
-        SCs[e] = in_scale[(size_t)bb * Ci + k0 + r];
+        const int rc = r < klen ? r : klen - 1;
+        glds4_raw(in_scale + (size_t)bb * Ci + k0 + rc, Xs + kc * kTileN);   // 64 floats reserved (NS <= 4)
+      }
+    } else {
+      for (int r = wv; r < klen; r += 4) glds16(xsrc + (size_t)(k0 + r) * S, Xs + r * kTileN);
+      const int n_inst = (rows + 3) >> 2;
+      for (int q = wv; q < n_inst; q += 4) {
+        int row = q * 4 + (lane >> 4);
+        if (row >= rows) row = rows - 1;
+        const int ksl = row / MTW, i = row - ksl * MTW;
+        int mt = mt0 + i;
+        if (mt >= MT) mt = MT - 1;
+        glds16(wp + ((size_t)((k0 >> 2) + ksl) * MT + mt) * 64 + 4 * (lane & 15), st + q * 256);
+      }
+      if (in_scale) {
+        float* SCs = Xs + kc * kTileN;
+        for (int e = tid; e < klen * NS; e += 256) {
+          const int r = e / NS, j = e - r * NS;
+          int bb = b_first + j;
+          if (bb >= B) bb = B - 1;
+          SCs[e] = in_scale[(size_t)bb * Ci + k0 + r];
+        }
       }
     }
   };
@@ -121,38 +181,54 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   issue(0);
+  if (PIPE && n_chunks > 1) issue(1);
   for (int c = 0; c < n_chunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < n_chunks) issue(c + 1);
-    const float* st = smem + (c & 1) * stage_sz;
-    const float* Xw = st + a_stage_floats(MTW) + 64 * wv + 4 * (lane & 15) + kq * kTileN;
-    const float* SCs = st + a_stage_floats(MTW) + kKC * kTileN + kq * NS + (bc - b_first);
-    const float* Aw = st + lane;
-    const int k0 = c * kKC;
-    const int ksteps = ((Ci - k0) < kKC ? (Ci - k0) : kKC) >> 2;
-    auto kstep = [&](int ks) {
-      float4 xv = *reinterpret_cast<const float4*>(Xw + ks * 4 * kTileN);
-      if (in_scale) {
-        const float s = SCs[ks * 4 * NS];
-        xv.x *= s; xv.y *= s; xv.z *= s; xv.w *= s;
+    if constexpr (PIPE) {
+      constexpr int kLoads = kPipeKC / 4 + (MTW + 3) / 4;   // LDS-DMA instructions per wave per chunk
+      if (c + 1 < n_chunks) {                                // leave chunk c+1 in flight
+        if (in_scale) wait_vmcnt<kLoads + 1>(); else wait_vmcnt<kLoads>();
+      } else {
+        wait_vmcnt<0>();
       }
-      float a[MTW];
+      // raw barrier: __syncthreads() would drain the LDS-DMA of chunk c+1 (vmcnt(0))
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (c + 2 < n_chunks) issue(c + 2);
+    } else {
+      wait_vmcnt<0>();
+      __syncthreads();
+      if (c + 1 < n_chunks) issue(c + 1);
+    }
+    const float* st = smem + (PIPE ? (c % n_stages) : (c & 1)) * stage_sz;
+    const float* Xw = st + a_sz + 64 * wv + 4 * (lane & 15) + kq * kTileN;
+    const float* SCs = st + a_sz + kc * kTileN + kq * NS + (bc - b_first);
+    const float* Aw = st + lane;
+    const int k0 = c * kc;
+    const int ksteps = ((Ci - k0) < kc ? (Ci - k0) : kc) >> 2;
+    // one software-pipelined loop: the fragments of k-step ks+1 are read from LDS while the
+    // MFMAs of k-step ks issue
+    float4 xv = *reinterpret_cast<const float4*>(Xw);
+    float sv = in_scale ? SCs[0] : 1.0f;
+    float a[MTW];
 #pragma unroll
-      for (int i = 0; i < MTW; ++i) a[i] = Aw[(ks * MTW + i) * 64];
+    for (int i = 0; i < MTW; ++i) a[i] = Aw[i * 64];
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int kn = (ks + 1 < ksteps) ? ks + 1 : ks;
+      const float4 xn = *reinterpret_cast<const float4*>(Xw + kn * 4 * kTileN);
+      const float sn = in_scale ? SCs[kn * 4 * NS] : 1.0f;
+      float an[MTW];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) an[i] = Aw[(kn * MTW + i) * 64];
+      const float b0 = xv.x * sv, b1 = xv.y * sv, b2 = xv.z * sv, b3 = xv.w * sv;
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
-        acc[i][0] = mfma16(a[i], xv.x, acc[i][0]);
-        acc[i][1] = mfma16(a[i], xv.y, acc[i][1]);
-        acc[i][2] = mfma16(a[i], xv.z, acc[i][2]);
-        acc[i][3] = mfma16(a[i], xv.w, acc[i][3]);
+        acc[i][0] = mfma16(a[i], b0, acc[i][0]);
+        acc[i][1] = mfma16(a[i], b1, acc[i][1]);
+        acc[i][2] = mfma16(a[i], b2, acc[i][2]);
+        acc[i][3] = mfma16(a[i], b3, acc[i][3]);
       }
-    };
-    if (ksteps == 8) {
+      xv = xn; sv = sn;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) kstep(ks);
-    } else {
-      for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
+      for (int i = 0; i < MTW; ++i) a[i] = an[i];
     }
   }
 
@@ -272,16 +348,31 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
   int NS = kTileN / S + 2;
   if (NS > B) NS = B;
   if (!in_scale) NS = 0;
-  const size_t smem = 2 * (size_t)stage_floats(MTW, NS) * sizeof(float);
+  const bool pipe = kPipeKC * NS <= 64;
+  int kc, n_stages;
+  size_t smem;
+  if (pipe) {
+    kc = kPipeKC;
+    const int n_chunks = (Ci + kc - 1) / kc;
+    n_stages = n_chunks < 3 ? n_chunks : 3;
+    // the scale slot is a fixed 64-float piece in this mode
+    smem = (size_t)n_stages * (a_stage_floats(MTW, kc) + kc * kTileN + (in_scale ? 64 : 0)) * sizeof(float);
+  } else {
+    // generic: <= 32 rows per stage, chunks balanced, multiple of 4
+    const int n_chunks = (Ci + kKC - 1) / kKC;
+    kc = (((Ci + n_chunks - 1) / n_chunks) + 3) & ~3;
+    n_stages = ((Ci + kc - 1) / kc) > 1 ? 2 : 1;
+    smem = (size_t)n_stages * stage_floats(MTW, kc, NS) * sizeof(float);
+  }
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: LDS stage too large (%zu B)", smem);
-  auto kern = pw_conv_kernel<MTW>;
+  auto kern = pipe ? pw_conv_kernel<MTW, true> : pw_conv_kernel<MTW, false>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_pw_conv_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
-                     MC, n_tiles, NS, act);
+                     MC, n_tiles, NS, kc, n_stages, act);
   return eat::check_launch("eat_pw_conv_fwd");
 }
 
@@ -307,13 +398,15 @@ extern "C" int eat_pw_conv_fwd(const float* x, const float* wp, const float* bia
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
   if (B < 1 || Ci < 4 || Co < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
   const int MT = (Co + 15) / 16;
+  // Row chunking.  Every block re-reads its 256-column x tile, and a CU takes in only ~10 B/clk, so
+  // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks
-  const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block, 1..8
+  const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block
   hipStream_t s = (hipStream_t)stream;
 #define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act);
   switch (mtw) {
-    EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4)
-    EAT_PW_CASE(5) EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
+    EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4) EAT_PW_CASE(5)
+    EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: internal tiling error");
   }
 #undef EAT_PW_CASE
