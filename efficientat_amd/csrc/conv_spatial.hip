@@ -44,67 +44,74 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 }
 
 // ----------------------------------------------------------------------------- depthwise
-// A block stages NC consecutive (b,c) planes x the input rows of TR output rows (+halo, zero
-// padded) in LDS; thread (tx, ty) owns plane ty % NC, output rows ty / NC + i*RS and columns
-// tx + j*TX, with its k*k filter taps in registers.  blockDim.x = TX * NC * RS = 256.
+// One thread = one output column of one (b,c) plane; it walks down the plane keeping the K input
+// rows under the filter in registers (a rotating ring, each step only loads the STRIDE new rows,
+// one step ahead of their use) with its K*K taps.  Lanes of a wave sit on consecutive columns, so every load / store
+// of a step is one coalesced row segment along the time axis; the horizontal overlap between
+// neighbouring lanes is served by L1.  No LDS, no barrier, ~70 VGPRs: 7-8 waves per SIMD keep
+// enough row segments in flight to stream from HBM.  The activated outputs of a plane are summed
+// on the fly for the squeeze of SqueezeExcitation.
 template <int K, int STRIDE, int ACT>
 __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ y, float* __restrict__ pool,
                                                       int n_planes, int C, int F, int T, int Fo, int To,
-                                                      int TX, int NC, int RS, int TR) {
-  extern __shared__ __attribute__((aligned(16))) float s_in[];
+                                                      int TX) {
   constexpr int P = (K - 1) / 2;
-  const int IR = (TR - 1) * STRIDE + K;      // staged input rows per plane
-  const int W = T + 2 * P;                   // staged row width (zero halo)
   const int tid = threadIdx.x;
   const int tx = tid % TX, ty = tid / TX;
-  const int plane0 = blockIdx.y * NC;
-  const int fo0 = blockIdx.x * TR;
-  const int fi0 = fo0 * STRIDE - P;
-
-  // stage: thread rows walk (plane, input row); lanes walk the time axis (coalesced)
-  const int row_groups = 256 / TX;
-  for (int rr = ty; rr < NC * IR; rr += row_groups) {
-    const int pl = rr / IR, ir = rr - pl * IR;
-    const int fi = fi0 + ir;
-    const int gp = plane0 + pl;
-    const bool row_ok = (gp < n_planes) && fi >= 0 && fi < F;
-    const float* src = x + ((size_t)gp * F + fi) * T;
-    float* dst = s_in + (size_t)rr * W;
-    for (int t = tx; t < W; t += TX) {
-      const int ti = t - P;
-      dst[t] = (row_ok && ti >= 0 && ti < T) ? src[ti] : 0.0f;
-    }
-  }
-  __syncthreads();
-
-  const int pl = ty % NC, rsub = ty / NC;
-  const int gp = plane0 + pl;
+  const int to = blockIdx.x * TX + tx;
+  const int gp = blockIdx.y * (256 / TX) + ty;
+  const bool live = gp < n_planes && to < To;
   float psum = 0.0f;
-  if (gp < n_planes) {
+  if (live) {
     const int c = gp % C;
     float wr[K * K];
 #pragma unroll
     for (int i = 0; i < K * K; ++i) wr[i] = w[c * K * K + i];
     const float bc = bias[c];
-    const float* sp = s_in + (size_t)pl * IR * W;
-    float* yp = y + (size_t)gp * Fo * To;
-    for (int r = rsub; r < TR; r += RS) {
-      const int fo = fo0 + r;
-      if (fo >= Fo) break;
-      const float* srow = sp + (size_t)(r * STRIDE) * W;
-      for (int to = tx; to < To; to += TX) {
-        const float* s0 = srow + to * STRIDE;
-        float acc = bc;
+    const float* xp = x + (size_t)gp * F * T;
+    float* yp = y + (size_t)gp * Fo * To + to;
+    const int t0 = to * STRIDE - P;
+    bool cok[K];
 #pragma unroll
-        for (int u = 0; u < K; ++u)
+    for (int v = 0; v < K; ++v) cok[v] = (t0 + v >= 0) && (t0 + v < T);
+
+    // Ring of K + STRIDE row slots: while step R multiplies the K rows in slots (u + R*STRIDE) % NSLOT,
+    // the STRIDE rows that step R+1 adds are already loading into the other STRIDE slots, so a wave
+    // always has the next row segment in flight (one dependent HBM round trip per step otherwise).
+    constexpr int NSLOT = K + STRIDE;
+    constexpr int PERIOD = (NSLOT % STRIDE == 0) ? NSLOT / STRIDE : NSLOT;   // steps until the ring realigns
+    float win[NSLOT][K];
+    auto load_row = [&](int fi, float (&dst)[K]) {
+      const bool rok = fi >= 0 && fi < F;              // uniform across the wave
+      const float* src = xp + (size_t)(rok ? fi : 0) * T + t0;
 #pragma unroll
-          for (int v = 0; v < K; ++v) acc = fmaf(wr[u * K + v], s0[u * W + v], acc);
-        const float o = eat::activate<ACT>(acc);
-        yp[(size_t)fo * To + to] = o;
-        psum += o;
+      for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? src[v] : 0.0f;
+    };
+#pragma unroll
+    for (int u = 0; u < K; ++u) load_row(u - P, win[u]);
+
+    for (int fo0 = 0; fo0 < Fo; fo0 += PERIOD) {
+#pragma unroll
+      for (int R = 0; R < PERIOD; ++R) {
+        const int fo = fo0 + R;
+        if (fo < Fo) {
+          if (fo + 1 < Fo) {
+#pragma unroll
+            for (int u = K - STRIDE; u < K; ++u)
+              load_row((fo + 1) * STRIDE - P + u, win[(u + (R + 1) * STRIDE) % NSLOT]);
+          }
+          float acc = bc;
+#pragma unroll
+          for (int u = 0; u < K; ++u)
+#pragma unroll
+            for (int v = 0; v < K; ++v) acc = fmaf(wr[u * K + v], win[(u + R * STRIDE) % NSLOT][v], acc);
+          const float o = eat::activate<ACT>(acc);
+          yp[(size_t)fo * To] = o;
+          psum += o;
+        }
       }
     }
   }
@@ -119,20 +126,13 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
 template <int K, int STRIDE>
 int launch_dw(const float* x, const float* w, const float* bias, float* y, float* pool, int B, int C,
               int F, int T, int Fo, int To, int act, hipStream_t stream) {
-  int TX = 32;
-  while (TX < To && TX < 256) TX <<= 1;
-  const int rest = 256 / TX;
-  int NC, RS, TR;
-  if (Fo <= 8) { NC = rest; RS = 1; TR = Fo; }
-  else { NC = 1; RS = rest; TR = 8 * RS; if (TR > 16) TR = 16; if (TR < 8) TR = 8; }
+  const int TX = To > 32 ? 64 : 32;
   const int n_planes = B * C;
-  auto smem_of = [&](int nc, int tr) { return (size_t)nc * ((tr - 1) * STRIDE + K) * (T + K - 1) * sizeof(float); };
-  while (smem_of(NC, TR) > 48 * 1024 && NC > 1) { NC >>= 1; RS <<= 1; }
-  while (smem_of(NC, TR) > 48 * 1024 && TR > 1) TR >>= 1;
-  if (smem_of(NC, TR) > 64 * 1024) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: row of %d floats too wide for LDS tile", T);
-  dim3 grid((Fo + TR - 1) / TR, (n_planes + NC - 1) / NC);
-  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT>), grid, dim3(256), smem_of(NC, TR),
-                                           stream, x, w, bias, y, pool, n_planes, C, F, T, Fo, To, TX, NC, RS, TR));
+  const int ppb = 256 / TX;
+  dim3 grid((To + TX - 1) / TX, (n_planes + ppb - 1) / ppb);
+  if (grid.y > 65535u * 32u) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: too many planes (%d)", n_planes);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT>), grid, dim3(256), 0, stream, x, w, bias,
+                                           y, pool, n_planes, C, F, T, Fo, To, TX));
   return eat::check_launch("eat_dw_conv_fwd");
 }
 
