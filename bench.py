@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12                      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3e12               # FLOP/s, dense fp32-input MFMA (= fp32 vector peak), same guide
 CLIP_SAMPLES = 320000                  # 10 s @ 32 kHz
 ALG_BYTES_PER_CLIP = 96.37e6           # mn10 fwd 94.50 MB + weights/B + mel 1.79 MB
 
@@ -50,32 +51,36 @@ def build_model(dev):
                 m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
             elif isinstance(m, torch.nn.Linear):
                 m.weight.normal_(0, (1.0 / m.weight.shape[1]) ** 0.5)
+        model.classifier[5].weight.mul_(0.05)      # keep |logits| O(1) so the parity probe reads like 1e-3 abs
     return mel, model.to(dev).eval()
 
 
 # ------------------------------------------------------------------ per-kernel event profile
 def _alg_bytes(name, a):
-    """Algorithmic HBM bytes of one launch (activations in + out once, weights once)."""
+    """(kernel symbol as rocprofv3 prints it, algorithmic HBM bytes, flops) of one launch:
+    activations in + out once, weights once (SURVEY.md 8d per-layer traffic model)."""
     if name == "eat_pw_conv_fwd":
         x, wp, bias, sc, res, y, pool, B, Ci, Co, S, act = a[:12]
         mt = (Co + 15) // 16
         chunks = (mt + 7) // 8
         mtw = (mt + chunks - 1) // chunks
+        ns = min(B, 256 // S + 2) if sc else 0
+        pipe = "true" if 16 * ns <= 64 else "false"
         nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + 4 * Co * Ci
-        return f"pw_conv_kernel<{mtw}>", nbytes
+        return f"pw_conv_kernel<{mtw},{pipe}>", nbytes, 2 * B * S * Ci * Co
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
-        return f"dw_conv_kernel<{k},{s}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k
+        return f"dw_conv_kernel<{k},{s},{act}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
     if name == "eat_stem_conv_fwd":
-        x, w, bias, y, B, C, F, T, Fo, To = a[:10]
-        return "stem_conv_kernel", 4 * B * (F * T + C * Fo * To)
+        x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
+        return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9
     if name == "eat_mel_fwd":
         B, L, n_mels, T = a[1], a[2], a[10], a[13]
-        return "mel_fwd_kernel", 4 * B * (L + n_mels * T)
+        return "mel_fwd_kernel", 4 * B * (L + n_mels * T), B * T * 60000
     if name == "eat_linear_fwd":
         x, w, bias, y, B, K, N = a[:7]
-        return "linear_kernel", 4 * (B * K + N * K + B * N)
-    return name, 0
+        return "linear_kernel", 4 * (B * K + N * K + B * N), 2 * B * K * N
+    return name, 0, 0
 
 
 def kernel_profile(step, iters=3):
@@ -101,17 +106,18 @@ def kernel_profile(step, iters=3):
     agg = {}
     if os.environ.get("EAT_BENCH_LAUNCHES"):      # debug: one line per launch of the last iteration
         for name, args, e0, e1 in rec[-(len(rec) // iters):]:
-            sym, nbytes = _alg_bytes(name, args)
+            sym, nbytes, _ = _alg_bytes(name, args)
             us = e0.elapsed_time(e1) * 1e3
             ints = [a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < 10 ** 7]
             print(f"[launch] {sym:24s} {us:9.1f} us {nbytes / us / 1e3:8.1f} GB/s  {ints}", file=sys.stderr)
     for name, args, e0, e1 in rec:
-        sym, nbytes = _alg_bytes(name, args)
-        d = agg.setdefault(sym, [0, 0.0, 0])
+        sym, nbytes, flops = _alg_bytes(name, args)
+        d = agg.setdefault(sym, [0, 0.0, 0, 0])
         d[0] += 1
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += nbytes
-    return {k: dict(launches=v[0] // iters, total_ms=v[1] / iters * 1e3, bytes=v[2] / iters,
+        d[3] += flops
+    return {k: dict(launches=v[0] // iters, total_ms=v[1] / iters * 1e3, bytes=v[2] / iters, flops=v[3] / iters,
                     gbps=(v[2] / v[1] / 1e9) if v[1] > 0 else 0.0) for k, v in agg.items()}
 
 
@@ -245,13 +251,30 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         name, d = dom
         per_launch_bytes = d["bytes"] / d["launches"]
+        per_launch_flops = d["flops"] / d["launches"]
         per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
-        result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(per_launch_bytes / per_launch_s / 1e9, 1),
-                              "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                              "frac": round(per_launch_bytes / per_launch_s / HBM_PEAK, 4), "traffic": None,
-                              "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
-                              "alg_bytes_per_launch": int(per_launch_bytes),
-                              "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r1.json")
+        if os.path.exists(tpath):
+            k = json.load(open(tpath))["kernels"].get(name.replace(" ", ""))
+            traffic = k["hbm_bytes_per_launch"] if k else None
+        # which roof binds this kernel: the larger of its HBM time and its fp32-MFMA time
+        mfma_bound = per_launch_flops / MFMA_F32_PEAK > per_launch_bytes / HBM_PEAK
+        common = {"kernel": name, "traffic": traffic, "launches_per_step": d["launches"],
+                  "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_bytes_per_launch": int(per_launch_bytes),
+                  "alg_flops_per_launch": int(per_launch_flops),
+                  "hbm_gbps": round(per_launch_bytes / per_launch_s / 1e9, 1),
+                  "mfma_tflops": round(per_launch_flops / per_launch_s / 1e12, 2),
+                  "traffic_source": "profiles/pmc_traffic_r1.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                  "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
+        if mfma_bound:
+            ach = per_launch_flops / per_launch_s
+            result["roofline"] = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12,
+                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), **common}
+        else:
+            ach = per_launch_bytes / per_launch_s
+            result["roofline"] = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), **common}
         if args.kernel_table:
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
                 print(f"[bench] {k:28s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "

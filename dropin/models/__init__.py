@@ -1,0 +1,1 @@
+"""Alias package: see dropin/README.md."""
