@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libeat_hip.so")
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_D = ctypes.c_double
 
 # name -> argtypes (restype is always int unless noted); must mirror include/eat_hip.h
 SIGNATURES = {
@@ -26,6 +27,15 @@ SIGNATURES = {
     "eat_pw_prepack": [_P, _P, _P, _I, _I, _P],
     "eat_pw_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "eat_bn_stats": [_P, _I, _I, _I, _P, _P],
+    "eat_bn_finalize": [_P, _P, _P, _P, _P, _F, _F, _D, _I, _P, _P, _P, _P, _P],
+    "eat_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_bn_act_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "eat_bn_act_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_plane_dot": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_dw_conv_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_dw_conv_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_pw_conv_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 
 _lib = None

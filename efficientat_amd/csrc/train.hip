@@ -1,0 +1,481 @@
+// Training-step kernels for gfx950: batch-statistics BatchNorm (forward and backward, with the
+// activation folded in), squeeze-excitation reductions, and the weight/data gradients of the
+// depthwise and pointwise convolutions.
+//   reference semantics: nn.BatchNorm2d(eps=1e-3, momentum=0.01) in train mode
+//   (models/mn/model.py:114-115), nn.Hardswish / nn.ReLU, autograd of F.conv2d
+//   (SURVEY.md Appendix C lists the formulas the reference leaves to autograd).
+// Round-1 structure: every pass is its own streaming kernel over (B, C, S) planes (one workgroup
+// per plane, float4 along the time axis, wave-shuffle + LDS block reduction, per-channel totals
+// accumulated in fp64 atomics so that sums over up to 8M elements do not lose precision).
+#include "eat_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int ACT>
+__device__ __forceinline__ float act_grad(float u) {   // d act(u) / du  (PyTorch conventions)
+  if constexpr (ACT == EAT_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
+  if constexpr (ACT == EAT_ACT_HSWISH) return u < -3.0f ? 0.0f : (u <= 3.0f ? u * (1.0f / 3.0f) + 0.5f : 1.0f);
+  return 1.0f;
+}
+
+// block-wide sum of two values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* s_red) {
+  a = eat::wave_sum(a);
+  b = eat::wave_sum(b);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { s_red[wv] = a; s_red[8 + wv] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < nw; ++i) { ta += s_red[i]; tb += s_red[8 + i]; }
+    a = ta; b = tb;
+  }
+}
+
+// ---- per-channel sum / sum of squares of z (B,C,S) -----------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int C, int S,
+                                                       double* __restrict__ sums) {
+  __shared__ float s_red[16];
+  const int plane = blockIdx.x, c = plane % C;
+  const float* p = z + (size_t)plane * S;
+  float s1 = 0.f, s2 = 0.f;
+  if ((S & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) { const float v = p[i]; s1 += v; s2 += v * v; }
+  }
+  block_sum2(s1, s2, s_red);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, (double)s1);
+    atomicAdd(sums + C + c, (double)s2);
+  }
+}
+
+// ---- finalize: batch mean / biased var -> affine (a, b), saved (mean, invstd), running buffers --
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, double n, int C,
+                                   float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean,
+                                   float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[c] / n;
+  double var = sums[C + c] / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[c] * is;
+  a[c] = av;
+  b[c] = beta[c] - (float)mu * av;
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ---- y = act(a_c z + b_c) [+ res]; optional per-(b,c) sums of y (SE squeeze / head pool) ----------
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                         const float* __restrict__ b, const float* __restrict__ res,
+                                                         float* __restrict__ y, float* __restrict__ pool, int C, int S) {
+  __shared__ float s_red[16];
+  const int plane = blockIdx.x, c = plane % C;
+  const float av = a[c], bv = b[c];
+  const size_t base = (size_t)plane * S;
+  float ps = 0.f, dummy = 0.f;
+  if ((S & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      float4 o = make_float4(eat::activate<ACT>(fmaf(av, v.x, bv)), eat::activate<ACT>(fmaf(av, v.y, bv)),
+                             eat::activate<ACT>(fmaf(av, v.z, bv)), eat::activate<ACT>(fmaf(av, v.w, bv)));
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      if (y) *reinterpret_cast<float4*>(y + base + i) = o;
+      ps += (o.x + o.y) + (o.z + o.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+      float o = eat::activate<ACT>(fmaf(av, z[base + i], bv));
+      if (res) o += res[base + i];
+      if (y) y[base + i] = o;
+      ps += o;
+    }
+  }
+  if (pool) {
+    block_sum2(ps, dummy, s_red);
+    if (threadIdx.x == 0) pool[plane] = ps;       // one block per plane: plain store, no atomics
+  }
+}
+
+// g = (dy * gscale[b,c] + gadd[b,c]) * act'(a z + b);  xhat = (z - mean) * invstd
+template <int ACT>
+__device__ __forceinline__ float grad_pre(float dy, float zv, float av, float bv, float gs, float ga) {
+  return fmaf(dy, gs, ga) * act_grad<ACT>(fmaf(av, zv, bv));
+}
+
+// ---- backward pass 1: per-channel sum g and sum g*xhat -------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ a,
+    const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gscale, const float* __restrict__ gadd, int C, int S, double* __restrict__ sums) {
+  __shared__ float s_red[16];
+  const int plane = blockIdx.x, c = plane % C;
+  const float av = a[c], bv = b[c], mu = mean[c], is = invstd[c];
+  const float gs = gscale ? gscale[plane] : 1.0f, ga = gadd ? gadd[plane] : 0.0f;
+  const size_t base = (size_t)plane * S;
+  float s1 = 0.f, s2 = 0.f;
+  if ((S & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      const float g0 = grad_pre<ACT>(d.x, v.x, av, bv, gs, ga), g1 = grad_pre<ACT>(d.y, v.y, av, bv, gs, ga);
+      const float g2 = grad_pre<ACT>(d.z, v.z, av, bv, gs, ga), g3 = grad_pre<ACT>(d.w, v.w, av, bv, gs, ga);
+      s1 += (g0 + g1) + (g2 + g3);
+      s2 += (g0 * (v.x - mu) + g1 * (v.y - mu)) + (g2 * (v.z - mu) + g3 * (v.w - mu));
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+      const float g = grad_pre<ACT>(dy[base + i], z[base + i], av, bv, gs, ga);
+      s1 += g;
+      s2 += g * (z[base + i] - mu);
+    }
+  }
+  s2 *= is;
+  block_sum2(s1, s2, s_red);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, (double)s1);
+    atomicAdd(sums + C + c, (double)s2);
+  }
+}
+
+// ---- backward pass 2: dz = a * (g - sum_g/N - xhat * sum_gx/N) ----------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ a,
+    const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gscale, const float* __restrict__ gadd, const double* __restrict__ sums,
+    float* __restrict__ dz, int C, int S, double n) {
+  const int plane = blockIdx.x, c = plane % C;
+  const float av = a[c], bv = b[c], mu = mean[c], is = invstd[c];
+  const float m1 = (float)(sums[c] / n), m2 = (float)(sums[C + c] / n);
+  const float gs = gscale ? gscale[plane] : 1.0f, ga = gadd ? gadd[plane] : 0.0f;
+  const size_t base = (size_t)plane * S;
+  auto f = [&](float d, float v) {
+    const float g = grad_pre<ACT>(d, v, av, bv, gs, ga);
+    return av * (g - m1 - (v - mu) * is * m2);
+  };
+  if ((S & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      *reinterpret_cast<float4*>(dz + base + i) = make_float4(f(d.x, v.x), f(d.y, v.y), f(d.z, v.z), f(d.w, v.w));
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) dz[base + i] = f(dy[base + i], z[base + i]);
+  }
+}
+
+// ---- out[b,c] = sum_s u[b,c,s] * v'[b,c,s], v' = v or act(a_c v + b_c) (SE: d scale) ---------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                        const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ out, int C, int S) {
+  __shared__ float s_red[16];
+  const int plane = blockIdx.x, c = plane % C;
+  const float av = a ? a[c] : 1.0f, bv = b ? b[c] : 0.0f;
+  const size_t base = (size_t)plane * S;
+  float s1 = 0.f, dummy = 0.f;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    float t = v[base + i];
+    if (a) t = eat::activate<ACT>(fmaf(av, t, bv));
+    s1 += u[base + i] * t;
+  }
+  block_sum2(s1, dummy, s_red);
+  if (threadIdx.x == 0) out[plane] = s1;
+}
+
+// ---- depthwise data gradient: dx[c,i,j] = sum_{u,v} w[c,u,v] dz[c,(i+p-u)/s,(j+p-v)/s] (+ res) ----------
+template <int K, int STRIDE>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                       const float* __restrict__ res, float* __restrict__ dx,
+                                                       int C, int F, int T, int Fo, int To) {
+  constexpr int P = (K - 1) / 2;
+  const int plane = blockIdx.y, c = plane % C;
+  float wr[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) wr[i] = w[c * K * K + i];
+  const float* g = dz + (size_t)plane * Fo * To;
+  const size_t base = (size_t)plane * F * T;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * T; e += gridDim.x * blockDim.x) {
+    const int i = e / T, j = e - i * T;
+    float acc = res ? res[base + e] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const int ii = i + P - u;
+      if (ii < 0 || (ii % STRIDE) != 0) continue;
+      const int io = ii / STRIDE;
+      if (io >= Fo) continue;
+#pragma unroll
+      for (int v = 0; v < K; ++v) {
+        const int jj = j + P - v;
+        if (jj < 0 || (jj % STRIDE) != 0) continue;
+        const int jo = jj / STRIDE;
+        if (jo < To) acc = fmaf(wr[u * K + v], g[(size_t)io * To + jo], acc);
+      }
+    }
+    dx[base + e] = acc;
+  }
+}
+
+// ---- depthwise / stem weight gradient: dw[c,u,v] = sum_{b,i,j} dz[b,c,i,j] x[b,cx,i*s+u-p,j*s+v-p] -------
+// One block per (channel, batch slice); x has XC channels (XC == C depthwise, XC == 1 stem).
+template <int K, int STRIDE>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                       float* __restrict__ dw, int B, int C, int XC, int F, int T,
+                                                       int Fo, int To, int b_per_block) {
+  constexpr int P = (K - 1) / 2;
+  __shared__ float s_red[4][K * K];
+  const int c = blockIdx.x, b0 = blockIdx.y * b_per_block;
+  const int b1 = (b0 + b_per_block) < B ? (b0 + b_per_block) : B;
+  float acc[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+  const int plane_o = Fo * To;
+  for (int bb = b0; bb < b1; ++bb) {
+    const float* g = dz + ((size_t)bb * C + c) * plane_o;
+    const float* xp = x + ((size_t)bb * XC + (XC == 1 ? 0 : c)) * F * T;
+    for (int e = threadIdx.x; e < plane_o; e += blockDim.x) {
+      const int i = e / To, j = e - i * To;
+      const float gv = g[e];
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        const int fi = i * STRIDE + u - P;
+        const bool rok = fi >= 0 && fi < F;
+#pragma unroll
+        for (int v = 0; v < K; ++v) {
+          const int ti = j * STRIDE + v - P;
+          const float xv = (rok && ti >= 0 && ti < T) ? xp[(size_t)fi * T + ti] : 0.0f;
+          acc[u * K + v] = fmaf(gv, xv, acc[u * K + v]);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) {
+    const float t = eat::wave_sum(acc[i]);
+    if (lane == 0) s_red[wv][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < K * K)
+    atomicAdd(dw + c * K * K + threadIdx.x,
+              s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// ---- pointwise weight gradient: dW[co,ci] = sum_{b,s} dz[b,co,s] x[b,ci,s] --------------------------------------
+// Both operands are contiguous along the reduction axis s: each lane loads 4 consecutive s as one
+// float4 and feeds them to 4 MFMAs (consistent k permutation).  Block = 4 waves on one 32 x 32
+// tile of dW, each wave reducing its own slice of the (b, s) range; partials combined in LDS and
+// added to dW with one atomic per element per block.
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                       const float* __restrict__ xscale, float* __restrict__ dW,
+                                                       int B, int Co, int Ci, int S, int b_per_block) {
+  __shared__ float s_red[3][4][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int b0 = blockIdx.z * b_per_block;
+  const int b1 = (b0 + b_per_block) < B ? (b0 + b_per_block) : B;
+  const int row = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool vec = (S & 3) == 0;
+  auto load4 = [&](const float* base, int r, int rmax, size_t rs, int s, float (&o)[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.f;
+    if (r >= rmax || s >= S) return;
+    const float* p = base + (size_t)r * rs + s;
+    if (vec) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (s + e < S) o[e] = p[e];
+    }
+  };
+  for (int bb = b0; bb < b1; ++bb) {
+    const float* gz = dz + (size_t)bb * Co * S;
+    const float* gx = x + (size_t)bb * Ci * S;
+    // the conv input may be x * xscale[b, ci] (squeeze-excitation): fold the scale into the B operand
+    const float sc0 = (xscale && n0 + row < Ci) ? xscale[(size_t)bb * Ci + n0 + row] : 1.0f;
+    const float sc1 = (xscale && n0 + 16 + row < Ci) ? xscale[(size_t)bb * Ci + n0 + 16 + row] : 1.0f;
+    for (int s0 = wv * 64; s0 < S; s0 += 256) {              // wave w takes s-blocks w, w+4, ...
+      float ga[4][2][4], xb[4][2][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + 16 * u + 4 * kq;
+        load4(gz, m0 + row, Co, S, s, ga[u][0]);
+        load4(gz, m0 + 16 + row, Co, S, s, ga[u][1]);
+        load4(gx, n0 + row, Ci, S, s, xb[u][0]);
+        load4(gx, n0 + 16 + row, Ci, S, s, xb[u][1]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u][i][e], xb[u][j][e] * (j ? sc1 : sc0), acc[i][j], 0, 0, 0);
+    }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[wv - 1][i * 2 + j][r][lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (wv != 0) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * i + kq * 4 + r, n = n0 + 16 * j + row;   // C/D: col = lane&15, row = kq*4+r
+        if (m < Co && n < Ci) {
+          const int q = i * 2 + j;
+          atomicAdd(dW + (size_t)m * Ci + n,
+                    acc[i][j][r] + s_red[0][q][r][lane] + s_red[1][q][r][lane] + s_red[2][q][r][lane]);
+        }
+      }
+}
+
+}  // namespace
+
+#define EAT_PLANES_GRID(B, C) dim3((unsigned)((B) * (C)))
+
+extern "C" int eat_bn_stats(const float* z, int B, int C, int S, double* sums, eat_stream_t stream) {
+  eat::clear_stale_error();
+  hipLaunchKernelGGL(bn_stats_kernel, EAT_PLANES_GRID(B, C), dim3(S >= 1024 ? 256 : 64), 0, (hipStream_t)stream, z, C, S,
+                     sums);
+  return eat::check_launch("eat_bn_stats");
+}
+
+extern "C" int eat_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, double n, int C, float* a, float* b,
+                               float* mean, float* invstd, eat_stream_t stream) {
+  eat::clear_stale_error();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, gamma, beta,
+                     running_mean, running_var, momentum, eps, n, C, a, b, mean, invstd);
+  return eat::check_launch("eat_bn_finalize");
+}
+
+extern "C" int eat_bn_act_fwd(const float* z, const float* a, const float* b, const float* res, float* y,
+                              float* pool, int B, int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd: bad act %d", act);
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<ACT>), EAT_PLANES_GRID(B, C), blk, 0, (hipStream_t)stream, z,
+                                           a, b, res, y, pool, C, S));
+  return eat::check_launch("eat_bn_act_fwd");
+}
+
+extern "C" int eat_bn_act_bwd_reduce(const float* dy, const float* z, const float* a, const float* b,
+                                     const float* mean, const float* invstd, const float* gscale, const float* gadd,
+                                     int B, int C, int S, int act, double* sums, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_reduce: bad act %d", act);
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT>), EAT_PLANES_GRID(B, C), blk, 0,
+                                           (hipStream_t)stream, dy, z, a, b, mean, invstd, gscale, gadd, C, S, sums));
+  return eat::check_launch("eat_bn_act_bwd_reduce");
+}
+
+extern "C" int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const float* b,
+                                    const float* mean, const float* invstd, const float* gscale, const float* gadd,
+                                    const double* sums, float* dz, int B, int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_apply: bad act %d", act);
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  const double n = (double)B * S;
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT>), EAT_PLANES_GRID(B, C), blk, 0,
+                                           (hipStream_t)stream, dy, z, a, b, mean, invstd, gscale, gadd, sums, dz, C, S, n));
+  return eat::check_launch("eat_bn_act_bwd_apply");
+}
+
+extern "C" int eat_plane_dot(const float* u, const float* v, const float* a, const float* b, float* out, int B,
+                             int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_plane_dot: bad act %d", act);
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((plane_dot_kernel<ACT>), EAT_PLANES_GRID(B, C), blk, 0, (hipStream_t)stream, u,
+                                           v, a, b, out, C, S));
+  return eat::check_launch("eat_plane_dot");
+}
+
+extern "C" int eat_dw_conv_dgrad(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F,
+                                 int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  int gx = (F * T + 255) / 256;
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, B * C);
+  hipStream_t s = (hipStream_t)stream;
+#define EAT_DG(KK, SS) hipLaunchKernelGGL((dw_dgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, w, res, dx, C, F, T, Fo, To)
+  if (k == 3 && stride == 1) EAT_DG(3, 1);
+  else if (k == 3 && stride == 2) EAT_DG(3, 2);
+  else if (k == 5 && stride == 1) EAT_DG(5, 1);
+  else if (k == 5 && stride == 2) EAT_DG(5, 2);
+  else return eat::fail(EAT_EINVAL, "eat_dw_conv_dgrad: unsupported k=%d stride=%d", k, stride);
+#undef EAT_DG
+  return eat::check_launch("eat_dw_conv_dgrad");
+}
+
+extern "C" int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T,
+                                 int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
+  // enough blocks to fill the chip: split the batch when there are few channels
+  int splits = (2048 + C - 1) / C;
+  if (splits > B) splits = B;
+  const int bpb = (B + splits - 1) / splits;
+  dim3 grid(C, (B + bpb - 1) / bpb);
+  hipStream_t s = (hipStream_t)stream;
+#define EAT_WG(KK, SS) hipLaunchKernelGGL((dw_wgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, x, dw, B, C, XC, F, T, Fo, To, bpb)
+  if (k == 3 && stride == 1) EAT_WG(3, 1);
+  else if (k == 3 && stride == 2) EAT_WG(3, 2);
+  else if (k == 5 && stride == 1) EAT_WG(5, 1);
+  else if (k == 5 && stride == 2) EAT_WG(5, 2);
+  else return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: unsupported k=%d stride=%d", k, stride);
+#undef EAT_WG
+  return eat::check_launch("eat_dw_conv_wgrad");
+}
+
+extern "C" int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
+                                 int Ci, int S, eat_stream_t stream) {
+  eat::clear_stale_error();
+  const int tiles = ((Co + 31) / 32) * ((Ci + 31) / 32);
+  int splits = (1024 + tiles - 1) / tiles;
+  if (splits > B) splits = B;
+  const int bpb = (B + splits - 1) / splits;
+  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, (B + bpb - 1) / bpb);
+  hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, bpb);
+  return eat::check_launch("eat_pw_conv_wgrad");
+}

@@ -228,10 +228,13 @@ class MN(nn.Module):
 
     # --------------------------------------------------------------------------- forward
     def _forward_impl(self, x, return_fmaps: bool = False):
-        if self.training:
-            raise NotImplementedError("train-mode forward/backward kernels are not wired up yet")
         if not x.is_cuda:
             raise ops._lib.EatHipError("MN.forward needs a GPU tensor: efficientat_amd has no CPU path")
+        if self.training:
+            if return_fmaps:
+                raise NotImplementedError("return_fmaps is only available in eval mode on the HIP path")
+            from .mn_train import forward_train
+            return forward_train(self, x)
         W = self._cache.get(self._fold_sources(), self._build_folded)
         x = x.contiguous().float()
         B = x.shape[0]

@@ -1,0 +1,265 @@
+"""Train-mode forward / backward of the MN trunk on the HIP kernels.
+
+The reference trains through autograd over ~210 per-op launches (`ex_audioset.py:147-199`,
+`models/mn/model.py:212-231`).  Here ONE `torch.autograd.Function` owns the whole network: its
+forward runs the train-mode launch plan (raw conv -> batch statistics -> fused BN-affine +
+activation), its backward the hand-derived reverse plan and returns the
+gradient of every parameter, so `loss.backward(); optimizer.step()` in the caller are unchanged.
+
+Round-1 structure: each pass is a separate streaming kernel (stats, apply, reduce, ...); the
+fusions (producer-epilogue statistics, consumer-prologue normalisation) come next.
+Tiny (B, C)-shaped glue of the SE gate and the head (ReLU/sigmoid/hardswish derivatives, bias
+sums, transposes) uses torch elementwise ops; every GEMM / conv / reduction over activations runs
+in libeat_hip.so.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .dp import GradReducer
+
+NONE, RELU, HSWISH, SIGMOID = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_HSWISH, ops.ACT_SIGMOID
+
+
+def _t(x):
+    return x.t().contiguous()
+
+
+def _mm_nt(x, w):
+    """x (M,K) @ w (N,K)^T on the MFMA linear kernel."""
+    return ops.linear(x, w, None, NONE)
+
+
+class _Zeros:
+    """Cached zero bias (the conv entry points take a bias pointer; train-mode convs have none)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, n, device):
+        if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            self.buf = torch.zeros((max(n, 4096),), device=device, dtype=torch.float32)
+        return self.buf[:n]
+
+
+_zeros = _Zeros()
+
+
+class _GradSink:
+    """`sink[name] = grad` forwards to GradReducer.push; `finish()` returns the (averaged) gradients."""
+
+    def __init__(self, reducer):
+        self.reducer = reducer
+
+    def __setitem__(self, name, grad):
+        self.reducer.push(name, grad)
+
+    def finish(self):
+        return self.reducer.finish()
+
+
+def _conv_bn_stats(z, bn):
+    B, C = z.shape[0], z.shape[1]
+    n = z.numel() // C
+    a, b, mean, invstd = ops.bn_finalize(ops.bn_stats(z), bn, n)
+    bn.num_batches_tracked += 1
+    return a, b, mean, invstd
+
+
+class MNTrainFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, drop_mask, *params):
+        keep = torch.is_grad_enabled() or any(p.requires_grad for p in params)
+        dev = x.device
+        x = x.contiguous().float()
+        B = x.shape[0]
+        saved = {}
+        blocks = list(model.features[1:-1])
+
+        # stem
+        stem = model.features[0]
+        C0 = stem[0].out_channels
+        z0 = ops.stem_conv(x, stem[0].weight.reshape(C0, 9), _zeros.get(C0, dev), NONE)
+        st0 = _conv_bn_stats(z0, stem[1])
+        cur = ops.bn_act_fwd(z0, st0[0], st0[1], HSWISH)
+        saved["stem"] = (x, z0, st0)
+
+        blk_saved = []
+        for blk in blocks:
+            cnf = blk.cnf
+            act = HSWISH if cnf.use_hs else RELU
+            inp = cur
+            rec = {"inp": inp}
+            if blk.i_expand is not None:
+                cna = blk.block[blk.i_expand]
+                wp = ops.pw_prepack(cna[0].weight.flatten(1))
+                z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+                st_e = _conv_bn_stats(z_e, cna[1])
+                y_e = ops.bn_act_fwd(z_e, st_e[0], st_e[1], act)
+                rec.update(z_e=z_e, st_e=st_e)
+            else:
+                y_e = inp
+            cna = blk.block[blk.i_dw]
+            k = cnf.kernel
+            z_d = ops.dw_conv(y_e, cna[0].weight.reshape(-1, k * k), _zeros.get(cnf.expanded_channels, dev), k,
+                              cnf.stride, NONE)
+            st_d = _conv_bn_stats(z_d, cna[1])
+            S_d = z_d.shape[2] * z_d.shape[3]
+            pool = torch.empty((B, cnf.expanded_channels), device=dev) if blk.i_se is not None else None
+            y_d = ops.bn_act_fwd(z_d, st_d[0], st_d[1], act, pool=pool)
+            rec.update(y_e=y_e, z_d=z_d, st_d=st_d, y_d=y_d)
+            scale = None
+            if blk.i_se is not None:
+                se = blk.block[blk.i_se].conc_se_layers[0]
+                h = ops.linear(pool, se.fc1.weight, se.fc1.bias, RELU, 1.0 / S_d)
+                scale = ops.linear(h, se.fc2.weight, se.fc2.bias, SIGMOID)
+                rec.update(pool=pool, h=h, scale=scale, S_d=S_d)
+            cna = blk.block[blk.i_proj]
+            wp = ops.pw_prepack(cna[0].weight.flatten(1))
+            z_p = ops.pw_conv(y_d, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, in_scale=scale)
+            st_p = _conv_bn_stats(z_p, cna[1])
+            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None)
+            rec.update(z_p=z_p, st_p=st_p)
+            blk_saved.append(rec)
+
+        last = model.features[-1]
+        c_feat = last.out_channels
+        wp = ops.pw_prepack(last[0].weight.flatten(1))
+        z_l = ops.pw_conv(cur, wp, _zeros.get(c_feat, dev), c_feat, NONE)
+        st_l = _conv_bn_stats(z_l, last[1])
+        pooled = torch.empty((B, c_feat), device=dev)
+        ops.bn_act_fwd(z_l, st_l[0], st_l[1], HSWISH, pool=pooled, write=False)
+        S_l = z_l.shape[2] * z_l.shape[3]
+        feat = pooled * (1.0 / S_l)
+        fc1, fc2 = model.classifier[2], model.classifier[5]
+        u = ops.linear(feat, fc1.weight, fc1.bias, NONE)
+        h2 = F.hardswish(u)
+        if drop_mask is not None:
+            h2 = h2 * drop_mask
+        logits = ops.linear(h2, fc2.weight, fc2.bias, NONE)
+        if keep:
+            saved.update(blocks=blk_saved, last=(cur, z_l, st_l, S_l), head=(feat, u, h2, drop_mask))
+            ctx.saved, ctx.model = saved, model
+            ctx.names = [n for n, _ in model.named_parameters()]
+        return logits, feat
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeat):
+        model, sv = ctx.model, ctx.saved
+        ctx.saved = None
+        # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
+        # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
+        g = _GradSink(getattr(model, "_grad_reducer", None) or GradReducer())
+        dev = dlogits.device
+        dlogits = dlogits.contiguous().float()
+        B = dlogits.shape[0]
+        blocks = list(model.features[1:-1])
+        nb = len(blocks)
+
+        # ---- head (mn/model.py:186-194)
+        feat, u, h2, drop_mask = sv["head"]
+        fc1, fc2 = model.classifier[2], model.classifier[5]
+        g["classifier.5.weight"] = _mm_nt(_t(dlogits), _t(h2))
+        g["classifier.5.bias"] = dlogits.sum(0)
+        dh2 = _mm_nt(dlogits, _t(fc2.weight))
+        if drop_mask is not None:
+            dh2 = dh2 * drop_mask
+        du = dh2 * torch.where(u < -3, torch.zeros_like(u), torch.where(u <= 3, u / 3 + 0.5, torch.ones_like(u)))
+        g["classifier.2.weight"] = _mm_nt(_t(du), _t(feat))
+        g["classifier.2.bias"] = du.sum(0)
+        dft = _mm_nt(du, _t(fc1.weight))
+        if dfeat is not None:
+            dft = dft + dfeat
+
+        # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
+        x_l, z_l, st_l, S_l = sv["last"]
+        last = model.features[-1]
+        zeros_bc = torch.zeros((B, z_l.shape[1]), device=dev)
+        dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l))
+        nm = f"features.{nb + 1}"
+        g[nm + ".1.weight"], g[nm + ".1.bias"] = dgam, dbet
+        g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
+        wpt = ops.pw_prepack(_t(last[0].weight.flatten(1)))
+        dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
+        del dz, z_l
+
+        # ---- inverted residual blocks, last to first (mn/block_types.py:177-181)
+        for i in range(nb - 1, -1, -1):
+            blk, rec = blocks[i], sv["blocks"][i]
+            cnf = blk.cnf
+            act = HSWISH if cnf.use_hs else RELU
+            pre = f"features.{i + 1}.block"
+            inp = rec["inp"]
+            res_grad = dout if blk.use_res_connect else None
+            # project conv + BN (no activation); the residual branch passes dout through unchanged
+            cna = blk.block[blk.i_proj]
+            dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE)
+            g[f"{pre}.{blk.i_proj}.1.weight"], g[f"{pre}.{blk.i_proj}.1.bias"] = dgam, dbet
+            scale = rec.get("scale")
+            g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale).view_as(cna[0].weight)
+            wpt = ops.pw_prepack(_t(cna[0].weight.flatten(1)))
+            dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+            del dz_p
+            gscale = gadd = None
+            if scale is not None:     # squeeze-excitation gate (mn/block_types.py:72-83)
+                se = blk.block[blk.i_se].conc_se_layers[0]
+                sp = f"{pre}.{blk.i_se}.conc_se_layers.0"
+                h, pool, S_d = rec["h"], rec["pool"], rec["S_d"]
+                ds = ops.plane_dot(dxs, rec["y_d"])
+                dq = ds * scale * (1.0 - scale)
+                g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
+                g[sp + ".fc2.bias"] = dq.sum(0)
+                dh = _mm_nt(dq, _t(se.fc2.weight)) * (h > 0).float()
+                zmean = pool * (1.0 / S_d)
+                g[sp + ".fc1.weight"] = _mm_nt(_t(dh), _t(zmean))
+                g[sp + ".fc1.bias"] = dh.sum(0)
+                gadd = _mm_nt(dh, _t(se.fc1.weight)) * (1.0 / S_d)
+                gscale = scale
+            # depthwise conv + BN + act
+            cna = blk.block[blk.i_dw]
+            k = cnf.kernel
+            dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd)
+            del dxs
+            g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
+            y_e = rec["y_e"]
+            g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
+            no_expand = blk.i_expand is None
+            dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), tuple(y_e.shape), k, cnf.stride,
+                                     res=res_grad if no_expand else None)
+            del dz_d
+            if no_expand:
+                dout = dy_e
+            else:
+                cna = blk.block[blk.i_expand]
+                dz_e, dgam, dbet = ops.bn_act_bwd(dy_e, rec["z_e"], *rec["st_e"], act)
+                del dy_e
+                g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
+                g[f"{pre}.{blk.i_expand}.0.weight"] = ops.pw_conv_wgrad(dz_e, inp).view_as(cna[0].weight)
+                wpt = ops.pw_prepack(_t(cna[0].weight.flatten(1)))
+                dout = ops.pw_conv(dz_e, wpt, _zeros.get(cnf.input_channels, dev), cnf.input_channels, NONE,
+                                   res=res_grad)
+                del dz_e
+            sv["blocks"][i] = None
+
+        # ---- stem
+        x, z0, st0 = sv["stem"]
+        stem = model.features[0]
+        dz0, dgam, dbet = ops.bn_act_bwd(dout, z0, *st0, HSWISH)
+        g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
+        g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
+        grads = g.finish()
+        return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+def forward_train(model, x):
+    """Train-mode `(logits, features)` with autograd support (mn/model.py:212-231 in `.train()`)."""
+    drop = model.classifier[4]
+    mask = None
+    if drop.p > 0:
+        n_hidden = model.classifier[2].out_features
+        mask = torch.empty((x.shape[0], n_hidden), device=x.device).bernoulli_(1.0 - drop.p) / (1.0 - drop.p)
+    override = getattr(model, "_drop_mask_override", None)       # tests replay the reference's mask
+    if override is not None:
+        mask = override.to(x.device).float() / (1.0 - drop.p)
+    params = [p for _, p in model.named_parameters()]
+    return MNTrainFunction.apply(model, x, mask, *params)

@@ -83,3 +83,83 @@ def linear(x, w, bias, act, x_scale=1.0):
     _lib.call("eat_linear_fwd", _dev(x, "x"), _dev(w, "w"), _opt(bias, "bias"), y.data_ptr(), B, K, N,
               float(x_scale), act, _stream())
     return y
+
+
+# ------------------------------------------------------------------ training-step launchers
+def bn_stats(z):
+    B, C = z.shape[0], z.shape[1]
+    S = z.numel() // (B * C)
+    sums = torch.zeros((2 * C,), device=z.device, dtype=torch.float64)
+    _lib.call("eat_bn_stats", _dev(z, "z"), B, C, S, sums.data_ptr(), _stream())
+    return sums
+
+
+def bn_finalize(sums, bn, n):
+    """-> (a, b, mean, invstd); updates bn.running_mean / running_var in place (momentum rule)."""
+    C = bn.num_features
+    out = torch.empty((4, C), device=sums.device, dtype=torch.float32)
+    mom = bn.momentum if bn.momentum is not None else 0.0
+    _lib.call("eat_bn_finalize", sums.data_ptr(), _dev(bn.weight, "gamma"), _dev(bn.bias, "beta"),
+              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps), float(n), C,
+              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True):
+    B, C = z.shape[0], z.shape[1]
+    S = z.numel() // (B * C)
+    y = torch.empty_like(z) if write else None
+    _lib.call("eat_bn_act_fwd", _dev(z, "z"), a.data_ptr(), b.data_ptr(), _opt(res, "res"),
+              None if y is None else y.data_ptr(), _opt(pool, "pool"), B, C, S, act, _stream())
+    return y
+
+
+def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None):
+    """-> (dz, dgamma, dbeta) for y = act(BN_batch(z)); incoming grad = dy*gscale[b,c] + gadd[b,c]."""
+    B, C = z.shape[0], z.shape[1]
+    S = z.numel() // (B * C)
+    sums = torch.zeros((2 * C,), device=z.device, dtype=torch.float64)
+    args = (_dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+            _opt(gscale, "gscale"), _opt(gadd, "gadd"))
+    _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
+    dz = torch.empty_like(z)
+    _lib.call("eat_bn_act_bwd_apply", *args, sums.data_ptr(), dz.data_ptr(), B, C, S, act, _stream())
+    sf = sums.float()
+    return dz, sf[C:], sf[:C]
+
+
+def plane_dot(u, v, a=None, b=None, act=ACT_NONE):
+    B, C = u.shape[0], u.shape[1]
+    S = u.numel() // (B * C)
+    out = torch.empty((B, C), device=u.device, dtype=torch.float32)
+    _lib.call("eat_plane_dot", _dev(u, "u"), _dev(v, "v"), None if a is None else a.data_ptr(),
+              None if b is None else b.data_ptr(), out.data_ptr(), B, C, S, act, _stream())
+    return out
+
+
+def dw_conv_dgrad(dz, w, x_shape, k, stride, res=None):
+    B, C, F, T = x_shape
+    Fo, To = dz.shape[2], dz.shape[3]
+    dx = torch.empty(x_shape, device=dz.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_dgrad", _dev(dz, "dz"), _dev(w, "w"), _opt(res, "res"), dx.data_ptr(), B, C, F, T, Fo, To,
+              k, stride, _stream())
+    return dx
+
+
+def dw_conv_wgrad(dz, x, k, stride):
+    B, C, Fo, To = dz.shape
+    XC, F, T = x.shape[1], x.shape[2], x.shape[3]
+    dw = torch.zeros((C, k * k), device=dz.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), dw.data_ptr(), B, C, XC, F, T, Fo, To, k, stride,
+              _stream())
+    return dw
+
+
+def pw_conv_wgrad(dz, x, x_scale=None):
+    B, Co = dz.shape[0], dz.shape[1]
+    Ci = x.shape[1]
+    S = dz.numel() // (B * Co)
+    dW = torch.zeros((Co, Ci), device=dz.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
+              S, _stream())
+    return dW

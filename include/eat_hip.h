@@ -95,6 +95,60 @@ int eat_pw_prepack(const float* w, const float* row_scale, float* wp, int Co, in
 int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
                    float x_scale, int act, eat_stream_t stream);
 
+/* ================= training step (batch-statistics BatchNorm + backward) ======================
+ * The reference trains with nn.BatchNorm2d(eps=1e-3, momentum=0.01) in train mode and leaves the
+ * backward pass to autograd (ex_audioset.py:147-199).  Formulas: SURVEY.md Appendix C. */
+
+/* sums (2C doubles, zeroed by the caller): sums[c] += sum z, sums[C+c] += sum z^2 over (B, S). */
+int eat_bn_stats(const float* z, int B, int C, int S, double* sums, eat_stream_t stream);
+
+/* From the sums: batch mean, biased variance -> a = gamma*invstd, b = beta - mean*a (so that
+ * BN(z) = a*z + b), saved mean / invstd for backward; if running_mean != NULL the running
+ * buffers get the momentum update with the unbiased variance (n = B*S elements per channel). */
+int eat_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, double n, int C, float* a, float* b,
+                    float* mean, float* invstd, eat_stream_t stream);
+
+/* y = act(a_c*z + b_c) [+ res]; pool (B,C) or NULL receives the plane sums of y (SE squeeze,
+ * block_types.py:72-73, or the head's global average pool); y may be NULL when only pool is needed. */
+int eat_bn_act_fwd(const float* z, const float* a, const float* b, const float* res, float* y,
+                   float* pool, int B, int C, int S, int act, eat_stream_t stream);
+
+/* Backward of y = act(a*z + b) under batch statistics, with the incoming gradient
+ * g_in[b,c,s] = dy[b,c,s]*gscale[b,c] + gadd[b,c] (gscale/gadd may be NULL: the SE scale and the
+ * broadcast gradient of the squeeze are folded in here).  Pass 1 accumulates per channel
+ * sums[c] += sum g, sums[C+c] += sum g*xhat with g = g_in*act'(a z + b) (= dbeta, dgamma);
+ * pass 2 writes dz = a*(g - sums[c]/n - xhat*sums[C+c]/n). */
+int eat_bn_act_bwd_reduce(const float* dy, const float* z, const float* a, const float* b,
+                          const float* mean, const float* invstd, const float* gscale,
+                          const float* gadd, int B, int C, int S, int act, double* sums,
+                          eat_stream_t stream);
+int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const float* b,
+                         const float* mean, const float* invstd, const float* gscale,
+                         const float* gadd, const double* sums, float* dz, int B, int C, int S,
+                         int act, eat_stream_t stream);
+
+/* out[b,c] = sum_s u[b,c,s] * v'[b,c,s] with v' = v (a == NULL) or act(a_c*v + b_c): the gradient
+ * w.r.t. the SE scale, d s[b,c] = sum_s d(x*s) * x. */
+int eat_plane_dot(const float* u, const float* v, const float* a, const float* b, float* out, int B,
+                  int C, int S, int act, eat_stream_t stream);
+
+/* Depthwise conv data gradient dx (B,C,F,T) from dz (B,C,Fo,To), taps w (C,k,k); res (B,C,F,T) or
+ * NULL is added (residual branch gradient). */
+int eat_dw_conv_dgrad(const float* dz, const float* w, const float* res, float* dx, int B, int C,
+                      int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
+
+/* Depthwise / stem weight gradient dw (C,k,k) += sum dz * shifted x; x has XC = C (depthwise) or
+ * XC = 1 (3x3 stem, stride 2) channels.  dw must be zeroed by the caller. */
+int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T,
+                      int Fo, int To, int k, int stride, eat_stream_t stream);
+
+/* Pointwise weight gradient dW (Co,Ci) += sum_{b,s} dz[b,co,s] * x[b,ci,s] * x_scale[b,ci]
+ * (fp32 MFMA; x_scale (B,Ci) or NULL is the SE scale the forward applied to x); dW must be
+ * zeroed by the caller.  The data gradient is eat_pw_conv_fwd with the packed W^T. */
+int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
+                      int Ci, int S, eat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

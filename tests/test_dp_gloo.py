@@ -1,0 +1,60 @@
+"""World-size-2 `gloo` test (CPU) of the data-parallel gradient exchange used by the train-mode
+backward: bucketed async all-reduce, averaging, unflattening (efficientat_amd/dp.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from efficientat_amd.dp import GradReducer
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = {"a.weight": (64, 16, 1, 1), "a.bias": (64,), "b.weight": (960, 160), "c": (7,), "d.weight": (3, 3)}
+        red = GradReducer(bucket_bytes=16 << 10)          # small buckets: several collectives + a tail bucket
+        gen = torch.Generator().manual_seed(100 + rank)
+        mine = {k: torch.randn(v, generator=gen) for k, v in shapes.items()}
+        for k in shapes:                                    # push order = production order in backward
+            red.push(k, mine[k].clone())
+        out = red.finish()
+        # expected: mean over ranks of the same seeded tensors
+        exp = {k: sum(torch.randn(v, generator=torch.Generator().manual_seed(100 + r)) if False else
+                      _regen(shapes, r)[k] for r in range(world)) / world for k, v in shapes.items()}
+        ok = all(torch.allclose(out[k], exp[k], atol=1e-6) and out[k].shape == torch.Size(shapes[k]) for k in shapes)
+        # a second round must start clean
+        red.push("c", torch.ones(7) * (rank + 1))
+        out2 = red.finish()
+        ok = ok and set(out2) == {"c"} and torch.allclose(out2["c"], torch.full((7,), (1 + world) / 2.0))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def _regen(shapes, rank):
+    gen = torch.Generator().manual_seed(100 + rank)
+    return {k: torch.randn(v, generator=gen) for k, v in shapes.items()}
+
+
+def test_grad_reducer_world2_gloo():
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_grad_reducer_single_process_passthrough():
+    red = GradReducer()
+    t = torch.arange(6.0).view(2, 3)
+    red.push("w", t)
+    out = red.finish()
+    assert out["w"] is t and red.finish() == {}

@@ -1,0 +1,199 @@
+"""GPU parity of the training step (train-mode BatchNorm forward + hand-written backward) against
+torch-CPU autograd over the oracle.  Per-op checks run on the oracle's exact forward tensors
+(identical activation masks, expect <= 1e-5 relative); the whole-network check uses rel-L2 <= 1e-2
+per parameter tensor because ReLU/Hardswish kinks make gradients discontinuous in forward
+rounding ("gradient-parity budget")."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import eat_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("no GPU", allow_module_level=True)
+
+from efficientat_amd import ops  # noqa: E402
+from efficientat_amd.mn import get_model  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ACTS = [lambda t: t, F.relu, F.hardswish]
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _rel(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = ref.detach().double().reshape(-1)
+    return float((got - ref).norm() / max(1e-30, float(ref.norm())))
+
+
+@pytest.mark.parametrize("B,C,F_,T,act", [(4, 16, 64, 500, 2), (3, 72, 16, 125, 1), (5, 40, 8, 63, 0), (2, 6, 3, 5, 2)])
+def test_bn_act_forward_backward(B, C, F_, T, act):
+    z = _rand(B, C, F_, T, seed=1, scale=2.0) + _rand(1, C, 1, 1, seed=2)
+    gamma, beta = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5, _rand(C, seed=4, scale=0.3)
+    res, dy = _rand(B, C, F_, T, seed=5), _rand(B, C, F_, T, seed=6)
+    gs = torch.rand(B, C, generator=torch.Generator().manual_seed(7)) + 0.5
+    ga = _rand(B, C, seed=8, scale=0.1)
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y_ref = ACTS[act](F.batch_norm(zr, rm, rv, gr, br, True, 0.01, 1e-3))
+    (y_ref * (dy * gs[:, :, None, None] + ga[:, :, None, None])).sum().backward()
+
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    zd = z.to(DEV)
+    a, b, mean, invstd = ops.bn_finalize(ops.bn_stats(zd), bn, B * F_ * T)
+    pool = torch.empty(B, C, device=DEV)
+    y = ops.bn_act_fwd(zd, a, b, act, res=res.to(DEV), pool=pool)
+    assert _rel(y, y_ref + res) < 2e-6
+    assert _rel(pool, (y_ref + res).sum(dim=(2, 3))) < 2e-5
+    assert _rel(bn.running_mean, rm) < 1e-5 and _rel(bn.running_var, rv) < 1e-5
+    dz, dgam, dbet = ops.bn_act_bwd(dy.to(DEV), zd, a, b, mean, invstd, act, gscale=gs.to(DEV), gadd=ga.to(DEV))
+    assert _rel(dz, zr.grad) < 2e-5
+    assert _rel(dgam, gr.grad) < 2e-5 and _rel(dbet, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s", [(2, 16, 64, 500, 3, 1), (2, 24, 32, 250, 5, 2), (3, 40, 16, 125, 3, 2),
+                                          (3, 48, 8, 63, 5, 1), (2, 5, 7, 9, 5, 2), (4, 96, 4, 32, 5, 1)])
+def test_dw_conv_gradients(B, C, F_, T, k, s):
+    x = _rand(B, C, F_, T, seed=1).requires_grad_(True)
+    w = _rand(C, 1, k, k, seed=2, scale=0.3).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, (k - 1) // 2, 1, C)
+    dz = _rand(*y.shape, seed=3)
+    res = _rand(B, C, F_, T, seed=4)
+    y.backward(dz)
+    dx = ops.dw_conv_dgrad(dz.to(DEV), w.detach().reshape(C, k * k).contiguous().to(DEV), tuple(x.shape), k, s,
+                           res=res.to(DEV))
+    assert _rel(dx, x.grad + res) < 2e-6
+    dw = ops.dw_conv_wgrad(dz.to(DEV), x.detach().to(DEV), k, s)
+    assert _rel(dw, w.grad.reshape(C, k * k)) < 2e-5
+
+
+def test_stem_weight_gradient():
+    x, w = _rand(3, 1, 128, 300, seed=1), _rand(16, 1, 3, 3, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 1)
+    dz = _rand(*y.shape, seed=3)
+    y.backward(dz)
+    assert _rel(ops.dw_conv_wgrad(dz.to(DEV), x.to(DEV), 3, 2), w.grad.reshape(16, 9)) < 2e-5
+
+
+@pytest.mark.parametrize("B,Ci,Co,F_,T,se", [(2, 16, 64, 64, 500, False), (3, 72, 40, 16, 125, True),
+                                             (4, 160, 960, 4, 32, False), (5, 960, 160, 4, 32, True),
+                                             (2, 12, 20, 3, 12, True), (3, 80, 200, 8, 63, False)])
+def test_pw_conv_gradients(B, Ci, Co, F_, T, se):
+    x = _rand(B, Ci, F_, T, seed=1).requires_grad_(True)
+    w = _rand(Co, Ci, 1, 1, seed=2, scale=Ci ** -0.5).requires_grad_(True)
+    sc = (torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) if se else torch.ones(B, Ci)).requires_grad_(True)
+    y = F.conv2d(x * sc[:, :, None, None], w)
+    dz = _rand(*y.shape, seed=3)
+    y.backward(dz)
+    dzd, xd = dz.to(DEV), x.detach().to(DEV)
+    dW = ops.pw_conv_wgrad(dzd, xd, x_scale=sc.detach().to(DEV) if se else None)
+    assert _rel(dW, w.grad.reshape(Co, Ci)) < 2e-5
+    wpt = ops.pw_prepack(w.detach().reshape(Co, Ci).t().contiguous().to(DEV))
+    dxs = ops.pw_conv(dzd, wpt, torch.zeros(Ci, device=DEV), Ci, ops.ACT_NONE)      # grad w.r.t. x*sc
+    assert _rel(dxs * sc.detach().to(DEV)[:, :, None, None], x.grad) < 2e-5
+    assert _rel(ops.plane_dot(dxs, xd), sc.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------- whole train step
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_mn10_train_step_matches_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
+    sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    x = O.mel_forward(synth.parity_clips(320000, seed=1234)).unsqueeze(1)
+    y = torch.from_numpy(g["train_labels"])
+    keep = torch.from_numpy(g["drop_keep"].astype(np.float32))
+
+    # oracle: torch-CPU autograd over the restatement (itself pinned to the reference's grads)
+    sdr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith(
+        ("running_mean", "running_var")) else v.clone()) for k, v in sd.items()}
+    stats = {}
+    logits_ref, _ = O.mn_forward(sdr, x, train=True, stats=stats, drop_mask=keep)
+    loss_ref = F.binary_cross_entropy_with_logits(logits_ref, y)
+    loss_ref.backward()
+
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    model._drop_mask_override = keep
+    logits, feat = model(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
+    loss.backward()
+
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-5          # vs the unmodified reference
+    assert float((logits.detach().cpu() - logits_ref.detach()).abs().max()) < 1e-3
+    assert np.abs(logits.detach().cpu().numpy() - g["train_logits"]).max() < 1e-3
+    gmax = max(float(v.grad.norm()) for k, v in sdr.items() if getattr(v, "grad", None) is not None)
+    # Measured on MI355X (scratch/diag_train.py): vs an fp64 evaluation the CPU fp32 oracle itself is
+    # off by 0.45 % median / 1.0 % max per tensor (activation-kink flips), the HIP path by 0.65 % / 1.9 %
+    # - the same error class.  Bound: 3 % per tensor, 1 % median.
+    bad, rels = [], []
+    for name, p in model.named_parameters():
+        ref = sdr[name].grad
+        assert p.grad is not None, name
+        if float(ref.norm()) < 1e-5 * gmax:      # project-BN biases: true gradient is exactly zero
+            continue
+        r = _rel(p.grad, ref)
+        rels.append(r)
+        if r > 3e-2:
+            bad.append((name, r))
+    assert not bad, bad[:8]
+    assert float(np.median(rels)) < 1e-2, float(np.median(rels))
+    # reference gradient norms stored in the golden file
+    for name, p in model.named_parameters():
+        ref = float(g["gnorm/" + name])
+        if ref > 1e-5 * gmax:
+            assert abs(float(p.grad.norm()) - ref) < 3e-2 * ref, name
+    # running statistics after one step (momentum 0.01, unbiased variance)
+    msd = model.state_dict()
+    for k, v in stats.items():
+        assert _rel(msd[k], v) < 1e-5, k
+    assert int(msd["features.0.1.num_batches_tracked"]) == 1
+
+
+def test_train_step_updates_weights_and_eval_follows(golden_dir):
+    """SGD step on the HIP gradients changes the eval output (fold cache follows the update)."""
+    model = _quiet(get_model, width_mult=0.4, num_classes=10)
+    model.to(DEV)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    x = _rand(4, 1, 128, 200, seed=3).to(DEV)
+    y = (torch.rand(4, 10, generator=torch.Generator().manual_seed(1)) < 0.3).float().to(DEV)
+    losses = []
+    for _ in range(6):
+        model.train()
+        opt.zero_grad()
+        logits, _ = model(x)
+        loss = F.binary_cross_entropy_with_logits(logits, y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    model.eval()
+    with torch.no_grad():
+        out, _ = model(x)
+    assert torch.isfinite(out).all()
