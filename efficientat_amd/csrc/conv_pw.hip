@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int kc_arg,
-    int n_stages, int act) {
+    int n_stages, int act, int tps, long long wp_bstride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int kc = PIPE ? kPipeKC : kc_arg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -99,9 +99,13 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
   if (tile >= n_tiles) return;
   const int mt0 = mchunk * MTW;
   const int mtw_eff = (MT - mt0) < MTW ? (MT - mt0) : MTW;
-  const long long N = (long long)B * S;
-  const long long n_base = (long long)tile * kTileN;
+  // tps == 0: the N axis is the flattened (sample, position) axis and tiles may straddle samples.
+  // tps  > 0: per-sample weights (DyMN dynamic conv, models/dymn/dy_block.py:111-127): a tile lies
+  //           inside one sample (tps tiles per sample) and reads that sample's packed weights.
+  const long long n_base = tps ? (long long)(tile / tps) * S + (long long)(tile % tps) * kTileN : (long long)tile * kTileN;
   const int b_first = (int)(n_base / S);
+  const long long N = tps ? (long long)(b_first + 1) * S : (long long)B * S;   // first column this tile must not touch
+  wp += tps ? (size_t)b_first * wp_bstride : 0;
 
   // loader role: this lane's 4 columns of every k-row
   long long nl = n_base + 4 * lane;
@@ -342,9 +346,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 
 template <int MTW>
 int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias, const float* in_scale,
-              const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act) {
+              const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act,
+              bool per_sample) {
   const long long N = (long long)B * S;
-  const int n_tiles = (int)((N + kTileN - 1) / kTileN);
+  const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
+  const int n_tiles = per_sample ? B * tps : (int)((N + kTileN - 1) / kTileN);
+  const long long wp_bstride = (long long)(Ci / 4) * MT * 64;
   int NS = kTileN / S + 2;
   if (NS > B) NS = B;
   if (!in_scale) NS = 0;
@@ -372,7 +379,7 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
-                     MC, n_tiles, NS, kc, n_stages, act);
+                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride);
   return eat::check_launch("eat_pw_conv_fwd");
 }
 
@@ -389,10 +396,8 @@ extern "C" int eat_pw_prepack(const float* w, const float* row_scale, float* wp,
   return eat::check_launch("eat_pw_prepack");
 }
 
-extern "C" int eat_pw_conv_fwd(const float* x, const float* wp, const float* bias, const float* in_scale,
-                               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
-                               eat_stream_t stream) {
-  eat::clear_stale_error();
+static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,
+                       float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s) {
   if (Ci % 4 != 0 || S % 4 != 0)
     return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d and S=%d must be multiples of 4", Ci, S);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
@@ -402,14 +407,26 @@ extern "C" int eat_pw_conv_fwd(const float* x, const float* wp, const float* bia
   // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks
   const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block
-  hipStream_t s = (hipStream_t)stream;
-#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act);
+#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample);
   switch (mtw) {
     EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4) EAT_PW_CASE(5)
     EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: internal tiling error");
   }
 #undef EAT_PW_CASE
+}
+
+extern "C" int eat_pw_conv_fwd(const float* x, const float* wp, const float* bias, const float* in_scale,
+                               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
+                               eat_stream_t stream) {
+  eat::clear_stale_error();
+  return pw_dispatch(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, false, (hipStream_t)stream);
+}
+
+extern "C" int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, const float* res, float* y,
+                                   int B, int Ci, int Co, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return pw_dispatch(x, wp_b, bias, nullptr, res, y, nullptr, B, Ci, Co, S, act, true, (hipStream_t)stream);
 }
 
 extern "C" int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,

@@ -51,13 +51,26 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // neighbouring lanes is served by L1.  No LDS, no barrier, ~70 VGPRs: 7-8 waves per SIMD keep
 // enough row segments in flight to stream from HBM.  The activated outputs of a plane are summed
 // on the fly for the squeeze of SqueezeExcitation.
-template <int K, int STRIDE, int ACT>
+//
+// DY = true is the DyMN variant (models/dymn/dy_block.py:399-402): the taps are per (b,c) plane (the
+// attention-weighted sum of the K=4 kernels, aggregated beforehand), and the epilogue applies
+// DyReLU-B  max(a1 v + b1, a2 v + b2)  with per-plane coefficients and the coordinate attention
+// sigmoid(g_cf[b,fo,c]) * sigmoid(g_ct[b,to,c]) (gates stored position-major: (B, L, C)).
+struct DwDyn {
+  const float* coef;    // (B*C, 4): a1, a2, b1, b2
+  const float* gate_f;  // (B, Fo, C) pre-sigmoid
+  const float* gate_t;  // (B, To, C) pre-sigmoid
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int K, int STRIDE, int ACT, bool DY>
 __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ y, float* __restrict__ pool,
                                                       int n_planes, int C, int F, int T, int Fo, int To,
-                                                      int TX) {
+                                                      int TX, DwDyn dyn) {
   constexpr int P = (K - 1) / 2;
   const int tid = threadIdx.x;
   const int tx = tid % TX, ty = tid / TX;
@@ -69,8 +82,17 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     const int c = gp % C;
     float wr[K * K];
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) wr[i] = w[c * K * K + i];
+    for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)(DY ? gp : c) * K * K + i];
     const float bc = bias[c];
+    float a1 = 1.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, sgt = 1.f;
+    const float* gfp = nullptr;
+    if constexpr (DY) {
+      const float4 cf = *reinterpret_cast<const float4*>(dyn.coef + (size_t)gp * 4);
+      a1 = cf.x; a2 = cf.y; b1 = cf.z; b2 = cf.w;
+      const int b = gp / C;
+      sgt = sigmoidf_(dyn.gate_t[((size_t)b * To + to) * C + c]);
+      gfp = dyn.gate_f + (size_t)b * Fo * C + c;
+    }
     const float* xp = x + (size_t)gp * F * T;
     float* yp = y + (size_t)gp * Fo * To + to;
     const int t0 = to * STRIDE - P;
@@ -108,7 +130,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
           for (int u = 0; u < K; ++u)
 #pragma unroll
             for (int v = 0; v < K; ++v) acc = fmaf(wr[u * K + v], win[(u + R * STRIDE) % NSLOT][v], acc);
-          const float o = eat::activate<ACT>(acc);
+          float o = eat::activate<ACT>(acc);
+          if constexpr (DY) o = fmaxf(fmaf(a1, o, b1), fmaf(a2, o, b2)) * (sigmoidf_(gfp[(size_t)fo * C]) * sgt);
           yp[(size_t)fo * To] = o;
           psum += o;
         }
@@ -125,15 +148,32 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
 
 template <int K, int STRIDE>
 int launch_dw(const float* x, const float* w, const float* bias, float* y, float* pool, int B, int C,
-              int F, int T, int Fo, int To, int act, hipStream_t stream) {
+              int F, int T, int Fo, int To, int act, const DwDyn* dyn, hipStream_t stream) {
   const int TX = To > 32 ? 64 : 32;
   const int n_planes = B * C;
   const int ppb = 256 / TX;
   dim3 grid((To + TX - 1) / TX, (n_planes + ppb - 1) / ppb);
   if (grid.y > 65535u * 32u) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: too many planes (%d)", n_planes);
-  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT>), grid, dim3(256), 0, stream, x, w, bias,
-                                           y, pool, n_planes, C, F, T, Fo, To, TX));
+  if (dyn) {
+    hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, EAT_ACT_NONE, true>), grid, dim3(256), 0, stream, x, w, bias, y, pool,
+                       n_planes, C, F, T, Fo, To, TX, *dyn);
+  } else {
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT, false>), grid, dim3(256), 0, stream, x, w,
+                                             bias, y, pool, n_planes, C, F, T, Fo, To, TX, DwDyn{nullptr, nullptr, nullptr}));
+  }
   return eat::check_launch("eat_dw_conv_fwd");
+}
+
+int dispatch_dw(const float* x, const float* w, const float* bias, float* y, float* pool, int B, int C, int F, int T,
+                int Fo, int To, int k, int stride, int act, const DwDyn* dyn, hipStream_t s) {
+  const int p = (k - 1) / 2;
+  if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: output %dx%d inconsistent with input %dx%d k=%d s=%d", Fo, To, F, T, k, stride);
+  if (k == 3 && stride == 1) return launch_dw<3, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
+  if (k == 3 && stride == 2) return launch_dw<3, 2>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
+  if (k == 5 && stride == 1) return launch_dw<5, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
+  if (k == 5 && stride == 2) return launch_dw<5, 2>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
+  return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: unsupported k=%d stride=%d", k, stride);
 }
 
 }  // namespace
@@ -153,13 +193,13 @@ extern "C" int eat_dw_conv_fwd(const float* x, const float* w, const float* bias
                                int B, int C, int F, int T, int Fo, int To, int k, int stride, int act,
                                eat_stream_t stream) {
   eat::clear_stale_error();
-  const int p = (k - 1) / 2;
-  if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
-    return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: output %dx%d inconsistent with input %dx%d k=%d s=%d", Fo, To, F, T, k, stride);
-  hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw<3, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, s);
-  if (k == 3 && stride == 2) return launch_dw<3, 2>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, s);
-  if (k == 5 && stride == 1) return launch_dw<5, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, s);
-  if (k == 5 && stride == 2) return launch_dw<5, 2>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, s);
-  return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: unsupported k=%d stride=%d", k, stride);
+  return dispatch_dw(x, w, bias, y, pool, B, C, F, T, Fo, To, k, stride, act, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const float* bias, const float* coef,
+                                   const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
+                                   int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  const DwDyn dyn{coef, gate_f, gate_t};
+  return dispatch_dw(x, w_bc, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
 }

@@ -163,3 +163,45 @@ def pw_conv_wgrad(dz, x, x_scale=None):
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
               S, _stream())
     return dW
+
+
+# ------------------------------------------------------------------------- DyMN launchers
+def ctx_pool(x):
+    B, C, F, T = x.shape
+    seq = torch.empty((B, F + T, C), device=x.device, dtype=torch.float32)
+    _lib.call("eat_ctx_pool", _dev(x, "x"), seq.data_ptr(), B, C, F, T, _stream())
+    return seq
+
+
+def dyn_aggregate(bank, att, gscale=None, group=1):
+    K, N = bank.shape
+    B = att.shape[0]
+    out = torch.empty((B, N), device=bank.device, dtype=torch.float32)
+    _lib.call("eat_dyn_aggregate", _dev(bank, "bank"), _dev(att, "att"), _opt(gscale, "gscale"), out.data_ptr(), B, K,
+              N, group, _stream())
+    return out
+
+
+def dyn_pw_pack(bank, att, Co, Ci, row_scale=None):
+    K, B = bank.shape[0], att.shape[0]
+    wp = torch.empty((B, (Ci // 4) * ((Co + 15) // 16) * 64), device=bank.device, dtype=torch.float32)
+    _lib.call("eat_dyn_pw_pack", _dev(bank, "bank"), _dev(att, "att"), _opt(row_scale, "row_scale"), wp.data_ptr(), B,
+              K, Co, Ci, _stream())
+    return wp
+
+
+def pw_conv_dyn(x, wp_b, bias, Co, act, res=None):
+    B, Ci, F, T = x.shape
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_dyn_fwd", _dev(x, "x"), _dev(wp_b, "wp_b"), _dev(bias, "bias"), _opt(res, "res"),
+              y.data_ptr(), B, Ci, Co, F * T, act, _stream())
+    return y
+
+
+def dw_conv_dyn(x, w_bc, bias, coef, gate_f, gate_t, k, stride):
+    B, C, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_dyn_fwd", _dev(x, "x"), _dev(w_bc, "w_bc"), _dev(bias, "bias"), _dev(coef, "coef"),
+              _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), y.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
+    return y

@@ -149,6 +149,36 @@ int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, 
 int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
                       int Ci, int S, eat_stream_t stream);
 
+/* ================= DyMN dynamic blocks (models/dymn/dy_block.py) ================================ */
+
+/* ContextGen's two average pools (dy_block.py:236-237): x (B,C,F,T) -> seq (B, F+T, C), position-
+ * major: rows 0..F-1 = mean over T, rows F..F+T-1 = mean over F. */
+int eat_ctx_pool(const float* x, float* seq, int B, int C, int F, int T, eat_stream_t stream);
+
+/* Kernel aggregation (dy_block.py:111-117): out[b,n] = gscale[n/group] * sum_k att[b,k]*bank[k,n];
+ * bank (K,N) is DynamicConv.weight viewed as (K, Cout*Cin/g*k*k); gscale (N/group) or NULL folds the
+ * eval-mode BatchNorm scale per output channel (group = Cin/g*k*k). */
+int eat_dyn_aggregate(const float* bank, const float* att, const float* gscale, float* out, int B,
+                      int K, int N, int group, eat_stream_t stream);
+
+/* The same aggregation for a 1x1 DynamicConv written straight into MFMA A-fragment order, one
+ * packed matrix of (Ci/4)*ceil(Co/16)*64 floats per sample (input of eat_pw_conv_dyn_fwd). */
+int eat_dyn_pw_pack(const float* bank, const float* att, const float* row_scale, float* wp, int B,
+                    int K, int Co, int Ci, eat_stream_t stream);
+
+/* 1x1 conv with per-sample weights (dy_block.py:120-127 for kernel_size 1): like eat_pw_conv_fwd
+ * but sample b multiplies by wp_b[b]. */
+int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, const float* res,
+                        float* y, int B, int Ci, int Co, int S, int act, eat_stream_t stream);
+
+/* Depthwise conv with per-(b,c) taps w_bc (B,C,k*k) + bias (C), followed in the epilogue by
+ * DyReLU-B max(a1 v + b1, a2 v + b2) with coef (B,C,4) = (a1,a2,b1,b2) (dy_block.py:172-188) and
+ * coordinate attention * sigmoid(gate_f[b,fo,c]) * sigmoid(gate_t[b,to,c]) (dy_block.py:195-201;
+ * gates position-major (B,Fo,C) / (B,To,C), pre-sigmoid). */
+int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const float* bias, const float* coef,
+                        const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
+                        int Fo, int To, int k, int stride, eat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,107 @@
+"""GPU parity of the DyMN eval forward (dynamic conv kernel aggregation, DyReLU-B, CoordAtt,
+context generator) against the CPU oracle and the stored outputs of the unmodified reference."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import eat_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("no GPU", allow_module_level=True)
+
+from efficientat_amd import ops  # noqa: E402
+from efficientat_amd.dymn import get_model  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _rel(got, ref):
+    got, ref = got.detach().cpu().double().reshape(-1), ref.detach().double().reshape(-1)
+    return float((got - ref).norm() / max(1e-30, float(ref.norm())))
+
+
+@pytest.mark.parametrize("B,C,F_,T", [(2, 16, 64, 500), (3, 40, 16, 125), (2, 80, 8, 63), (3, 160, 4, 32), (1, 5, 3, 7)])
+def test_ctx_pool(B, C, F_, T):
+    x = _rand(B, C, F_, T, seed=1)
+    ref = torch.cat([x.mean(dim=3), x.mean(dim=2)], dim=2).transpose(1, 2)       # (B, F+T, C)
+    assert _rel(ops.ctx_pool(x.to(DEV)), ref) < 2e-6
+
+
+def test_dyn_aggregate_and_pack():
+    B, K, Co, Ci = 3, 4, 40, 24
+    bank, att = _rand(K, Co * Ci, seed=1), torch.softmax(_rand(B, K, seed=2), dim=-1)
+    rs = torch.rand(Co, generator=torch.Generator().manual_seed(3)) + 0.5
+    agg = ops.dyn_aggregate(bank.to(DEV), att.to(DEV), rs.to(DEV), Ci)
+    ref = (att @ bank).view(B, Co, Ci) * rs[None, :, None]
+    assert _rel(agg, ref) < 2e-6
+    # per-sample packed weights through the per-sample 1x1 conv
+    x = _rand(B, Ci, 8, 63, seed=4)
+    wp = ops.dyn_pw_pack(bank.to(DEV), att.to(DEV), Co, Ci, rs.to(DEV))
+    bias, res = _rand(Co, seed=5, scale=0.1), _rand(B, Co, 8, 63, seed=6)
+    y = ops.pw_conv_dyn(x.to(DEV), wp, bias.to(DEV), Co, ops.ACT_HSWISH, res=res.to(DEV))
+    yref = torch.stack([F.hardswish(F.conv2d(x[b:b + 1], ref[b].view(Co, Ci, 1, 1), bias))[0] for b in range(B)]) + res
+    assert _rel(y, yref) < 5e-6
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s", [(2, 32, 64, 500, 3, 1), (2, 48, 32, 250, 5, 2), (3, 240, 16, 125, 3, 2),
+                                          (3, 96, 8, 63, 5, 1), (4, 160, 4, 32, 5, 1)])
+def test_dw_conv_dyn(B, C, F_, T, k, s):
+    x, w = _rand(B, C, F_, T, seed=1), _rand(B, C, k, k, seed=2, scale=0.3)
+    bias, coef = _rand(C, seed=3, scale=0.1), _rand(B, C, 4, seed=4)
+    z = F.conv2d(x.reshape(1, B * C, F_, T), w.reshape(B * C, 1, k, k), None, s, (k - 1) // 2, 1, B * C)
+    z = z.reshape(B, C, *z.shape[2:]) + bias[None, :, None, None]
+    Fo, To = z.shape[2], z.shape[3]
+    gf, gt = _rand(B, Fo, C, seed=5), _rand(B, To, C, seed=6)
+    c = coef[:, :, None, None, :]
+    ref = torch.maximum(z * c[..., 0] + c[..., 2], z * c[..., 1] + c[..., 3])
+    ref = ref * torch.sigmoid(gf.permute(0, 2, 1))[:, :, :, None] * torch.sigmoid(gt.permute(0, 2, 1))[:, :, None, :]
+    got = ops.dw_conv_dyn(x.to(DEV), w.reshape(B, C * k * k).contiguous().to(DEV), bias.to(DEV), coef.contiguous().to(DEV),
+                          gf.to(DEV), gt.to(DEV), k, s)
+    assert _rel(got, ref) < 5e-6
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_dymn10_eval_matches_oracle_and_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "dymn10_ref.npz"))
+    sd = synth.synth_state(synth.dymn_shapes(1.0), seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    temp = float(g["temp_eval"])
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd, strict=True)
+    for m in model.modules():
+        if hasattr(m, "temperature"):
+            m.temperature = temp
+    model.to(DEV).eval()
+    x = O.mel_forward(synth.parity_clips(320000, seed=1234)).unsqueeze(1)
+    with torch.no_grad():
+        ref_logits, ref_fmaps = O.dymn_forward(sd, x, temperature=temp, return_fmaps=True)
+        logits, fmaps = model(x.to(DEV), return_fmaps=True)
+        logits2, feat = model(x.to(DEV))
+    assert len(fmaps) == 17
+    for i, (a, b) in enumerate(zip(fmaps, ref_fmaps)):
+        assert a.shape == b.shape
+        assert _rel(a, b) < 2e-4, (i, _rel(a, b))
+    # synthetic dynamic weights amplify the loud-noise clip (|logit| ~ 1e2): compare relative to the
+    # per-sample logit scale, which is <= 1e-3 absolute for the O(1) samples
+    scale = np.maximum(1.0, np.abs(g["eval_logits"]).max(axis=1, keepdims=True))
+    assert (np.abs(logits.cpu().numpy() - ref_logits.numpy()) / scale).max() < 1e-3
+    assert (np.abs(logits.cpu().numpy() - g["eval_logits"]) / scale).max() < 1e-3
+    assert (np.abs(logits2.cpu().numpy() - g["eval_logits"]) / scale).max() < 1e-3
+    assert feat.shape == (5, 960)
