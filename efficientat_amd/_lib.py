@@ -41,6 +41,13 @@ SIGNATURES = {
     "eat_dyn_pw_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_pw_conv_dyn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dyn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_ctx_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_dyrelu_ca_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_dyrelu_ca_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_dyn_bank_grad": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eat_pw_conv_dyn_wgrad": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_dw_conv_dyn_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_dw_conv_dyn_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 
 _lib = None

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     const float bc = bias[c];
     float a1 = 1.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, sgt = 1.f;
     const float* gfp = nullptr;
-    if constexpr (DY) {
+    const bool dy_epi = DY && dyn.coef != nullptr;      // coef == NULL: per-plane taps only (train mode:
+    if (dy_epi) {                                        // BN statistics come before DyReLU / CoordAtt)
       const float4 cf = *reinterpret_cast<const float4*>(dyn.coef + (size_t)gp * 4);
       a1 = cf.x; a2 = cf.y; b1 = cf.z; b2 = cf.w;
       const int b = gp / C;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
 #pragma unroll
             for (int v = 0; v < K; ++v) acc = fmaf(wr[u * K + v], win[(u + R * STRIDE) % NSLOT][v], acc);
           float o = eat::activate<ACT>(acc);
-          if constexpr (DY) o = fmaxf(fmaf(a1, o, b1), fmaf(a2, o, b2)) * (sigmoidf_(gfp[(size_t)fo * C]) * sgt);
+          if (dy_epi) o = fmaxf(fmaf(a1, o, b1), fmaf(a2, o, b2)) * (sigmoidf_(gfp[(size_t)fo * C]) * sgt);
           yp[(size_t)fo * To] = o;
           psum += o;
         }

@@ -71,6 +71,142 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restric
   }
 }
 
+// backward of ctx_pool: dx[b,c,f,t] = dseq[b,f,c]/T + dseq[b,F+t,c]/F  (+ add[b,c,f,t])
+__global__ __launch_bounds__(256) void ctx_pool_bwd_kernel(const float* __restrict__ dseq, const float* __restrict__ add,
+                                                           float* __restrict__ dx, int C, int F, int T) {
+  extern __shared__ float s_g[];                         // [F + T]
+  const int plane = blockIdx.x, b = plane / C, c = plane % C;
+  const float* g = dseq + (size_t)b * (F + T) * C + c;
+  for (int i = threadIdx.x; i < F + T; i += 256) s_g[i] = g[(size_t)i * C] / (float)(i < F ? T : F);
+  __syncthreads();
+  const size_t base = (size_t)plane * F * T;
+  for (int e = threadIdx.x; e < F * T; e += 256) {
+    const int f = e / T, t = e - f * T;
+    float v = s_g[f] + s_g[F + t];
+    if (add) v += add[base + e];
+    dx[base + e] = v;
+  }
+}
+
+// DyReLU-B + coordinate attention on v = a_c z + b_c (BatchNorm affine, a == NULL: v = z):
+//   out = max(a1 v + b1, a2 v + b2) * sigmoid(gf[b,f,c]) * sigmoid(gt[b,t,c])
+__global__ __launch_bounds__(256) void dyrelu_ca_fwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                            const float* __restrict__ b, const float* __restrict__ coef,
+                                                            const float* __restrict__ gf, const float* __restrict__ gt,
+                                                            float* __restrict__ out, int C, int Fo, int To) {
+  extern __shared__ float s_g[];                         // [Fo + To] sigmoids
+  const int plane = blockIdx.x, bb = plane / C, c = plane % C;
+  const float av = a ? a[c] : 1.0f, bv = a ? b[c] : 0.0f;
+  const float4 cf = *reinterpret_cast<const float4*>(coef + (size_t)plane * 4);
+  for (int i = threadIdx.x; i < Fo + To; i += 256) {
+    const float g = i < Fo ? gf[((size_t)bb * Fo + i) * C + c] : gt[((size_t)bb * To + (i - Fo)) * C + c];
+    s_g[i] = 1.0f / (1.0f + expf(-g));
+  }
+  __syncthreads();
+  const size_t base = (size_t)plane * Fo * To;
+  for (int e = threadIdx.x; e < Fo * To; e += 256) {
+    const int f = e / To, t = e - f * To;
+    const float v = fmaf(av, z[base + e], bv);
+    out[base + e] = fmaxf(fmaf(cf.x, v, cf.z), fmaf(cf.y, v, cf.w)) * (s_g[f] * s_g[Fo + t]);
+  }
+}
+
+// backward: dv (grad w.r.t. v), dcoef (B*C,4), dgf (B,Fo,C), dgt (B,To,C) [pre-sigmoid]
+__global__ __launch_bounds__(256) void dyrelu_ca_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                            const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ coef, const float* __restrict__ gf,
+                                                            const float* __restrict__ gt, float* __restrict__ dv,
+                                                            float* __restrict__ dcoef, float* __restrict__ dgf,
+                                                            float* __restrict__ dgt, int C, int Fo, int To) {
+  extern __shared__ float s_m[];                         // [Fo + To] sigmoids, [4][To] column partials, [16] coef partials
+  float* s_g = s_m;
+  float* s_col = s_m + Fo + To;
+  float* s_cf = s_col + 4 * To;
+  const int plane = blockIdx.x, bb = plane / C, c = plane % C;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float av = a ? a[c] : 1.0f, bv = a ? b[c] : 0.0f;
+  const float4 cf = *reinterpret_cast<const float4*>(coef + (size_t)plane * 4);
+  for (int i = threadIdx.x; i < Fo + To; i += 256) {
+    const float g = i < Fo ? gf[((size_t)bb * Fo + i) * C + c] : gt[((size_t)bb * To + (i - Fo)) * C + c];
+    s_g[i] = 1.0f / (1.0f + expf(-g));
+  }
+  for (int i = threadIdx.x; i < 4 * To; i += 256) s_col[i] = 0.0f;
+  __syncthreads();
+  const size_t base = (size_t)plane * Fo * To;
+  float da1 = 0.f, da2 = 0.f, db1 = 0.f, db2 = 0.f;
+  float* mycol = s_col + wv * To;
+  for (int f = wv; f < Fo; f += 4) {
+    const float af = s_g[f];
+    float rs = 0.0f;
+    for (int t = lane; t < To; t += 64) {
+      const size_t e = base + (size_t)f * To + t;
+      const float at = s_g[Fo + t];
+      const float v = fmaf(av, z[e], bv);
+      const float l1 = fmaf(cf.x, v, cf.z), l2 = fmaf(cf.y, v, cf.w);
+      const bool sel = l1 >= l2;
+      const float m = sel ? l1 : l2;
+      const float d = dout[e];
+      const float dm = d * af * at;
+      dv[e] = dm * (sel ? cf.x : cf.y);
+      if (sel) { da1 = fmaf(dm, v, da1); db1 += dm; } else { da2 = fmaf(dm, v, da2); db2 += dm; }
+      rs = fmaf(d * m, at, rs);                 // d out / d af summed over t
+      mycol[t] = fmaf(d * m, af, mycol[t]);     // d out / d at summed over this wave's rows
+    }
+    rs = eat::wave_sum(rs);
+    if (lane == 0) dgf[((size_t)bb * Fo + f) * C + c] = rs * af * (1.0f - af);
+  }
+  da1 = eat::wave_sum(da1); da2 = eat::wave_sum(da2); db1 = eat::wave_sum(db1); db2 = eat::wave_sum(db2);
+  if (lane == 0) { s_cf[wv * 4 + 0] = da1; s_cf[wv * 4 + 1] = da2; s_cf[wv * 4 + 2] = db1; s_cf[wv * 4 + 3] = db2; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < To; t += 256) {
+    const float at = s_g[Fo + t];
+    dgt[((size_t)bb * To + t) * C + c] = (s_col[t] + s_col[To + t] + s_col[2 * To + t] + s_col[3 * To + t]) * at * (1.0f - at);
+  }
+  if (threadIdx.x < 4)
+    dcoef[(size_t)plane * 4 + threadIdx.x] = s_cf[threadIdx.x] + s_cf[4 + threadIdx.x] + s_cf[8 + threadIdx.x] + s_cf[12 + threadIdx.x];
+}
+
+// gradients of the kernel aggregation W_b = sum_k att[b,k] bank[k]:  dbank[k,n] = sum_b att[b,k] G[b,n]
+__global__ __launch_bounds__(256) void dyn_dbank_kernel(const float* __restrict__ G, const float* __restrict__ att,
+                                                        float* __restrict__ dbank, int B, int K, int N) {
+  extern __shared__ float s_att[];                       // [B*K]
+  for (int i = threadIdx.x; i < B * K; i += 256) s_att[i] = att[i];
+  __syncthreads();
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+      const float g = G[(size_t)b * N + n];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k < K) acc[k] = fmaf(s_att[b * K + k], g, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < K) dbank[(size_t)k * N + n] = acc[k];
+  }
+}
+
+// datt[b,k] = <G[b,:], bank[k,:]>   (grid.y = b; partial sums per block, atomics into zeroed datt)
+__global__ __launch_bounds__(256) void dyn_datt_kernel(const float* __restrict__ G, const float* __restrict__ bank,
+                                                       float* __restrict__ datt, int K, int N) {
+  __shared__ float s_red[4][8];
+  const int b = blockIdx.y;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const float g = G[(size_t)b * N + n];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < K) acc[k] = fmaf(g, bank[(size_t)k * N + n], acc[k]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = eat::wave_sum(acc[k]);
+    if (lane == 0) s_red[wv][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < K)
+    atomicAdd(datt + (size_t)b * K + threadIdx.x,
+              s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" int eat_ctx_pool(const float* x, float* seq, int B, int C, int F, int T, eat_stream_t stream) {
@@ -103,4 +239,46 @@ extern "C" int eat_dyn_pw_pack(const float* bank, const float* att, const float*
   hipLaunchKernelGGL(dyn_pw_pack_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, bank, att, row_scale, wp, K, Co,
                      Ci, MT);
   return eat::check_launch("eat_dyn_pw_pack");
+}
+
+extern "C" int eat_ctx_pool_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T,
+                                eat_stream_t stream) {
+  eat::clear_stale_error();
+  hipLaunchKernelGGL(ctx_pool_bwd_kernel, dim3(B * C), dim3(256), (size_t)(F + T) * sizeof(float), (hipStream_t)stream,
+                     dseq, add, dx, C, F, T);
+  return eat::check_launch("eat_ctx_pool_bwd");
+}
+
+extern "C" int eat_dyrelu_ca_fwd(const float* z, const float* a, const float* b, const float* coef, const float* gate_f,
+                                 const float* gate_t, float* out, int B, int C, int Fo, int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  hipLaunchKernelGGL(dyrelu_ca_fwd_kernel, dim3(B * C), dim3(256), (size_t)(Fo + To) * sizeof(float),
+                     (hipStream_t)stream, z, a, b, coef, gate_f, gate_t, out, C, Fo, To);
+  return eat::check_launch("eat_dyrelu_ca_fwd");
+}
+
+extern "C" int eat_dyrelu_ca_bwd(const float* dout, const float* z, const float* a, const float* b, const float* coef,
+                                 const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
+                                 float* dgate_t, int B, int C, int Fo, int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  const size_t smem = (size_t)(Fo + To + 4 * To + 16) * sizeof(float);
+  hipLaunchKernelGGL(dyrelu_ca_bwd_kernel, dim3(B * C), dim3(256), smem, (hipStream_t)stream, dout, z, a, b, coef, gate_f,
+                     gate_t, dv, dcoef, dgate_f, dgate_t, C, Fo, To);
+  return eat::check_launch("eat_dyrelu_ca_bwd");
+}
+
+extern "C" int eat_dyn_bank_grad(const float* G, const float* att, const float* bank, float* dbank, float* datt, int B,
+                                 int K, int N, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (K > 8) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: K=%d > 8", K);
+  if ((size_t)B * K * sizeof(float) > 48 * 1024) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: batch too large");
+  int gx = (N + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(dyn_dbank_kernel, dim3(gx), dim3(256), (size_t)B * K * sizeof(float), (hipStream_t)stream, G, att,
+                     dbank, B, K, N);
+  int gy = (N + 256 * 16 - 1) / (256 * 16);
+  if (gy > 64) gy = 64;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(dyn_datt_kernel, dim3(gy, B), dim3(256), 0, (hipStream_t)stream, G, bank, datt, K, N);
+  return eat::check_launch("eat_dyn_bank_grad");
 }

@@ -210,12 +210,12 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
 template <int K, int STRIDE>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                        const float* __restrict__ res, float* __restrict__ dx,
-                                                       int C, int F, int T, int Fo, int To) {
+                                                       int C, int F, int T, int Fo, int To, int per_plane_w) {
   constexpr int P = (K - 1) / 2;
   const int plane = blockIdx.y, c = plane % C;
   float wr[K * K];
 #pragma unroll
-  for (int i = 0; i < K * K; ++i) wr[i] = w[c * K * K + i];
+  for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)(per_plane_w ? plane : c) * K * K + i];
   const float* g = dz + (size_t)plane * Fo * To;
   const size_t base = (size_t)plane * F * T;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * T; e += gridDim.x * blockDim.x) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
 template <int K, int STRIDE>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                        float* __restrict__ dw, int B, int C, int XC, int F, int T,
-                                                       int Fo, int To, int b_per_block) {
+                                                       int Fo, int To, int b_per_block, int per_sample) {
   constexpr int P = (K - 1) / 2;
   __shared__ float s_red[4][K * K];
   const int c = blockIdx.x, b0 = blockIdx.y * b_per_block;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   }
   __syncthreads();
   if (threadIdx.x < K * K)
-    atomicAdd(dw + c * K * K + threadIdx.x,
+    atomicAdd(dw + ((size_t)(per_sample ? b0 * C : 0) + c) * K * K + threadIdx.x,
               s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 // added to dW with one atomic per element per block.
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                        const float* __restrict__ xscale, float* __restrict__ dW,
-                                                       int B, int Co, int Ci, int S, int b_per_block) {
+                                                       int B, int Co, int Ci, int S, int b_per_block, int per_sample) {
   __shared__ float s_red[3][4][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
         const int m = m0 + 16 * i + kq * 4 + r, n = n0 + 16 * j + row;   // C/D: col = lane&15, row = kq*4+r
         if (m < Co && n < Ci) {
           const int q = i * 2 + j;
-          atomicAdd(dW + (size_t)m * Ci + n,
+          atomicAdd(dW + (per_sample ? (size_t)b0 * Co * Ci : 0) + (size_t)m * Ci + n,
                     acc[i][j][r] + s_red[0][q][r][lane] + s_red[1][q][r][lane] + s_red[2][q][r][lane]);
         }
       }
@@ -431,14 +431,13 @@ extern "C" int eat_plane_dot(const float* u, const float* v, const float* a, con
   return eat::check_launch("eat_plane_dot");
 }
 
-extern "C" int eat_dw_conv_dgrad(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F,
-                                 int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
-  eat::clear_stale_error();
+static int dw_dgrad_impl(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T,
+                         int Fo, int To, int k, int stride, int per_plane_w, eat_stream_t stream) {
   int gx = (F * T + 255) / 256;
   if (gx > 64) gx = 64;
   dim3 grid(gx, B * C);
   hipStream_t s = (hipStream_t)stream;
-#define EAT_DG(KK, SS) hipLaunchKernelGGL((dw_dgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, w, res, dx, C, F, T, Fo, To)
+#define EAT_DG(KK, SS) hipLaunchKernelGGL((dw_dgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, w, res, dx, C, F, T, Fo, To, per_plane_w)
   if (k == 3 && stride == 1) EAT_DG(3, 1);
   else if (k == 3 && stride == 2) EAT_DG(3, 2);
   else if (k == 5 && stride == 1) EAT_DG(5, 1);
@@ -448,17 +447,28 @@ extern "C" int eat_dw_conv_dgrad(const float* dz, const float* w, const float* r
   return eat::check_launch("eat_dw_conv_dgrad");
 }
 
-extern "C" int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T,
-                                 int Fo, int To, int k, int stride, eat_stream_t stream) {
+extern "C" int eat_dw_conv_dgrad(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F,
+                                 int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();
+  return dw_dgrad_impl(dz, w, res, dx, B, C, F, T, Fo, To, k, stride, 0, stream);
+}
+
+extern "C" int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const float* res, float* dx, int B, int C,
+                                     int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return dw_dgrad_impl(dz, w_bc, res, dx, B, C, F, T, Fo, To, k, stride, 1, stream);
+}
+
+static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T, int Fo, int To,
+                         int k, int stride, int per_sample, eat_stream_t stream) {
   if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
   // enough blocks to fill the chip: split the batch when there are few channels
   int splits = (2048 + C - 1) / C;
-  if (splits > B) splits = B;
+  if (splits > B || per_sample) splits = B;
   const int bpb = (B + splits - 1) / splits;
   dim3 grid(C, (B + bpb - 1) / bpb);
   hipStream_t s = (hipStream_t)stream;
-#define EAT_WG(KK, SS) hipLaunchKernelGGL((dw_wgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, x, dw, B, C, XC, F, T, Fo, To, bpb)
+#define EAT_WG(KK, SS) hipLaunchKernelGGL((dw_wgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, x, dw, B, C, XC, F, T, Fo, To, bpb, per_sample)
   if (k == 3 && stride == 1) EAT_WG(3, 1);
   else if (k == 3 && stride == 2) EAT_WG(3, 2);
   else if (k == 5 && stride == 1) EAT_WG(5, 1);
@@ -468,14 +478,38 @@ extern "C" int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int
   return eat::check_launch("eat_dw_conv_wgrad");
 }
 
+extern "C" int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T,
+                                 int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return dw_wgrad_impl(dz, x, dw, B, C, XC, F, T, Fo, To, k, stride, 0, stream);
+}
+
+extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T, int Fo,
+                                     int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return dw_wgrad_impl(dz, x, dw_bc, B, C, C, F, T, Fo, To, k, stride, 1, stream);
+}
+
+static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
+                         int per_sample, eat_stream_t stream) {
+  const int tiles = ((Co + 31) / 32) * ((Ci + 31) / 32);
+  int splits = (1024 + tiles - 1) / tiles;
+  if (splits > B || per_sample) splits = B;
+  const int bpb = (B + splits - 1) / splits;
+  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, (B + bpb - 1) / bpb);
+  hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, bpb,
+                     per_sample);
+  return eat::check_launch("eat_pw_conv_wgrad");
+}
+
 extern "C" int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
                                  int Ci, int S, eat_stream_t stream) {
   eat::clear_stale_error();
-  const int tiles = ((Co + 31) / 32) * ((Ci + 31) / 32);
-  int splits = (1024 + tiles - 1) / tiles;
-  if (splits > B) splits = B;
-  const int bpb = (B + splits - 1) / splits;
-  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, (B + bpb - 1) / bpb);
-  hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, bpb);
-  return eat::check_launch("eat_pw_conv_wgrad");
+  return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, stream);
+}
+
+extern "C" int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,
+                                     eat_stream_t stream) {
+  eat::clear_stale_error();
+  return pw_wgrad_impl(dz, x, nullptr, dW_b, B, Co, Ci, S, 1, stream);
 }

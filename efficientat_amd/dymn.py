@@ -19,7 +19,7 @@ a launch plan over libeat_hip.so:
 The reference materialises (B*Cout, Cin/g, k, k) weights and runs a grouped conv with groups*B
 (dy_block.py:111-127).  Sequence-level glue on (B, L, H)-shaped tensors (mean over L, 3-tap average
 pool, softmax over K=4, sigmoid of the DyReLU coefficients) uses torch ops; every pass over a
-feature map and every GEMM runs in the library.  Eval mode only in this round.
+feature map and every GEMM runs in the library.  Train mode: dymn_train.py.
 """
 from functools import partial
 
@@ -152,6 +152,18 @@ class DY_Block(nn.Module):
         self.context_gen = ContextGen(H, cin, cexp, stride=cnf.stride)
 
 
+def _pool3(t, stride):
+    """AvgPool(kernel 3, stride, padding 1, count_include_pad) along dim 1 of a (B, L, H) sequence
+    (ContextGen.pool_f / pool_t, dy_block.py:227-229), written with pad + strided slices so that it
+    stays in the position-major layout (avg_pool1d on the transposed view gave wrong input
+    gradients on ROCm for this non-contiguous layout)."""
+    L = t.shape[1]
+    Lo = (L + 2 - 3) // stride + 1
+    tp = F.pad(t, (0, 0, 1, 1))
+    hi = stride * (Lo - 1)
+    return (tp[:, 0:hi + 1:stride] + tp[:, 1:hi + 2:stride] + tp[:, 2:hi + 3:stride]) / 3.0
+
+
 def _attention(conv, h_c):
     logits = ops.linear(h_c, conv.residuals[0].weight, conv.residuals[0].bias, ops.ACT_NONE)
     return F.softmax(logits / conv.temperature, dim=-1).contiguous()
@@ -242,8 +254,7 @@ class DyMN(nn.Module):
         h_c = g.mean(dim=1)
         h_cf, h_ct = g[:, :Fq], g[:, Fq:]
         if stride > 1:
-            pool = lambda t: F.avg_pool1d(t.transpose(1, 2), 3, stride, 1).transpose(1, 2)
-            h_cf, h_ct = pool(h_cf), pool(h_ct)
+            h_cf, h_ct = _pool3(h_cf, stride), _pool3(h_ct, stride)
         Fo, To = h_cf.shape[1], h_ct.shape[1]
         g_cf = ops.linear(h_cf.reshape(B * Fo, H), cg.conv_f.weight.flatten(1), cg.conv_f.bias, ops.ACT_NONE)
         g_ct = ops.linear(h_ct.reshape(B * To, H), cg.conv_t.weight.flatten(1), cg.conv_t.bias, ops.ACT_NONE)
@@ -268,7 +279,10 @@ class DyMN(nn.Module):
         if not x.is_cuda:
             raise ops._lib.EatHipError("DyMN.forward needs a GPU tensor: efficientat_amd has no CPU path")
         if self.training:
-            raise NotImplementedError("DyMN train-mode forward/backward is not on the HIP path yet")
+            if return_fmaps:
+                raise NotImplementedError("return_fmaps is only available in eval mode on the HIP path")
+            from .dymn_train import forward_train
+            return forward_train(self, x)
         W = self._cache.get(self._fold_sources(), self._build_folded)
         x = x.contiguous().float()
         B = x.shape[0]

@@ -179,6 +179,37 @@ int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const float* bias, co
                         const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
                         int Fo, int To, int k, int stride, eat_stream_t stream);
 
+/* ---- DyMN training step: backward of the dynamic pieces -------------------- */
+
+/* dx (B,C,F,T) = broadcast of dseq (B,F+T,C): dseq[b,f,c]/T + dseq[b,F+t,c]/F, plus add (same shape
+ * as dx) or NULL. */
+int eat_ctx_pool_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T,
+                     eat_stream_t stream);
+
+/* Stand-alone DyReLU-B + CoordAtt (train mode, after the BatchNorm statistics are known):
+ * out = max(a1 v + b1, a2 v + b2) * sigmoid(gate_f) * sigmoid(gate_t), v = a_c z + b_c (a,b NULL: v=z);
+ * the backward returns dv (same shape as z), dcoef (B,C,4), and the PRE-sigmoid gate gradients. */
+int eat_dyrelu_ca_fwd(const float* z, const float* a, const float* b, const float* coef,
+                      const float* gate_f, const float* gate_t, float* out, int B, int C, int Fo, int To,
+                      eat_stream_t stream);
+int eat_dyrelu_ca_bwd(const float* dout, const float* z, const float* a, const float* b, const float* coef,
+                      const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
+                      float* dgate_t, int B, int C, int Fo, int To, eat_stream_t stream);
+
+/* From the per-sample weight gradients G (B,N): dbank (K,N) = att^T G, datt (B,K) += G bank^T
+ * (datt zeroed by the caller). */
+int eat_dyn_bank_grad(const float* G, const float* att, const float* bank, float* dbank, float* datt,
+                      int B, int K, int N, eat_stream_t stream);
+
+/* Per-sample / per-plane variants of the conv gradients used by the dynamic convs: dW_b (B,Co,Ci)
+ * (zeroed), dw_bc (B,C,k*k) (zeroed), and the depthwise data gradient with per-plane taps. */
+int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,
+                          eat_stream_t stream);
+int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T,
+                          int Fo, int To, int k, int stride, eat_stream_t stream);
+int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const float* res, float* dx, int B, int C,
+                          int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,132 @@ def test_dymn10_eval_matches_oracle_and_reference(golden_dir):
     assert (np.abs(logits.cpu().numpy() - g["eval_logits"]) / scale).max() < 1e-3
     assert (np.abs(logits2.cpu().numpy() - g["eval_logits"]) / scale).max() < 1e-3
     assert feat.shape == (5, 960)
+
+
+# ----------------------------------------------------------------------------- training step
+def test_dyrelu_coordatt_backward():
+    from efficientat_amd.dymn_train import DyReluCoordAtt
+    B, C, Fo, To = 3, 24, 8, 63
+    v, coef = _rand(B, C, Fo, To, seed=1), _rand(B, C, 4, seed=2)
+    gf, gt, dout = _rand(B, Fo, C, seed=3), _rand(B, To, C, seed=4), _rand(B, C, Fo, To, seed=5)
+    ts = [t.clone().requires_grad_(True) for t in (v, coef, gf, gt)]
+    c = ts[1][:, :, None, None, :]
+    ref = torch.maximum(ts[0] * c[..., 0] + c[..., 2], ts[0] * c[..., 1] + c[..., 3])
+    ref = ref * torch.sigmoid(ts[2].permute(0, 2, 1))[:, :, :, None] * torch.sigmoid(ts[3].permute(0, 2, 1))[:, :, None, :]
+    ref.backward(dout)
+    td = [t.detach().to(DEV).requires_grad_(True) for t in (v, coef, gf, gt)]
+    out = DyReluCoordAtt.apply(*td)
+    out.backward(dout.to(DEV))
+    assert _rel(out, ref) < 5e-6
+    for a, b in zip(td, ts):
+        assert _rel(a.grad, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("kind", ["pw", "dw"])
+def test_dynamic_conv_backward(kind):
+    from efficientat_amd.dymn_train import DynDwConv, DynPwConv
+    B, K = 3, 4
+    if kind == "pw":
+        Ci, Co, Fq, T = 24, 40, 8, 63
+        x, w = _rand(B, Ci, Fq, T, seed=1), _rand(1, 1, K, Co * Ci, seed=2, scale=Ci ** -0.5)
+    else:
+        C, Fq, T, k, s = 24, 16, 125, 5, 2
+        x, w = _rand(B, C, Fq, T, seed=1), _rand(1, 1, K, C * k * k, seed=2, scale=0.3)
+    att = torch.softmax(_rand(B, K, seed=3), dim=-1)
+    xr, wr, ar = (t.clone().requires_grad_(True) for t in (x, w, att))
+    agg = ar @ wr[0, 0]
+    if kind == "pw":
+        y = torch.stack([F.conv2d(xr[b:b + 1], agg[b].view(Co, Ci, 1, 1))[0] for b in range(B)])
+    else:
+        y = F.conv2d(xr.reshape(1, B * C, Fq, T), agg.reshape(B * C, 1, k, k), None, s, (k - 1) // 2, 1, B * C)
+        y = y.reshape(B, C, *y.shape[2:])
+    dz = _rand(*y.shape, seed=4)
+    y.backward(dz)
+    xd, wd, ad = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, att))
+    out = DynPwConv.apply(xd, wd, ad, Co) if kind == "pw" else DynDwConv.apply(xd, wd, ad, k, s)
+    out.backward(dz.to(DEV))
+    assert _rel(out, y) < 5e-6
+    assert _rel(xd.grad, xr.grad) < 2e-5 and _rel(wd.grad, wr.grad) < 2e-5 and _rel(ad.grad, ar.grad) < 2e-5
+
+
+def test_dymn10_train_step_matches_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "dymn10_ref.npz"))
+    sd = synth.synth_state(synth.dymn_shapes(1.0), seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    temp = float(g["temp_train"])
+    x = O.mel_forward(synth.parity_clips(320000, seed=1234)).unsqueeze(1)
+    y = torch.from_numpy(g["train_labels"])
+    keep = torch.from_numpy(g["drop_keep"].astype(np.float32))
+    skip = ("running_mean", "running_var", "num_batches_tracked", "lambdas", "init_v")
+    sdr = {k: (v.clone().requires_grad_(True) if not k.endswith(skip) else v.clone()) for k, v in sd.items()}
+    stats = {}
+    logits_ref, _ = O.dymn_forward(sdr, x, temperature=temp, train=True, stats=stats, drop_mask=keep)
+    F.binary_cross_entropy_with_logits(logits_ref, y).backward()
+
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd)
+    for m in model.modules():
+        if hasattr(m, "temperature"):
+            m.temperature = temp
+    model.to(DEV).train()
+    model._drop_mask_override = keep
+    logits, emb = model(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(g["train_loss"])) < 2e-5              # vs the unmodified reference
+    assert np.abs(logits.detach().cpu().numpy() - g["train_logits"]).max() < 1e-3
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    rels, bad = [], []
+    for name, p in model.named_parameters():
+        ref = sdr[name].grad
+        assert p.grad is not None, name
+        if float(ref.norm()) < 1e-4 * gmax:      # zero-gradient BN biases, cancellation-dominated attention logits
+            continue
+        r = _rel(p.grad, ref)
+        rels.append(r)
+        if r > 5e-2:
+            bad.append((name, r))
+    assert not bad, bad[:8]
+    assert float(np.median(rels)) < 1e-2
+    msd = model.state_dict()
+    for k, v in stats.items():
+        assert _rel(msd[k], v) < 1e-4, k
+
+
+@pytest.mark.parametrize("i,Fq,T", [(0, 64, 500), (1, 64, 500), (3, 32, 250), (5, 16, 125), (12, 8, 63), (13, 4, 32)])
+def test_dy_block_train_forward_backward(i, Fq, T):
+    """One DY_Block in train mode (stride 1 and 2, with/without expand, with/without residual): output,
+    input gradient and every parameter gradient vs torch-CPU autograd over the oracle block."""
+    from efficientat_amd.dymn_train import _block_train
+    sd = synth.synth_state(synth.dymn_shapes(1.0), seed=0)
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    blocks, _ = O.block_table(1.0)
+    c, B, temp = blocks[i], 3, 30.0
+    H = O.context_dim(c["cexp"], 1.0)
+    x = _rand(B, c["cin"], Fq, T, seed=i)
+    skip = ("running_mean", "running_var", "num_batches_tracked", "lambdas", "init_v")
+    sdr = {k: (v.clone().requires_grad_(True) if not k.endswith(skip) else v.clone())
+           for k, v in sd.items() if k.startswith(f"layers.{i}.")}
+    xr = x.clone().requires_grad_(True)
+    out_ref = O._dy_block(sdr, f"layers.{i}", xr, c, H, True, {}, temp)
+    dout = _rand(*out_ref.shape, seed=99)
+    out_ref.backward(dout)
+    blk = model.layers[i]
+    for m in blk.modules():
+        if hasattr(m, "temperature"):
+            m.temperature = temp
+    xd = x.to(DEV).requires_grad_(True)
+    out = _block_train(blk, xd)
+    out.backward(dout.to(DEV))
+    assert _rel(out, out_ref) < 5e-6
+    # random inputs put a few pre-activations next to a ReLU/Hardswish kink: allow 1 % there
+    assert _rel(xd.grad, xr.grad) < 1e-2
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    for n, p in blk.named_parameters():
+        ref = sdr[f"layers.{i}.{n}"].grad
+        if float(ref.norm()) > 1e-4 * gmax:
+            assert _rel(p.grad, ref) < 2e-2, (n, _rel(p.grad, ref))

@@ -98,3 +98,29 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):
         from efficientat_amd.mn import MN
         MN([], 1280)
+
+
+@pytest.mark.parametrize("width,n_params", [(1.0, 10548479), (2.0, 39966143)])
+def test_dymn_state_dict_layout_matches_reference(width, n_params):
+    from efficientat_amd.dymn import get_model as get_dymn
+    model = _quiet(get_dymn, width_mult=width)
+    shapes = synth.dymn_shapes(width)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert sum(p.numel() for p in model.parameters()) == n_params
+    assert [b.context_dim for b in model.layers] == [O.context_dim(c["cexp"], width) for c in O.block_table(width)[0]]
+
+
+def test_dymn_temperature_schedule_and_api():
+    from efficientat_amd.dymn import DynamicConv, get_model as get_dymn
+    m = _quiet(get_dymn, width_mult=0.4, T_max=30.0, T0_slope=1.0, T1_slope=0.02, T_min=1)
+    convs = [c for c in m.modules() if isinstance(c, DynamicConv)]
+    assert len(convs) == 44 and all(c.temperature == 30.0 for c in convs)
+    for epoch in (0, 10, 29, 40, 200):
+        _quiet(m.update_params, epoch)
+        assert abs(convs[0].temperature - O.dyconv_temperature(epoch)) < 1e-9
+    with pytest.raises(NotImplementedError):
+        _quiet(get_dymn, use_dy_blocks="bogus")
+    with pytest.raises(Exception):
+        m.eval()(torch.zeros(1, 1, 128, 100))          # CPU tensor: no fallback
