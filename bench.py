@@ -71,6 +71,11 @@ def _alg_bytes(name, a):
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
         return f"dw_conv_kernel<{k},{s},{act}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
+    if name == "eat_fused_expand_dw_fwd":
+        x, wp, be, wd, bd, y, pool, B, Cin, Cexp, F, T, Fo, To, k, s, act = a[:17]
+        # algorithmic bytes of the TWO layers it replaces (expand out + dw in/out), per SURVEY 8(d)
+        nbytes = 4 * B * (Cin * F * T + 2 * Cexp * F * T + Cexp * Fo * To) + 4 * Cexp * (Cin + k * k)
+        return f"fused_expand_dw_kernel<{k},{s},{act}>", nbytes, 2 * B * Cexp * (Cin * F * T + k * k * Fo * To)
     if name == "eat_stem_conv_fwd":
         x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9
@@ -171,11 +176,26 @@ def train_bench(args, mel, model, wave, dev, dist, world, barrier):
     y = (torch.rand((bt, 527), device=dev, generator=g) < 2.7 / 527).float()
     if world > 1:
         enable_data_parallel(model)
-    opt = torch.optim.Adam(model.parameters(), lr=8e-4)
+    graphed = world == 1 and not args.no_graph
+    opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=graphed)
     model.train()
     mel.train()
+    launch = "eager"
+    if graphed:
+        # the step is launch-bound when issued eagerly (~35 ms of host time for ~500 launches):
+        # capture fwd + loss + bwd + Adam once, replay per step; the mel front-end stays outside
+        try:
+            from efficientat_amd.graphs import GraphedTrainStep
+            gstep = GraphedTrainStep(model, opt, F.binary_cross_entropy_with_logits, mel(w).unsqueeze(1), y)
+            launch = "hipGraph replay (mel eager)"
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] train-step graph capture failed ({e}); eager", file=sys.stderr)
+            graphed = False
+            opt = torch.optim.Adam(model.parameters(), lr=8e-4)
 
     def tstep():
+        if graphed:
+            return gstep(mel(w).unsqueeze(1), y)
         opt.zero_grad(set_to_none=True)
         logits, _ = model(mel(w).unsqueeze(1))
         loss = F.binary_cross_entropy_with_logits(logits, y)
@@ -198,7 +218,7 @@ def train_bench(args, mel, model, wave, dev, dist, world, barrier):
         el = float(t.item())
     cps = world * bt * steps / el
     return {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
-            "batch_per_gpu": bt, "final_loss": round(float(loss), 5),
+            "batch_per_gpu": bt, "final_loss": round(float(loss), 5), "launch": launch,
             "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if world > 1 else "") + "Adam, fp32",
             "roofline_e2e_frac": round(cps / world * 285.8e6 / HBM_PEAK, 4),
             "alg_bytes_per_clip": 285.8e6}

@@ -41,6 +41,9 @@ SIGNATURES = {
     "eat_dyn_pw_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_pw_conv_dyn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dyn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_fused_expand_dw_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_pw_prepack_bf16": [_P, _P, _P, _I, _I, _I, _P],
+    "eat_pw_conv_bf16_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_ctx_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dyrelu_ca_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dyrelu_ca_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

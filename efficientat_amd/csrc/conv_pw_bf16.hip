@@ -1,0 +1,277 @@
+// Pointwise (1x1) convolution on the bf16 matrix cores of gfx950 with fp32 activations in HBM.
+//   v_mfma_f32_16x16x32_bf16 runs at 16x the fp32-input MFMA rate.  Two uses:
+//     NPROD = 3  "bf16x3": x = x_hi + x_lo, w = w_hi + w_lo (each a bf16, round-to-nearest), and
+//                y = w_hi x_hi + w_hi x_lo + w_lo x_hi accumulated in fp32: ~2^-16 relative error per
+//                product at 3/16 of the fp32 MFMA time - for the compute-bound layers of the fp32 model;
+//     NPROD = 1  plain bf16 operands, fp32 accumulation (BASELINE config 3: bf16 compute).
+//   Same call sites as conv_pw.hip (models/mn/block_types.py:138-147,167-171,83,177-181).
+//
+// Structure = conv_pw.hip's: block = 4 waves = (MTW*16 rows) x 256 flattened (b,s) columns, K walked
+// in 32-row chunks through a 2-stage LDS ring filled by LDS-DMA issued from inline asm (so hipcc does
+// not drain the chunk in flight before every ds_read).  Per chunk a lane reads 8 rows x float4 of its
+// 4 columns (ds_read_b128, conflict-free), splits them into bf16 hi/lo with v_cvt_pk_bf16_f32 and
+// feeds 4 n-tiles; A fragments (hi/lo) were packed once on the device (eat_pw_prepack_bf16) so that a
+// fragment is one 16-byte LDS read.  The fp32 epilogue (bias, activation, residual, pooled sums) is
+// the one of conv_pw.hip.
+#include "eat_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kKC = 32;
+constexpr int kTileN = 256;
+
+__device__ __forceinline__ unsigned lds_addr_uniform(void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)p);
+}
+__device__ __forceinline__ void glds16_raw(const void* g, void* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds_addr_uniform(lds_wave_base)), "v"(g) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4_raw(const void* g, void* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+               :: "s"(lds_addr_uniform(lds_wave_base)), "v"(g) : "memory", "m0");
+}
+
+// wp16[((kk*MT + mt)*NP2 + h)*512 + lane*8 + i] = bf16 part h of W[mt*16 + (lane&15)][kk*32 + 8*(lane>>4) + i]
+__global__ void pw_prepack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,
+                                       __bf16* __restrict__ wp, int Co, int Ci, int MT, int NP2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (kk, mt, lane)
+  const int KK = (Ci + 31) / 32;
+  if (t >= KK * MT * 64) return;
+  const int lane = t & 63, mt = (t >> 6) % MT, kk = (t >> 6) / MT;
+  const int m = mt * 16 + (lane & 15), kb = kk * 32 + 8 * (lane >> 4);
+  const float rs = (row_scale && m < Co) ? row_scale[m] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = kb + i;
+    const float v = (m < Co && k < Ci) ? w[(size_t)m * Ci + k] * rs : 0.0f;
+    const __bf16 hi = (__bf16)v;
+    wp[((size_t)(kk * MT + mt) * NP2 + 0) * 512 + lane * 8 + i] = hi;
+    if (NP2 == 2) wp[((size_t)(kk * MT + mt) * NP2 + 1) * 512 + lane * 8 + i] = (__bf16)(v - (float)hi);
+  }
+}
+
+template <int MTW, int NPROD>
+__global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
+    const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
+    float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int NP2 = NPROD == 3 ? 2 : 1;
+  constexpr int kABytes = MTW * NP2 * 1024;                 // A fragments of one chunk
+  constexpr int kXBytes = kKC * kTileN * 4;
+  constexpr int kStage = kABytes + kXBytes + 512;            // + 128 floats of SE scales
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+  const int mchunk = jj % MC, tile = (jj / MC) * 8 + xcd;
+  if (tile >= n_tiles) return;
+  const int mt0 = mchunk * MTW;
+  const int mtw_eff = (MT - mt0) < MTW ? (MT - mt0) : MTW;
+  const long long N = (long long)B * S;
+  const long long n_base = (long long)tile * kTileN;
+  const int b_first = (int)(n_base / S);
+  long long nl = n_base + 4 * lane;
+  if (nl > N - 4) nl = N - 4;
+  const int bl = (int)(nl / S), sl = (int)(nl - (long long)bl * S);
+  const float* xsrc = x + ((size_t)bl * Ci) * S + sl;
+  const long long nc = n_base + 64 * wv + 4 * (lane & 15);
+  const bool col_ok = nc < N;
+  const long long ncc = col_ok ? nc : N - 4;
+  const int bc = (int)(ncc / S), sc_ = (int)(ncc - (long long)bc * S);
+  const int kq = lane >> 4;
+  const int n_chunks = (Ci + kKC - 1) / kKC;
+
+  auto issue = [&](int c) {
+    unsigned char* st = smem_raw + (c & 1) * kStage;
+    const int k0 = c * kKC;
+    const int klen = (Ci - k0) < kKC ? (Ci - k0) : kKC;
+    float* Xs = reinterpret_cast<float*>(st + kABytes);
+#pragma unroll
+    for (int i = 0; i < kKC / 4; ++i) {
+      const int r = wv + 4 * i;
+      const int rc = r < klen ? r : klen - 1;                // padded k: finite data x zero weight
+      glds16_raw(xsrc + (size_t)(k0 + rc) * S, Xs + r * kTileN);
+    }
+#pragma unroll
+    for (int i = 0; i < (MTW * NP2 + 3) / 4; ++i) {
+      int q = wv + 4 * i;                                     // piece = (m-tile, hi/lo): 1 KiB
+      if (q >= MTW * NP2) q = 0;
+      int mt = mt0 + q / NP2;
+      if (mt >= MT) mt = MT - 1;
+      glds16_raw(wp + ((size_t)(c * MT + mt) * NP2 + (q % NP2)) * 512 + lane * 8, st + q * 1024);
+    }
+    if (in_scale) {
+      float* SCs = reinterpret_cast<float*>(st + kABytes + kXBytes);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int e = h * 64 + lane;
+        if (e >= kKC * NS) e = kKC * NS - 1;
+        const int r = e / NS, j = e - r * NS;
+        int bb = b_first + j;
+        if (bb >= B) bb = B - 1;
+        const int rc = r < klen ? r : klen - 1;
+        glds4_raw(in_scale + (size_t)bb * Ci + k0 + rc, SCs + h * 64);
+      }
+    }
+  };
+
+  f32x4 acc[MTW][4];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int c = 0; c < n_chunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk c landed; stage (c+1)&1 is free
+    if (c + 1 < n_chunks) issue(c + 1);
+    const unsigned char* st = smem_raw + (c & 1) * kStage;
+    const float* Xw = reinterpret_cast<const float*>(st + kABytes) + (8 * kq) * kTileN + 64 * wv + 4 * (lane & 15);
+    const float* SCs = reinterpret_cast<const float*>(st + kABytes + kXBytes) + (8 * kq) * NS + (bc - b_first);
+    float4 xr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4*>(Xw + i * kTileN);
+    if (in_scale) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = SCs[i * NS];
+        xr[i].x *= s; xr[i].y *= s; xr[i].z *= s; xr[i].w *= s;
+      }
+    }
+    bf16x8 bh[4], bl_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const float v0 = j == 0 ? xr[i].x : j == 1 ? xr[i].y : j == 2 ? xr[i].z : xr[i].w;
+        const float v1 = j == 0 ? xr[i + 1].x : j == 1 ? xr[i + 1].y : j == 2 ? xr[i + 1].z : xr[i + 1].w;
+        const bf16x2 h = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
+        bh[j][i] = h[0]; bh[j][i + 1] = h[1];
+        if constexpr (NPROD == 3) {
+          const bf16x2 l = __builtin_convertvector(f32x2{v0 - (float)h[0], v1 - (float)h[1]}, bf16x2);
+          bl_[j][i] = l[0]; bl_[j][i + 1] = l[1];
+        }
+      }
+    }
+    const bf16x8* Af = reinterpret_cast<const bf16x8*>(st) + lane;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const bf16x8 ah = Af[(i * NP2) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+      if constexpr (NPROD == 3) {
+        const bf16x8 al = Af[(i * NP2 + 1) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl_[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue (as conv_pw.hip): row m = (mt0+i)*16 + kq*4 + r, columns nc .. nc+3 of sample bc
+  bool group_one_sample = true;
+  if (pool) {
+    const int b_lo = __shfl(bc, lane & ~15, 64), b_hi = __shfl(bc, lane | 15, 64);
+    group_one_sample = (b_lo == b_hi);
+  }
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    if (i >= mtw_eff) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (mt0 + i) * 16 + kq * 4 + r;
+      const bool ok = col_ok && m < Co;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float bm = bias[m];
+        v = make_float4(eat::activate_rt(acc[i][0][r] + bm, act), eat::activate_rt(acc[i][1][r] + bm, act),
+                        eat::activate_rt(acc[i][2][r] + bm, act), eat::activate_rt(acc[i][3][r] + bm, act));
+        const size_t off = ((size_t)bc * Co + m) * S + sc_;
+        if (res) {
+          const float4 rv = *reinterpret_cast<const float4*>(res + off);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (y) *reinterpret_cast<float4*>(y + off) = v;
+      }
+      if (pool) {
+        float ps = v.x + v.y + v.z + v.w;
+        if (group_one_sample) {
+          ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
+          ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
+          if ((lane & 15) == 0 && m < Co) atomicAdd(pool + (size_t)bc * Co + m, ps);
+        } else if (ok) {
+          atomicAdd(pool + (size_t)bc * Co + m, ps);
+        }
+      }
+    }
+  }
+}
+
+template <int MTW, int NPROD>
+int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
+           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act) {
+  const long long N = (long long)B * S;
+  const int n_tiles = (int)((N + kTileN - 1) / kTileN);
+  int NS = kTileN / S + 2;
+  if (NS > B) NS = B;
+  if (!in_scale) NS = 0;
+  if (kKC * NS > 128) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: plane of %d positions too small for the scale slot", S);
+  constexpr int NP2 = NPROD == 3 ? 2 : 1;
+  const size_t smem = 2 * (size_t)(MTW * NP2 * 1024 + kKC * kTileN * 4 + 512);
+  auto kern = pw_conv_bf16_kernel<MTW, NPROD>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_pw_conv_bf16_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+  }
+  const int tiles8 = (n_tiles + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
+                     n_tiles, NS, act);
+  return eat::check_launch("eat_pw_conv_bf16_fwd");
+}
+
+template <int NPROD>
+int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
+             float* y, float* pool, int B, int Ci, int Co, int S, int act) {
+  const int MT = (Co + 15) / 16;
+  const int MC = (MT + 7) / 8;
+  const int mtw = (MT + MC - 1) / MC;
+#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act);
+  switch (mtw) {
+    EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
+    default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
+  }
+#undef EAT_CASE
+}
+
+}  // namespace
+
+extern "C" int eat_pw_prepack_bf16(const float* w, const float* row_scale, void* wp, int Co, int Ci, int split,
+                                   eat_stream_t stream) {
+  eat::clear_stale_error();
+  const int MT = (Co + 15) / 16, KK = (Ci + 31) / 32;
+  const int total = KK * MT * 64;
+  hipLaunchKernelGGL(pw_prepack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, row_scale,
+                     reinterpret_cast<__bf16*>(wp), Co, Ci, MT, split ? 2 : 1);
+  return eat::check_launch("eat_pw_prepack_bf16");
+}
+
+extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, const float* in_scale,
+                                    const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
+                                    int split, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Ci % 4 != 0 || S % 4 != 0)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: bad act %d", act);
+  const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
+  hipStream_t s = (hipStream_t)stream;
+  return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act)
+               : dispatch<1>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act);
+}

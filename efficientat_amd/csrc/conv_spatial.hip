@@ -60,6 +60,9 @@ struct DwDyn {
   const float* coef;    // (B*C, 4): a1, a2, b1, b2
   const float* gate_f;  // (B, Fo, C) pre-sigmoid
   const float* gate_t;  // (B, To, C) pre-sigmoid
+  const float* res;     // (B, C, Fo, To) added to the output, or NULL
+  int flip;             // read the taps reversed: the stride-1 data gradient is a correlation with flipped taps
+  int per_plane_w;      // taps indexed by (b,c) plane instead of channel
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     const int c = gp % C;
     float wr[K * K];
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)(DY ? gp : c) * K * K + i];
-    const float bc = bias[c];
+    for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)(dyn.per_plane_w ? gp : c) * K * K + (dyn.flip ? K * K - 1 - i : i)];
+    const float bc = bias ? bias[c] : 0.0f;
     float a1 = 1.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, sgt = 1.f;
     const float* gfp = nullptr;
     const bool dy_epi = DY && dyn.coef != nullptr;      // coef == NULL: per-plane taps only (train mode:
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
             for (int v = 0; v < K; ++v) acc = fmaf(wr[u * K + v], win[(u + R * STRIDE) % NSLOT][v], acc);
           float o = eat::activate<ACT>(acc);
           if (dy_epi) o = fmaxf(fmaf(a1, o, b1), fmaf(a2, o, b2)) * (sigmoidf_(gfp[(size_t)fo * C]) * sgt);
+          if (dyn.res) o += dyn.res[(size_t)gp * Fo * To + (size_t)fo * To + to];
           yp[(size_t)fo * To] = o;
           psum += o;
         }
@@ -160,7 +164,7 @@ int launch_dw(const float* x, const float* w, const float* bias, float* y, float
                        n_planes, C, F, T, Fo, To, TX, *dyn);
   } else {
     EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT, false>), grid, dim3(256), 0, stream, x, w,
-                                             bias, y, pool, n_planes, C, F, T, Fo, To, TX, DwDyn{nullptr, nullptr, nullptr}));
+                                             bias, y, pool, n_planes, C, F, T, Fo, To, TX, DwDyn{nullptr, nullptr, nullptr, nullptr, 0, 0}));
   }
   return eat::check_launch("eat_dw_conv_fwd");
 }
@@ -197,10 +201,19 @@ extern "C" int eat_dw_conv_fwd(const float* x, const float* w, const float* bias
   return dispatch_dw(x, w, bias, y, pool, B, C, F, T, Fo, To, k, stride, act, nullptr, (hipStream_t)stream);
 }
 
+// stride-1 depthwise data gradient = the same sliding-window kernel with the taps read reversed
+namespace eat {
+int dw_conv_dgrad_s1(const float* dz, const float* w, const float* zero_bias, const float* res, float* dx, int B, int C,
+                     int F, int T, int k, int per_plane_w, hipStream_t s) {
+  const DwDyn dyn{nullptr, nullptr, nullptr, res, 1, per_plane_w};
+  return dispatch_dw(dz, w, zero_bias, dx, nullptr, B, C, F, T, F, T, k, 1, EAT_ACT_NONE, &dyn, s);
+}
+}  // namespace eat
+
 extern "C" int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const float* bias, const float* coef,
                                    const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
                                    int Fo, int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();
-  const DwDyn dyn{coef, gate_f, gate_t};
+  const DwDyn dyn{coef, gate_f, gate_t, nullptr, 0, 1};
   return dispatch_dw(x, w_bc, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
 }

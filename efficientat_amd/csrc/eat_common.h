@@ -43,6 +43,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kWave = 64;
 
+// conv_spatial.hip: stride-1 depthwise data gradient on the forward sliding-window kernel
+int dw_conv_dgrad_s1(const float* dz, const float* w, const float* zero_bias, const float* res, float* dx, int B, int C,
+                     int F, int T, int k, int per_plane_w, hipStream_t s);
+
 }  // namespace eat
 
 #define EAT_DISPATCH_ACT(act, ...)                                    \

@@ -6,7 +6,7 @@
 // Mapping: one wavefront (64 lanes) per frame.  The 1024 real samples are packed as 512
 // complex points; three radix-8 Stockham passes (8 points per lane, in registers) exchange
 // through a private LDS buffer of the wave, so the FFT needs no workgroup barrier.  A block of
-// 4 waves produces 32 consecutive frames and stages its (n_mels x 32) output tile in LDS so
+// 4 waves produces 16 consecutive frames and stages its (n_mels x 16) output tile in LDS so
 // the store to out (B, n_mels, T) is coalesced along the time axis.
 #include "eat_common.h"
 
@@ -14,7 +14,7 @@ namespace {
 
 constexpr int kNfft = 1024;
 constexpr int kHalf = 512;        // complex points
-constexpr int kFramesPerBlock = 32;
+constexpr int kFramesPerBlock = 16;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBufStride = kHalf + kHalf / 8;  // padded: idx + idx/8 (breaks the stride-8 store conflict)
 
@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* s_tw = reinterpret_cast<float2*>(smem);                          // [1024]
   float2* s_buf = s_tw + kNfft;                                            // [4][kBufStride]
-  float* s_pow = reinterpret_cast<float*>(s_buf + kWavesPerBlock * kBufStride);  // [4][512]
-  float* s_win = s_pow + kWavesPerBlock * kHalf;                           // [1024] zero-padded window
+  float* s_win = reinterpret_cast<float*>(s_buf + kWavesPerBlock * kBufStride);  // [1024] zero-padded window
   float* s_bw = s_win + kNfft;                                             // [band_len][n_mels]
   int* s_bs = reinterpret_cast<int*>(s_bw + band_len * n_mels);            // [n_mels]
   float* s_out = reinterpret_cast<float*>(s_bs + n_mels);                  // [n_mels][33]
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
   const float* x = wave + (size_t)b * L;
   const int Lp = L - 1;  // length of the pre-emphasised signal
   float2* buf = s_buf + wv * kBufStride;
-  float* pw = s_pow + wv * kHalf;
+  float* pw = reinterpret_cast<float*>(buf);     // power spectrum aliases the wave's FFT buffer
 
   // Raw samples of one frame: lane holds frame positions n = 2*(lane + 64 r) + e as (x[j], x[j+1])
   // with j the reflect-padded index into the pre-emphasised signal.  All 32 loads are
@@ -155,6 +154,8 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
         wave_lds_fence();
       }
       // unpack the real FFT and take the power:  X[k] = E[k] + w^k O[k]
+      // (the power spectrum overwrites the front of this wave's FFT buffer: read everything first)
+      float pk[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int k = lane + 64 * m;
@@ -163,8 +164,11 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
         const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
         const float2 xk = cadd(e, cmul(s_tw[k], o));
-        pw[k] = xk.x * xk.x + xk.y * xk.y;
+        pk[m] = xk.x * xk.x + xk.y * xk.y;
       }
+      wave_lds_fence();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) pw[lane + 64 * m] = pk[m];
       wave_lds_fence();
       // banded mel filterbank + log + masking + normalisation
       for (int m = lane; m < n_mels; m += 64) {
@@ -204,7 +208,7 @@ extern "C" int eat_mel_fwd(const float* wave, int B, int L, const float* window,
   if (L - 1 <= n_fft / 2) return eat::fail(EAT_EINVAL, "eat_mel_fwd: clip too short for reflect padding (L=%d)", L);
   if (T != 1 + (L - 1) / hop) return eat::fail(EAT_EINVAL, "eat_mel_fwd: T=%d does not match L=%d hop=%d", T, L, hop);
   size_t smem = sizeof(float2) * (kNfft + kWavesPerBlock * kBufStride) +
-                sizeof(float) * (kWavesPerBlock * kHalf + kNfft + (size_t)band_len * n_mels) +
+                sizeof(float) * (kNfft + (size_t)band_len * n_mels) +
                 sizeof(int) * n_mels + sizeof(float) * (size_t)n_mels * (kFramesPerBlock + 1);
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_mel_fwd: mel table too large for LDS (%zu B)", smem);
   if (smem > 64 * 1024) {

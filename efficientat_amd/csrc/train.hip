@@ -239,6 +239,59 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
   }
 }
 
+// ---- depthwise data gradient, stride 2, sliding form: one thread per dx column j walking down the
+// rows; only the taps whose parity matches contribute (<= ceil(K/2)^2 loads per element instead of
+// K*K predicated iterations), lanes on consecutive j read dz at half stride (coalesced).
+template <int K>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                          const float* __restrict__ res, float* __restrict__ dx,
+                                                          int n_planes, int C, int F, int T, int Fo, int To,
+                                                          int per_plane_w) {
+  constexpr int P = (K - 1) / 2;
+  constexpr int NV = (K + 1) / 2;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int plane = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (plane >= n_planes || j >= T) return;
+  const int c = plane % C;
+  float wr[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)(per_plane_w ? plane : c) * K * K + i];
+  // taps of this column: v = v0 + 2q with (j + P - v) even
+  const int v0 = (j + P) & 1;
+  int jo[NV];
+  bool jok[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int v = v0 + 2 * q;
+    jo[q] = (j + P - v) >> 1;
+    jok[q] = v < K && (j + P - v) >= 0 && jo[q] < To;
+    if (!jok[q]) jo[q] = 0;
+  }
+  const float* g = dz + (size_t)plane * Fo * To;
+  const size_t base = (size_t)plane * F * T + j;
+  for (int i = 0; i < F; ++i) {
+    const int u0 = (i + P) & 1;
+    float acc = res ? res[base + (size_t)i * T] : 0.0f;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int u = u0 + 2 * p;
+      const int ii = i + P - u;
+      const int io = ii >> 1;
+      if (u < K && ii >= 0 && io < Fo) {
+        const float* row = g + (size_t)io * To;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int v = v0 + 2 * q;
+          const float gv = jok[q] ? row[jo[q]] : 0.0f;
+          const float wv = (v < K) ? wr[(u < K ? u : 0) * K + (v < K ? v : 0)] : 0.0f;
+          acc = fmaf(wv, gv, acc);
+        }
+      }
+    }
+    dx[base + (size_t)i * T] = acc;
+  }
+}
+
 // ---- depthwise / stem weight gradient: dw[c,u,v] = sum_{b,i,j} dz[b,c,i,j] x[b,cx,i*s+u-p,j*s+v-p] -------
 // One block per (channel, batch slice); x has XC channels (XC == C depthwise, XC == 1 stem).
 template <int K, int STRIDE>
@@ -433,10 +486,19 @@ extern "C" int eat_plane_dot(const float* u, const float* v, const float* a, con
 
 static int dw_dgrad_impl(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T,
                          int Fo, int To, int k, int stride, int per_plane_w, eat_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (stride == 1 && (k == 3 || k == 5)) {
+    return eat::dw_conv_dgrad_s1(dz, w, nullptr, res, dx, B, C, F, T, k, per_plane_w, s);
+  }
+  if (stride == 2 && (k == 3 || k == 5)) {
+    dim3 g2((T + 63) / 64, (B * C + 3) / 4);
+    if (k == 3) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3>), g2, dim3(256), 0, s, dz, w, res, dx, B * C, C, F, T, Fo, To, per_plane_w);
+    else hipLaunchKernelGGL((dw_dgrad_s2_kernel<5>), g2, dim3(256), 0, s, dz, w, res, dx, B * C, C, F, T, Fo, To, per_plane_w);
+    return eat::check_launch("eat_dw_conv_dgrad");
+  }
   int gx = (F * T + 255) / 256;
   if (gx > 64) gx = 64;
   dim3 grid(gx, B * C);
-  hipStream_t s = (hipStream_t)stream;
 #define EAT_DG(KK, SS) hipLaunchKernelGGL((dw_dgrad_kernel<KK, SS>), grid, dim3(256), 0, s, dz, w, res, dx, C, F, T, Fo, To, per_plane_w)
   if (k == 3 && stride == 1) EAT_DG(3, 1);
   else if (k == 3 && stride == 2) EAT_DG(3, 2);

@@ -13,6 +13,7 @@ a fused launch plan over libeat_hip.so:
 Eval-mode BatchNorm is folded into the conv weights (cached, re-folded when a parameter or
 buffer changes).  There is no CPU path: CPU tensors raise.
 """
+import os
 from functools import partial
 from typing import List, Optional
 
@@ -23,6 +24,13 @@ from . import ops
 from .utils import make_divisible, cnn_out_size, NAME_TO_WIDTH  # noqa: F401
 
 BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
+# Stride-2 blocks whose input has at most this many channels run expand+depthwise fused
+# (csrc/fused_block.hip); measured on MI355X the fusion only pays there (blocks 2 and 4 of mn10:
+# 0.99 vs 1.18 ms, 0.47 vs 0.51 ms) - elsewhere the per-16-channel re-read of the input patch and the
+# recomputed halo cost more than the expanded tensor's round trip through HBM.  0 disables (A/B switch).
+_FUSE_MAX_CIN = int(os.environ.get("EAT_FUSE_MAX_CIN", "24"))
+# arithmetic of the 1x1 convs in eval: fp32 | bf16x3 | bf16 | auto (see _pw_mode)
+_PW_MODE = os.environ.get("EAT_PW_MODE", "fp32")
 model_url = "https://github.com/fschmid56/EfficientAT/releases/download/v0.0.1/"
 model_dir = "resources"
 
@@ -138,6 +146,31 @@ def _fold(conv, bn):
     return scale, bn.bias - bn.running_mean * scale
 
 
+def _pw_mode(Co, Ci):
+    """Arithmetic of a 1x1 layer: 'fp32' (exact fp32 MFMA), 'bf16x3' (split bf16, fp32-class accuracy)
+    or 'bf16' (plain bf16 operands).  EAT_PW_MODE=auto picks bf16x3 for the K-heavy project layers
+    (Ci >= 512), the only ones where it measured faster than the fp32 MFMA kernel on MI355X
+    (960->160: 82 vs 133 us, 672->112: 156 vs 210 us at B=256); logit error 4e-5 vs 7e-6."""
+    if _PW_MODE == "auto":
+        return "bf16x3" if Ci >= 512 else "fp32"
+    return _PW_MODE
+
+
+def _pack_pw(w2d, scale, bias):
+    """(packed weights, bias, mode) of one BN-folded 1x1 layer."""
+    mode = _pw_mode(*w2d.shape)
+    if mode == "fp32":
+        return ops.pw_prepack(w2d, scale), bias, mode
+    return ops.pw_prepack_bf16(w2d, scale, split=(mode == "bf16x3")), bias, mode
+
+
+def _pw(x, pack, Co, act, **kw):
+    wp, bias, mode = pack
+    if mode == "fp32":
+        return ops.pw_conv(x, wp, bias, Co, act, **kw)
+    return ops.pw_conv_bf16(x, wp, bias, Co, act, mode == "bf16x3", **kw)
+
+
 class _FoldCache:
     """Folded / packed weights keyed on the version counters of their source tensors."""
 
@@ -212,18 +245,18 @@ class MN(nn.Module):
             if blk.i_expand is not None:
                 cna = blk.block[blk.i_expand]
                 s, b = _fold(cna[0], cna[1])
-                d["exp"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
+                d["exp"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
             cna = blk.block[blk.i_dw]
             s, b = _fold(cna[0], cna[1])
             k = blk.cnf.kernel
             d["dw"] = ((cna[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, k * k).contiguous(), b.contiguous())
             cna = blk.block[blk.i_proj]
             s, b = _fold(cna[0], cna[1])
-            d["proj"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
+            d["proj"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
             out[i] = d
         last = self.features[-1]
         s, b = _fold(last[0], last[1])
-        out["last"] = (ops.pw_prepack(last[0].weight.flatten(1), s.contiguous()), b.contiguous())
+        out["last"] = _pack_pw(last[0].weight.flatten(1), s.contiguous(), b.contiguous())
         return out
 
     # --------------------------------------------------------------------------- forward
@@ -259,24 +292,31 @@ class MN(nn.Module):
             cnf, w = blk.cnf, W[i]
             act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
             inp = x
-            if blk.i_expand is not None:
-                x = ops.pw_conv(x, w["exp"][0], w["exp"][1], cnf.expanded_channels, act)
             pool = scale = None
             if blk.i_se is not None:
                 pool = take(cnf.expanded_channels)
-            x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
+            # early, bandwidth-bound blocks: expand + depthwise in one kernel, the expanded tensor stays
+            # on chip (csrc/fused_block.hip); late blocks are MFMA-bound and keep the two kernels
+            if (blk.i_expand is not None and cnf.stride == 2 and cnf.input_channels <= _FUSE_MAX_CIN
+                    and not return_fmaps and w["exp"][2] == "fp32"):
+                x = ops.fused_expand_dw(x, w["exp"][0], w["exp"][1], w["dw"][0], w["dw"][1], cnf.expanded_channels,
+                                        cnf.kernel, cnf.stride, act, pool)
+            else:
+                if blk.i_expand is not None:
+                    x = _pw(x, w["exp"], cnf.expanded_channels, act)
+                x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
             if pool is not None:
                 se = blk.block[blk.i_se].conc_se_layers[0]
                 inv_s = 1.0 / (x.shape[2] * x.shape[3])
                 h = ops.linear(pool, se.fc1.weight, se.fc1.bias, ops.ACT_RELU, inv_s)
                 scale = ops.linear(h, se.fc2.weight, se.fc2.bias, ops.ACT_SIGMOID)
-            x = ops.pw_conv(x, w["proj"][0], w["proj"][1], cnf.out_channels, ops.ACT_NONE, in_scale=scale,
+            x = _pw(x, w["proj"], cnf.out_channels, ops.ACT_NONE, in_scale=scale,
                             res=inp if blk.use_res_connect else None)
             if return_fmaps:
                 fmaps.append(x)
         pooled = take(c_feat)
         S = x.shape[2] * x.shape[3]
-        y = ops.pw_conv(x, W["last"][0], W["last"][1], c_feat, ops.ACT_HSWISH, pool=pooled, write=return_fmaps)
+        y = _pw(x, W["last"], c_feat, ops.ACT_HSWISH, pool=pooled, write=return_fmaps)
         if return_fmaps:
             fmaps.append(y)
         fc1, fc2 = self.classifier[2], self.classifier[5]

@@ -205,3 +205,33 @@ def dw_conv_dyn(x, w_bc, bias, coef, gate_f, gate_t, k, stride):
     _lib.call("eat_dw_conv_dyn_fwd", _dev(x, "x"), _dev(w_bc, "w_bc"), _dev(bias, "bias"), _dev(coef, "coef"),
               _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), y.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
     return y
+
+
+def fused_expand_dw(x, wp_e, bias_e, w_d, bias_d, Cexp, k, stride, act, pool=None):
+    """expand 1x1 + BN + act -> depthwise k x k + BN + act in one kernel (eval; early blocks)."""
+    B, Cin, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    y = torch.empty((B, Cexp, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_fused_expand_dw_fwd", _dev(x, "x"), _dev(wp_e, "wp_e"), _dev(bias_e, "bias_e"), _dev(w_d, "w_d"),
+              _dev(bias_d, "bias_d"), y.data_ptr(), _opt(pool, "pool"), B, Cin, Cexp, F, T, Fo, To, k, stride, act,
+              _stream())
+    return y
+
+
+def pw_prepack_bf16(w2d, row_scale=None, split=True):
+    Co, Ci = w2d.shape
+    n = ((Ci + 31) // 32) * ((Co + 15) // 16) * (2 if split else 1) * 512
+    wp = torch.empty((n,), device=w2d.device, dtype=torch.bfloat16)
+    _lib.call("eat_pw_prepack_bf16", _dev(w2d, "w"), _opt(row_scale, "row_scale"), wp.data_ptr(), Co, Ci,
+              1 if split else 0, _stream())
+    return wp
+
+
+def pw_conv_bf16(x, wp16, bias, Co, act, split=True, in_scale=None, res=None, pool=None, write=True):
+    """1x1 conv on the bf16 matrix cores (split=True: bf16x3, fp32-class accuracy; False: plain bf16)."""
+    B, Ci, F, T = x.shape
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32) if write else None
+    _lib.call("eat_pw_conv_bf16_fwd", _dev(x, "x"), wp16.data_ptr(), _dev(bias, "bias"), _opt(in_scale, "in_scale"),
+              _opt(res, "res"), None if y is None else y.data_ptr(), _opt(pool, "pool"), B, Ci, Co, F * T, act,
+              1 if split else 0, _stream())
+    return y

@@ -210,6 +210,26 @@ int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, 
 int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const float* res, float* dx, int B, int C,
                           int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
 
+/* ---- fused expand 1x1 + depthwise k x k (eval): models/mn/block_types.py:138-162 (+ :72-73) ------
+ * y (B,Cexp,Fo,To) = act(dw_k,s( act(W_e x + bias_e) ) + bias_d) without materialising the expanded
+ * tensor: wp_e = eat_pw_prepack of the BN-folded expand weights, w_d (Cexp,k*k) BN-folded taps;
+ * pool (B,Cexp) or NULL accumulates plane sums (zeroed by the caller).  act in {relu, hswish}. */
+int eat_fused_expand_dw_fwd(const float* x, const float* wp_e, const float* bias_e, const float* w_d,
+                            const float* bias_d, float* y, float* pool, int B, int Cin, int Cexp, int F,
+                            int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream);
+
+/* ---- 1x1 conv on the bf16 matrix cores (fp32 activations in memory, fp32 accumulation) -----------
+ * split != 0: "bf16x3" - x and w are split into bf16 hi + lo parts and y = w_hi x_hi + w_hi x_lo +
+ *             w_lo x_hi (~2^-16 relative error per product) at 3/16 of the fp32-MFMA time;
+ * split == 0: plain bf16 operands (BASELINE config 3, bf16 compute).
+ * wp from eat_pw_prepack_bf16: ceil(Ci/32)*ceil(Co/16)*(split?2:1)*512 bf16 values.  Other arguments
+ * as eat_pw_conv_fwd. */
+int eat_pw_prepack_bf16(const float* w, const float* row_scale, void* wp, int Co, int Ci, int split,
+                        eat_stream_t stream);
+int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, const float* in_scale,
+                         const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
+                         int split, eat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

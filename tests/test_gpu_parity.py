@@ -223,3 +223,45 @@ def test_cpu_tensor_fails_loudly():
     model = _quiet(get_model, width_mult=0.1).eval()
     with pytest.raises(Exception):
         model(torch.zeros(1, 1, 128, 100))
+
+
+@pytest.mark.parametrize("B,Ci,Ce,F_,T,k,s,act", [
+    (2, 16, 64, 64, 500, 3, 2, 1), (2, 24, 72, 32, 250, 3, 1, 1), (2, 24, 72, 32, 250, 5, 2, 1),
+    (3, 40, 120, 16, 125, 5, 1, 1), (3, 40, 240, 16, 125, 3, 2, 2), (2, 8, 24, 9, 21, 5, 2, 2), (1, 12, 40, 5, 7, 3, 1, 1)])
+def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
+    """expand 1x1 + act -> depthwise + act fused (csrc/fused_block.hip) vs the two-step torch reference."""
+    x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
+    be, rs = _rand(Ce, seed=3, scale=0.2), torch.rand(Ce, generator=torch.Generator().manual_seed(4)) + 0.5
+    wd, bd = _rand(Ce, 1, k, k, seed=5, scale=0.3), _rand(Ce, seed=6, scale=0.1)
+    f = [None, F.relu, F.hardswish][act]
+    e = f(F.conv2d(x, (we * rs[:, None]).view(Ce, Ci, 1, 1), be))
+    ref = f(F.conv2d(e, wd, bd, s, (k - 1) // 2, 1, Ce))
+    pool = torch.zeros(B, Ce, device=DEV)
+    got = ops.fused_expand_dw(x.to(DEV), ops.pw_prepack(we.to(DEV), rs.to(DEV)), be.to(DEV),
+                              wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), Ce, k, s, act, pool)
+    _close(got, ref, 5e-6, "fused expand+dw")
+    _close(pool, ref.sum(dim=(2, 3)), 5e-5, "fused pool")
+
+
+@pytest.mark.parametrize("split,tol", [(True, 3e-5), (False, 1.5e-2)])
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act,se,res", [
+    (3, 80, 200, 8, 63, 2, False, False), (3, 184, 80, 8, 63, 0, False, True), (3, 112, 672, 8, 63, 2, False, False),
+    (4, 672, 160, 4, 32, 0, True, False), (4, 160, 960, 4, 32, 2, False, False), (5, 960, 160, 4, 32, 0, True, True),
+    (2, 40, 240, 16, 125, 2, False, False), (2, 24, 72, 32, 250, 1, False, False), (2, 72, 40, 16, 125, 0, True, False)])
+def test_pw_conv_bf16(B, Ci, Co, F_, T, act, se, res, split, tol):
+    """bf16x3 (split) must be fp32-class; plain bf16 within bf16 round-off (config 3 compute dtype)."""
+    x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
+    bias, rs = _rand(Co, seed=3, scale=0.1), torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5
+    sc = torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) if se else None
+    r = _rand(B, Co, F_, T, seed=6) if res else None
+    xs = x * sc[:, :, None, None] if se else x
+    ref = F.conv2d(xs.double(), (w * rs[:, None]).double().view(Co, Ci, 1, 1), bias.double()).float()
+    ref = [ref, F.relu(ref), F.hardswish(ref)][act]
+    if res:
+        ref = ref + r
+    wp = ops.pw_prepack_bf16(w.to(DEV), rs.to(DEV), split)
+    pool = torch.zeros(B, Co, device=DEV)
+    got = ops.pw_conv_bf16(x.to(DEV), wp, bias.to(DEV), Co, act, split, in_scale=None if sc is None else sc.to(DEV),
+                           res=None if r is None else r.to(DEV), pool=pool)
+    _close(got, ref, tol, f"pw bf16 split={split}")
+    _close(pool, ref.sum(dim=(2, 3)), 20 * tol, "pw bf16 pool")
