@@ -172,6 +172,23 @@ def train_bench(args, mel, model, wave, dev, dist, world, barrier):
     from efficientat_amd.dp import enable_data_parallel
     bt = min(args.train_batch, wave.shape[0])
     w = wave[:bt]
+    alg = 285.8e6                                    # SURVEY 8(d) train-step bytes per clip, mn10 fp32
+    if args.train_model != "mn10":                   # BASELINE configs 3 / 4 (parity cases, timed on request)
+        torch.manual_seed(0)
+        if args.train_model.startswith("dymn"):
+            from efficientat_amd.dymn import get_model as gm
+            model = quiet(gm, width_mult=2.0 if args.train_model == "dymn20" else 1.0).to(dev)
+            alg = 324.6e6 if args.train_model == "dymn20" else None
+        else:
+            from efficientat_amd.mn import get_model as gm
+            model = quiet(gm, width_mult=4.0).to(dev)
+            model.train_precision = "bf16" if args.train_model.endswith("bf16") else "fp32"
+            alg = 581.5e6
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.Conv2d):
+                    fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                    m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
     g = torch.Generator(device=dev).manual_seed(99)
     y = (torch.rand((bt, 527), device=dev, generator=g) < 2.7 / 527).float()
     if world > 1:
@@ -220,14 +237,17 @@ def train_bench(args, mel, model, wave, dev, dist, world, barrier):
     return {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
             "batch_per_gpu": bt, "final_loss": round(float(loss), 5), "launch": launch,
             "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if world > 1 else "") + "Adam, fp32",
-            "roofline_e2e_frac": round(cps / world * 285.8e6 / HBM_PEAK, 4),
-            "alg_bytes_per_clip": 285.8e6}
+            "model": args.train_model,
+            "roofline_e2e_frac": round(cps / world * alg / HBM_PEAK, 4) if alg else None,
+            "alg_bytes_per_clip": alg}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-train", action="store_true", help="skip the train-step measurement")
     ap.add_argument("--train-batch", type=int, default=128, help="clips per GPU per train step")
+    ap.add_argument("--train-model", default="mn10", choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20"],
+                    help="network of the train-step measurement (mn40_bf16 / dymn20 = BASELINE configs 3 / 4)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)

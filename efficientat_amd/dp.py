@@ -72,5 +72,40 @@ def enable_data_parallel(model, process_group=None, bucket_bytes=4 << 20, broadc
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t, src=0, group=process_group)
-    model._grad_reducer = GradReducer(process_group, bucket_bytes)
+    reducer = GradReducer(process_group, bucket_bytes)
+    if getattr(model, "_monolithic_backward", False):
+        # MN: the single backward Function pushes gradients itself as it produces them (mn_train.py)
+        model._grad_reducer = reducer
+    else:
+        # DyMN and any autograd-driven module: per-parameter post-accumulate hooks feed the same
+        # bucketed reducer; a callback queued on the autograd engine averages at the end of backward
+        install_grad_hooks(model, reducer)
+    return model
+
+
+def install_grad_hooks(model, reducer):
+    names = {p: n for n, p in model.named_parameters()}
+    state = {"pending": False}
+
+    def finalize():
+        out = reducer.finish()
+        state["pending"] = False
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                g = out.get(n)
+                if g is not None and g.data_ptr() != p.grad.data_ptr():
+                    p.grad.copy_(g)
+
+    def hook(p):
+        if reducer.world == 1:
+            return
+        if not state["pending"]:
+            state["pending"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(finalize)
+        reducer.push(names[p], p.grad)
+
+    for p in model.parameters():
+        if p.requires_grad:
+            p.register_post_accumulate_grad_hook(hook)
+    model._grad_hooks_reducer = reducer
     return model

@@ -228,6 +228,8 @@ class MN(nn.Module):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.zeros_(m.bias)
         self._cache = _FoldCache()
+        self._monolithic_backward = True      # train-mode backward is one autograd Function (mn_train.py)
+        self.train_precision = "fp32"         # "bf16": 1x1 convs of the train step on the bf16 matrix cores
 
     # ------------------------------------------------------------------ folded weights
     def _fold_sources(self):

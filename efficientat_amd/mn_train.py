@@ -147,6 +147,11 @@ class MNTrainFunction(torch.autograd.Function):
     def backward(ctx, dlogits, dfeat):
         model, sv = ctx.model, ctx.saved
         ctx.saved = None
+        with ops.precision(getattr(model, "train_precision", "fp32")):
+            return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat)
+
+    @staticmethod
+    def _backward_impl(ctx, model, sv, dlogits, dfeat):
         # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
         # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
         g = _GradSink(getattr(model, "_grad_reducer", None) or GradReducer())
@@ -262,4 +267,5 @@ def forward_train(model, x):
     if override is not None:
         mask = override.to(x.device).float() / (1.0 - drop.p)
     params = [p for _, p in model.named_parameters()]
-    return MNTrainFunction.apply(model, x, mask, *params)
+    with ops.precision(getattr(model, "train_precision", "fp32")):
+        return MNTrainFunction.apply(model, x, mask, *params)

@@ -235,3 +235,37 @@ def pw_conv_bf16(x, wp16, bias, Co, act, split=True, in_scale=None, res=None, po
               _opt(res, "res"), None if y is None else y.data_ptr(), _opt(pool, "pool"), B, Ci, Co, F * T, act,
               1 if split else 0, _stream())
     return y
+
+
+# ------------------------------------------------------------------ precision switch (training plans)
+class precision:
+    """Context manager selecting the arithmetic of the 1x1 convs issued through pw_prepack/pw_conv:
+    'fp32' (exact fp32 MFMA, default) or 'bf16' (plain bf16 operands on v_mfma_f32_16x16x32_bf16, fp32
+    accumulation and fp32 activations in memory - BASELINE config 3)."""
+    mode = "fp32"
+
+    def __init__(self, mode):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError(f"unknown precision {mode!r}")
+        self.new = mode
+
+    def __enter__(self):
+        self.old, precision.mode = precision.mode, self.new
+
+    def __exit__(self, *exc):
+        precision.mode = self.old
+
+
+_pw_prepack_fp32, _pw_conv_fp32 = pw_prepack, pw_conv
+
+
+def pw_prepack(w2d, row_scale=None):  # noqa: F811
+    if precision.mode == "bf16":
+        return pw_prepack_bf16(w2d, row_scale, split=False)
+    return _pw_prepack_fp32(w2d, row_scale)
+
+
+def pw_conv(x, wp, bias, Co, act, in_scale=None, res=None, pool=None, write=True):  # noqa: F811
+    if wp.dtype == torch.bfloat16:
+        return pw_conv_bf16(x, wp, bias, Co, act, False, in_scale=in_scale, res=res, pool=pool, write=write)
+    return _pw_conv_fp32(x, wp, bias, Co, act, in_scale=in_scale, res=res, pool=pool, write=write)

@@ -58,3 +58,36 @@ def test_grad_reducer_single_process_passthrough():
     red.push("w", t)
     out = red.finish()
     assert out["w"] is t and red.finish() == {}
+
+
+def _hook_worker(rank, world, port, ret):
+    """Autograd-driven module (the DyMN path): post-accumulate hooks -> bucketed reducer -> averaged .grad"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from efficientat_amd.dp import enable_data_parallel
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 5))
+        enable_data_parallel(net, bucket_bytes=2 << 10)
+        x = torch.randn(8, 20, generator=torch.Generator().manual_seed(10 + rank))
+        net(x).square().mean().backward()
+        mine = [p.grad.clone() for p in net.parameters()]
+        # reference: every rank recomputes all ranks' local gradients and averages them
+        ref = [torch.zeros_like(p) for p in net.parameters()]
+        for r in range(world):
+            net2 = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 5))
+            net2.load_state_dict(net.state_dict())
+            xr = torch.randn(8, 20, generator=torch.Generator().manual_seed(10 + r))
+            net2(xr).square().mean().backward()
+            for a, p in zip(ref, net2.parameters()):
+                a += p.grad / world
+        ret[rank] = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(mine, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_hooks_world2_gloo():
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_hook_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
