@@ -32,6 +32,20 @@ def _t(x):
     return x.t().contiguous()
 
 
+_ones = {}
+
+
+def _col_sum(m):
+    """Column sums of a (R, C) matrix as a 1 x R times R x C product on the MFMA linear kernel.
+    (torch's multi-block `sum(0)` returned stray non-finite entries when replayed inside a captured
+    hipGraph at R >= ~1000 on ROCm 7.0 / torch 2.10; this keeps the bias gradients on our own kernels.)"""
+    R = m.shape[0]
+    one = _ones.get((R, m.device))
+    if one is None:
+        one = _ones[(R, m.device)] = torch.ones((1, R), device=m.device, dtype=torch.float32)
+    return ops.linear(one, _t(m), None, NONE).view(-1)
+
+
 # ------------------------------------------------------------------------------- Functions
 class CtxPool(torch.autograd.Function):
     @staticmethod
@@ -62,7 +76,8 @@ class Linear(torch.autograd.Function):
         dy = dy.contiguous()
         dx = ops.linear(dy, _t(w), None, NONE)
         dw = ops.linear(_t(dy), _t(x), None, NONE)
-        return dx, dw, dy.sum(0) if ctx.has_bias else None
+        db = _col_sum(dy) if ctx.has_bias else None
+        return dx, dw, db
 
 
 class BnAct(torch.autograd.Function):
