@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12                      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK = 2.5e15                 # FLOP/s, dense bf16 MFMA (no sparsity), same guide
 MFMA_F32_PEAK = 157.3e12               # FLOP/s, dense fp32-input MFMA (= fp32 vector peak), same guide
 CLIP_SAMPLES = 320000                  # 10 s @ 32 kHz
 ALG_BYTES_PER_CLIP = 96.37e6           # mn10 fwd 94.50 MB + weights/B + mel 1.79 MB
@@ -68,6 +69,13 @@ def _alg_bytes(name, a):
         pipe = "true" if 16 * ns <= 64 else "false"
         nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + 4 * Co * Ci
         return f"pw_conv_kernel<{mtw},{pipe}>", nbytes, 2 * B * S * Ci * Co
+    if name == "eat_pw_conv_bf16_fwd":
+        x, wp, bias, sc, res, y, pool, B, Ci, Co, S, act, split = a[:13]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + (4 if split else 2) * Co * Ci
+        return f"pw_conv_bf16_kernel<{mtw},{3 if split else 1}>", nbytes, 2 * B * S * Ci * Co
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
         return f"dw_conv_kernel<{k},{s},{act}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
@@ -350,8 +358,13 @@ def main():
         if os.path.exists(tpath):
             k = json.load(open(tpath))["kernels"].get(name.replace(" ", ""))
             traffic = k["hbm_bytes_per_launch"] if k else None
-        # which roof binds this kernel: the larger of its HBM time and its fp32-MFMA time
-        mfma_bound = per_launch_flops / MFMA_F32_PEAK > per_launch_bytes / HBM_PEAK
+        # which roof binds this kernel: the larger of its HBM time and its MFMA time.  The MFMA peak is the
+        # one of the instruction the kernel issues: fp32 16x16x4 (157 TF), bf16 16x16x32 (2.5 PF dense), and
+        # for the bf16x3 split kernel 2.5 PF / 3 because each useful product costs three bf16 MFMAs.
+        mfma_peak = MFMA_F32_PEAK
+        if name.startswith("pw_conv_bf16_kernel"):
+            mfma_peak = MFMA_BF16_PEAK / (3 if name.endswith(",3>") else 1)
+        mfma_bound = per_launch_flops / mfma_peak > per_launch_bytes / HBM_PEAK
         common = {"kernel": name, "traffic": traffic, "launches_per_step": d["launches"],
                   "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_bytes_per_launch": int(per_launch_bytes),
                   "alg_flops_per_launch": int(per_launch_flops),
@@ -361,8 +374,8 @@ def main():
                   "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
         if mfma_bound:
             ach = per_launch_flops / per_launch_s
-            result["roofline"] = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12,
-                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), **common}
+            result["roofline"] = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": round(mfma_peak / 1e12, 1),
+                                  "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4), **common}
         else:
             ach = per_launch_bytes / per_launch_s
             result["roofline"] = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9,

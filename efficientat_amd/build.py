@@ -14,7 +14,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
-    deps = [src, os.path.join(CSRC, "eat_common.h"), os.path.join(HERE, "..", "include", "eat_hip.h")]
+    deps = [src, os.path.join(HERE, "..", "include", "eat_hip.h")] + [
+        os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 
 

@@ -18,6 +18,7 @@
 // it to MFMA n-tile j, so in the C/D layout lane l holds, for a fixed row, 4 consecutive columns:
 // the epilogue (bias, activation, residual, pooled sums) loads/stores float4.
 #include "eat_common.h"
+#include "pw_epilogue.h"
 
 namespace {
 
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
   const int mchunk = jj % MC, tile = (jj / MC) * 8 + xcd;
   if (tile >= n_tiles) return;
   const int mt0 = mchunk * MTW;
-  const int mtw_eff = (MT - mt0) < MTW ? (MT - mt0) : MTW;
   // tps == 0: the N axis is the flattened (sample, position) axis and tiles may straddle samples.
   // tps  > 0: per-sample weights (DyMN dynamic conv, models/dymn/dy_block.py:111-127): a tile lies
   //           inside one sample (tps tiles per sample) and reads that sample's packed weights.
@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  __shared__ float s_bias[128];
+  eat::pw_stage_bias(bias, s_bias, mt0, Co, wv, lane);    // older than every chunk: landed when chunk 0 is
   issue(0);
   if (PIPE && n_chunks > 1) issue(1);
   for (int c = 0; c < n_chunks; ++c) {
@@ -236,43 +238,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     }
   }
 
-  // epilogue: row m = (mt0+i)*16 + kq*4 + r, columns nc .. nc+3 of sample bc
-  bool group_one_sample = true;
-  if (pool) {
-    const int b_lo = __shfl(bc, lane & ~15, 64), b_hi = __shfl(bc, lane | 15, 64);
-    group_one_sample = (b_lo == b_hi);
-  }
-#pragma unroll
-  for (int i = 0; i < MTW; ++i) {
-    if (i >= mtw_eff) break;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = (mt0 + i) * 16 + kq * 4 + r;
-      const bool ok = col_ok && m < Co;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        const float bm = bias[m];
-        v = make_float4(eat::activate_rt(acc[i][0][r] + bm, act), eat::activate_rt(acc[i][1][r] + bm, act),
-                        eat::activate_rt(acc[i][2][r] + bm, act), eat::activate_rt(acc[i][3][r] + bm, act));
-        const size_t off = ((size_t)bc * Co + m) * S + sc_;
-        if (res) {
-          const float4 rv = *reinterpret_cast<const float4*>(res + off);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
-        if (y) *reinterpret_cast<float4*>(y + off) = v;
-      }
-      if (pool) {
-        float ps = v.x + v.y + v.z + v.w;
-        if (group_one_sample) {
-          ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
-          ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
-          if ((lane & 15) == 0 && m < Co) atomicAdd(pool + (size_t)bc * Co + m, ps);
-        } else if (ok) {
-          atomicAdd(pool + (size_t)bc * Co + m, ps);
-        }
-      }
-    }
-  }
+  eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
 }
 
 // y (M,N) = act((x (M,K) * xs) . w (N,K)^T + bias): both operands K-contiguous; each lane loads 4

@@ -14,6 +14,7 @@
 // fragment is one 16-byte LDS read.  The fp32 epilogue (bias, activation, residual, pooled sums) is
 // the one of conv_pw.hip.
 #include "eat_common.h"
+#include "pw_epilogue.h"
 
 namespace {
 
@@ -72,7 +73,6 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   const int mchunk = jj % MC, tile = (jj / MC) * 8 + xcd;
   if (tile >= n_tiles) return;
   const int mt0 = mchunk * MTW;
-  const int mtw_eff = (MT - mt0) < MTW ? (MT - mt0) : MTW;
   const long long N = (long long)B * S;
   const long long n_base = (long long)tile * kTileN;
   const int b_first = (int)(n_base / S);
@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  __shared__ float s_bias[128];
+  eat::pw_stage_bias(bias, s_bias, mt0, Co, wv, lane);
   issue(0);
   for (int c = 0; c < n_chunks; ++c) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk c landed; stage (c+1)&1 is free
@@ -176,43 +178,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     }
   }
 
-  // epilogue (as conv_pw.hip): row m = (mt0+i)*16 + kq*4 + r, columns nc .. nc+3 of sample bc
-  bool group_one_sample = true;
-  if (pool) {
-    const int b_lo = __shfl(bc, lane & ~15, 64), b_hi = __shfl(bc, lane | 15, 64);
-    group_one_sample = (b_lo == b_hi);
-  }
-#pragma unroll
-  for (int i = 0; i < MTW; ++i) {
-    if (i >= mtw_eff) break;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = (mt0 + i) * 16 + kq * 4 + r;
-      const bool ok = col_ok && m < Co;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        const float bm = bias[m];
-        v = make_float4(eat::activate_rt(acc[i][0][r] + bm, act), eat::activate_rt(acc[i][1][r] + bm, act),
-                        eat::activate_rt(acc[i][2][r] + bm, act), eat::activate_rt(acc[i][3][r] + bm, act));
-        const size_t off = ((size_t)bc * Co + m) * S + sc_;
-        if (res) {
-          const float4 rv = *reinterpret_cast<const float4*>(res + off);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
-        if (y) *reinterpret_cast<float4*>(y + off) = v;
-      }
-      if (pool) {
-        float ps = v.x + v.y + v.z + v.w;
-        if (group_one_sample) {
-          ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
-          ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
-          if ((lane & 15) == 0 && m < Co) atomicAdd(pool + (size_t)bc * Co + m, ps);
-        } else if (ok) {
-          atomicAdd(pool + (size_t)bc * Co + m, ps);
-        }
-      }
-    }
-  }
+  eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
 }
 
 template <int MTW, int NPROD>

@@ -1,0 +1,131 @@
+// Shared epilogue of the 1x1-convolution kernels (conv_pw.hip, conv_pw_bf16.hip):
+//   y = act(acc + bias) [+ residual], optional plane sums (SE squeeze / global average pool).
+// Replaces the tail of models/mn/block_types.py:138-147,167-171,177-181 (BN affine folded into the
+// weights, activation, residual add) and the pooling of models/mn/model.py:220.
+//
+// Written so that the stores stream: gfx9 counts loads and stores on the same in-order vmcnt, so a
+// load whose result is needed right away also waits for every store issued before it.  The bias
+// values of the block's rows are therefore staged in LDS before the main loop (pw_stage_bias: an
+// LDS-DMA that rides in front of the first k-chunk), the activation is branch-free (uniform
+// coefficients instead of a switch), and the residual of m-tile i+1 is requested before the stores of
+// m-tile i are issued.
+#pragma once
+#include "eat_common.h"
+
+namespace eat {
+
+using acc_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct ActCoef { float lo, a, b; };
+
+// act(v) = max(v, lo) * clamp(v*a + b, 0, 1):  none (-inf, 0, 1), ReLU (0, 0, 1), Hardswish (-inf, 1/6, 1/2)
+__device__ __forceinline__ ActCoef act_coef(int act) {
+  ActCoef c;
+  c.lo = act == EAT_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+  c.a = act == EAT_ACT_HSWISH ? (1.0f / 6.0f) : 0.0f;
+  c.b = act == EAT_ACT_HSWISH ? 0.5f : 1.0f;
+  return c;
+}
+__device__ __forceinline__ float act_apply(float v, const ActCoef& c) {
+  return fmaxf(v, c.lo) * __builtin_amdgcn_fmed3f(fmaf(v, c.a, c.b), 0.0f, 1.0f);
+}
+
+// Lane layout (both kernels): lane owns rows m = (mt0+i)*16 + kq*4 + r (i < MTW, r < 4) and the 4
+// consecutive columns starting at position sc_ of sample bc; acc[i][j][r] is column j of row r.
+// Every wave DMAs 64 of the block's (at most 128) bias values into s_bias; issue it BEFORE the first
+// k-chunk so that the chunk's own wait + barrier also publishes the bias.
+typedef __attribute__((address_space(3))) void epi_lds_void;
+__device__ __forceinline__ void pw_stage_bias(const float* __restrict__ bias, float* s_bias, int mt0, int Co, int wv,
+                                              int lane) {
+  const int half = wv & 1;
+  int m = mt0 * 16 + half * 64 + lane;
+  if (m >= Co) m = Co - 1;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(epi_lds_void*)(s_bias + half * 64));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(bias + m) : "memory", "m0");
+}
+
+template <int MTW>
+__device__ __forceinline__ void pw_epilogue(const acc_f32x4 (&acc)[MTW][4], const float* s_bias,
+                                            const float* __restrict__ res, float* __restrict__ y,
+                                            float* __restrict__ pool, int mt0, int kq, int lane, bool col_ok, int bc,
+                                            int sc_, int Co, int S, int act) {
+  const ActCoef ac = act_coef(act);
+  const size_t plane = (size_t)S;
+  const size_t base = (size_t)bc * Co * plane + sc_;
+  auto value = [&](int i, int r) {
+    const float bm = s_bias[i * 16 + kq * 4 + r];
+    return make_float4(act_apply(acc[i][0][r] + bm, ac), act_apply(acc[i][1][r] + bm, ac),
+                       act_apply(acc[i][2][r] + bm, ac), act_apply(acc[i][3][r] + bm, ac));
+  };
+  auto row_of = [&](int i, int r) { return (mt0 + i) * 16 + kq * 4 + r; };
+
+  if (!pool) {
+    if (res) {
+      float4 rv[4], rn[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = row_of(0, r);
+        rv[r] = *reinterpret_cast<const float4*>(res + base + (size_t)(m < Co ? m : Co - 1) * plane);
+      }
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        if (i + 1 < MTW) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = row_of(i + 1, r);
+            rn[r] = *reinterpret_cast<const float4*>(res + base + (size_t)(m < Co ? m : Co - 1) * plane);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = row_of(i, r);
+          float4 v = value(i, r);
+          v.x += rv[r].x; v.y += rv[r].y; v.z += rv[r].z; v.w += rv[r].w;
+          if (col_ok && m < Co) *reinterpret_cast<float4*>(y + base + (size_t)m * plane) = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rn[r];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = row_of(i, r);
+          if (col_ok && m < Co) *reinterpret_cast<float4*>(y + base + (size_t)m * plane) = value(i, r);
+        }
+    }
+    return;
+  }
+
+  // pooled variant (head conv: y may be NULL, the plane sums are the product)
+  const int b_lo = __shfl(bc, lane & ~15, 64), b_hi = __shfl(bc, lane | 15, 64);
+  const bool group_one_sample = (b_lo == b_hi);
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = row_of(i, r);
+      const bool ok = col_ok && m < Co;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        v = value(i, r);
+        const size_t off = base + (size_t)m * plane;
+        if (res) {
+          const float4 q = *reinterpret_cast<const float4*>(res + off);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (y) *reinterpret_cast<float4*>(y + off) = v;
+      }
+      float ps = v.x + v.y + v.z + v.w;
+      if (group_one_sample) {
+        ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64);
+        ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
+        if ((lane & 15) == 0 && m < Co) atomicAdd(pool + (size_t)bc * Co + m, ps);
+      } else if (ok) {
+        atomicAdd(pool + (size_t)bc * Co + m, ps);
+      }
+    }
+}
+
+}  // namespace eat

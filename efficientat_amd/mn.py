@@ -30,7 +30,7 @@ BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
 # recomputed halo cost more than the expanded tensor's round trip through HBM.  0 disables (A/B switch).
 _FUSE_MAX_CIN = int(os.environ.get("EAT_FUSE_MAX_CIN", "24"))
 # arithmetic of the 1x1 convs in eval: fp32 | bf16x3 | bf16 | auto (see _pw_mode)
-_PW_MODE = os.environ.get("EAT_PW_MODE", "fp32")
+_PW_MODE = os.environ.get("EAT_PW_MODE", "auto")
 model_url = "https://github.com/fschmid56/EfficientAT/releases/download/v0.0.1/"
 model_dir = "resources"
 
@@ -147,12 +147,15 @@ def _fold(conv, bn):
 
 
 def _pw_mode(Co, Ci):
-    """Arithmetic of a 1x1 layer: 'fp32' (exact fp32 MFMA), 'bf16x3' (split bf16, fp32-class accuracy)
-    or 'bf16' (plain bf16 operands).  EAT_PW_MODE=auto picks bf16x3 for the K-heavy project layers
-    (Ci >= 512), the only ones where it measured faster than the fp32 MFMA kernel on MI355X
-    (960->160: 82 vs 133 us, 672->112: 156 vs 210 us at B=256); logit error 4e-5 vs 7e-6."""
+    """Arithmetic of a 1x1 layer in the eval plan: 'fp32' (exact fp32 MFMA 16x16x4), 'bf16x3' (each fp32
+    operand split into two bf16, three bf16 MFMAs, fp32 accumulation: ~2^-16 relative error per product) or
+    'bf16' (plain bf16 operands).  EAT_PW_MODE=auto (default) uses bf16x3 from C_in >= 40 on: those layers
+    are bound by the 157 TFLOP/s fp32 MFMA rate, and the split kernel measured 1.1-2.7x faster on every one
+    of them on MI355X (e.g. 112->672 @ 8x63: 154 vs 206 us, 960->160 @ 4x32: 42 vs 114 us at B=256) at a
+    logit error of ~1e-4 against the 1e-3 bar; the narrow streaming layers (C_in 16/24) stay exact fp32.
+    EAT_PW_MODE=fp32 forces the exact kernel everywhere."""
     if _PW_MODE == "auto":
-        return "bf16x3" if Ci >= 512 else "fp32"
+        return "bf16x3" if Ci >= 40 else "fp32"
     return _PW_MODE
 
 

@@ -169,7 +169,14 @@ def _calibrated_state(golden_dir):
     return sd, g
 
 
-def test_mn10_eval_logits_and_fmaps(golden_dir):
+@pytest.mark.parametrize("pw_mode", ["fp32", "auto"])
+def test_mn10_eval_logits_and_fmaps(golden_dir, pw_mode, monkeypatch):
+    """fp32: every 1x1 on the exact fp32 MFMA kernel (tight per-block bars).  auto (the default plan):
+    bf16x3 split-operand MFMA from C_in >= 40 on - the logits keep the 1e-3 bar of BASELINE.json, the
+    per-block feature maps get a 10x looser internal bar (max over ~1e7 elements of a ~3e-5 sigma)."""
+    from efficientat_amd import mn as mn_mod
+    monkeypatch.setattr(mn_mod, "_PW_MODE", pw_mode)
+    ftol = 1e-3 if pw_mode == "fp32" else 1e-2
     sd, g = _calibrated_state(golden_dir)
     model = _quiet(get_model, width_mult=1.0)
     model.load_state_dict(sd, strict=True)
@@ -186,10 +193,10 @@ def test_mn10_eval_logits_and_fmaps(golden_dir):
     for i, (a, b) in enumerate(zip(fmaps, ref_fmaps)):
         assert a.shape == b.shape
         err = float((a.cpu() - b).abs().max())
-        assert err < 1e-4 * max(1.0, float(b.std())) * 10, f"fmap {i}: {err}"
+        assert err < ftol * max(1.0, float(b.std())), f"fmap {i}: {err}"
     assert float((logits.cpu() - ref_logits).abs().max()) < 1e-3
     assert float((logits2.cpu() - ref_logits).abs().max()) < 1e-3
-    assert float((feat.cpu() - ref_feat).abs().max()) < 1e-4
+    assert float((feat.cpu() - ref_feat).abs().max()) < ftol / 10
     # and against the stored output of the unmodified reference
     assert np.abs(logits.cpu().numpy() - g["eval_logits"]).max() < 1e-3
     # T3: waveform -> logits through the HIP mel
