@@ -84,6 +84,13 @@ def _alg_bytes(name, a):
         # algorithmic bytes of the TWO layers it replaces (expand out + dw in/out), per SURVEY 8(d)
         nbytes = 4 * B * (Cin * F * T + 2 * Cexp * F * T + Cexp * Fo * To) + 4 * Cexp * (Cin + k * k)
         return f"fused_expand_dw_kernel<{k},{s},{act}>", nbytes, 2 * B * Cexp * (Cin * F * T + k * k * Fo * To)
+    if name == "eat_mbconv_fwd":
+        x, wpe, be, wd, bd, wpp, bp, res, y, B, Cin, Cexp, Cout, F, T, Fo, To, k, s, act = a[:20]
+        # algorithmic bytes of the THREE layers it replaces (expand, depthwise, project [+ residual read])
+        nbytes = (4 * B * (Cin * F * T + 2 * Cexp * F * T + 2 * Cexp * Fo * To + Cout * Fo * To * (2 if res else 1))
+                  + 4 * Cexp * (Cin + k * k + Cout))
+        flops = 2 * B * (Cexp * Cin * F * T + Cexp * k * k * Fo * To + Cout * Cexp * Fo * To)
+        return f"mbconv_kernel<{k},{s},{act},proj>", nbytes, flops
     if name == "eat_stem_conv_fwd":
         x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9

@@ -24,13 +24,13 @@ inline int check_launch(const char* what) {
 template <int ACT>
 __device__ __forceinline__ float activate(float v) {
   if constexpr (ACT == EAT_ACT_RELU) return fmaxf(v, 0.0f);
-  if constexpr (ACT == EAT_ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+  if constexpr (ACT == EAT_ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
   return v;
 }
 
 __device__ __forceinline__ float activate_rt(float v, int act) {
   if (act == EAT_ACT_RELU) return fmaxf(v, 0.0f);
-  if (act == EAT_ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+  if (act == EAT_ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
   return v;
 }
 

@@ -24,10 +24,11 @@ from . import ops
 from .utils import make_divisible, cnn_out_size, NAME_TO_WIDTH  # noqa: F401
 
 BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
-# Stride-2 blocks whose input has at most this many channels run expand+depthwise fused
-# (csrc/fused_block.hip); measured on MI355X the fusion only pays there (blocks 2 and 4 of mn10:
-# 0.99 vs 1.18 ms, 0.47 vs 0.51 ms) - elsewhere the per-16-channel re-read of the input patch and the
-# recomputed halo cost more than the expanded tensor's round trip through HBM.  0 disables (A/B switch).
+# Blocks whose input has at most this many channels run as one fused kernel (csrc/mbconv.hip): whole
+# block when it has no SE, expand + depthwise when it has.  Measured on MI355X at B=256 (fused vs separate
+# kernels): mn10 block 2 0.72 vs 1.13 ms, block 3 0.54 vs 0.65, block 4 0.40 vs 0.51; from C_in = 40 on the
+# fused kernel is VALU/MFMA-bound (blocks 5-7: 0.38 vs 0.24, 0.64 vs 0.39 ms) and the separate kernels win.
+# 0 disables (A/B switch).
 _FUSE_MAX_CIN = int(os.environ.get("EAT_FUSE_MAX_CIN", "24"))
 # arithmetic of the 1x1 convs in eval: fp32 | bf16x3 | bf16 | auto (see _pw_mode)
 _PW_MODE = os.environ.get("EAT_PW_MODE", "auto")
@@ -159,6 +160,12 @@ def _pw_mode(Co, Ci):
     return _PW_MODE
 
 
+def _fusable(blk):
+    cnf = blk.cnf
+    return (blk.i_expand is not None and cnf.input_channels <= _FUSE_MAX_CIN and cnf.input_channels % 4 == 0
+            and cnf.expanded_channels % 4 == 0 and cnf.dilation == 1)
+
+
 def _pack_pw(w2d, scale, bias):
     """(packed weights, bias, mode) of one BN-folded 1x1 layer."""
     mode = _pw_mode(*w2d.shape)
@@ -258,6 +265,13 @@ class MN(nn.Module):
             cna = blk.block[blk.i_proj]
             s, b = _fold(cna[0], cna[1])
             d["proj"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
+            if _fusable(blk):
+                # the block kernel (csrc/mbconv.hip) multiplies on the exact fp32 MFMA: its own fp32 packs
+                ce = blk.block[blk.i_expand]
+                se_, be_ = _fold(ce[0], ce[1])
+                d["exp32"] = (ops.pw_prepack(ce[0].weight.flatten(1), se_.contiguous()), be_.contiguous())
+                if blk.i_se is None and blk.cnf.out_channels <= 80:
+                    d["proj32"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
             out[i] = d
         last = self.features[-1]
         s, b = _fold(last[0], last[1])
@@ -300,12 +314,18 @@ class MN(nn.Module):
             pool = scale = None
             if blk.i_se is not None:
                 pool = take(cnf.expanded_channels)
-            # early, bandwidth-bound blocks: expand + depthwise in one kernel, the expanded tensor stays
-            # on chip (csrc/fused_block.hip); late blocks are MFMA-bound and keep the two kernels
-            if (blk.i_expand is not None and cnf.stride == 2 and cnf.input_channels <= _FUSE_MAX_CIN
-                    and not return_fmaps and w["exp"][2] == "fp32"):
-                x = ops.fused_expand_dw(x, w["exp"][0], w["exp"][1], w["dw"][0], w["dw"][1], cnf.expanded_channels,
-                                        cnf.kernel, cnf.stride, act, pool)
+            # early, bandwidth-bound blocks: the whole block (without SE) or expand + depthwise (with SE) in
+            # one kernel, the expanded tensor stays on chip (csrc/mbconv.hip); late blocks are MFMA-bound
+            # and keep the separate kernels
+            if "proj32" in w:
+                x = ops.mbconv(x, *w["exp32"], *w["dw"], *w["proj32"], cnf.expanded_channels, cnf.out_channels,
+                               cnf.kernel, cnf.stride, act, res=inp if blk.use_res_connect else None)
+                if return_fmaps:
+                    fmaps.append(x)
+                continue
+            if "exp32" in w:
+                x = ops.fused_expand_dw(x, *w["exp32"], *w["dw"], cnf.expanded_channels, cnf.kernel, cnf.stride, act,
+                                        pool)
             else:
                 if blk.i_expand is not None:
                     x = _pw(x, w["exp"], cnf.expanded_channels, act)

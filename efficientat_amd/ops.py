@@ -218,6 +218,18 @@ def fused_expand_dw(x, wp_e, bias_e, w_d, bias_d, Cexp, k, stride, act, pool=Non
     return y
 
 
+def mbconv(x, wp_e, bias_e, w_d, bias_d, wp_p, bias_p, Cexp, Cout, k, stride, act, res=None):
+    """Whole inverted-residual block without SE in one kernel (eval; early blocks): expand + depthwise +
+    project (+ residual); wp_e / wp_p are fp32 `pw_prepack` buffers."""
+    B, Cin, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    y = torch.empty((B, Cout, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_mbconv_fwd", _dev(x, "x"), _dev(wp_e, "wp_e"), _dev(bias_e, "bias_e"), _dev(w_d, "w_d"),
+              _dev(bias_d, "bias_d"), _dev(wp_p, "wp_p"), _dev(bias_p, "bias_p"), _opt(res, "res"), y.data_ptr(), B, Cin,
+              Cexp, Cout, F, T, Fo, To, k, stride, act, _stream())
+    return y
+
+
 def pw_prepack_bf16(w2d, row_scale=None, split=True):
     Co, Ci = w2d.shape
     n = ((Ci + 31) // 32) * ((Co + 15) // 16) * (2 if split else 1) * 512

@@ -218,6 +218,17 @@ int eat_fused_expand_dw_fwd(const float* x, const float* wp_e, const float* bias
                             const float* bias_d, float* y, float* pool, int B, int Cin, int Cexp, int F,
                             int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream);
 
+/* ---- whole inverted-residual block without SE (eval): models/mn/block_types.py:138-181 -----------
+ * y (B,Cout,Fo,To) = W_p . act(dw_k,s( act(W_e x + bias_e) ) + bias_d) + bias_p [+ res]; neither the
+ * expanded tensor nor the depthwise output touches HBM.  wp_e / wp_p = eat_pw_prepack of the BN-folded
+ * expand (Cexp,Cin) / project (Cout,Cexp) weights, w_d (Cexp,k*k) BN-folded taps.  res (B,Cout,Fo,To)
+ * or NULL is the residual input (stride 1, Cin == Cout).  Cin % 4 == 0, Cin <= 40, Cout <= 80,
+ * act in {relu, hswish}. */
+int eat_mbconv_fwd(const float* x, const float* wp_e, const float* bias_e, const float* w_d,
+                   const float* bias_d, const float* wp_p, const float* bias_p, const float* res, float* y,
+                   int B, int Cin, int Cexp, int Cout, int F, int T, int Fo, int To, int k, int stride,
+                   int act, eat_stream_t stream);
+
 /* ---- 1x1 conv on the bf16 matrix cores (fp32 activations in memory, fp32 accumulation) -----------
  * split != 0: "bf16x3" - x and w are split into bf16 hi + lo parts and y = w_hi x_hi + w_hi x_lo +
  *             w_lo x_hi (~2^-16 relative error per product) at 3/16 of the fp32-MFMA time;

@@ -236,7 +236,7 @@ def test_cpu_tensor_fails_loudly():
     (2, 16, 64, 64, 500, 3, 2, 1), (2, 24, 72, 32, 250, 3, 1, 1), (2, 24, 72, 32, 250, 5, 2, 1),
     (3, 40, 120, 16, 125, 5, 1, 1), (3, 40, 240, 16, 125, 3, 2, 2), (2, 8, 24, 9, 21, 5, 2, 2), (1, 12, 40, 5, 7, 3, 1, 1)])
 def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
-    """expand 1x1 + act -> depthwise + act fused (csrc/fused_block.hip) vs the two-step torch reference."""
+    """expand 1x1 + act -> depthwise + act fused (csrc/mbconv.hip, SE variant) vs the two-step torch reference."""
     x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
     be, rs = _rand(Ce, seed=3, scale=0.2), torch.rand(Ce, generator=torch.Generator().manual_seed(4)) + 0.5
     wd, bd = _rand(Ce, 1, k, k, seed=5, scale=0.3), _rand(Ce, seed=6, scale=0.1)
@@ -248,6 +248,30 @@ def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
                               wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), Ce, k, s, act, pool)
     _close(got, ref, 5e-6, "fused expand+dw")
     _close(pool, ref.sum(dim=(2, 3)), 5e-5, "fused pool")
+
+
+@pytest.mark.parametrize("B,Ci,Ce,Co,F_,T,k,s,act,res", [
+    (2, 16, 64, 24, 64, 500, 3, 2, 1, False), (2, 24, 72, 24, 32, 250, 3, 1, 1, True), (2, 24, 72, 40, 32, 250, 5, 2, 1, False),
+    (3, 40, 120, 40, 16, 125, 5, 1, 1, True), (3, 40, 240, 80, 16, 125, 3, 2, 2, False), (2, 8, 24, 16, 9, 21, 5, 2, 2, False),
+    (1, 12, 40, 12, 5, 7, 3, 1, 1, True), (2, 16, 72, 24, 33, 70, 3, 1, 2, False)])
+def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
+    """Whole inverted-residual block (expand + depthwise + project [+ residual]) in one kernel
+    (csrc/mbconv.hip) vs the three-step torch reference (models/mn/block_types.py:138-181)."""
+    x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
+    be, rs = _rand(Ce, seed=3, scale=0.2), torch.rand(Ce, generator=torch.Generator().manual_seed(4)) + 0.5
+    wd, bd = _rand(Ce, 1, k, k, seed=5, scale=0.3), _rand(Ce, seed=6, scale=0.1)
+    wpj, bp = _rand(Co, Ce, seed=7, scale=Ce ** -0.5), _rand(Co, seed=8, scale=0.2)
+    rp = torch.rand(Co, generator=torch.Generator().manual_seed(9)) + 0.5
+    f = [None, F.relu, F.hardswish][act]
+    e = f(F.conv2d(x.double(), (we * rs[:, None]).double().view(Ce, Ci, 1, 1), be.double()))
+    d = f(F.conv2d(e, wd.double(), bd.double(), s, (k - 1) // 2, 1, Ce))
+    ref = F.conv2d(d, (wpj * rp[:, None]).double().view(Co, Ce, 1, 1), bp.double())
+    if res:
+        ref = ref + x.double()
+    got = ops.mbconv(x.to(DEV), ops.pw_prepack(we.to(DEV), rs.to(DEV)), be.to(DEV),
+                     wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), ops.pw_prepack(wpj.to(DEV), rp.to(DEV)),
+                     bp.to(DEV), Ce, Co, k, s, act, res=x.to(DEV) if res else None)
+    _close(got, ref.float(), 1e-5, "mbconv block")
 
 
 @pytest.mark.parametrize("split,tol", [(True, 3e-5), (False, 1.5e-2)])
