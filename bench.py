@@ -91,6 +91,12 @@ def _alg_bytes(name, a):
                   + 4 * Cexp * (Cin + k * k + Cout))
         flops = 2 * B * (Cexp * Cin * F * T + Cexp * k * k * Fo * To + Cout * Cexp * Fo * To)
         return f"mbconv_kernel<{k},{s},{act},proj>", nbytes, flops
+    if name == "eat_front_fwd":
+        x, ws, bs, wd, bd, wpp, bp, y, B, C, F, T, Fo, To, act = a[:15]
+        # algorithmic bytes of the three layers it replaces: stem (in + out), depthwise (in + out),
+        # project (in + out + residual read)
+        nbytes = 4 * B * (F * T + 6 * C * Fo * To) + 4 * C * (9 + 9 + C)
+        return f"front_kernel<{act}>", nbytes, 2 * B * C * Fo * To * (9 + 9 + C)
     if name == "eat_stem_conv_fwd":
         x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9

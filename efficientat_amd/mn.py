@@ -30,6 +30,8 @@ BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
 # fused kernel is VALU/MFMA-bound (blocks 5-7: 0.38 vs 0.24, 0.64 vs 0.39 ms) and the separate kernels win.
 # 0 disables (A/B switch).
 _FUSE_MAX_CIN = int(os.environ.get("EAT_FUSE_MAX_CIN", "24"))
+# stem + first block as one kernel (csrc/front.hip); 0 disables (A/B switch)
+_FUSE_FRONT = int(os.environ.get("EAT_FUSE_FRONT", "1"))
 # arithmetic of the 1x1 convs in eval: fp32 | bf16x3 | bf16 | auto (see _pw_mode)
 _PW_MODE = os.environ.get("EAT_PW_MODE", "auto")
 model_url = "https://github.com/fschmid56/EfficientAT/releases/download/v0.0.1/"
@@ -273,6 +275,12 @@ class MN(nn.Module):
                 if blk.i_se is None and blk.cnf.out_channels <= 80:
                     d["proj32"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
             out[i] = d
+        b0 = self.features[1]
+        if (_FUSE_FRONT and stem[0].out_channels == 16 and b0.i_expand is None and b0.i_se is None and b0.use_res_connect
+                and b0.cnf.kernel == 3 and b0.cnf.stride == 1):
+            cna = b0.block[b0.i_proj]
+            s, b = _fold(cna[0], cna[1])
+            out["front"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
         last = self.features[-1]
         s, b = _fold(last[0], last[1])
         out["last"] = _pack_pw(last[0].weight.flatten(1), s.contiguous(), b.contiguous())
@@ -304,10 +312,19 @@ class MN(nn.Module):
             off += B * c
             return t
 
-        x = ops.stem_conv(x, *W["stem"], ops.ACT_HSWISH)
-        if return_fmaps:
-            fmaps.append(x)
+        first = 0
+        if "front" in W and not return_fmaps:
+            # stem + first block in one kernel (csrc/front.hip): the 16 x 64 x 500 stem map never leaves the CU
+            c0 = blocks[0].cnf
+            x = ops.front(x, *W["stem"], *W[0]["dw"], *W["front"], ops.ACT_HSWISH if c0.use_hs else ops.ACT_RELU)
+            first = 1
+        else:
+            x = ops.stem_conv(x, *W["stem"], ops.ACT_HSWISH)
+            if return_fmaps:
+                fmaps.append(x)
         for i, blk in enumerate(blocks):
+            if i < first:
+                continue
             cnf, w = blk.cnf, W[i]
             act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
             inp = x

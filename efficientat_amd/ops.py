@@ -218,6 +218,18 @@ def fused_expand_dw(x, wp_e, bias_e, w_d, bias_d, Cexp, k, stride, act, pool=Non
     return y
 
 
+def front(x, w_s, bias_s, w_d, bias_d, wp_p, bias_p, act):
+    """Stem conv + BN + Hardswish and the first (expand-less, SE-less) block in one kernel (eval)."""
+    B, _, F, T = x.shape
+    C = w_s.shape[0]
+    Fo, To = conv_out(F, 3, 2), conv_out(T, 3, 2)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_front_fwd", _dev(x, "x"), _dev(w_s, "w_s"), _dev(bias_s, "bias_s"), _dev(w_d, "w_d"),
+              _dev(bias_d, "bias_d"), _dev(wp_p, "wp_p"), _dev(bias_p, "bias_p"), y.data_ptr(), B, C, F, T, Fo, To, act,
+              _stream())
+    return y
+
+
 def mbconv(x, wp_e, bias_e, w_d, bias_d, wp_p, bias_p, Cexp, Cout, k, stride, act, res=None):
     """Whole inverted-residual block without SE in one kernel (eval; early blocks): expand + depthwise +
     project (+ residual); wp_e / wp_p are fp32 `pw_prepack` buffers."""

@@ -218,6 +218,15 @@ int eat_fused_expand_dw_fwd(const float* x, const float* wp_e, const float* bias
                             const float* bias_d, float* y, float* pool, int B, int Cin, int Cexp, int F,
                             int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream);
 
+/* ---- network front (eval): stem conv + first block in one kernel --------------------------------
+ * models/mn/model.py:124-133 (3x3/s2 conv + BN + Hardswish on the (B,1,F,T) log-mel) followed by the first
+ * inverted-residual block (no expand, no SE: depthwise 3x3/s1 + BN + act, project 1x1 + BN, + residual;
+ * block_types.py:150-181).  w_s (C,9) / w_d (C,9) BN-folded taps, wp_p = eat_pw_prepack of the BN-folded
+ * (C,C) project weights.  y (B,C,Fo,To), Fo = (F-1)/2+1, To = (T-1)/2+1.  C must be 16. */
+int eat_front_fwd(const float* x, const float* w_s, const float* bias_s, const float* w_d,
+                  const float* bias_d, const float* wp_p, const float* bias_p, float* y, int B, int C, int F,
+                  int T, int Fo, int To, int act, eat_stream_t stream);
+
 /* ---- whole inverted-residual block without SE (eval): models/mn/block_types.py:138-181 -----------
  * y (B,Cout,Fo,To) = W_p . act(dw_k,s( act(W_e x + bias_e) ) + bias_d) + bias_p [+ res]; neither the
  * expanded tensor nor the depthwise output touches HBM.  wp_e / wp_p = eat_pw_prepack of the BN-folded

@@ -250,6 +250,25 @@ def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
     _close(pool, ref.sum(dim=(2, 3)), 5e-5, "fused pool")
 
 
+@pytest.mark.parametrize("B,F_,T,act", [(2, 128, 1000, 1), (3, 128, 250, 1), (2, 37, 75, 2), (1, 128, 998, 1)])
+def test_front_stem_plus_first_block(B, F_, T, act):
+    """stem conv + hswish -> depthwise 3x3 + act -> project 1x1 + residual in one kernel (csrc/front.hip)
+    vs the torch composition (models/mn/model.py:124-133, block_types.py:150-181)."""
+    C = 16
+    x = _rand(B, 1, F_, T, seed=1)
+    ws, bs = _rand(C, 1, 3, 3, seed=2, scale=0.4), _rand(C, seed=3, scale=0.2)
+    wd, bd = _rand(C, 1, 3, 3, seed=4, scale=0.3), _rand(C, seed=5, scale=0.1)
+    wpj, bp = _rand(C, C, seed=6, scale=0.25), _rand(C, seed=7, scale=0.2)
+    rp = torch.rand(C, generator=torch.Generator().manual_seed(8)) + 0.5
+    f = [None, F.relu, F.hardswish][act]
+    s0 = F.hardswish(F.conv2d(x.double(), ws.double(), bs.double(), 2, 1))
+    d = f(F.conv2d(s0, wd.double(), bd.double(), 1, 1, 1, C))
+    ref = F.conv2d(d, (wpj * rp[:, None]).double().view(C, C, 1, 1), bp.double()) + s0
+    got = ops.front(x.to(DEV), ws.reshape(C, 9).contiguous().to(DEV), bs.to(DEV), wd.reshape(C, 9).contiguous().to(DEV),
+                    bd.to(DEV), ops.pw_prepack(wpj.to(DEV), rp.to(DEV)), bp.to(DEV), act)
+    _close(got, ref.float(), 1e-5, "front")
+
+
 @pytest.mark.parametrize("B,Ci,Ce,Co,F_,T,k,s,act,res", [
     (2, 16, 64, 24, 64, 500, 3, 2, 1, False), (2, 24, 72, 24, 32, 250, 3, 1, 1, True), (2, 24, 72, 40, 32, 250, 5, 2, 1, False),
     (3, 40, 120, 40, 16, 125, 5, 1, 1, True), (3, 40, 240, 80, 16, 125, 3, 2, 2, False), (2, 8, 24, 16, 9, 21, 5, 2, 2, False),
