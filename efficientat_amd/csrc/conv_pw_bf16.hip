@@ -13,6 +13,7 @@
 // feeds 4 n-tiles; A fragments (hi/lo) were packed once on the device (eat_pw_prepack_bf16) so that a
 // fragment is one 16-byte LDS read.  The fp32 epilogue (bias, activation, residual, pooled sums) is
 // the one of conv_pw.hip.
+#include <cstdlib>
 #include "eat_common.h"
 #include "pw_epilogue.h"
 
@@ -58,11 +59,12 @@ __global__ void pw_prepack_bf16_kernel(const float* __restrict__ w, const float*
   }
 }
 
-template <int MTW, int NPROD>
+template <int MTW, int NPROD, int NSTG>
 __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act) {
+  constexpr int n_stages = NSTG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
   constexpr int kABytes = MTW * NP2 * 1024;                 // A fragments of one chunk
@@ -73,22 +75,23 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   const int mchunk = jj % MC, tile = (jj / MC) * 8 + xcd;
   if (tile >= n_tiles) return;
   const int mt0 = mchunk * MTW;
-  const long long N = (long long)B * S;
-  const long long n_base = (long long)tile * kTileN;
-  const int b_first = (int)(n_base / S);
-  long long nl = n_base + 4 * lane;
+  // 32-bit index math: the host checks B*S < 2^31 (64-bit divisions cost ~150 VALU instructions each)
+  const unsigned N = (unsigned)B * (unsigned)S;
+  const unsigned n_base = (unsigned)tile * kTileN;
+  const int b_first = (int)(n_base / (unsigned)S);
+  unsigned nl = n_base + 4 * lane;
   if (nl > N - 4) nl = N - 4;
-  const int bl = (int)(nl / S), sl = (int)(nl - (long long)bl * S);
+  const int bl = (int)(nl / (unsigned)S), sl = (int)(nl - (unsigned)bl * (unsigned)S);
   const float* xsrc = x + ((size_t)bl * Ci) * S + sl;
-  const long long nc = n_base + 64 * wv + 4 * (lane & 15);
+  const unsigned nc = n_base + 64 * wv + 4 * (lane & 15);
   const bool col_ok = nc < N;
-  const long long ncc = col_ok ? nc : N - 4;
-  const int bc = (int)(ncc / S), sc_ = (int)(ncc - (long long)bc * S);
+  const unsigned ncc = col_ok ? nc : N - 4;
+  const int bc = (int)(ncc / (unsigned)S), sc_ = (int)(ncc - (unsigned)bc * (unsigned)S);
   const int kq = lane >> 4;
   const int n_chunks = (Ci + kKC - 1) / kKC;
 
   auto issue = [&](int c) {
-    unsigned char* st = smem_raw + (c & 1) * kStage;
+    unsigned char* st = smem_raw + (c & (n_stages - 1)) * kStage;
     const int k0 = c * kKC;
     const int klen = (Ci - k0) < kKC ? (Ci - k0) : kKC;
     float* Xs = reinterpret_cast<float*>(st + kABytes);
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   issue(0);
   for (int c = 0; c < n_chunks; ++c) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk c landed; stage (c+1)&1 is free
-    if (c + 1 < n_chunks) issue(c + 1);
-    const unsigned char* st = smem_raw + (c & 1) * kStage;
+    if (n_stages == 2 && c + 1 < n_chunks) issue(c + 1);
+    const unsigned char* st = smem_raw + (c & (n_stages - 1)) * kStage;
     const float* Xw = reinterpret_cast<const float*>(st + kABytes) + (8 * kq) * kTileN + 64 * wv + 4 * (lane & 15);
     const float* SCs = reinterpret_cast<const float*>(st + kABytes + kXBytes) + (8 * kq) * NS + (bc - b_first);
     float4 xr[8];
@@ -176,6 +179,10 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
         }
       }
     }
+    if (n_stages == 1 && c + 1 < n_chunks) {      // single stage: refill it once every wave has consumed chunk c
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue(c + 1);
+    }
   }
 
   eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
@@ -185,14 +192,23 @@ template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
            float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act) {
   const long long N = (long long)B * S;
+  if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
   const int n_tiles = (int)((N + kTileN - 1) / kTileN);
   int NS = kTileN / S + 2;
   if (NS > B) NS = B;
   if (!in_scale) NS = 0;
   if (kKC * NS > 128) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: plane of %d positions too small for the scale slot", S);
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
-  const size_t smem = 2 * (size_t)(MTW * NP2 * 1024 + kKC * kTileN * 4 + 512);
-  auto kern = pw_conv_bf16_kernel<MTW, NPROD>;
+  // Two LDS stages (chunk c+1 in flight under the MFMAs of chunk c) when two such blocks fit a CU or when
+  // there are not enough blocks for two per CU anyway; otherwise ONE stage, so that a second resident
+  // block hides the load latency and the store phase instead (measured on MI355X, B=256: 80->480 95 vs
+  // 135 us, 160->960 48 vs 83 us; the K-heavy 960->160 with 256 blocks keeps two stages: 45 vs 56 us).
+  const size_t stage = (size_t)(MTW * NP2 * 1024 + kKC * kTileN * 4 + 512);
+  static const int forced = getenv("EAT_PW_BF16_STAGES") ? atoi(getenv("EAT_PW_BF16_STAGES")) : 0;
+  const int n_blocks = ((n_tiles + 7) / 8 * 8) * MC;
+  const int n_stages = forced ? forced : ((2 * stage <= 78 * 1024 || n_blocks < 2 * 256) ? 2 : 1);
+  const size_t smem = n_stages * stage;
+  auto kern = n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2> : pw_conv_bf16_kernel<MTW, NPROD, 1>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_pw_conv_bf16_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));

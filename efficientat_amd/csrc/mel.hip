@@ -14,7 +14,8 @@ namespace {
 
 constexpr int kNfft = 1024;
 constexpr int kHalf = 512;        // complex points
-constexpr int kFramesPerBlock = 16;
+constexpr int kFramesPerBlock = 16;   // frames of one output tile (staged in LDS, stored coalesced)
+constexpr int kGroupsPerBlock = 4;    // tiles per block: the 28 KB of tables are loaded once per 64 frames
 constexpr int kWavesPerBlock = 4;
 constexpr int kBufStride = kHalf + kHalf / 8;  // padded: idx + idx/8 (breaks the stride-8 store conflict)
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
   float* s_out = reinterpret_cast<float*>(s_bs + n_mels);                  // [n_mels][33]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.y, t_base = blockIdx.x * kFramesPerBlock;
+  const int b = blockIdx.y;
   const int lpad = (kNfft - win_length) / 2;
 
   for (int i = tid; i < kNfft; i += 256) {
@@ -89,6 +90,17 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
   // the current frame's FFT so their latency hides behind it.
   auto load_frame = [&](int t, float (&lo)[16], float (&hi)[16]) {
     const int q0 = t * hop - kNfft / 2;        // padded-signal origin of this frame, in pre[] indices
+    if (q0 >= 0 && q0 + kNfft <= Lp && ((q0 | L) & 1) == 0) {
+      // interior frame (no reflection): x[j], x[j+1] as one aligned 8-byte load, x[j+2] as a third word
+      const float* xf = x + q0 + 2 * lane;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float2 a = *reinterpret_cast<const float2*>(xf + 128 * r);
+        const float c = xf[128 * r + 2];
+        lo[2 * r] = a.x; hi[2 * r] = a.y; lo[2 * r + 1] = a.y; hi[2 * r + 1] = c;
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -102,6 +114,10 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
       }
   };
   float cur_lo[16], cur_hi[16], nxt_lo[16], nxt_hi[16];
+  float* o = out + (size_t)b * n_mels * T;
+  for (int grp = 0; grp < kGroupsPerBlock; ++grp) {
+  const int t_base = (blockIdx.x * kGroupsPerBlock + grp) * kFramesPerBlock;
+  if (t_base >= T) break;                      // block-uniform
   if (t_base + wv < T) load_frame(t_base + wv, cur_lo, cur_hi);
 
   for (int fi = 0; fi < kFramesPerBlock / kWavesPerBlock; ++fi) {
@@ -187,11 +203,12 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(
     }
   }
   __syncthreads();
-  float* o = out + (size_t)b * n_mels * T;
   for (int i = tid; i < n_mels * kFramesPerBlock; i += 256) {
     const int m = i / kFramesPerBlock, c = i % kFramesPerBlock;
     const int t = t_base + c;
     if (t < T) o[(size_t)m * T + t] = s_out[m * (kFramesPerBlock + 1) + c];
+  }
+  __syncthreads();                             // s_out is rewritten by the next tile
   }
 }
 
@@ -216,7 +233,7 @@ extern "C" int eat_mel_fwd(const float* wave, int B, int L, const float* window,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_mel_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
-  dim3 grid((T + kFramesPerBlock - 1) / kFramesPerBlock, B);
+  dim3 grid((T + kFramesPerBlock * kGroupsPerBlock - 1) / (kFramesPerBlock * kGroupsPerBlock), B);
   hipLaunchKernelGGL(mel_fwd_kernel, grid, dim3(256), smem, (hipStream_t)stream, wave, L, window, win_length,
                      hop, reinterpret_cast<const float2*>(twiddle), band_w, band_start, n_mels, band_len, out, T,
                      mask_f0, mask_f1, mask_t0, mask_t1);

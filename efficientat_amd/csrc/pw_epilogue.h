@@ -30,8 +30,6 @@ __device__ __forceinline__ float act_apply(float v, const ActCoef& c) {
   return fmaxf(v, c.lo) * __builtin_amdgcn_fmed3f(fmaf(v, c.a, c.b), 0.0f, 1.0f);
 }
 
-// Lane layout (both kernels): lane owns rows m = (mt0+i)*16 + kq*4 + r (i < MTW, r < 4) and the 4
-// consecutive columns starting at position sc_ of sample bc; acc[i][j][r] is column j of row r.
 // Every wave DMAs 64 of the block's (at most 128) bias values into s_bias; issue it BEFORE the first
 // k-chunk so that the chunk's own wait + barrier also publishes the bias.
 typedef __attribute__((address_space(3))) void epi_lds_void;
@@ -44,18 +42,22 @@ __device__ __forceinline__ void pw_stage_bias(const float* __restrict__ bias, fl
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(bias + m) : "memory", "m0");
 }
 
-template <int MTW>
-__device__ __forceinline__ void pw_epilogue(const acc_f32x4 (&acc)[MTW][4], const float* s_bias,
-                                            const float* __restrict__ res, float* __restrict__ y,
-                                            float* __restrict__ pool, int mt0, int kq, int lane, bool col_ok, int bc,
-                                            int sc_, int Co, int S, int act) {
-  const ActCoef ac = act_coef(act);
+// Lane layout (both kernels): lane owns rows m = (mt0+i)*16 + kq*4 + r (i < MTW, r < 4) and the 4
+// consecutive columns starting at position sc_ of sample bc; acc[i][j][r] is column j of row r.
+template <int MTW, bool LINEAR>
+__device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], const float* s_bias,
+                                                const float* __restrict__ res, float* __restrict__ y,
+                                                float* __restrict__ pool, int mt0, int kq, int lane, bool col_ok,
+                                                int bc, int sc_, int Co, int S, const ActCoef ac) {
   const size_t plane = (size_t)S;
   const size_t base = (size_t)bc * Co * plane + sc_;
   auto value = [&](int i, int r) {
     const float bm = s_bias[i * 16 + kq * 4 + r];
-    return make_float4(act_apply(acc[i][0][r] + bm, ac), act_apply(acc[i][1][r] + bm, ac),
-                       act_apply(acc[i][2][r] + bm, ac), act_apply(acc[i][3][r] + bm, ac));
+    if constexpr (LINEAR)
+      return make_float4(acc[i][0][r] + bm, acc[i][1][r] + bm, acc[i][2][r] + bm, acc[i][3][r] + bm);
+    else
+      return make_float4(act_apply(acc[i][0][r] + bm, ac), act_apply(acc[i][1][r] + bm, ac),
+                         act_apply(acc[i][2][r] + bm, ac), act_apply(acc[i][3][r] + bm, ac));
   };
   auto row_of = [&](int i, int r) { return (mt0 + i) * 16 + kq * 4 + r; };
 
@@ -126,6 +128,21 @@ __device__ __forceinline__ void pw_epilogue(const acc_f32x4 (&acc)[MTW][4], cons
         atomicAdd(pool + (size_t)bc * Co + m, ps);
       }
     }
+}
+
+// `act` is wave-uniform: the project layers (no activation) take a branch without any activation math,
+// ReLU / Hardswish share the branch-free 4-op form (a third specialisation pushed the 7-8 m-tile kernels
+// over 256 VGPRs).
+template <int MTW>
+__device__ __forceinline__ void pw_epilogue(const acc_f32x4 (&acc)[MTW][4], const float* s_bias,
+                                            const float* __restrict__ res, float* __restrict__ y,
+                                            float* __restrict__ pool, int mt0, int kq, int lane, bool col_ok, int bc,
+                                            int sc_, int Co, int S, int act) {
+  const ActCoef ac = act_coef(act);
+  if (act == EAT_ACT_NONE)
+    pw_epilogue_act<MTW, true>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, ac);
+  else
+    pw_epilogue_act<MTW, false>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, ac);
 }
 
 }  // namespace eat

