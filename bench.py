@@ -75,28 +75,24 @@ def _alg_bytes(name, a):
         chunks = (mt + 7) // 8
         mtw = (mt + chunks - 1) // chunks
         nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + (4 if split else 2) * Co * Ci
-        return f"pw_conv_bf16_kernel<{mtw},{3 if split else 1}>", nbytes, 2 * B * S * Ci * Co
+        return f"pw_conv_bf16_kernel<{mtw},{3 if split else 1},*>", nbytes, 2 * B * S * Ci * Co
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
         return f"dw_conv_kernel<{k},{s},{act}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
     if name == "eat_fused_expand_dw_fwd":
         x, wp, be, wd, bd, y, pool, B, Cin, Cexp, F, T, Fo, To, k, s, act = a[:17]
-        # algorithmic bytes of the TWO layers it replaces (expand out + dw in/out), per SURVEY 8(d)
-        nbytes = 4 * B * (Cin * F * T + 2 * Cexp * F * T + Cexp * Fo * To) + 4 * Cexp * (Cin + k * k)
-        return f"fused_expand_dw_kernel<{k},{s},{act}>", nbytes, 2 * B * Cexp * (Cin * F * T + k * k * Fo * To)
+        nbytes = 4 * B * (Cin * F * T + Cexp * Fo * To) + 4 * Cexp * (Cin + k * k)
+        return f"mbconv_kernel<{k},{s},*,{act},false>", nbytes, 2 * B * Cexp * (Cin * F * T + k * k * Fo * To)
     if name == "eat_mbconv_fwd":
         x, wpe, be, wd, bd, wpp, bp, res, y, B, Cin, Cexp, Cout, F, T, Fo, To, k, s, act = a[:20]
-        # algorithmic bytes of the THREE layers it replaces (expand, depthwise, project [+ residual read])
-        nbytes = (4 * B * (Cin * F * T + 2 * Cexp * F * T + 2 * Cexp * Fo * To + Cout * Fo * To * (2 if res else 1))
-                  + 4 * Cexp * (Cin + k * k + Cout))
+        # a fused kernel is priced at its OWN unavoidable traffic (input once [+ residual re-read], output once),
+        # not at the traffic of the three layers it replaces
+        nbytes = 4 * B * (Cin * F * T * (2 if res else 1) + Cout * Fo * To) + 4 * Cexp * (Cin + k * k + Cout)
         flops = 2 * B * (Cexp * Cin * F * T + Cexp * k * k * Fo * To + Cout * Cexp * Fo * To)
-        return f"mbconv_kernel<{k},{s},{act},proj>", nbytes, flops
+        return f"mbconv_kernel<{k},{s},*,{act},true>", nbytes, flops
     if name == "eat_front_fwd":
         x, ws, bs, wd, bd, wpp, bp, y, B, C, F, T, Fo, To, act = a[:15]
-        # algorithmic bytes of the three layers it replaces: stem (in + out), depthwise (in + out),
-        # project (in + out + residual read)
-        nbytes = 4 * B * (F * T + 6 * C * Fo * To) + 4 * C * (9 + 9 + C)
-        return f"front_kernel<{act}>", nbytes, 2 * B * C * Fo * To * (9 + 9 + C)
+        return f"front_kernel<{act}>", 4 * B * (F * T + C * Fo * To) + 4 * C * (9 + 9 + C), 2 * B * C * Fo * To * (9 + 9 + C)
     if name == "eat_stem_conv_fwd":
         x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9
@@ -369,14 +365,18 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r1.json")
         if os.path.exists(tpath):
-            k = json.load(open(tpath))["kernels"].get(name.replace(" ", ""))
-            traffic = k["hbm_bytes_per_launch"] if k else None
+            # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
+            import fnmatch
+            ks = json.load(open(tpath))["kernels"]
+            hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
+            traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches_sampled"] for h in hit) /
+                          sum(h["launches_sampled"] for h in hit)) if hit else None
         # which roof binds this kernel: the larger of its HBM time and its MFMA time.  The MFMA peak is the
         # one of the instruction the kernel issues: fp32 16x16x4 (157 TF), bf16 16x16x32 (2.5 PF dense), and
         # for the bf16x3 split kernel 2.5 PF / 3 because each useful product costs three bf16 MFMAs.
         mfma_peak = MFMA_F32_PEAK
         if name.startswith("pw_conv_bf16_kernel"):
-            mfma_peak = MFMA_BF16_PEAK / (3 if name.endswith(",3>") else 1)
+            mfma_peak = MFMA_BF16_PEAK / (3 if ",3," in name else 1)
         mfma_bound = per_launch_flops / mfma_peak > per_launch_bytes / HBM_PEAK
         common = {"kernel": name, "traffic": traffic, "launches_per_step": d["launches"],
                   "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_bytes_per_launch": int(per_launch_bytes),
