@@ -241,7 +241,9 @@ class MN(nn.Module):
                 nn.init.zeros_(m.bias)
         self._cache = _FoldCache()
         self._monolithic_backward = True      # train-mode backward is one autograd Function (mn_train.py)
-        self.train_precision = "fp32"         # "bf16": 1x1 convs of the train step on the bf16 matrix cores
+        # arithmetic of the 1x1 forward / data-gradient GEMMs of the train step (ops.precision): "auto" =
+        # exact fp32 below C_in 40, split-operand bf16x3 (fp32-class) above; "fp32"; "bf16" = BASELINE config 3
+        self.train_precision = os.environ.get("EAT_TRAIN_PRECISION", "auto")
 
     # ------------------------------------------------------------------ folded weights
     def _fold_sources(self):

@@ -264,12 +264,14 @@ def pw_conv_bf16(x, wp16, bias, Co, act, split=True, in_scale=None, res=None, po
 # ------------------------------------------------------------------ precision switch (training plans)
 class precision:
     """Context manager selecting the arithmetic of the 1x1 convs issued through pw_prepack/pw_conv:
-    'fp32' (exact fp32 MFMA, default) or 'bf16' (plain bf16 operands on v_mfma_f32_16x16x32_bf16, fp32
-    accumulation and fp32 activations in memory - BASELINE config 3)."""
+    'fp32' (exact fp32 MFMA), 'auto' (fp32 below C_in = 40, split-operand bf16x3 - fp32-class accuracy at a
+    multiple of the fp32 MFMA rate - from there on; see mn._pw_mode), 'bf16x3' (split everywhere) or 'bf16'
+    (plain bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation and fp32 activations in memory -
+    BASELINE config 3)."""
     mode = "fp32"
 
     def __init__(self, mode):
-        if mode not in ("fp32", "bf16"):
+        if mode not in ("fp32", "auto", "bf16x3", "bf16"):
             raise ValueError(f"unknown precision {mode!r}")
         self.new = mode
 
@@ -284,12 +286,18 @@ _pw_prepack_fp32, _pw_conv_fp32 = pw_prepack, pw_conv
 
 
 def pw_prepack(w2d, row_scale=None):  # noqa: F811
-    if precision.mode == "bf16":
+    m = precision.mode
+    if m == "bf16":
         return pw_prepack_bf16(w2d, row_scale, split=False)
+    if m == "bf16x3" or (m == "auto" and w2d.shape[1] >= 40 and w2d.shape[1] % 4 == 0):
+        wp = pw_prepack_bf16(w2d, row_scale, split=True)
+        wp._eat_split = True                 # both bf16 packs share the dtype: mark the hi/lo one
+        return wp
     return _pw_prepack_fp32(w2d, row_scale)
 
 
 def pw_conv(x, wp, bias, Co, act, in_scale=None, res=None, pool=None, write=True):  # noqa: F811
     if wp.dtype == torch.bfloat16:
-        return pw_conv_bf16(x, wp, bias, Co, act, False, in_scale=in_scale, res=res, pool=pool, write=write)
+        return pw_conv_bf16(x, wp, bias, Co, act, getattr(wp, "_eat_split", False), in_scale=in_scale, res=res,
+                            pool=pool, write=write)
     return _pw_conv_fp32(x, wp, bias, Co, act, in_scale=in_scale, res=res, pool=pool, write=write)
