@@ -7,6 +7,7 @@
 // Round-1 structure: every pass is its own streaming kernel over (B, C, S) planes (one workgroup
 // per plane, float4 along the time axis, wave-shuffle + LDS block reduction, per-channel totals
 // accumulated in fp64 atomics so that sums over up to 8M elements do not lose precision).
+#include <cstdlib>
 #include "eat_common.h"
 
 namespace {
@@ -421,6 +422,242 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
       }
 }
 
+
+// ---- pointwise weight gradient on the bf16 matrix cores ("bf16x3", see conv_pw_bf16.hip) ---------------------------
+// dW (Co x Ci) = sum over k = (b, s) of dz[co, k] x[ci, k]: both operands are contiguous along k, which is exactly the
+// operand layout of v_mfma_f32_16x16x32_bf16 (lane = (row, 8 consecutive k)), so every lane loads its 8 k-values
+// straight from HBM/L2 as two float4, splits them into bf16 hi + lo in registers and issues hi*hi + hi*lo + lo*hi.
+// Block = 4 waves as 2 x 2 on a 128 x 128 tile of dW (each wave 64 x 64 = 4 x 4 MFMA tiles, 64 accumulator VGPRs):
+// dz is read ceil(Ci/128) times and x ceil(Co/128) times (the 32 x 32-tile fp32 kernel above reads them Ci/32 and
+// Co/32 times: 1.3 GB of L2 traffic for the 112 -> 672 layer instead of 0.35 GB).  The k range is cut into units of 32
+// positions of one sample and split over blockIdx.z; partial tiles are added to dW with atomics.
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{v[i], v[i + 1]}, bf16x2_t);
+    const bf16x2_t l = __builtin_convertvector(f32x2_t{v[i] - (float)h[0], v[i + 1] - (float)h[1]}, bf16x2_t);
+    hi[i] = h[0]; hi[i + 1] = h[1];
+    lo[i] = l[0]; lo[i + 1] = l[1];
+  }
+}
+
+// LDS staging (v3): a lane-per-row direct load makes every lane of a load instruction touch a different cache line
+// (measured: ~18 k cycles per 32-k step, the texture-address unit is the bottleneck).  Instead the operand tiles go
+// through LDS by LDS-DMA with a coalesced mapping - lane l of one instruction fetches the 16-byte chunk
+// (l & 7) ^ ((row >> 1) & 7) of row l >> 3, i.e. 8 rows x one full 128-byte line - and the XOR swizzle of the chunk
+// index makes the later MFMA-fragment reads (16 lanes = 16 rows, same chunk) hit 16 different bank groups.
+typedef __attribute__((address_space(3))) void wg_lds_void;
+__device__ __forceinline__ void wg_glds16(const void* g, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(wg_lds_void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory", "m0");
+}
+
+__global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                             const float* __restrict__ xscale, float* __restrict__ dW,
+                                                             int B, int Co, int Ci, int S, int sps, int units_per_block,
+                                                             int per_sample) {
+  // stage = [A: 128 rows x 128 B][B: 128 rows x 128 B] = 32 KB; 2 stages
+  __shared__ __attribute__((aligned(16))) float s_op[2][2][128 * 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int mb = blockIdx.x * 128, nb = blockIdx.y * 128;         // block tile origin
+  const int mw = (wv & 1) * 64, nw = (wv >> 1) * 64;              // wave sub-tile inside the block tile
+  const int total = B * sps;
+  const int u0 = blockIdx.z * units_per_block;
+  const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
+  if (u0 >= u1) return;
+  int mt_n = (Co - mb - mw + 15) / 16, nt_n = (Ci - nb - nw + 15) / 16;   // valid 16-row tiles of this wave (uniform)
+  mt_n = mt_n < 0 ? 0 : (mt_n > 4 ? 4 : mt_n);
+  nt_n = nt_n < 0 ? 0 : (nt_n > 4 ? 4 : nt_n);
+  const bool active = mt_n > 0 && nt_n > 0;                        // idle waves still help with the loads
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loader role: this wave moves rows [32 wv, 32 wv + 32) of both operand tiles: 4 DMA instructions per operand
+  const int lrow = lane >> 3;                                      // row within the 8-row group
+  auto issue = [&](int bb, int stt, int stage) {
+    const int s_base = stt * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 32 * wv + 8 * q + lrow;                      // row of the 128-row tile
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);             // swizzled 16-byte chunk this lane fetches
+      int sidx = s_base + 4 * chunk;
+      if (sidx > S - 4) sidx = S - 4;                              // tail unit: valid dummy, zeroed by the reader
+      if (mb + 32 * wv + 8 * q < Co) {                             // skip row groups beyond the matrix (uniform)
+        int ra = mb + row;
+        if (ra >= Co) ra = Co - 1;
+        wg_glds16(dz + ((size_t)bb * Co + ra) * S + sidx, &s_op[stage][0][(32 * wv + 8 * q) * 32]);
+      }
+      if (nb + 32 * wv + 8 * q < Ci) {
+        int rb = nb + row;
+        if (rb >= Ci) rb = Ci - 1;
+        wg_glds16(x + ((size_t)bb * Ci + rb) * S + sidx, &s_op[stage][1][(32 * wv + 8 * q) * 32]);
+      }
+    }
+  };
+
+  int b = u0 / sps, st = u0 - b * sps;
+  float sc[4] = {1.f, 1.f, 1.f, 1.f};
+  int b_sc = -1;
+  issue(b, st, 0);
+  int stage = 0;
+  for (int u = u0; u < u1; ++u) {
+    int bn = b, stn = st + 1;
+    if (stn == sps) { stn = 0; ++bn; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // unit u landed; the other stage is free
+    if (u + 1 < u1) issue(bn, stn, stage ^ 1);
+    if (active) {
+      if (xscale && b != b_sc) {      // squeeze-excitation scale of the conv input, per (sample, input channel)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = nb + nw + 16 * j + r;
+          sc[j] = row < Ci ? xscale[(size_t)b * Ci + row] : 0.0f;
+        }
+        b_sc = b;
+      }
+      // fragment of (row, kg): global chunks 2kg and 2kg+1 of that row, stored at the swizzled slots
+      const int s_lo = st * 32 + 8 * kg;
+      const bool k0 = s_lo < S, k1 = s_lo + 4 < S;
+      auto frag = [&](const float* tile, int row_in_tile, bool row_ok, float scale, bf16x8_t& hi, bf16x8_t& lo) {
+        const int sw = (row_in_tile >> 1) & 7;
+        const float4 t0 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg) ^ sw));
+        const float4 t1 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg + 1) ^ sw));
+        // row_ok also guards LDS rows that were never loaded (select, not multiply: they may hold anything)
+        const bool q0 = row_ok && k0, q1 = row_ok && k1;
+        const float v[8] = {q0 ? t0.x * scale : 0.0f, q0 ? t0.y * scale : 0.0f, q0 ? t0.z * scale : 0.0f,
+                            q0 ? t0.w * scale : 0.0f, q1 ? t1.x * scale : 0.0f, q1 ? t1.y * scale : 0.0f,
+                            q1 ? t1.z * scale : 0.0f, q1 ? t1.w * scale : 0.0f};
+        split8(v, hi, lo);
+      };
+      bf16x8_t bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = nw + 16 * j + r;
+        frag(&s_op[stage][1][0], row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < mt_n) {
+          const int row = mw + 16 * i + r;
+          bf16x8_t ah, al;
+          frag(&s_op[stage][0][0], row, mb + row < Co, 1.0f, ah, al);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < nt_n) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    b = bn; st = stn; stage ^= 1;
+  }
+  if (!active) return;
+  float* out = dW + (per_sample ? (size_t)(u0 / sps) * Co * Ci : 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = mb + mw + 16 * i + kg * 4 + q, n = nb + nw + 16 * j + r;   // C/D: row = kg*4+q, col = lane&15
+        if (i < mt_n && j < nt_n && m < Co && n < Ci) atomicAdd(out + (size_t)m * Ci + n, acc[i][j][q]);
+      }
+}
+
+// Narrow layers (one side <= 16 channels, the other <= 64: mn10 block 1 and the expand of block 2, planes of 32000
+// positions): dW is a single 64 x 64 wave tile and the gradient is a pure streaming reduction over k.  Here the direct,
+// LDS-free form wins: the 4 waves of a block split the k range, every lane loads the 8 consecutive k of its row straight
+// from HBM (16 rows x 32 B per instruction is a poor pattern for the texture unit, but with <= 5 row tiles per unit it
+// is not the bottleneck).
+__global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                    const float* __restrict__ xscale, float* __restrict__ dW,
+                                                                    int B, int Co, int Ci, int S, int sps,
+                                                                    int units_per_block) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int total = B * sps;
+  const int u0 = blockIdx.z * units_per_block;
+  const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
+  const int mt_n = (Co + 15) / 16, nt_n = (Ci + 15) / 16;         // <= 4 each
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sc[4] = {1.f, 1.f, 1.f, 1.f};
+  int b_sc = -1;
+  for (int u = u0 + wv; u < u1; u += 4) {
+    const int b = u / sps, st = u - b * sps;
+    const int s = st * 32 + 8 * kg;
+    if (xscale && b != b_sc) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * j + r;
+        sc[j] = row < Ci ? xscale[(size_t)b * Ci + row] : 0.0f;
+      }
+      b_sc = b;
+    }
+    float av[4][8], bv[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + r;
+      const float* p = dz + ((size_t)b * Co + (row < Co ? row : Co - 1)) * S + s;
+      const bool ok0 = i < mt_n && row < Co && s < S, ok1 = ok0 && s + 4 < S;
+      const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[i][0] = t0.x; av[i][1] = t0.y; av[i][2] = t0.z; av[i][3] = t0.w;
+      av[i][4] = t1.x; av[i][5] = t1.y; av[i][6] = t1.z; av[i][7] = t1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 16 * j + r;
+      const float* p = x + ((size_t)b * Ci + (row < Ci ? row : Ci - 1)) * S + s;
+      const bool ok0 = j < nt_n && row < Ci && s < S, ok1 = ok0 && s + 4 < S;
+      const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[j][0] = t0.x * sc[j]; bv[j][1] = t0.y * sc[j]; bv[j][2] = t0.z * sc[j]; bv[j][3] = t0.w * sc[j];
+      bv[j][4] = t1.x * sc[j]; bv[j][5] = t1.y * sc[j]; bv[j][6] = t1.z * sc[j]; bv[j][7] = t1.w * sc[j];
+    }
+    bf16x8_t bh[4], bl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split8(bv[j], bh[j], bl[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < mt_n) {
+        bf16x8_t ah, al;
+        split8(av[i], ah, al);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < nt_n) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = 16 * i + kg * 4 + q, n = 16 * j + r;
+        if (i < mt_n && j < nt_n && m < Co && n < Ci) atomicAdd(dW + (size_t)m * Ci + n, acc[i][j][q]);
+      }
+}
+
 }  // namespace
 
 #define EAT_PLANES_GRID(B, C) dim3((unsigned)((B) * (C)))
@@ -554,6 +791,33 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 
 static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
                          int per_sample, eat_stream_t stream) {
+  // default: split-operand bf16 MFMA kernel (fp32-class accuracy); EAT_WGRAD_FP32=1 or S % 4 != 0: exact fp32 MFMA kernel
+  static const bool force_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
+  if (!force_fp32 && (S & 3) == 0) {
+    const int sps = (S + 31) / 32;
+    const int tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
+    const long long total = (long long)B * sps;
+    int upb = sps;                                             // per-sample gradients: one sample per block
+    if (!per_sample) {
+      // ~1024 blocks, but at least 16 units (512 k) of MFMA work in front of a block's Co x Ci atomics
+      long long splits = (1024 + tiles - 1) / tiles;
+      if (splits > total / 16) splits = total / 16;
+      if (splits < 1) splits = 1;
+      upb = (int)((total + splits - 1) / splits);
+    }
+    dim3 grid((Co + 127) / 128, (Ci + 127) / 128, (unsigned)((total + upb - 1) / upb));
+    if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16) && !per_sample) {
+      // narrow streaming layers: ~2048 single-tile blocks whose 4 waves split the k range
+      long long splits = 2048 < total ? 2048 : total;
+      upb = (int)((total + splits - 1) / splits);
+      hipLaunchKernelGGL(pw_wgrad_x3_narrow_kernel, dim3(1, 1, (unsigned)((total + upb - 1) / upb)), dim3(256), 0,
+                         (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, sps, upb);
+    } else {
+      hipLaunchKernelGGL(pw_wgrad_x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, sps,
+                         upb, per_sample);
+    }
+    return eat::check_launch("eat_pw_conv_wgrad");
+  }
   const int tiles = ((Co + 31) / 32) * ((Ci + 31) / 32);
   int splits = (1024 + tiles - 1) / tiles;
   if (splits > B || per_sample) splits = B;
