@@ -208,9 +208,10 @@ def train_bench(args, mel, model, wave, dev, dist, world, barrier):
                     m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
     g = torch.Generator(device=dev).manual_seed(99)
     y = (torch.rand((bt, 527), device=dev, generator=g) < 2.7 / 527).float()
-    if world > 1:
+    use_dp = world > 1 or dist is not None
+    if use_dp:
         enable_data_parallel(model)
-    graphed = world == 1 and not args.no_graph
+    graphed = not use_dp and not args.no_graph
     # fused=True: one multi-tensor kernel per step (the foreach path spends ~350 tiny launches per step on the
     # per-parameter bias-correction scalars)
     opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=graphed, fused=True)
@@ -284,8 +285,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("EAT_BENCH_FORCE_DIST") == "1"    # exercise the RCCL path with a single rank (debug)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 

@@ -275,6 +275,12 @@ class DyMN(nn.Module):
         wp = ops.dyn_pw_pack(blk.proj_conv.weight.view(blk.proj_conv.k, -1), att, cout, cexp, w["proj"][0])
         return ops.pw_conv_dyn(x, wp, w["proj"][1], cout, ops.ACT_NONE, res=inp if blk.use_res_connect else None)
 
+    def train(self, mode: bool = True):
+        """nn.Module.train plus dropping the folded eval weights (see mn._FoldCache)."""
+        if getattr(self, "_cache", None) is not None:
+            self._cache.invalidate()
+        return super().train(mode)
+
     def _forward_impl(self, x, return_fmaps=False):
         if not x.is_cuda:
             raise ops._lib.EatHipError("DyMN.forward needs a GPU tensor: efficientat_amd has no CPU path")

@@ -47,4 +47,7 @@ class GraphedTrainStep:
         self.x.copy_(x)
         self.y.copy_(y)
         self.graph.replay()
+        cache = getattr(self.model, "_cache", None)
+        if cache is not None:            # a replay updates the weights without bumping their version counters
+            cache.invalidate()
         return self.loss

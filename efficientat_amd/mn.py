@@ -184,9 +184,17 @@ def _pw(x, pack, Co, act, **kw):
 
 
 class _FoldCache:
-    """Folded / packed weights keyed on the version counters of their source tensors."""
+    """Folded / packed weights keyed on the version counters of their source tensors.
+
+    Version counters catch in-place updates made through autograd-visible ops (`load_state_dict`, `mul_`,
+    the default optimizers) but NOT fused optimizers (`Adam(fused=True)`), hipGraph replays or our own
+    kernels writing BN buffers through raw pointers - so the cache is also dropped on every train()/eval()
+    switch (`invalidate`, called from `MN.train` / `DyMN.train`) and by `GraphedTrainStep`."""
 
     def __init__(self):
+        self.key, self.val = None, None
+
+    def invalidate(self):
         self.key, self.val = None, None
 
     def get(self, tensors, build):
@@ -244,6 +252,13 @@ class MN(nn.Module):
         # arithmetic of the 1x1 forward / data-gradient GEMMs of the train step (ops.precision): "auto" =
         # exact fp32 below C_in 40, split-operand bf16x3 (fp32-class) above; "fp32"; "bf16" = BASELINE config 3
         self.train_precision = os.environ.get("EAT_TRAIN_PRECISION", "auto")
+
+    def train(self, mode: bool = True):
+        """nn.Module.train plus dropping the folded eval weights: parameters may have been updated by paths
+        that do not bump tensor versions (fused optimizers, graph replays), see _FoldCache."""
+        if getattr(self, "_cache", None) is not None:
+            self._cache.invalidate()
+        return super().train(mode)
 
     # ------------------------------------------------------------------ folded weights
     def _fold_sources(self):

@@ -199,6 +199,43 @@ def test_train_step_updates_weights_and_eval_follows(golden_dir):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("how", ["fused_adam", "graph"])
+def test_eval_after_versionless_updates_uses_fresh_weights(how):
+    """Fused optimizers and hipGraph replays update parameters / BN buffers WITHOUT bumping tensor version
+    counters; the folded eval weights must still follow (train()/eval() switch drops the fold cache)."""
+    model = _quiet(get_model, width_mult=0.4, num_classes=10).to(DEV)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
+    x = _rand(4, 1, 128, 200, seed=3).to(DEV)
+    y = (torch.rand(4, 10, generator=torch.Generator().manual_seed(1)) < 0.3).float().to(DEV)
+    model.eval()
+    with torch.no_grad():
+        before, _ = model(x)                      # populates the fold cache with the initial weights
+    model.train()
+    if how == "fused_adam":
+        opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
+        for _ in range(3):
+            opt.zero_grad()
+            F.binary_cross_entropy_with_logits(model(x)[0], y).backward()
+            opt.step()
+    else:
+        from efficientat_amd.graphs import GraphedTrainStep
+        opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=True)
+        step = GraphedTrainStep(model, opt, F.binary_cross_entropy_with_logits, x, y, warmup=1)
+        for _ in range(3):
+            step(x, y)
+    model.eval()
+    with torch.no_grad():
+        after, _ = model(x)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ref, _ = O.mn_forward(sd, x.cpu(), width_mult=0.4)
+    assert float((after - before).abs().max()) > 1e-3            # the update is visible ...
+    assert float((after.cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))   # ... and exact
+
+
 # --------------------------------------------------------- BASELINE config 3: mn40, bf16 MFMA 1x1
 def _mn40_calibrated(n_samples=96000):
     wave = synth.parity_clips(n_samples, seed=21)[:3]
