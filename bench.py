@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--streams", type=int, default=2, help="sub-batches issued on concurrent HIP streams per step")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event profile to stderr")
@@ -299,10 +300,28 @@ def main():
     wave = (0.1 * torch.randn(args.batch, CLIP_SAMPLES, device=dev, generator=g)).clamp_(-1, 1)
 
     out = {}
+    n_str = max(1, args.streams)
+    streams = [torch.cuda.Stream() for _ in range(n_str)] if n_str > 1 else []
+    chunks = wave.chunk(n_str) if n_str > 1 else [wave]
 
     def step():
         with torch.no_grad():
-            out["logits"], out["feat"] = model(mel(wave).unsqueeze(1))
+            if n_str == 1:
+                out["logits"], out["feat"] = model(mel(wave).unsqueeze(1))
+                return
+            # the batch is cut into `streams` sub-batches issued on their own HIP streams (fork / join inside
+            # the captured graph): latency-bound kernels of one sub-batch (SE GEMMs, mel, kernel tails) overlap
+            # with bandwidth-bound kernels of the other
+            cur = torch.cuda.current_stream()
+            res = []
+            for st, wv in zip(streams, chunks):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    res.append(model(mel(wv).unsqueeze(1)))
+            for st in streams:
+                cur.wait_stream(st)
+            out["logits"] = [r[0] for r in res]
+            out["feat"] = [r[1] for r in res]
 
     step()                               # folds / packs weights, builds mel tables
     torch.cuda.synchronize()
@@ -349,7 +368,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 synthetic "
                                "10 s @ 32 kHz clips per GPU, fp32 [BASELINE.json configs[1]]",
-                   "batch_per_gpu": args.batch, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "batch_per_gpu": args.batch, "launch": ("hipGraph replay" if graph is not None else "eager") +
+                             (f", {n_str} concurrent sub-batch streams" if n_str > 1 else ""),
                    "parallelism": f"dp{world} (independent clips, no collective)"},
         "roofline_e2e": {"bound": "hbm", "achieved": round(clips_per_s / world * ALG_BYTES_PER_CLIP / 1e9, 1),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s",
