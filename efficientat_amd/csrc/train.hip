@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const float* p = z + (size_t)plane * S;
   float s1 = 0.f, s2 = 0.f;
   if ((S & 3) == 0) {
+#pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
       const float4 v = *reinterpret_cast<const float4*>(p + i);
       s1 += (v.x + v.y) + (v.z + v.w);
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   const size_t base = (size_t)plane * S;
   float ps = 0.f, dummy = 0.f;
   if ((S & 3) == 0) {
+#pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
       const float4 v = *reinterpret_cast<const float4*>(z + base + i);
       float4 o = make_float4(eat::activate<ACT>(fmaf(av, v.x, bv)), eat::activate<ACT>(fmaf(av, v.y, bv)),
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   const size_t base = (size_t)plane * S;
   float s1 = 0.f, s2 = 0.f;
   if ((S & 3) == 0) {
+#pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
       const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
       const float4 v = *reinterpret_cast<const float4*>(z + base + i);
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     return av * (g - m1 - (v - mu) * is * m2);
   };
   if ((S & 3) == 0) {
+#pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
       const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
       const float4 v = *reinterpret_cast<const float4*>(z + base + i);
