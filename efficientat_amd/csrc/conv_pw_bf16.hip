@@ -63,13 +63,14 @@ template <int MTW, int NPROD, int NSTG>
 __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
-    float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act) {
+    float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
+    int sc_bytes) {
   constexpr int n_stages = NSTG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
   constexpr int kABytes = MTW * NP2 * 1024;                 // A fragments of one chunk
   constexpr int kXBytes = kKC * kTileN * 4;
-  constexpr int kStage = kABytes + kXBytes + 512;            // + 128 floats of SE scales
+  const int kStage = kABytes + kXBytes + sc_bytes;           // + the SE scales of the chunk: kKC x NS floats, 256 B pieces
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
   const int mchunk = jj % MC, tile = (jj / MC) * 8 + xcd;
@@ -111,8 +112,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     }
     if (in_scale) {
       float* SCs = reinterpret_cast<float*>(st + kABytes + kXBytes);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < (sc_bytes >> 8); ++h) {           // 2 pieces for planes >= 128 positions (NS <= 4)
         int e = h * 64 + lane;
         if (e >= kKC * NS) e = kKC * NS - 1;
         const int r = e / NS, j = e - r * NS;
@@ -197,25 +197,26 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   int NS = kTileN / S + 2;
   if (NS > B) NS = B;
   if (!in_scale) NS = 0;
-  if (kKC * NS > 128) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: plane of %d positions too small for the scale slot", S);
+  const int sc_bytes = in_scale ? ((kKC * NS + 63) / 64) * 256 : 0;
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
   // Two LDS stages (chunk c+1 in flight under the MFMAs of chunk c) when two such blocks fit a CU or when
   // there are not enough blocks for two per CU anyway; otherwise ONE stage, so that a second resident
   // block hides the load latency and the store phase instead (measured on MI355X, B=256: 80->480 95 vs
   // 135 us, 160->960 48 vs 83 us; the K-heavy 960->160 with 256 blocks keeps two stages: 45 vs 56 us).
-  const size_t stage = (size_t)(MTW * NP2 * 1024 + kKC * kTileN * 4 + 512);
+  const size_t stage = (size_t)(MTW * NP2 * 1024 + kKC * kTileN * 4 + sc_bytes);
   static const int forced = getenv("EAT_PW_BF16_STAGES") ? atoi(getenv("EAT_PW_BF16_STAGES")) : 0;
   const int n_blocks = ((n_tiles + 7) / 8 * 8) * MC;
   const int n_stages = forced ? forced : ((2 * stage <= 78 * 1024 || n_blocks < 2 * 256) ? 2 : 1);
   const size_t smem = n_stages * stage;
   auto kern = n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2> : pw_conv_bf16_kernel<MTW, NPROD, 1>;
+  if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: LDS stage too large (%zu B; planes of %d positions)", smem, S);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_pw_conv_bf16_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act);
+                     n_tiles, NS, act, sc_bytes);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 

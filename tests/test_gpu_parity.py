@@ -207,6 +207,21 @@ def test_mn10_eval_logits_and_fmaps(golden_dir, pw_mode, monkeypatch):
     assert np.abs(logits3.cpu().numpy() - g["eval_logits"]).max() < 1e-3
 
 
+def test_mn10_short_clips_match_oracle(golden_dir):
+    """2 s clips: the late stages shrink to 4x7 / 2x4 planes (many samples per 256-column tile, large SE-scale
+    slots) - the shapes __graft_entry__.smoke() uses."""
+    sd, _ = _calibrated_state(golden_dir)
+    model = _quiet(get_model, width_mult=1.0)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    wave = synth.parity_clips(64000, seed=3)
+    x_ref = O.mel_forward(wave).unsqueeze(1)
+    with torch.no_grad():
+        ref, _ = O.mn_forward(sd, x_ref)
+        got, _ = model(x_ref.to(DEV))
+    assert float((got.cpu() - ref).abs().max()) < 1e-3
+
+
 def test_refold_after_weight_update(golden_dir):
     """Folded/packed weights must follow in-place parameter updates (optimizer steps, load_state_dict)."""
     sd, _ = _calibrated_state(golden_dir)
@@ -298,7 +313,8 @@ def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
 @pytest.mark.parametrize("B,Ci,Co,F_,T,act,se,res", [
     (3, 80, 200, 8, 63, 2, False, False), (3, 184, 80, 8, 63, 0, False, True), (3, 112, 672, 8, 63, 2, False, False),
     (4, 672, 160, 4, 32, 0, True, False), (4, 160, 960, 4, 32, 2, False, False), (5, 960, 160, 4, 32, 0, True, True),
-    (2, 40, 240, 16, 125, 2, False, False), (2, 24, 72, 32, 250, 1, False, False), (2, 72, 40, 16, 125, 0, True, False)])
+    (2, 40, 240, 16, 125, 2, False, False), (2, 24, 72, 32, 250, 1, False, False), (2, 72, 40, 16, 125, 0, True, False),
+    (5, 672, 160, 4, 7, 0, True, False), (9, 960, 160, 2, 2, 0, True, True), (3, 160, 960, 1, 4, 2, False, False)])
 def test_pw_conv_bf16(B, Ci, Co, F_, T, act, se, res, split, tol):
     """bf16x3 (split) must be fp32-class; plain bf16 within bf16 round-off (config 3 compute dtype)."""
     x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
