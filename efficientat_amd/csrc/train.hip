@@ -342,6 +342,74 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
               s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 
+
+// Column-walking variant (depthwise, XC == C): the kernel above loads K*K predicated 4-byte x values per output
+// element (25 narrow loads for a 5x5) and is bound by the texture unit at ~1.4 TB/s.  Here a thread owns one output
+// column of one (b, c) plane and walks down the rows with the K x K input window in a register ring, as the forward
+// kernel does: K*STRIDE new x values + one dz value per output.  A block = one channel, TY samples x TX columns, and
+// loops over its slice of the batch; the K*K partial sums are reduced once per block (shuffles, LDS, K*K atomics).
+template <int K, int STRIDE>
+__global__ __launch_bounds__(256) void dw_wgrad_col_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                           float* __restrict__ dw, int B, int C, int F, int T, int Fo,
+                                                           int To, int TX, int b_per_block, int per_sample) {
+  constexpr int P = (K - 1) / 2;
+  constexpr int NSLOT = K;                              // ring of K rows: step R uses slots (u + R*STRIDE) % K
+  __shared__ float s_red[4][K * K];
+  const int tid = threadIdx.x;
+  const int tx = tid % TX, ty = tid / TX, TY = 256 / TX;
+  const int to = blockIdx.x * TX + tx;
+  const int c = blockIdx.y;
+  const int b0 = blockIdx.z * b_per_block;
+  const int b1 = (b0 + b_per_block) < B ? (b0 + b_per_block) : B;
+  float acc[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+  if (to < To) {
+    const int t0 = to * STRIDE - P;
+    bool cok[K];
+#pragma unroll
+    for (int v = 0; v < K; ++v) cok[v] = (t0 + v >= 0) && (t0 + v < T);
+    for (int bb = b0 + ty; bb < b1; bb += TY) {
+      const float* g = dz + ((size_t)bb * C + c) * Fo * To + to;
+      const float* xp = x + ((size_t)bb * C + c) * F * T;
+      float win[NSLOT][K];
+      auto load_row = [&](int fi, float (&dst)[K]) {
+        const bool rok = fi >= 0 && fi < F;
+        const float* src = xp + (size_t)(rok ? fi : 0) * T + t0;
+#pragma unroll
+        for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? src[v] : 0.0f;
+      };
+#pragma unroll
+      for (int u = 0; u < K - STRIDE; ++u) load_row(u - P, win[u]);      // rows kept from "step -1"
+      for (int fo0 = 0; fo0 < Fo; fo0 += K) {
+#pragma unroll
+        for (int R = 0; R < K; ++R) {                   // K steps = one full rotation of the ring
+          const int fo = fo0 + R;
+          if (fo < Fo) {
+#pragma unroll
+            for (int u = K - STRIDE; u < K; ++u) load_row(fo * STRIDE - P + u, win[(u + R * STRIDE) % NSLOT]);
+            const float gv = g[(size_t)fo * To];
+#pragma unroll
+            for (int u = 0; u < K; ++u)
+#pragma unroll
+              for (int v = 0; v < K; ++v) acc[u * K + v] = fmaf(gv, win[(u + R * STRIDE) % NSLOT][v], acc[u * K + v]);
+          }
+        }
+      }
+    }
+  }
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) {
+    const float t = eat::wave_sum(acc[i]);
+    if (lane == 0) s_red[wv][i] = t;
+  }
+  __syncthreads();
+  if (tid < K * K)
+    atomicAdd(dw + ((size_t)(per_sample ? b0 * C : 0) + c) * K * K + tid,
+              s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
+}
+
 // ---- pointwise weight gradient: dW[co,ci] = sum_{b,s} dz[b,co,s] x[b,ci,s] --------------------------------------
 // Both operands are contiguous along the reduction axis s: each lane loads 4 consecutive s as one
 // float4 and feeds them to 4 MFMAs (consistent k permutation).  Block = 4 waves on one 32 x 32
@@ -765,6 +833,29 @@ extern "C" int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const f
 static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T, int Fo, int To,
                          int k, int stride, int per_sample, eat_stream_t stream) {
   if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
+  static const bool old_kernel = getenv("EAT_DW_WGRAD_OLD") && atoi(getenv("EAT_DW_WGRAD_OLD")) != 0;
+  if (XC == C && !old_kernel && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+    // column-walking kernel: block = (column tile, channel, batch slice)
+    const int TX = To > 32 ? 64 : 32, TY = 256 / TX;
+    const int ct = (To + TX - 1) / TX;
+    int bpb = per_sample ? 1 : B;
+    if (!per_sample) {
+      // ~2048 blocks, but every thread should walk several planes before the block-wide reduction
+      long long want = (2048 + (long long)C * ct - 1) / ((long long)C * ct);
+      if (want < 1) want = 1;
+      bpb = (int)((B + want - 1) / want);
+      if (bpb < 4 * TY) bpb = 4 * TY < B ? 4 * TY : B;
+    }
+    dim3 grid(ct, C, (B + bpb - 1) / bpb);
+    hipStream_t s = (hipStream_t)stream;
+#define EAT_WGC(KK, SS) hipLaunchKernelGGL((dw_wgrad_col_kernel<KK, SS>), grid, dim3(256), 0, s, dz, x, dw, B, C, F, T, Fo, To, TX, bpb, per_sample)
+    if (k == 3 && stride == 1) EAT_WGC(3, 1);
+    else if (k == 3 && stride == 2) EAT_WGC(3, 2);
+    else if (k == 5 && stride == 1) EAT_WGC(5, 1);
+    else EAT_WGC(5, 2);
+#undef EAT_WGC
+    return eat::check_launch("eat_dw_conv_wgrad");
+  }
   // enough blocks to fill the chip: split the batch when there are few channels
   int splits = (2048 + C - 1) / C;
   if (splits > B || per_sample) splits = B;
