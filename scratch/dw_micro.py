@@ -3,7 +3,7 @@ import torch
 from efficientat_amd import ops
 dev = torch.device('cuda:0'); torch.manual_seed(0)
 B = 256
-cases = [(672,8,63,5,2,2,1),(672,8,63,5,2,2,0),(960,4,32,5,1,2,1),(960,4,32,5,1,2,0),(672,8,63,3,1,2,1),(672,8,63,3,1,2,0),(120,16,125,5,1,1,1),(120,16,125,5,1,1,0)]
+cases = [(672,8,63,5,2,2,1),(960,4,32,5,1,2,1),(240,16,125,3,2,2,0),(672,8,63,3,1,2,1),(480,8,63,3,1,2,1),(200,8,63,3,1,2,0)]
 def timeit(f, n=20):
     for _ in range(3): f()
     torch.cuda.synchronize()
