@@ -63,6 +63,9 @@ struct DwDyn {
   const float* res;     // (B, C, Fo, To) added to the output, or NULL
   int flip;             // read the taps reversed: the stride-1 data gradient is a correlation with flipped taps
   int per_plane_w;      // taps indexed by (b,c) plane instead of channel
+  const float* in_a;    // (C) or NULL: the conv input is act_in(in_a[c] * x + in_b[c]) evaluated on load (training:
+  const float* in_b;    //   batch-norm + activation of the expand conv fused into the depthwise conv, the activated
+  int in_act;           //   tensor is never materialised)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -110,11 +113,18 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     constexpr int NSLOT = K + STRIDE;
     constexpr int PERIOD = (NSLOT % STRIDE == 0) ? NSLOT / STRIDE : NSLOT;   // steps until the ring realigns
     float win[NSLOT][K];
+    const bool has_tf = DY && dyn.in_a != nullptr;
+    const float ia = has_tf ? dyn.in_a[c] : 1.0f, ib = has_tf ? dyn.in_b[c] : 0.0f;
     auto load_row = [&](int fi, float (&dst)[K]) {
       const bool rok = fi >= 0 && fi < F;              // uniform across the wave
       const float* src = xp + (size_t)(rok ? fi : 0) * T + t0;
+      if (has_tf) {                                    // zero padding applies to the TRANSFORMED map
 #pragma unroll
-      for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? src[v] : 0.0f;
+        for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? eat::activate_rt(fmaf(ia, src[v], ib), dyn.in_act) : 0.0f;
+      } else {
+#pragma unroll
+        for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? src[v] : 0.0f;
+      }
     };
 #pragma unroll
     for (int u = 0; u < K; ++u) load_row(u - P, win[u]);
@@ -199,6 +209,16 @@ extern "C" int eat_dw_conv_fwd(const float* x, const float* w, const float* bias
                                eat_stream_t stream) {
   eat::clear_stale_error();
   return dispatch_dw(x, w, bias, y, pool, B, C, F, T, Fo, To, k, stride, act, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int eat_dw_conv_fwd_tf(const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                                  const float* bias, float* y, int B, int C, int F, int T, int Fo, int To, int k,
+                                  int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!in_a || !in_b) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_tf: in_a and in_b are required");
+  if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_tf: bad in_act %d", in_act);
+  const DwDyn dyn{nullptr, nullptr, nullptr, nullptr, 0, 0, in_a, in_b, in_act};
+  return dispatch_dw(x, w, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
 }
 
 // stride-1 depthwise data gradient = the same sliding-window kernel with the taps read reversed

@@ -351,7 +351,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 template <int K, int STRIDE>
 __global__ __launch_bounds__(256) void dw_wgrad_col_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                            float* __restrict__ dw, int B, int C, int F, int T, int Fo,
-                                                           int To, int TX, int b_per_block, int per_sample) {
+                                                           int To, int TX, int b_per_block, int per_sample,
+                                                           const float* __restrict__ in_a,
+                                                           const float* __restrict__ in_b, int in_act) {
   constexpr int P = (K - 1) / 2;
   constexpr int NSLOT = K;                              // ring of K rows: step R uses slots (u + R*STRIDE) % K
   __shared__ float s_red[4][K * K];
@@ -364,6 +366,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_col_kernel(const float* __restri
   float acc[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+  // in_a != NULL: the conv input was act_in(in_a[c] * x + in_b[c]) evaluated on load (eat_dw_conv_fwd_tf)
+  const bool has_tf = in_a != nullptr;
+  const float ia = has_tf ? in_a[c] : 1.0f, ib = has_tf ? in_b[c] : 0.0f;
   if (to < To) {
     const int t0 = to * STRIDE - P;
     bool cok[K];
@@ -376,8 +381,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_col_kernel(const float* __restri
       auto load_row = [&](int fi, float (&dst)[K]) {
         const bool rok = fi >= 0 && fi < F;
         const float* src = xp + (size_t)(rok ? fi : 0) * T + t0;
+        if (has_tf) {
 #pragma unroll
-        for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? src[v] : 0.0f;
+          for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? eat::activate_rt(fmaf(ia, src[v], ib), in_act) : 0.0f;
+        } else {
+#pragma unroll
+          for (int v = 0; v < K; ++v) dst[v] = (rok && cok[v]) ? src[v] : 0.0f;
+        }
       };
 #pragma unroll
       for (int u = 0; u < K - STRIDE; ++u) load_row(u - P, win[u]);      // rows kept from "step -1"
@@ -831,9 +841,11 @@ extern "C" int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const f
 }
 
 static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T, int Fo, int To,
-                         int k, int stride, int per_sample, eat_stream_t stream) {
+                         int k, int stride, int per_sample, eat_stream_t stream, const float* in_a = nullptr,
+                         const float* in_b = nullptr, int in_act = 0) {
   if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
   static const bool old_kernel = getenv("EAT_DW_WGRAD_OLD") && atoi(getenv("EAT_DW_WGRAD_OLD")) != 0;
+  if (in_a && (XC != C || old_kernel)) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: needs the column-walking kernel");
   if (XC == C && !old_kernel && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
     // column-walking kernel: block = (column tile, channel, batch slice)
     const int TX = To > 32 ? 64 : 32, TY = 256 / TX;
@@ -848,7 +860,7 @@ static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int 
     }
     dim3 grid(ct, C, (B + bpb - 1) / bpb);
     hipStream_t s = (hipStream_t)stream;
-#define EAT_WGC(KK, SS) hipLaunchKernelGGL((dw_wgrad_col_kernel<KK, SS>), grid, dim3(256), 0, s, dz, x, dw, B, C, F, T, Fo, To, TX, bpb, per_sample)
+#define EAT_WGC(KK, SS) hipLaunchKernelGGL((dw_wgrad_col_kernel<KK, SS>), grid, dim3(256), 0, s, dz, x, dw, B, C, F, T, Fo, To, TX, bpb, per_sample, in_a, in_b, in_act)
     if (k == 3 && stride == 1) EAT_WGC(3, 1);
     else if (k == 3 && stride == 2) EAT_WGC(3, 2);
     else if (k == 5 && stride == 1) EAT_WGC(5, 1);
@@ -876,6 +888,15 @@ extern "C" int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int
                                  int Fo, int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();
   return dw_wgrad_impl(dz, x, dw, B, C, XC, F, T, Fo, To, k, stride, 0, stream);
+}
+
+extern "C" int eat_dw_conv_wgrad_tf(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act,
+                                    float* dw, int B, int C, int F, int T, int Fo, int To, int k, int stride,
+                                    eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!in_a || !in_b) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: in_a and in_b are required");
+  if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: bad in_act %d", in_act);
+  return dw_wgrad_impl(dz, x, dw, B, C, C, F, T, Fo, To, k, stride, 0, stream, in_a, in_b, in_act);
 }
 
 extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T, int Fo,

@@ -12,6 +12,8 @@ Tiny (B, C)-shaped glue of the SE gate and the head (ReLU/sigmoid/hardswish deri
 sums, transposes) uses torch elementwise ops; every GEMM / conv / reduction over activations runs
 in libeat_hip.so.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -43,6 +45,13 @@ class _Zeros:
 
 
 _zeros = _Zeros()
+
+
+# expand conv's BN + activation evaluated inside the depthwise conv / its weight gradient instead of a separate
+# bn_act_fwd pass (saves writing + re-reading the activated tensor).  OFF by default: measured 25.8 vs 24.6 ms per
+# mn10 step on MI355X - the activation is re-evaluated for each of the k taps a loaded value feeds, and the
+# depthwise kernels are issue/latency-bound, so the extra VALU work costs more than the saved 5.7 GB.
+_FUSE_EXPAND_BN = os.environ.get("EAT_FUSE_EXPAND_BN", "0") == "1"
 
 
 class _GradSink:
@@ -95,14 +104,19 @@ class MNTrainFunction(torch.autograd.Function):
                 wp = ops.pw_prepack(cna[0].weight.flatten(1))
                 z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
                 st_e = _conv_bn_stats(z_e, cna[1])
-                y_e = ops.bn_act_fwd(z_e, st_e[0], st_e[1], act)
                 rec.update(z_e=z_e, st_e=st_e)
-            else:
-                y_e = inp
             cna = blk.block[blk.i_dw]
             k = cnf.kernel
-            z_d = ops.dw_conv(y_e, cna[0].weight.reshape(-1, k * k), _zeros.get(cnf.expanded_channels, dev), k,
-                              cnf.stride, NONE)
+            if blk.i_expand is not None and _FUSE_EXPAND_BN:
+                # y_e = act(BN(z_e)) is consumed only by the depthwise conv (and its weight gradient): both
+                # evaluate it on load from z_e and the BN affine - the activated tensor is never written
+                y_e = None
+                z_d = ops.dw_conv_tf(z_e, st_e[0], st_e[1], act, cna[0].weight.reshape(-1, k * k),
+                                     _zeros.get(cnf.expanded_channels, dev), k, cnf.stride)
+            else:
+                y_e = ops.bn_act_fwd(z_e, st_e[0], st_e[1], act) if blk.i_expand is not None else inp
+                z_d = ops.dw_conv(y_e, cna[0].weight.reshape(-1, k * k), _zeros.get(cnf.expanded_channels, dev), k,
+                                  cnf.stride, NONE)
             st_d = _conv_bn_stats(z_d, cna[1])
             S_d = z_d.shape[2] * z_d.shape[3]
             pool = torch.empty((B, cnf.expanded_channels), device=dev) if blk.i_se is not None else None
@@ -227,9 +241,16 @@ class MNTrainFunction(torch.autograd.Function):
             del dxs
             g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
             y_e = rec["y_e"]
-            g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
+            if y_e is None:             # fused expand-BN: the depthwise input is act(a z_e + b), evaluated on load
+                st_e = rec["st_e"]
+                g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad_tf(dz_d, rec["z_e"], st_e[0], st_e[1], act, k,
+                                                                       cnf.stride).view_as(cna[0].weight)
+                in_shape = tuple(rec["z_e"].shape)
+            else:
+                g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
+                in_shape = tuple(y_e.shape)
             no_expand = blk.i_expand is None
-            dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), tuple(y_e.shape), k, cnf.stride,
+            dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
                                      res=res_grad if no_expand else None)
             del dz_d
             if no_expand:

@@ -60,6 +60,16 @@ def dw_conv(x, w, bias, k, stride, act, pool=None):
     return y
 
 
+def dw_conv_tf(x, in_a, in_b, in_act, w, bias, k, stride):
+    """Depthwise conv of act_in(in_a[c] * x + in_b[c]) (evaluated on load), no output activation (train mode)."""
+    B, C, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_fwd_tf", _dev(x, "x"), _dev(in_a, "in_a"), _dev(in_b, "in_b"), in_act, _dev(w, "w"),
+              _dev(bias, "bias"), y.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
+    return y
+
+
 def pw_prepack(w2d, row_scale=None):
     Co, Ci = w2d.shape
     wp = torch.empty(((Ci // 4) * ((Co + 15) // 16) * 64,), device=w2d.device, dtype=torch.float32)
@@ -152,6 +162,16 @@ def dw_conv_wgrad(dz, x, k, stride):
     dw = torch.zeros((C, k * k), device=dz.device, dtype=torch.float32)
     _lib.call("eat_dw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), dw.data_ptr(), B, C, XC, F, T, Fo, To, k, stride,
               _stream())
+    return dw
+
+
+def dw_conv_wgrad_tf(dz, x, in_a, in_b, in_act, k, stride):
+    """Depthwise weight gradient whose x operand is act_in(in_a[c] * x + in_b[c]), evaluated on load."""
+    B, C, Fo, To = dz.shape
+    F, T = x.shape[2], x.shape[3]
+    dw = torch.zeros((C, k * k), device=dz.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_wgrad_tf", _dev(dz, "dz"), _dev(x, "x"), _dev(in_a, "in_a"), _dev(in_b, "in_b"), in_act,
+              dw.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
     return dw
 
 

@@ -218,6 +218,20 @@ int eat_fused_expand_dw_fwd(const float* x, const float* wp_e, const float* bias
                             const float* bias_d, float* y, float* pool, int B, int Cin, int Cexp, int F,
                             int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream);
 
+/* ---- training: batch-norm + activation of the expand conv fused into the depthwise conv -----------------
+ * The depthwise conv of an inverted-residual block consumes act(BN(z_e)) (models/mn/block_types.py:138-162).
+ * In the training step z_e and the per-channel affine (a, b) of its batch-norm are known, so the activated
+ * tensor need not exist: the conv evaluates act_in(in_a[c] * x + in_b[c]) on load (zero padding applies to the
+ * transformed map), and so does the weight gradient, which needs the same tensor as its x operand.
+ *   eat_dw_conv_fwd_tf:   y (B,C,Fo,To) = dwconv_k,s(act_in(in_a x + in_b)) + bias, no output activation;
+ *   eat_dw_conv_wgrad_tf: dw (C,k*k) ZEROED by the caller += sum dz * act_in(in_a x + in_b) (shifted). */
+int eat_dw_conv_fwd_tf(const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                       const float* bias, float* y, int B, int C, int F, int T, int Fo, int To, int k,
+                       int stride, eat_stream_t stream);
+int eat_dw_conv_wgrad_tf(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act,
+                         float* dw, int B, int C, int F, int T, int Fo, int To, int k, int stride,
+                         eat_stream_t stream);
+
 /* ---- network front (eval): stem conv + first block in one kernel --------------------------------
  * models/mn/model.py:124-133 (3x3/s2 conv + BN + Hardswish on the (B,1,F,T) log-mel) followed by the first
  * inverted-residual block (no expand, no SE: depthwise 3x3/s1 + BN + act, project 1x1 + BN, + residual;

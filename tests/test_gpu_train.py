@@ -199,6 +199,27 @@ def test_train_step_updates_weights_and_eval_follows(golden_dir):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("B,C,F_,T,k,s,act", [(2, 64, 32, 100, 3, 2, 1), (3, 120, 16, 125, 5, 1, 2), (2, 672, 8, 63, 5, 2, 2),
+                                              (2, 40, 9, 21, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1)])
+def test_dw_conv_with_input_transform(B, C, F_, T, k, s, act):
+    """Depthwise conv / weight gradient whose input is act(a[c] x + b[c]) evaluated on load (eat_dw_conv_fwd_tf,
+    eat_dw_conv_wgrad_tf) vs materialising the activated tensor first (zero padding applies to the activated map)."""
+    x, w = _rand(B, C, F_, T, seed=1), _rand(C, 1, k, k, seed=2, scale=0.3)
+    a = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5
+    b = _rand(C, seed=4, scale=0.5)
+    f = [None, F.relu, F.hardswish][act]
+    xa = f(x.double() * a.double().view(1, C, 1, 1) + b.double().view(1, C, 1, 1))
+    ref = F.conv2d(xa, w.double(), None, s, (k - 1) // 2, 1, C)
+    wd = w.reshape(C, k * k).contiguous().to(DEV)
+    got = ops.dw_conv_tf(x.to(DEV), a.to(DEV), b.to(DEV), act, wd, torch.zeros(C, device=DEV), k, s)
+    assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    dz = _rand(*ref.shape, seed=5)
+    cols = F.unfold(xa.reshape(B * C, 1, F_, T), k, padding=(k - 1) // 2, stride=s)            # (B*C, k*k, Fo*To)
+    ref_dw = (cols * dz.double().reshape(B * C, 1, -1)).sum(-1).reshape(B, C, k * k).sum(0)
+    got_dw = ops.dw_conv_wgrad_tf(dz.to(DEV), x.to(DEV), a.to(DEV), b.to(DEV), act, k, s)
+    assert float((got_dw.cpu().double() - ref_dw).abs().max()) < 2e-5 * float(ref_dw.abs().max())
+
+
 @pytest.mark.parametrize("how", ["fused_adam", "graph"])
 def test_eval_after_versionless_updates_uses_fresh_weights(how):
     """Fused optimizers and hipGraph replays update parameters / BN buffers WITHOUT bumping tensor version
