@@ -172,11 +172,12 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
       if constexpr (NPROD == 3) {
         const bf16x8 al = Af[(i * NP2 + 1) * 64];
+        // the three products of one accumulator are issued 4 MFMAs apart (back-to-back MFMAs on the SAME
+        // accumulator stall on the read-after-write of the previous result)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl_[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl_[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
       }
     }
     if (n_stages == 1 && c + 1 < n_chunks) {      // single stage: refill it once every wave has consumed chunk c
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 
   eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
 }
+
 
 template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
