@@ -846,7 +846,7 @@ static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int 
   if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
   static const bool old_kernel = getenv("EAT_DW_WGRAD_OLD") && atoi(getenv("EAT_DW_WGRAD_OLD")) != 0;
   if (in_a && (XC != C || old_kernel)) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: needs the column-walking kernel");
-  if (XC == C && !old_kernel && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+  if (XC == C && !old_kernel && !per_sample && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
     // column-walking kernel: block = (column tile, channel, batch slice)
     const int TX = To > 32 ? 64 : 32, TY = 256 / TX;
     const int ct = (To + TX - 1) / TX;
@@ -909,7 +909,9 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
                          int per_sample, eat_stream_t stream) {
   // default: split-operand bf16 MFMA kernel (fp32-class accuracy); EAT_WGRAD_FP32=1 or S % 4 != 0: exact fp32 MFMA kernel
   static const bool force_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
-  if (!force_fp32 && (S & 3) == 0) {
+  // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs) keep the 32 x 32-tile fp32 kernel: a 128 x 128 tile
+  // of atomics per sample and block costs more than the short reduction it follows (dymn20 step: 163 vs 115 ms)
+  if (!force_fp32 && !per_sample && (S & 3) == 0) {
     const int sps = (S + 31) / 32;
     const int tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
     const long long total = (long long)B * sps;
