@@ -368,7 +368,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 synthetic "
                                "10 s @ 32 kHz clips per GPU, fp32 [BASELINE.json configs[1]]",
-                   "batch_per_gpu": args.batch, "launch": ("hipGraph replay" if graph is not None else "eager") +
+                   "batch_per_gpu": args.batch,
+                   "arithmetic": "fp32 activations and accumulation; 1x1 convs: exact fp32 MFMA for C_in < 40, split-operand "
+                                 "bf16x3 MFMA (x = hi + lo, 3 products, ~2^-16 rel. error) for C_in >= 40 [EAT_PW_MODE=fp32 forces "
+                                 "exact fp32 everywhere]",
+                   "launch": ("hipGraph replay" if graph is not None else "eager") +
                              (f", {n_str} concurrent sub-batch streams" if n_str > 1 else ""),
                    "parallelism": f"dp{world} (independent clips, no collective)"},
         "roofline_e2e": {"bound": "hbm", "achieved": round(clips_per_s / world * ALG_BYTES_PER_CLIP / 1e9, 1),
