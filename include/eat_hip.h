@@ -99,7 +99,9 @@ int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
  * The reference trains with nn.BatchNorm2d(eps=1e-3, momentum=0.01) in train mode and leaves the
  * backward pass to autograd (ex_audioset.py:147-199).  Formulas: SURVEY.md Appendix C. */
 
-/* sums (2C doubles, zeroed by the caller): sums[c] += sum z, sums[C+c] += sum z^2 over (B, S). */
+/* Batch statistics of nn.BatchNorm2d in train mode (norm layer of every ConvNormActivation:
+ * models/mn/model.py:114-115, block_types.py:138-171).
+ * sums (2C doubles, zeroed by the caller): sums[c] += sum z, sums[C+c] += sum z^2 over (B, S). */
 int eat_bn_stats(const float* z, int B, int C, int S, double* sums, eat_stream_t stream);
 
 /* From the sums: batch mean, biased variance -> a = gamma*invstd, b = beta - mean*a (so that
@@ -114,7 +116,9 @@ int eat_bn_finalize(const double* sums, const float* gamma, const float* beta, f
 int eat_bn_act_fwd(const float* z, const float* a, const float* b, const float* res, float* y,
                    float* pool, int B, int C, int S, int act, eat_stream_t stream);
 
-/* Backward of y = act(a*z + b) under batch statistics, with the incoming gradient
+/* autograd of BatchNorm2d (train) + activation [+ the SE multiply of block_types.py:83] in
+ * ex_audioset.py:197 (loss.backward()):
+ * Backward of y = act(a*z + b) under batch statistics, with the incoming gradient
  * g_in[b,c,s] = dy[b,c,s]*gscale[b,c] + gadd[b,c] (gscale/gadd may be NULL: the SE scale and the
  * broadcast gradient of the squeeze are folded in here).  Pass 1 accumulates per channel
  * sums[c] += sum g, sums[C+c] += sum g*xhat with g = g_in*act'(a z + b) (= dbeta, dgamma);
@@ -128,23 +132,27 @@ int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const 
                          const float* gadd, const double* sums, float* dz, int B, int C, int S,
                          int act, eat_stream_t stream);
 
-/* out[b,c] = sum_s u[b,c,s] * v'[b,c,s] with v' = v (a == NULL) or act(a_c*v + b_c): the gradient
+/* autograd of the SE scale multiply (models/mn/block_types.py:83):
+ * out[b,c] = sum_s u[b,c,s] * v'[b,c,s] with v' = v (a == NULL) or act(a_c*v + b_c): the gradient
  * w.r.t. the SE scale, d s[b,c] = sum_s d(x*s) * x. */
 int eat_plane_dot(const float* u, const float* v, const float* a, const float* b, float* out, int B,
                   int C, int S, int act, eat_stream_t stream);
 
-/* Depthwise conv data gradient dx (B,C,F,T) from dz (B,C,Fo,To), taps w (C,k,k); res (B,C,F,T) or
+/* autograd of the depthwise Conv2d of models/mn/block_types.py:150-162 (data gradient):
+ * Depthwise conv data gradient dx (B,C,F,T) from dz (B,C,Fo,To), taps w (C,k,k); res (B,C,F,T) or
  * NULL is added (residual branch gradient). */
 int eat_dw_conv_dgrad(const float* dz, const float* w, const float* res, float* dx, int B, int C,
                       int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
 
-/* Depthwise / stem weight gradient dw (C,k,k) += sum dz * shifted x; x has XC = C (depthwise) or
+/* autograd of the depthwise Conv2d (models/mn/block_types.py:150-162) and of the stem Conv2d (mn/model.py:124-133):
+ * Depthwise / stem weight gradient dw (C,k,k) += sum dz * shifted x; x has XC = C (depthwise) or
  * XC = 1 (3x3 stem, stride 2) channels.  dw must be zeroed by the caller. */
 int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, int XC, int F, int T,
                       int Fo, int To, int k, int stride, eat_stream_t stream);
 
-/* Pointwise weight gradient dW (Co,Ci) += sum_{b,s} dz[b,co,s] * x[b,ci,s] * x_scale[b,ci]
- * (fp32 MFMA; x_scale (B,Ci) or NULL is the SE scale the forward applied to x); dW must be
+/* autograd of the 1x1 Conv2d layers (models/mn/block_types.py:138-147,167-171; mn/model.py:159-167):
+ * Pointwise weight gradient dW (Co,Ci) += sum_{b,s} dz[b,co,s] * x[b,ci,s] * x_scale[b,ci]
+ * (split-operand bf16 MFMA with fp32-class accuracy by default, exact fp32 MFMA with EAT_WGRAD_FP32=1; x_scale (B,Ci) or NULL is the SE scale the forward applied to x); dW must be
  * zeroed by the caller.  The data gradient is eat_pw_conv_fwd with the packed W^T. */
 int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
                       int Ci, int S, eat_stream_t stream);
@@ -161,7 +169,8 @@ int eat_ctx_pool(const float* x, float* seq, int B, int C, int F, int T, eat_str
 int eat_dyn_aggregate(const float* bank, const float* att, const float* gscale, float* out, int B,
                       int K, int N, int group, eat_stream_t stream);
 
-/* The same aggregation for a 1x1 DynamicConv written straight into MFMA A-fragment order, one
+/* DynamicConv.forward, models/dymn/dy_block.py:111-119 (attention-weighted sum of the K kernels):
+ * the same aggregation for a 1x1 DynamicConv written straight into MFMA A-fragment order, one
  * packed matrix of (Ci/4)*ceil(Co/16)*64 floats per sample (input of eat_pw_conv_dyn_fwd). */
 int eat_dyn_pw_pack(const float* bank, const float* att, const float* row_scale, float* wp, int B,
                     int K, int Co, int Ci, eat_stream_t stream);
@@ -181,12 +190,14 @@ int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const float* bias, co
 
 /* ---- DyMN training step: backward of the dynamic pieces -------------------- */
 
-/* dx (B,C,F,T) = broadcast of dseq (B,F+T,C): dseq[b,f,c]/T + dseq[b,F+t,c]/F, plus add (same shape
+/* autograd of the context pooling, models/dymn/dy_block.py:236-237 (adaptive_avg_pool2d over T and over F):
+ * dx (B,C,F,T) = broadcast of dseq (B,F+T,C): dseq[b,f,c]/T + dseq[b,F+t,c]/F, plus add (same shape
  * as dx) or NULL. */
 int eat_ctx_pool_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T,
                      eat_stream_t stream);
 
-/* Stand-alone DyReLU-B + CoordAtt (train mode, after the BatchNorm statistics are known):
+/* DyReLUB.forward (models/dymn/dy_block.py:172-188) + CoordAtt.forward (:195-201) and their autograd.
+ * Stand-alone DyReLU-B + CoordAtt (train mode, after the BatchNorm statistics are known):
  * out = max(a1 v + b1, a2 v + b2) * sigmoid(gate_f) * sigmoid(gate_t), v = a_c z + b_c (a,b NULL: v=z);
  * the backward returns dv (same shape as z), dcoef (B,C,4), and the PRE-sigmoid gate gradients. */
 int eat_dyrelu_ca_fwd(const float* z, const float* a, const float* b, const float* coef,
@@ -196,12 +207,14 @@ int eat_dyrelu_ca_bwd(const float* dout, const float* z, const float* a, const f
                       const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
                       float* dgate_t, int B, int C, int Fo, int To, eat_stream_t stream);
 
-/* From the per-sample weight gradients G (B,N): dbank (K,N) = att^T G, datt (B,K) += G bank^T
+/* autograd of the kernel aggregation of DynamicConv.forward (models/dymn/dy_block.py:103-127):
+ * From the per-sample weight gradients G (B,N): dbank (K,N) = att^T G, datt (B,K) += G bank^T
  * (datt zeroed by the caller). */
 int eat_dyn_bank_grad(const float* G, const float* att, const float* bank, float* dbank, float* datt,
                       int B, int K, int N, eat_stream_t stream);
 
-/* Per-sample / per-plane variants of the conv gradients used by the dynamic convs: dW_b (B,Co,Ci)
+/* autograd of the grouped F.conv2d of DynamicConv.forward (models/dymn/dy_block.py:120-127):
+ * Per-sample / per-plane variants of the conv gradients used by the dynamic convs: dW_b (B,Co,Ci)
  * (zeroed), dw_bc (B,C,k*k) (zeroed), and the depthwise data gradient with per-plane taps. */
 int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,
                           eat_stream_t stream);
