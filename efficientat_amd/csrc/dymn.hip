@@ -51,23 +51,49 @@ __global__ __launch_bounds__(256) void dyn_aggregate_kernel(const float* __restr
 }
 
 // wp[b][(ks*MT + mt)*64 + lane] = rs[m] * sum_k att[b,k] * bank[k][m*Ci + kc],  m = mt*16 + (lane&15), kc = ks*4 + (lane>>4)
+// Block = (16-row m-tile, sample).  The 16 rows of a bank are one contiguous run of 16*Ci floats, so they are read
+// with coalesced loads in 256-column pieces, mixed with the sample's attention weights and parked in LDS (row pitch
+// 257: the transposing reads below then hit 16 different banks); the MFMA A-fragment order is written back as
+// 256-byte runs.  (Computing each packed element straight from global memory made every lane of a load touch a
+// different row, i.e. a different cache line, for each of the K banks: 2.6 TB/s of packed output at best.)
+constexpr int kPackCols = 256;
 __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restrict__ bank, const float* __restrict__ att,
                                                           const float* __restrict__ row_scale, float* __restrict__ wp,
                                                           int K, int Co, int Ci, int MT) {
-  const int b = blockIdx.y;
-  const int total = (Ci / 4) * MT * 64;
+  __shared__ float s_w[16 * (kPackCols + 1)];
+  const int mt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int m0 = mt * 16;
+  const int rows = (Co - m0) < 16 ? (Co - m0) : 16;
   const float* a = att + (size_t)b * K;
   const size_t N = (size_t)Co * Ci;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, mt = (i >> 6) % MT, ks = (i >> 6) / MT;
-    const int m = mt * 16 + (lane & 15), kc = ks * 4 + (lane >> 4);
-    float v = 0.0f;
-    if (m < Co) {
-      const size_t n = (size_t)m * Ci + kc;
-      for (int k = 0; k < K; ++k) v = fmaf(a[k], bank[(size_t)k * N + n], v);
-      if (row_scale) v *= row_scale[m];
+  float* out = wp + (size_t)b * (Ci / 4) * MT * 64;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int m = lane & 15;
+  const float rs = (row_scale && m0 + m < Co) ? row_scale[m0 + m] : 1.0f;
+  for (int c0 = 0; c0 < Ci; c0 += kPackCols) {
+    const int cols = (Ci - c0) < kPackCols ? (Ci - c0) : kPackCols;     // multiple of 4
+    // phase 1: 16 x cols aggregated weights -> LDS (thread = (row, 4 columns))
+    for (int e = tid; e < 16 * (cols >> 2); e += 256) {
+      const int r = e / (cols >> 2), q = e - r * (cols >> 2);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows) {
+        const size_t n = (size_t)(m0 + r) * Ci + c0 + 4 * q;
+        for (int k = 0; k < K; ++k) {
+          const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + n);
+          const float ak = a[k];
+          v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
+        }
+      }
+      float* d = s_w + r * (kPackCols + 1) + 4 * q;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    wp[(size_t)b * total + i] = v;
+    __syncthreads();
+    // phase 2: fragment order, one k-step (64 floats) per wave and iteration
+    for (int ks = wv; ks < (cols >> 2); ks += 4) {
+      const int kc = ks * 4 + (lane >> 4);
+      out[((size_t)((c0 >> 2) + ks) * MT + mt) * 64 + lane] = s_w[m * (kPackCols + 1) + kc] * rs;
+    }
+    __syncthreads();
   }
 }
 
@@ -233,10 +259,7 @@ extern "C" int eat_dyn_pw_pack(const float* bank, const float* att, const float*
   eat::clear_stale_error();
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack: Ci=%d must be a multiple of 4", Ci);
   const int MT = (Co + 15) / 16;
-  const int total = (Ci / 4) * MT * 64;
-  int gx = (total + 255) / 256;
-  if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(dyn_pw_pack_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, bank, att, row_scale, wp, K, Co,
+  hipLaunchKernelGGL(dyn_pw_pack_kernel, dim3(MT, B), dim3(256), 0, (hipStream_t)stream, bank, att, row_scale, wp, K, Co,
                      Ci, MT);
   return eat::check_launch("eat_dyn_pw_pack");
 }
