@@ -75,7 +75,13 @@ class Linear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.linear(dy, _t(w), None, NONE)
-        dw = ops.linear(_t(dy), _t(x), None, NONE)
+        M = dy.shape[0]
+        if M >= 4096 and M % 4 == 0 and x.shape[1] % 4 == 0:
+            # long reductions (M = B * (F + T) rows of the context sequence): dW = dy^T x is the 1x1 weight-gradient
+            # GEMM with one "sample" of M positions - split-K over many blocks instead of 4 waves of the linear kernel
+            dw = ops.pw_conv_wgrad(_t(dy).view(1, dy.shape[1], M, 1), _t(x).view(1, x.shape[1], M, 1))
+        else:
+            dw = ops.linear(_t(dy), _t(x), None, NONE)
         db = _col_sum(dy) if ctx.has_bias else None
         return dx, dw, db
 
