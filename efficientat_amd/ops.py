@@ -8,6 +8,9 @@ from . import _lib
 ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_SIGMOID = 0, 1, 2, 3
 
 
+_PRIMARY = ("x", "dz", "wave", "z", "dy")
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -18,6 +21,10 @@ def _dev(t, name):
                                f"(got device {t.device})")
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise _lib.EatHipError(f"{name} must be contiguous float32 (got {t.dtype}, contiguous={t.is_contiguous()})")
+    if name in _PRIMARY and t.device.index != torch.cuda.current_device():   # checked on the main operand only
+        # kernels are launched on the CURRENT device's stream: one process per GPU (torch.cuda.set_device), or
+        # wrap the call in `with torch.cuda.device(t.device):`
+        raise _lib.EatHipError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}")
     return t.data_ptr()
 
 
