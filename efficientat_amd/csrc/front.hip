@@ -39,6 +39,8 @@ __global__ __launch_bounds__(256) void front_kernel(const float* __restrict__ x,
   __shared__ __attribute__((aligned(16))) float Ms[kMF * kMTPad];
   __shared__ __attribute__((aligned(16))) float Ss[kC * kSPad];
   __shared__ __attribute__((aligned(16))) float Ds[kC * kTF * kTT];
+  __shared__ float s_wd[kC * 9 + kC];          // depthwise taps + bias: staged once per block (phase C read them with
+                                               // 18 per-thread global loads, a dependent L2 round trip per pass)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kq = lane >> 4;
   const int tile = blockIdx.x, b = blockIdx.y;
   const int tf = tile / tiles_t, tt = tile - tf * tiles_t;
@@ -55,6 +57,8 @@ __global__ __launch_bounds__(256) void front_kernel(const float* __restrict__ x,
 #pragma unroll
   for (int r = 0; r < 4; ++r) bpv[r] = bp[kq * 4 + r];
 
+  if (tid < kC * 9) s_wd[tid] = wd[tid];
+  else if (tid < kC * 9 + kC) s_wd[tid] = bd[tid - kC * 9];
   // ---- A. log-mel patch
   for (int e = tid; e < kMF * kMTPad; e += 256) {
     const int i = e / kMTPad, j = e - i * kMTPad;
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(256) void front_kernel(const float* __restrict__ x,
       for (int v = 0; v < 3; ++v) col[u][v] = sp[u * kST + v];
     float wr[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) wr[i] = wd[ch * 9 + i];
-    const float bdc = bd[ch];
+    for (int i = 0; i < 9; ++i) wr[i] = s_wd[ch * 9 + i];
+    const float bdc = s_wd[kC * 9 + ch];
 #pragma unroll
     for (int fl = 0; fl < kTF; ++fl) {
       float s = bdc;
