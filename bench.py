@@ -1,21 +1,31 @@
 """bench.py -- hot-path throughput on MI355X.
 
-One "step" = one pass of the hot path (fused log-mel front-end + mn10_as forward, eval, fp32)
-over one batch of synthetic 10 s @ 32 kHz clips already resident in HBM (BASELINE.json configs[1]:
-"mn10_as forward-only, batch 256 synthetic 10 s clips, 1xMI355X, fp32").  With --gpus N every rank
-processes its own batch of the same size (clips are independent: no data-path collective), so
-value = N * batch * steps / max-over-ranks time and scaling is "weak".
+One "step" = one pass of the hot path (fused log-mel front-end + mn10_as forward, eval, fp32) over one batch of
+synthetic 10 s @ 32 kHz clips already resident in HBM (BASELINE.json configs[1]: "mn10_as forward-only, batch 256
+synthetic 10 s clips, 1xMI355X, fp32").  With --gpus N every rank processes its own batch of the same size (clips are
+independent: no data-path collective), value = N * batch * steps / max-over-ranks time, scaling "weak".
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel's algorithmic HBM bytes per launch / its mean launch duration
-                (HIP events on the launch stream), against the 8 TB/s HBM3E peak
-  cpu_baseline  the CPU oracle (a port of the reference's torch-CPU path) timed on this host
+`python bench.py --gpus N` started WITHOUT a torchrun environment re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` (one rank per GPU, RCCL); started by torchrun it
+reads RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to print a line when fewer than N ranks / GPUs are available.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline       dominant kernel's algorithmic HBM bytes (or flops) per launch / its mean launch duration (HIP events
+                 on the launch stream) against the 8 TB/s HBM3E (or MFMA) peak
+  roofline_e2e   whole forward at SURVEY 8(d)'s 96.37 MB algorithmic bytes per clip
+  fp32_exact     the same forward with EVERY 1x1 conv on the exact fp32 MFMA (EAT_PW_MODE=fp32 arithmetic)
+  train_step     BASELINE's fwd+bwd metric: mel + forward (batch-stat BN) + BCE + backward + [RCCL all-reduce] + Adam,
+                 mn10, 256 clips per GPU, hipGraph replay
+  train_step_mn40_bf16 / train_step_dymn20   BASELINE configs[2] / configs[3] (batch 128; N = 1 only)
+  cpu_baseline   the CPU oracle (a port of the reference's torch-CPU path) timed on this host: mel, forward, train step
 """
 import argparse
 import contextlib
 import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,11 +40,26 @@ MFMA_BF16_PEAK = 2.5e15                 # FLOP/s, dense bf16 MFMA (no sparsity),
 MFMA_F32_PEAK = 157.3e12               # FLOP/s, dense fp32-input MFMA (= fp32 vector peak), same guide
 CLIP_SAMPLES = 320000                  # 10 s @ 32 kHz
 ALG_BYTES_PER_CLIP = 96.37e6           # mn10 fwd 94.50 MB + weights/B + mel 1.79 MB
+ALG_TRAIN = {"mn10": 285.8e6, "mn40": 581.5e6, "mn40_bf16": 581.5e6, "dymn20": 324.6e6, "dymn10": None}
 
 
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
+
+
+def _fan_in_init(model, head_scale=None):
+    """random init that keeps activations O(1) through ~46 un-trained BN layers (fan-in scaling), so the kernels
+    see realistic (non-collapsed, non-zero) data"""
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
+            elif isinstance(m, torch.nn.Linear) and head_scale is not None:
+                m.weight.normal_(0, (1.0 / m.weight.shape[1]) ** 0.5)
+        if head_scale is not None:
+            model.classifier[5].weight.mul_(head_scale)   # keep |logits| O(1) so the parity probe reads like 1e-3 abs
 
 
 def build_model(dev):
@@ -43,16 +68,7 @@ def build_model(dev):
     torch.manual_seed(0)
     mel = quiet(AugmentMelSTFT, freqm=0, timem=0).to(dev).eval()
     model = quiet(get_model, width_mult=1.0)
-    # random init that keeps activations O(1) through 46 un-trained BN layers (fan-in scaling),
-    # so the kernels see realistic (non-collapsed, non-zero) data
-    with torch.no_grad():
-        for m in model.modules():
-            if isinstance(m, torch.nn.Conv2d):
-                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
-                m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
-            elif isinstance(m, torch.nn.Linear):
-                m.weight.normal_(0, (1.0 / m.weight.shape[1]) ** 0.5)
-        model.classifier[5].weight.mul_(0.05)      # keep |logits| O(1) so the parity probe reads like 1e-3 abs
+    _fan_in_init(model, head_scale=0.05)
     return mel, model.to(dev).eval()
 
 
@@ -102,6 +118,12 @@ def _alg_bytes(name, a):
     if name == "eat_linear_fwd":
         x, w, bias, y, B, K, N = a[:7]
         return "linear_kernel", 4 * (B * K + N * K + B * N), 2 * B * K * N
+    if name == "eat_se_gate_fwd":
+        pool, w1, b1, w2, b2, out, B, C, Q = a[:9]
+        return "se_gate_kernel", 4 * (2 * B * C + 2 * C * Q), 4 * B * C * Q
+    if name == "eat_head_fwd":
+        pool, w1, b1, w2, b2, out, B, C, H, N = a[:10]
+        return "head_kernel", 4 * (B * C + C * H + H * N + B * N), 2 * B * H * (C + N)
     return name, 0, 0
 
 
@@ -144,29 +166,60 @@ def kernel_profile(step, iters=3):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(budget_s=12.0, batch=16):
-    """The CPU oracle (port of the reference torch-CPU path: mel + mn10 eval forward) on host cores."""
+def cpu_baseline(budget_s=7.0, batch=32):
+    """The CPU oracle (a port of the reference's torch-CPU path) on this host's cores, SURVEY 8(d): batch 32, fp32,
+    torch.set_num_threads(all cores), separate figures for the log-mel front-end, the mn10 eval forward and the full
+    training step (mel + forward with batch-stat BN + BCE + backward + Adam; ex_audioset.py:139-199).  Each leg is a
+    bounded sample: one warm-up pass, then whole passes until `budget_s` seconds are spent."""
+    import torch.nn.functional as F
     from oracle import eat_oracle as O
     from oracle import synth
+    cores = torch.get_num_threads()              # torch's default: one thread per physical core of the host
     sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
     g = torch.Generator().manual_seed(1234)
     x = (0.1 * torch.randn(batch, CLIP_SAMPLES, generator=g)).clamp_(-1, 1)
+    y = (torch.rand(batch, 527, generator=g) < 2.7 / 527).float()
+    with torch.no_grad():
+        m = O.mel_forward(x).unsqueeze(1)
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))]
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    opt = torch.optim.Adam(list(params.values()), lr=8e-4)
 
-    def once():
+    def mel_leg():
         with torch.no_grad():
-            O.mn_forward(sd, O.mel_forward(x).unsqueeze(1))
+            O.mel_forward(x)
 
-    once()
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        once()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 50:
-            break
-    return {"value": round(batch * n / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n} iters x batch {batch} of the same workload (mel + mn10 fwd, fp32, torch CPU)"}
+    def fwd_leg():
+        with torch.no_grad():
+            O.mn_forward(sd, m)
+
+    def train_leg():
+        sdt = dict(sd)
+        sdt.update(params)
+        opt.zero_grad(set_to_none=True)
+        logits, _ = O.mn_forward(sdt, O.mel_forward(x).unsqueeze(1), train=True, stats={})
+        F.binary_cross_entropy_with_logits(logits, y).backward()
+        opt.step()
+
+    def rate(fn, max_iters=50):
+        fn()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= max_iters:
+                return batch * n / dt, n
+
+    mel_r, mel_n = rate(mel_leg)
+    fwd_r, fwd_n = rate(fwd_leg)
+    trn_r, trn_n = rate(train_leg)
+    both = 1.0 / (1.0 / mel_r + 1.0 / fwd_r)
+    return {"value": round(both, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "mel_clips_s": round(mel_r, 2), "fwd_clips_s": round(fwd_r, 2), "train_step_clips_s": round(trn_r, 2),
+            "sample": f"batch {batch}, fp32, torch CPU with {cores} threads ({os.cpu_count()} logical CPUs): mel {mel_n} / mn10 fwd {fwd_n} / train step "
+                      f"{trn_n} passes (~{budget_s:.0f} s each); value = mel + fwd, the bench workload"}
 
 
 def parity_probe(mel, model, dev):
@@ -181,54 +234,107 @@ def parity_probe(mel, model, dev):
     return float((got.cpu() - ref).abs().max()), float(ref.abs().max())
 
 
-def train_bench(args, mel, model, wave, dev, dist, world, barrier):
+# ----------------------------------------------------------------------------- timing helpers
+class Ranks:
+    """torch.distributed plumbing of the bench: barrier + device sync on both sides of a timed region, max over ranks."""
+
+    def __init__(self, dist, world, dev):
+        self.dist, self.world, self.dev = dist, world, dev
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def timed(self, run, steps):
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        self.barrier()
+        el = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([el], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+
+def forward_bench(args, mel, model, wave, ranks):
+    """(clips/s over all ranks, ms per step, launch description) of the eval forward on `wave`."""
+    from efficientat_amd.graphs import GraphedForward
+    launch = "eager"
+    run = None
+    if not args.no_graph:
+        try:
+            gf = GraphedForward(model, mel, wave, streams=args.streams)
+            run = gf.replay
+            launch = "hipGraph replay" + (f", {len(gf.streams)} concurrent sub-batch streams" if gf.streams else "")
+        except Exception as e:  # pragma: no cover - report, then measure eagerly
+            print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
+    if run is None:
+        def run():
+            with torch.no_grad():
+                model(mel(wave).unsqueeze(1))
+    for _ in range(args.warmup):
+        run()
+    el = ranks.timed(run, args.steps)
+    return ranks.world * wave.shape[0] * args.steps / el, el / args.steps * 1e3, launch
+
+
+def make_train_model(name, dev):
+    torch.manual_seed(0)
+    if name.startswith("dymn"):
+        from efficientat_amd.dymn import get_model as gm
+        model = quiet(gm, width_mult=2.0 if name == "dymn20" else 1.0)
+    else:
+        from efficientat_amd.mn import get_model as gm
+        model = quiet(gm, width_mult=4.0 if name.startswith("mn40") else 1.0)
+        model.train_precision = "bf16" if name.endswith("bf16") else os.environ.get("EAT_TRAIN_PRECISION", "auto")
+    _fan_in_init(model, head_scale=0.05 if name == "mn10" else None)
+    return model.to(dev)
+
+
+def train_bench(name, batch, steps, warmup, args, mel, wave, ranks):
     """Full training step per GPU: log-mel (train mode) -> forward (batch-stat BN) -> BCE-with-logits ->
-    hand-written backward -> [bucketed RCCL all-reduce of the 19.5 MB gradient, overlapped] -> Adam.
-    Mirrors ex_audioset.py:139-199 without data loading / wandb / KD teacher."""
+    hand-written backward -> [bucketed RCCL all-reduce of the gradient, overlapped with backward] -> fused Adam.
+    Mirrors ex_audioset.py:139-199 without data loading / wandb / KD teacher.  The step (incl. the collectives when
+    N > 1) is captured into one hipGraph and replayed; the log-mel stays outside (host RNG draws per step)."""
     import torch.nn.functional as F
     from efficientat_amd.dp import enable_data_parallel
-    bt = min(args.train_batch, wave.shape[0])
+    dev = ranks.dev
+    model = make_train_model(name, dev)
+    bt = min(batch, wave.shape[0])
     w = wave[:bt]
-    alg = 285.8e6                                    # SURVEY 8(d) train-step bytes per clip, mn10 fp32
-    if args.train_model != "mn10":                   # BASELINE configs 3 / 4 (parity cases, timed on request)
-        torch.manual_seed(0)
-        if args.train_model.startswith("dymn"):
-            from efficientat_amd.dymn import get_model as gm
-            model = quiet(gm, width_mult=2.0 if args.train_model == "dymn20" else 1.0).to(dev)
-            alg = 324.6e6 if args.train_model == "dymn20" else None
-        else:
-            from efficientat_amd.mn import get_model as gm
-            model = quiet(gm, width_mult=4.0).to(dev)
-            model.train_precision = "bf16" if args.train_model.endswith("bf16") else "fp32"
-            alg = 581.5e6
-        with torch.no_grad():
-            for m in model.modules():
-                if isinstance(m, torch.nn.Conv2d):
-                    fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
-                    m.weight.normal_(0, (2.0 / fan_in) ** 0.5)
     g = torch.Generator(device=dev).manual_seed(99)
     y = (torch.rand((bt, 527), device=dev, generator=g) < 2.7 / 527).float()
-    use_dp = world > 1 or dist is not None
+    use_dp = ranks.dist is not None
     if use_dp:
-        enable_data_parallel(model)
-    graphed = not use_dp and not args.no_graph
-    # fused=True: one multi-tensor kernel per step (the foreach path spends ~350 tiny launches per step on the
-    # per-parameter bias-correction scalars)
-    opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=graphed, fused=True)
+        enable_data_parallel(model, force_buckets=ranks.world == 1)
+    graphed = not args.no_graph
     model.train()
     mel.train()
     launch = "eager"
+    opt = None
     if graphed:
-        # the step is launch-bound when issued eagerly (~35 ms of host time for ~500 launches):
-        # capture fwd + loss + bwd + Adam once, replay per step; the mel front-end stays outside
+        # the step is launch-bound when issued eagerly (~35 ms of host time for ~500 launches): capture fwd + loss +
+        # bwd + [all-reduce] + Adam once, replay per step.  fused=True: one multi-tensor kernel per step (the foreach
+        # path spends ~350 tiny launches per step on the per-parameter bias-correction scalars)
         try:
             from efficientat_amd.graphs import GraphedTrainStep
+            opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=True, fused=True)
             gstep = GraphedTrainStep(model, opt, F.binary_cross_entropy_with_logits, mel(w).unsqueeze(1), y)
-            launch = "hipGraph replay (mel eager)"
+            launch = "hipGraph replay (mel eager" + (", RCCL all-reduce captured)" if use_dp else ")")
         except Exception as e:  # pragma: no cover
-            print(f"[bench] train-step graph capture failed ({e}); eager", file=sys.stderr)
+            print(f"[bench] train-step graph capture failed for {name} ({type(e).__name__}: {e}); eager", file=sys.stderr)
             graphed = False
-            opt = torch.optim.Adam(model.parameters(), lr=8e-4, fused=True)
+            model = make_train_model(name, dev)
+            if use_dp:
+                enable_data_parallel(model, force_buckets=ranks.world == 1)
+            model.train()
+    if not graphed:
+        opt = torch.optim.Adam(model.parameters(), lr=8e-4, fused=True)
 
     def tstep():
         if graphed:
@@ -240,149 +346,158 @@ def train_bench(args, mel, model, wave, dev, dist, world, barrier):
         opt.step()
         return loss
 
-    for _ in range(max(2, args.warmup // 2)):
-        tstep()
-    steps = max(3, args.steps // 3)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tstep()
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    cps = world * bt * steps / el
-    return {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
-            "batch_per_gpu": bt, "final_loss": round(float(loss), 5), "launch": launch,
-            "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if world > 1 else "") + "Adam, fp32",
-            "model": args.train_model,
-            "roofline_e2e_frac": round(cps / world * alg / HBM_PEAK, 4) if alg else None,
-            "alg_bytes_per_clip": alg}
+    out = {}
+    for _ in range(max(2, warmup)):
+        out["loss"] = tstep()
+    el = ranks.timed(lambda: out.__setitem__("loss", tstep()), steps)
+    cps = ranks.world * bt * steps / el
+    alg = ALG_TRAIN.get(name)
+    res = {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+           "warmup": max(2, warmup), "batch_per_gpu": bt, "n_gpus": ranks.world, "final_loss": round(float(out["loss"]), 5),
+           "launch": launch, "model": name,
+           "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if use_dp else "") + "fused Adam; "
+                   + ("bf16 MFMA 1x1 GEMMs, fp32 activations" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
+           "roofline_e2e_frac": round(cps / ranks.world * alg / HBM_PEAK, 4) if alg else None,
+           "alg_bytes_per_clip": alg}
+    mel.eval()
+    del model, opt
+    if graphed:
+        del gstep
+    torch.cuda.empty_cache()
+    return res
 
 
-def main():
+# ----------------------------------------------------------------------------- launch plumbing
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a torchrun environment: become the launcher of N ranks."""
+    if not args.dry_run:
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {n_vis} GPU(s) visible: refusing to print a bench line")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (needed by RCCL on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--no-train", action="store_true", help="skip the train-step measurement")
-    ap.add_argument("--train-batch", type=int, default=128, help="clips per GPU per train step")
-    ap.add_argument("--train-model", default="mn10", choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20"],
-                    help="network of the train-step measurement (mn40_bf16 / dymn20 = BASELINE configs 3 / 4)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches issued on concurrent HIP streams per step")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-train", action="store_true", help="skip every train-step measurement")
+    ap.add_argument("--train-batch", type=int, default=256, help="clips per GPU per mn10 train step")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed mn10 train steps (>= 20 by default)")
+    ap.add_argument("--no-train-configs", action="store_true", help="skip the mn40_bf16 / dymn20 train steps (configs 2/3)")
+    ap.add_argument("--train-model", default=None, choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20"],
+                    help="only this train-step network (debug)")
+    ap.add_argument("--no-fp32-exact", action="store_true", help="skip the exact-fp32 forward measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event profile to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank plumbing only (gloo, CPU, no kernels): used by the CPU test of the N-rank launch path")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a bench line")
     force_dist = os.environ.get("EAT_BENCH_FORCE_DIST") == "1"    # exercise the RCCL path with a single rank (debug)
+    dist = None
     if world > 1 or force_dist:
         import torch.distributed as dist
-        if force_dist and world == 1:
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-            os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")    # required to capture collectives in a graph
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if dist is not None:
+            dist.init_process_group("gloo")
+        ranks = Ranks(dist, world, dev)
+        el = ranks.timed(lambda: time.sleep(0.001 * (rank + 1)), args.steps)
+        if rank == 0:
+            print(json.dumps({"metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": 0.0, "unit": "clips/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+                              "dry_run": True}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist is not None:
         dist.init_process_group("nccl", device_id=dev)
+    ranks = Ranks(dist, world, dev)
 
+    from efficientat_amd import mn as mn_mod
     mel, model = build_model(dev)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(args.batch, CLIP_SAMPLES, device=dev, generator=g)).clamp_(-1, 1)
 
-    out = {}
-    n_str = max(1, args.streams)
-    streams = [torch.cuda.Stream() for _ in range(n_str)] if n_str > 1 else []
-    chunks = wave.chunk(n_str) if n_str > 1 else [wave]
-
-    def step():
-        with torch.no_grad():
-            if n_str == 1:
-                out["logits"], out["feat"] = model(mel(wave).unsqueeze(1))
-                return
-            # the batch is cut into `streams` sub-batches issued on their own HIP streams (fork / join inside
-            # the captured graph): latency-bound kernels of one sub-batch (SE GEMMs, mel, kernel tails) overlap
-            # with bandwidth-bound kernels of the other
-            cur = torch.cuda.current_stream()
-            res = []
-            for st, wv in zip(streams, chunks):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    res.append(model(mel(wv).unsqueeze(1)))
-            for st in streams:
-                cur.wait_stream(st)
-            out["logits"] = [r[0] for r in res]
-            out["feat"] = [r[1] for r in res]
-
-    step()                               # folds / packs weights, builds mel tables
-    torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-        except Exception as e:  # pragma: no cover - report, then measure eagerly
-            print(f"[bench] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr)
-            graph = None
-    run = graph.replay if graph is not None else step
-
-    for _ in range(args.warmup):
-        run()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    clips_per_s = world * args.batch * args.steps / elapsed
+    clips_per_s, ms_step, launch = forward_bench(args, mel, model, wave, ranks)
+    arithmetic = {
+        "auto": "fp32 activations and accumulation; 1x1 convs: exact fp32 MFMA for C_in < 40, split-operand bf16x3 MFMA "
+                "(x = hi + lo, 3 products, ~2^-16 rel. error) for C_in >= 40 [fp32_exact: every 1x1 on the exact fp32 MFMA]",
+        "fp32": "fp32 activations, exact fp32 MFMA / VALU everywhere"}.get(mn_mod._PW_MODE, mn_mod._PW_MODE)
     result = {
         "metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": round(clips_per_s, 1), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 synthetic "
                                "10 s @ 32 kHz clips per GPU, fp32 [BASELINE.json configs[1]]",
-                   "batch_per_gpu": args.batch,
-                   "arithmetic": "fp32 activations and accumulation; 1x1 convs: exact fp32 MFMA for C_in < 40, split-operand "
-                                 "bf16x3 MFMA (x = hi + lo, 3 products, ~2^-16 rel. error) for C_in >= 40 [EAT_PW_MODE=fp32 forces "
-                                 "exact fp32 everywhere]",
-                   "launch": ("hipGraph replay" if graph is not None else "eager") +
-                             (f", {n_str} concurrent sub-batch streams" if n_str > 1 else ""),
-                   "parallelism": f"dp{world} (independent clips, no collective)"},
+                   "batch_per_gpu": args.batch, "arithmetic": arithmetic, "launch": launch,
+                   "parallelism": f"dp{world} (independent clips, no collective in the forward)"},
         "roofline_e2e": {"bound": "hbm", "achieved": round(clips_per_s / world * ALG_BYTES_PER_CLIP / 1e9, 1),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(clips_per_s / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
                          "note": "whole forward: clips/s per GPU x 96.37 MB algorithmic bytes per clip (SURVEY 8d)"},
     }
 
+    if not args.no_fp32_exact and mn_mod._PW_MODE != "fp32":
+        keep = mn_mod._PW_MODE
+        mn_mod._PW_MODE = "fp32"
+        model._cache.invalidate()
+        try:
+            v, ms, _ = forward_bench(args, mel, model, wave, ranks)
+            result["fp32_exact"] = {"value": round(v, 1), "unit": "clips/s", "ms_per_step": round(ms, 4),
+                                    "roofline_e2e_frac": round(v / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
+                                    "what": "the same forward with every 1x1 conv on v_mfma_f32_16x16x4_f32 (exact fp32 products)"}
+        finally:
+            mn_mod._PW_MODE = keep
+            model._cache.invalidate()
+
     if not args.no_train:
-        result["train_step"] = train_bench(args, mel, model, wave, dev, dist, world, barrier)
+        legs = [("train_step", args.train_model or "mn10", args.train_batch, max(args.train_steps, 1), 3)]
+        if world == 1 and not args.no_train_configs and args.train_model is None:
+            legs += [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2)]
+        for key, name, bt, st, wu in legs:
+            try:
+                result[key] = train_bench(name, bt, st, wu, args, mel, wave, ranks)
+            except Exception as e:  # pragma: no cover - one failing leg must not lose the line
+                if dist is not None:
+                    raise
+                result[key] = {"error": f"{type(e).__name__}: {e}", "model": name}
+                torch.cuda.empty_cache()
         model.eval()
         mel.eval()
 
@@ -396,15 +511,19 @@ def main():
         per_launch_bytes = d["bytes"] / d["launches"]
         per_launch_flops = d["flops"] / d["launches"]
         per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r1.json")
-        if os.path.exists(tpath):
-            # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
-            import fnmatch
-            ks = json.load(open(tpath))["kernels"]
-            hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
-            traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches_sampled"] for h in hit) /
-                          sum(h["launches_sampled"] for h in hit)) if hit else None
+        traffic, tsrc = None, None
+        for tfile in ("pmc_traffic_r2.json", "pmc_traffic_r1.json"):
+            tpath = os.path.join(ROOT, "profiles", tfile)
+            if os.path.exists(tpath):
+                # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
+                import fnmatch
+                ks = json.load(open(tpath))["kernels"]
+                hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
+                if hit:
+                    traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches_sampled"] for h in hit) /
+                                  sum(h["launches_sampled"] for h in hit))
+                    tsrc = f"profiles/{tfile} (rocprofv3 FETCH_SIZE [x2 for 16-byte-lane readers] + WRITE_SIZE, separate passes, B=256 launches only)"
+                    break
         # which roof binds this kernel: the larger of its HBM time and its MFMA time.  The MFMA peak is the
         # one of the instruction the kernel issues: fp32 16x16x4 (157 TF), bf16 16x16x32 (2.5 PF dense), and
         # for the bf16x3 split kernel 2.5 PF / 3 because each useful product costs three bf16 MFMAs.
@@ -417,7 +536,7 @@ def main():
                   "alg_flops_per_launch": int(per_launch_flops),
                   "hbm_gbps": round(per_launch_bytes / per_launch_s / 1e9, 1),
                   "mfma_tflops": round(per_launch_flops / per_launch_s / 1e12, 2),
-                  "traffic_source": "profiles/pmc_traffic_r1.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                  "traffic_source": tsrc,
                   "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
         if mfma_bound:
             ach = per_launch_flops / per_launch_s

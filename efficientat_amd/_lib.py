@@ -35,7 +35,7 @@ SIGNATURES = {
     "eat_plane_dot": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dw_conv_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "eat_pw_conv_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_pw_conv_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_ctx_pool": [_P, _P, _I, _I, _I, _I, _P],
     "eat_dyn_aggregate": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dyn_pw_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -364,11 +364,13 @@ extern "C" int eat_pw_prepack(const float* w, const float* row_scale, float* wp,
 
 static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,
                        float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s) {
-  if (Ci % 4 != 0 || S % 4 != 0)
-    return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d must be a multiple of 4", Ci);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
-  if (B < 1 || Ci < 4 || Co < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
+  if (B < 1 || Ci < 4 || Co < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
   const int MT = (Co + 15) / 16;
+  if (S % 4 != 0)      // planes that do not start on 16-byte boundaries (e.g. 40-mel models): plain 4-byte kernel
+    return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, 0,
+                                per_sample ? (long long)(Ci / 4) * MT * 64 * (long long)sizeof(float) : 0, s);
   // Row chunking.  Every block re-reads its 256-column x tile, and a CU takes in only ~10 B/clk, so
   // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks

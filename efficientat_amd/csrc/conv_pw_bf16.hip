@@ -252,11 +252,13 @@ extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float*
                                     const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
                                     int split, eat_stream_t stream) {
   eat::clear_stale_error();
-  if (Ci % 4 != 0 || S % 4 != 0)
-    return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: Ci=%d must be a multiple of 4", Ci);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: bad act %d", act);
+  if (B < 1 || Co < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: bad shape");
   const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
   hipStream_t s = (hipStream_t)stream;
+  if (S % 4 != 0)      // planes that do not start on 16-byte boundaries: plain 4-byte kernel on the same packs
+    return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split ? 2 : 1, 0, s);
   return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act)
                : dispatch<1>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act);
 }

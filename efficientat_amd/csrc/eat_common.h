@@ -47,6 +47,12 @@ constexpr int kWave = 64;
 int dw_conv_dgrad_s1(const float* dz, const float* w, const float* zero_bias, const float* res, float* dx, int B, int C,
                      int F, int T, int k, int per_plane_w, hipStream_t s);
 
+// conv_pw_generic.hip: 1x1 conv for plane sizes that are not a multiple of 4 (same packed weights / epilogue contract;
+// wmode 0 = fp32 pack, 1 = bf16 pack, 2 = bf16 hi/lo pack; wp_bstride_bytes != 0 selects per-sample weights)
+int pw_conv_generic(const float* x, const void* wp, const float* bias, const float* in_scale, const float* res, float* y,
+                    float* pool, int B, int Ci, int Co, int S, int act, int wmode, long long wp_bstride_bytes,
+                    hipStream_t s);
+
 }  // namespace eat
 
 #define EAT_DISPATCH_ACT(act, ...)                                    \

@@ -906,9 +906,11 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 }
 
 static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                         int per_sample, eat_stream_t stream) {
-  // default: split-operand bf16 MFMA kernel (fp32-class accuracy); EAT_WGRAD_FP32=1 or S % 4 != 0: exact fp32 MFMA kernel
-  static const bool force_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
+                         int per_sample, int exact_fp32, eat_stream_t stream) {
+  // default: split-operand bf16 MFMA kernel (fp32-class accuracy); exact_fp32 (the caller's precision choice),
+  // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel
+  static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
+  const bool force_fp32 = env_fp32 || exact_fp32 != 0;
   // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs) keep the 32 x 32-tile fp32 kernel: a 128 x 128 tile
   // of atomics per sample and block costs more than the short reduction it follows (dymn20 step: 163 vs 115 ms)
   if (!force_fp32 && !per_sample && (S & 3) == 0) {
@@ -947,13 +949,13 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
 }
 
 extern "C" int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
-                                 int Ci, int S, eat_stream_t stream) {
+                                 int Ci, int S, int exact_fp32, eat_stream_t stream) {
   eat::clear_stale_error();
-  return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, stream);
+  return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream);
 }
 
 extern "C" int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,
                                      eat_stream_t stream) {
   eat::clear_stale_error();
-  return pw_wgrad_impl(dz, x, nullptr, dW_b, B, Co, Ci, S, 1, stream);
+  return pw_wgrad_impl(dz, x, nullptr, dW_b, B, Co, Ci, S, 1, 0, stream);
 }

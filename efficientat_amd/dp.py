@@ -18,10 +18,17 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, process_group=None, bucket_bytes=4 << 20):
+    def __init__(self, process_group=None, bucket_bytes=4 << 20, local=False, force_buckets=False):
+        """local=True: pass-through (no collective) whatever the state of torch.distributed - what a model that was
+        never handed to `enable_data_parallel` uses, so that wrapping it in torch DDP, or running backward on a
+        subset of ranks, neither reduces twice nor deadlocks.  force_buckets=True: pack / all-reduce / unpack even
+        with a single rank (exercises the bucket path on one GPU; tests and EAT_BENCH_FORCE_DIST)."""
         self.group = process_group
         self.bucket_bytes = bucket_bytes
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.world = 1 if local or not dist.is_initialized() else dist.get_world_size(process_group)
+        self.bucketed = (self.world > 1 or force_buckets) and not local
+        if self.bucketed and not dist.is_initialized():
+            raise RuntimeError("GradReducer(force_buckets=True) needs an initialised torch.distributed process group")
         self._reset()
 
     def _reset(self):
@@ -30,7 +37,7 @@ class GradReducer:
         self.out = {}
 
     def push(self, name, grad):
-        if self.world == 1:
+        if not self.bucketed:
             self.out[name] = grad
             return
         self.cur.append((name, grad))
@@ -63,7 +70,7 @@ class GradReducer:
         return out
 
 
-def enable_data_parallel(model, process_group=None, bucket_bytes=4 << 20, broadcast=True):
+def enable_data_parallel(model, process_group=None, bucket_bytes=4 << 20, broadcast=True, force_buckets=False):
     """Attach a GradReducer to `model` (used by its train-mode backward) and, like DDP, broadcast
     rank 0's parameters and buffers so all replicas start identical."""
     if not dist.is_initialized():
@@ -72,7 +79,7 @@ def enable_data_parallel(model, process_group=None, bucket_bytes=4 << 20, broadc
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t, src=0, group=process_group)
-    reducer = GradReducer(process_group, bucket_bytes)
+    reducer = GradReducer(process_group, bucket_bytes, force_buckets=force_buckets)
     if getattr(model, "_monolithic_backward", False):
         # MN: the single backward Function pushes gradients itself as it produces them (mn_train.py)
         model._grad_reducer = reducer
@@ -97,7 +104,7 @@ def install_grad_hooks(model, reducer):
                     p.grad.copy_(g)
 
     def hook(p):
-        if reducer.world == 1:
+        if not reducer.bucketed:
             return
         if not state["pending"]:
             state["pending"] = True

@@ -79,7 +79,7 @@ class Linear(torch.autograd.Function):
         if M >= 4096 and M % 4 == 0 and x.shape[1] % 4 == 0:
             # long reductions (M = B * (F + T) rows of the context sequence): dW = dy^T x is the 1x1 weight-gradient
             # GEMM with one "sample" of M positions - split-K over many blocks instead of 4 waves of the linear kernel
-            dw = ops.pw_conv_wgrad(_t(dy).view(1, dy.shape[1], M, 1), _t(x).view(1, x.shape[1], M, 1))
+            dw = ops.pw_conv_wgrad(_t(dy).view(1, dy.shape[1], M, 1), _t(x).view(1, x.shape[1], M, 1), exact=False)
         else:
             dw = ops.linear(_t(dy), _t(x), None, NONE)
         db = _col_sum(dy) if ctx.has_bias else None
@@ -93,16 +93,16 @@ class BnAct(torch.autograd.Function):
     def forward(ctx, z, gamma, beta, bn, act):
         z = z.contiguous()
         C = z.shape[1]
-        st = ops.bn_finalize(ops.bn_stats(z), bn, z.numel() // C)
-        bn.num_batches_tracked += 1
+        st = ops.bn_train_state(z, bn)
         ctx.save_for_backward(z, *st)
         ctx.act = act
+        ctx.frozen = getattr(st[2], "_eat_frozen", False)
         return ops.bn_act_fwd(z, st[0], st[1], act)
 
     @staticmethod
     def backward(ctx, dy):
         z, a, b, mean, invstd = ctx.saved_tensors
-        dz, dgam, dbet = ops.bn_act_bwd(dy.contiguous(), z, a, b, mean, invstd, ctx.act)
+        dz, dgam, dbet = ops.bn_act_bwd(dy.contiguous(), z, a, b, mean, invstd, ctx.act, frozen=ctx.frozen)
         return dz, dgam, dbet, None, None
 
 
@@ -134,7 +134,7 @@ class PwConv(torch.autograd.Function):
         dz = dz.contiguous()
         Ci = x.shape[1]
         dx = ops.pw_conv(dz, ops.pw_prepack(_t(w.flatten(1))), _zeros.get(Ci, x.device), Ci, NONE)
-        return dx, ops.pw_conv_wgrad(dz, x).view_as(w)
+        return dx, ops.pw_conv_wgrad(dz, x, exact=False).view_as(w)
 
 
 def _bank_grad(G, att, bank):
@@ -254,8 +254,12 @@ def _block_train(blk, x):
     gj = Linear.apply(seq.view(B * L, cin), cg.joint_conv.weight.flatten(1), None)     # (B*L, H)
     # BatchNorm of the context sequence over (B, L) per channel (joint_norm), batch statistics
     bn = cg.joint_norm
-    gj = F.batch_norm(gj, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
-    bn.num_batches_tracked += 1
+    if bn.training:
+        gj = F.batch_norm(gj, bn.running_mean, bn.running_var, bn.weight, bn.bias, True,
+                          bn.momentum if bn.momentum is not None else 1.0 / (int(bn.num_batches_tracked) + 1), bn.eps)
+        bn.num_batches_tracked += 1
+    else:                                    # frozen BatchNorm inside a train-mode pass: running statistics
+        gj = F.batch_norm(gj, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
     g = F.hardswish(gj).view(B, L, H)
     h_c = g.mean(dim=1)
     h_cf, h_ct = g[:, :Fq], g[:, Fq:]
@@ -291,7 +295,9 @@ def forward_train(model, x):
     fc1, fc2, drop = model.classifier[2], model.classifier[5], model.classifier[4]
     h = F.hardswish(Linear.apply(feat, fc1.weight, fc1.bias))
     override = getattr(model, "_drop_mask_override", None)
-    if override is not None:
+    if not drop.training:
+        pass                                  # nn.Dropout switched to eval() inside model.train()
+    elif override is not None:
         h = h * (override.to(h.device).float() / (1.0 - drop.p))
     elif drop.p > 0:
         h = F.dropout(h, drop.p, True)

@@ -9,8 +9,67 @@ they are recorded like any other node) and replayed with one host call per step.
 
 The log-mel front-end stays outside the graph: in train mode its mel basis changes every step
 (fmin/fmax jitter drawn on the host, models/preprocess.py:45-55) and is uploaded from host memory.
+
+`GraphedForward` does the same for the eval path (log-mel + network, ~60 launches per batch): the batch is cut into
+sub-batches issued on concurrent HIP streams inside the captured graph, so that the latency-bound kernels of one
+sub-batch (SE / head GEMMs, kernel tails) overlap with the bandwidth-bound kernels of the other.
 """
 import torch
+
+
+class GraphedForward:
+    """logits, features = fwd(wave): hipGraph replay of eval-mode `model(mel(wave).unsqueeze(1))`.
+
+    Static shapes: every call must pass a (B, L) batch of the example's shape (it is copied into the captured input
+    buffer; pass nothing / the buffer itself - `fwd.wave` - to skip the copy).  The weights are folded / packed at
+    construction: rebuild the object after a parameter update.  `streams` sub-batches run concurrently."""
+
+    def __init__(self, model, mel, wave_example, streams=2):
+        if model.training or mel.training:
+            raise RuntimeError("GraphedForward captures the eval path: call model.eval() / mel.eval() first")
+        self.model, self.mel = model, mel
+        self.wave = wave_example.detach().clone()
+        n = max(1, min(int(streams), self.wave.shape[0]))
+        self.chunks = list(self.wave.chunk(n))
+        self.streams = [torch.cuda.Stream() for _ in self.chunks] if len(self.chunks) > 1 else []
+        self.logits = self.features = None
+        self._issue()                                    # folds / packs the weights, builds the mel tables
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._issue()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._issue()
+
+    def _issue(self):
+        with torch.no_grad():
+            if not self.streams:
+                self.logits, self.features = self.model(self.mel(self.wave).unsqueeze(1))
+                return
+            cur = torch.cuda.current_stream()
+            res = []
+            for st, wv in zip(self.streams, self.chunks):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    res.append(self.model(self.mel(wv).unsqueeze(1)))
+            for st in self.streams:
+                cur.wait_stream(st)
+            self.logits = torch.cat([r[0] for r in res])
+            self.features = torch.cat([r[1] for r in res])
+
+    def replay(self):
+        self.graph.replay()
+
+    def __call__(self, wave=None):
+        if wave is not None and wave.data_ptr() != self.wave.data_ptr():
+            if wave.shape != self.wave.shape:
+                raise ValueError(f"GraphedForward was captured for {tuple(self.wave.shape)}, got {tuple(wave.shape)}")
+            self.wave.copy_(wave)
+        self.graph.replay()
+        return self.logits, self.features
 
 
 class GraphedTrainStep:

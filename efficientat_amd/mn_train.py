@@ -68,11 +68,7 @@ class _GradSink:
 
 
 def _conv_bn_stats(z, bn):
-    B, C = z.shape[0], z.shape[1]
-    n = z.numel() // C
-    a, b, mean, invstd = ops.bn_finalize(ops.bn_stats(z), bn, n)
-    bn.num_batches_tracked += 1
-    return a, b, mean, invstd
+    return ops.bn_train_state(z, bn)
 
 
 class MNTrainFunction(torch.autograd.Function):
@@ -168,7 +164,8 @@ class MNTrainFunction(torch.autograd.Function):
     def _backward_impl(ctx, model, sv, dlogits, dfeat):
         # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
         # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
-        g = _GradSink(getattr(model, "_grad_reducer", None) or GradReducer())
+        # a model that was never handed to dp.enable_data_parallel keeps its gradients local (no hidden collective)
+        g = _GradSink(getattr(model, "_grad_reducer", None) or GradReducer(local=True))
         dev = dlogits.device
         dlogits = dlogits.contiguous().float()
         B = dlogits.shape[0]
@@ -281,11 +278,11 @@ def forward_train(model, x):
     """Train-mode `(logits, features)` with autograd support (mn/model.py:212-231 in `.train()`)."""
     drop = model.classifier[4]
     mask = None
-    if drop.p > 0:
+    if drop.p > 0 and drop.training:
         n_hidden = model.classifier[2].out_features
         mask = torch.empty((x.shape[0], n_hidden), device=x.device).bernoulli_(1.0 - drop.p) / (1.0 - drop.p)
     override = getattr(model, "_drop_mask_override", None)       # tests replay the reference's mask
-    if override is not None:
+    if override is not None and drop.training:
         mask = override.to(x.device).float() / (1.0 - drop.p)
     params = [p for _, p in model.named_parameters()]
     with ops.precision(getattr(model, "train_precision", "fp32")):

@@ -111,15 +111,37 @@ def bn_stats(z):
     return sums
 
 
-def bn_finalize(sums, bn, n):
+def bn_finalize(sums, bn, n, momentum=None):
     """-> (a, b, mean, invstd); updates bn.running_mean / running_var in place (momentum rule)."""
     C = bn.num_features
     out = torch.empty((4, C), device=sums.device, dtype=torch.float32)
-    mom = bn.momentum if bn.momentum is not None else 0.0
+    mom = momentum if momentum is not None else (bn.momentum if bn.momentum is not None else 0.0)
     _lib.call("eat_bn_finalize", sums.data_ptr(), _dev(bn.weight, "gamma"), _dev(bn.bias, "beta"),
               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom), float(bn.eps), float(n), C,
               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
     return out[0], out[1], out[2], out[3]
+
+
+def bn_train_state(z, bn):
+    """(a, b, mean, invstd) of one BatchNorm layer inside a train-mode pass, honouring the layer's OWN mode:
+    * bn.training: batch statistics; running buffers updated with `momentum` (None = cumulative moving average
+      with factor 1 / num_batches_tracked, torch semantics), num_batches_tracked += 1;
+    * bn.eval() inside model.train() (the freeze-BN fine-tuning recipe): running statistics, no buffer update; the
+      returned state is flagged so that `bn_act_bwd` treats the layer as a fixed affine map."""
+    C = z.shape[1]
+    if not bn.training:
+        with torch.no_grad():
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+            a = (bn.weight * invstd).contiguous()
+            st = (a, (bn.bias - bn.running_mean * a).contiguous(), bn.running_mean.clone(), invstd.contiguous())
+        st[2]._eat_frozen = True
+        return st
+    mom = bn.momentum
+    if mom is None:
+        mom = 1.0 / (int(bn.num_batches_tracked) + 1)          # host read: this mode is not graph-capturable
+    st = bn_finalize(bn_stats(z), bn, z.numel() // C, momentum=mom)
+    bn.num_batches_tracked += 1
+    return st
 
 
 def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True):
@@ -131,8 +153,12 @@ def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True):
     return y
 
 
-def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None):
-    """-> (dz, dgamma, dbeta) for y = act(BN_batch(z)); incoming grad = dy*gscale[b,c] + gadd[b,c]."""
+def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None):
+    """-> (dz, dgamma, dbeta) for y = act(BN_batch(z)); incoming grad = dy*gscale[b,c] + gadd[b,c].
+    frozen (default: the flag `bn_train_state` left on `mean`): the layer normalised with its running statistics,
+    i.e. dz = a * g without the batch-mean terms (dgamma / dbeta are the same reductions)."""
+    if frozen is None:
+        frozen = getattr(mean, "_eat_frozen", False)
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
     sums = torch.zeros((2 * C,), device=z.device, dtype=torch.float64)
@@ -140,7 +166,8 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None):
             _opt(gscale, "gscale"), _opt(gadd, "gadd"))
     _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
     dz = torch.empty_like(z)
-    _lib.call("eat_bn_act_bwd_apply", *args, sums.data_ptr(), dz.data_ptr(), B, C, S, act, _stream())
+    asums = torch.zeros_like(sums) if frozen else sums
+    _lib.call("eat_bn_act_bwd_apply", *args, asums.data_ptr(), dz.data_ptr(), B, C, S, act, _stream())
     sf = sums.float()
     return dz, sf[C:], sf[:C]
 
@@ -182,13 +209,17 @@ def dw_conv_wgrad_tf(dz, x, in_a, in_b, in_act, k, stride):
     return dw
 
 
-def pw_conv_wgrad(dz, x, x_scale=None):
+def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
+    """dW (Co, Ci) = sum_b dz[b] (Co,S) . (x[b] * x_scale[b])^T.  exact=True: fp32 MFMA kernel; False: split-operand
+    bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact)."""
+    if exact is None:
+        exact = precision.mode == "fp32"
     B, Co = dz.shape[0], dz.shape[1]
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
     dW = torch.zeros((Co, Ci), device=dz.device, dtype=torch.float32)
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
-              S, _stream())
+              S, 1 if exact else 0, _stream())
     return dW
 
 

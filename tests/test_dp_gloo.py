@@ -91,3 +91,61 @@ def test_grad_hooks_world2_gloo():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_hook_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_modes(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # local=True: no collective although a process group exists (a model that was never handed to
+        # enable_data_parallel must not all-reduce behind the caller's back, e.g. under torch DDP or rank-0-only backward)
+        red = GradReducer(local=True)
+        t = torch.full((5,), float(rank + 1))
+        if rank == 0:                      # only ONE rank pushes: a hidden collective would deadlock here
+            red.push("w", t)
+            out = red.finish()
+            ok = out["w"] is t
+        else:
+            ok = True
+        dist.barrier()
+        # default reducer in the same group: averaged
+        red2 = GradReducer(bucket_bytes=8)
+        red2.push("w", t.clone())
+        red2.push("v", torch.ones(3) * rank)
+        out2 = red2.finish()
+        ok = ok and torch.allclose(out2["w"], torch.full((5,), (1 + world) / 2.0)) and \
+            torch.allclose(out2["v"], torch.full((3,), (world - 1) / 2.0))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_local_reducer_issues_no_collective_world2_gloo():
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker_modes, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_forced(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # force_buckets: the pack / all-reduce / unpack path with ONE rank must be the identity (what
+        # EAT_BENCH_FORCE_DIST and the single-GPU reducer test rely on)
+        red = GradReducer(bucket_bytes=64, force_buckets=True)
+        g = torch.Generator().manual_seed(3)
+        ts = {f"p{i}": torch.randn(7, i + 1, generator=g) for i in range(6)}
+        for k, v in ts.items():
+            red.push(k, v.clone())
+        out = red.finish()
+        ret[rank] = all(torch.equal(out[k], v) and out[k].shape == v.shape for k, v in ts.items())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_bucketing_with_one_rank_is_identity():
+    port = _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker_forced, args=(1, port, ret), nprocs=1, join=True)
+    assert dict(ret) == {0: True}

@@ -130,7 +130,10 @@ def test_dw_conv(B, C, F_, T, k, s, act):
     (2, 16, 64, 64, 500, 1, False, False), (2, 16, 16, 64, 500, 0, False, True), (2, 64, 24, 32, 250, 0, False, False),
     (2, 72, 40, 16, 125, 0, True, False), (3, 80, 200, 8, 63, 2, False, False), (3, 184, 80, 8, 63, 0, False, True),
     (3, 112, 672, 8, 63, 2, False, False), (4, 672, 160, 4, 32, 0, True, False), (4, 160, 960, 4, 32, 2, False, False),
-    (5, 960, 160, 4, 32, 0, True, True), (1, 8, 8, 1, 4, 2, False, False), (2, 12, 20, 3, 12, 1, True, True)])
+    (5, 960, 160, 4, 32, 0, True, True), (1, 8, 8, 1, 4, 2, False, False), (2, 12, 20, 3, 12, 1, True, True),
+    # plane sizes that are not a multiple of 4 (40-/64-mel models, odd frame counts): conv_pw_generic.hip
+    (3, 40, 120, 5, 125, 1, False, False), (2, 672, 160, 3, 63, 0, True, True), (4, 16, 64, 7, 9, 2, False, True),
+    (1, 24, 72, 1, 1, 1, True, False)])
 def test_pw_conv(B, Ci, Co, F_, T, act, se, res):
     x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
     bias, rs = _rand(Co, seed=3, scale=0.1), torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5
@@ -220,6 +223,52 @@ def test_mn10_short_clips_match_oracle(golden_dir):
         ref, _ = O.mn_forward(sd, x_ref)
         got, _ = model(x_ref.to(DEV))
     assert float((got.cpu() - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("n_mels,n_samples", [(40, 320000), (64, 310400)])
+def test_mn10_other_mel_geometries_match_oracle(n_mels, n_samples):
+    """mn10_as_mels_40 / mn10_as_mels_64 geometries (models/mn/model.py:60-63): planes of 5x125, 3x63 (40 mels) and
+    2 x 31 (64 mels, 9.7 s) positions are not multiples of 4, so every late 1x1 conv runs on the plain 4-byte
+    kernel (conv_pw_generic.hip) instead of the 16-byte MFMA tiles; eval logits + a train step vs the oracle."""
+    wave = synth.parity_clips(n_samples, seed=11)[:3]
+    x = O.mel_forward(wave, n_mels=n_mels).unsqueeze(1)
+    sd = synth.calibrate(synth.synth_state(synth.mn_shapes(1.0), seed=0), O.mn_forward, x)
+    with torch.no_grad():
+        ref, _ = O.mn_forward(sd, x)
+    mel = _quiet(AugmentMelSTFT, n_mels=n_mels, freqm=0, timem=0).to(DEV).eval()
+    model = _quiet(get_model, width_mult=1.0, input_dim_f=n_mels, input_dim_t=x.shape[3])
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        m = mel(wave.to(DEV))
+        got, _ = model(x.to(DEV))
+        got3, _ = model(m.unsqueeze(1))
+    assert float((m.cpu() - x[:, 0]).abs().max()) < 5e-4
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got.cpu() - ref).abs().max()) < 1e-3 * scale
+    assert float((got3.cpu() - ref).abs().max()) < 1e-3 * scale
+    # one train step: loss and parameter gradients vs torch-CPU autograd over the oracle
+    y = (torch.rand(3, 527, generator=torch.Generator().manual_seed(2)) < 0.01).float()
+    keep = torch.ones(3, 1280)
+    sdr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith(
+        ("running_mean", "running_var")) else v.clone()) for k, v in sd.items()}
+    lref, _ = O.mn_forward(sdr, x, train=True, stats={}, drop_mask=keep)
+    loss_ref = F.binary_cross_entropy_with_logits(lref, y)
+    loss_ref.backward()
+    model.train()
+    model._drop_mask_override = keep
+    logits, _ = model(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    rels = []
+    for name, p in model.named_parameters():
+        r = sdr[name].grad
+        if float(r.norm()) < 1e-5 * gmax:
+            continue
+        rels.append(float((p.grad.cpu().double() - r.double()).norm() / r.double().norm()))
+    assert max(rels) < 5e-2 and float(np.median(rels)) < 1e-2, (max(rels), float(np.median(rels)))
 
 
 def test_refold_after_weight_update(golden_dir):
@@ -314,7 +363,8 @@ def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
     (3, 80, 200, 8, 63, 2, False, False), (3, 184, 80, 8, 63, 0, False, True), (3, 112, 672, 8, 63, 2, False, False),
     (4, 672, 160, 4, 32, 0, True, False), (4, 160, 960, 4, 32, 2, False, False), (5, 960, 160, 4, 32, 0, True, True),
     (2, 40, 240, 16, 125, 2, False, False), (2, 24, 72, 32, 250, 1, False, False), (2, 72, 40, 16, 125, 0, True, False),
-    (5, 672, 160, 4, 7, 0, True, False), (9, 960, 160, 2, 2, 0, True, True), (3, 160, 960, 1, 4, 2, False, False)])
+    (5, 672, 160, 4, 7, 0, True, False), (9, 960, 160, 2, 2, 0, True, True), (3, 160, 960, 1, 4, 2, False, False),
+    (2, 672, 160, 3, 63, 0, True, True), (3, 120, 40, 5, 125, 0, True, False), (2, 160, 960, 3, 63, 2, False, False)])
 def test_pw_conv_bf16(B, Ci, Co, F_, T, act, se, res, split, tol):
     """bf16x3 (split) must be fp32-class; plain bf16 within bf16 round-off (config 3 compute dtype)."""
     x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
