@@ -113,7 +113,7 @@ def _alg_bytes(name, a):
         x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9
     if name == "eat_mel_fwd":
-        B, L, n_mels, T = a[1], a[2], a[10], a[13]
+        B, L, n_mels, T = a[1], a[2], a[11], a[14]
         return "mel_fwd_kernel", 4 * B * (L + n_mels * T), B * T * 60000
     if name == "eat_linear_fwd":
         x, w, bias, y, B, K, N = a[:7]

@@ -21,7 +21,7 @@ _D = ctypes.c_double
 
 # name -> argtypes (restype is always int unless noted); must mirror include/eat_hip.h
 SIGNATURES = {
-    "eat_mel_fwd": [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P],
+    "eat_mel_fwd": [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "eat_stem_conv_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_pw_prepack": [_P, _P, _P, _I, _I, _P],

@@ -53,6 +53,11 @@ int pw_conv_generic(const float* x, const void* wp, const float* bias, const flo
                     float* pool, int B, int Ci, int Co, int S, int act, int wmode, long long wp_bstride_bytes,
                     hipStream_t s);
 
+// irb.hip: register-resident inverted-residual block; returns 1 when the shape has no instantiation (fall back)
+int irb_try(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,
+            const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
+            int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s);
+
 }  // namespace eat
 
 #define EAT_DISPATCH_ACT(act, ...)                                    \

@@ -1,0 +1,425 @@
+// Register-resident inverted-residual block for gfx950 (round 2 replacement of the LDS-staged mbconv kernel for the
+// early, bandwidth-bound blocks):
+//   expand 1x1 + BN + act  ->  depthwise k x k + BN + act  ->  project 1x1 + BN (+ residual)        [PROJ]
+//   expand 1x1 + BN + act  ->  depthwise k x k + BN + act  (+ SE squeeze sums), output to HBM          [!PROJ]
+//   reference: InvertedResidual.forward (models/mn/block_types.py:138-181), SE mean (:72-73).
+//
+// The round-1 kernel staged the expanded patch, the depthwise output and the project input through LDS with 3-4
+// workgroup barriers per 16 channels; counters: MFMA pipe 27 % busy, 39 % of wave cycles parked in waits, 37 % issue
+// stalls, 9 of 16 wave slots idle in the expand phase.  Here one WAVE owns a strip of 32 output columns and marches
+// down the rows; nothing but the weights ever touches LDS and there is no barrier after the prologue:
+//
+//   * expand: v_mfma_f32_16x16x4_f32 with N = 16 consecutive (stride 1) or every-other (stride 2: an "even" tile
+//     E(u) = column 2 oc and an "odd" tile O(u) = column 2 oc - 1) input columns of one row; the B operand is loaded
+//     straight from global memory (lane (k, n) = channel 4 ks + k, column n: 64-byte segments), the A operand from LDS;
+//     the accumulator starts at the BN bias;
+//   * the C layout of the result (lane (kq, n) holds channels 4 kq + r, r = 0..3, at column n) IS the layout the
+//     depthwise conv wants: vertical taps are other registers of the same lane (a window of the last K - S expanded
+//     rows stays in registers while the wave marches down), horizontal taps are neighbouring lanes of the same
+//     16-lane row, i.e. DPP row shifts folded into the FMAs (lane 0 / 15 take the neighbour tile's edge lane through
+//     a second row_shl:15 / row_shr:15 FMA).  The outermost column(s) of a strip have no neighbour: 30 or 31 of the 32
+//     columns are valid outputs, strips overlap by the halo;
+//   * the same registers are the B operand of the project MFMA: k-step r of chunk c multiplies channels
+//     {16 c + 4 k + r}, so the project A fragments are re-ordered once (prologue) instead of moving any data;
+//   * positions outside the image are forced to 0 after the activation (the depthwise conv zero-pads the ACTIVATED map).
+//
+// A wave's serial work is one row at a time: S new expanded rows (all chunks), the depthwise row, the project row.
+// The next row's B operands are requested right after the last chunk's expand MFMAs have issued, i.e. one depthwise +
+// project phase ahead of their use.
+#include <cstdlib>
+#include "eat_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kNT = 2;          // output column tiles (of 16) per wave
+constexpr int kWaves = 4;       // waves per block (they share the LDS weights only)
+
+struct IrbArgs {
+  const float *x, *wpe, *bias_e, *wd, *bias_d, *wpp, *bias_p, *res;
+  float *y, *pool;
+  int B, Cin, Cexp, Cout, F, T, Fo, To;
+  int MT;                                 // 16-channel chunks of the expanded tensor
+  int n_strips, n_parts, rows_per_part;   // work decomposition: item = (sample, column strip, row range)
+  int n_items;
+};
+
+// Raw buffer access (128-bit descriptor in SGPRs + 32-bit per-lane byte offset + scalar byte offset): the per-lane
+// offsets are a handful of loop-invariant registers and everything that changes per row / k-step / channel is scalar.
+// With flat pointers hipcc materialised one 64-bit VGPR address per load and hoisted dozens of them out of the loops
+// (256 VGPRs + spills).  A lane whose offset is kOOB (>= num_records) loads 0 / stores nothing (hardware range check).
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
+constexpr int kShr1 = 0x111, kShl1 = 0x101, kShl15 = 0x10F, kShr15 = 0x11F;   // DPP row shifts
+template <int CTRL>
+__device__ __forceinline__ float dpp0(float v) {      // lane j <- lane j -/+ n of its 16-lane row; 0 where there is none
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// Depthwise taps, factored so that the horizontal shifts are applied ONCE per output instead of once per tap: per input
+// row only plain FMAs into three partial sums - L (taps whose input is the left neighbour u - 1), M (same lane), R (right
+// neighbour u + 1) - and after the last row  d(u) = M(u) + L(u - 1) + R(u + 1)  with two DPP row shifts (+ the neighbour
+// tile's edge lane for lanes 0 / 15).  Shifting is linear, so this equals shifting every input (zero fill included).
+struct DwAcc {
+  f32x4 l[kNT], m[kNT], r[kNT];
+};
+__device__ __forceinline__ void fma_tiles(f32x4 (&d)[kNT], const f32x4* row, const f32x4 w) {
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[t][r] = fmaf(w[r], row[t][r], d[t][r]);
+}
+// one input row's contribution; row = [E tiles (kNT)] [O tiles (kNT), stride 2 only]
+template <int K, int S>
+__device__ __forceinline__ void dw_row(DwAcc& d, const f32x4* row, const f32x4* w) {
+  if constexpr (S == 1 && K == 3) {                 // columns oc-1, oc, oc+1
+    fma_tiles(d.l, row, w[0]); fma_tiles(d.m, row, w[1]); fma_tiles(d.r, row, w[2]);
+  } else if constexpr (S == 2 && K == 3) {          // columns 2oc-1, 2oc, 2oc+1 = O(u), E(u), O(u+1)
+    fma_tiles(d.m, row + kNT, w[0]); fma_tiles(d.m, row, w[1]); fma_tiles(d.r, row + kNT, w[2]);
+  } else {                                          // S == 2, K == 5: E(u-1), O(u), E(u), O(u+1), E(u+1)
+    fma_tiles(d.l, row, w[0]); fma_tiles(d.m, row + kNT, w[1]); fma_tiles(d.m, row, w[2]);
+    fma_tiles(d.r, row + kNT, w[3]); fma_tiles(d.r, row, w[4]);
+  }
+}
+template <int K, int S>
+__device__ __forceinline__ void dw_finish(const DwAcc& a, f32x4 (&d)[kNT]) {
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = a.m[t][r] + dpp0<kShl1>(a.r[t][r]);
+      if (t + 1 < kNT) v += dpp0<kShr15>(a.r[t + 1][r]);
+      if constexpr (!(S == 2 && K == 3)) {
+        v += dpp0<kShr1>(a.l[t][r]);
+        if (t > 0) v += dpp0<kShl15>(a.l[t - 1][r]);
+      }
+      d[t][r] = v;
+    }
+}
+
+// K, S: depthwise kernel / stride; NKS = Cin / 4; MTI = chunks per row march (all of them with PROJ, 1 without);
+// MTO = project m-tiles (PROJ)
+template <int K, int S, int NKS, int MTI, int MTO, int ACT, bool PROJ>
+__global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
+  constexpr int P_ = (K - 1) / 2, KK = K * K;
+  constexpr int KW = K - S;                 // expanded rows kept between output rows
+  constexpr int TI = kNT * S;               // tiles per input row (stride 2: even + odd)
+  constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * kNT - 2;   // lanes (tile-major index u) with a valid output
+  constexpr int VO = UHI - ULO + 1;
+  static_assert((K == 3 && (S == 1 || S == 2)) || (K == 5 && S == 2), "unsupported depthwise geometry");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int MT = a.MT;
+  float* As = smem;                          // [NKS][MT][64]       expand A fragments (the eat_pw_prepack layout)
+  float* Wd = As + NKS * MT * 64;            // [MT][KK][16]        depthwise taps, channel-minor
+  float* Be = Wd + MT * KK * 16;             // [MT*16]             expand bias
+  float* Bd = Be + MT * 16;                  // [MT*16]             depthwise bias
+  float* Ap = Bd + MT * 16;                  // [MT*4][MTO][64]     project A fragments, k order {16c + 4k + r}
+  float* Bp = Ap + (PROJ ? MT * 4 * MTO * 64 : 0);   // [MTO*16]
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+  // the wave index is wave-uniform, but only readfirstlane tells the compiler: with it the work-item geometry (sample,
+  // strip, rows), every row address and every loop / image-border branch live in SGPRs
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cexp = a.Cexp, F = a.F, T = a.T, Fo = a.Fo, To = a.To;
+
+  // ---- prologue: weights -> LDS (zero beyond Cexp / Cout)
+  for (int i = tid; i < NKS * MT * 64; i += 64 * kWaves) As[i] = a.wpe[i];
+  for (int i = tid; i < MT * KK * 16; i += 64 * kWaves) {
+    const int ch = (i / (KK * 16)) * 16 + (i & 15), tap = (i >> 4) % KK;
+    Wd[i] = ch < Cexp ? a.wd[(size_t)ch * KK + tap] : 0.0f;
+  }
+  for (int i = tid; i < MT * 16; i += 64 * kWaves) {
+    Be[i] = i < Cexp ? a.bias_e[i] : 0.0f;
+    Bd[i] = i < Cexp ? a.bias_d[i] : 0.0f;
+  }
+  if constexpr (PROJ) {
+    for (int i = tid; i < MT * 4 * MTO * 64; i += 64 * kWaves) {
+      const int l = i & 63, mo = (i >> 6) % MTO, cr = (i >> 6) / MTO, c = cr >> 2, r = cr & 3;
+      const int ks = 4 * c + (l >> 4);                    // source k-step holds channels 4 ks .. 4 ks + 3
+      Ap[i] = 4 * ks < Cexp ? a.wpp[((size_t)ks * MTO + mo) * 64 + r * 16 + (l & 15)] : 0.0f;
+    }
+    for (int i = tid; i < MTO * 16; i += 64 * kWaves) Bp[i] = i < a.Cout ? a.bias_p[i] : 0.0f;
+  }
+  __syncthreads();
+
+  const int item = blockIdx.x * kWaves + wv;
+  if (item >= a.n_items) return;             // no barrier below
+  const int per_b = a.n_strips * a.n_parts;
+  const int b = item / per_b, rem = item - b * per_b;
+  const int strip = rem / a.n_parts, part = rem - strip * a.n_parts;
+  const int o0 = strip * VO;
+  const int i0 = part * a.rows_per_part;
+  const int i1 = (i0 + a.rows_per_part) < Fo ? (i0 + a.rows_per_part) : Fo;
+  if (i0 >= i1) return;
+
+  // ---- per-lane column geometry (constant while marching down)
+  const int plane = F * T, plane_o = Fo * To;
+  unsigned lb[TI];                           // byte offset of (channel kq, clamped column) inside the sample
+  float cmask[TI];                           // 1 inside the image, 0 outside
+  unsigned ob[kNT];                          // byte offset of (channel kq*4, output column) inside the output sample
+  bool ov[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    const int u = 16 * t + n;
+    const int oc = o0 + u - ULO;
+    ov[t] = u >= ULO && u <= UHI && oc < To;
+    ob[t] = 4u * (unsigned)(kq * 4 * plane_o + oc);
+#pragma unroll
+    for (int h = 0; h < S; ++h) {            // h = 0: even tile (or the only one), h = 1: odd tile
+      const int ci = S * oc - h;
+      const bool in = ci >= 0 && ci < T;
+      cmask[h * kNT + t] = in ? 1.0f : 0.0f;
+      lb[h * kNT + t] = 4u * (unsigned)(kq * plane + (ci < 0 ? 0 : (ci >= T ? T - 1 : ci)));
+    }
+  }
+  const int Cy = PROJ ? a.Cout : Cexp;       // channels of y (and of the residual)
+  const __amdgpu_buffer_rsrc_t xr_ = make_rsrc(a.x + (size_t)b * a.Cin * plane, 4u * (unsigned)(a.Cin * plane));
+  const __amdgpu_buffer_rsrc_t yr_ = make_rsrc(a.y + (size_t)b * Cy * plane_o, 4u * (unsigned)(Cy * plane_o));
+  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc(a.res ? a.res + (size_t)b * Cy * plane_o : a.y, a.res ? 4u * (unsigned)(Cy * plane_o) : 0u);
+
+  float xb[S][NKS][TI];                      // B operands of the S new input rows of this output row
+  auto load_rows = [&](int i) {              // input rows S i - P + KW + j, j < S
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      int fi = S * i - P_ + KW + j;
+      fi = fi < 0 ? 0 : (fi >= F ? F - 1 : fi);          // out-of-image rows are zeroed in expand()
+      const unsigned ro = 4u * (unsigned)fi * (unsigned)T;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) xb[j][ks][ti] = buf_load(xr_, lb[ti], ro + 16u * (unsigned)ks * (unsigned)plane);
+    }
+  };
+  // expanded row of chunk c from B operands xr; fi = its input row (wave-uniform)
+  auto expand = [&](int c, const float (&xr)[NKS][TI], int fi, f32x4 (&e)[TI]) {
+    if (fi < 0 || fi >= F) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) e[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+    const f32x4 be = *reinterpret_cast<const f32x4*>(Be + c * 16 + kq * 4);
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) e[ti] = be;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const float av = As[(ks * MT + c) * 64 + lane];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) e[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xr[ks][ti], e[ti], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[ti][r] = eat::activate<ACT>(e[ti][r]) * cmask[ti];
+  };
+
+  const int n_groups = PROJ ? 1 : MT;        // !PROJ: one chunk per march, chunks in an outer loop
+  for (int g = 0; g < n_groups; ++g) {
+    const int c0 = PROJ ? 0 : g;
+    f32x4 win[MTI][KW][TI];
+    float psum[MTI][4];
+#pragma unroll
+    for (int c = 0; c < MTI; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) psum[c][r] = 0.0f;
+
+    // ---- prime the window: input rows S i0 - P + w, w < KW (loaded through the same S-row loader)
+    {
+      // rows come in groups of S: group q covers window rows q S .. q S + S - 1  (KW = 2, S = 1: two groups; KW = 1,
+      // S = 2: half a group; KW = 3, S = 2: one and a half) - load "output row" i0 - ceil(KW / S) + q and keep what falls
+      // inside the window
+      constexpr int NG = (KW + S - 1) / S;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const int iq = i0 - NG + q;          // pseudo output row whose new rows are S iq - P + KW + j
+        load_rows(iq);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          const int w = KW - NG * S + q * S + j;           // window slot of that row (may be < 0: not needed)
+          if (w >= 0) {
+            const int fi = S * iq - P_ + KW + j;
+#pragma unroll
+            for (int c = 0; c < MTI; ++c) expand(c0 + c, xb[j], fi, win[c][w]);
+          }
+        }
+      }
+    }
+    load_rows(i0);
+
+    for (int i = i0; i < i1; ++i) {
+      f32x4 accp[PROJ ? MTO : 1][kNT];
+      f32x4 rres[PROJ ? MTO : 1][kNT];
+      if constexpr (PROJ) {
+#pragma unroll
+        for (int mo = 0; mo < MTO; ++mo)
+#pragma unroll
+          for (int t = 0; t < kNT; ++t) {
+            accp[mo][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // residual of this output row: requested before the row's arithmetic (all zeros without a residual: the
+            // descriptor then has 0 records)
+            const unsigned vo = (ov[t] && mo * 16 + kq * 4 < a.Cout) ? ob[t] : kOOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              rres[mo][t][r] = buf_load(rr_, vo, 4u * (unsigned)((mo * 16 + r) * plane_o + i * To));
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < MTI; ++c) {
+        const int cg = c0 + c;
+        // compiler barrier: the weights in LDS are loop-invariant, and hipcc would otherwise hoist ALL of them (~250
+        // registers for 5 chunks) out of the row loop and spill; they are re-read per chunk instead (LDS has the bandwidth)
+        asm volatile("" ::: "memory");
+        f32x4 enew[S][TI];
+#pragma unroll
+        for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
+        if (c == MTI - 1 && i + 1 < i1) load_rows(i + 1);     // the B operands are free: next row's loads fly from here
+        // depthwise row: K input rows = the window (KW) + the new rows (S)
+        const f32x4 bd = *reinterpret_cast<const f32x4*>(Bd + cg * 16 + kq * 4);
+        DwAcc da;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+          da.m[t] = bd;
+          da.l[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          da.r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int di = 0; di < K; ++di) {
+          asm volatile("" ::: "memory");
+          f32x4 w[K];
+#pragma unroll
+          for (int dj = 0; dj < K; ++dj) w[dj] = *reinterpret_cast<const f32x4*>(Wd + (cg * KK + di * K + dj) * 16 + kq * 4);
+          if (di < KW) dw_row<K, S>(da, win[c][di], w);
+          else dw_row<K, S>(da, enew[di - KW], w);
+        }
+        f32x4 d[kNT];
+        dw_finish<K, S>(da, d);
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[t][r] = eat::activate<ACT>(d[t][r]);
+        if constexpr (PROJ) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mo = 0; mo < MTO; ++mo) {
+              const float ap = Ap[((cg * 4 + r) * MTO + mo) * 64 + lane];
+#pragma unroll
+              for (int t = 0; t < kNT; ++t) accp[mo][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, d[t][r], accp[mo][t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < kNT; ++t) {
+            const bool ok = ov[t] && cg * 16 + kq * 4 < Cexp;          // channel counts are multiples of 8
+            const unsigned vo = ok ? ob[t] : kOOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              buf_store(d[t][r], yr_, vo, 4u * (unsigned)((cg * 16 + r) * plane_o + i * To));
+              psum[c][r] += ok ? d[t][r] : 0.0f;
+            }
+          }
+        }
+        // slide the window by S rows
+#pragma unroll
+        for (int w = 0; w + S < KW; ++w)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) win[c][w][ti] = win[c][w + S][ti];
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+          if (KW - S + j >= 0) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) win[c][KW - S + j][ti] = enew[j][ti];
+          }
+      }
+      if constexpr (PROJ) {
+#pragma unroll
+        for (int mo = 0; mo < MTO; ++mo) {
+          const f32x4 bp = *reinterpret_cast<const f32x4*>(Bp + mo * 16 + kq * 4);
+#pragma unroll
+          for (int t = 0; t < kNT; ++t) {
+            const unsigned vo = (ov[t] && mo * 16 + kq * 4 < a.Cout) ? ob[t] : kOOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              buf_store(accp[mo][t][r] + bp[r] + rres[mo][t][r], yr_, vo, 4u * (unsigned)((mo * 16 + r) * plane_o + i * To));
+          }
+        }
+      }
+    }
+    if constexpr (!PROJ) {
+      if (a.pool) {                          // SE squeeze: plane sums of this strip's rows, one atomic per channel
+#pragma unroll
+        for (int c = 0; c < MTI; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float s = psum[c][r];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            const int ch = (c0 + c) * 16 + kq * 4 + r;
+            if (n == 0 && ch < Cexp) atomicAdd(a.pool + (size_t)b * Cexp + ch, s);
+          }
+      }
+    }
+  }
+}
+
+template <int K, int S, int NKS, int MTI, int MTO, int ACT, bool PROJ>
+int launch_irb(IrbArgs a, hipStream_t s) {
+  constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * kNT - 2, VO = UHI - ULO + 1;
+  a.MT = (a.Cexp + 15) / 16;
+  a.n_strips = (a.To + VO - 1) / VO;
+  // enough waves to fill the chip a few times over, but row ranges of >= 8 rows (each range re-expands K - S halo rows)
+  const long long strips = (long long)a.B * a.n_strips;
+  int parts = (int)((6144 + strips - 1) / strips);
+  const int max_parts = a.Fo / 8 > 1 ? a.Fo / 8 : 1;
+  parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
+  a.rows_per_part = (a.Fo + parts - 1) / parts;
+  a.n_parts = (a.Fo + a.rows_per_part - 1) / a.rows_per_part;
+  const long long items = strips * a.n_parts;
+  if (items > 0x7fffffffLL) return eat::fail(EAT_EINVAL, "eat_mbconv_fwd: too many work items");
+  a.n_items = (int)items;
+  const size_t smem = sizeof(float) * ((size_t)NKS * a.MT * 64 + (size_t)a.MT * K * K * 16 + 2 * (size_t)a.MT * 16 +
+                                       (PROJ ? (size_t)a.MT * 4 * MTO * 64 + MTO * 16 : 0));
+  auto kern = irb_kernel<K, S, NKS, MTI, MTO, ACT, PROJ>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "irb: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((items + kWaves - 1) / kWaves)), dim3(64 * kWaves), smem, s, a);
+  return eat::check_launch("irb_kernel");
+}
+
+}  // namespace
+
+namespace eat {
+
+// Returns 1 when the shape has no instantiation (the caller falls back to the LDS-staged kernel), 0 / <0 otherwise.
+int irb_try(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,
+            const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
+            int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s) {
+  static const bool off = getenv("EAT_IRB") && atoi(getenv("EAT_IRB")) == 0;
+  if (off || act != EAT_ACT_RELU) return 1;
+  if (4LL * Cin * F * T >= (1LL << 31) || 4LL * (Cexp > Cout ? Cexp : Cout) * Fo * To >= (1LL << 31)) return 1;   // 32-bit byte offsets inside a sample
+  if (Cexp % 8 != 0 || (wp_p && Cout % 4 != 0)) return 1;
+  IrbArgs a{};
+  a.x = x; a.wpe = wp_e; a.bias_e = bias_e; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = res;
+  a.y = y; a.pool = pool;
+  a.B = B; a.Cin = Cin; a.Cexp = Cexp; a.Cout = Cout; a.F = F; a.T = T; a.Fo = Fo; a.To = To;
+  const bool proj = wp_p != nullptr;
+  const int MT = (Cexp + 15) / 16, MTO = (Cout + 15) / 16;
+  if (proj) {
+    if (k == 3 && stride == 2 && Cin == 16 && MT == 4 && MTO == 2) return launch_irb<3, 2, 4, 4, 2, EAT_ACT_RELU, true>(a, s);
+    if (k == 3 && stride == 1 && Cin == 24 && MT == 5 && MTO == 2) return launch_irb<3, 1, 6, 5, 2, EAT_ACT_RELU, true>(a, s);
+    return 1;
+  }
+  if (k == 5 && stride == 2 && Cin == 24) return launch_irb<5, 2, 6, 1, 1, EAT_ACT_RELU, false>(a, s);
+  if (k == 3 && stride == 2 && Cin == 16) return launch_irb<3, 2, 4, 1, 1, EAT_ACT_RELU, false>(a, s);
+  if (k == 3 && stride == 1 && Cin == 24) return launch_irb<3, 1, 6, 1, 1, EAT_ACT_RELU, false>(a, s);
+  return 1;
+}
+
+}  // namespace eat

@@ -446,6 +446,11 @@ int mbconv(const float* x, const float* wp_e, const float* bias_e, const float* 
   const int p = (k - 1) / 2;
   if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
     return eat::fail(EAT_EINVAL, "%s: output %dx%d inconsistent with input %dx%d", who, Fo, To, F, T);
+  {   // round 2: the register-resident kernel (irb.hip) where it has an instantiation; this LDS-staged one otherwise
+    const int rc = eat::irb_try(x, wp_e, bias_e, w_d, bias_d, wp_p, bias_p, res, y, pool, B, Cin, Cexp, Cout, F, T, Fo, To,
+                                k, stride, act, s);
+    if (rc != 1) return rc;
+  }
   MbArgs a{};
   a.x = x; a.wpe = wp_e; a.bias_e = bias_e; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = res;
   a.y = y; a.pool = pool;

@@ -38,13 +38,15 @@ def conv_out(n, k, stride):
     return (n + 2 * p - (k - 1) - 1) // stride + 1
 
 
-def mel_fwd(wave, window, twiddle, band_w, band_start, n_fft, hop, n_mels, fmask=(0, 0), tmask=(0, 0)):
+def mel_fwd(wave, window, twiddle, band_w2, band_start, band_cnt, n_fft, hop, n_mels, fmask=(0, 0), tmask=(0, 0)):
     B, L = wave.shape
     T = 1 + (L - 1) // hop
+    if band_w2.shape[1:] != (n_mels, 2) or band_start.numel() != n_mels or band_cnt.numel() != n_mels:
+        raise _lib.EatHipError("mel_fwd: band table must be (pairs, n_mels, 2) with n_mels starts / counts")
     out = torch.empty((B, n_mels, T), device=wave.device, dtype=torch.float32)
     _lib.call("eat_mel_fwd", _dev(wave, "wave"), B, L, _dev(window, "window"), window.numel(), n_fft, hop,
-              _dev(twiddle, "twiddle"), _dev(band_w, "band_w"), band_start.data_ptr(), n_mels,
-              band_w.shape[1], out.data_ptr(), T, fmask[0], fmask[1], tmask[0], tmask[1], _stream())
+              _dev(twiddle, "twiddle"), _dev(band_w2, "band_w2"), band_start.data_ptr(), band_cnt.data_ptr(), n_mels,
+              band_w2.shape[0], out.data_ptr(), T, fmask[0], fmask[1], tmask[0], tmask[1], _stream())
     return out
 
 

@@ -5,7 +5,7 @@ Same constructor signature, buffers (``window`` and ``preemphasis_coefficient``,
 non-persistent so the state_dict stays empty), host RNG draw sequence and output
 ``(B, n_mels, T)``.  The kaldi mel basis is built on the host with the reference's exact fp32
 op order (so the set of non-zero (mel, bin) pairs is identical, incl. the fp32-only entry at
-bin 480 / filter 127) and shipped to the kernel as a banded table.
+bin 480 / filter 127) and shipped to the kernel as a banded table of 8-byte weight pairs.
 """
 import math
 
@@ -39,18 +39,27 @@ def kaldi_mel_basis(n_mels, n_fft, sr, fmin, fmax):
 
 
 def band_table(basis):
-    """Dense (n_mels, n_fft/2) basis -> (band_w (n_mels, band_len) fp32, band_start (n_mels) int32).
-    Every non-zero of row m lies in [start[m], start[m]+band_len); start+band_len <= n_fft/2."""
+    """Dense (n_mels, n_fft/2) basis -> the banded table the kernel walks in 8-byte pairs:
+         band_w2    (P, n_mels, 2) fp32   pair j of row m = basis[m, start[m] + 2j : start[m] + 2j + 2]
+         band_start (n_mels) int32        EVEN first bin of each band, start[m] + 2 P <= n_fft/2
+         band_cnt   (n_mels) int32        pairs that cover row m's non-zeros (0 for an empty row)
+    Every non-zero of row m lies in [start[m], start[m] + 2 cnt[m]); pairs beyond cnt[m] are zero."""
     nz = basis != 0
     n_mels, nb = basis.shape
+    assert nb % 2 == 0
     cols = torch.arange(nb)
     first = torch.where(nz, cols, nb).min(dim=1).values
     last = torch.where(nz, cols, -1).max(dim=1).values
-    first = torch.where(last < 0, torch.zeros_like(first), first)   # empty rows
-    band_len = int(max(1, (last - first + 1).max().item()))
-    start = torch.minimum(first, torch.full_like(first, nb - band_len)).clamp_(min=0)
-    gather = start.unsqueeze(1) + torch.arange(band_len).unsqueeze(0)
-    return basis.gather(1, gather).contiguous(), start.to(torch.int32).contiguous()
+    empty = last < 0
+    first = torch.where(empty, torch.zeros_like(first), first)
+    last = torch.where(empty, torch.zeros_like(last), last)
+    start = first - first % 2
+    pairs = int(max(1, ((last - start + 2) // 2).max().item()))
+    start = torch.minimum(start, torch.full_like(start, nb - 2 * pairs)).clamp_(min=0)
+    cnt = torch.where(empty, torch.zeros_like(last), (last - start + 2) // 2)
+    gather = start.unsqueeze(1) + torch.arange(2 * pairs).unsqueeze(0)
+    w2 = basis.gather(1, gather).reshape(n_mels, pairs, 2).permute(1, 0, 2).contiguous()
+    return w2, start.to(torch.int32).contiguous(), cnt.to(torch.int32).contiguous()
 
 
 def fft_twiddles(n_fft):
@@ -77,15 +86,15 @@ class AugmentMelSTFT(nn.Module):
         self.register_buffer("preemphasis_coefficient", torch.as_tensor([[[-.97, 1]]]), persistent=False)
         self.freqm, self.timem = freqm, timem          # mask parameters (0 = off), fused into the kernel
         self._twiddle = None
-        self._tables = {}                              # (fmin, fmax, device) -> (band_w, band_start)
+        self._tables = {}                              # (fmin, fmax, device) -> (band_w2, band_start, band_cnt)
 
     # -- host helpers -------------------------------------------------------------------
     def _device_tables(self, fmin, fmax, device):
         key = (float(fmin), float(fmax), str(device))
         hit = self._tables.get(key)
         if hit is None:
-            bw, bs = band_table(kaldi_mel_basis(self.n_mels, self.n_fft, self.sr, fmin, fmax))
-            hit = (bw.to(device, non_blocking=True), bs.to(device, non_blocking=True))
+            hit = tuple(t.to(device, non_blocking=True)
+                        for t in band_table(kaldi_mel_basis(self.n_mels, self.n_fft, self.sr, fmin, fmax)))
             if len(self._tables) > 64:
                 self._tables.clear()
             self._tables[key] = hit
@@ -115,6 +124,6 @@ class AugmentMelSTFT(nn.Module):
                 fmask = self._draw_mask(self.freqm, self.n_mels)
             if self.timem:
                 tmask = self._draw_mask(self.timem, T)
-        band_w, band_start = self._device_tables(fmin, fmax, x.device)
-        return ops.mel_fwd(x, self.window, self._twiddle, band_w, band_start, self.n_fft, self.hopsize,
+        band_w2, band_start, band_cnt = self._device_tables(fmin, fmax, x.device)
+        return ops.mel_fwd(x, self.window, self._twiddle, band_w2, band_start, band_cnt, self.n_fft, self.hopsize,
                            self.n_mels, fmask, tmask)

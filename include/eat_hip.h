@@ -44,16 +44,18 @@ const char* eat_last_error_string(void);
  * optional frequency / time masking (:61-63), (x + 4.5) / 5 (:65).
  *   window      (win_length)   the reference's torch.hann_window(win_length, periodic=False)
  *   twiddle     (n_fft, 2)     exp(-2*pi*i*j/n_fft) as (cos, -sin) pairs, fp32 from fp64
- *   band_w      (n_mels, band_len)  non-zero band of each row of the kaldi mel basis (:52-55),
- *                              built on the host with the reference's fp32 op order
- *   band_start  (n_mels)       first FFT bin of each band; band_start[m]+band_len <= n_fft/2
+ *   band_w2     (band_pairs, n_mels, 2)  the non-zero band of each row of the kaldi mel basis (:52-55), built on
+ *                              the host with the reference's fp32 op order, as 8-byte pairs: pair j of row m =
+ *                              basis[m][band_start[m] + 2j .. +1]; pairs beyond band_cnt[m] are zero
+ *   band_start  (n_mels)       EVEN first FFT bin of each band; band_start[m] + 2*band_pairs <= n_fft/2
+ *   band_cnt    (n_mels)       pairs that cover row m's non-zeros (the kernel walks max(band_cnt) per 64 rows)
  *   mask_f0..mask_t1           [f0,f1) mel rows and [t0,t1) frames set to 0.0 after the log
  *                              (train-mode masking); pass f0==f1 / t0==t1 for none
- * Only n_fft == 1024 is implemented (every reference config); others return EAT_EINVAL. */
+ * Only n_fft == 1024 and n_mels <= 256 are implemented (every reference config); others return EAT_EINVAL. */
 int eat_mel_fwd(const float* wave, int B, int L, const float* window, int win_length, int n_fft,
-                int hop, const float* twiddle, const float* band_w, const int* band_start,
-                int n_mels, int band_len, float* out, int T, int mask_f0, int mask_f1,
-                int mask_t0, int mask_t1, eat_stream_t stream);
+                int hop, const float* twiddle, const float* band_w2, const int* band_start,
+                const int* band_cnt, int n_mels, int band_pairs, float* out, int T, int mask_f0,
+                int mask_f1, int mask_t0, int mask_t1, eat_stream_t stream);
 
 /* ---- stem: models/mn/model.py:124-133 (ConvNormActivation 3x3 stride 2, 1 -> C) ----------
  * x (B,1,F,T) -> y (B,C,Fo,To), Fo=(F+1)/2-ish per cnn_out_size; w (C,1,3,3) with the eval-mode

@@ -112,9 +112,46 @@ def _bn(sd, prefix, x, train, stats=None):
     return y
 
 
+class _PwBf16(torch.autograd.Function):
+    """1x1 conv on bf16-rounded operands with fp32 accumulation - the arithmetic of `train_precision="bf16"`
+    (BASELINE configs[2]: bf16 MFMA 1x1 GEMMs, fp32 activations in memory): forward rounds x and W to bf16, the data
+    gradient rounds dz and W, the weight gradient keeps fp32-class operands (the product path runs it on the
+    split-operand bf16x3 kernel).  Lets the tests anchor the bf16 path on an ORACLE evaluation of the same arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x.bfloat16().float(), w.bfloat16().float())
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        dx = F.conv_transpose2d(dz.bfloat16().float(), w.bfloat16().float())
+        dw = torch.einsum("bohw,bihw->oi", dz, x).reshape(w.shape)
+        return dx, dw
+
+
+PW_BF16 = False      # set through `emulate_bf16_pointwise()` only
+
+
+class emulate_bf16_pointwise:
+    """with O.emulate_bf16_pointwise(): every 1x1 convolution of mn_forward runs as `_PwBf16`."""
+
+    def __enter__(self):
+        global PW_BF16
+        self.old, PW_BF16 = PW_BF16, True
+
+    def __exit__(self, *exc):
+        global PW_BF16
+        PW_BF16 = self.old
+
+
 def _cna(sd, prefix, x, train, stats, k, stride, groups, act):
     """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2) + BN + act."""
-    x = F.conv2d(x, sd[prefix + ".0.weight"], None, stride, (k - 1) // 2, 1, groups)
+    if PW_BF16 and k == 1 and groups == 1:
+        x = _PwBf16.apply(x, sd[prefix + ".0.weight"])
+    else:
+        x = F.conv2d(x, sd[prefix + ".0.weight"], None, stride, (k - 1) // 2, 1, groups)
     x = _bn(sd, prefix + ".1", x, train, stats)
     if act == "hs":
         x = F.hardswish(x)

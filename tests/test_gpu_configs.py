@@ -243,12 +243,40 @@ def test_mn40_train_step_auto_matches_oracle(mn40_case):
 
 def test_mn40_train_step_bf16_tracks_oracle(mn40_case):
     """BASELINE configs[2]: 1x1 GEMMs on plain bf16 operands (2^-9 relative round-off per operand), anchored on the
-    fp32 ORACLE (not on our own fp32 path): loss within 2 % and median per-tensor gradient rel-L2 within 5 % on 8
-    full-length clips (bf16 runs are judged at bf16-level tolerance, ~1e-2 relative)."""
+    ORACLE, not on our own fp32 path:
+      (a) an oracle evaluation of the SAME arithmetic (`O.emulate_bf16_pointwise`: bf16-rounded operands, fp32
+          accumulation; that the kernel computes exactly this per layer is test_pw_conv_bf16's tight check) - loss and
+          logits must agree at the level where only rounding-boundary flips differ (measured on MI355X: a value within
+          fp32 noise of a bf16 rounding boundary rounds the other way in ~2.5e-4 of the elements, which ~30 bf16 layers
+          and the activation kinks amplify to ~3e-3 of the logit scale; the same mechanism as the fp32 gradient budget
+          of SURVEY 8c, with a 2^16 times larger seed);
+      (b) the fp32 oracle: bf16 noise of this 47-layer synthetic net is large (the emulated oracle's own gradients are
+          ~20 % median rel-L2 away from the fp32 ones), so the criterion is "not further from the fp32 oracle than the
+          oracle's bf16 evaluation is" (x1.25 + 1 %), for the gradients and for the logits."""
     d = mn40_case
-    _, loss, logits, rels = _mn40_step(d, "bf16")
+    sdr = _grad_state(d["sd"])
+    fwd = lambda sd, xm, **k: O.mn_forward(sd, xm, width_mult=4.0, **k)
+    with O.emulate_bf16_pointwise():
+        logits_e, _ = fwd(sdr, d["x"], train=True, stats={}, drop_mask=d["keep"])
+        loss_e = F.binary_cross_entropy_with_logits(logits_e, d["y"])
+        loss_e.backward()
+    logits_e = logits_e.detach()
+    gmax = max(float(g.norm()) for g in d["grads"].values())
+    emu_vs_fp32 = {n: _rel(v.grad, d["grads"][n]) for n, v in sdr.items()
+                   if getattr(v, "grad", None) is not None and float(d["grads"][n].norm()) >= 1e-5 * gmax}
+
+    model, loss, logits, hip_vs_fp32 = _mn40_step(d, "bf16")
+    scale = float(d["logits"].abs().max())
+    # (a) same arithmetic, oracle vs HIP
+    assert abs(loss - float(loss_e)) < 2e-3 * abs(float(loss_e)), (loss, float(loss_e))
+    assert float((logits - logits_e).abs().max()) < 2e-2 * scale
+    hip_vs_emu = np.array([_rel(p.grad, sdr[n].grad) for n, p in model.named_parameters() if n in emu_vs_fp32])
+    assert np.isfinite(hip_vs_emu).all()
+    ev = np.array(list(emu_vs_fp32.values()))
+    assert float(np.median(hip_vs_emu)) < float(np.median(ev)), (float(np.median(hip_vs_emu)), float(np.median(ev)))
+    # (b) bf16 noise vs the fp32 oracle: not larger than the emulated oracle's own
     assert abs(loss - d["loss"]) < 2e-2 * abs(d["loss"]), (loss, d["loss"])
-    vals = np.array(list(rels.values()))
-    assert np.isfinite(vals).all()
-    assert float(np.median(vals)) < 5e-2, (float(np.median(vals)), float(vals.max()))
-    assert float((logits - d["logits"]).abs().max()) < 0.1 * float(d["logits"].abs().max())
+    hv = np.array(list(hip_vs_fp32.values()))
+    assert float(np.median(hv)) < 1.25 * float(np.median(ev)) + 1e-2, (float(np.median(hv)), float(np.median(ev)))
+    e_hip, e_emu = float((logits - d["logits"]).abs().max()), float((logits_e - d["logits"]).abs().max())
+    assert e_hip < 1.5 * e_emu + 1e-2 * scale, (e_hip, e_emu)

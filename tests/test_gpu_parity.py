@@ -299,7 +299,10 @@ def test_cpu_tensor_fails_loudly():
 
 @pytest.mark.parametrize("B,Ci,Ce,F_,T,k,s,act", [
     (2, 16, 64, 64, 500, 3, 2, 1), (2, 24, 72, 32, 250, 3, 1, 1), (2, 24, 72, 32, 250, 5, 2, 1),
-    (3, 40, 120, 16, 125, 5, 1, 1), (3, 40, 240, 16, 125, 3, 2, 2), (2, 8, 24, 9, 21, 5, 2, 2), (1, 12, 40, 5, 7, 3, 1, 1)])
+    (3, 40, 120, 16, 125, 5, 1, 1), (3, 40, 240, 16, 125, 3, 2, 2), (2, 8, 24, 9, 21, 5, 2, 2), (1, 12, 40, 5, 7, 3, 1, 1),
+    # shapes of the register-resident kernel (csrc/irb.hip): ragged planes, strips / row ranges that end mid-tile
+    (3, 24, 72, 33, 71, 5, 2, 1), (2, 24, 72, 9, 30, 5, 2, 1), (3, 16, 64, 17, 63, 3, 2, 1), (2, 24, 72, 8, 31, 3, 1, 1),
+    (1, 24, 40, 5, 7, 5, 2, 1), (2, 24, 72, 1, 3, 5, 2, 1)])
 def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
     """expand 1x1 + act -> depthwise + act fused (csrc/mbconv.hip, SE variant) vs the two-step torch reference."""
     x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
@@ -337,7 +340,10 @@ def test_front_stem_plus_first_block(B, F_, T, act):
 @pytest.mark.parametrize("B,Ci,Ce,Co,F_,T,k,s,act,res", [
     (2, 16, 64, 24, 64, 500, 3, 2, 1, False), (2, 24, 72, 24, 32, 250, 3, 1, 1, True), (2, 24, 72, 40, 32, 250, 5, 2, 1, False),
     (3, 40, 120, 40, 16, 125, 5, 1, 1, True), (3, 40, 240, 80, 16, 125, 3, 2, 2, False), (2, 8, 24, 16, 9, 21, 5, 2, 2, False),
-    (1, 12, 40, 12, 5, 7, 3, 1, 1, True), (2, 16, 72, 24, 33, 70, 3, 1, 2, False)])
+    (1, 12, 40, 12, 5, 7, 3, 1, 1, True), (2, 16, 72, 24, 33, 70, 3, 1, 2, False),
+    # shapes of the register-resident kernel (csrc/irb.hip): ragged planes, strips / row ranges that end mid-tile
+    (3, 16, 64, 24, 33, 70, 3, 2, 1, False), (2, 16, 64, 24, 64, 125, 3, 2, 1, False), (3, 24, 72, 24, 17, 61, 3, 1, 1, True),
+    (2, 24, 72, 24, 9, 30, 3, 1, 1, False), (1, 16, 64, 24, 2, 5, 3, 2, 1, False), (5, 24, 72, 24, 32, 250, 3, 1, 1, True)])
 def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
     """Whole inverted-residual block (expand + depthwise + project [+ residual]) in one kernel
     (csrc/mbconv.hip) vs the three-step torch reference (models/mn/block_types.py:138-181)."""
@@ -382,3 +388,14 @@ def test_pw_conv_bf16(B, Ci, Co, F_, T, act, se, res, split, tol):
                            res=None if r is None else r.to(DEV), pool=pool)
     _close(got, ref, tol, f"pw bf16 split={split}")
     _close(pool, ref.sum(dim=(2, 3)), 20 * tol, "pw bf16 pool")
+    if not split:
+        # the plain-bf16 kernel must compute EXACTLY "operands rounded to bf16 (round-to-nearest-even), fp32 accumulation":
+        # against a float64 product of the rounded operands only fp32 accumulation noise is left (what the oracle's
+        # bf16 emulation, O.emulate_bf16_pointwise, assumes for BASELINE configs[2])
+        xr = xs.bfloat16().double()
+        wr = (w * rs[:, None]).bfloat16().double()
+        ref2 = F.conv2d(xr, wr.view(Co, Ci, 1, 1), bias.double()).float()
+        ref2 = [ref2, F.relu(ref2), F.hardswish(ref2)][act]
+        if res:
+            ref2 = ref2 + r
+        _close(got, ref2, 3e-6, "pw bf16 vs bf16-rounded operands")

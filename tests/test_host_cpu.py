@@ -45,12 +45,14 @@ def test_mel_basis_is_bit_identical_to_oracle_and_banded():
         b = kaldi_mel_basis(128, 1024, 32000, fmin, fmax)
         ref = O.kaldi_mel_banks(128, 1024, 32000, fmin, float(fmax))
         assert torch.equal(b, ref[:, :512])                       # same fp32 values => same bin indices
-        bw, bs = band_table(b)
+        bw2, bs, cnt = band_table(b)
+        pairs = bw2.shape[0]
         dense = torch.zeros_like(b)
         for m in range(128):
-            dense[m, bs[m]:bs[m] + bw.shape[1]] = bw[m]
+            dense[m, bs[m]:bs[m] + 2 * pairs] = bw2[:, m, :].reshape(-1)
+            assert not bw2[int(cnt[m]):, m, :].any()             # the kernel stops after max(cnt) pairs per 64 rows
         assert torch.equal(dense, b)
-        assert int(bs.max()) + bw.shape[1] <= 512
+        assert int(bs.max()) + 2 * pairs <= 512 and not (bs % 2).any() and int(cnt.max()) == pairs
     b = kaldi_mel_basis(128, 1024, 32000, 0.0, 15000)
     assert int((b != 0).sum()) == 948 and float(b[127, 480]) > 0
 
