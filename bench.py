@@ -98,17 +98,17 @@ def _alg_bytes(name, a):
     if name == "eat_fused_expand_dw_fwd":
         x, wp, be, wd, bd, y, pool, B, Cin, Cexp, F, T, Fo, To, k, s, act = a[:17]
         nbytes = 4 * B * (Cin * F * T + Cexp * Fo * To) + 4 * Cexp * (Cin + k * k)
-        return f"mbconv_kernel<{k},{s},*,{act},false>", nbytes, 2 * B * Cexp * (Cin * F * T + k * k * Fo * To)
+        return f"irb_kernel<{k},{s},{Cin // 4},*,false,*>", nbytes, 2 * B * Cexp * (Cin * F * T + k * k * Fo * To)
     if name == "eat_mbconv_fwd":
         x, wpe, be, wd, bd, wpp, bp, res, y, B, Cin, Cexp, Cout, F, T, Fo, To, k, s, act = a[:20]
         # a fused kernel is priced at its OWN unavoidable traffic (input once [+ residual re-read], output once),
         # not at the traffic of the three layers it replaces
         nbytes = 4 * B * (Cin * F * T * (2 if res else 1) + Cout * Fo * To) + 4 * Cexp * (Cin + k * k + Cout)
         flops = 2 * B * (Cexp * Cin * F * T + Cexp * k * k * Fo * To + Cout * Cexp * Fo * To)
-        return f"mbconv_kernel<{k},{s},*,{act},true>", nbytes, flops
+        return f"irb_kernel<{k},{s},{Cin // 4},*,true,*>", nbytes, flops
     if name == "eat_front_fwd":
         x, ws, bs, wd, bd, wpp, bp, y, B, C, F, T, Fo, To, act = a[:15]
-        return f"front_kernel<{act}>", 4 * B * (F * T + C * Fo * To) + 4 * C * (9 + 9 + C), 2 * B * C * Fo * To * (9 + 9 + C)
+        return "irb_kernel<3,1,3,*,true,*,true>", 4 * B * (F * T + C * Fo * To) + 4 * C * (9 + 9 + C), 2 * B * C * Fo * To * (9 + 9 + C)
     if name == "eat_stem_conv_fwd":
         x, w, bias, y, B, C, F, T, Fo, To, act = a[:11]
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9

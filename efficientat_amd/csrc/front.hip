@@ -161,6 +161,10 @@ extern "C" int eat_front_fwd(const float* x, const float* w_s, const float* bias
   if (Fo != (F - 1) / 2 + 1 || To != (T - 1) / 2 + 1)
     return eat::fail(EAT_EINVAL, "eat_front_fwd: output %dx%d does not match input %dx%d", Fo, To, F, T);
   if (act != EAT_ACT_RELU && act != EAT_ACT_HSWISH) return eat::fail(EAT_EINVAL, "eat_front_fwd: act must be relu/hswish");
+  {   // round 2: register-resident kernel (irb.hip, FRONT mode); this LDS-staged one is the fallback / A-B reference
+    const int rc = eat::front_try(x, w_s, bias_s, w_d, bias_d, wp_p, bias_p, y, B, C, F, T, Fo, To, act, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   const int tiles_t = (To + kTT - 1) / kTT, tiles_f = (Fo + kTF - 1) / kTF;
   dim3 grid(tiles_t * tiles_f, B);
   hipStream_t s = (hipStream_t)stream;

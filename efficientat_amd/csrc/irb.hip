@@ -32,13 +32,13 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int kNT = 2;          // output column tiles (of 16) per wave
 constexpr int kWaves = 4;       // waves per block (they share the LDS weights only)
 
 struct IrbArgs {
   const float *x, *wpe, *bias_e, *wd, *bias_d, *wpp, *bias_p, *res;
   float *y, *pool;
   int B, Cin, Cexp, Cout, F, T, Fo, To;
+  int Fm, Tm;                             // FRONT: log-mel plane (F, T are the stem plane)
   int MT;                                 // 16-channel chunks of the expanded tensor
   int n_strips, n_parts, rows_per_part;   // work decomposition: item = (sample, column strip, row range)
   int n_items;
@@ -69,18 +69,21 @@ __device__ __forceinline__ float dpp0(float v) {      // lane j <- lane j -/+ n 
 // row only plain FMAs into three partial sums - L (taps whose input is the left neighbour u - 1), M (same lane), R (right
 // neighbour u + 1) - and after the last row  d(u) = M(u) + L(u - 1) + R(u + 1)  with two DPP row shifts (+ the neighbour
 // tile's edge lane for lanes 0 / 15).  Shifting is linear, so this equals shifting every input (zero fill included).
+template <int NT>
 struct DwAcc {
-  f32x4 l[kNT], m[kNT], r[kNT];
+  f32x4 l[NT], m[NT], r[NT];
 };
-__device__ __forceinline__ void fma_tiles(f32x4 (&d)[kNT], const f32x4* row, const f32x4 w) {
+template <int NT>
+__device__ __forceinline__ void fma_tiles(f32x4 (&d)[NT], const f32x4* row, const f32x4 w) {
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[t][r] = fmaf(w[r], row[t][r], d[t][r]);
 }
-// one input row's contribution; row = [E tiles (kNT)] [O tiles (kNT), stride 2 only]
-template <int K, int S>
-__device__ __forceinline__ void dw_row(DwAcc& d, const f32x4* row, const f32x4* w) {
+// one input row's contribution; row = [E tiles (NT)] [O tiles (NT), stride 2 only]
+template <int K, int S, int NT>
+__device__ __forceinline__ void dw_row(DwAcc<NT>& d, const f32x4* row, const f32x4* w) {
+  constexpr int kNT = NT;
   if constexpr (S == 1 && K == 3) {                 // columns oc-1, oc, oc+1
     fma_tiles(d.l, row, w[0]); fma_tiles(d.m, row, w[1]); fma_tiles(d.r, row, w[2]);
   } else if constexpr (S == 2 && K == 3) {          // columns 2oc-1, 2oc, 2oc+1 = O(u), E(u), O(u+1)
@@ -90,8 +93,9 @@ __device__ __forceinline__ void dw_row(DwAcc& d, const f32x4* row, const f32x4* 
     fma_tiles(d.r, row + kNT, w[3]); fma_tiles(d.r, row, w[4]);
   }
 }
-template <int K, int S>
-__device__ __forceinline__ void dw_finish(const DwAcc& a, f32x4 (&d)[kNT]) {
+template <int K, int S, int NT>
+__device__ __forceinline__ void dw_finish(const DwAcc<NT>& a, f32x4 (&d)[NT]) {
+  constexpr int kNT = NT;
 #pragma unroll
   for (int t = 0; t < kNT; ++t)
 #pragma unroll
@@ -106,10 +110,20 @@ __device__ __forceinline__ void dw_finish(const DwAcc& a, f32x4 (&d)[kNT]) {
     }
 }
 
-// K, S: depthwise kernel / stride; NKS = Cin / 4; MTI = chunks per row march (all of them with PROJ, 1 without);
-// MTO = project m-tiles (PROJ)
-template <int K, int S, int NKS, int MTI, int MTO, int ACT, bool PROJ>
-__global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
+// K, S: depthwise kernel / stride; NKS = Cin / 4; NT = output column tiles (of 16) per wave; MTI = 16-channel chunks
+// marched together (all of them with PROJ; without, ceil(MT / MTI) marches re-read the input); MTO = project m-tiles;
+// PF: the next row's B operands are requested one whole row ahead into a second register set (otherwise after the last
+// chunk's expand MFMAs, into the same registers)
+// FRONT: the network front (stem 3x3 / stride 2 conv of the 1-channel log-mel + BN + Hardswish -> first block: depthwise
+//   3x3 + BN + act -> project 1x1 + BN + residual; models/mn/model.py:124-133, block_types.py:150-181).  The stem IS the
+//   "expand" of this kernel: an MFMA with K = 9 taps (padded to 12, NKS = 3) whose B operand is the im2col gather of the
+//   log-mel (lane (k, n): tap 4 ks + k of stem column n, zero outside the image through the buffer range check); the
+//   residual (= the stem output) is the middle row of the register window, in the accumulator layout already.
+//   F, T (a.F, a.T) are then the STEM plane, a.Fm / a.Tm the log-mel plane; ACT_E = Hardswish.
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false>
+__global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
+  static_assert(!FRONT || (K == 3 && S == 1 && NKS == 3 && MTI == 1 && PROJ), "front = stem + 3x3/s1 block with project");
+  constexpr int kNT = NT;
   constexpr int P_ = (K - 1) / 2, KK = K * K;
   constexpr int KW = K - S;                 // expanded rows kept between output rows
   constexpr int TI = kNT * S;               // tiles per input row (stride 2: even + odd)
@@ -131,7 +145,15 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
   const int Cexp = a.Cexp, F = a.F, T = a.T, Fo = a.Fo, To = a.To;
 
   // ---- prologue: weights -> LDS (zero beyond Cexp / Cout)
-  for (int i = tid; i < NKS * MT * 64; i += 64 * kWaves) As[i] = a.wpe[i];
+  for (int i = tid; i < NKS * MT * 64; i += 64 * kWaves) {
+    if constexpr (FRONT) {                   // stem weights (C, 9) -> A fragments over the 12 (9 + 3 zero) taps
+      const int l = i & 63, c = (i >> 6) % MT, ks = (i >> 6) / MT;
+      const int ch = c * 16 + (l & 15), tap = 4 * ks + (l >> 4);
+      As[i] = (ch < Cexp && tap < 9) ? a.wpe[ch * 9 + tap] : 0.0f;
+    } else {
+      As[i] = a.wpe[i];
+    }
+  }
   for (int i = tid; i < MT * KK * 16; i += 64 * kWaves) {
     const int ch = (i / (KK * 16)) * 16 + (i & 15), tap = (i >> 4) % KK;
     Wd[i] = ch < Cexp ? a.wd[(size_t)ch * KK + tap] : 0.0f;
@@ -180,13 +202,53 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
       lb[h * kNT + t] = 4u * (unsigned)(kq * plane + (ci < 0 ? 0 : (ci >= T ? T - 1 : ci)));
     }
   }
+  unsigned fv[FRONT ? NKS : 1][TI];          // FRONT: byte offset of tap 4 ks + kq (row di, column 2 st - 1 + dj) or kOOB
+  int fdi[FRONT ? NKS : 1];
+  if constexpr (FRONT) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int tap = 4 * ks + kq, di = tap / 3, dj = tap - 3 * di;
+      fdi[ks] = di;
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) {
+        const int st = o0 + 16 * t + n - ULO, cm = 2 * st - 1 + dj;
+        fv[ks][t] = (tap < 9 && cm >= 0 && cm < a.Tm) ? 4u * (unsigned)(di * a.Tm + cm) : kOOB;
+      }
+    }
+  }
   const int Cy = PROJ ? a.Cout : Cexp;       // channels of y (and of the residual)
-  const __amdgpu_buffer_rsrc_t xr_ = make_rsrc(a.x + (size_t)b * a.Cin * plane, 4u * (unsigned)(a.Cin * plane));
+  const __amdgpu_buffer_rsrc_t xr_ = FRONT ? make_rsrc(a.x + (size_t)b * a.Fm * a.Tm, 4u * (unsigned)(a.Fm * a.Tm))
+                                           : make_rsrc(a.x + (size_t)b * a.Cin * plane, 4u * (unsigned)(a.Cin * plane));
   const __amdgpu_buffer_rsrc_t yr_ = make_rsrc(a.y + (size_t)b * Cy * plane_o, 4u * (unsigned)(Cy * plane_o));
   const __amdgpu_buffer_rsrc_t rr_ = make_rsrc(a.res ? a.res + (size_t)b * Cy * plane_o : a.y, a.res ? 4u * (unsigned)(Cy * plane_o) : 0u);
 
   float xb[S][NKS][TI];                      // B operands of the S new input rows of this output row
-  auto load_rows = [&](int i) {              // input rows S i - P + KW + j, j < S
+  float xn[PF ? S : 1][PF ? NKS : 1][PF ? TI : 1];   // ... and of the next output row (PF)
+  auto load_into = [&](int i, auto& dst) {   // input rows S i - P + KW + j, j < S
+    if constexpr (FRONT) {
+      const int sf = i - P_ + KW;              // stem row (the "input row" of the depthwise conv)
+      if (sf < 0 || sf >= F) return;           // zeroed in expand(); wave-uniform
+      const int fb = 2 * sf - 1;               // first log-mel row under the stem tap window
+      if (fb >= 0 && fb + 2 < a.Fm) {
+        const unsigned ro = 4u * (unsigned)fb * (unsigned)a.Tm;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) dst[0][ks][ti] = buf_load(xr_, fv[ks][ti], ro);
+      } else {                                 // top / bottom edge of the log-mel: rows outside read 0 (conv zero padding)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int fr = fb + fdi[ks];
+          const bool rin = fr >= 0 && fr < a.Fm;
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) {
+            const unsigned v = (rin && fv[ks][ti] != kOOB) ? fv[ks][ti] - 4u * (unsigned)(fdi[ks] * a.Tm) + 4u * (unsigned)(fr * a.Tm) : kOOB;
+            dst[0][ks][ti] = buf_load(xr_, v, 0u);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       int fi = S * i - P_ + KW + j;
@@ -195,9 +257,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) xb[j][ks][ti] = buf_load(xr_, lb[ti], ro + 16u * (unsigned)ks * (unsigned)plane);
+        for (int ti = 0; ti < TI; ++ti) dst[j][ks][ti] = buf_load(xr_, lb[ti], ro + 16u * (unsigned)ks * (unsigned)plane);
     }
   };
+  auto load_rows = [&](int i) { load_into(i, xb); };
   // expanded row of chunk c from B operands xr; fi = its input row (wave-uniform)
   auto expand = [&](int c, const float (&xr)[NKS][TI], int fi, f32x4 (&e)[TI]) {
     if (fi < 0 || fi >= F) {
@@ -217,12 +280,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) e[ti][r] = eat::activate<ACT>(e[ti][r]) * cmask[ti];
+      for (int r = 0; r < 4; ++r) e[ti][r] = eat::activate<ACT_E>(e[ti][r]) * cmask[ti];
   };
 
-  const int n_groups = PROJ ? 1 : MT;        // !PROJ: one chunk per march, chunks in an outer loop
+  const int n_groups = (MT + MTI - 1) / MTI;  // PROJ: 1 (all chunks marched together); otherwise MTI chunks per march
   for (int g = 0; g < n_groups; ++g) {
-    const int c0 = PROJ ? 0 : g;
+    const int c0 = g * MTI;
     f32x4 win[MTI][KW][TI];
     float psum[MTI][4];
 #pragma unroll
@@ -246,7 +309,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
           if (w >= 0) {
             const int fi = S * iq - P_ + KW + j;
 #pragma unroll
-            for (int c = 0; c < MTI; ++c) expand(c0 + c, xb[j], fi, win[c][w]);
+            for (int c = 0; c < MTI; ++c) expand(c0 + c < MT ? c0 + c : MT - 1, xb[j], fi, win[c][w]);
           }
         }
       }
@@ -254,6 +317,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
     load_rows(i0);
 
     for (int i = i0; i < i1; ++i) {
+      if constexpr (PF) {
+        if (i + 1 < i1) load_into(i + 1, xn);            // a whole row of arithmetic ahead of its use
+      }
       f32x4 accp[PROJ ? MTO : 1][kNT];
       f32x4 rres[PROJ ? MTO : 1][kNT];
       if constexpr (PROJ) {
@@ -264,25 +330,32 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
             accp[mo][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             // residual of this output row: requested before the row's arithmetic (all zeros without a residual: the
             // descriptor then has 0 records)
-            const unsigned vo = (ov[t] && mo * 16 + kq * 4 < a.Cout) ? ob[t] : kOOB;
+            if constexpr (FRONT) {
+              rres[mo][t] = win[0][KW - 1][t];           // the stem output of this row: already in the accumulator layout
+            } else {
+              const unsigned vo = (ov[t] && mo * 16 + kq * 4 < a.Cout) ? ob[t] : kOOB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              rres[mo][t][r] = buf_load(rr_, vo, 4u * (unsigned)((mo * 16 + r) * plane_o + i * To));
+              for (int r = 0; r < 4; ++r)
+                rres[mo][t][r] = buf_load(rr_, vo, 4u * (unsigned)((mo * 16 + r) * plane_o + i * To));
+            }
           }
       }
 #pragma unroll
       for (int c = 0; c < MTI; ++c) {
-        const int cg = c0 + c;
+        const bool c_ok = c0 + c < MT;       // a partial last group re-does chunk MT - 1 with its stores masked
+        const int cg = c_ok ? c0 + c : MT - 1;
         // compiler barrier: the weights in LDS are loop-invariant, and hipcc would otherwise hoist ALL of them (~250
         // registers for 5 chunks) out of the row loop and spill; they are re-read per chunk instead (LDS has the bandwidth)
         asm volatile("" ::: "memory");
         f32x4 enew[S][TI];
 #pragma unroll
         for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
-        if (c == MTI - 1 && i + 1 < i1) load_rows(i + 1);     // the B operands are free: next row's loads fly from here
+        if constexpr (!PF) {
+          if (c == MTI - 1 && i + 1 < i1) load_rows(i + 1);   // the B operands are free: next row's loads fly from here
+        }
         // depthwise row: K input rows = the window (KW) + the new rows (S)
         const f32x4 bd = *reinterpret_cast<const f32x4*>(Bd + cg * 16 + kq * 4);
-        DwAcc da;
+        DwAcc<NT> da;
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
           da.m[t] = bd;
@@ -295,11 +368,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
           f32x4 w[K];
 #pragma unroll
           for (int dj = 0; dj < K; ++dj) w[dj] = *reinterpret_cast<const f32x4*>(Wd + (cg * KK + di * K + dj) * 16 + kq * 4);
-          if (di < KW) dw_row<K, S>(da, win[c][di], w);
-          else dw_row<K, S>(da, enew[di - KW], w);
+          if (di < KW) dw_row<K, S, NT>(da, win[c][di], w);
+          else dw_row<K, S, NT>(da, enew[di - KW], w);
         }
         f32x4 d[kNT];
-        dw_finish<K, S>(da, d);
+        dw_finish<K, S, NT>(da, d);
 #pragma unroll
         for (int t = 0; t < kNT; ++t)
 #pragma unroll
@@ -316,7 +389,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
         } else {
 #pragma unroll
           for (int t = 0; t < kNT; ++t) {
-            const bool ok = ov[t] && cg * 16 + kq * 4 < Cexp;          // channel counts are multiples of 8
+            const bool ok = ov[t] && c_ok && cg * 16 + kq * 4 < Cexp;  // channel counts are multiples of 8
             const unsigned vo = ok ? ob[t] : kOOB;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -336,6 +409,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti) win[c][KW - S + j][ti] = enew[j][ti];
           }
+      }
+      if constexpr (PF) {
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) xb[j][ks][ti] = xn[j][ks][ti];
       }
       if constexpr (PROJ) {
 #pragma unroll
@@ -360,21 +441,22 @@ __global__ __launch_bounds__(64 * kWaves, 2) void irb_kernel(const IrbArgs a) {
             float s = psum[c][r];
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
             const int ch = (c0 + c) * 16 + kq * 4 + r;
-            if (n == 0 && ch < Cexp) atomicAdd(a.pool + (size_t)b * Cexp + ch, s);
+            if (n == 0 && c0 + c < MT && ch < Cexp) atomicAdd(a.pool + (size_t)b * Cexp + ch, s);
           }
       }
     }
   }
 }
 
-template <int K, int S, int NKS, int MTI, int MTO, int ACT, bool PROJ>
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF>
 int launch_irb(IrbArgs a, hipStream_t s) {
-  constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * kNT - 2, VO = UHI - ULO + 1;
+  constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * NT - 2, VO = UHI - ULO + 1;
   a.MT = (a.Cexp + 15) / 16;
   a.n_strips = (a.To + VO - 1) / VO;
   // enough waves to fill the chip a few times over, but row ranges of >= 8 rows (each range re-expands K - S halo rows)
+  static const int target = getenv("EAT_IRB_ITEMS") ? atoi(getenv("EAT_IRB_ITEMS")) : 6144;
   const long long strips = (long long)a.B * a.n_strips;
-  int parts = (int)((6144 + strips - 1) / strips);
+  int parts = (int)((target + strips - 1) / strips);
   const int max_parts = a.Fo / 8 > 1 ? a.Fo / 8 : 1;
   parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
   a.rows_per_part = (a.Fo + parts - 1) / parts;
@@ -384,7 +466,7 @@ int launch_irb(IrbArgs a, hipStream_t s) {
   a.n_items = (int)items;
   const size_t smem = sizeof(float) * ((size_t)NKS * a.MT * 64 + (size_t)a.MT * K * K * 16 + 2 * (size_t)a.MT * 16 +
                                        (PROJ ? (size_t)a.MT * 4 * MTO * 64 + MTO * 16 : 0));
-  auto kern = irb_kernel<K, S, NKS, MTI, MTO, ACT, PROJ>;
+  auto kern = irb_kernel<K, S, NKS, NT, MTI, MTO, ACT, PROJ, PF>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "irb: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
@@ -393,15 +475,58 @@ int launch_irb(IrbArgs a, hipStream_t s) {
   return eat::check_launch("irb_kernel");
 }
 
+template <int NT, int ACT, bool PF>
+int launch_front(IrbArgs a, hipStream_t s) {
+  constexpr int VO = 16 * NT - 2;
+  a.MT = 1;
+  a.n_strips = (a.To + VO - 1) / VO;
+  static const int target = getenv("EAT_IRB_ITEMS") ? atoi(getenv("EAT_IRB_ITEMS")) : 6144;
+  const long long strips = (long long)a.B * a.n_strips;
+  int parts = (int)((target + strips - 1) / strips);
+  const int max_parts = a.Fo / 8 > 1 ? a.Fo / 8 : 1;
+  parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
+  a.rows_per_part = (a.Fo + parts - 1) / parts;
+  a.n_parts = (a.Fo + a.rows_per_part - 1) / a.rows_per_part;
+  const long long items = strips * a.n_parts;
+  if (items > 0x7fffffffLL) return eat::fail(EAT_EINVAL, "eat_front_fwd: too many work items");
+  a.n_items = (int)items;
+  const size_t smem = sizeof(float) * (3 * 64 + 9 * 16 + 2 * 16 + 4 * 64 + 16);
+  hipLaunchKernelGGL((irb_kernel<3, 1, 3, NT, 1, 1, ACT, true, PF, EAT_ACT_HSWISH, true>),
+                     dim3((unsigned)((items + kWaves - 1) / kWaves)), dim3(64 * kWaves), smem, s, a);
+  return eat::check_launch("irb_kernel (front)");
+}
+
 }  // namespace
 
 namespace eat {
+
+// Network front (stem + first block) on the register-resident kernel; 1 = no instantiation (caller falls back).
+int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,
+              const float* wp_p, const float* bias_p, float* y, int B, int C, int F, int T, int Fo, int To, int act,
+              hipStream_t s) {
+  static const bool off = getenv("EAT_IRB") && atoi(getenv("EAT_IRB")) == 0;
+  static const int var = getenv("EAT_IRB_FRONT") ? atoi(getenv("EAT_IRB_FRONT")) : 2;   // 1 / 2 column tiles per wave: 0.275 / 0.269 ms (round-1 kernel 0.41)
+  if (off || var == 0 || C != 16) return 1;
+  if (4LL * F * T >= (1LL << 31) || 4LL * C * Fo * To >= (1LL << 31)) return 1;
+  IrbArgs a{};
+  a.x = x; a.wpe = w_s; a.bias_e = bias_s; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = nullptr;
+  a.y = y; a.pool = nullptr;
+  a.B = B; a.Cin = 1; a.Cexp = C; a.Cout = C; a.F = Fo; a.T = To; a.Fo = Fo; a.To = To; a.Fm = F; a.Tm = T;
+  if (act == EAT_ACT_RELU)
+    return var == 2 ? launch_front<2, EAT_ACT_RELU, true>(a, s) : launch_front<1, EAT_ACT_RELU, true>(a, s);
+  return var == 2 ? launch_front<2, EAT_ACT_HSWISH, true>(a, s) : launch_front<1, EAT_ACT_HSWISH, true>(a, s);
+}
 
 // Returns 1 when the shape has no instantiation (the caller falls back to the LDS-staged kernel), 0 / <0 otherwise.
 int irb_try(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,
             const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
             int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s) {
   static const bool off = getenv("EAT_IRB") && atoi(getenv("EAT_IRB")) == 0;
+  // A/B switch between tilings.  Measured on MI355X at B = 256 (blocks 2 / 3 / 4 of mn10, ms): 0 = two column tiles per
+  // wave, B operands re-requested late in the row: 0.40 / 0.31 / 0.34; 1 (default) = ONE tile per wave (half the
+  // registers: 3-4 waves per SIMD instead of 2), next row's B operands a whole row ahead, SE block marches all 5 chunks
+  // together: 0.36 / 0.28 / 0.25; 2 = two tiles + full-row prefetch: 0.40 / 0.32 / 0.36.  (LDS-staged round-1 kernel: 0.65 / 0.51 / 0.40.)
+  static const int var = getenv("EAT_IRB_V") ? atoi(getenv("EAT_IRB_V")) : 1;
   if (off || act != EAT_ACT_RELU) return 1;
   if (4LL * Cin * F * T >= (1LL << 31) || 4LL * (Cexp > Cout ? Cexp : Cout) * Fo * To >= (1LL << 31)) return 1;   // 32-bit byte offsets inside a sample
   if (Cexp % 8 != 0 || (wp_p && Cout % 4 != 0)) return 1;
@@ -411,14 +536,20 @@ int irb_try(const float* x, const float* wp_e, const float* bias_e, const float*
   a.B = B; a.Cin = Cin; a.Cexp = Cexp; a.Cout = Cout; a.F = F; a.T = T; a.Fo = Fo; a.To = To;
   const bool proj = wp_p != nullptr;
   const int MT = (Cexp + 15) / 16, MTO = (Cout + 15) / 16;
+  constexpr int R = EAT_ACT_RELU;
   if (proj) {
-    if (k == 3 && stride == 2 && Cin == 16 && MT == 4 && MTO == 2) return launch_irb<3, 2, 4, 4, 2, EAT_ACT_RELU, true>(a, s);
-    if (k == 3 && stride == 1 && Cin == 24 && MT == 5 && MTO == 2) return launch_irb<3, 1, 6, 5, 2, EAT_ACT_RELU, true>(a, s);
+    if (k == 3 && stride == 2 && Cin == 16 && MT == 4 && MTO == 2)
+      return var == 1 ? launch_irb<3, 2, 4, 1, 4, 2, R, true, true>(a, s) : launch_irb<3, 2, 4, 2, 4, 2, R, true, false>(a, s);
+    if (k == 3 && stride == 1 && Cin == 24 && MT == 5 && MTO == 2)
+      return var == 1 ? launch_irb<3, 1, 6, 1, 5, 2, R, true, true>(a, s)
+           : var == 2 ? launch_irb<3, 1, 6, 2, 5, 2, R, true, true>(a, s) : launch_irb<3, 1, 6, 2, 5, 2, R, true, false>(a, s);
     return 1;
   }
-  if (k == 5 && stride == 2 && Cin == 24) return launch_irb<5, 2, 6, 1, 1, EAT_ACT_RELU, false>(a, s);
-  if (k == 3 && stride == 2 && Cin == 16) return launch_irb<3, 2, 4, 1, 1, EAT_ACT_RELU, false>(a, s);
-  if (k == 3 && stride == 1 && Cin == 24) return launch_irb<3, 1, 6, 1, 1, EAT_ACT_RELU, false>(a, s);
+  if (k == 5 && stride == 2 && Cin == 24)
+    return (var == 1 && MT == 5) ? launch_irb<5, 2, 6, 1, 5, 1, R, false, false>(a, s)
+         : var == 2 ? launch_irb<5, 2, 6, 1, 1, 1, R, false, true>(a, s) : launch_irb<5, 2, 6, 2, 1, 1, R, false, false>(a, s);
+  if (k == 3 && stride == 2 && Cin == 16) return launch_irb<3, 2, 4, 2, 1, 1, R, false, false>(a, s);
+  if (k == 3 && stride == 1 && Cin == 24) return launch_irb<3, 1, 6, 2, 1, 1, R, false, false>(a, s);
   return 1;
 }
 
