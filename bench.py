@@ -410,10 +410,21 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def _claim_stdout():
+    """Keep fd 1 for the ONE JSON line: libraries print to stdout from C (RCCL's version banner at communicator init,
+    flushed at exit, i.e. AFTER Python's own prints), so fd 1 is pointed at stderr for the run and the line is written to
+    the saved descriptor at the end."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, "w")
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         respawn_under_torchrun(args)
+    json_out = _claim_stdout()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -437,7 +448,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": 0.0, "unit": "clips/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
-                              "dry_run": True}))
+                              "dry_run": True}), file=json_out, flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -554,7 +565,7 @@ def main():
         result["parity"] = {"logit_max_abs_err": err, "logit_abs_max": scale, "vs": "CPU oracle, 4 clips, same weights"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result))
+        print(json.dumps(result), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,7 +7,7 @@
 // mn10_as_mels_64 with an odd number of frames).  This kernel takes the SAME packed weights and the same
 // epilogue contract with plain 4-byte accesses: one wave = 64 consecutive positions of one sample x one
 // 16-row m-tile, the k loop on the fp32 VALU (exact fp32 fmaf chain; split bf16 weights are recombined
-// hi + lo first).  Those planes are tiny (<= a few hundred positions), so the kernel is latency-bound and
+// hi + lo first; plain-bf16 packs round the activation to bf16 as well, like the MFMA kernel).  Those planes are tiny (<= a few hundred positions), so the kernel is latency-bound and
 // not on any measured path; it exists so that the model runs for every input geometry the reference accepts.
 #include "eat_common.h"
 
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64) void pw_conv_generic_kernel(
   for (int k = 0; k < Ci; ++k) {
     float xv = xb[(size_t)k * S];
     if (in_scale) xv *= in_scale[(size_t)b * Ci + k];
+    if constexpr (WMODE == 1) xv = (float)(__bf16)xv;     // plain-bf16 arithmetic: both operands rounded, as on the MFMA path
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = fmaf(packed_w<WMODE>(wb, MT, mt, i, k), xv, acc[i]);
   }
