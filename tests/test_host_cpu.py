@@ -6,6 +6,7 @@ import io
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -126,3 +127,47 @@ def test_dymn_temperature_schedule_and_api():
         _quiet(get_dymn, use_dy_blocks="bogus")
     with pytest.raises(Exception):
         m.eval()(torch.zeros(1, 1, 128, 100))          # CPU tensor: no fallback
+
+
+def test_synthetic_audioset_standin_matches_reference_tuple_layout(tmp_path, monkeypatch):
+    """dropin/datasets/audioset.py: same public functions and item layout as the reference's datasets/audioset.py
+    (:94-103 AddIndexDataset, :138-161 item = (waveform (1, 320000) f32, name, target (527,) f32))."""
+    import importlib.util
+    monkeypatch.setenv("EAT_SYNTH_AUDIOSET_TRAIN", "16")
+    monkeypatch.setenv("EAT_SYNTH_AUDIOSET_TEST", "527")
+    spec = importlib.util.spec_from_file_location("eat_synth_audioset", os.path.join(ROOT, "dropin", "datasets", "audioset.py"))
+    ds = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(ds)
+        full, test = ds.get_full_training_set(), ds.get_test_set()
+        sampler = ds.get_ft_weighted_sampler(epoch_len=24)
+    assert len(full) == 64 and len(test) == 527 and len(list(sampler)) == 24
+    x, name, y, idx = full[5]
+    assert x.shape == (1, 320000) and x.dtype == np.float32 and y.shape == (527,) and y.dtype == np.float32 and idx == 5
+    assert name == "syn0000005" and y.sum() >= 1 and np.abs(x).max() <= 1.0
+    x2, _, y2, _ = full[5]
+    assert np.array_equal(x, x2) and np.array_equal(y, y2)                 # deterministic per index
+    xt, nt, yt = test[3]
+    assert xt.shape == (1, 320000) and isinstance(nt, str) and len(test[3]) == 3
+    ys = test.targets()
+    assert ys.sum(0).min() >= 1 and (1 - ys).sum(0).min() >= 1             # per-class AP / ROC of `_test` are defined
+    with contextlib.redirect_stdout(io.StringIO()):
+        mixed = ds.get_training_set(roll=True, wavmix=True, gain_augment=3)
+    xm, _, ym, _ = mixed[1]
+    assert xm.shape == (1, 320000) and ym.shape == (527,)
+
+
+def test_audio_loader_resamples_like_librosa_load(tmp_path):
+    """efficientat_amd.audio_io.load_audio = the `librosa.core.load(path, sr=32000, mono=True)` contract of
+    inference.py:45: PCM decode, channel mean, 44.1 -> 32 kHz polyphase resampling."""
+    from scipy.io import wavfile
+    from efficientat_amd.audio_io import load_audio
+    t = np.arange(44100) / 44100.0
+    sig = 0.5 * np.sin(2 * np.pi * 1000.0 * t)
+    wavfile.write(tmp_path / "a.wav", 44100, (np.stack([sig, sig], 1) * 32767).astype(np.int16))
+    y, sr = load_audio(str(tmp_path / "a.wav"), sr=32000, mono=True)
+    assert sr == 32000 and y.dtype == np.float32 and y.shape == (32000,)
+    ref = 0.5 * np.sin(2 * np.pi * 1000.0 * np.arange(32000) / 32000.0)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3                # away from the filter's edge transients
+    y2, sr2 = load_audio(str(tmp_path / "a.wav"), sr=None, mono=False)
+    assert sr2 == 44100 and y2.shape == (2, 44100)
