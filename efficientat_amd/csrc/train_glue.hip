@@ -1,0 +1,118 @@
+// Training-loop glue of ex_audioset.py on the device: the reference builds these from ~25 tiny
+// torch ops per step and reads three scalars back to the host every step (ex_audioset.py:142-194).
+//   eat_mixup_fwd        x[b] * lam[b] + x[perm[b]] * (1 - lam[b])                      (ex_audioset.py:142-148)
+//   eat_kd_loss_fwd_bwd  hard-label BCE-with-logits on the mixed targets + knowledge-distillation BCE against the
+//                        (mixed) teacher probabilities, lambda-weighted, AND its gradient w.r.t. the logits, in one
+//                        pass over the (B, C) logits (ex_audioset.py:149-189)
+#include "eat_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                                    const float* __restrict__ lam, float* __restrict__ out, int n4) {
+  const int b = blockIdx.y;
+  const float l = lam[b], m = 1.0f - l;
+  const float4* xa = reinterpret_cast<const float4*>(x) + (size_t)b * n4;
+  const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)perm[b] * n4;
+  float4* o = reinterpret_cast<float4*>(out) + (size_t)b * n4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const float4 p = xa[i], q = xb[i];
+    o[i] = make_float4(p.x * l + q.x * m, p.y * l + q.y * m, p.z * l + q.z * m, p.w * l + q.w * m);
+  }
+}
+__global__ __launch_bounds__(256) void mixup_tail_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                                         const float* __restrict__ lam, float* __restrict__ out, int n) {
+  const int b = blockIdx.y;
+  const float l = lam[b], m = 1.0f - l;
+  const size_t pa = (size_t)b * n, pb = (size_t)perm[b] * n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[pa + i] = x[pa + i] * l + x[pb + i] * m;
+}
+
+// numerically stable BCE-with-logits term (torch: max(z,0) - z t + log1p(exp(-|z|)))
+__device__ __forceinline__ float bce(float z, float t) { return fmaxf(z, 0.0f) - z * t + log1pf(expf(-fabsf(z))); }
+
+// one block per sample; sums[0..2] += (total, label part, distillation part) of the batch-mean loss
+__global__ __launch_bounds__(256) void kd_loss_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                      const int* __restrict__ perm, const float* __restrict__ lam,
+                                                      const float* __restrict__ teacher, const long long* __restrict__ tidx,
+                                                      int n_teacher, float kd_lambda, int B, int C,
+                                                      float* __restrict__ sums, float* __restrict__ dz) {
+  __shared__ float s_red[2][4];
+  const int b = blockIdx.x;
+  const bool mix = perm != nullptr;
+  const int pb = mix ? perm[b] : b;
+  const float l = mix ? lam[b] : 1.0f, m = 1.0f - l;
+  const bool kd = teacher != nullptr && kd_lambda < 1.0f;
+  // the reference indexes teacher_preds[-1] for files without a teacher entry and zeroes THIS sample's KD term; the
+  // mix-up partner's row is used whatever its own status is (ex_audioset.py:160-180): reproduced
+  long long ia = 0, ib = 0;
+  bool known = false;
+  if (kd) {
+    ia = tidx[b]; ib = tidx[pb];
+    known = ia >= 0;
+    ia = ia < 0 ? n_teacher - 1 : ia;
+    ib = ib < 0 ? n_teacher - 1 : ib;
+  }
+  const float wl = kd ? kd_lambda : 1.0f, wk = kd ? (1.0f - kd_lambda) * (known ? 1.0f : 0.0f) : 0.0f;
+  const float inv = 1.0f / ((float)B * (float)C);
+  float s_label = 0.0f, s_kd = 0.0f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float zz = z[(size_t)b * C + c];
+    const float ym = y[(size_t)b * C + c] * l + (mix ? y[(size_t)pb * C + c] * m : 0.0f);
+    const float sg = 1.0f / (1.0f + expf(-zz));
+    s_label += bce(zz, ym);
+    float g = wl * (sg - ym);
+    if (kd) {
+      const float ta = teacher[(size_t)ia * C + c], tb = teacher[(size_t)ib * C + c];
+      s_kd += bce(zz, ta) * l + bce(zz, tb) * m;
+      g += wk * (sg - (ta * l + tb * m));
+    }
+    dz[(size_t)b * C + c] = g * inv;
+  }
+  s_label = eat::wave_sum(s_label);
+  s_kd = eat::wave_sum(s_kd);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { s_red[0][wv] = s_label; s_red[1][wv] = s_kd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = (s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]) * inv * wl;
+    const float k = (s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) * inv * wk;
+    atomicAdd(sums + 0, a + k);
+    atomicAdd(sums + 1, a);
+    atomicAdd(sums + 2, k);
+  }
+}
+
+}  // namespace
+
+extern "C" int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n,
+                             eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || n < 1) return eat::fail(EAT_EINVAL, "eat_mixup_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if ((n & 3) == 0) {
+    const int n4 = n >> 2;
+    int gx = (n4 + 255) / 256;
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(mixup_kernel, dim3(gx, B), dim3(256), 0, s, x, perm, lam, out, n4);
+  } else {
+    int gx = (n + 255) / 256;
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(mixup_tail_kernel, dim3(gx, B), dim3(256), 0, s, x, perm, lam, out, n);
+  }
+  return eat::check_launch("eat_mixup_fwd");
+}
+
+extern "C" int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, const float* lam,
+                                   const float* teacher, const long long* teacher_idx, int n_teacher, float kd_lambda,
+                                   int B, int C, float* sums, float* dlogits, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1) return eat::fail(EAT_EINVAL, "eat_kd_loss_fwd_bwd: bad shape");
+  if ((perm == nullptr) != (lam == nullptr)) return eat::fail(EAT_EINVAL, "eat_kd_loss_fwd_bwd: perm and lam go together");
+  if (teacher && (!teacher_idx || n_teacher < 1)) return eat::fail(EAT_EINVAL, "eat_kd_loss_fwd_bwd: teacher needs its index");
+  if (kd_lambda < 0.0f || kd_lambda > 1.0f) return eat::fail(EAT_EINVAL, "eat_kd_loss_fwd_bwd: kd_lambda outside [0, 1]");
+  hipLaunchKernelGGL(kd_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, y, perm, lam, teacher, teacher_idx,
+                     n_teacher, kd_lambda, B, C, sums, dlogits);
+  return eat::check_launch("eat_kd_loss_fwd_bwd");
+}

@@ -361,3 +361,23 @@ def pw_conv(x, wp, bias, Co, act, in_scale=None, res=None, pool=None, write=True
         return pw_conv_bf16(x, wp, bias, Co, act, getattr(wp, "_eat_split", False), in_scale=in_scale, res=res,
                             pool=pool, write=write)
     return _pw_conv_fp32(x, wp, bias, Co, act, in_scale=in_scale, res=res, pool=pool, write=write)
+
+
+# ------------------------------------------------------------------ training-loop glue (ex_audioset.py:142-194)
+def mixup_fwd(x, perm, lam):
+    """x[b] * lam[b] + x[perm[b]] * (1 - lam[b]) over the flattened per-sample axis; perm int32 (B), lam fp32 (B)."""
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    _lib.call("eat_mixup_fwd", _dev(x, "x"), perm.data_ptr(), lam.data_ptr(), out.data_ptr(), B, x.numel() // B, _stream())
+    return out
+
+
+def kd_loss_fwd_bwd(logits, y, perm, lam, teacher, teacher_idx, kd_lambda, sums):
+    """-> dlogits; accumulates (loss, label part, distillation part) into `sums` (3,) on the device."""
+    B, C = logits.shape
+    dlogits = torch.empty_like(logits)
+    _lib.call("eat_kd_loss_fwd_bwd", _dev(logits, "logits"), _dev(y, "y"), None if perm is None else perm.data_ptr(),
+              None if lam is None else lam.data_ptr(), None if teacher is None else _dev(teacher, "teacher"),
+              None if teacher_idx is None else teacher_idx.data_ptr(), 0 if teacher is None else teacher.shape[0],
+              float(kd_lambda), B, C, sums.data_ptr(), dlogits.data_ptr(), _stream())
+    return dlogits

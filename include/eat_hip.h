@@ -280,6 +280,25 @@ int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, cons
                          const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
                          int split, eat_stream_t stream);
 
+/* ================= training-loop glue (ex_audioset.py:142-194) ========================= */
+
+/* Mix-up of a batch with itself (ex_audioset.py:142-148, helpers/utils.py:90-95): out[b] = x[b]*lam[b] + x[perm[b]]*(1-lam[b]);
+ * x, out (B, n) fp32 (n = the flattened per-sample size), perm (B) int32, lam (B) fp32.  out must not alias x. */
+int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n, eat_stream_t stream);
+
+/* Loss of the KD training step and its gradient w.r.t. the logits in one pass (ex_audioset.py:149-189):
+ *   label = mean_{b,c} BCEwithLogits(z, y*lam + y[perm]*(1-lam))
+ *   kd    = mean_b known[b] * ( lam[b] * mean_c BCE(z, t[idx[b]]) + (1-lam[b]) * mean_c BCE(z, t[idx[perm[b]]]) )
+ *   loss  = kd_lambda * label + (1 - kd_lambda) * kd              (kd_lambda in [0,1]; teacher == NULL: loss = label)
+ * logits, y, dlogits (B, C); perm / lam (B) or both NULL (no mix-up); teacher (n_teacher, C) PROBABILITIES
+ * (sigmoid(teacher_logits / temperature), as the reference stores them), teacher_idx (B) int64 with -1 for files that
+ * have no teacher entry (their KD term is zeroed; like the reference, row n_teacher-1 stands in for the lookup).
+ * sums (3) fp32 += (loss, kd_lambda*label, (1-kd_lambda)*kd): accumulate over steps on the device, read once per epoch
+ * (the reference syncs three scalars to the host every step, ex_audioset.py:192-194).  dlogits = d loss / d logits. */
+int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, const float* lam, const float* teacher,
+                        const long long* teacher_idx, int n_teacher, float kd_lambda, int B, int C, float* sums,
+                        float* dlogits, eat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
