@@ -237,3 +237,55 @@ extern "C" int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const floa
   const DwDyn dyn{coef, gate_f, gate_t, nullptr, 0, 1};
   return dispatch_dw(x, w_bc, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
 }
+
+// ---- depthwise conv with dilation (models/mn/model.py:244-269 `dilated=True`: the last three blocks run their 5x5
+// depthwise conv with dilation 2 and stride 1; torch pads (k-1)/2*dilation).  Not a measured path (no released
+// checkpoint uses it): one thread per output element, taps and bias through the scalar cache, reads coalesced along T.
+namespace {
+__global__ __launch_bounds__(256) void dw_conv_dilated_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              float* __restrict__ pool, int C, int F, int T, int Fo, int To,
+                                                              int k, int stride, int dil, int act) {
+  const int plane = blockIdx.y, c = plane % C;
+  const int pad = (k - 1) / 2 * dil;
+  const float* xp = x + (size_t)plane * F * T;
+  const float* wc = w + (size_t)c * k * k;
+  const float bc = bias[c];
+  float ps = 0.0f;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < Fo * To; e += gridDim.x * blockDim.x) {
+    const int i = e / To, j = e - i * To;
+    float acc = bc;
+    for (int u = 0; u < k; ++u) {
+      const int fi = i * stride - pad + u * dil;
+      if (fi < 0 || fi >= F) continue;
+      for (int v = 0; v < k; ++v) {
+        const int ti = j * stride - pad + v * dil;
+        if (ti >= 0 && ti < T) acc = fmaf(wc[u * k + v], xp[(size_t)fi * T + ti], acc);
+      }
+    }
+    const float o = eat::activate_rt(acc, act);
+    y[(size_t)plane * Fo * To + e] = o;
+    ps += o;
+  }
+  if (pool) {
+    ps = eat::wave_sum(ps);
+    if ((threadIdx.x & 63) == 0) atomicAdd(pool + plane, ps);
+  }
+}
+}  // namespace
+
+extern "C" int eat_dw_conv_dilated_fwd(const float* x, const float* w, const float* bias, float* y, float* pool, int B,
+                                       int C, int F, int T, int Fo, int To, int k, int stride, int dilation, int act,
+                                       eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (k < 1 || k > 7 || (k & 1) == 0 || stride < 1 || dilation < 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_dilated_fwd: bad geometry");
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_dilated_fwd: bad act %d", act);
+  const int pad = (k - 1) / 2 * dilation;
+  if (Fo != (F + 2 * pad - dilation * (k - 1) - 1) / stride + 1 || To != (T + 2 * pad - dilation * (k - 1) - 1) / stride + 1)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dilated_fwd: output %dx%d inconsistent with input %dx%d", Fo, To, F, T);
+  int gx = (Fo * To + 255) / 256;
+  gx = gx > 32 ? 32 : gx;
+  hipLaunchKernelGGL(dw_conv_dilated_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, pool, C, F, T,
+                     Fo, To, k, stride, dilation, act);
+  return eat::check_launch("eat_dw_conv_dilated_fwd");
+}

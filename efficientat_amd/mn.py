@@ -91,26 +91,61 @@ def _conv_bn_act(cin, cout, k, stride=1, groups=1, act=None):
 
 
 class SqueezeExcitation(nn.Module):
-    """fc1 / ReLU / fc2 / Sigmoid gate over channels (models/mn/block_types.py:45-83)."""
+    """fc1 / ReLU / fc2 / Sigmoid gate over one of the dimensions channel (1), frequency (2), time (3)
+    (models/mn/block_types.py:45-83)."""
 
-    def __init__(self, input_dim, squeeze_dim):
+    def __init__(self, input_dim, squeeze_dim, se_dim=1):
         super().__init__()
         self.fc1 = nn.Linear(input_dim, squeeze_dim)
         self.fc2 = nn.Linear(squeeze_dim, input_dim)
+        assert se_dim in [1, 2, 3]
+        self.gate_dim = se_dim
 
 
 class ConcurrentSEBlock(nn.Module):
-    """Holder for ``conc_se_layers.0`` (models/mn/block_types.py:10-42); only channel SE is on the HIP path."""
+    """Holder for ``conc_se_layers.{i}`` (models/mn/block_types.py:10-42): one SqueezeExcitation per entry of `se_dims`
+    (1 = channels, 2 = frequency, 3 = time), their scaled outputs combined by `se_agg`.  The default (channel SE only)
+    runs fused into the depthwise / project kernels; the other configurations run as a separate, unfused eval plan."""
 
-    def __init__(self, c_dim, se_cnf):
+    def __init__(self, c_dim, f_dim, t_dim, se_cnf):
         super().__init__()
-        if list(se_cnf["se_dims"]) != [1]:
-            raise NotImplementedError("HIP path implements squeeze-excitation over channels only (se_dims='c')")
         if se_cnf["se_agg"] not in ("max", "avg", "add", "min"):
             raise NotImplementedError(f"SE aggregation operation '{se_cnf['se_agg']}' not implemented")
-        self.sum_factor = 1.0  # a single SE layer: max/avg/min/add of one element is the identity
+        dims = [c_dim, f_dim, t_dim]
+        if 2 in se_cnf["se_dims"]:
+            # the reference cannot run a frequency gate either: block_types.py:75 squeezes dim 2 twice, which leaves
+            # (B, 1, F, 1) and fc1 fails on a last dimension of 1 - there is no reference behaviour to match
+            raise NotImplementedError("squeeze-excitation over the frequency dimension ('f') fails in the reference "
+                                      "(models/mn/block_types.py:75); use se_dims from {'c', 't'}")
+        self.se_dims, self.se_agg = list(se_cnf["se_dims"]), se_cnf["se_agg"]
+        self.channel_only = self.se_dims == [1]          # max / avg / min of one element is the identity ('add' too)
         self.conc_se_layers = nn.ModuleList(
-            [SqueezeExcitation(c_dim, make_divisible(c_dim // se_cnf["se_r"], 8))])
+            [SqueezeExcitation(dims[d - 1], make_divisible(dims[d - 1] // se_cnf["se_r"], 8), d) for d in self.se_dims])
+
+
+class MultiHeadAttentionPooling(nn.Module):
+    """Parameter holder + eval forward of the PSLA multi-head attention pooling head (models/mn/attention_pooling.py:9-56):
+    mean over frequency, Linear to (att, val) x heads x classes on the MFMA linear kernel, sigmoid attention normalised
+    over time, weighted sum, head-weighted sum.  The (B, heads, T, classes) algebra after the GEMM is a few KB per clip
+    and stays in torch ops."""
+
+    def __init__(self, in_dim, out_dim, att_activation="sigmoid", clf_activation="ident", num_heads=4, epsilon=1e-7):
+        super().__init__()
+        if att_activation != "sigmoid" or clf_activation != "ident":
+            raise NotImplementedError("HIP path implements the reference's default activations (sigmoid / ident)")
+        self.in_dim, self.out_dim, self.num_heads, self.epsilon = in_dim, out_dim, num_heads, epsilon
+        self.subspace_proj = nn.Linear(in_dim, out_dim * 2 * num_heads)
+        self.head_weight = nn.Parameter(torch.tensor([1.0 / num_heads] * num_heads).view(1, -1, 1))
+
+    def forward(self, x):
+        b, c = x.shape[0], x.shape[1]
+        xm = x.mean(dim=2).transpose(1, 2).contiguous()                  # collapse_dim(x, 2) -> (B, T, C)
+        n = xm.shape[1]
+        p = ops.linear(xm.view(b * n, c), self.subspace_proj.weight, self.subspace_proj.bias, ops.ACT_NONE)
+        p = p.view(b, n, 2, self.num_heads, self.out_dim).permute(2, 0, 3, 1, 4)
+        att, val = torch.sigmoid(p[0]).clamp(self.epsilon, 1.0 - self.epsilon), p[1]
+        att = att / att.sum(dim=2, keepdim=True)
+        return ((att * val).sum(dim=2) * self.head_weight).sum(dim=1)
 
 
 class InvertedResidual(nn.Module):
@@ -120,9 +155,8 @@ class InvertedResidual(nn.Module):
         super().__init__()
         if not (1 <= cnf.stride <= 2):
             raise ValueError("illegal stride value")
-        if cnf.dilation != 1:
-            raise NotImplementedError("dilated depthwise convs are not on the HIP path yet")
         self.cnf = cnf
+        self.dw_stride = 1 if cnf.dilation > 1 else cnf.stride        # block_types.py:150
         self.use_res_connect = cnf.stride == 1 and cnf.input_channels == cnf.out_channels
         act = nn.Hardswish if cnf.use_hs else nn.ReLU
         layers: List[nn.Module] = []
@@ -131,11 +165,14 @@ class InvertedResidual(nn.Module):
             self.i_expand = len(layers)
             layers.append(_conv_bn_act(cnf.input_channels, cnf.expanded_channels, 1, act=act))
         self.i_dw = len(layers)
-        layers.append(_conv_bn_act(cnf.expanded_channels, cnf.expanded_channels, cnf.kernel, cnf.stride,
-                                   cnf.expanded_channels, act))
+        dw = _conv_bn_act(cnf.expanded_channels, cnf.expanded_channels, cnf.kernel, self.dw_stride,
+                          cnf.expanded_channels, act)
+        if cnf.dilation > 1:
+            dw[0].dilation, dw[0].padding = (cnf.dilation,) * 2, ((cnf.kernel - 1) // 2 * cnf.dilation,) * 2
+        layers.append(dw)
         if cnf.use_se and se_cnf["se_dims"] is not None:
             self.i_se = len(layers)
-            layers.append(ConcurrentSEBlock(cnf.expanded_channels, se_cnf))
+            layers.append(ConcurrentSEBlock(cnf.expanded_channels, cnf.f_dim, cnf.t_dim, se_cnf))
         self.i_proj = len(layers)
         layers.append(_conv_bn_act(cnf.expanded_channels, cnf.out_channels, 1, act=None))
         self.block = nn.Sequential(*layers)
@@ -165,7 +202,38 @@ def _pw_mode(Co, Ci):
 def _fusable(blk):
     cnf = blk.cnf
     return (blk.i_expand is not None and cnf.input_channels <= _FUSE_MAX_CIN and cnf.input_channels % 4 == 0
-            and cnf.expanded_channels % 4 == 0 and cnf.dilation == 1)
+            and cnf.expanded_channels % 4 == 0 and cnf.dilation == 1
+            and (blk.i_se is None or blk.block[blk.i_se].channel_only))
+
+
+def _concurrent_se(se_block, y, pool_c):
+    """ConcurrentSEBlock.forward for se_dims beyond 'c' (models/mn/block_types.py:36-42,72-83): every gate is two small
+    GEMMs on the MFMA linear kernel over the mean of the other two dimensions; the gated copies are combined by se_agg.
+    Scales are positive (sigmoid), so max / min over the gated copies is y times the max / min gate where y >= 0 and
+    the min / max gate where y < 0 - no stack of full tensors is materialised."""
+    B, C, Fq, T = y.shape
+    gates = []
+    for se in se_block.conc_se_layers:
+        d = se.gate_dim
+        if d == 1:
+            m = pool_c * (1.0 / (Fq * T))
+        else:
+            m = y.mean(dim=[k for k in (1, 2, 3) if k != d]).contiguous()
+        h = ops.linear(m, se.fc1.weight, se.fc1.bias, ops.ACT_RELU)
+        g = ops.linear(h, se.fc2.weight, se.fc2.bias, ops.ACT_SIGMOID)
+        shape = [B, 1, 1, 1]
+        shape[d] = g.shape[1]
+        gates.append(g.view(shape))
+    if se_block.se_agg == "add":
+        return y * sum(gates)
+    if se_block.se_agg == "avg":
+        return y * (sum(gates) / len(gates))
+    hi = lo = gates[0]
+    for g in gates[1:]:
+        hi, lo = torch.maximum(hi, g), torch.minimum(lo, g)
+    if se_block.se_agg == "min":
+        hi, lo = lo, hi
+    return torch.where(y >= 0, y * hi, y * lo).contiguous()
 
 
 def _pack_pw(w2d, scale, bias):
@@ -233,8 +301,12 @@ class MN(nn.Module):
             self.classifier = nn.Sequential(
                 nn.AdaptiveAvgPool2d(1), nn.Flatten(start_dim=1), nn.Linear(6 * c_last, last_channel),
                 nn.Hardswish(inplace=True), nn.Dropout(p=dropout, inplace=True), nn.Linear(last_channel, num_classes))
-        elif self.head_type in ("fully_convolutional", "multihead_attention_pooling"):
-            raise NotImplementedError(f"Head '{self.head_type}' is not on the HIP path yet (only 'mlp')")
+        elif self.head_type == "fully_convolutional":       # models/mn/model.py:173-185
+            self.classifier = nn.Sequential(nn.Conv2d(6 * c_last, num_classes, (1, 1), bias=False),
+                                            nn.BatchNorm2d(num_classes), nn.AdaptiveAvgPool2d((1, 1)))
+        elif self.head_type == "multihead_attention_pooling":   # models/mn/model.py:170-172
+            self.classifier = MultiHeadAttentionPooling(6 * c_last, num_classes,
+                                                        num_heads=kwargs.get("multihead_attention_heads") or 4)
         else:
             raise NotImplementedError(f"Head '{self.head_type}' unknown. Must be one of: 'mlp', "
                                       f"'fully_convolutional', 'multihead_attention_pooling'")
@@ -262,7 +334,8 @@ class MN(nn.Module):
 
     # ------------------------------------------------------------------ folded weights
     def _fold_sources(self):
-        return [t for m in self.features.modules() if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))
+        mods = list(self.features.modules()) + (list(self.classifier.modules()) if self.head_type == "fully_convolutional" else [])
+        return [t for m in mods if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))
                 for t in ([m.weight] if isinstance(m, nn.Conv2d) else
                           [m.weight, m.bias, m.running_mean, m.running_var])]
 
@@ -301,6 +374,10 @@ class MN(nn.Module):
         last = self.features[-1]
         s, b = _fold(last[0], last[1])
         out["last"] = _pack_pw(last[0].weight.flatten(1), s.contiguous(), b.contiguous())
+        if self.head_type == "fully_convolutional":
+            # eval: mean_s BN(conv1x1(x)) = (scale * W) mean_s(x) + bias - the head collapses onto the pooled features
+            s, b = _fold(self.classifier[0], self.classifier[1])
+            out["fc_head"] = ((self.classifier[0].weight.flatten(1) * s.view(-1, 1)).contiguous(), b.contiguous())
         return out
 
     # --------------------------------------------------------------------------- forward
@@ -310,6 +387,10 @@ class MN(nn.Module):
         if self.training:
             if return_fmaps:
                 raise NotImplementedError("return_fmaps is only available in eval mode on the HIP path")
+            if self.head_type != "mlp" or any(b.cnf.dilation > 1 or (b.i_se is not None and not b.block[b.i_se].channel_only)
+                                              for b in self.features[1:-1]):
+                raise NotImplementedError("training on the HIP path covers the default configuration (head_type='mlp', "
+                                          "se_dims='c', dilation 1); the other variants are eval-only")
             from .mn_train import forward_train
             return forward_train(self, x)
         W = self._cache.get(self._fold_sources(), self._build_folded)
@@ -363,8 +444,13 @@ class MN(nn.Module):
             else:
                 if blk.i_expand is not None:
                     x = _pw(x, w["exp"], cnf.expanded_channels, act)
-                x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
-            if pool is not None:
+                if cnf.dilation > 1:
+                    x = ops.dw_conv_dilated(x, w["dw"][0], w["dw"][1], cnf.kernel, blk.dw_stride, cnf.dilation, act, pool)
+                else:
+                    x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
+            if pool is not None and not blk.block[blk.i_se].channel_only:
+                x = _concurrent_se(blk.block[blk.i_se], x, pool)          # SE over f / t (and c), aggregated: unfused plan
+            elif pool is not None:
                 se = blk.block[blk.i_se].conc_se_layers[0]
                 inv_s = 1.0 / (x.shape[2] * x.shape[3])
                 h = ops.linear(pool, se.fc1.weight, se.fc1.bias, ops.ACT_RELU, inv_s)
@@ -375,12 +461,18 @@ class MN(nn.Module):
                 fmaps.append(x)
         pooled = take(c_feat)
         S = x.shape[2] * x.shape[3]
-        y = _pw(x, W["last"], c_feat, ops.ACT_HSWISH, pool=pooled, write=return_fmaps)
+        need_map = return_fmaps or self.head_type == "multihead_attention_pooling"
+        y = _pw(x, W["last"], c_feat, ops.ACT_HSWISH, pool=pooled, write=need_map)
         if return_fmaps:
             fmaps.append(y)
-        fc1, fc2 = self.classifier[2], self.classifier[5]
-        h = ops.linear(pooled, fc1.weight, fc1.bias, ops.ACT_HSWISH, 1.0 / S)
-        logits = ops.linear(h, fc2.weight, fc2.bias, ops.ACT_NONE)
+        if self.head_type == "mlp":
+            fc1, fc2 = self.classifier[2], self.classifier[5]
+            h = ops.linear(pooled, fc1.weight, fc1.bias, ops.ACT_HSWISH, 1.0 / S)
+            logits = ops.linear(h, fc2.weight, fc2.bias, ops.ACT_NONE)
+        elif self.head_type == "fully_convolutional":
+            logits = ops.linear(pooled, W["fc_head"][0], W["fc_head"][1], ops.ACT_NONE, 1.0 / S)
+        else:
+            logits = self.classifier(y)
         if return_fmaps:
             return logits, fmaps
         return logits, pooled * (1.0 / S)

@@ -69,6 +69,17 @@ def dw_conv(x, w, bias, k, stride, act, pool=None):
     return y
 
 
+def dw_conv_dilated(x, w, bias, k, stride, dilation, act, pool=None):
+    B, C, F, T = x.shape
+    pad = (k - 1) // 2 * dilation
+    Fo = (F + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+    To = (T + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_dilated_fwd", _dev(x, "x"), _dev(w, "w"), _dev(bias, "bias"), y.data_ptr(), _opt(pool, "pool"),
+              B, C, F, T, Fo, To, k, stride, dilation, act, _stream())
+    return y
+
+
 def dw_conv_tf(x, in_a, in_b, in_act, w, bias, k, stride):
     """Depthwise conv of act_in(in_a[c] * x + in_b[c]) (evaluated on load), no output activation (train mode)."""
     B, C, F, T = x.shape

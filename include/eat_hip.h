@@ -72,6 +72,11 @@ int eat_dw_conv_fwd(const float* x, const float* w, const float* bias, float* y,
                     int B, int C, int F, int T, int Fo, int To, int k, int stride, int act,
                     eat_stream_t stream);
 
+/* The same with a dilation (models/mn/model.py:244-269 `dilated=True`; block_types.py:150: stride forced to 1, padding
+ * (k-1)/2*dilation): generic thread-per-output kernel, any odd k <= 7 / stride / dilation. */
+int eat_dw_conv_dilated_fwd(const float* x, const float* w, const float* bias, float* y, float* pool, int B, int C,
+                            int F, int T, int Fo, int To, int k, int stride, int dilation, int act, eat_stream_t stream);
+
 /* ---- pointwise 1x1 conv (GEMM): models/mn/block_types.py:138-147,167-171; mn/model.py:159-167
  * y[b] (Co,S) = act( W (Co,Ci) . (x[b] (Ci,S) * in_scale[b,:,None]) + bias[:,None] ) + res[b]
  * wp = W packed by eat_pw_prepack (BN scale folded in via row_scale), bias (Co);

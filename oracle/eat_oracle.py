@@ -83,14 +83,21 @@ _ROWS = [
 ]
 
 
-def block_table(width_mult=1.0, strides=(2, 2, 2, 2)):
-    """List of dicts (cin, k, cexp, cout, se, hs, stride) per inverted-residual block."""
+def block_table(width_mult=1.0, strides=(2, 2, 2, 2), reduced_tail=False, dilated=False):
+    """List of dicts (cin, k, cexp, cout, se, hs, stride, dil) per inverted-residual block; `reduced_tail` halves the
+    channels and `dilated` sets dilation 2 in the last three blocks (mn/model.py:244-269)."""
     adj = lambda c: make_divisible(c * width_mult, 8)
+    div, dil = (2 if reduced_tail else 1), (2 if dilated else 1)
     out = []
-    for cin, k, cexp, cout, se, hs, si in _ROWS:
+    for i, (cin, k, cexp, cout, se, hs, si) in enumerate(_ROWS):
+        tail = i >= 12
+        if tail:            # rows 13-15: (112, 5, 672, 160/div), (160/div, 5, 960/div, 160/div) x 2
+            cin = cin if i == 12 else cin // div
+            cexp = cexp if i == 12 else cexp // div
+            cout = cout // div
         out.append(dict(cin=adj(cin), k=k, cexp=adj(cexp), cout=adj(cout), se=se, hs=hs,
-                        stride=1 if si is None else strides[si]))
-    return out, adj(1280)
+                        stride=1 if si is None else strides[si], dil=dil if tail else 1))
+    return out, adj(1280 // div)
 
 
 def _act(x, hs):
@@ -146,12 +153,12 @@ class emulate_bf16_pointwise:
         PW_BF16 = self.old
 
 
-def _cna(sd, prefix, x, train, stats, k, stride, groups, act):
-    """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2) + BN + act."""
+def _cna(sd, prefix, x, train, stats, k, stride, groups, act, dil=1):
+    """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2*dilation) + BN + act."""
     if PW_BF16 and k == 1 and groups == 1:
         x = _PwBf16.apply(x, sd[prefix + ".0.weight"])
     else:
-        x = F.conv2d(x, sd[prefix + ".0.weight"], None, stride, (k - 1) // 2, 1, groups)
+        x = F.conv2d(x, sd[prefix + ".0.weight"], None, stride, (k - 1) // 2 * dil, dil, groups)
     x = _bn(sd, prefix + ".1", x, train, stats)
     if act == "hs":
         x = F.hardswish(x)
@@ -168,16 +175,37 @@ def _se(sd, prefix, x):
     return x * s[:, :, None, None]
 
 
-def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True):
+def _concurrent_se(sd, prefix, x, se_dims, se_agg):
+    """ConcurrentSEBlock (block_types.py:10-42) with SqueezeExcitation over dim d in {1: c, 2: f, 3: t} (:66-83): mean over
+    the other two dims -> fc1 / ReLU / fc2 / Sigmoid -> gate broadcast along d; gated copies combined by se_agg."""
+    outs = []
+    for i, d in enumerate(se_dims):
+        other = [k for k in (1, 2, 3) if k != d]
+        m = x.mean(dim=other, keepdim=True)
+        shape = m.shape
+        q = f"{prefix}.conc_se_layers.{i}"
+        z = F.relu(F.linear(m.squeeze(other[1]).squeeze(other[0]), sd[q + ".fc1.weight"], sd[q + ".fc1.bias"]))
+        g = torch.sigmoid(F.linear(z, sd[q + ".fc2.weight"], sd[q + ".fc2.bias"])).view(shape)
+        outs.append(g * x)
+    st = torch.stack(outs, dim=0)
+    return {"max": lambda t: t.max(dim=0)[0], "avg": lambda t: t.mean(dim=0), "add": lambda t: t.sum(dim=0),
+            "min": lambda t: t.min(dim=0)[0]}[se_agg](st)
+
+
+def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True, se_dims=(1,), se_agg="max"):
     """block_types.py:120-181: [expand] -> depthwise -> [SE] -> project (+ residual)."""
     inp, j = x, 0
     a = "hs" if c["hs"] else "re"
+    dil = c.get("dil", 1)
     if c["cexp"] != c["cin"]:
         x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, a)
         j += 1
-    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, c["k"], c["stride"], c["cexp"], a)
+    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, c["k"], 1 if dil > 1 else c["stride"], c["cexp"], a, dil)   # :150
     j += 1
-    if c["se"] and use_se:
+    if c["se"] and use_se and se_dims is not None and tuple(se_dims) != (1,):
+        x = _concurrent_se(sd, f"{prefix}.block.{j}", x, se_dims, se_agg)
+        j += 1
+    elif c["se"] and use_se and se_dims is not None:
         x = _se(sd, f"{prefix}.block.{j}.conc_se_layers.0", x)
         j += 1
     x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, None)
@@ -195,19 +223,47 @@ def _mlp_head(sd, x, train, drop_mask):
     return F.linear(h, sd["classifier.5.weight"], sd["classifier.5.bias"]), pooled
 
 
+def _fc_head(sd, x, train, stats):
+    """head_type='fully_convolutional' (mn/model.py:173-185): Conv2d 1x1 (no bias) -> BatchNorm2d (default eps 1e-5) ->
+    AdaptiveAvgPool2d((1,1)); features = pooled input (mn/model.py:220)."""
+    z = F.conv2d(x, sd["classifier.0.weight"])
+    w, b, rm, rv = (sd["classifier.1." + k] for k in ("weight", "bias", "running_mean", "running_var"))
+    z = F.batch_norm(z, rm.clone(), rv.clone(), w, b, train, 0.1, 1e-5)
+    return z.mean(dim=(2, 3)), x.mean(dim=(2, 3))
+
+
+def _attention_head(sd, x, num_heads=4, eps=1e-7):
+    """head_type='multihead_attention_pooling' (mn/attention_pooling.py:37-56)."""
+    xm = x.mean(dim=2).transpose(1, 2)                                        # (B, T, C)
+    b, n, _ = xm.shape
+    p = F.linear(xm, sd["classifier.subspace_proj.weight"], sd["classifier.subspace_proj.bias"])
+    out_dim = p.shape[-1] // (2 * num_heads)
+    p = p.reshape(b, n, 2, num_heads, out_dim).permute(2, 0, 3, 1, 4)
+    att, val = torch.clamp(torch.sigmoid(p[0]), eps, 1.0 - eps), p[1]
+    att = att / att.sum(dim=2, keepdim=True)
+    out = (att * val).sum(dim=2) * sd["classifier.head_weight"]
+    return out.sum(dim=1), x.mean(dim=(2, 3))
+
+
 def mn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), train=False, stats=None,
-               drop_mask=None, return_fmaps=False):
+               drop_mask=None, return_fmaps=False, head_type="mlp", se_dims=(1,), se_agg="max",
+               reduced_tail=False, dilated=False, num_heads=4):
     """x (B,1,F,T) -> (logits, pooled features) or (logits, fmaps)   (mn/model.py:212-231)."""
-    blocks, _ = block_table(width_mult, strides)
+    blocks, _ = block_table(width_mult, strides, reduced_tail, dilated)
     fmaps = []
     x = _cna(sd, "features.0", x, train, stats, 3, 2, 1, "hs")
     fmaps.append(x)
     for i, c in enumerate(blocks):
-        x = _inverted_residual(sd, f"features.{i + 1}", x, c, train, stats)
+        x = _inverted_residual(sd, f"features.{i + 1}", x, c, train, stats, se_dims=se_dims, se_agg=se_agg)
         fmaps.append(x)
     x = _cna(sd, "features.16", x, train, stats, 1, 1, 1, "hs")
     fmaps.append(x)
-    logits, pooled = _mlp_head(sd, x, train, drop_mask)
+    if head_type == "mlp":
+        logits, pooled = _mlp_head(sd, x, train, drop_mask)
+    elif head_type == "fully_convolutional":
+        logits, pooled = _fc_head(sd, x, train, stats)
+    else:
+        logits, pooled = _attention_head(sd, x, num_heads)
     return (logits, fmaps) if return_fmaps else (logits, pooled)
 
 

@@ -166,9 +166,49 @@ def golden_model(kind, mel, width, tag, temp_eval=1.0, temp_train=30.0):
           "absmax", float(logits.abs().max()), "train loss", loss.item())
 
 
+VARIANTS = {   # non-default model variants: get_model kwargs of the reference
+    "fc": dict(head_type="fully_convolutional"),
+    "fc_s2211": dict(head_type="fully_convolutional", strides=(2, 2, 1, 1)),
+    "att": dict(head_type="multihead_attention_pooling", multihead_attention_heads=4),
+    # (se over 'f' cannot run in the reference: block_types.py:75 squeezes dim 2 twice, which leaves (B, 1, F, 1) for the
+    #  frequency gate and fc1 then sees a last dimension of 1 - RuntimeError; 'c' and 't' work)
+    "se_ct_max": dict(se_dims="ct", se_agg="max", input_dim_t=300),
+    "se_t_avg": dict(se_dims="t", se_agg="avg", input_dim_t=300),
+    "se_ct_min": dict(se_dims="ct", se_agg="min", input_dim_t=300),
+    "se_ct_add": dict(se_dims="ct", se_agg="add", input_dim_t=300),
+    "se_none": dict(se_dims="none"),
+    "dilated_reduced": dict(dilated=True, reduced_tail=True),
+}
+
+
+def golden_variants(mel):
+    """Eval logits / features of the reference for every variant on 3 s clips (T = 300 frames), weights from
+    synth.synth_state over the reference model's own state_dict shapes, BN statistics calibrated by the reference."""
+    res = {}
+    with torch.no_grad():
+        x_cal = mel(synth.calibration_clips(96000)).unsqueeze(1)
+        x = mel(synth.parity_clips(96000, seed=41)).unsqueeze(1)
+    for tag, kw in VARIANTS.items():
+        model = quiet(get_mn, width_mult=1.0, **kw)
+        sd = synth.synth_state(synth.shapes_of(model), seed=3)
+        model.load_state_dict(sd, strict=True)
+        calibrate_reference(model, x_cal)
+        model.eval()
+        with torch.no_grad():
+            logits, feats = model(x)
+        res[f"{tag}/logits"], res[f"{tag}/features"] = logits.numpy(), feats.numpy()
+        res[f"{tag}/n_state"] = np.int64(len(model.state_dict()))
+        for k, v in bn_buffers(model).items():
+            res[f"{tag}/bn/{k}"] = v.numpy()
+        print("variant", tag, "logits absmax", float(logits.abs().max()), "std", float(logits.std()))
+    np.savez_compressed(os.path.join(OUT, "mn_variants_ref.npz"), **res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     mel = golden_mel()
-    golden_model("mn", mel, 1.0, "mn10")
-    golden_model("dymn", mel, 1.0, "dymn10")
+    if "--variants-only" not in sys.argv:
+        golden_model("mn", mel, 1.0, "mn10")
+        golden_model("dymn", mel, 1.0, "dymn10")
+    golden_variants(mel)

@@ -88,6 +88,12 @@ def dymn_shapes(width_mult=1.0, num_classes=527, K=4):
     return sh
 
 
+def shapes_of(module):
+    """name -> shape of a module's state_dict: lets `synth_state` fill ANY variant of the model (the reference's in
+    make_golden.py, the product's in the tests) with the same seeded weights - identical keys and shapes required."""
+    return OrderedDict((k, tuple(v.shape)) for k, v in module.state_dict().items())
+
+
 def n_params(shapes):
     """Learnable parameter count (buffers excluded), to compare with README.md:94-113."""
     skip = ("running_mean", "running_var", "num_batches_tracked", "lambdas", "init_v")
@@ -111,6 +117,8 @@ def synth_state(shapes, seed=0):
             sd[name] = torch.tensor([1.0, 1.0, 0.5, 0.5])
         elif leaf == "init_v":
             sd[name] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+        elif leaf == "head_weight":                           # attention-pooling head weights (1, heads, 1)
+            sd[name] = torch.from_numpy(rng.uniform(0.1, 0.4, shape).astype(np.float32))
         elif len(shape) == 1 and leaf == "weight":            # BN gamma
             sd[name] = torch.from_numpy(rng.uniform(0.5, 1.5, shape).astype(np.float32))
         elif leaf == "bias":

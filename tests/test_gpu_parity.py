@@ -399,3 +399,62 @@ def test_pw_conv_bf16(B, Ci, Co, F_, T, act, se, res, split, tol):
         if res:
             ref2 = ref2 + r
         _close(got, ref2, 3e-6, "pw bf16 vs bf16-rounded operands")
+
+
+def test_ensemble_averages_member_logits(golden_dir):
+    """models/ensemble.py:8-22 (EnsemblerModel): mean of the members' logits, returned twice."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin"))
+    cwd = os.getcwd()
+    from efficientat_amd.dymn import get_model as get_dymn
+    sd1 = synth.synth_state(synth.mn_shapes(0.4), seed=1)
+    sd2 = synth.synth_state(synth.dymn_shapes(0.4), seed=2)
+    x = O.mel_forward(synth.parity_clips(96000, seed=9)[:3]).unsqueeze(1)
+    sd1 = synth.calibrate(sd1, lambda s, xm, **k: O.mn_forward(s, xm, width_mult=0.4, **k), x)
+    sd2 = synth.calibrate(sd2, lambda s, xm, **k: O.dymn_forward(s, xm, width_mult=0.4, **k), x)
+    m1, m2 = _quiet(get_model, width_mult=0.4), _quiet(get_dymn, width_mult=0.4)
+    m1.load_state_dict(sd1)
+    m2.load_state_dict(sd2)
+    for m in m2.modules():
+        if hasattr(m, "temperature"):
+            m.temperature = 1.0
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "eat_dropin_ensemble", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin", "models", "ensemble.py"))
+    ens_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ens_mod)
+    ens = ens_mod.EnsemblerModel([m1, m2]).to(DEV).eval()
+    with torch.no_grad():
+        r1, _ = O.mn_forward(sd1, x, width_mult=0.4)
+        r2, _ = O.dymn_forward(sd2, x, width_mult=0.4, temperature=1.0)
+        a, b = ens(x.to(DEV))
+    ref = (r1 + r2) / 2
+    assert torch.equal(a, b)
+    assert float((a.cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+# ---------------------------------------------------------------- non-default model variants (SURVEY 8f row f4)
+from tests.test_oracle_golden import VARIANTS, variant_state  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_mn_variants_match_reference_and_oracle(tag, golden_dir):
+    """head_type fully_convolutional / multihead_attention_pooling (models/mn/model.py:170-185), SE over c / t with
+    max / avg / min / add aggregation (block_types.py:10-42), se_dims='none', dilated + reduced_tail (:244-269): eval
+    logits and features vs the stored outputs of the unmodified reference and vs the oracle."""
+    model, sd, g = variant_state(tag, golden_dir)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    x = O.mel_forward(synth.parity_clips(96000, seed=41)).unsqueeze(1)
+    with torch.no_grad():
+        ref, ref_f = O.mn_forward(sd, x, **VARIANTS[tag][1])
+        got, feat = model(x.to(DEV))
+    scale = max(1.0, float(ref.abs().max()))
+    assert got.shape == ref.shape and feat.shape == ref_f.shape
+    assert float((got.cpu() - ref).abs().max()) < 1e-3 * scale
+    assert np.abs(got.cpu().numpy() - g[f"{tag}/logits"]).max() < 1e-3 * scale
+    assert np.abs(feat.cpu().numpy() - g[f"{tag}/features"]).max() < 1e-3 * max(1.0, np.abs(g[f"{tag}/features"]).max())
+    if tag != "se_none":
+        model.train()
+        with pytest.raises(NotImplementedError):
+            model(x.to(DEV))          # the training plan covers the default configuration only: fails loudly

@@ -139,3 +139,45 @@ def test_dymn10_oracle_matches_reference(golden_dir):
     sd, x = _check_model("dymn", g, fwd_e, 2e-4)
     # attention-logit grads at T=30 are cancellation-dominated (norm 1e-4): looser bound
     _check_train("dymn", g, sd, x, fwd_t, gtol=3e-2)
+
+
+# ---------------------------------------------------------------- non-default model variants
+VARIANTS = {   # tag -> (product get_model kwargs, oracle mn_forward kwargs); tags = oracle/make_golden.py VARIANTS
+    "fc": (dict(head_type="fully_convolutional"), dict(head_type="fully_convolutional")),
+    "fc_s2211": (dict(head_type="fully_convolutional", strides=(2, 2, 1, 1)),
+                 dict(head_type="fully_convolutional", strides=(2, 2, 1, 1))),
+    "att": (dict(head_type="multihead_attention_pooling", multihead_attention_heads=4), dict(head_type="att", num_heads=4)),
+    "se_ct_max": (dict(se_dims="ct", se_agg="max", input_dim_t=300), dict(se_dims=(1, 3), se_agg="max")),
+    "se_t_avg": (dict(se_dims="t", se_agg="avg", input_dim_t=300), dict(se_dims=(3,), se_agg="avg")),
+    "se_ct_min": (dict(se_dims="ct", se_agg="min", input_dim_t=300), dict(se_dims=(1, 3), se_agg="min")),
+    "se_ct_add": (dict(se_dims="ct", se_agg="add", input_dim_t=300), dict(se_dims=(1, 3), se_agg="add")),
+    "se_none": (dict(se_dims="none"), dict(se_dims=None)),
+    "dilated_reduced": (dict(dilated=True, reduced_tail=True), dict(dilated=True, reduced_tail=True)),
+}
+
+
+def variant_state(tag, golden_dir):
+    """(product model, seeded state with the reference-calibrated BN buffers, golden arrays) of one variant."""
+    import contextlib
+    import io
+    from efficientat_amd.mn import get_model
+    g = np.load(os.path.join(golden_dir, "mn_variants_ref.npz"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = get_model(width_mult=1.0, **VARIANTS[tag][0])
+    sd = synth.synth_state(synth.shapes_of(model), seed=3)
+    assert len(sd) == int(g[f"{tag}/n_state"])                  # same state_dict layout as the reference's variant
+    for k in g.files:
+        if k.startswith(f"{tag}/bn/"):
+            sd[k[len(tag) + 4:]] = torch.from_numpy(g[k])
+    return model, sd, g
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_oracle_variants_match_reference(tag, golden_dir):
+    _, sd, g = variant_state(tag, golden_dir)
+    x = O.mel_forward(synth.parity_clips(96000, seed=41)).unsqueeze(1)
+    with torch.no_grad():
+        logits, feats = O.mn_forward(sd, x, **VARIANTS[tag][1])
+    ref = g[f"{tag}/logits"]
+    assert np.abs(logits.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(feats.numpy() - g[f"{tag}/features"]).max() < 2e-5 * max(1.0, np.abs(g[f"{tag}/features"]).max())

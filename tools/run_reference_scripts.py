@@ -96,6 +96,9 @@ def main():
             ("ex_audioset.py", ["--cuda", "--batch_size", "31", "--num_workers", "0"]),               # evaluate(): fp16 autocast
             ("ex_audioset.py", ["--train", "--cuda", "--batch_size", "8", "--num_workers", "0", "--n_epochs", "1",
                                 "--epoch_len", "32", "--pretrained"])]
+    if os.path.exists(os.path.join(a.ref, "windowed_inference.py")):
+        runs.append(("windowed_inference.py", ["--cuda", "--audio_path", "resources/synthetic_clip.wav", "--window_size", "4.0",
+                                               "--hop_length", "3.0"]))
     rc_all = 0
     for script, argv in runs:
         rc, out, err = run_script(a.ref, script, argv, work, env)
