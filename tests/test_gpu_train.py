@@ -145,7 +145,7 @@ def test_mn10_train_step_matches_oracle(golden_dir):
     assert float((logits.detach().cpu() - logits_ref.detach()).abs().max()) < 1e-3
     assert np.abs(logits.detach().cpu().numpy() - g["train_logits"]).max() < 1e-3
     gmax = max(float(v.grad.norm()) for k, v in sdr.items() if getattr(v, "grad", None) is not None)
-    # Measured on MI355X (scratch/diag_train.py): vs an fp64 evaluation the CPU fp32 oracle itself is
+    # Measured on MI355X (a per-tensor diagnostic): vs an fp64 evaluation the CPU fp32 oracle itself is
     # off by 0.45 % median / 1.0 % max per tensor (activation-kink flips), the HIP path by 0.65 % / 1.9 %
     # - the same error class.  Bound: 3 % per tensor, 1 % median.
     bad, rels = [], []

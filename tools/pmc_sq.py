@@ -1,7 +1,8 @@
 """Summarise rocprofv3 --pmc SQ_* / GRBM_* passes: per kernel (largest-grid launches only), mean counter value per
 launch plus the derived figures north_star asks for:
 
-  mfma_util      SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)      (gfx94x MfmaUtil formula)
+  mfma_util      SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)   (busy cycles of all 1024 SIMDs over
+                 the kernel's cycles; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs - checked: 32 cycles x SQ_INSTS_MFMA)
   wait_frac      SQ_WAIT_ANY / SQ_WAVE_CYCLES        waves parked in s_waitcnt / s_barrier
   stall_frac     SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   issue stalls
   active_frac    SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
@@ -38,7 +39,7 @@ def main(out_json, *paths):
                 if c in d:
                     d[key] = round(d[c] / wc, 4)
         if d.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
-            d["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 256 * 4), 4)
+            d["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4), 4)   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         out[sym] = d
     json.dump({"note": "mean per launch over the largest-grid launches of each kernel; see tools/pmc_sq.py for the derived figures",
                "kernels": out}, open(out_json, "w"), indent=1)

@@ -1,4 +1,5 @@
-import sys, io, contextlib, collections; sys.path.insert(0,'.')
+"""Per-entry-point HIP-event profile of one eager mn10 training step: python tools/prof_train.py [batch]  (GPU diagnostic)."""
+import sys, io, contextlib, collections; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch, torch.nn.functional as F
 import bench
 from efficientat_amd import _lib
