@@ -60,6 +60,28 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
+// Small planes (late stages: 8x63, 4x32 positions): with one block per plane the 2 x B x C fp64 atomics on C addresses
+// are the whole cost (~50 us per launch for 20 MB tensors, 46 launches per step).  Here a block owns PPB samples of ONE
+// channel: the same coalesced float4 reads, PPB times fewer atomics per channel.
+__global__ __launch_bounds__(256) void bn_stats_multi_kernel(const float* __restrict__ z, int B, int C, int S4, int PPB,
+                                                             double* __restrict__ sums) {
+  __shared__ float s_red[16];
+  const int c = blockIdx.x, b0 = blockIdx.y * PPB;
+  const int nb = (B - b0) < PPB ? (B - b0) : PPB;
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = threadIdx.x; e < nb * S4; e += 256) {
+    const int bl = e / S4, i = e - bl * S4;
+    const float4 v = *reinterpret_cast<const float4*>(z + ((size_t)(b0 + bl) * C + c) * (4 * S4) + 4 * i);
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  block_sum2(s1, s2, s_red);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, (double)s1);
+    atomicAdd(sums + C + c, (double)s2);
+  }
+}
+
 // ---- finalize: batch mean / biased var -> affine (a, b), saved (mean, invstd), running buffers --
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -164,6 +186,37 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   }
 }
 
+// small planes: one block per (channel, PPB samples), see bn_stats_multi_kernel
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ a,
+    const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gscale, const float* __restrict__ gadd, int B, int C, int S4, int PPB,
+    double* __restrict__ sums) {
+  __shared__ float s_red[16];
+  const int c = blockIdx.x, b0 = blockIdx.y * PPB;
+  const int nb = (B - b0) < PPB ? (B - b0) : PPB;
+  const float av = a[c], bv = b[c], mu = mean[c], is = invstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = threadIdx.x; e < nb * S4; e += 256) {
+    const int bl = e / S4, i = e - bl * S4;
+    const size_t plane = (size_t)(b0 + bl) * C + c;
+    const float gs = gscale ? gscale[plane] : 1.0f, ga = gadd ? gadd[plane] : 0.0f;
+    const float4 d = *reinterpret_cast<const float4*>(dy + plane * (4 * S4) + 4 * i);
+    const float4 v = *reinterpret_cast<const float4*>(z + plane * (4 * S4) + 4 * i);
+    const float g0 = grad_pre<ACT>(d.x, v.x, av, bv, gs, ga), g1 = grad_pre<ACT>(d.y, v.y, av, bv, gs, ga);
+    const float g2 = grad_pre<ACT>(d.z, v.z, av, bv, gs, ga), g3 = grad_pre<ACT>(d.w, v.w, av, bv, gs, ga);
+    s1 += (g0 + g1) + (g2 + g3);
+    s2 += (g0 * (v.x - mu) + g1 * (v.y - mu)) + (g2 * (v.z - mu) + g3 * (v.w - mu));
+  }
+  s2 *= is;
+  block_sum2(s1, s2, s_red);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, (double)s1);
+    atomicAdd(sums + C + c, (double)s2);
+  }
+}
+
 // ---- backward pass 2: dz = a * (g - sum_g/N - xhat * sum_gx/N) ----------------------------------------------
 template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
@@ -252,17 +305,20 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restric
                                                           const float* __restrict__ res, float* __restrict__ dx,
                                                           int n_planes, int C, int F, int T, int Fo, int To,
                                                           int per_plane_w) {
+  // Polyphase form: dx[i][j] = sum over the taps (u, v) with (i + P - u), (j + P - v) even of w[u][v] dz[(i+P-u)/2][(j+P-v)/2].
+  // The column parity of a thread is fixed, so its tap columns v = v0 + 2q are selected ONCE into registers (the round-1
+  // kernel indexed the tap array with run-time (u, v) inside the row loop); the rows are walked in pairs (2m, 2m+1), whose
+  // tap rows are compile-time constants, over a sliding window of dz rows m-1, m, m+1 - every dz row is loaded once per
+  // thread, one row ahead of its use.  Writes are coalesced 256-byte row segments per wave.
   constexpr int P = (K - 1) / 2;
   constexpr int NV = (K + 1) / 2;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int plane = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (plane >= n_planes || j >= T) return;
   const int c = plane % C;
-  float wr[K * K];
-#pragma unroll
-  for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)(per_plane_w ? plane : c) * K * K + i];
-  // taps of this column: v = v0 + 2q with (j + P - v) even
+  const float* wp = w + (size_t)(per_plane_w ? plane : c) * K * K;
   const int v0 = (j + P) & 1;
+  float ws[K][NV];
   int jo[NV];
   bool jok[NV];
 #pragma unroll
@@ -271,29 +327,41 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restric
     jo[q] = (j + P - v) >> 1;
     jok[q] = v < K && (j + P - v) >= 0 && jo[q] < To;
     if (!jok[q]) jo[q] = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) ws[u][q] = v < K ? wp[u * K + v] : 0.0f;
   }
   const float* g = dz + (size_t)plane * Fo * To;
+  auto load_row = [&](int io, float (&r)[NV]) {
+    const bool rok = io >= 0 && io < Fo;
+    const float* row = g + (size_t)(rok ? io : 0) * To;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) r[q] = (rok && jok[q]) ? row[jo[q]] : 0.0f;
+  };
   const size_t base = (size_t)plane * F * T + j;
-  for (int i = 0; i < F; ++i) {
-    const int u0 = (i + P) & 1;
-    float acc = res ? res[base + (size_t)i * T] : 0.0f;
+  float rm[NV], r0[NV], r1[NV], r2[NV];        // dz rows m-1, m, m+1 and the prefetched m+2
 #pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      const int u = u0 + 2 * p;
-      const int ii = i + P - u;
-      const int io = ii >> 1;
-      if (u < K && ii >= 0 && io < Fo) {
-        const float* row = g + (size_t)io * To;
+  for (int q = 0; q < NV; ++q) rm[q] = 0.0f;
+  load_row(0, r0);
+  load_row(1, r1);
+  for (int m = 0; 2 * m < F; ++m) {
+    load_row(m + 2, r2);
+    const int ie = 2 * m, io_ = 2 * m + 1;
+    float ae = res ? res[base + (size_t)ie * T] : 0.0f;
+    float ao = (res && io_ < F) ? res[base + (size_t)io_ * T] : 0.0f;
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-          const int v = v0 + 2 * q;
-          const float gv = jok[q] ? row[jo[q]] : 0.0f;
-          const float wv = (v < K) ? wr[(u < K ? u : 0) * K + (v < K ? v : 0)] : 0.0f;
-          acc = fmaf(wv, gv, acc);
-        }
+    for (int q = 0; q < NV; ++q) {
+      if constexpr (K == 3) {
+        ae = fmaf(ws[1][q], r0[q], ae);                                 // row 2m:   u = 1 -> dz row m
+        ao = fmaf(ws[0][q], r1[q], fmaf(ws[2][q], r0[q], ao));          // row 2m+1: u = 0 -> m+1, u = 2 -> m
+      } else {
+        ae = fmaf(ws[0][q], r1[q], fmaf(ws[2][q], r0[q], fmaf(ws[4][q], rm[q], ae)));   // u = 0, 2, 4 -> m+1, m, m-1
+        ao = fmaf(ws[1][q], r1[q], fmaf(ws[3][q], r0[q], ao));                          // u = 1, 3    -> m+1, m
       }
     }
-    dx[base + (size_t)i * T] = acc;
+    dx[base + (size_t)ie * T] = ae;
+    if (io_ < F) dx[base + (size_t)io_ * T] = ao;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { rm[q] = r0[q]; r0[q] = r1[q]; r1[q] = r2[q]; }
   }
 }
 
@@ -744,8 +812,20 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
 
 #define EAT_PLANES_GRID(B, C) dim3((unsigned)((B) * (C)))
 
+// samples per block of the small-plane reducers: ~2048 blocks; 0 = use the one-block-per-plane kernels
+static int bn_multi_ppb(int B, int C, int S) {
+  if ((S & 3) != 0 || S > 2048 || (long long)B * C <= 4096) return 0;
+  long long ppb = ((long long)B * C + 2047) / 2048;
+  return (int)(ppb > B ? B : ppb);
+}
+
 extern "C" int eat_bn_stats(const float* z, int B, int C, int S, double* sums, eat_stream_t stream) {
   eat::clear_stale_error();
+  if (const int ppb = bn_multi_ppb(B, C, S)) {
+    hipLaunchKernelGGL(bn_stats_multi_kernel, dim3(C, (B + ppb - 1) / ppb), dim3(256), 0, (hipStream_t)stream, z, B, C, S >> 2,
+                       ppb, sums);
+    return eat::check_launch("eat_bn_stats");
+  }
   hipLaunchKernelGGL(bn_stats_kernel, EAT_PLANES_GRID(B, C), dim3(S >= 1024 ? 256 : 64), 0, (hipStream_t)stream, z, C, S,
                      sums);
   return eat::check_launch("eat_bn_stats");
@@ -775,6 +855,11 @@ extern "C" int eat_bn_act_bwd_reduce(const float* dy, const float* z, const floa
                                      int B, int C, int S, int act, double* sums, eat_stream_t stream) {
   eat::clear_stale_error();
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_reduce: bad act %d", act);
+  if (const int ppb = bn_multi_ppb(B, C, S)) {
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_multi_kernel<ACT>), dim3(C, (B + ppb - 1) / ppb), dim3(256), 0,
+                                             (hipStream_t)stream, dy, z, a, b, mean, invstd, gscale, gadd, B, C, S >> 2, ppb, sums));
+    return eat::check_launch("eat_bn_act_bwd_reduce");
+  }
   const dim3 blk(S >= 1024 ? 256 : 64);
   EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT>), EAT_PLANES_GRID(B, C), blk, 0,
                                            (hipStream_t)stream, dy, z, a, b, mean, invstd, gscale, gadd, C, S, sums));

@@ -36,7 +36,8 @@ def _rel(got, ref):
     return float((got - ref).norm() / max(1e-30, float(ref.norm())))
 
 
-@pytest.mark.parametrize("B,C,F_,T,act", [(4, 16, 64, 500, 2), (3, 72, 16, 125, 1), (5, 40, 8, 63, 0), (2, 6, 3, 5, 2)])
+@pytest.mark.parametrize("B,C,F_,T,act", [(4, 16, 64, 500, 2), (3, 72, 16, 125, 1), (5, 40, 8, 63, 0), (2, 6, 3, 5, 2),
+                                         (48, 96, 4, 32, 2), (70, 80, 8, 63, 1)])     # small planes, many of them: multi-sample reducers
 def test_bn_act_forward_backward(B, C, F_, T, act):
     z = _rand(B, C, F_, T, seed=1, scale=2.0) + _rand(1, C, 1, 1, seed=2)
     gamma, beta = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5, _rand(C, seed=4, scale=0.3)
@@ -66,7 +67,8 @@ def test_bn_act_forward_backward(B, C, F_, T, act):
 
 
 @pytest.mark.parametrize("B,C,F_,T,k,s", [(2, 16, 64, 500, 3, 1), (2, 24, 32, 250, 5, 2), (3, 40, 16, 125, 3, 2),
-                                          (3, 48, 8, 63, 5, 1), (2, 5, 7, 9, 5, 2), (4, 96, 4, 32, 5, 1)])
+                                          (3, 48, 8, 63, 5, 1), (2, 5, 7, 9, 5, 2), (4, 96, 4, 32, 5, 1),
+                                          (2, 64, 64, 500, 3, 2), (3, 9, 33, 71, 3, 2), (2, 7, 8, 63, 5, 2), (1, 3, 1, 2, 3, 2)])
 def test_dw_conv_gradients(B, C, F_, T, k, s):
     x = _rand(B, C, F_, T, seed=1).requires_grad_(True)
     w = _rand(C, 1, k, k, seed=2, scale=0.3).requires_grad_(True)

@@ -1,0 +1,35 @@
+"""Per-entry-point HIP-event profile of one eager dymn20 training step (GPU diagnostic): python tools/prof_dymn.py [batch]"""
+import sys, os, collections, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+import bench
+from efficientat_amd import _lib
+dev = torch.device('cuda:0')
+mel, _ = bench.build_model(dev)
+model = bench.make_train_model(os.environ.get("MODEL", "dymn20"), dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+wave = (0.1 * torch.randn(B, 320000, device=dev)).clamp_(-1, 1)
+y = (torch.rand(B, 527, device=dev) < 0.005).float()
+opt = torch.optim.Adam(model.parameters(), lr=8e-4, fused=True)
+model.train(); mel.train()
+def tstep():
+    opt.zero_grad(set_to_none=True)
+    logits, _ = model(mel(wave).unsqueeze(1)); loss = F.binary_cross_entropy_with_logits(logits, y); loss.backward(); opt.step()
+for _ in range(2): tstep()
+torch.cuda.synchronize()
+real = _lib.call; rec = []
+def traced(name, *a):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); real(name, *a); e1.record(); rec.append((name, a, e0, e1))
+_lib.call = traced
+s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); s0.record(); tstep(); s1.record(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+_lib.call = real
+agg = collections.defaultdict(lambda: [0, 0.0])
+for n, a, e0, e1 in rec:
+    agg[n][0] += 1; agg[n][1] += e0.elapsed_time(e1)
+tot = sum(v[1] for v in agg.values())
+print(f'wall {wall*1e3:.1f} ms, GPU span {s0.elapsed_time(s1):.1f} ms, sum of HIP-lib kernels {tot:.1f} ms (rest = torch ops + gaps), launches {len(rec)}')
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]): print(f'{n:28s} {c:4d} {t:8.2f} ms')
+top = sorted(rec, key=lambda r: -r[2].elapsed_time(r[3]))[:16]
+for n, a, e0, e1 in top: print(f'  {n:26s} {e0.elapsed_time(e1)*1e3:8.1f} us', [v for v in a if isinstance(v, int) and abs(v) < 10**7])
