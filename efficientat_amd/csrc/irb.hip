@@ -120,7 +120,8 @@ __device__ __forceinline__ void dw_finish(const DwAcc<NT>& a, f32x4 (&d)[NT]) {
 //   log-mel (lane (k, n): tap 4 ks + k of stem column n, zero outside the image through the buffer range check); the
 //   residual (= the stem output) is the middle row of the register window, in the accumulator layout already.
 //   F, T (a.F, a.T) are then the STEM plane, a.Fm / a.Tm the log-mel plane; ACT_E = Hardswish.
-template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false>
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false,
+          bool SWP = false>
 __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
   static_assert(!FRONT || (K == 3 && S == 1 && NKS == 3 && MTI == 1 && PROJ), "front = stem + 3x3/s1 block with project");
   constexpr int kNT = NT;
@@ -340,6 +341,15 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) v
             }
           }
       }
+      // SWP: the expand MFMAs of chunk c + 1 are issued BEFORE the depthwise arithmetic of chunk c (one chunk of software
+      // pipelining): on one SIMD a wave's VALU and MFMA instructions only overlap when they are interleaved in program
+      // order, and hipcc otherwise emits [6-12 MFMA][~60 VALU][8 MFMA] per chunk
+      f32x4 epipe[SWP ? S : 1][SWP ? TI : 1];
+      if constexpr (SWP) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < S; ++j) expand(c0 < MT ? c0 : MT - 1, xb[j], S * i - P_ + KW + j, epipe[j]);
+      }
 #pragma unroll
       for (int c = 0; c < MTI; ++c) {
         const bool c_ok = c0 + c < MT;       // a partial last group re-does chunk MT - 1 with its stores masked
@@ -348,8 +358,20 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) v
         // registers for 5 chunks) out of the row loop and spill; they are re-read per chunk instead (LDS has the bandwidth)
         asm volatile("" ::: "memory");
         f32x4 enew[S][TI];
+        if constexpr (SWP) {
 #pragma unroll
-        for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
+          for (int j = 0; j < S; ++j)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) enew[j][ti] = epipe[j][ti];
+          if (c + 1 < MTI) {
+            const int cn = c0 + c + 1 < MT ? c0 + c + 1 : MT - 1;
+#pragma unroll
+            for (int j = 0; j < S; ++j) expand(cn, xb[j], S * i - P_ + KW + j, epipe[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
+        }
         if constexpr (!PF) {
           if (c == MTI - 1 && i + 1 < i1) load_rows(i + 1);   // the B operands are free: next row's loads fly from here
         }
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) v
   }
 }
 
-template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF>
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, bool SWP = false>
 int launch_irb(IrbArgs a, hipStream_t s) {
   constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * NT - 2, VO = UHI - ULO + 1;
   a.MT = (a.Cexp + 15) / 16;
@@ -466,7 +488,7 @@ int launch_irb(IrbArgs a, hipStream_t s) {
   a.n_items = (int)items;
   const size_t smem = sizeof(float) * ((size_t)NKS * a.MT * 64 + (size_t)a.MT * K * K * 16 + 2 * (size_t)a.MT * 16 +
                                        (PROJ ? (size_t)a.MT * 4 * MTO * 64 + MTO * 16 : 0));
-  auto kern = irb_kernel<K, S, NKS, NT, MTI, MTO, ACT, PROJ, PF>;
+  auto kern = irb_kernel<K, S, NKS, NT, MTI, MTO, ACT, PROJ, PF, ACT, false, SWP>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "irb: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
@@ -539,14 +561,19 @@ int irb_try(const float* x, const float* wp_e, const float* bias_e, const float*
   constexpr int R = EAT_ACT_RELU;
   if (proj) {
     if (k == 3 && stride == 2 && Cin == 16 && MT == 4 && MTO == 2)
-      return var == 1 ? launch_irb<3, 2, 4, 1, 4, 2, R, true, true>(a, s) : launch_irb<3, 2, 4, 2, 4, 2, R, true, false>(a, s);
+      return var == 3 ? launch_irb<3, 2, 4, 1, 4, 2, R, true, true, true>(a, s)
+           : var == 1 ? launch_irb<3, 2, 4, 1, 4, 2, R, true, true>(a, s) : launch_irb<3, 2, 4, 2, 4, 2, R, true, false>(a, s);
     if (k == 3 && stride == 1 && Cin == 24 && MT == 5 && MTO == 2)
-      return var == 1 ? launch_irb<3, 1, 6, 1, 5, 2, R, true, true>(a, s)
+      return var == 3 ? launch_irb<3, 1, 6, 1, 5, 2, R, true, true, true>(a, s)
+           : var == 1 ? launch_irb<3, 1, 6, 1, 5, 2, R, true, true>(a, s)
            : var == 2 ? launch_irb<3, 1, 6, 2, 5, 2, R, true, true>(a, s) : launch_irb<3, 1, 6, 2, 5, 2, R, true, false>(a, s);
+    // (mn10 block 7 - 40 -> 240 -> 80, 3x3 / stride 2, Hardswish - as <3, 2, 10, 1, 15, 5>: the window of 15 chunks plus the
+    //  project accumulators need 256 VGPRs + 64 spilled registers; not instantiated)
     return 1;
   }
   if (k == 5 && stride == 2 && Cin == 24)
-    return (var == 1 && MT == 5) ? launch_irb<5, 2, 6, 1, 5, 1, R, false, false>(a, s)
+    return (var == 3 && MT == 5) ? launch_irb<5, 2, 6, 1, 5, 1, R, false, false, true>(a, s)
+         : (var == 1 && MT == 5) ? launch_irb<5, 2, 6, 1, 5, 1, R, false, false>(a, s)
          : var == 2 ? launch_irb<5, 2, 6, 1, 1, 1, R, false, true>(a, s) : launch_irb<5, 2, 6, 2, 1, 1, R, false, false>(a, s);
   if (k == 3 && stride == 2 && Cin == 16) return launch_irb<3, 2, 4, 2, 1, 1, R, false, false>(a, s);
   if (k == 3 && stride == 1 && Cin == 24) return launch_irb<3, 1, 6, 2, 1, 1, R, false, false>(a, s);
