@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .mn import BN_EPS, BN_MOMENTUM, _FoldCache, _conv_bn_act, _fold
+from .mn import BN_EPS, BN_MOMENTUM, InvertedResidual, _FoldCache, _conv_bn_act, _fold, fold_block, fold_front, run_block
 from .utils import cnn_out_size, make_divisible
 
 model_url = "https://github.com/fschmid56/EfficientAT/releases/download/v0.0.1/"
@@ -186,7 +186,9 @@ class DyMN(nn.Module):
         self.layers = nn.ModuleList()
         for cnf in inverted_residual_setting:
             if not cnf.use_dy_block:
-                raise NotImplementedError("use_dy_blocks='replace_se' is not on the HIP path yet")
+                # use_dy_blocks="replace_se": a plain SE-less inverted residual (models/dymn/model.py:102-103)
+                self.layers.append(InvertedResidual(cnf, None))
+                continue
             self.layers.append(DY_Block(cnf, context_ratio=context_ratio, max_context_size=max_context_size,
                                         min_context_size=min_context_size, dyrelu_k=dyrelu_k, dyconv_k=dyconv_k,
                                         no_dyrelu=no_dyrelu, no_dyconv=no_dyconv, no_ca=no_ca,
@@ -219,13 +221,19 @@ class DyMN(nn.Module):
     def _fold_sources(self):
         return [t for m in self.modules() if isinstance(m, nn.BatchNorm2d)
                 for t in (m.weight, m.bias, m.running_mean, m.running_var)] + \
-               [self.in_c[0].weight, self.out_c[0].weight] + [blk.context_gen.joint_conv.weight for blk in self.layers]
+               [self.in_c[0].weight, self.out_c[0].weight] + \
+               [blk.context_gen.joint_conv.weight for blk in self.layers if isinstance(blk, DY_Block)] + \
+               [m.weight for blk in self.layers if isinstance(blk, InvertedResidual) for m in blk.modules()
+                if isinstance(m, nn.Conv2d)]
 
     def _build_folded(self):
         out = {}
         s, b = _fold(self.in_c[0], self.in_c[1])
         out["stem"] = ((self.in_c[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, 9).contiguous(), b.contiguous())
         for i, blk in enumerate(self.layers):
+            if isinstance(blk, InvertedResidual):
+                out[i] = fold_block(blk)
+                continue
             d = {}
             cg = blk.context_gen
             s, b = _fold(None, cg.joint_norm)
@@ -236,6 +244,10 @@ class DyMN(nn.Module):
                     s, b = _fold(None, bn)
                     d[name] = (s.contiguous(), b.contiguous())
             out[i] = d
+        if isinstance(self.layers[0], InvertedResidual):
+            front = fold_front(self.in_c, self.layers[0])
+            if front is not None:
+                out["front"] = front
         s, b = _fold(self.out_c[0], self.out_c[1])
         out["last"] = (ops.pw_prepack(self.out_c[0].weight.flatten(1), s.contiguous()), b.contiguous())
         return out
@@ -293,10 +305,19 @@ class DyMN(nn.Module):
         x = x.contiguous().float()
         B = x.shape[0]
         fmaps = []
-        x = ops.stem_conv(x, *W["stem"], ops.ACT_HSWISH)
-        fmaps.append(x)
+        first = 0
+        if "front" in W and not return_fmaps:
+            # static first block (replace_se): stem + block in one kernel, as in MN (csrc/front.hip)
+            x = ops.front(x, *W["stem"], *W[0]["dw"], *W["front"],
+                          ops.ACT_HSWISH if self.layers[0].cnf.use_hs else ops.ACT_RELU)
+            first = 1
+        else:
+            x = ops.stem_conv(x, *W["stem"], ops.ACT_HSWISH)
+            fmaps.append(x)
         for i, blk in enumerate(self.layers):
-            x = self._block_forward(blk, W[i], x)
+            if i < first:
+                continue
+            x = run_block(blk, W[i], x) if isinstance(blk, InvertedResidual) else self._block_forward(blk, W[i], x)
             fmaps.append(x)
         c_feat = self.out_c.out_channels
         pooled = torch.zeros((B, c_feat), device=x.device, dtype=torch.float32)

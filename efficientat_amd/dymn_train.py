@@ -137,6 +137,26 @@ class PwConv(torch.autograd.Function):
         return dx, ops.pw_conv_wgrad(dz, x, exact=False).view_as(w)
 
 
+class DwConv(torch.autograd.Function):
+    """Static depthwise k x k conv (no bias) of the SE-less blocks of a `use_dy_blocks="replace_se"` network."""
+
+    @staticmethod
+    def forward(ctx, x, w, k, stride):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.k, ctx.stride = k, stride
+        C = x.shape[1]
+        return ops.dw_conv(x, w.reshape(C, k * k), _zeros.get(C, x.device), k, stride, NONE)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        k, stride = ctx.k, ctx.stride
+        dx = ops.dw_conv_dgrad(dz, w.reshape(-1, k * k).contiguous(), x.shape, k, stride)
+        return dx, ops.dw_conv_wgrad(dz, x, k, stride).view_as(w), None, None
+
+
 def _bank_grad(G, att, bank):
     B, K, N = att.shape[0], bank.shape[0], bank.shape[1]
     dbank = torch.empty_like(bank)
@@ -282,13 +302,30 @@ def _block_train(blk, x):
     return x + inp if blk.use_res_connect else x
 
 
+def _static_block_train(blk, x):
+    """SE-less InvertedResidual in train mode (models/mn/block_types.py:138-181 with se_cnf None)."""
+    cnf = blk.cnf
+    act = HSWISH if cnf.use_hs else RELU
+    if cnf.dilation > 1:
+        raise NotImplementedError("training a dilated block is not on the HIP path")
+    inp = x
+    if blk.i_expand is not None:
+        conv, bn = blk.block[blk.i_expand][0], blk.block[blk.i_expand][1]
+        x = BnAct.apply(PwConv.apply(x, conv.weight), bn.weight, bn.bias, bn, act)
+    conv, bn = blk.block[blk.i_dw][0], blk.block[blk.i_dw][1]
+    x = BnAct.apply(DwConv.apply(x, conv.weight, cnf.kernel, cnf.stride), bn.weight, bn.bias, bn, act)
+    conv, bn = blk.block[blk.i_proj][0], blk.block[blk.i_proj][1]
+    x = BnAct.apply(PwConv.apply(x, conv.weight), bn.weight, bn.bias, bn, NONE)
+    return x + inp if blk.use_res_connect else x
+
+
 def forward_train(model, x):
     """Train-mode `(logits, embedding)` of DyMN with autograd support (models/dymn/model.py:185-200)."""
     x = x.contiguous().float()
     z = StemConv.apply(x, model.in_c[0].weight)
     x = BnAct.apply(z, model.in_c[1].weight, model.in_c[1].bias, model.in_c[1], HSWISH)
     for blk in model.layers:
-        x = _block_train(blk, x)
+        x = _block_train(blk, x) if hasattr(blk, "context_gen") else _static_block_train(blk, x)
     z = PwConv.apply(x, model.out_c[0].weight)
     x = BnAct.apply(z, model.out_c[1].weight, model.out_c[1].bias, model.out_c[1], HSWISH)
     feat = x.mean(dim=(2, 3))

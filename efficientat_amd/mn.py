@@ -251,6 +251,73 @@ def _pw(x, pack, Co, act, **kw):
     return ops.pw_conv_bf16(x, wp, bias, Co, act, mode == "bf16x3", **kw)
 
 
+def fold_block(blk):
+    """BN-folded, MFMA-packed weights of one static InvertedResidual (also the static blocks of a
+    `use_dy_blocks="replace_se"` DyMN, models/dymn/model.py:103)."""
+    d = {}
+    if blk.i_expand is not None:
+        cna = blk.block[blk.i_expand]
+        s, b = _fold(cna[0], cna[1])
+        d["exp"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
+    cna = blk.block[blk.i_dw]
+    s, b = _fold(cna[0], cna[1])
+    k = blk.cnf.kernel
+    d["dw"] = ((cna[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, k * k).contiguous(), b.contiguous())
+    cna = blk.block[blk.i_proj]
+    s, b = _fold(cna[0], cna[1])
+    d["proj"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
+    if _fusable(blk):
+        # the block kernel (csrc/mbconv.hip) multiplies on the exact fp32 MFMA: its own fp32 packs
+        ce = blk.block[blk.i_expand]
+        se_, be_ = _fold(ce[0], ce[1])
+        d["exp32"] = (ops.pw_prepack(ce[0].weight.flatten(1), se_.contiguous()), be_.contiguous())
+        if blk.i_se is None and blk.cnf.out_channels <= 80:
+            d["proj32"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
+    return d
+
+
+def fold_front(stem, b0):
+    """Packed project layer of the first block when stem + block 0 run as one kernel (csrc/front.hip), else None."""
+    if (_FUSE_FRONT and stem[0].out_channels == 16 and b0.i_expand is None and b0.i_se is None and b0.use_res_connect
+            and b0.cnf.kernel == 3 and b0.cnf.stride == 1 and b0.cnf.dilation == 1):
+        cna = b0.block[b0.i_proj]
+        s, b = _fold(cna[0], cna[1])
+        return ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous()
+    return None
+
+
+def run_block(blk, w, x, pool=None):
+    """Eval forward of one static InvertedResidual (models/mn/block_types.py:138-181) on the folded weights `w`;
+    `pool` is the zeroed (B, C_exp) accumulator of the SE squeeze for blocks that have one."""
+    cnf = blk.cnf
+    act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
+    inp = x
+    scale = None
+    # early, bandwidth-bound blocks: the whole block (without SE) or expand + depthwise (with SE) in
+    # one kernel, the expanded tensor stays on chip (csrc/mbconv.hip); late blocks are MFMA-bound
+    # and keep the separate kernels
+    if "proj32" in w:
+        return ops.mbconv(x, *w["exp32"], *w["dw"], *w["proj32"], cnf.expanded_channels, cnf.out_channels,
+                          cnf.kernel, cnf.stride, act, res=inp if blk.use_res_connect else None)
+    if "exp32" in w:
+        x = ops.fused_expand_dw(x, *w["exp32"], *w["dw"], cnf.expanded_channels, cnf.kernel, cnf.stride, act, pool)
+    else:
+        if blk.i_expand is not None:
+            x = _pw(x, w["exp"], cnf.expanded_channels, act)
+        if cnf.dilation > 1:
+            x = ops.dw_conv_dilated(x, w["dw"][0], w["dw"][1], cnf.kernel, blk.dw_stride, cnf.dilation, act, pool)
+        else:
+            x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
+    if pool is not None and not blk.block[blk.i_se].channel_only:
+        x = _concurrent_se(blk.block[blk.i_se], x, pool)          # SE over f / t (and c), aggregated: unfused plan
+    elif pool is not None:
+        se = blk.block[blk.i_se].conc_se_layers[0]
+        inv_s = 1.0 / (x.shape[2] * x.shape[3])
+        h = ops.linear(pool, se.fc1.weight, se.fc1.bias, ops.ACT_RELU, inv_s)
+        scale = ops.linear(h, se.fc2.weight, se.fc2.bias, ops.ACT_SIGMOID)
+    return _pw(x, w["proj"], cnf.out_channels, ops.ACT_NONE, in_scale=scale, res=inp if blk.use_res_connect else None)
+
+
 class _FoldCache:
     """Folded / packed weights keyed on the version counters of their source tensors.
 
@@ -345,32 +412,10 @@ class MN(nn.Module):
         s, b = _fold(stem[0], stem[1])
         out["stem"] = ((stem[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, 9).contiguous(), b.contiguous())
         for i, blk in enumerate(self.features[1:-1]):
-            d = {}
-            if blk.i_expand is not None:
-                cna = blk.block[blk.i_expand]
-                s, b = _fold(cna[0], cna[1])
-                d["exp"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
-            cna = blk.block[blk.i_dw]
-            s, b = _fold(cna[0], cna[1])
-            k = blk.cnf.kernel
-            d["dw"] = ((cna[0].weight * s.view(-1, 1, 1, 1)).reshape(-1, k * k).contiguous(), b.contiguous())
-            cna = blk.block[blk.i_proj]
-            s, b = _fold(cna[0], cna[1])
-            d["proj"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
-            if _fusable(blk):
-                # the block kernel (csrc/mbconv.hip) multiplies on the exact fp32 MFMA: its own fp32 packs
-                ce = blk.block[blk.i_expand]
-                se_, be_ = _fold(ce[0], ce[1])
-                d["exp32"] = (ops.pw_prepack(ce[0].weight.flatten(1), se_.contiguous()), be_.contiguous())
-                if blk.i_se is None and blk.cnf.out_channels <= 80:
-                    d["proj32"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
-            out[i] = d
-        b0 = self.features[1]
-        if (_FUSE_FRONT and stem[0].out_channels == 16 and b0.i_expand is None and b0.i_se is None and b0.use_res_connect
-                and b0.cnf.kernel == 3 and b0.cnf.stride == 1):
-            cna = b0.block[b0.i_proj]
-            s, b = _fold(cna[0], cna[1])
-            out["front"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
+            out[i] = fold_block(blk)
+        front = fold_front(stem, self.features[1])
+        if front is not None:
+            out["front"] = front
         last = self.features[-1]
         s, b = _fold(last[0], last[1])
         out["last"] = _pack_pw(last[0].weight.flatten(1), s.contiguous(), b.contiguous())
@@ -423,40 +468,7 @@ class MN(nn.Module):
         for i, blk in enumerate(blocks):
             if i < first:
                 continue
-            cnf, w = blk.cnf, W[i]
-            act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
-            inp = x
-            pool = scale = None
-            if blk.i_se is not None:
-                pool = take(cnf.expanded_channels)
-            # early, bandwidth-bound blocks: the whole block (without SE) or expand + depthwise (with SE) in
-            # one kernel, the expanded tensor stays on chip (csrc/mbconv.hip); late blocks are MFMA-bound
-            # and keep the separate kernels
-            if "proj32" in w:
-                x = ops.mbconv(x, *w["exp32"], *w["dw"], *w["proj32"], cnf.expanded_channels, cnf.out_channels,
-                               cnf.kernel, cnf.stride, act, res=inp if blk.use_res_connect else None)
-                if return_fmaps:
-                    fmaps.append(x)
-                continue
-            if "exp32" in w:
-                x = ops.fused_expand_dw(x, *w["exp32"], *w["dw"], cnf.expanded_channels, cnf.kernel, cnf.stride, act,
-                                        pool)
-            else:
-                if blk.i_expand is not None:
-                    x = _pw(x, w["exp"], cnf.expanded_channels, act)
-                if cnf.dilation > 1:
-                    x = ops.dw_conv_dilated(x, w["dw"][0], w["dw"][1], cnf.kernel, blk.dw_stride, cnf.dilation, act, pool)
-                else:
-                    x = ops.dw_conv(x, w["dw"][0], w["dw"][1], cnf.kernel, cnf.stride, act, pool)
-            if pool is not None and not blk.block[blk.i_se].channel_only:
-                x = _concurrent_se(blk.block[blk.i_se], x, pool)          # SE over f / t (and c), aggregated: unfused plan
-            elif pool is not None:
-                se = blk.block[blk.i_se].conc_se_layers[0]
-                inv_s = 1.0 / (x.shape[2] * x.shape[3])
-                h = ops.linear(pool, se.fc1.weight, se.fc1.bias, ops.ACT_RELU, inv_s)
-                scale = ops.linear(h, se.fc2.weight, se.fc2.bias, ops.ACT_SIGMOID)
-            x = _pw(x, w["proj"], cnf.out_channels, ops.ACT_NONE, in_scale=scale,
-                            res=inp if blk.use_res_connect else None)
+            x = run_block(blk, W[i], x, take(blk.cnf.expanded_channels) if blk.i_se is not None else None)
             if return_fmaps:
                 fmaps.append(x)
         pooled = take(c_feat)

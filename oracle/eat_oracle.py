@@ -320,16 +320,24 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature):
     return x
 
 
+REPLACE_SE_DY = (False, False, False, True, True, True, False, False, False, False, True, True, True, True, True)
+
+
 def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, train=False,
-                 stats=None, drop_mask=None, return_fmaps=False):
-    """DyMN with use_dy_blocks='all' (dymn/model.py:157-200)."""
+                 stats=None, drop_mask=None, return_fmaps=False, use_dy_blocks="all"):
+    """DyMN (dymn/model.py:157-200); use_dy_blocks "all" or "replace_se" (dymn/model.py:225-231: dynamic blocks only
+    where MobileNetV3 has SE, plain SE-less inverted residuals elsewhere, dymn/model.py:102-103)."""
     blocks, _ = block_table(width_mult, strides)
+    dy = (True,) * 15 if use_dy_blocks == "all" else REPLACE_SE_DY
     fmaps = []
     x = _cna(sd, "in_c", x, train, stats, 3, 2, 1, "hs")
     fmaps.append(x)
     for i, c in enumerate(blocks):
         H = context_dim(c["cexp"], width_mult)
-        x = _dy_block(sd, f"layers.{i}", x, c, H, train, stats, temperature)
+        if dy[i]:
+            x = _dy_block(sd, f"layers.{i}", x, c, H, train, stats, temperature)
+        else:
+            x = _inverted_residual(sd, f"layers.{i}", x, c, train, stats, use_se=False)
         fmaps.append(x)
     x = _cna(sd, "out_c", x, train, stats, 1, 1, 1, "hs")
     fmaps.append(x)

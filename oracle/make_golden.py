@@ -204,11 +204,61 @@ def golden_variants(mel):
     np.savez_compressed(os.path.join(OUT, "mn_variants_ref.npz"), **res)
 
 
+DYMN_VARIANTS = {   # models/dymn/model.py:225-231
+    "replace_se": dict(use_dy_blocks="replace_se"),
+}
+
+
+def golden_dymn_variants(mel):
+    """Reference outputs of the DyMN variants on 3 s clips: eval logits / features (DynamicConv temperature 1) and the
+    train-mode logits of the same clips (batch-statistics BatchNorm, Dropout off, temperature 30)."""
+    res = {}
+    with torch.no_grad():
+        x_cal = mel(synth.calibration_clips(96000)).unsqueeze(1)
+        x = mel(synth.parity_clips(96000, seed=43)).unsqueeze(1)
+    for tag, kw in DYMN_VARIANTS.items():
+        model = quiet(get_dymn, width_mult=1.0, **kw)
+        sd = synth.synth_state(synth.shapes_of(model), seed=4)
+        model.load_state_dict(sd, strict=True)
+
+        def set_temp(t):
+            for m in model.modules():
+                if isinstance(m, DynamicConv):
+                    m.temperature = t
+
+        set_temp(1.0)
+        calibrate_reference(model, x_cal)
+        for k, v in bn_buffers(model).items():
+            res[f"{tag}/bn/{k}"] = v.numpy()
+        model.eval()
+        with torch.no_grad():
+            logits, feats = model(x)
+        res[f"{tag}/logits"], res[f"{tag}/features"] = logits.numpy(), feats.numpy()
+        res[f"{tag}/n_state"] = np.int64(len(model.state_dict()))
+        res[f"{tag}/n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+        res[f"{tag}/keys"] = np.array(list(model.state_dict().keys()))     # synth_state draws in this order
+        set_temp(30.0)
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        with torch.no_grad():
+            tl, tf = model(x)
+        res[f"{tag}/train_logits"], res[f"{tag}/train_features"] = tl.numpy(), tf.numpy()
+        print("dymn variant", tag, "logits absmax", float(logits.abs().max()), "std", float(logits.std()),
+              "train std", float(tl.std()))
+    np.savez_compressed(os.path.join(OUT, "dymn_variants_ref.npz"), **res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     mel = golden_mel()
+    if "--dymn-variants-only" in sys.argv:
+        golden_dymn_variants(mel)
+        sys.exit(0)
     if "--variants-only" not in sys.argv:
         golden_model("mn", mel, 1.0, "mn10")
         golden_model("dymn", mel, 1.0, "dymn10")
     golden_variants(mel)
+    golden_dymn_variants(mel)

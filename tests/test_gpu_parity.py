@@ -458,3 +458,76 @@ def test_mn_variants_match_reference_and_oracle(tag, golden_dir):
         model.train()
         with pytest.raises(NotImplementedError):
             model(x.to(DEV))          # the training plan covers the default configuration only: fails loudly
+
+
+from tests.test_oracle_golden import DYMN_VARIANTS, dymn_variant_state  # noqa: E402
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("tag", list(DYMN_VARIANTS))
+def test_dymn_variants_match_reference_and_oracle(tag, golden_dir):
+    """use_dy_blocks="replace_se" (models/dymn/model.py:225-231): dynamic blocks only where MobileNetV3 has SE, static
+    SE-less inverted residuals elsewhere.  Eval vs the reference's stored outputs, train-mode logits vs the reference's,
+    and one train step (loss, every parameter gradient, BN running buffers) vs the oracle's autograd."""
+    model, sd, g = dymn_variant_state(tag, golden_dir)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    x = O.mel_forward(synth.parity_clips(96000, seed=43)).unsqueeze(1)
+
+    def set_temp(t):
+        for m in model.modules():
+            if hasattr(m, "temperature"):
+                m.temperature = t
+
+    set_temp(1.0)
+    with torch.no_grad():
+        got, feat = model(x.to(DEV))
+        _, fmaps = model(x.to(DEV), return_fmaps=True)
+        _, ref_fmaps = O.dymn_forward(sd, x, temperature=1.0, return_fmaps=True, **DYMN_VARIANTS[tag][1])
+    assert len(fmaps) == len(ref_fmaps)
+    for i, (a, b) in enumerate(zip(fmaps, ref_fmaps)):
+        assert a.shape == b.shape and rel_err(a, b) < 2e-4, (i, rel_err(a, b))
+    scale = max(1.0, np.abs(g[f"{tag}/logits"]).max())
+    assert np.abs(got.cpu().numpy() - g[f"{tag}/logits"]).max() < 1e-3 * scale
+    assert np.abs(feat.cpu().numpy() - g[f"{tag}/features"]).max() < 1e-3 * max(1.0, np.abs(g[f"{tag}/features"]).max())
+
+    # train mode
+    set_temp(30.0)
+    model.train()
+    B = x.shape[0]
+    keep = torch.ones(B, model.classifier[2].out_features)
+    model._drop_mask_override = (keep * 0.8).to(DEV)          # h * 0.8 / (1 - 0.2): Dropout off, as in the golden run
+    y = (torch.rand(B, 527, generator=torch.Generator().manual_seed(8)) < 0.01).float()
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    stats = {}
+    logits_ref, _ = O.dymn_forward(sdr, x, temperature=30.0, train=True, stats=stats, **DYMN_VARIANTS[tag][1])
+    loss_ref = F.binary_cross_entropy_with_logits(logits_ref, y)
+    loss_ref.backward()
+    logits, emb = model(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
+    loss.backward()
+    tscale = max(1.0, np.abs(g[f"{tag}/train_logits"]).max())
+    assert np.abs(logits.detach().cpu().numpy() - g[f"{tag}/train_logits"]).max() < 1e-3 * tscale
+    assert np.abs(emb.detach().cpu().numpy() - g[f"{tag}/train_features"]).max() < 1e-3 * max(1.0, np.abs(g[f"{tag}/train_features"]).max())
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    rels, bad = [], []
+    for name, p in model.named_parameters():
+        ref = sdr[name].grad
+        assert p.grad is not None, name
+        if float(ref.norm()) < 1e-4 * gmax:
+            continue
+        r = rel_err(p.grad, ref)
+        rels.append(r)
+        if r > 5e-2:
+            bad.append((name, r))
+    assert not bad, bad[:8]
+    assert float(np.median(rels)) < 1e-2
+    msd = model.state_dict()
+    for k, v in stats.items():
+        assert rel_err(msd[k], v) < 1e-4, k

@@ -181,3 +181,40 @@ def test_oracle_variants_match_reference(tag, golden_dir):
     ref = g[f"{tag}/logits"]
     assert np.abs(logits.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(feats.numpy() - g[f"{tag}/features"]).max() < 2e-5 * max(1.0, np.abs(g[f"{tag}/features"]).max())
+
+
+# ---------------------------------------------------------------- DyMN variants (use_dy_blocks="replace_se")
+DYMN_VARIANTS = {"replace_se": (dict(use_dy_blocks="replace_se"), dict(use_dy_blocks="replace_se"))}
+
+
+def dymn_variant_state(tag, golden_dir):
+    import contextlib
+    import io
+    from efficientat_amd.dymn import get_model
+    g = np.load(os.path.join(golden_dir, "dymn_variants_ref.npz"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = get_model(width_mult=1.0, **DYMN_VARIANTS[tag][0])
+    shapes = synth.shapes_of(model)
+    keys = [str(k) for k in g[f"{tag}/keys"]]                   # the reference's state_dict order (seeded draws follow it)
+    assert sorted(keys) == sorted(shapes) and len(keys) == int(g[f"{tag}/n_state"])   # same state_dict layout
+    sd = synth.synth_state({k: shapes[k] for k in keys}, seed=4)
+    assert sum(p.numel() for p in model.parameters()) == int(g[f"{tag}/n_params"])
+    for k in g.files:
+        if k.startswith(f"{tag}/bn/"):
+            sd[k[len(tag) + 4:]] = torch.from_numpy(g[k])
+    return model, sd, g
+
+
+@pytest.mark.parametrize("tag", list(DYMN_VARIANTS))
+def test_oracle_dymn_variants_match_reference(tag, golden_dir):
+    """models/dymn/model.py:225-231,102-103: eval (temperature 1) and train-mode (batch statistics, temperature 30)
+    logits / features of the unmodified reference."""
+    _, sd, g = dymn_variant_state(tag, golden_dir)
+    x = O.mel_forward(synth.parity_clips(96000, seed=43)).unsqueeze(1)
+    kw = DYMN_VARIANTS[tag][1]
+    with torch.no_grad():
+        logits, feats = O.dymn_forward(sd, x, temperature=1.0, **kw)
+        tl, tf = O.dymn_forward(sd, x, temperature=30.0, train=True, **kw)
+    for got, key in ((logits, "logits"), (feats, "features"), (tl, "train_logits"), (tf, "train_features")):
+        ref = g[f"{tag}/{key}"]
+        assert np.abs(got.numpy() - ref).max() < 5e-5 * max(1.0, np.abs(ref).max()), key
