@@ -94,7 +94,13 @@ def _alg_bytes(name, a):
         return f"pw_conv_bf16_kernel<{mtw},{3 if split else 1},*>", nbytes, 2 * B * S * Ci * Co
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
-        return f"dw_conv_kernel<{k},{s},{act}>", 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
+        nbytes, flops = 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
+        # the small late-layer planes run on the register-resident kernel (csrc/dw_plane.hip: dw_plane_try's table)
+        plane = {(3, 1, 8): (32, 64, 1, 64), (5, 1, 16): (64, 128, 2, 64), (5, 2, 8): (32, 64, 2, 32),
+                 (3, 2, 16): (64, 128, 2, 64), (5, 1, 4): (0, 32, 1, 32)}.get((k, s, F))
+        if plane and plane[0] < T <= plane[1]:
+            return f"dw_plane_kernel<{k},{s},{plane[2]},{plane[3]},{F},*>", nbytes, flops
+        return f"dw_conv_kernel<{k},{s},{act}>", nbytes, flops
     if name == "eat_fused_expand_dw_fwd":
         x, wp, be, wd, bd, y, pool, B, Cin, Cexp, F, T, Fo, To, k, s, act = a[:17]
         nbytes = 4 * B * (Cin * F * T + Cexp * Fo * To) + 4 * Cexp * (Cin + k * k)

@@ -1,0 +1,275 @@
+// Depthwise k x k convolution for the SMALL planes of the late MobileNetV3 blocks (4x32, 8x63, 16x125 at 128 mels /
+// 1000 frames; models/mn/block_types.py:150-162), register-resident:
+//
+//   * one wave owns a whole (b,c) plane (or, for <= 32 columns, the planes of the SAME channel of two consecutive samples
+//     side by side in its two half-waves, so that the taps stay wave-uniform); a lane owns
+//     CPL consecutive columns.  Every input element is loaded from HBM exactly once, by exactly one lane, as part of a
+//     coalesced row segment - the row-ring kernel (conv_spatial.hip) loads each element K times (through L1) and walks
+//     4-16 DEPENDENT load rounds down the plane; here all F rows of the plane are requested up front (F*CPL registers)
+//     and the next plane group of the wave is already loading while the current one is multiplied;
+//   * the horizontal neighbours come from the adjacent lanes by DPP wavefront shifts (wave_shr:1 / wave_shl:1, VALU rate,
+//     no LDS): K-1 (stride 1) or <= 3 (stride 2) shifts per input row, shared by the K output rows the row feeds;
+//   * taps and bias are wave-uniform (one channel per wave) and live in SGPRs;
+//   * the epilogue is conv_spatial.hip's: bias (folded BatchNorm), activation, optional residual add (the stride-1 data
+//     gradient of training runs through the same kernel with the taps flipped), per-plane sum for the squeeze of
+//     SqueezeExcitation - one atomicAdd per plane, the wave holds the whole plane.
+//
+// `dw_plane_try` returns 1 when the geometry is not one of the instantiated ones; the caller then uses the row-ring kernel.
+#include <cstdlib>
+#include "eat_common.h"
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// value held by the previous / next lane of the plane's lane group; 0 beyond the group (= zero padding of the conv)
+template <int LPP>
+__device__ __forceinline__ float from_prev(float v, bool first) {
+  const float r = dpp0<0x138>(v);                       // wave_shr:1  (lane 0 keeps the 0 of `old`)
+  return (LPP < 64 && first) ? 0.0f : r;
+}
+template <int LPP>
+__device__ __forceinline__ float from_next(float v, bool last) {
+  const float r = dpp0<0x130>(v);                       // wave_shl:1  (lane 63 keeps 0)
+  return (LPP < 64 && last) ? 0.0f : r;
+}
+
+struct PlaneArgs {
+  const float* x; const float* w; const float* bias; const float* res; float* y; float* pool;
+  int B, C, T, To, G, flip, act;
+};
+
+
+// K, S: kernel size / stride; CPL: input columns per lane; LPP: lanes per plane (64, or 32 = two planes per wave);
+// F: input rows (compile time: the whole plane is a static register array)
+// Raw buffer access (see irb.hip): per-lane byte offset + scalar row offset; a lane whose offset is kOOB loads 0 /
+// stores nothing (hardware range check) - no divergent branches around the edge lanes.
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes_to_end) {
+  const int n = bytes_to_end < 0x7fffffffLL ? (int)bytes_to_end : 0x7fffffff;   // exact end of the tensor: see fetch()
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+// 8-byte forms (dword-aligned addresses: rows of an odd width start on 4-byte boundaries)
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store2(float v0, float v1, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), r, (int)voff, (int)soff, 0);
+}
+
+// PF: keep the next plane group of the wave loading while the current one is multiplied (small planes; big planes have
+// enough bytes in flight from the waves of the CU alone and need the registers)
+template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, bool RES>
+__global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const float* __restrict__ w_,
+                                                       const float* __restrict__ bias_) {
+  constexpr int P = (K - 1) / 2;
+  constexpr int NPW = 64 / LPP;                          // planes per wave
+  constexpr int NE = S == 1 ? CPL + 2 * P : K;           // extended row: input columns CPL*l - P ... as seen by lane l
+  constexpr int NO = S == 1 ? CPL : 1;                   // output columns per lane
+  constexpr int Fo = (F + 2 * P - K) / S + 1;
+  static_assert(S == 1 || CPL == 2, "stride 2: a lane owns input columns 2l, 2l+1 and output column l");
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (LPP - 1);
+  const int half = NPW == 1 ? 0 : lane / LPP;
+  const bool first = l == 0, last = l == LPP - 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int T = a.T, To = a.To, C = a.C;
+  const int g0 = wave * a.G;                             // first plane group of this wave
+  // group g = (sample pair bp, channel c): planes (NPW*bp + half)*C + c
+  const int n_groups = ((a.B + NPW - 1) / NPW) * C;
+  // per-lane byte offsets inside the group's planes (the half-wave's plane is C planes further on)
+  // A lane with two columns moves them as one 8-byte access.  In the last lane of an odd-width row only the first
+  // column exists: the LOAD still reads 8 bytes (the second dword is the next row's first element - or, at the very end
+  // of the tensor, out of the descriptor's range, which the hardware checks per dword and returns as 0) and the lane
+  // zeroes it; the STORE of that lane is a separate dword (vout[1]), the 8-byte store (vout[0]) skips it.
+  unsigned vin, vout[NO];
+  {
+    const unsigned bi = 4u * (unsigned)(half * C * (F * T) + CPL * l), bo = 4u * (unsigned)(half * C * (Fo * To) + NO * l);
+    vin = CPL * l < T ? bi : kOOB;
+    vout[0] = NO * l + NO - 1 < To ? bo : kOOB;
+    if (NO == 2) vout[NO - 1] = (NO * l < To && NO * l + 1 >= To) ? bo : kOOB;
+  }
+  const bool in_part = CPL == 2 && CPL * l + 1 >= T;      // second input column of this lane does not exist
+  const long long x_elems = (long long)a.B * C * (F * T), y_elems = (long long)a.B * C * (Fo * To);
+
+  float raw[PF ? 2 : 1][F][CPL];
+  // first plane of group g (wave-uniform), its channel, and whether this lane's half-wave has a sample
+  auto plane_of = [&](int g, int& c, bool& mine) {
+    const int gg = g < n_groups ? g : 0;
+    const int bp = gg / C;
+    c = gg - bp * C;
+    mine = g < n_groups && NPW * bp + half < a.B;
+    return NPW * bp * C + c;
+  };
+  auto fetch = [&](int g, float (&r)[F][CPL]) {
+    int c; bool mine;
+    const int p = plane_of(g, c, mine);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * (F * T), 4 * (x_elems - (long long)p * (F * T)));
+    const unsigned v = mine ? vin : kOOB;
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+      if constexpr (CPL == 1) {
+        r[i][0] = buf_load(rx, v, 4u * (unsigned)(i * T));
+      } else {
+        const f32x2 pv = buf_load2(rx, v, 4u * (unsigned)(i * T));
+        r[i][0] = pv[0];
+        r[i][1] = in_part ? 0.0f : pv[1];
+      }
+    }
+  };
+
+  auto compute = [&](int g, const float (&r)[F][CPL]) {
+    int c; bool mine;
+    const int p = plane_of(g, c, mine);
+    // taps and bias of the (wave-uniform) channel: scalar loads, issued while the rows of the plane are still in flight
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = w_[c * (K * K) + i];                   // __restrict__ kernel args: s_load
+    if (a.flip) {                                                                   // data gradient: correlate with reversed taps
+#pragma unroll
+      for (int i = 0; i < K * K / 2; ++i) { const float t = wk[i]; wk[i] = wk[K * K - 1 - i]; wk[K * K - 1 - i] = t; }
+    }
+    const float b = bias_ ? bias_[c] : 0.0f;
+    const long long y_left = 4 * (y_elems - (long long)p * (Fo * To));
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)p * (Fo * To), y_left);
+    const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((RES ? a.res : a.y) + (size_t)p * (Fo * To), y_left);
+    unsigned vo[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) vo[j] = mine ? vout[j] : kOOB;
+    const bool has0 = NO * l < To && mine, has1 = NO * l + 1 < To && mine;     // which of the lane's output columns exist
+    float ext[F][NE];
+    float psum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < Fo; ++i) {
+      __builtin_amdgcn_sched_barrier(0);      // keep the shifted copies of later rows from being hoisted (VGPR pressure)
+      // extended rows this output row is the first to need
+      const int lo = i == 0 ? 0 : (i - 1) * S + P + 1;
+      const int hi = i * S + P < F - 1 ? i * S + P : F - 1;
+#pragma unroll
+      for (int rr = 0; rr < F; ++rr) {
+        if (rr < lo || rr > hi) continue;
+#pragma unroll
+        for (int t = 0; t < NE; ++t) {
+          const int o = t - P;                                      // column offset from CPL*l
+          const int q = o >= 0 ? o / CPL : -((-o + CPL - 1) / CPL);  // lane offset
+          const int idx = o - q * CPL;
+          float v = r[rr][idx];
+          if (q == -1) v = from_prev<LPP>(v, first);
+          if (q == -2) v = from_prev<LPP>(from_prev<LPP>(v, first), first);
+          if (q == 1) v = from_next<LPP>(v, last);
+          if (q == 2) v = from_next<LPP>(from_next<LPP>(v, last), last);
+          ext[rr][t] = v;
+        }
+      }
+      float acc[NO];
+      {
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] = b;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int rr = i * S - P + u;
+          if (rr < 0 || rr >= F) continue;
+#pragma unroll
+          for (int v = 0; v < K; ++v)
+#pragma unroll
+            for (int j = 0; j < NO; ++j) acc[j] = fmaf(wk[u * K + v], ext[rr][j + v], acc[j]);
+        }
+      }
+      const unsigned so = 4u * (unsigned)(i * To);
+      if constexpr (NO == 1) {
+        float o = eat::activate<ACT>(acc[0]);
+        if constexpr (RES) o += buf_load(rr_, vo[0], so);
+        buf_store(o, ry, vo[0], so);
+        psum += has0 ? o : 0.0f;
+      } else {
+        float o0 = eat::activate<ACT>(acc[0]), o1 = eat::activate<ACT>(acc[1]);
+        if constexpr (RES) {
+          const f32x2 rv = buf_load2(rr_, has0 ? 4u * (unsigned)(half * C * (Fo * To) + NO * l) : kOOB, so);
+          o0 += rv[0]; o1 += rv[1];             // (o1 of a lane without a second column is never stored)
+        }
+        buf_store2(o0, o1, ry, vo[0], so);
+        buf_store(o0, ry, vo[1], so);
+        psum += (has0 ? o0 : 0.0f) + (has1 ? o1 : 0.0f);
+      }
+    }
+    if (a.pool) {
+      if (LPP == 64) {
+        psum = eat::wave_sum(psum);
+      } else {
+#pragma unroll
+        for (int o = LPP >> 1; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+      }
+      if (l == 0 && mine) atomicAdd(a.pool + p + half * C, psum);
+    }
+  };
+
+  if constexpr (PF) {
+    fetch(g0, raw[0]);
+    for (int gi = 0; gi < a.G; gi += 2) {
+      fetch(g0 + gi + 1, raw[1]);
+      compute(g0 + gi, raw[0]);
+      if (gi + 2 < a.G) fetch(g0 + gi + 2, raw[0]);
+      compute(g0 + gi + 1, raw[1]);
+    }
+  } else {
+    for (int gi = 0; gi < a.G; ++gi) {
+      fetch(g0 + gi, raw[0]);
+      compute(g0 + gi, raw[0]);
+    }
+  }
+}
+
+template <int K, int S, int CPL, int LPP, int F, bool PF>
+int launch_plane(const PlaneArgs& a0, hipStream_t s) {
+  PlaneArgs a = a0;
+  constexpr int NPW = 64 / LPP;
+  const int n_groups = ((a.B + NPW - 1) / NPW) * a.C;
+  // plane groups per wave: enough waves to fill the chip several times over, an even count for the 2-deep prefetch
+  static const int g_env = getenv("EAT_DWP_G") ? atoi(getenv("EAT_DWP_G")) : 0;
+  int G = g_env > 0 ? g_env : (PF ? 2 : 1);
+  if (PF) G = (G + 1) & ~1;
+  a.G = G;
+  const int waves = (n_groups + G - 1) / G;
+  const dim3 grid((waves + 3) / 4), blk(256);
+  if (a.res) {
+    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, true>), grid, blk, 0, s, a, a.w, a.bias);
+  } else {
+    EAT_DISPATCH_ACT(a.act, hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, ACT, false>), grid, blk, 0, s, a, a.w, a.bias));
+  }
+  return eat::check_launch("eat_dw_conv_fwd(plane)");
+}
+
+}  // namespace
+
+namespace eat {
+
+int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B, int C,
+                 int F, int T, int Fo, int To, int k, int stride, int act, int flip, hipStream_t s) {
+  static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
+  if (off) return 1;
+  const long long n_planes = (long long)B * C;
+  if (n_planes > 0x3fffffffLL) return 1;
+  if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only                 // plane bases are 64-bit, offsets inside a plane 32-bit
+  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act};
+  if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane<3, 1, 1, 64, 8, true>(a, s);
+  static const int pfb = getenv("EAT_DWP_PFB") ? atoi(getenv("EAT_DWP_PFB")) : 0;
+  if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128)
+    return pfb ? launch_plane<5, 1, 2, 64, 16, true>(a, s) : launch_plane<5, 1, 2, 64, 16, false>(a, s);
+  if (k == 5 && stride == 2 && F == 8 && T > 32 && T <= 64) return launch_plane<5, 2, 2, 32, 8, true>(a, s);
+  if (k == 3 && stride == 2 && F == 16 && T > 64 && T <= 128) return launch_plane<3, 2, 2, 64, 16, true>(a, s);
+  if (k == 5 && stride == 1 && F == 4 && T <= 32) return launch_plane<5, 1, 1, 32, 4, true>(a, s);
+  (void)Fo;
+  return 1;
+}
+
+}  // namespace eat

@@ -58,6 +58,8 @@ int irb_try(const float* x, const float* wp_e, const float* bias_e, const float*
             const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
             int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s);
 
+int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B,
+                 int C, int F, int T, int Fo, int To, int k, int stride, int act, int flip, hipStream_t s);
 int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,
               const float* wp_p, const float* bias_p, float* y, int B, int C, int F, int T, int Fo, int To, int act,
               hipStream_t s);

@@ -115,7 +115,10 @@ def test_stem_conv(B, C, F_, T):
 @pytest.mark.parametrize("B,C,F_,T,k,s,act", [
     (2, 16, 64, 500, 3, 1, 1), (2, 64, 64, 500, 3, 2, 1), (2, 72, 32, 250, 5, 2, 1), (2, 120, 16, 125, 5, 1, 1),
     (2, 240, 16, 125, 3, 2, 2), (3, 200, 8, 63, 3, 1, 2), (3, 672, 8, 63, 5, 2, 2), (5, 960, 4, 32, 5, 1, 2),
-    (1, 8, 7, 9, 3, 2, 0), (2, 5, 1, 3, 5, 1, 2), (1, 3, 33, 700, 5, 2, 1)])
+    (1, 8, 7, 9, 3, 2, 0), (2, 5, 1, 3, 5, 1, 2), (1, 3, 33, 700, 5, 2, 1),
+    # register-resident plane kernel (dw_plane.hip): odd plane counts, narrower planes, full-width planes
+    (1, 3, 4, 32, 5, 1, 1), (3, 7, 4, 20, 5, 1, 2), (1, 5, 8, 40, 3, 1, 0), (3, 11, 8, 64, 3, 1, 2), (1, 9, 16, 100, 5, 1, 1),
+    (2, 3, 16, 128, 5, 1, 2), (1, 7, 8, 50, 5, 2, 1), (3, 5, 8, 64, 5, 2, 2), (1, 3, 16, 128, 3, 2, 0), (2, 9, 16, 77, 3, 2, 2)])
 def test_dw_conv(B, C, F_, T, k, s, act):
     x, w, b = _rand(B, C, F_, T, seed=1), _rand(C, 1, k, k, seed=2, scale=0.3), _rand(C, seed=3, scale=0.1)
     ref = F.conv2d(x, w, b, s, (k - 1) // 2, 1, C)

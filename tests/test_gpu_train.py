@@ -68,7 +68,8 @@ def test_bn_act_forward_backward(B, C, F_, T, act):
 
 @pytest.mark.parametrize("B,C,F_,T,k,s", [(2, 16, 64, 500, 3, 1), (2, 24, 32, 250, 5, 2), (3, 40, 16, 125, 3, 2),
                                           (3, 48, 8, 63, 5, 1), (2, 5, 7, 9, 5, 2), (4, 96, 4, 32, 5, 1),
-                                          (2, 64, 64, 500, 3, 2), (3, 9, 33, 71, 3, 2), (2, 7, 8, 63, 5, 2), (1, 3, 1, 2, 3, 2)])
+                                          (2, 64, 64, 500, 3, 2), (3, 9, 33, 71, 3, 2), (2, 7, 8, 63, 5, 2), (1, 3, 1, 2, 3, 2),
+                                          (3, 7, 8, 63, 3, 1), (1, 5, 16, 125, 5, 1), (3, 3, 4, 31, 5, 1)])
 def test_dw_conv_gradients(B, C, F_, T, k, s):
     x = _rand(B, C, F_, T, seed=1).requires_grad_(True)
     w = _rand(C, 1, k, k, seed=2, scale=0.3).requires_grad_(True)
