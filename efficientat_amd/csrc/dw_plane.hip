@@ -249,6 +249,151 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   return eat::check_launch("eat_dw_conv_fwd(plane)");
 }
 
+// ---- weight gradient on the same ownership: dw[c][u][v] = sum_{b,i,j} dz[b,c,i,j] * x[b,c,i*S+u-P,j*S+v-P] -----------
+// One wave walks G plane groups of ONE channel (different samples), each lane accumulating its K*K partial products in
+// registers (the extended rows are the forward kernel's: DPP neighbours, vertical taps by register reuse); one
+// cross-lane reduction per wave, then K*K atomics - or, per_plane (DyMN: taps are per (b,c), models/dymn/dy_block.py:
+// 103-131), one reduction per plane and a plain store of its K*K sums.
+struct PlaneWgArgs {
+  const float* dz; const float* x; float* dw;
+  int B, C, T, To, G, per_plane;
+};
+
+template <int K, int S, int CPL, int LPP, int F>
+__global__ __launch_bounds__(256) void dw_plane_wgrad_kernel(const PlaneWgArgs a) {
+  constexpr int P = (K - 1) / 2;
+  constexpr int NPW = 64 / LPP;
+  constexpr int NE = S == 1 ? CPL + 2 * P : K;
+  constexpr int NO = S == 1 ? CPL : 1;                   // dz columns per lane
+  constexpr int Fo = (F + 2 * P - K) / S + 1;
+  constexpr int KK = K * K;
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (LPP - 1);
+  const int half = NPW == 1 ? 0 : lane / LPP;
+  const bool first = l == 0, last = l == LPP - 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int T = a.T, To = a.To, C = a.C;
+  const int spw = NPW * a.G;                             // samples per wave
+  const int n_sg = (a.B + spw - 1) / spw;
+  if (wave >= C * n_sg) return;                          // wave-uniform
+  const int sg = wave / C, c = wave - sg * C;            // consecutive waves: consecutive channels of the same samples
+  unsigned vin, vdz;
+  {
+    const unsigned bi = 4u * (unsigned)(half * C * (F * T) + CPL * l), bo = 4u * (unsigned)(half * C * (Fo * To) + NO * l);
+    vin = CPL * l < T ? bi : kOOB;
+    vdz = NO * l < To ? bo : kOOB;
+  }
+  const bool in_part = CPL == 2 && CPL * l + 1 >= T;
+  const bool dz_part = NO == 2 && NO * l + 1 >= To;
+  const long long x_elems = (long long)a.B * C * (F * T), z_elems = (long long)a.B * C * (Fo * To);
+
+  float acc[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) acc[i] = 0.0f;
+
+  auto flush = [&](int plane_lo) {
+    // sums over the lanes of a plane (per_plane) or of the whole wave (both half-waves hold the same channel)
+    float mine_v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) {
+      float v = acc[i];
+#pragma unroll
+      for (int o = LPP >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (NPW == 2 && !a.per_plane) v += __shfl_xor(v, 32, 64);
+      mine_v = l == i ? v : mine_v;
+      acc[i] = 0.0f;
+    }
+    if (a.per_plane) {
+      const bool ok = plane_lo >= 0 && (plane_lo / C + half) < a.B;     // plane_lo = b_lo * C + c
+      if (l < KK && ok) a.dw[(size_t)(plane_lo + half * C) * KK + l] = mine_v;
+    } else if (lane < KK) {
+      atomicAdd(a.dw + c * KK + lane, mine_v);
+    }
+  };
+
+  for (int gi = 0; gi < a.G; ++gi) {
+    const int b_lo = (sg * a.G + gi) * NPW;
+    if (b_lo >= a.B) break;                               // wave-uniform
+    const bool mine = b_lo + half < a.B;
+    const int p = b_lo * C + c;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * (F * T), 4 * (x_elems - (long long)p * (F * T)));
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * (Fo * To), 4 * (z_elems - (long long)p * (Fo * To)));
+    const unsigned vx = mine ? vin : kOOB, vz = mine ? vdz : kOOB;
+    float r[F][CPL], d[Fo][NO];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+      if constexpr (CPL == 1) {
+        r[i][0] = buf_load(rx, vx, 4u * (unsigned)(i * T));
+      } else {
+        const f32x2 pv = buf_load2(rx, vx, 4u * (unsigned)(i * T));
+        r[i][0] = pv[0];
+        r[i][1] = in_part ? 0.0f : pv[1];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Fo; ++i) {
+      if constexpr (NO == 1) {
+        d[i][0] = buf_load(rz, vz, 4u * (unsigned)(i * To));
+      } else {
+        const f32x2 pv = buf_load2(rz, vz, 4u * (unsigned)(i * To));
+        d[i][0] = pv[0];
+        d[i][1] = dz_part ? 0.0f : pv[1];
+      }
+    }
+    float ext[F][NE];
+#pragma unroll
+    for (int i = 0; i < Fo; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int lo = i == 0 ? 0 : (i - 1) * S + P + 1;
+      const int hi = i * S + P < F - 1 ? i * S + P : F - 1;
+#pragma unroll
+      for (int rr = 0; rr < F; ++rr) {
+        if (rr < lo || rr > hi) continue;
+#pragma unroll
+        for (int t = 0; t < NE; ++t) {
+          const int o = t - P;
+          const int q = o >= 0 ? o / CPL : -((-o + CPL - 1) / CPL);
+          const int idx = o - q * CPL;
+          float v = r[rr][idx];
+          if (q == -1) v = from_prev<LPP>(v, first);
+          if (q == -2) v = from_prev<LPP>(from_prev<LPP>(v, first), first);
+          if (q == 1) v = from_next<LPP>(v, last);
+          if (q == 2) v = from_next<LPP>(from_next<LPP>(v, last), last);
+          ext[rr][t] = v;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        const int rr = i * S - P + u;
+        if (rr < 0 || rr >= F) continue;
+#pragma unroll
+        for (int v = 0; v < K; ++v)
+#pragma unroll
+          for (int j = 0; j < NO; ++j) acc[u * K + v] = fmaf(d[i][j], ext[rr][j + v], acc[u * K + v]);
+      }
+    }
+    if (a.per_plane) flush(p);
+  }
+  if (!a.per_plane) flush(-1);
+}
+
+template <int K, int S, int CPL, int LPP, int F>
+int launch_plane_wgrad(const PlaneWgArgs& a0, hipStream_t s) {
+  PlaneWgArgs a = a0;
+  constexpr int NPW = 64 / LPP;
+  static const int g_env = getenv("EAT_DWP_WG") ? atoi(getenv("EAT_DWP_WG")) : 0;
+  // samples per wave: every wave should multiply several planes before its K*K-value reduction, but keep >= ~8 k waves
+  int G = 1;
+  if (!a.per_plane) {
+    G = g_env > 0 ? g_env : 8;
+    while (G > 1 && (long long)a.C * ((a.B + NPW * G - 1) / (NPW * G)) < 8192) G >>= 1;
+  }
+  a.G = G;
+  const long long waves = (long long)a.C * ((a.B + NPW * G - 1) / (NPW * G));
+  hipLaunchKernelGGL((dw_plane_wgrad_kernel<K, S, CPL, LPP, F>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  return eat::check_launch("eat_dw_conv_wgrad(plane)");
+}
+
 }  // namespace
 
 namespace eat {
@@ -268,6 +413,21 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
   if (k == 5 && stride == 2 && F == 8 && T > 32 && T <= 64) return launch_plane<5, 2, 2, 32, 8, true>(a, s);
   if (k == 3 && stride == 2 && F == 16 && T > 64 && T <= 128) return launch_plane<3, 2, 2, 64, 16, true>(a, s);
   if (k == 5 && stride == 1 && F == 4 && T <= 32) return launch_plane<5, 1, 1, 32, 4, true>(a, s);
+  (void)Fo;
+  return 1;
+}
+
+int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
+                       int stride, int per_plane, hipStream_t s) {
+  static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
+  if (off) return 1;
+  if ((long long)B * C > 0x3fffffffLL) return 1;
+  PlaneWgArgs a{dz, x, dw, B, C, T, To, 1, per_plane};
+  if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane_wgrad<3, 1, 1, 64, 8>(a, s);
+  if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128) return launch_plane_wgrad<5, 1, 2, 64, 16>(a, s);
+  if (k == 5 && stride == 2 && F == 8 && T > 32 && T <= 64) return launch_plane_wgrad<5, 2, 2, 32, 8>(a, s);
+  if (k == 3 && stride == 2 && F == 16 && T > 64 && T <= 128) return launch_plane_wgrad<3, 2, 2, 64, 16>(a, s);
+  if (k == 5 && stride == 1 && F == 4 && T <= 32) return launch_plane_wgrad<5, 1, 1, 32, 4>(a, s);
   (void)Fo;
   return 1;
 }

@@ -126,7 +126,10 @@ def test_dyrelu_coordatt_backward():
         assert _rel(a.grad, b.grad) < 2e-5
 
 
-@pytest.mark.parametrize("kind", ["pw", "dw"])
+# dw shapes: a generic one plus every geometry of the register-resident plane kernels (dw_plane.hip: forward, data and
+# per-plane weight gradient), with odd sample counts for the two-planes-per-wave forms
+@pytest.mark.parametrize("kind", ["pw", "dw", (7, 8, 63, 3, 1), (5, 16, 125, 5, 1), (6, 8, 63, 5, 2), (9, 16, 125, 3, 2),
+                                  (10, 4, 32, 5, 1), (3, 4, 20, 5, 1)])
 def test_dynamic_conv_backward(kind):
     from efficientat_amd.dymn_train import DynDwConv, DynPwConv
     B, K = 3, 4
@@ -134,8 +137,9 @@ def test_dynamic_conv_backward(kind):
         Ci, Co, Fq, T = 24, 40, 8, 63
         x, w = _rand(B, Ci, Fq, T, seed=1), _rand(1, 1, K, Co * Ci, seed=2, scale=Ci ** -0.5)
     else:
-        C, Fq, T, k, s = 24, 16, 125, 5, 2
+        C, Fq, T, k, s = (24, 16, 125, 5, 2) if kind == "dw" else kind
         x, w = _rand(B, C, Fq, T, seed=1), _rand(1, 1, K, C * k * k, seed=2, scale=0.3)
+        kind = "dw"
     att = torch.softmax(_rand(B, K, seed=3), dim=-1)
     xr, wr, ar = (t.clone().requires_grad_(True) for t in (x, w, att))
     agg = ar @ wr[0, 0]
