@@ -8,6 +8,7 @@
 // The reference materialises (B*Cout, Cin/g, k, k) aggregated weights with a batched matmul and runs a
 // grouped conv with groups*B; here the aggregation is one streaming kernel and the conv is the same
 // MFMA / sliding-window kernel as the static network, reading per-sample weights.
+#include <cstdlib>
 #include "eat_common.h"
 
 namespace {
@@ -233,6 +234,87 @@ __global__ __launch_bounds__(256) void dyn_datt_kernel(const float* __restrict__
               s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 
+// Both gradients of the aggregation in ONE pass over G (the two kernels above read G twice, each with one load in flight
+// per thread): a thread owns 4 consecutive columns n (16-byte loads, 4 samples of them in flight), keeps the K x 4
+// dbank accumulators and its bank columns in registers; the K partial dot products of a sample are reduced across the
+// wave with DPP adds (scan inside each 16-lane row, row_bcast:15 / :31 across rows; VALU rate, no LDS crossbar), summed
+// per block in LDS and added to the zeroed datt once per block.
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ float wave_total_in_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave total
+  return v;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dyn_bank_grad_fused_kernel(const float* __restrict__ G, const float* __restrict__ att,
+                                                                  const float* __restrict__ bank, float* __restrict__ dbank,
+                                                                  float* __restrict__ datt, int B, int N, int bpb) {
+  // blockIdx.y = batch slice of bpb samples (small N: not enough column tiles to fill the chip; dbank is then zeroed by
+  // the host and accumulated with atomics)
+  extern __shared__ float s_mem[];                       // [B*K] attention, [B*K] per-block datt sums
+  float* s_att = s_mem;
+  float* s_da = s_mem + B * K;
+  for (int i = threadIdx.x; i < B * K; i += 256) { s_att[i] = att[i]; s_da[i] = 0.0f; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t n4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = n4 < (size_t)N;                      // N % 4 == 0 (host)
+  const size_t nn = live ? n4 : 0;
+  float4 bk[K], acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    bk[k] = live ? *reinterpret_cast<const float4*>(bank + (size_t)k * N + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  constexpr int U = 4;                                   // samples in flight per thread
+  const int b_begin = blockIdx.y * bpb, b_end = b_begin + bpb < B ? b_begin + bpb : B;
+  for (int b0 = b_begin; b0 < b_end; b0 += U) {
+    float4 g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u < b_end ? b0 + u : b_end - 1;
+      g[u] = *reinterpret_cast<const float4*>(G + (size_t)b * N + nn);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u;
+      if (b >= b_end) break;                             // uniform
+      const float4 gv = live ? g[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float a = s_att[b * K + k];
+        acc[k].x = fmaf(a, gv.x, acc[k].x); acc[k].y = fmaf(a, gv.y, acc[k].y);
+        acc[k].z = fmaf(a, gv.z, acc[k].z); acc[k].w = fmaf(a, gv.w, acc[k].w);
+        float t = fmaf(gv.x, bk[k].x, fmaf(gv.y, bk[k].y, fmaf(gv.z, bk[k].z, gv.w * bk[k].w)));
+        t = wave_total_in_lane63(t);
+        if (lane == 63) atomicAdd(&s_da[b * K + k], t);
+      }
+    }
+  }
+  if (live) {
+    if (gridDim.y == 1) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(dbank + (size_t)k * N + nn) = acc[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float* d = dbank + (size_t)k * N + nn;
+        atomicAdd(d, acc[k].x); atomicAdd(d + 1, acc[k].y); atomicAdd(d + 2, acc[k].z); atomicAdd(d + 3, acc[k].w);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = b_begin * K + threadIdx.x; i < b_end * K; i += 256) atomicAdd(datt + i, s_da[i]);
+}
+
 }  // namespace
 
 extern "C" int eat_ctx_pool(const float* x, float* seq, int B, int C, int F, int T, eat_stream_t stream) {
@@ -294,7 +376,23 @@ extern "C" int eat_dyn_bank_grad(const float* G, const float* att, const float* 
                                  int K, int N, eat_stream_t stream) {
   eat::clear_stale_error();
   if (K > 8) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: K=%d > 8", K);
-  if ((size_t)B * K * sizeof(float) > 48 * 1024) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: batch too large");
+  if ((size_t)B * K * sizeof(float) > 24 * 1024) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: batch too large");
+  static const bool two_pass = getenv("EAT_BANK_GRAD_OLD") && atoi(getenv("EAT_BANK_GRAD_OLD")) != 0;
+  if (K == 4 && (N & 3) == 0 && !two_pass) {            // DynamicConv's k = 4 (models/dymn/dy_block.py:68): one pass over G
+    const int gx = (N / 4 + 255) / 256;
+    // few column tiles (N <= 64 k): slice the batch over ~512 blocks, a slice walks at least 8 samples (the atomics on
+    // dbank cost more than they gain once the column tiles alone fill the chip: 301 k columns 96 vs 105 us)
+    int slices = gx <= 64 ? (512 + gx - 1) / gx : 1;
+    if (slices > B / 8) slices = B / 8;
+    if (slices < 1) slices = 1;
+    const int bpb = (B + slices - 1) / slices;
+    slices = (B + bpb - 1) / bpb;
+    if (slices > 1 && hipMemsetAsync(dbank, 0, (size_t)K * N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return eat::fail(EAT_ELAUNCH, "eat_dyn_bank_grad: memset failed");
+    hipLaunchKernelGGL(dyn_bank_grad_fused_kernel<4>, dim3(gx, slices), dim3(256), (size_t)2 * B * K * sizeof(float),
+                       (hipStream_t)stream, G, att, bank, dbank, datt, B, N, bpb);
+    return eat::check_launch("eat_dyn_bank_grad");
+  }
   int gx = (N + 255) / 256;
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(dyn_dbank_kernel, dim3(gx), dim3(256), (size_t)B * K * sizeof(float), (hipStream_t)stream, G, att,

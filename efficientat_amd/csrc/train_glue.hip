@@ -84,6 +84,29 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const float* __restrict__ 
   }
 }
 
+// ---- out[c] = sum_r m[r, c] for a row-major (R, C) matrix: the bias gradients of the context-path Linear layers of DyMN
+// (models/dymn/dy_block.py:235-254; R = B * (F + T) up to 64 k rows).  Consecutive threads read consecutive elements
+// (fully coalesced whatever C is), every element goes into a per-block LDS accumulator of its column, one global atomic
+// per column and block.  (The 1 x R times R x C product on the linear kernel that this replaces ran on ONE block.)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ m, float* __restrict__ out, long long n,
+                                                      int C, long long per_block) {
+  extern __shared__ float s_acc[];
+  for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.0f;
+  __syncthreads();
+  const long long e0 = (long long)blockIdx.x * per_block;            // per_block is a multiple of C: column of e0 is 0
+  long long e1 = e0 + per_block;
+  if (e1 > n) e1 = n;
+  int col = threadIdx.x % C;
+  const int step = 256 % C;
+  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+    atomicAdd(&s_acc[col], m[e]);
+    col += step;
+    if (col >= C) col -= C;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(out + i, s_acc[i]);
+}
+
 }  // namespace
 
 extern "C" int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n,
@@ -115,4 +138,19 @@ extern "C" int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const in
   hipLaunchKernelGGL(kd_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, y, perm, lam, teacher, teacher_idx,
                      n_teacher, kd_lambda, B, C, sums, dlogits);
   return eat::check_launch("eat_kd_loss_fwd_bwd");
+}
+
+extern "C" int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (R < 1 || C < 1 || C > 8192) return eat::fail(EAT_EINVAL, "eat_col_sum: bad shape (%d x %d)", R, C);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_col_sum: memset failed");
+  const long long n = (long long)R * C;
+  long long rows_pb = (R + 1023) / 1024;                              // ~1024 blocks
+  const long long min_rows = (8192 + C - 1) / C;                      // but at least ~8 k elements per block
+  if (rows_pb < min_rows) rows_pb = min_rows;
+  const long long per_block = rows_pb * C;
+  const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+  hipLaunchKernelGGL(col_sum_kernel, dim3(blocks), dim3(256), (size_t)C * sizeof(float), s, m, out, n, C, per_block);
+  return eat::check_launch("eat_col_sum");
 }

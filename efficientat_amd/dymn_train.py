@@ -32,18 +32,10 @@ def _t(x):
     return x.t().contiguous()
 
 
-_ones = {}
-
-
 def _col_sum(m):
-    """Column sums of a (R, C) matrix as a 1 x R times R x C product on the MFMA linear kernel.
-    (torch's multi-block `sum(0)` returned stray non-finite entries when replayed inside a captured
-    hipGraph at R >= ~1000 on ROCm 7.0 / torch 2.10; this keeps the bias gradients on our own kernels.)"""
-    R = m.shape[0]
-    one = _ones.get((R, m.device))
-    if one is None:
-        one = _ones[(R, m.device)] = torch.ones((1, R), device=m.device, dtype=torch.float32)
-    return ops.linear(one, _t(m), None, NONE).view(-1)
+    """Column sums of a (R, C) matrix on our own kernel (torch's multi-block `sum(0)` returned stray non-finite entries
+    when replayed inside a captured hipGraph at R >= ~1000 on ROCm 7.0 / torch 2.10)."""
+    return ops.col_sum(m.contiguous())
 
 
 # ------------------------------------------------------------------------------- Functions

@@ -375,6 +375,14 @@ def pw_conv(x, wp, bias, Co, act, in_scale=None, res=None, pool=None, write=True
 
 
 # ------------------------------------------------------------------ training-loop glue (ex_audioset.py:142-194)
+def col_sum(m):
+    """Column sums of a contiguous (R, C) matrix (bias gradients of the DyMN context path)."""
+    R, C = m.shape
+    out = torch.empty((C,), device=m.device, dtype=torch.float32)
+    _lib.call("eat_col_sum", _dev(m, "m"), out.data_ptr(), R, C, _stream())
+    return out
+
+
 def mixup_fwd(x, perm, lam):
     """x[b] * lam[b] + x[perm[b]] * (1 - lam[b]) over the flattened per-sample axis; perm int32 (B), lam fp32 (B)."""
     B = x.shape[0]

@@ -287,6 +287,11 @@ int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, cons
 
 /* ================= training-loop glue (ex_audioset.py:142-194) ========================= */
 
+/* Column sums of a row-major (R, C) matrix: out[c] = sum_r m[r, c] (out is overwritten).  Replaces the `dy.sum(0)` bias
+ * gradients autograd computes for the context-path Linear / 1x1-conv layers of DyMN (models/dymn/dy_block.py:235-254,
+ * `conv_f`, `conv_t`, `joint_conv` biases; ex_audioset.py:150-153 `loss.backward()`). */
+int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_t stream);
+
 /* Mix-up of a batch with itself (ex_audioset.py:142-148, helpers/utils.py:90-95): out[b] = x[b]*lam[b] + x[perm[b]]*(1-lam[b]);
  * x, out (B, n) fp32 (n = the flattened per-sample size), perm (B) int32, lam (B) fp32.  out must not alias x. */
 int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n, eat_stream_t stream);

@@ -238,3 +238,21 @@ def test_dy_block_train_forward_backward(i, Fq, T):
         ref = sdr[f"layers.{i}.{n}"].grad
         if float(ref.norm()) > 1e-4 * gmax:
             assert _rel(p.grad, ref) < 2e-2, (n, _rel(p.grad, ref))
+
+
+@pytest.mark.parametrize("B,K,N", [(37, 4, 1000), (128, 4, 6400), (5, 4, 1002), (9, 3, 64)])
+def test_dyn_bank_grad(B, K, N):
+    """dbank = att^T G, datt = G bank^T (gradients of the kernel aggregation, models/dymn/dy_block.py:103-131): the
+    one-pass kernel (K = 4, N % 4 == 0) and the two-pass fallback."""
+    from efficientat_amd.dymn_train import _bank_grad
+    G, att, bank = _rand(B, N, seed=1), torch.softmax(_rand(B, K, seed=2), dim=-1), _rand(K, N, seed=3)
+    dbank, datt = _bank_grad(G.to(DEV), att.to(DEV), bank.to(DEV))
+    assert _rel(dbank, att.double().t() @ G.double()) < 2e-6
+    assert _rel(datt, G.double() @ bank.double().t()) < 2e-6
+
+
+@pytest.mark.parametrize("R,C", [(64000, 32), (8064, 1344), (1000, 7), (3, 300), (16000, 240)])
+def test_col_sum(R, C):
+    m = _rand(R, C, seed=1)
+    got = ops.col_sum(m.to(DEV))
+    assert _rel(got, m.double().sum(0)) < 2e-6

@@ -33,3 +33,8 @@ print(f'wall {wall*1e3:.1f} ms, GPU span {s0.elapsed_time(s1):.1f} ms, sum of HI
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]): print(f'{n:28s} {c:4d} {t:8.2f} ms')
 top = sorted(rec, key=lambda r: -r[2].elapsed_time(r[3]))[:16]
 for n, a, e0, e1 in top: print(f'  {n:26s} {e0.elapsed_time(e1)*1e3:8.1f} us', [v for v in a if isinstance(v, int) and abs(v) < 10**7])
+if os.environ.get("EAT_PROF_ALL"):
+    want = os.environ["EAT_PROF_ALL"].split(",")
+    for n, a, e0, e1 in rec:
+        if any(w in n for w in want):
+            print(f'  {n:26s} {e0.elapsed_time(e1)*1e3:8.1f} us', [v for v in a if isinstance(v, int) and abs(v) < 10**7])
