@@ -57,6 +57,7 @@ SIGNATURES = {
     "eat_dw_conv_dyn_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_mixup_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "eat_col_sum": [_P, _P, _I, _I, _P],
+    "eat_pw_conv_kcat_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dilated_fwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "eat_kd_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P],
 }

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
-    int sc_bytes) {
+    int sc_bytes, int ci_x) {
+  // ci_x: channels of x.  ci_x == Ci: plain 1x1 conv.  ci_x < Ci ("K-concat", DyMN): the reduction axis is nbank
+  // copies of x's channels, k = bank * ci_x + ci - the weights are the banks side by side, the per-(sample, k) input
+  // scale carries the attention (host: ci_x % 32 == 0, so a 32-row chunk never straddles two banks)
   constexpr int n_stages = NSTG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   unsigned nl = n_base + 4 * lane;
   if (nl > N - 4) nl = N - 4;
   const int bl = (int)(nl / (unsigned)S), sl = (int)(nl - (unsigned)bl * (unsigned)S);
-  const float* xsrc = x + ((size_t)bl * Ci) * S + sl;
+  const float* xsrc = x + ((size_t)bl * ci_x) * S + sl;
   const unsigned nc = n_base + 64 * wv + 4 * (lane & 15);
   const bool col_ok = nc < N;
   const unsigned ncc = col_ok ? nc : N - 4;
@@ -95,12 +98,13 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     unsigned char* st = smem_raw + (c & (n_stages - 1)) * kStage;
     const int k0 = c * kKC;
     const int klen = (Ci - k0) < kKC ? (Ci - k0) : kKC;
+    const int kx0 = k0 % ci_x;                                // row of x the chunk starts at
     float* Xs = reinterpret_cast<float*>(st + kABytes);
 #pragma unroll
     for (int i = 0; i < kKC / 4; ++i) {
       const int r = wv + 4 * i;
       const int rc = r < klen ? r : klen - 1;                // padded k: finite data x zero weight
-      glds16_raw(xsrc + (size_t)(k0 + rc) * S, Xs + r * kTileN);
+      glds16_raw(xsrc + (size_t)(kx0 + rc) * S, Xs + r * kTileN);
     }
 #pragma unroll
     for (int i = 0; i < (MTW * NP2 + 3) / 4; ++i) {
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 
 template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act) {
+           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x) {
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
   const int n_tiles = (int)((N + kTileN - 1) / kTileN);
@@ -218,17 +222,19 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act, sc_bytes);
+                     n_tiles, NS, act, sc_bytes, ci_x);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
 template <int NPROD>
 int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-             float* y, float* pool, int B, int Ci, int Co, int S, int act) {
+             float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x) {
   const int MT = (Co + 15) / 16;
+  // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
+  // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act);
+#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -259,6 +265,22 @@ extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float*
   hipStream_t s = (hipStream_t)stream;
   if (S % 4 != 0)      // planes that do not start on 16-byte boundaries: plain 4-byte kernel on the same packs
     return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split ? 2 : 1, 0, s);
-  return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act)
-               : dispatch<1>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act);
+  return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci)
+               : dispatch<1>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci);
+}
+
+// DyMN dynamic 1x1 conv WITHOUT per-sample weights (models/dymn/dy_block.py:103-131):
+//   z_b = (sum_k att[b,k] W_k) x_b = [W_0 | ... | W_{K-1}] [att[b,0] x_b ; ... ; att[b,K-1] x_b]
+// one GEMM over the K-concatenated banks (wp: eat_pw_prepack_bf16 of the Co x (nbank * Ci) matrix, shared by every
+// sample) with the attention as the per-(sample, k) input scale (att_scale: (B, nbank * Ci), att[b,k] repeated Ci times).
+extern "C" int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float* bias, const float* att_scale,
+                                    const float* res, float* y, int B, int Ci, int nbank, int Co, int S, int act,
+                                    eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Ci % 32 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: Ci=%d must be a multiple of 32", Ci);
+  if (S % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: S=%d must be a multiple of 4", S);
+  if (nbank < 1 || B < 1 || Co < 1 || !att_scale) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: bad arguments");
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: bad act %d", act);
+  return dispatch<3>((hipStream_t)stream, x, reinterpret_cast<const __bf16*>(wp), bias, att_scale, res, y, nullptr, B,
+                     nbank * Ci, Co, S, act, Ci);
 }

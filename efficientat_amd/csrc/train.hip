@@ -720,7 +720,11 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int m = mb + mw + 16 * i + kg * 4 + q, n = nb + nw + 16 * j + r;   // C/D: row = kg*4+q, col = lane&15
-        if (i < mt_n && j < nt_n && m < Co && n < Ci) atomicAdd(out + (size_t)m * Ci + n, acc[i][j][q]);
+        if (i < mt_n && j < nt_n && m < Co && n < Ci) {
+          // per-sample gradients: the block covered the sample's whole k range - a plain store, no read-modify-write
+          if (per_sample) out[(size_t)m * Ci + n] = acc[i][j][q];
+          else atomicAdd(out + (size_t)m * Ci + n, acc[i][j][q]);
+        }
       }
 }
 
@@ -1001,9 +1005,12 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
   const bool force_fp32 = env_fp32 || exact_fp32 != 0;
-  // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs) keep the 32 x 32-tile fp32 kernel: a 128 x 128 tile
-  // of atomics per sample and block costs more than the short reduction it follows (dymn20 step: 163 vs 115 ms)
-  if (!force_fp32 && !per_sample && (S & 3) == 0) {
+  // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs): the bf16x3 kernel with one block per (tile, sample)
+  // and plain stores from Co, Ci >= 64 on (round 1 measured it with atomics on every sample's tile: 163 vs 115 ms per
+  // dymn20 step; EAT_DYN_WGRAD_X3=0 restores the 32 x 32-tile fp32 kernel)
+  static const bool dyn_x3 = !(getenv("EAT_DYN_WGRAD_X3") && atoi(getenv("EAT_DYN_WGRAD_X3")) == 0);
+  const bool ps_x3 = per_sample && dyn_x3 && Co >= 64 && Ci >= 64;
+  if (!force_fp32 && (!per_sample || ps_x3) && (S & 3) == 0) {
     const int sps = (S + 31) / 32;
     const int tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
     const long long total = (long long)B * sps;

@@ -223,6 +223,7 @@ class DyMN(nn.Module):
                 for t in (m.weight, m.bias, m.running_mean, m.running_var)] + \
                [self.in_c[0].weight, self.out_c[0].weight] + \
                [blk.context_gen.joint_conv.weight for blk in self.layers if isinstance(blk, DY_Block)] + \
+               [m.weight for m in self.modules() if isinstance(m, DynamicConv)] + \
                [m.weight for blk in self.layers if isinstance(blk, InvertedResidual) for m in blk.modules()
                 if isinstance(m, nn.Conv2d)]
 
@@ -273,8 +274,7 @@ class DyMN(nn.Module):
         # ---- expand (dynamic 1x1)
         if blk.has_expand:
             att = _attention(blk.exp_conv, h_c)
-            wp = ops.dyn_pw_pack(blk.exp_conv.weight.view(blk.exp_conv.k, -1), att, cexp, cin, w["exp"][0])
-            x = ops.pw_conv_dyn(x, wp, w["exp"][1], cexp, act)
+            x = self._dyn_pw(blk.exp_conv, w, "exp", x, att, cexp, cin, act)
         # ---- depthwise (dynamic taps) + BN + DyReLU-B + CoordAtt
         att = _attention(blk.depth_conv, h_c)
         taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att, w["depth"][0], k * k)
@@ -284,8 +284,24 @@ class DyMN(nn.Module):
         x = ops.dw_conv_dyn(x, taps, w["depth"][1], coef, g_cf, g_ct, k, stride)
         # ---- project (dynamic 1x1) + BN (+ residual)
         att = _attention(blk.proj_conv, h_c)
-        wp = ops.dyn_pw_pack(blk.proj_conv.weight.view(blk.proj_conv.k, -1), att, cout, cexp, w["proj"][0])
-        return ops.pw_conv_dyn(x, wp, w["proj"][1], cout, ops.ACT_NONE, res=inp if blk.use_res_connect else None)
+        return self._dyn_pw(blk.proj_conv, w, "proj", x, att, cout, cexp, ops.ACT_NONE,
+                            res=inp if blk.use_res_connect else None)
+
+    @staticmethod
+    def _dyn_pw(conv, w, name, x, att, Co, Ci, act, res=None):
+        """Dynamic 1x1 conv + folded BN (models/dymn/dy_block.py:103-131).  Late, small-plane layers (a sample's
+        aggregated weight matrix larger than its activations): ONE GEMM over the K-concatenated banks with the attention
+        as input scale - no per-sample weights exist (`ops.kcat_eligible`; the packed banks are cached with the folded
+        weights).  Elsewhere: aggregate + pack per sample, then the per-sample-weight GEMM."""
+        scale, bias = w[name]
+        bank = conv.weight.view(conv.k, -1)
+        if ops.kcat_eligible(Co, Ci, x.shape[2] * x.shape[3]):
+            key = name + "_cat"
+            if key not in w:
+                w[key] = ops.kcat_pack(bank, Co, Ci, scale)
+            return ops.pw_conv_kcat(x, w[key], bias, att, Co, act, res=res)
+        wp = ops.dyn_pw_pack(bank, att, Co, Ci, scale)
+        return ops.pw_conv_dyn(x, wp, bias, Co, act, res=res)
 
     def train(self, mode: bool = True):
         """nn.Module.train plus dropping the folded eval weights (see mn._FoldCache)."""

@@ -169,6 +169,8 @@ class DynPwConv(torch.autograd.Function):
         bank = weight.view(K, Co * Ci)
         ctx.save_for_backward(x, weight, att)
         ctx.Co = Co
+        if ops.kcat_eligible(Co, Ci, x.shape[2] * x.shape[3]):       # late layers: no per-sample weights (ops.kcat_*)
+            return ops.pw_conv_kcat(x, ops.kcat_pack(bank, Co, Ci), _zeros.get(Co, x.device), att, Co, NONE)
         wp = ops.dyn_pw_pack(bank, att, Co, Ci)
         return ops.pw_conv_dyn(x, wp, _zeros.get(Co, x.device), Co, NONE)
 
@@ -181,8 +183,11 @@ class DynPwConv(torch.autograd.Function):
         bank = weight.view(K, Co, Ci)
         # data gradient: per-sample W_b^T, packed from the transposed bank
         bank_t = bank.transpose(1, 2).contiguous().view(K, Ci * Co)
-        wpt = ops.dyn_pw_pack(bank_t, att, Ci, Co)
-        dx = ops.pw_conv_dyn(dz, wpt, _zeros.get(Ci, x.device), Ci, NONE)
+        if ops.kcat_eligible(Ci, Co, Fq * T):
+            dx = ops.pw_conv_kcat(dz, ops.kcat_pack(bank_t, Ci, Co), _zeros.get(Ci, x.device), att, Ci, NONE)
+        else:
+            wpt = ops.dyn_pw_pack(bank_t, att, Ci, Co)
+            dx = ops.pw_conv_dyn(dz, wpt, _zeros.get(Ci, x.device), Ci, NONE)
         # per-sample weight gradient G_b, then the gradients of the aggregation
         G = torch.zeros((B, Co * Ci), device=x.device, dtype=torch.float32)
         _lib.call("eat_pw_conv_dyn_wgrad", dz.data_ptr(), x.data_ptr(), G.data_ptr(), B, Co, Ci, Fq * T, _s())

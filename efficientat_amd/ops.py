@@ -1,6 +1,8 @@
 """Python-side launchers for the C ABI (include/eat_hip.h): argument checks, output
 allocation through PyTorch's caching allocator, launch on torch's current HIP stream.
 PyTorch is plumbing here (device memory + streams); all arithmetic is in libeat_hip.so."""
+import os
+
 import torch
 
 from . import _lib
@@ -30,6 +32,8 @@ def _dev(t, name):
 
 def _opt(t, name):
     return None if t is None else _dev(t, name)
+
+_KCAT = os.environ.get("EAT_DYN_KCAT", "1") == "1"   # K-concat form of the late dynamic 1x1 convs (A/B switch)
 
 
 def conv_out(n, k, stride):
@@ -266,6 +270,30 @@ def pw_conv_dyn(x, wp_b, bias, Co, act, res=None):
     y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
     _lib.call("eat_pw_conv_dyn_fwd", _dev(x, "x"), _dev(wp_b, "wp_b"), _dev(bias, "bias"), _opt(res, "res"),
               y.data_ptr(), B, Ci, Co, F * T, act, _stream())
+    return y
+
+
+def kcat_eligible(Co, Ci, S):
+    """K-concat form of a dynamic 1x1 conv (no per-sample weights) pays where a sample's aggregated weight matrix is
+    larger than its activations: the late, small-plane layers.  (Ci % 32: a k-chunk must not straddle two banks.)"""
+    return _KCAT and Ci % 32 == 0 and S % 4 == 0 and Co * Ci > (Ci + Co) * S
+
+
+def kcat_pack(bank, Co, Ci, row_scale=None):
+    """bank (K, Co*Ci) -> packed bf16 hi/lo fragments of [W_0 | ... | W_{K-1}]  (Co x K*Ci)."""
+    K = bank.shape[0]
+    wcat = bank.view(K, Co, Ci).permute(1, 0, 2).reshape(Co, K * Ci).contiguous()
+    return pw_prepack_bf16(wcat, row_scale, split=True)
+
+
+def pw_conv_kcat(x, wp_cat, bias, att, Co, act, res=None):
+    """Dynamic 1x1 conv as one GEMM over the concatenated banks; att (B, K) is the attention of the sample."""
+    B, Ci, F, T = x.shape
+    K = att.shape[1]
+    scale = att.repeat_interleave(Ci, dim=1).contiguous()                  # (B, K*Ci)
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_kcat_fwd", _dev(x, "x"), wp_cat.data_ptr(), _dev(bias, "bias"), _dev(scale, "att_scale"),
+              _opt(res, "res"), y.data_ptr(), B, Ci, K, Co, F * T, act, _stream())
     return y
 
 

@@ -215,6 +215,14 @@ int eat_dyrelu_ca_bwd(const float* dout, const float* z, const float* a, const f
                       const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
                       float* dgate_t, int B, int C, int Fo, int To, eat_stream_t stream);
 
+/* DyMN dynamic 1x1 conv without per-sample weights (models/dymn/dy_block.py:103-131, DynamicConv.forward with a 1x1
+ * kernel): z_b = (sum_k att[b,k] W_k) x_b evaluated as ONE GEMM over the K-concatenated banks [W_0|...|W_{nbank-1}]
+ * (wp = eat_pw_prepack_bf16 of the Co x (nbank*Ci) matrix, split form) with the attention as a per-(sample, k) scale of
+ * the input (att_scale (B, nbank*Ci): att[b,k] repeated Ci times).  bf16x3 arithmetic (fp32-class).  Ci % 32 == 0,
+ * S % 4 == 0.  The data gradient is the same call with the transposed banks. */
+int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float* bias, const float* att_scale, const float* res,
+                         float* y, int B, int Ci, int nbank, int Co, int S, int act, eat_stream_t stream);
+
 /* autograd of the kernel aggregation of DynamicConv.forward (models/dymn/dy_block.py:103-127):
  * From the per-sample weight gradients G (B,N): dbank (K,N) = att^T G, datt (B,K) += G bank^T
  * (datt zeroed by the caller). */

@@ -256,3 +256,25 @@ def test_col_sum(R, C):
     m = _rand(R, C, seed=1)
     got = ops.col_sum(m.to(DEV))
     assert _rel(got, m.double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,Fq,T,act,res", [(3, 64, 96, 4, 32, 2, False), (5, 160, 160, 4, 32, 0, True),
+                                                   (2, 32, 200, 8, 63, 1, False), (4, 320, 48, 2, 10, 0, False)])
+def test_pw_conv_kcat(B, Ci, Co, Fq, T, act, res):
+    """Dynamic 1x1 conv as one GEMM over the K-concatenated banks with the attention as input scale
+    (models/dymn/dy_block.py:103-131) vs the per-sample aggregated-weight formulation; bf16x3 arithmetic."""
+    K = 4
+    if (Fq * T) % 4:
+        pytest.skip("K-concat form needs planes of a multiple of 4 positions")
+    x, bank = _rand(B, Ci, Fq, T, seed=1), _rand(K, Co * Ci, seed=2, scale=Ci ** -0.5)
+    att = torch.softmax(_rand(B, K, seed=3), dim=-1)
+    rs, bias = torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(Co, seed=5, scale=0.1)
+    r = _rand(B, Co, Fq, T, seed=6) if res else None
+    W = (att.double() @ bank.double()).view(B, Co, Ci) * rs.double()[None, :, None]
+    ref = torch.einsum("boi,bist->bost", W, x.double()) + bias.double()[None, :, None, None]
+    ref = [ref, F.relu(ref), F.hardswish(ref)][act]
+    if res:
+        ref = ref + r.double()
+    wp = ops.kcat_pack(bank.to(DEV), Co, Ci, rs.to(DEV))
+    got = ops.pw_conv_kcat(x.to(DEV), wp, bias.to(DEV), att.to(DEV), Co, act, res=None if r is None else r.to(DEV))
+    assert _rel(got, ref) < 3e-5
