@@ -249,6 +249,244 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   return eat::check_launch("eat_dw_conv_fwd(plane)");
 }
 
+// ---- the same recipe for LARGE planes: a wave owns a tile of RO output rows x one column strip, with halo lanes / halo
+// rows re-read from the neighbouring tiles (L2 hits).  Lane l holds input columns c0 + 2l, c0 + 2l + 1 of every tile row
+// (one 8-byte load each, all rows of the tile requested up front); lane 0 (and lane 63 where the filter needs it) are
+// halo lanes that produce no output.  Strip width WO (outputs per strip) is balanced by the host: 125 columns for a 3x3 /
+// stride-1 conv on 500- or 250-wide planes (4 / 2 strips, no waste), 63 for 3x3 / stride 2, <= 124 / 62 for 5x5.
+// per_plane_w: taps per (b,c) plane (DyMN train-mode depthwise conv, models/dymn/dy_block.py:103-131).
+struct TileArgs {
+  const float* x; const float* res; float* y; float* pool;
+  int B, C, F, T, Fo, To, n_rc, n_cs, WO, flip, per_plane_w;
+};
+
+template <int K, int S, int RO, int ACT, bool RES>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const float* __restrict__ w_,
+                                                      const float* __restrict__ bias_) {
+  constexpr int P = (K - 1) / 2, CPL = 2, LPP = 64;
+  constexpr int NE = S == 1 ? CPL + 2 * P : K;
+  constexpr int NO = S == 1 ? 2 : 1;
+  constexpr int FI = (RO - 1) * S + K;                   // input rows under a tile
+  const int l = threadIdx.x & 63;
+  const bool first = l == 0, last = l == 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int tpp = a.n_rc * a.n_cs;
+  if (wave >= a.B * a.C * tpp) return;                   // wave-uniform (host: B*C*tpp < 2^31)
+  const int p = wave / tpp, t = wave - p * tpp;
+  const int rc = t / a.n_cs, cs = t - rc * a.n_cs;
+  const int c = p % a.C;
+  const int F = a.F, T = a.T, Fo = a.Fo, To = a.To;
+  const int o_lo = cs * a.WO, o_hi = (o_lo + a.WO) < To ? (o_lo + a.WO) : To;   // output columns of this strip
+  const int c0 = (S == 1 ? o_lo : 2 * o_lo) - 2;         // input column of lane 0 (a halo lane)
+  const int col_in = c0 + 2 * l;
+  const unsigned vin = (col_in >= 0 && col_in < T) ? 4u * (unsigned)col_in : kOOB;
+  const bool in_part = col_in + 1 >= T;
+  // output columns of this lane
+  const int oc = S == 1 ? col_in : o_lo - 1 + l;
+  const bool ok0 = oc >= o_lo && oc < o_hi, ok1 = NO == 2 && oc + 1 >= o_lo && oc + 1 < o_hi;
+  unsigned vout[2];
+  vout[0] = (NO == 2 ? (ok0 && ok1) : ok0) ? 4u * (unsigned)oc : kOOB;
+  vout[1] = (NO == 2 && ok0 && !ok1) ? 4u * (unsigned)oc : kOOB;
+  const int r0o = rc * RO, r0i = r0o * S - P;
+  const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
+  const long long y_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)p * Fo * To, y_left);
+  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((RES ? a.res : a.y) + (size_t)p * Fo * To, y_left);
+
+  float r[FI][CPL];
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    const int rin = r0i + i;
+    const bool rok = rin >= 0 && rin < F;                // wave-uniform: rows above / below the plane read as zero
+    const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
+    r[i][0] = pv[0];
+    r[i][1] = in_part ? 0.0f : pv[1];
+  }
+  float wk[K * K];
+  const int wb = a.per_plane_w ? p : c;
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) wk[i] = w_[(size_t)wb * (K * K) + i];
+  if (a.flip) {
+#pragma unroll
+    for (int i = 0; i < K * K / 2; ++i) { const float tt = wk[i]; wk[i] = wk[K * K - 1 - i]; wk[K * K - 1 - i] = tt; }
+  }
+  const float b = bias_ ? bias_[c] : 0.0f;
+
+  float ext[FI][NE];
+  float psum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < RO; ++i) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int lo = i == 0 ? 0 : (i - 1) * S + K;
+    const int hi = i * S + K - 1;
+#pragma unroll
+    for (int rr = 0; rr < FI; ++rr) {
+      if (rr < lo || rr > hi) continue;
+#pragma unroll
+      for (int tt = 0; tt < NE; ++tt) {
+        const int o = tt - P;
+        const int q = o >= 0 ? o / CPL : -((-o + CPL - 1) / CPL);
+        const int idx = o - q * CPL;
+        float v = r[rr][idx];
+        if (q == -1) v = from_prev<LPP>(v, first);
+        if (q == 1) v = from_next<LPP>(v, last);
+        ext[rr][tt] = v;
+      }
+    }
+    float acc[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) acc[j] = b;
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+#pragma unroll
+      for (int v = 0; v < K; ++v)
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] = fmaf(wk[u * K + v], ext[i * S + u][j + v], acc[j]);
+    const int ro = r0o + i;
+    const bool rowok = ro < Fo;                          // wave-uniform
+    const unsigned so = rowok ? 4u * (unsigned)(ro * To) : 0u;
+    const unsigned v0 = rowok ? vout[0] : kOOB, v1 = rowok ? vout[1] : kOOB;
+    if constexpr (NO == 1) {
+      float o = eat::activate<ACT>(acc[0]);
+      if constexpr (RES) o += buf_load(rr_, v0, so);
+      buf_store(o, ry, v0, so);
+      psum += (rowok && ok0) ? o : 0.0f;
+    } else {
+      float o0 = eat::activate<ACT>(acc[0]), o1 = eat::activate<ACT>(acc[1]);
+      if constexpr (RES) {
+        const f32x2 rv = buf_load2(rr_, (rowok && ok0) ? 4u * (unsigned)oc : kOOB, so);
+        o0 += rv[0]; o1 += rv[1];
+      }
+      buf_store2(o0, o1, ry, v0, so);
+      buf_store(o0, ry, v1, so);
+      psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
+    }
+  }
+  if (a.pool) {
+    psum = eat::wave_sum(psum);
+    if (l == 0) atomicAdd(a.pool + p, psum);
+  }
+}
+
+template <int K, int S, int RO>
+int launch_tile(TileArgs a, const float* w, const float* bias, int act, hipStream_t s) {
+  constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : (K == 3 ? 63 : 62);
+  a.n_cs = (a.To + WMAX - 1) / WMAX;
+  a.WO = (a.To + a.n_cs - 1) / a.n_cs;                   // balanced strips
+  a.n_rc = (a.Fo + RO - 1) / RO;
+  const long long waves = (long long)a.B * a.C * a.n_rc * a.n_cs;
+  if (waves > 0x7fffffffLL) return 1;
+  const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+  if (a.res) {
+    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, true>), grid, blk, 0, s, a, w, bias);
+  } else {
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, ACT, false>), grid, blk, 0, s, a, w, bias));
+  }
+  return eat::check_launch("eat_dw_conv_fwd(tile)");
+}
+
+// ---- stride-2 data gradient, tile form: dx[i][j] = sum_{u,v} w[u][v] dz[(i+P-u)/2][(j+P-v)/2] over the (u, v) for which
+// both quotients are integers.  Roles reversed with respect to the forward: a lane holds ONE dz column q of every tile row
+// (neighbours q-1 / q+1 by DPP) and produces the dx columns 2q, 2q+1 of the rows 2r, 2r+1 - each of the four
+// (row parity, column parity) classes has its own compile-time tap subset (K*K/4 FMAs per dx element on average), and
+// every dx row segment leaves as one 8-byte store per lane.  Lanes 0 and 63 are halo lanes.
+struct TileDgArgs {
+  const float* dz; const float* res; float* dx;
+  int B, C, F, T, Fo, To, n_rc, n_cs, WO, per_plane_w;
+};
+
+template <int K, int RO, bool RES>
+__global__ __launch_bounds__(256) void dw_tile_dgrad2_kernel(const TileDgArgs a, const float* __restrict__ w_) {
+  constexpr int P = (K - 1) / 2, LPP = 64;
+  constexpr int FI = RO + 2;                             // dz rows of a tile incl. one halo row above and below
+  const int l = threadIdx.x & 63;
+  const bool first = l == 0, last = l == 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int tpp = a.n_rc * a.n_cs;
+  if (wave >= a.B * a.C * tpp) return;
+  const int p = wave / tpp, t = wave - p * tpp;
+  const int rc = t / a.n_cs, cs = t - rc * a.n_cs;
+  const int c = p % a.C;
+  const int F = a.F, T = a.T, Fo = a.Fo, To = a.To;
+  const int q_lo = cs * a.WO, q_hi = (q_lo + a.WO) < To ? (q_lo + a.WO) : To;
+  const int q = q_lo - 1 + l;                            // dz column of this lane
+  const unsigned vz = (q >= 0 && q < To) ? 4u * (unsigned)q : kOOB;
+  const bool mine = q >= q_lo && q < q_hi;               // this lane produces dx columns 2q, 2q+1
+  const bool two = 2 * q + 1 < T;
+  const unsigned vx2 = (mine && two) ? 8u * (unsigned)q : kOOB, vx1 = (mine && !two) ? 8u * (unsigned)q : kOOB;
+  const int r_lo = rc * RO;
+  const long long z_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+  const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * Fo * To, z_left);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.dx + (size_t)p * F * T, x_left);
+  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((RES ? a.res : a.dx) + (size_t)p * F * T, x_left);
+  float z[FI][3];                                        // [row][q-1, q, q+1]
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    const int r = r_lo - 1 + i;
+    const bool rok = r >= 0 && r < Fo;
+    z[i][1] = buf_load(rz, rok ? vz : kOOB, rok ? 4u * (unsigned)(r * To) : 0u);
+  }
+  float wk[K * K];
+  const int wb = a.per_plane_w ? p : c;
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) wk[i] = w_[(size_t)wb * (K * K) + i];
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    z[i][0] = from_prev<LPP>(z[i][1], first);
+    z[i][2] = from_next<LPP>(z[i][1], last);
+  }
+#pragma unroll
+  for (int i = 0; i < RO; ++i) {                         // dz row r = r_lo + i  ->  dx rows 2r, 2r+1
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa) {
+      float o[2];
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          if ((pa + P - u) & 1) continue;
+          const int dr = (pa + P - u) / 2;               // even numerator: exact
+#pragma unroll
+          for (int v = 0; v < K; ++v) {
+            if ((pb + P - v) & 1) continue;
+            const int dc = (pb + P - v) / 2;
+            acc = fmaf(wk[u * K + v], z[i + 1 + dr][1 + dc], acc);
+          }
+        }
+        o[pb] = acc;
+      }
+      const int row = 2 * (r_lo + i) + pa;
+      const bool rowok = row < F;                        // wave-uniform
+      const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
+      const unsigned v2 = rowok ? vx2 : kOOB, v1 = rowok ? vx1 : kOOB;
+      if constexpr (RES) {
+        const f32x2 rv = buf_load2(rr_, v2, so);
+        o[0] += rv[0] + buf_load(rr_, v1, so);
+        o[1] += rv[1];
+      }
+      buf_store2(o[0], o[1], rx, v2, so);
+      buf_store(o[0], rx, v1, so);
+    }
+  }
+}
+
+template <int K>
+int launch_tile_dgrad2(TileDgArgs a, const float* w, hipStream_t s) {
+  constexpr int RO = 8;
+  a.n_cs = (a.To + 61) / 62;
+  a.WO = (a.To + a.n_cs - 1) / a.n_cs;
+  a.n_rc = (a.Fo + RO - 1) / RO;
+  const long long waves = (long long)a.B * a.C * a.n_rc * a.n_cs;
+  if (waves > 0x7fffffffLL) return 1;
+  const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+  if (a.res) hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, true>), grid, blk, 0, s, a, w);
+  else hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, false>), grid, blk, 0, s, a, w);
+  return eat::check_launch("eat_dw_conv_dgrad(tile)");
+}
+
 // ---- weight gradient on the same ownership: dw[c][u][v] = sum_{b,i,j} dz[b,c,i,j] * x[b,c,i*S+u-P,j*S+v-P] -----------
 // One wave walks G plane groups of ONE channel (different samples), each lane accumulating its K*K partial products in
 // registers (the extended rows are the forward kernel's: DPP neighbours, vertical taps by register reuse); one
@@ -377,6 +615,135 @@ __global__ __launch_bounds__(256) void dw_plane_wgrad_kernel(const PlaneWgArgs a
   if (!a.per_plane) flush(-1);
 }
 
+// tile form of the weight gradient for large planes: one wave = (channel, tile, G samples)
+struct TileWgArgs {
+  const float* dz; const float* x; float* dw;
+  int B, C, F, T, Fo, To, n_rc, n_cs, WO, G, per_plane;
+};
+
+template <int K, int S, int RO>
+__global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const TileWgArgs a) {
+  constexpr int P = (K - 1) / 2, CPL = 2, LPP = 64;
+  constexpr int NE = S == 1 ? CPL + 2 * P : K;
+  constexpr int NO = S == 1 ? 2 : 1;
+  constexpr int FI = (RO - 1) * S + K;
+  constexpr int KK = K * K;
+  const int l = threadIdx.x & 63;
+  const bool first = l == 0, last = l == 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int tpp = a.n_rc * a.n_cs;
+  const int n_sg = (a.B + a.G - 1) / a.G;
+  if (wave >= n_sg * a.C * tpp) return;
+  // consecutive waves: the tiles of one plane, then the next channel, then the next sample group
+  const int pc = wave / tpp, t = wave - pc * tpp;
+  const int sg = pc / a.C, c = pc - sg * a.C;
+  const int rc = t / a.n_cs, cs = t - rc * a.n_cs;
+  const int F = a.F, T = a.T, Fo = a.Fo, To = a.To;
+  const int o_lo = cs * a.WO, o_hi = (o_lo + a.WO) < To ? (o_lo + a.WO) : To;
+  const int c0 = (S == 1 ? o_lo : 2 * o_lo) - 2;
+  const int col_in = c0 + 2 * l;
+  const unsigned vin = (col_in >= 0 && col_in < T) ? 4u * (unsigned)col_in : kOOB;
+  const bool in_part = col_in + 1 >= T;
+  const int oc = S == 1 ? col_in : o_lo - 1 + l;
+  const bool ok0 = oc >= o_lo && oc < o_hi, ok1 = NO == 2 && oc + 1 >= o_lo && oc + 1 < o_hi;
+  // dz: an 8-byte load needs its first column inside the tensor; a lane whose first column is a halo column but whose
+  // second is valid does not occur (halo lanes are whole lanes on the left, and the right edge only drops column 1)
+  const unsigned vdz = ok0 ? 4u * (unsigned)oc : kOOB;
+  const int r0o = rc * RO, r0i = r0o * S - P;
+  float acc[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) acc[i] = 0.0f;
+
+  auto flush = [&](int plane) {
+    float mine_v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) {
+      const float v = eat::wave_sum(acc[i]);
+      mine_v = l == i ? v : mine_v;
+      acc[i] = 0.0f;
+    }
+    if (l < KK) atomicAdd(a.dw + (size_t)(a.per_plane ? plane : c) * KK + l, mine_v);
+  };
+
+  for (int gi = 0; gi < a.G; ++gi) {
+    const int b = sg * a.G + gi;
+    if (b >= a.B) break;
+    const int p = b * a.C + c;
+    const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
+    const long long z_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * Fo * To, z_left);
+    float r[FI][CPL], d[RO][NO];
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      const int rin = r0i + i;
+      const bool rok = rin >= 0 && rin < F;
+      const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
+      r[i][0] = pv[0];
+      r[i][1] = in_part ? 0.0f : pv[1];
+    }
+#pragma unroll
+    for (int i = 0; i < RO; ++i) {
+      const int ro = r0o + i;
+      const bool rok = ro < Fo;
+      if constexpr (NO == 1) {
+        d[i][0] = buf_load(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(ro * To) : 0u);
+      } else {
+        const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(ro * To) : 0u);
+        d[i][0] = pv[0];
+        d[i][1] = ok1 ? pv[1] : 0.0f;
+      }
+    }
+    float ext[FI][NE];
+#pragma unroll
+    for (int i = 0; i < RO; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int lo = i == 0 ? 0 : (i - 1) * S + K;
+      const int hi = i * S + K - 1;
+#pragma unroll
+      for (int rr = 0; rr < FI; ++rr) {
+        if (rr < lo || rr > hi) continue;
+#pragma unroll
+        for (int tt = 0; tt < NE; ++tt) {
+          const int o = tt - P;
+          const int q = o >= 0 ? o / CPL : -((-o + CPL - 1) / CPL);
+          const int idx = o - q * CPL;
+          float v = r[rr][idx];
+          if (q == -1) v = from_prev<LPP>(v, first);
+          if (q == 1) v = from_next<LPP>(v, last);
+          ext[rr][tt] = v;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u)
+#pragma unroll
+        for (int v = 0; v < K; ++v)
+#pragma unroll
+          for (int j = 0; j < NO; ++j) acc[u * K + v] = fmaf(d[i][j], ext[i * S + u][j + v], acc[u * K + v]);
+    }
+    if (a.per_plane) flush(p);
+  }
+  if (!a.per_plane) flush(0);
+}
+
+template <int K, int S, int RO>
+int launch_tile_wgrad(TileWgArgs a, hipStream_t s) {
+  constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : (K == 3 ? 63 : 62);
+  a.n_cs = (a.To + WMAX - 1) / WMAX;
+  a.WO = (a.To + a.n_cs - 1) / a.n_cs;
+  a.n_rc = (a.Fo + RO - 1) / RO;
+  int G = 1;
+  if (!a.per_plane) {
+    G = 8;
+    while (G > 1 && (long long)a.C * a.n_rc * a.n_cs * ((a.B + G - 1) / G) < 8192) G >>= 1;
+  }
+  a.G = G;
+  const long long waves = (long long)((a.B + G - 1) / G) * a.C * a.n_rc * a.n_cs;
+  if (waves > 0x7fffffffLL) return 1;
+  hipLaunchKernelGGL((dw_tile_wgrad_kernel<K, S, RO>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  return eat::check_launch("eat_dw_conv_wgrad(tile)");
+}
+
 template <int K, int S, int CPL, int LPP, int F>
 int launch_plane_wgrad(const PlaneWgArgs& a0, hipStream_t s) {
   PlaneWgArgs a = a0;
@@ -399,12 +766,21 @@ int launch_plane_wgrad(const PlaneWgArgs& a0, hipStream_t s) {
 namespace eat {
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B, int C,
-                 int F, int T, int Fo, int To, int k, int stride, int act, int flip, hipStream_t s) {
+                 int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, hipStream_t s) {
   static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
   if (off) return 1;
   const long long n_planes = (long long)B * C;
-  if (n_planes > 0x3fffffffLL) return 1;
-  if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only                 // plane bases are 64-bit, offsets inside a plane 32-bit
+  if (n_planes > 0x3fffffffLL) return 1;                 // plane bases are 64-bit, offsets inside a plane 32-bit
+  if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only
+  static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
+  if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {            // large planes: tiles of rows x column strips
+    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w};
+    if (k == 3 && stride == 1) return launch_tile<3, 1, 16>(ta, w, bias, act, s);
+    if (k == 5 && stride == 1) return launch_tile<5, 1, 16>(ta, w, bias, act, s);
+    if (k == 3 && stride == 2) return launch_tile<3, 2, 8>(ta, w, bias, act, s);
+    if (k == 5 && stride == 2) return launch_tile<5, 2, 8>(ta, w, bias, act, s);
+  }
+  if (per_plane_w) return 1;                             // whole-plane kernels below: per-channel taps only
   PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane<3, 1, 1, 64, 8, true>(a, s);
   static const int pfb = getenv("EAT_DWP_PFB") ? atoi(getenv("EAT_DWP_PFB")) : 0;
@@ -422,6 +798,13 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
   static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
   if (off) return 1;
   if ((long long)B * C > 0x3fffffffLL) return 1;
+  static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
+  if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {
+    TileWgArgs ta{dz, x, dw, B, C, F, T, Fo, To, 0, 0, 0, 1, per_plane};
+    if (k == 3 && stride == 1) return launch_tile_wgrad<3, 1, 16>(ta, s);
+    if (k == 3 && stride == 2) return launch_tile_wgrad<3, 2, 8>(ta, s);
+    if (k == 5 && stride == 2) return launch_tile_wgrad<5, 2, 8>(ta, s);
+  }
   PlaneWgArgs a{dz, x, dw, B, C, T, To, 1, per_plane};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane_wgrad<3, 1, 1, 64, 8>(a, s);
   if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128) return launch_plane_wgrad<5, 1, 2, 64, 16>(a, s);
@@ -429,6 +812,16 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
   if (k == 3 && stride == 2 && F == 16 && T > 64 && T <= 128) return launch_plane_wgrad<3, 2, 2, 64, 16>(a, s);
   if (k == 5 && stride == 1 && F == 4 && T <= 32) return launch_plane_wgrad<5, 1, 1, 32, 4>(a, s);
   (void)Fo;
+  return 1;
+}
+
+int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
+                       int To, int k, int per_plane_w, hipStream_t s) {
+  static const int on = getenv("EAT_DWP_DGRAD2") ? atoi(getenv("EAT_DWP_DGRAD2")) : 1;
+  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
+  TileDgArgs a{dz, res, dx, B, C, F, T, Fo, To, 0, 0, 0, per_plane_w};
+  if (k == 3) return launch_tile_dgrad2<3>(a, w, s);
+  if (k == 5) return launch_tile_dgrad2<5>(a, w, s);
   return 1;
 }
 

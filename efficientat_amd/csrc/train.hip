@@ -899,6 +899,9 @@ static int dw_dgrad_impl(const float* dz, const float* w, const float* res, floa
     return eat::dw_conv_dgrad_s1(dz, w, nullptr, res, dx, B, C, F, T, k, per_plane_w, s);
   }
   if (stride == 2 && (k == 3 || k == 5)) {
+    // tile kernel (dw_plane.hip): one dz column per lane, dx row segments as 8-byte stores; 1 = not applicable
+    const int rc = eat::dw_tile_dgrad2_try(dz, w, res, dx, B, C, F, T, Fo, To, k, per_plane_w, s);
+    if (rc != 1) return rc;
     dim3 g2((T + 63) / 64, (B * C + 3) / 4);
     if (k == 3) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3>), g2, dim3(256), 0, s, dz, w, res, dx, B * C, C, F, T, Fo, To, per_plane_w);
     else hipLaunchKernelGGL((dw_dgrad_s2_kernel<5>), g2, dim3(256), 0, s, dz, w, res, dx, B * C, C, F, T, Fo, To, per_plane_w);

@@ -129,7 +129,7 @@ def test_dyrelu_coordatt_backward():
 # dw shapes: a generic one plus every geometry of the register-resident plane kernels (dw_plane.hip: forward, data and
 # per-plane weight gradient), with odd sample counts for the two-planes-per-wave forms
 @pytest.mark.parametrize("kind", ["pw", "dw", (7, 8, 63, 3, 1), (5, 16, 125, 5, 1), (6, 8, 63, 5, 2), (9, 16, 125, 3, 2),
-                                  (10, 4, 32, 5, 1), (3, 4, 20, 5, 1)])
+                                  (10, 4, 32, 5, 1), (3, 4, 20, 5, 1), (6, 32, 250, 3, 1), (4, 32, 250, 5, 2), (3, 20, 300, 3, 2)])
 def test_dynamic_conv_backward(kind):
     from efficientat_amd.dymn_train import DynDwConv, DynPwConv
     B, K = 3, 4

@@ -118,7 +118,9 @@ def test_stem_conv(B, C, F_, T):
     (1, 8, 7, 9, 3, 2, 0), (2, 5, 1, 3, 5, 1, 2), (1, 3, 33, 700, 5, 2, 1),
     # register-resident plane kernel (dw_plane.hip): odd plane counts, narrower planes, full-width planes
     (1, 3, 4, 32, 5, 1, 1), (3, 7, 4, 20, 5, 1, 2), (1, 5, 8, 40, 3, 1, 0), (3, 11, 8, 64, 3, 1, 2), (1, 9, 16, 100, 5, 1, 1),
-    (2, 3, 16, 128, 5, 1, 2), (1, 7, 8, 50, 5, 2, 1), (3, 5, 8, 64, 5, 2, 2), (1, 3, 16, 128, 3, 2, 0), (2, 9, 16, 77, 3, 2, 2)])
+    (2, 3, 16, 128, 5, 1, 2), (1, 7, 8, 50, 5, 2, 1), (3, 5, 8, 64, 5, 2, 2), (1, 3, 16, 128, 3, 2, 0), (2, 9, 16, 77, 3, 2, 2),
+    # tile kernel (large planes): strip / row-chunk boundaries, ragged last strips and row chunks
+    (1, 3, 17, 129, 3, 1, 1), (2, 5, 40, 251, 5, 1, 2), (1, 4, 31, 253, 3, 2, 0), (1, 3, 20, 375, 5, 2, 1), (1, 2, 64, 1000, 3, 1, 2)])
 def test_dw_conv(B, C, F_, T, k, s, act):
     x, w, b = _rand(B, C, F_, T, seed=1), _rand(C, 1, k, k, seed=2, scale=0.3), _rand(C, seed=3, scale=0.1)
     ref = F.conv2d(x, w, b, s, (k - 1) // 2, 1, C)

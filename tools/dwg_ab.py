@@ -5,7 +5,8 @@ import torch
 from efficientat_amd import _lib, ops
 dev = torch.device("cuda:0")
 def s(): return torch.cuda.current_stream().cuda_stream
-cases = [(256, 200, 8, 63, 3, 1), (256, 672, 8, 63, 3, 1), (256, 120, 16, 125, 5, 1), (256, 672, 8, 63, 5, 2), (256, 240, 16, 125, 3, 2),
+cases = [(256, 16, 64, 500, 3, 1), (256, 64, 64, 500, 3, 2), (256, 72, 32, 250, 3, 1), (256, 72, 32, 250, 5, 2), (128, 128, 64, 500, 3, 2),
+         (256, 200, 8, 63, 3, 1), (256, 672, 8, 63, 3, 1), (256, 120, 16, 125, 5, 1), (256, 672, 8, 63, 5, 2), (256, 240, 16, 125, 3, 2),
          (256, 960, 4, 32, 5, 1), (128, 1920, 4, 32, 5, 1), (128, 1344, 8, 63, 5, 2), (128, 240, 16, 125, 5, 1)]
 for B, C, F, T, k, st in cases:
     Fo, To = ops.conv_out(F, k, st), ops.conv_out(T, k, st)
