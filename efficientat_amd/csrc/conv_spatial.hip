@@ -184,10 +184,11 @@ int dispatch_dw(const float* x, const float* w, const float* bias, float* y, flo
   const int p = (k - 1) / 2;
   if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
     return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: output %dx%d inconsistent with input %dx%d k=%d s=%d", Fo, To, F, T, k, stride);
-  if (!dyn || (!dyn->coef && !dyn->in_a)) {
+  if (!dyn || !dyn->coef) {
     // register-resident kernels (dw_plane.hip: whole small planes, tiles of large ones); 1 = geometry not instantiated
     const int rc = eat::dw_plane_try(x, w, bias, dyn ? dyn->res : nullptr, y, pool, B, C, F, T, Fo, To, k, stride, act,
-                                     dyn ? dyn->flip : 0, dyn ? dyn->per_plane_w : 0, s);
+                                     dyn ? dyn->flip : 0, dyn ? dyn->per_plane_w : 0, dyn ? dyn->in_a : nullptr,
+                                     dyn ? dyn->in_b : nullptr, dyn ? dyn->in_act : 0, s);
     if (rc != 1) return rc;
   }
   if (k == 3 && stride == 1) return launch_dw<3, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);

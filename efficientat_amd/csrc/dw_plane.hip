@@ -36,9 +36,31 @@ __device__ __forceinline__ float from_next(float v, bool last) {
   return (LPP < 64 && last) ? 0.0f : r;
 }
 
+// Optional transform of the conv INPUT, evaluated once per loaded element: act_in(in_a[c] * x + in_b[c]) - the train-mode
+// BatchNorm + activation of the expand conv, so that the activated tensor is never written (mn_train.py,
+// EAT_FUSE_EXPAND_BN).  Zero padding applies to the transformed map: elements outside the plane stay 0.
+struct InTf {
+  const float* a; const float* b; int act;
+};
+struct TfCoef { float a, b, lo, ca, cb; };
+__device__ __forceinline__ TfCoef tf_coef(const InTf& t, int c) {
+  TfCoef k;
+  k.a = t.a[c]; k.b = t.b[c];
+  k.lo = t.act == EAT_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+  k.ca = t.act == EAT_ACT_HSWISH ? (1.0f / 6.0f) : 0.0f;
+  k.cb = t.act == EAT_ACT_HSWISH ? 0.5f : 1.0f;
+  return k;
+}
+__device__ __forceinline__ float tf_apply(float v, const TfCoef& k, bool valid) {
+  const float u = fmaf(k.a, v, k.b);
+  const float y = fmaxf(u, k.lo) * __builtin_amdgcn_fmed3f(fmaf(u, k.ca, k.cb), 0.0f, 1.0f);
+  return valid ? y : 0.0f;
+}
+
 struct PlaneArgs {
   const float* x; const float* w; const float* bias; const float* res; float* y; float* pool;
   int B, C, T, To, G, flip, act;
+  InTf tf;
 };
 
 
@@ -128,9 +150,18 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
     }
   };
 
-  auto compute = [&](int g, const float (&r)[F][CPL]) {
+  auto compute = [&](int g, float (&r)[F][CPL]) {
     int c; bool mine;
     const int p = plane_of(g, c, mine);
+    if (a.tf.a) {                                          // wave-uniform
+      const TfCoef tk = tf_coef(a.tf, c);
+      const bool v0 = mine && vin != kOOB, v1 = v0 && !in_part;
+#pragma unroll
+      for (int i = 0; i < F; ++i) {
+        r[i][0] = tf_apply(r[i][0], tk, v0);
+        if constexpr (CPL == 2) r[i][1] = tf_apply(r[i][1], tk, v1);
+      }
+    }
     // taps and bias of the (wave-uniform) channel: scalar loads, issued while the rows of the plane are still in flight
     float wk[K * K];
 #pragma unroll
@@ -258,6 +289,7 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
 struct TileArgs {
   const float* x; const float* res; float* y; float* pool;
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, flip, per_plane_w;
+  InTf tf;
 };
 
 template <int K, int S, int RO, int ACT, bool RES>
@@ -302,6 +334,16 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
     const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
     r[i][0] = pv[0];
     r[i][1] = in_part ? 0.0f : pv[1];
+  }
+  if (a.tf.a) {                                            // wave-uniform
+    const TfCoef tk = tf_coef(a.tf, c);
+    const bool v0 = vin != kOOB, v1 = v0 && !in_part;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      const bool rok = r0i + i >= 0 && r0i + i < F;
+      r[i][0] = tf_apply(r[i][0], tk, rok && v0);
+      r[i][1] = tf_apply(r[i][1], tk, rok && v1);
+    }
   }
   float wk[K * K];
   const int wb = a.per_plane_w ? p : c;
@@ -495,6 +537,7 @@ int launch_tile_dgrad2(TileDgArgs a, const float* w, hipStream_t s) {
 struct PlaneWgArgs {
   const float* dz; const float* x; float* dw;
   int B, C, T, To, G, per_plane;
+  InTf tf;
 };
 
 template <int K, int S, int CPL, int LPP, int F>
@@ -568,6 +611,15 @@ __global__ __launch_bounds__(256) void dw_plane_wgrad_kernel(const PlaneWgArgs a
         r[i][1] = in_part ? 0.0f : pv[1];
       }
     }
+    if (a.tf.a) {                                          // wave-uniform
+      const TfCoef tk = tf_coef(a.tf, c);
+      const bool v0 = vx != kOOB, v1 = v0 && !in_part;
+#pragma unroll
+      for (int i = 0; i < F; ++i) {
+        r[i][0] = tf_apply(r[i][0], tk, v0);
+        if constexpr (CPL == 2) r[i][1] = tf_apply(r[i][1], tk, v1);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < Fo; ++i) {
       if constexpr (NO == 1) {
@@ -619,6 +671,7 @@ __global__ __launch_bounds__(256) void dw_plane_wgrad_kernel(const PlaneWgArgs a
 struct TileWgArgs {
   const float* dz; const float* x; float* dw;
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, G, per_plane;
+  InTf tf;
 };
 
 template <int K, int S, int RO>
@@ -681,6 +734,16 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const TileWgArgs a) 
       const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
       r[i][0] = pv[0];
       r[i][1] = in_part ? 0.0f : pv[1];
+    }
+    if (a.tf.a) {                                          // wave-uniform
+      const TfCoef tk = tf_coef(a.tf, c);
+      const bool v0 = vin != kOOB, v1 = v0 && !in_part;
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const bool rok = r0i + i >= 0 && r0i + i < F;
+        r[i][0] = tf_apply(r[i][0], tk, rok && v0);
+        r[i][1] = tf_apply(r[i][1], tk, rok && v1);
+      }
     }
 #pragma unroll
     for (int i = 0; i < RO; ++i) {
@@ -766,7 +829,8 @@ int launch_plane_wgrad(const PlaneWgArgs& a0, hipStream_t s) {
 namespace eat {
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B, int C,
-                 int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, hipStream_t s) {
+                 int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
+                 const float* in_b, int in_act, hipStream_t s) {
   static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
   if (off) return 1;
   const long long n_planes = (long long)B * C;
@@ -774,14 +838,14 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
   if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only
   static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
   if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {            // large planes: tiles of rows x column strips
-    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w};
+    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w, InTf{in_a, in_b, in_act}};
     if (k == 3 && stride == 1) return launch_tile<3, 1, 16>(ta, w, bias, act, s);
     if (k == 5 && stride == 1) return launch_tile<5, 1, 16>(ta, w, bias, act, s);
     if (k == 3 && stride == 2) return launch_tile<3, 2, 8>(ta, w, bias, act, s);
     if (k == 5 && stride == 2) return launch_tile<5, 2, 8>(ta, w, bias, act, s);
   }
   if (per_plane_w) return 1;                             // whole-plane kernels below: per-channel taps only
-  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act};
+  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane<3, 1, 1, 64, 8, true>(a, s);
   static const int pfb = getenv("EAT_DWP_PFB") ? atoi(getenv("EAT_DWP_PFB")) : 0;
   if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128)
@@ -794,18 +858,18 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
 }
 
 int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
-                       int stride, int per_plane, hipStream_t s) {
+                       int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s) {
   static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
   if (off) return 1;
   if ((long long)B * C > 0x3fffffffLL) return 1;
   static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
   if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {
-    TileWgArgs ta{dz, x, dw, B, C, F, T, Fo, To, 0, 0, 0, 1, per_plane};
+    TileWgArgs ta{dz, x, dw, B, C, F, T, Fo, To, 0, 0, 0, 1, per_plane, InTf{in_a, in_b, in_act}};
     if (k == 3 && stride == 1) return launch_tile_wgrad<3, 1, 16>(ta, s);
     if (k == 3 && stride == 2) return launch_tile_wgrad<3, 2, 8>(ta, s);
     if (k == 5 && stride == 2) return launch_tile_wgrad<5, 2, 8>(ta, s);
   }
-  PlaneWgArgs a{dz, x, dw, B, C, T, To, 1, per_plane};
+  PlaneWgArgs a{dz, x, dw, B, C, T, To, 1, per_plane, InTf{in_a, in_b, in_act}};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane_wgrad<3, 1, 1, 64, 8>(a, s);
   if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128) return launch_plane_wgrad<5, 1, 2, 64, 16>(a, s);
   if (k == 5 && stride == 2 && F == 8 && T > 32 && T <= 64) return launch_plane_wgrad<5, 2, 2, 32, 8>(a, s);

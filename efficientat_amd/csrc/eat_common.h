@@ -59,9 +59,10 @@ int irb_try(const float* x, const float* wp_e, const float* bias_e, const float*
             int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s);
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B,
-                 int C, int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, hipStream_t s);
+                 int C, int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
+                 const float* in_b, int in_act, hipStream_t s);
 int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
-                       int stride, int per_plane, hipStream_t s);
+                       int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s);
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s);
 int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,

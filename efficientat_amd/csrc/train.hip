@@ -938,9 +938,10 @@ static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int 
   if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
   static const bool old_kernel = getenv("EAT_DW_WGRAD_OLD") && atoi(getenv("EAT_DW_WGRAD_OLD")) != 0;
   if (in_a && (XC != C || old_kernel)) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: needs the column-walking kernel");
-  if (XC == C && !in_a && !old_kernel) {
-    // small late-layer planes: one wave per plane, every element loaded once (dw_plane.hip); 1 = geometry not instantiated
-    const int rc = eat::dw_plane_wgrad_try(dz, x, dw, B, C, F, T, Fo, To, k, stride, per_sample, (hipStream_t)stream);
+  if (XC == C && !old_kernel) {
+    // register-resident kernels (dw_plane.hip): every element loaded once; 1 = geometry not instantiated
+    const int rc = eat::dw_plane_wgrad_try(dz, x, dw, B, C, F, T, Fo, To, k, stride, per_sample, in_a, in_b, in_act,
+                                           (hipStream_t)stream);
     if (rc != 1) return rc;
   }
   if (XC == C && !old_kernel && !per_sample && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {

@@ -48,10 +48,11 @@ _zeros = _Zeros()
 
 
 # expand conv's BN + activation evaluated inside the depthwise conv / its weight gradient instead of a separate
-# bn_act_fwd pass (saves writing + re-reading the activated tensor).  OFF by default: measured 25.8 vs 24.6 ms per
-# mn10 step on MI355X - the activation is re-evaluated for each of the k taps a loaded value feeds, and the
-# depthwise kernels are issue/latency-bound, so the extra VALU work costs more than the saved 5.7 GB.
-_FUSE_EXPAND_BN = os.environ.get("EAT_FUSE_EXPAND_BN", "0") == "1"
+# bn_act_fwd pass (saves writing + re-reading the activated tensor: 2 of the 10 forward passes over expanded tensors).
+# Round 1 measured this SLOWER (25.8 vs 24.6 ms per mn10 step): the row-ring depthwise kernels load every element K
+# times and re-evaluated the activation for each.  The register-resident kernels (csrc/dw_plane.hip) load - and
+# transform - every element once: 35.8 vs 37.9 ms per step at B = 256, so it is ON by default now (=0: A/B).
+_FUSE_EXPAND_BN = os.environ.get("EAT_FUSE_EXPAND_BN", "1") == "1"
 
 
 class _GradSink:

@@ -256,14 +256,16 @@ def test_train_step_updates_weights_and_eval_follows(golden_dir):
 
 
 @pytest.mark.parametrize("B,C,F_,T,k,s,act", [(2, 64, 32, 100, 3, 2, 1), (3, 120, 16, 125, 5, 1, 2), (2, 672, 8, 63, 5, 2, 2),
-                                              (2, 40, 9, 21, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1)])
+                                              (2, 40, 9, 21, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1), (2, 16, 64, 500, 3, 1, 1),
+                                              (2, 200, 8, 63, 3, 1, 2), (3, 96, 4, 32, 5, 1, 2), (2, 240, 16, 125, 3, 2, 2),
+                                              (1, 5, 33, 300, 3, 2, 1), (2, 24, 32, 250, 3, 1, 0)])
 def test_dw_conv_with_input_transform(B, C, F_, T, k, s, act):
     """Depthwise conv / weight gradient whose input is act(a[c] x + b[c]) evaluated on load (eat_dw_conv_fwd_tf,
     eat_dw_conv_wgrad_tf) vs materialising the activated tensor first (zero padding applies to the activated map)."""
     x, w = _rand(B, C, F_, T, seed=1), _rand(C, 1, k, k, seed=2, scale=0.3)
     a = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5
     b = _rand(C, seed=4, scale=0.5)
-    f = [None, F.relu, F.hardswish][act]
+    f = [lambda v: v, F.relu, F.hardswish][act]
     xa = f(x.double() * a.double().view(1, C, 1, 1) + b.double().view(1, C, 1, 1))
     ref = F.conv2d(xa, w.double(), None, s, (k - 1) // 2, 1, C)
     wd = w.reshape(C, k * k).contiguous().to(DEV)
