@@ -606,6 +606,9 @@ __device__ __forceinline__ void wg_glds16(const void* g, void* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory", "m0");
 }
 
+// NPROD = 3: split operands (hi*hi + hi*lo + lo*hi, fp32-class); NPROD = 1: plain bf16 operands, fp32 accumulation
+// (train_precision "bf16", BASELINE configs[2] - what autocast does to the conv weight gradient in the reference)
+template <int NPROD>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                              const float* __restrict__ xscale, float* __restrict__ dW,
                                                              int B, int Co, int Ci, int S, int sps, int units_per_block,
@@ -684,7 +687,15 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
         const float v[8] = {q0 ? t0.x * scale : 0.0f, q0 ? t0.y * scale : 0.0f, q0 ? t0.z * scale : 0.0f,
                             q0 ? t0.w * scale : 0.0f, q1 ? t1.x * scale : 0.0f, q1 ? t1.y * scale : 0.0f,
                             q1 ? t1.z * scale : 0.0f, q1 ? t1.w * scale : 0.0f};
-        split8(v, hi, lo);
+        if constexpr (NPROD == 3) {
+          split8(v, hi, lo);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) {
+            const bf16x2_t h = __builtin_convertvector(f32x2_t{v[i], v[i + 1]}, bf16x2_t);
+            hi[i] = h[0]; hi[i + 1] = h[1];
+          }
+        }
       };
       bf16x8_t bh[4], bl[4];
 #pragma unroll
@@ -702,8 +713,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
           for (int j = 0; j < 4; ++j) {
             if (j < nt_n) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+              if constexpr (NPROD == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+              }
             }
           }
         }
@@ -1008,7 +1021,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   // default: split-operand bf16 MFMA kernel (fp32-class accuracy); exact_fp32 (the caller's precision choice),
   // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
-  const bool force_fp32 = env_fp32 || exact_fp32 != 0;
+  const bool force_fp32 = env_fp32 || exact_fp32 == 1;      // exact_fp32: 0 = bf16x3, 1 = exact fp32, 2 = plain bf16
   // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs): the bf16x3 kernel with one block per (tile, sample)
   // and plain stores from Co, Ci >= 64 on (round 1 measured it with atomics on every sample's tile: 163 vs 115 ms per
   // dymn20 step; EAT_DYN_WGRAD_X3=0 restores the 32 x 32-tile fp32 kernel)
@@ -1034,8 +1047,12 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
       hipLaunchKernelGGL(pw_wgrad_x3_narrow_kernel, dim3(1, 1, (unsigned)((total + upb - 1) / upb)), dim3(256), 0,
                          (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, sps, upb);
     } else {
-      hipLaunchKernelGGL(pw_wgrad_x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, sps,
-                         upb, per_sample);
+      if (exact_fp32 == 2)
+        hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
+                           sps, upb, per_sample);
+      else
+        hipLaunchKernelGGL(pw_wgrad_x3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
+                           sps, upb, per_sample);
     }
     return eat::check_launch("eat_pw_conv_wgrad");
   }

@@ -228,15 +228,17 @@ def dw_conv_wgrad_tf(dz, x, in_a, in_b, in_act, k, stride):
 
 def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
     """dW (Co, Ci) = sum_b dz[b] (Co,S) . (x[b] * x_scale[b])^T.  exact=True: fp32 MFMA kernel; False: split-operand
-    bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact)."""
+    bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact, 'bf16' -> plain bf16
+    operands with fp32 accumulation, as autocast does to the conv weight gradient; otherwise bf16x3)."""
+    mode = 1 if exact else 0
     if exact is None:
-        exact = precision.mode == "fp32"
+        mode = {"fp32": 1, "bf16": 2}.get(precision.mode, 0)
     B, Co = dz.shape[0], dz.shape[1]
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
     dW = torch.zeros((Co, Ci), device=dz.device, dtype=torch.float32)
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
-              S, 1 if exact else 0, _stream())
+              S, mode, _stream())
     return dW
 
 

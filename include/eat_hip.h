@@ -160,7 +160,8 @@ int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, 
 /* autograd of the 1x1 Conv2d layers (models/mn/block_types.py:138-147,167-171; mn/model.py:159-167):
  * Pointwise weight gradient dW (Co,Ci) += sum_{b,s} dz[b,co,s] * x[b,ci,s] * x_scale[b,ci]
  * (exact_fp32 = 0: split-operand bf16 MFMA with fp32-class accuracy; exact_fp32 = 1, or a plane size that is not a
- * multiple of 4: exact fp32 MFMA; x_scale (B,Ci) or NULL is the SE scale the forward applied to x); dW must be
+ * multiple of 4: exact fp32 MFMA; exact_fp32 = 2: plain bf16 operands with fp32 accumulation - the arithmetic autocast
+ * gives the conv weight gradient in the reference's bf16 training; x_scale (B,Ci) or NULL is the SE scale the forward applied to x); dW must be
  * zeroed by the caller.  The data gradient is eat_pw_conv_fwd with the packed W^T. */
 int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
                       int Ci, int S, int exact_fp32, eat_stream_t stream);

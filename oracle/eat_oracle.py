@@ -122,8 +122,8 @@ def _bn(sd, prefix, x, train, stats=None):
 class _PwBf16(torch.autograd.Function):
     """1x1 conv on bf16-rounded operands with fp32 accumulation - the arithmetic of `train_precision="bf16"`
     (BASELINE configs[2]: bf16 MFMA 1x1 GEMMs, fp32 activations in memory): forward rounds x and W to bf16, the data
-    gradient rounds dz and W, the weight gradient keeps fp32-class operands (the product path runs it on the
-    split-operand bf16x3 kernel).  Lets the tests anchor the bf16 path on an ORACLE evaluation of the same arithmetic."""
+    gradient rounds dz and W, the weight gradient rounds dz and x (what autocast does to all three conv GEMMs in the
+    reference's bf16 training).  Lets the tests anchor the bf16 path on an ORACLE evaluation of the same arithmetic."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -134,7 +134,7 @@ class _PwBf16(torch.autograd.Function):
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
         dx = F.conv_transpose2d(dz.bfloat16().float(), w.bfloat16().float())
-        dw = torch.einsum("bohw,bihw->oi", dz, x).reshape(w.shape)
+        dw = torch.einsum("bohw,bihw->oi", dz.bfloat16().float(), x.bfloat16().float()).reshape(w.shape)
         return dx, dw
 
 
