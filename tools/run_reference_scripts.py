@@ -14,6 +14,7 @@ import argparse
 import csv
 import os
 import pickle
+import re
 import subprocess
 import sys
 import tempfile
@@ -74,6 +75,20 @@ def build_workdir(work, n_train=48, n_test=527):
     return dict(EAT_SYNTH_AUDIOSET_TRAIN=str(n_train), EAT_SYNTH_AUDIOSET_TEST=str(n_test))
 
 
+def _drop_repr(text):
+    """The reference's get_model prints the whole module tree: keep the log readable (one line instead of ~350)."""
+    out, skip = [], False
+    for line in text.splitlines():
+        if not skip and re.match(r"^(MN|DyMN)\($", line):
+            skip = True
+            out.append(line + " ... module tree (printed by the reference's get_model) elided ... )")
+        elif skip:
+            skip = line != ")"
+        else:
+            out.append(line)
+    return "\n".join(out)
+
+
 def run_script(ref, script, argv, work, extra_env=None, timeout=900):
     path = os.path.join(ref, script)
     boot = ("import sys, runpy; sys.path[:0] = %r; sys.argv = %r; runpy.run_path(%r, run_name='__main__')"
@@ -103,7 +118,7 @@ def main():
     for script, argv in runs:
         rc, out, err = run_script(a.ref, script, argv, work, env)
         tail = "\n".join(err.strip().splitlines()[-6:])
-        log.append(f"$ python {script} {' '.join(argv)}   [unmodified reference script, dropin/ modules]\nrc={rc}\n{out.strip()}\n--- stderr tail ---\n{tail}\n")
+        log.append(f"$ python {script} {' '.join(argv)}   [unmodified reference script, dropin/ modules]\nrc={rc}\n{_drop_repr(out.strip())}\n--- stderr tail ---\n{tail}\n")
         rc_all |= rc
     wl = os.path.join(work, "wandb_run", "wandb_log.jsonl")
     if os.path.exists(wl):
