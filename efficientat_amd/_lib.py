@@ -83,6 +83,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _I
         h.eat_version.restype = _I
+        h.eat_pw_stream_mode.argtypes = [_I]
+        h.eat_pw_stream_mode.restype = _I
         h.eat_last_error_string.restype = ctypes.c_char_p
         _lib = h
     return _lib
@@ -96,4 +98,4 @@ def call(name, *args):
 
 
 def exported_symbols():
-    return list(SIGNATURES) + ["eat_version", "eat_last_error_string"]
+    return list(SIGNATURES) + ["eat_version", "eat_last_error_string", "eat_pw_stream_mode"]

@@ -265,6 +265,10 @@ extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float*
   hipStream_t s = (hipStream_t)stream;
   if (S % 4 != 0)      // planes that do not start on 16-byte boundaries: plain 4-byte kernel on the same packs
     return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split ? 2 : 1, 0, s);
+  {
+    const int rc = eat::pw_stream_try(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split, s);
+    if (rc != 1) return rc;
+  }
   return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci)
                : dispatch<1>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci);
 }

@@ -352,6 +352,12 @@ def pw_prepack_bf16(w2d, row_scale=None, split=True):
     return wp
 
 
+def pw_stream_mode(mode=-1):
+    """Variant of the bf16 1x1 kernels (eat_pw_stream_mode): bit 0 expand-shaped layers on the x-resident kernel,
+    bit 1 project-shaped layers on the K-streaming kernel; returns the previous mode, a negative argument only queries."""
+    return _lib.lib().eat_pw_stream_mode(int(mode))
+
+
 def pw_conv_bf16(x, wp16, bias, Co, act, split=True, in_scale=None, res=None, pool=None, write=True):
     """1x1 conv on the bf16 matrix cores (split=True: bf16x3, fp32-class accuracy; False: plain bf16)."""
     B, Ci, F, T = x.shape

@@ -369,6 +369,71 @@ def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
     _close(got, ref.float(), 1e-5, "mbconv block")
 
 
+@pytest.fixture
+def pw_stream_all():
+    """Route the bf16 1x1 convs through the barrier-free kernels of csrc/conv_pw_stream.hip for one test."""
+    prev = ops.pw_stream_mode(3)
+    yield
+    ops.pw_stream_mode(prev)
+
+
+@pytest.mark.parametrize("split,tol", [(True, 3e-5), (False, 1.5e-2)])
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act", [
+    (3, 80, 200, 8, 63, 2), (3, 112, 672, 8, 63, 2), (2, 40, 240, 16, 125, 2), (2, 24, 72, 32, 250, 1),
+    (3, 80, 184, 8, 63, 0), (2, 40, 120, 16, 125, 1), (1, 16, 64, 64, 500, 1), (5, 128, 512, 4, 7, 2),
+    (7, 96, 200, 1, 4, 0), (3, 12, 24, 8, 63, 2), (130, 112, 672, 8, 63, 2), (2, 100, 1030, 8, 63, 1)])
+def test_pw_conv_bf16_expand_kernel(B, Ci, Co, F_, T, act, split, tol, pw_stream_all):
+    """x-resident kernel (pw_expand_kernel): every chunk count 1-4, ragged Co (200, 184, 1030 = 65 m-tiles: two row
+    chunks), ragged last column tile, column tiles that straddle samples, the row split for small grids (B=3) and the
+    single-row-chunk grid (B=130), all activations - same bars as the LDS-staged kernel."""
+    x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
+    bias, rs = _rand(Co, seed=3, scale=0.1), torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5
+    ref = F.conv2d(x.double(), (w * rs[:, None]).double().view(Co, Ci, 1, 1), bias.double()).float()
+    ref = [ref, F.relu(ref), F.hardswish(ref)][act]
+    wp = ops.pw_prepack_bf16(w.to(DEV), rs.to(DEV), split)
+    got = ops.pw_conv_bf16(x.to(DEV), wp, bias.to(DEV), Co, act, split)
+    _close(got, ref, tol, f"pw expand kernel split={split}")
+    # same arithmetic as the LDS-staged kernel: identical products, only the position of the bias add differs
+    prev = ops.pw_stream_mode(0)
+    old = ops.pw_conv_bf16(x.to(DEV), wp, bias.to(DEV), Co, act, split)
+    ops.pw_stream_mode(prev)
+    _close(got, old.cpu(), 2e-6, "expand kernel vs LDS-staged kernel")
+
+
+@pytest.mark.parametrize("split,tol", [(True, 3e-5), (False, 1.5e-2)])
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act,se,res,use_pool", [
+    (3, 184, 80, 8, 63, 0, False, True, False), (4, 672, 160, 4, 32, 0, True, False, False),
+    (5, 960, 160, 4, 32, 0, True, True, True), (2, 72, 40, 16, 125, 0, True, False, False),
+    (5, 672, 160, 4, 7, 0, True, False, True), (9, 960, 160, 2, 2, 0, True, True, True),
+    (2, 672, 112, 3, 63, 0, True, True, False), (3, 120, 40, 5, 125, 0, True, False, False),
+    (3, 480, 112, 8, 63, 0, True, False, False), (2, 240, 80, 8, 63, 0, False, False, False),
+    (2, 64, 64, 16, 125, 1, False, True, False), (3, 100, 96, 8, 63, 2, False, False, True),
+    (130, 200, 80, 8, 63, 0, False, True, False), (2, 36, 16, 32, 250, 0, False, True, False)])
+def test_pw_conv_bf16_kstream_kernel(B, Ci, Co, F_, T, act, se, res, use_pool, split, tol, pw_stream_all):
+    """K-streaming kernel (pw_kstream_kernel): 1-6 m-tiles per wave incl. the 7 = 4 + 3 and 10 = 5 + 5 row splits,
+    partial last chunk (Ci = 72, 100, 36, 184), SE scale, residual, pooled sums."""
+    x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
+    bias, rs = _rand(Co, seed=3, scale=0.1), torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5
+    sc = torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) if se else None
+    r = _rand(B, Co, F_, T, seed=6) if res else None
+    xs = x * sc[:, :, None, None] if se else x
+    ref = F.conv2d(xs.double(), (w * rs[:, None]).double().view(Co, Ci, 1, 1), bias.double()).float()
+    ref = [ref, F.relu(ref), F.hardswish(ref)][act]
+    if res:
+        ref = ref + r
+    wp = ops.pw_prepack_bf16(w.to(DEV), rs.to(DEV), split)
+    args = dict(in_scale=None if sc is None else sc.to(DEV), res=None if r is None else r.to(DEV))
+    pool = torch.zeros(B, Co, device=DEV) if use_pool else None
+    got = ops.pw_conv_bf16(x.to(DEV), wp, bias.to(DEV), Co, act, split, pool=pool, **args)
+    _close(got, ref, tol, f"pw kstream kernel split={split}")
+    if use_pool:
+        _close(pool, ref.sum(dim=(2, 3)), 20 * tol, "pw kstream pool")
+    prev = ops.pw_stream_mode(0)
+    old = ops.pw_conv_bf16(x.to(DEV), wp, bias.to(DEV), Co, act, split, **args)
+    ops.pw_stream_mode(prev)
+    _close(got, old.cpu(), 2e-6, "kstream kernel vs LDS-staged kernel")
+
+
 @pytest.mark.parametrize("split,tol", [(True, 3e-5), (False, 1.5e-2)])
 @pytest.mark.parametrize("B,Ci,Co,F_,T,act,se,res", [
     (3, 80, 200, 8, 63, 2, False, False), (3, 184, 80, 8, 63, 0, False, True), (3, 112, 672, 8, 63, 2, False, False),
