@@ -266,7 +266,7 @@ extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float*
   if (S % 4 != 0)      // planes that do not start on 16-byte boundaries: plain 4-byte kernel on the same packs
     return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split ? 2 : 1, 0, s);
   {
-    const int rc = eat::pw_stream_try(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split, s);
+    const int rc = eat::pw_stream_try(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, split, Ci, s);
     if (rc != 1) return rc;
   }
   return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci)
@@ -285,6 +285,11 @@ extern "C" int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float*
   if (S % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: S=%d must be a multiple of 4", S);
   if (nbank < 1 || B < 1 || Co < 1 || !att_scale) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: bad arguments");
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_kcat_fwd: bad act %d", act);
+  {
+    const int rc = eat::pw_stream_try(x, wp, bias, att_scale, res, y, nullptr, B, nbank * Ci, Co, S, act, 1, Ci,
+                                      (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   return dispatch<3>((hipStream_t)stream, x, reinterpret_cast<const __bf16*>(wp), bias, att_scale, res, y, nullptr, B,
                      nbank * Ci, Co, S, act, Ci);
 }

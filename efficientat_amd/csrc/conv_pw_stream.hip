@@ -231,7 +231,9 @@ template <int MTW, int NPROD, bool SCALE>
 __global__ __launch_bounds__(256, (MTW <= 2 ? 3 : 2)) void pw_kstream_kernel(
     const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y, float* __restrict__ pool,
-    int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int act) {
+    int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int act, int ci_x) {
+  // ci_x: channels of x.  ci_x == Ci: plain 1x1 conv.  ci_x < Ci: DyMN "K-concat" (conv_pw_bf16.hip): k = bank * ci_x + ci,
+  // the scale (B, Ci) carries the attention; ci_x % 32 == 0, so a chunk never straddles two banks.
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
   __shared__ float s_bias[128];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256, (MTW <= 2 ? 3 : 2)) void pw_kstream_kernel(
 
   const ColGeom g = col_geom(tile, wv, lane, B, S);
   const int kq = lane >> 4;
-  const float* xcol = x + (size_t)g.bc * Ci * S + g.sc_;
+  const float* xcol = x + (size_t)g.bc * ci_x * S + g.sc_;
   const float* scp = SCALE ? in_scale + (size_t)g.bc * Ci : nullptr;
   const int n_chunks = (Ci + kKC - 1) / kKC;
 
@@ -261,10 +263,12 @@ __global__ __launch_bounds__(256, (MTW <= 2 ? 3 : 2)) void pw_kstream_kernel(
         sc[q] = *reinterpret_cast<const float4*>(scp + (k < Ci ? k : Ci - 4));
       }
     }
+    const int kx0 = (c * kKC) % ci_x;                       // row of x the chunk starts at (wave-uniform)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = c * kKC + 8 * kq + i;
-      xr[i] = *reinterpret_cast<const float4*>(xcol + (size_t)(k < Ci ? k : Ci - 1) * S);   // padded k: finite x, zero w
+      const int kx = kx0 + 8 * kq + i;
+      xr[i] = *reinterpret_cast<const float4*>(xcol + (size_t)(k < Ci ? kx : ci_x - 1) * S);   // padded k: finite x, zero w
     }
   };
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (long long)n_chunks * MT * NP2 * 1024);
@@ -335,21 +339,21 @@ int launch_expand(hipStream_t s, const float* x, const void* wp, const float* bi
 
 template <int MTW, int NPROD>
 int launch_kstream(hipStream_t s, const float* x, const void* wp, const float* bias, const float* in_scale,
-                   const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int act) {
+                   const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int act, int ci_x) {
   const int MC = (MT + MTW - 1) / MTW;
   const int n_tiles = (int)(((long long)B * S + kTileN - 1) / kTileN);
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   auto kern = in_scale ? pw_kstream_kernel<MTW, NPROD, true> : pw_kstream_kernel<MTW, NPROD, false>;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), 0, s, x, reinterpret_cast<const bf16x8*>(wp), bias, in_scale,
-                     res, y, pool, B, Ci, Co, S, MT, MC, n_tiles, act);
+                     res, y, pool, B, Ci, Co, S, MT, MC, n_tiles, act, ci_x);
   return eat::check_launch("eat_pw_conv_bf16_fwd (kstream)");
 }
 
 template <int NPROD>
 int try_stream(hipStream_t s, const float* x, const void* wp, const float* bias, const float* in_scale, const float* res,
-               float* y, float* pool, int B, int Ci, int Co, int S, int act, int mode) {
+               float* y, float* pool, int B, int Ci, int Co, int S, int act, int mode, int ci_x) {
   const int n_chunks = (Ci + kKC - 1) / kKC;
-  if ((mode & 1) && !in_scale && !res && !pool && y && n_chunks <= 4 && Co >= 2 * Ci &&
+  if ((mode & 1) && ci_x == Ci && !in_scale && !res && !pool && y && n_chunks <= 4 && Co >= 2 * Ci &&
       (long long)B * Co * S * 4 < 0x7fffffffLL) {
     switch (n_chunks) {
       case 1: return launch_expand<1, NPROD>(s, x, wp, bias, y, B, Ci, Co, S, act);
@@ -358,11 +362,14 @@ int try_stream(hipStream_t s, const float* x, const void* wp, const float* bias,
       default: return launch_expand<4, NPROD>(s, x, wp, bias, y, B, Ci, Co, S, act);
     }
   }
-  if ((mode & 2) && Co <= 2 * Ci) {
+  // bit 2: expand-shaped layers the x-resident kernel cannot take (C_in > 128, pooled head conv) as row chunks of the
+  // K-streaming kernel (x is re-read from L2 once per 96 output rows: it is the small operand of these layers)
+  if (ci_x != Ci ? (mode & 8) != 0 : (((mode & 2) && Co <= 2 * Ci) || (mode & 4))) {
     const int MT = (Co + 15) / 16;
     const int MC = (MT + 5) / 6;                             // at most 6 m-tiles of accumulators + fragments per wave
     const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch_kstream<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, act);
+#define EAT_CASE(n) \
+  case n: return launch_kstream<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, act, ci_x);
     switch (mtw) {
       EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6)
       default: break;
@@ -382,20 +389,22 @@ std::atomic<int>& stream_mode() {
 }  // namespace
 
 extern "C" int eat_pw_stream_mode(int mode) {
-  return mode >= 0 ? stream_mode().exchange(mode & 3) : stream_mode().load();
+  return mode >= 0 ? stream_mode().exchange(mode & 15) : stream_mode().load();
 }
 
 namespace eat {
 
-// Returns 1 when the shape (or the EAT_PW_STREAM switch: bit 0 = expand kernel, bit 1 = k-stream kernel) leaves the layer
-// to the LDS-staged kernel of conv_pw_bf16.hip; otherwise the launch status.  Caller has checked S % 4 == 0, Ci % 4 == 0.
+// Returns 1 when the shape (or the EAT_PW_STREAM switch: bit 0 = expand kernel, bit 1 = k-stream kernel for project-shaped
+// layers, bit 2 = k-stream kernel for whatever is left, bit 3 = k-stream kernel for DyMN's K-concat launches) leaves the
+// layer to the LDS-staged kernel of conv_pw_bf16.hip; otherwise the launch status.  Caller has checked S % 4 == 0,
+// Ci % 4 == 0 (and ci_x % 32 == 0, in_scale != NULL when ci_x != Ci).
 int pw_stream_try(const float* x, const void* wp, const float* bias, const float* in_scale, const float* res, float* y,
-                  float* pool, int B, int Ci, int Co, int S, int act, int split, hipStream_t s) {
+                  float* pool, int B, int Ci, int Co, int S, int act, int split, int ci_x, hipStream_t s) {
   const int mode = stream_mode().load(std::memory_order_relaxed);
   if (!mode) return 1;
   if ((long long)B * S > 0x7fff0000LL) return 1;
-  return split ? try_stream<3>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, mode)
-               : try_stream<1>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, mode);
+  return split ? try_stream<3>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, mode, ci_x)
+               : try_stream<1>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, mode, ci_x);
 }
 
 }  // namespace eat

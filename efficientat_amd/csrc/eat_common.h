@@ -56,7 +56,7 @@ int pw_conv_generic(const float* x, const void* wp, const float* bias, const flo
 // conv_pw_stream.hip: barrier-free bf16 1x1 kernels (x or the output tile resident in registers); returns 1 when the
 // shape / the EAT_PW_STREAM switch leaves the layer to conv_pw_bf16.hip
 int pw_stream_try(const float* x, const void* wp, const float* bias, const float* in_scale, const float* res, float* y,
-                  float* pool, int B, int Ci, int Co, int S, int act, int split, hipStream_t s);
+                  float* pool, int B, int Ci, int Co, int S, int act, int split, int ci_x, hipStream_t s);
 
 // irb.hip: register-resident inverted-residual block; returns 1 when the shape has no instantiation (fall back)
 int irb_try(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,

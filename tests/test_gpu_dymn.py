@@ -260,9 +260,11 @@ def test_col_sum(R, C):
 
 @pytest.mark.parametrize("B,Ci,Co,Fq,T,act,res", [(3, 64, 96, 4, 32, 2, False), (5, 160, 160, 4, 32, 0, True),
                                                    (2, 32, 200, 8, 63, 1, False), (4, 320, 48, 2, 10, 0, False)])
-def test_pw_conv_kcat(B, Ci, Co, Fq, T, act, res):
+@pytest.mark.parametrize("stream", [0, 15])
+def test_pw_conv_kcat(B, Ci, Co, Fq, T, act, res, stream):
     """Dynamic 1x1 conv as one GEMM over the K-concatenated banks with the attention as input scale
-    (models/dymn/dy_block.py:103-131) vs the per-sample aggregated-weight formulation; bf16x3 arithmetic."""
+    (models/dymn/dy_block.py:103-131) vs the per-sample aggregated-weight formulation; bf16x3 arithmetic; on the LDS-staged
+    kernel (stream 0) and on the K-streaming kernel of csrc/conv_pw_stream.hip (stream 15)."""
     K = 4
     if (Fq * T) % 4:
         pytest.skip("K-concat form needs planes of a multiple of 4 positions")
@@ -276,5 +278,9 @@ def test_pw_conv_kcat(B, Ci, Co, Fq, T, act, res):
     if res:
         ref = ref + r.double()
     wp = ops.kcat_pack(bank.to(DEV), Co, Ci, rs.to(DEV))
-    got = ops.pw_conv_kcat(x.to(DEV), wp, bias.to(DEV), att.to(DEV), Co, act, res=None if r is None else r.to(DEV))
+    prev = ops.pw_stream_mode(stream)
+    try:
+        got = ops.pw_conv_kcat(x.to(DEV), wp, bias.to(DEV), att.to(DEV), Co, act, res=None if r is None else r.to(DEV))
+    finally:
+        ops.pw_stream_mode(prev)
     assert _rel(got, ref) < 3e-5

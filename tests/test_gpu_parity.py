@@ -372,7 +372,7 @@ def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
 @pytest.fixture
 def pw_stream_all():
     """Route the bf16 1x1 convs through the barrier-free kernels of csrc/conv_pw_stream.hip for one test."""
-    prev = ops.pw_stream_mode(3)
+    prev = ops.pw_stream_mode(15)
     yield
     ops.pw_stream_mode(prev)
 
@@ -408,10 +408,12 @@ def test_pw_conv_bf16_expand_kernel(B, Ci, Co, F_, T, act, split, tol, pw_stream
     (2, 672, 112, 3, 63, 0, True, True, False), (3, 120, 40, 5, 125, 0, True, False, False),
     (3, 480, 112, 8, 63, 0, True, False, False), (2, 240, 80, 8, 63, 0, False, False, False),
     (2, 64, 64, 16, 125, 1, False, True, False), (3, 100, 96, 8, 63, 2, False, False, True),
-    (130, 200, 80, 8, 63, 0, False, True, False), (2, 36, 16, 32, 250, 0, False, True, False)])
+    (130, 200, 80, 8, 63, 0, False, True, False), (2, 36, 16, 32, 250, 0, False, True, False),
+    (4, 160, 960, 4, 32, 2, False, False, True), (2, 160, 960, 3, 63, 2, False, False, False)])
 def test_pw_conv_bf16_kstream_kernel(B, Ci, Co, F_, T, act, se, res, use_pool, split, tol, pw_stream_all):
     """K-streaming kernel (pw_kstream_kernel): 1-6 m-tiles per wave incl. the 7 = 4 + 3 and 10 = 5 + 5 row splits,
-    partial last chunk (Ci = 72, 100, 36, 184), SE scale, residual, pooled sums."""
+    partial last chunk (Ci = 72, 100, 36, 184), SE scale, residual, pooled sums; the last two are expand-shaped layers
+    the x-resident kernel cannot take (mode bit 2: 60 m-tiles as 10 row chunks)."""
     x, w = _rand(B, Ci, F_, T, seed=1), _rand(Co, Ci, seed=2, scale=Ci ** -0.5)
     bias, rs = _rand(Co, seed=3, scale=0.1), torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5
     sc = torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) if se else None
