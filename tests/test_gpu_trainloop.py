@@ -144,3 +144,38 @@ def test_kd_trainer_step_equals_the_reference_loop_formulation():
     assert len(rels) > 50 and max(rels) < 5e-2 and float(np.median(rels)) < 1e-2, (max(rels), float(np.median(rels)))
     stats = tr.epoch_stats()
     assert abs(stats["train_loss"] - loss.item()) < 1e-5 and tr.steps == 0
+
+
+# ------------------------------------------------------------------------------------------------ f2: input staging
+def test_device_prefetcher_delivers_the_loader_batches_in_order():
+    """DevicePrefetcher (efficientat_amd/input_pipeline.py): pinned, double-buffered H2D on a copy stream must hand out
+    exactly the DataLoader's batches (datasets/audioset.py:138-161 tuple layout, file names passed through), in order,
+    while the consumer keeps the compute stream busy; slots are recycled only after the consumer moved on."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin", "datasets", "audioset.py")
+    spec = importlib.util.spec_from_file_location("eat_dropin_audioset", path)    # (not `import datasets`: the
+    audioset = importlib.util.module_from_spec(spec)                                 #  HuggingFace package has that name)
+    spec.loader.exec_module(audioset)
+    from torch.utils.data import DataLoader, Subset
+    from efficientat_amd.input_pipeline import DevicePrefetcher
+
+    ds = Subset(audioset.get_training_set(add_index=True), list(range(22)))       # 22 clips: a ragged last batch
+    loader = DataLoader(ds, batch_size=4, shuffle=False, num_workers=0)
+    want = [(w.clone(), list(n), y.clone(), i.clone()) for w, n, y, i in loader]
+    assert want[0][0].shape == (4, 1, 320000) and want[-1][0].shape[0] == 2
+    got = []
+    burn = torch.randn(2048, 2048, device=DEV)
+    for depth in (1, 2, 3):
+        got.clear()
+        for w, n, y, i in DevicePrefetcher(loader, DEV, depth=depth):
+            assert w.is_cuda and y.is_cuda and i.is_cuda and isinstance(n[0], str)
+            for _ in range(4):
+                burn = torch.tanh(burn @ burn * 1e-3)                                # compute-stream work between batches
+            got.append((w.float().sum(dim=(1, 2)), list(n), y.clone(), i.clone(), w[:, 0, 12345].clone()))
+        assert len(got) == len(want)
+        for (ws, n, y, i, probe), (w0, n0, y0, i0) in zip(got, want):
+            assert n == n0
+            assert torch.equal(y.cpu(), y0) and torch.equal(i.cpu(), i0)
+            assert torch.equal(probe.cpu(), w0[:, 0, 12345])
+            assert torch.allclose(ws.cpu(), w0.sum(dim=(1, 2)), rtol=1e-4, atol=1e-3)
