@@ -41,6 +41,7 @@ SIGNATURES = {
     "eat_dyn_pw_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_pw_conv_dyn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dyn_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eat_dw_conv_dyn_act_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_fused_expand_dw_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_mbconv_fwd": [_P] * 9 + [_I] * 11 + [_P],
     "eat_front_fwd": [_P] * 8 + [_I] * 7 + [_P],

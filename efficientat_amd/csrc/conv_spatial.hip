@@ -92,10 +92,15 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     const float bc = bias ? bias[c] : 0.0f;
     float a1 = 1.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, sgt = 1.f;
     const float* gfp = nullptr;
-    const bool dy_epi = DY && dyn.coef != nullptr;      // coef == NULL: per-plane taps only (train mode:
-    if (dy_epi) {                                        // BN statistics come before DyReLU / CoordAtt)
+    // coef == NULL and gates == NULL: per-plane taps only (train mode: BN statistics come before DyReLU / CoordAtt);
+    // one of them NULL: the `no_dyrelu` / `no_ca` ablations of the block (dy_block.py:353-356)
+    const bool dy_relu = DY && dyn.coef != nullptr;
+    const bool dy_gate = DY && dyn.gate_f != nullptr;
+    if (dy_relu) {
       const float4 cf = *reinterpret_cast<const float4*>(dyn.coef + (size_t)gp * 4);
       a1 = cf.x; a2 = cf.y; b1 = cf.z; b2 = cf.w;
+    }
+    if (dy_gate) {
       const int b = gp / C;
       sgt = sigmoidf_(dyn.gate_t[((size_t)b * To + to) * C + c]);
       gfp = dyn.gate_f + (size_t)b * Fo * C + c;
@@ -145,7 +150,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
 #pragma unroll
             for (int v = 0; v < K; ++v) acc = fmaf(wr[u * K + v], win[(u + R * STRIDE) % NSLOT][v], acc);
           float o = eat::activate<ACT>(acc);
-          if (dy_epi) o = fmaxf(fmaf(a1, o, b1), fmaf(a2, o, b2)) * (sigmoidf_(gfp[(size_t)fo * C]) * sgt);
+          if (dy_relu) o = fmaxf(fmaf(a1, o, b1), fmaf(a2, o, b2));
+          if (dy_gate) o *= sigmoidf_(gfp[(size_t)fo * C]) * sgt;
           if (dyn.res) o += dyn.res[(size_t)gp * Fo * To + (size_t)fo * To + to];
           yp[(size_t)fo * To] = o;
           psum += o;
@@ -170,8 +176,8 @@ int launch_dw(const float* x, const float* w, const float* bias, float* y, float
   dim3 grid((To + TX - 1) / TX, (n_planes + ppb - 1) / ppb);
   if (grid.y > 65535u * 32u) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: too many planes (%d)", n_planes);
   if (dyn) {
-    hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, EAT_ACT_NONE, true>), grid, dim3(256), 0, stream, x, w, bias, y, pool,
-                       n_planes, C, F, T, Fo, To, TX, *dyn);
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT, true>), grid, dim3(256), 0, stream, x, w, bias,
+                                             y, pool, n_planes, C, F, T, Fo, To, TX, *dyn));
   } else {
     EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_conv_kernel<K, STRIDE, ACT, false>), grid, dim3(256), 0, stream, x, w,
                                              bias, y, pool, n_planes, C, F, T, Fo, To, TX, DwDyn{nullptr, nullptr, nullptr, nullptr, 0, 0}));
@@ -184,7 +190,7 @@ int dispatch_dw(const float* x, const float* w, const float* bias, float* y, flo
   const int p = (k - 1) / 2;
   if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
     return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: output %dx%d inconsistent with input %dx%d k=%d s=%d", Fo, To, F, T, k, stride);
-  if (!dyn || !dyn->coef) {
+  if (!dyn || (!dyn->coef && !dyn->gate_f)) {
     // register-resident kernels (dw_plane.hip: whole small planes, tiles of large ones); 1 = geometry not instantiated
     const int rc = eat::dw_plane_try(x, w, bias, dyn ? dyn->res : nullptr, y, pool, B, C, F, T, Fo, To, k, stride, act,
                                      dyn ? dyn->flip : 0, dyn ? dyn->per_plane_w : 0, dyn ? dyn->in_a : nullptr,
@@ -243,6 +249,20 @@ extern "C" int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const floa
   eat::clear_stale_error();
   const DwDyn dyn{coef, gate_f, gate_t, nullptr, 0, 1};
   return dispatch_dw(x, w_bc, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
+}
+
+// Ablations of the dynamic block (models/dymn/dy_block.py:353-356, `no_dyrelu` / `no_ca`): `act` is the plain activation
+// that replaces DyReLU-B (applied to the BN output), coef == NULL skips DyReLU-B, gate_f == gate_t == NULL skips the
+// coordinate attention.  With everything present and act = none this is eat_dw_conv_dyn_fwd.
+extern "C" int eat_dw_conv_dyn_act_fwd(const float* x, const float* w_bc, const float* bias, int act, const float* coef,
+                                       const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
+                                       int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_act_fwd: bad act %d", act);
+  if ((gate_f == nullptr) != (gate_t == nullptr))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_act_fwd: gate_f and gate_t come together");
+  const DwDyn dyn{coef, gate_f, gate_t, nullptr, 0, 1};
+  return dispatch_dw(x, w_bc, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, act, &dyn, (hipStream_t)stream);
 }
 
 // ---- depthwise conv with dilation (models/mn/model.py:244-269 `dilated=True`: the last three blocks run their 5x5

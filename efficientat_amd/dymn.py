@@ -106,6 +106,15 @@ class CoordAtt(nn.Module):
     pass
 
 
+class DynamicWrapper(nn.Module):
+    """Holder of a static module in a dynamic slot (dy_block.py:204-211): gives the `.module.` level of the reference's
+    state-dict keys for the ablated blocks (`no_dyconv`, `no_dyrelu`, `no_ca`)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
 class ContextGen(nn.Module):
     """Parameter holder of the context generator (dy_block.py:214-254)."""
 
@@ -126,28 +135,36 @@ class DY_Block(nn.Module):
         super().__init__()
         if not (1 <= cnf.stride <= 2):
             raise ValueError("illegal stride value")
-        if no_dyrelu or no_dyconv or no_ca or cnf.dilation != 1:
-            raise NotImplementedError("HIP path implements the full dynamic block (DyConv + DyReLU-B + CoordAtt), dilation 1")
+        if cnf.dilation != 1:
+            raise NotImplementedError("HIP path implements the dynamic block with dilation 1")
         self.cnf = cnf
+        # ablations of the block (dy_block.py:269-271): static convs / plain activation / no coordinate attention
+        self.no_dyrelu, self.no_dyconv, self.no_ca = bool(no_dyrelu), bool(no_dyconv), bool(no_ca)
         self.use_res_connect = cnf.stride == 1 and cnf.input_channels == cnf.out_channels
         self.context_dim = int(np.clip(make_divisible(cnf.expanded_channels // context_ratio, 8),
                                        make_divisible(min_context_size * cnf.width_mult, 8),
                                        make_divisible(max_context_size * cnf.width_mult, 8)))
         H, cin, cexp, cout = self.context_dim, cnf.input_channels, cnf.expanded_channels, cnf.out_channels
         norm = partial(nn.BatchNorm2d, eps=BN_EPS, momentum=BN_MOMENTUM)
+        act_layer = nn.Hardswish if cnf.use_hs else nn.ReLU
+
+        def conv(ci, co, k, stride=1, groups=1):
+            if no_dyconv:                                            # dy_block.py:291-302,320-332,359-370
+                return DynamicWrapper(nn.Conv2d(ci, co, (k, k), (stride, stride), (k - 1) // 2, groups=groups, bias=False))
+            return DynamicConv(ci, co, H, k, stride=stride, groups=groups, k=dyconv_k, temp_schedule=temp_schedule)
+
         self.has_expand = cexp != cin
         if self.has_expand:
-            self.exp_conv = DynamicConv(cin, cexp, H, 1, k=dyconv_k, temp_schedule=temp_schedule)
+            self.exp_conv = conv(cin, cexp, 1)
             self.exp_norm = norm(cexp)
-            self.exp_act = (nn.Hardswish if cnf.use_hs else nn.ReLU)(inplace=True)
+            self.exp_act = act_layer(inplace=True)
         else:
             self.exp_conv, self.exp_norm, self.exp_act = nn.Identity(), nn.Identity(), nn.Identity()
-        self.depth_conv = DynamicConv(cexp, cexp, H, cnf.kernel, stride=cnf.stride, groups=cexp, k=dyconv_k,
-                                      temp_schedule=temp_schedule)
+        self.depth_conv = conv(cexp, cexp, cnf.kernel, cnf.stride, cexp)
         self.depth_norm = norm(cexp)
-        self.depth_act = DyReLUB(cexp, H, M=dyrelu_k)
-        self.ca = CoordAtt()
-        self.proj_conv = DynamicConv(cexp, cout, H, 1, k=dyconv_k, temp_schedule=temp_schedule)
+        self.depth_act = DynamicWrapper(act_layer(inplace=True)) if no_dyrelu else DyReLUB(cexp, H, M=dyrelu_k)
+        self.ca = DynamicWrapper(nn.Identity()) if no_ca else CoordAtt()
+        self.proj_conv = conv(cexp, cout, 1)
         self.proj_norm = norm(cout)
         self.context_gen = ContextGen(H, cin, cexp, stride=cnf.stride)
 
@@ -224,6 +241,8 @@ class DyMN(nn.Module):
                [self.in_c[0].weight, self.out_c[0].weight] + \
                [blk.context_gen.joint_conv.weight for blk in self.layers if isinstance(blk, DY_Block)] + \
                [m.weight for m in self.modules() if isinstance(m, DynamicConv)] + \
+               [m.module.weight for m in self.modules() if isinstance(m, DynamicWrapper)
+                and isinstance(m.module, nn.Conv2d)] + \
                [m.weight for blk in self.layers if isinstance(blk, InvertedResidual) for m in blk.modules()
                 if isinstance(m, nn.Conv2d)]
 
@@ -244,6 +263,13 @@ class DyMN(nn.Module):
                 if isinstance(bn, nn.BatchNorm2d):
                     s, b = _fold(None, bn)
                     d[name] = (s.contiguous(), b.contiguous())
+                    conv = getattr(blk, name + "_conv")
+                    if isinstance(conv, DynamicWrapper):             # `no_dyconv`: static weights, BN scale folded in
+                        wt = conv.module.weight
+                        if name == "depth":
+                            d["depth_taps"] = (wt.flatten(1) * s.view(-1, 1)).contiguous()
+                        else:
+                            d[name + "_w"] = ops.pw_prepack(wt.flatten(1), s.contiguous())
             out[i] = d
         if isinstance(self.layers[0], InvertedResidual):
             front = fold_front(self.in_c, self.layers[0])
@@ -260,32 +286,53 @@ class DyMN(nn.Module):
         H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
         act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
         inp = x
-        # ---- context generator (dy_block.py:235-254)
+        # ---- context generator (dy_block.py:235-254); the ablated blocks (`no_dyconv`, `no_dyrelu`, `no_ca`) only
+        # evaluate the parts of it that something still consumes
         cg = blk.context_gen
-        seq = ops.ctx_pool(x)                                                      # (B, F+T, cin)
-        g = ops.linear(seq.view(B * (Fq + T), cin), w["joint"][0], w["joint"][1], ops.ACT_HSWISH).view(B, Fq + T, H)
-        h_c = g.mean(dim=1)
-        h_cf, h_ct = g[:, :Fq], g[:, Fq:]
-        if stride > 1:
-            h_cf, h_ct = _pool3(h_cf, stride), _pool3(h_ct, stride)
-        Fo, To = h_cf.shape[1], h_ct.shape[1]
-        g_cf = ops.linear(h_cf.reshape(B * Fo, H), cg.conv_f.weight.flatten(1), cg.conv_f.bias, ops.ACT_NONE)
-        g_ct = ops.linear(h_ct.reshape(B * To, H), cg.conv_t.weight.flatten(1), cg.conv_t.bias, ops.ACT_NONE)
+        need_hc = not (blk.no_dyconv and blk.no_dyrelu)
+        h_c = g_cf = g_ct = None
+        if need_hc or not blk.no_ca:
+            seq = ops.ctx_pool(x)                                                  # (B, F+T, cin)
+            g = ops.linear(seq.view(B * (Fq + T), cin), w["joint"][0], w["joint"][1], ops.ACT_HSWISH).view(B, Fq + T, H)
+            if need_hc:
+                h_c = g.mean(dim=1)
+            if not blk.no_ca:
+                h_cf, h_ct = g[:, :Fq], g[:, Fq:]
+                if stride > 1:
+                    h_cf, h_ct = _pool3(h_cf, stride), _pool3(h_ct, stride)
+                Fo, To = h_cf.shape[1], h_ct.shape[1]
+                g_cf = ops.linear(h_cf.reshape(B * Fo, H), cg.conv_f.weight.flatten(1), cg.conv_f.bias, ops.ACT_NONE)
+                g_ct = ops.linear(h_ct.reshape(B * To, H), cg.conv_t.weight.flatten(1), cg.conv_t.bias, ops.ACT_NONE)
         # ---- expand (dynamic 1x1)
         if blk.has_expand:
-            att = _attention(blk.exp_conv, h_c)
-            x = self._dyn_pw(blk.exp_conv, w, "exp", x, att, cexp, cin, act)
+            if blk.no_dyconv:
+                x = ops.pw_conv(x, w["exp_w"], w["exp"][1], cexp, act)
+            else:
+                x = self._dyn_pw(blk.exp_conv, w, "exp", x, _attention(blk.exp_conv, h_c), cexp, cin, act)
         # ---- depthwise (dynamic taps) + BN + DyReLU-B + CoordAtt
-        att = _attention(blk.depth_conv, h_c)
-        taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att, w["depth"][0], k * k)
-        da = blk.depth_act
-        theta = 2.0 * torch.sigmoid(ops.linear(h_c, da.coef_net[0].weight, da.coef_net[0].bias, ops.ACT_NONE)) - 1.0
-        coef = (theta.view(B, cexp, 4) * da.lambdas + da.init_v).contiguous()
-        x = ops.dw_conv_dyn(x, taps, w["depth"][1], coef, g_cf, g_ct, k, stride)
+        if blk.no_dyconv and blk.no_dyrelu and blk.no_ca:
+            x = ops.dw_conv(x, w["depth_taps"], w["depth"][1], k, stride, act)     # nothing dynamic left: the static kernel
+        else:
+            if blk.no_dyconv:
+                taps = w["depth_taps"].unsqueeze(0).expand(B, -1, -1).reshape(B, -1).contiguous()
+            else:
+                att = _attention(blk.depth_conv, h_c)
+                taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att, w["depth"][0], k * k)
+            coef = None
+            if not blk.no_dyrelu:
+                da = blk.depth_act
+                theta = 2.0 * torch.sigmoid(ops.linear(h_c, da.coef_net[0].weight, da.coef_net[0].bias, ops.ACT_NONE)) - 1.0
+                coef = (theta.view(B, cexp, 4) * da.lambdas + da.init_v).contiguous()
+            if coef is not None and g_cf is not None:
+                x = ops.dw_conv_dyn(x, taps, w["depth"][1], coef, g_cf, g_ct, k, stride)
+            else:
+                x = ops.dw_conv_dyn_act(x, taps, w["depth"][1], act if blk.no_dyrelu else ops.ACT_NONE, coef, g_cf, g_ct,
+                                        k, stride)
         # ---- project (dynamic 1x1) + BN (+ residual)
-        att = _attention(blk.proj_conv, h_c)
-        return self._dyn_pw(blk.proj_conv, w, "proj", x, att, cout, cexp, ops.ACT_NONE,
-                            res=inp if blk.use_res_connect else None)
+        res = inp if blk.use_res_connect else None
+        if blk.no_dyconv:
+            return ops.pw_conv(x, w["proj_w"], w["proj"][1], cout, ops.ACT_NONE, res=res)
+        return self._dyn_pw(blk.proj_conv, w, "proj", x, _attention(blk.proj_conv, h_c), cout, cexp, ops.ACT_NONE, res=res)
 
     @staticmethod
     def _dyn_pw(conv, w, name, x, att, Co, Ci, act, res=None):

@@ -285,16 +285,32 @@ def _block_train(blk, x):
     Fo, To = h_cf.shape[1], h_ct.shape[1]
     g_cf = Linear.apply(h_cf.reshape(B * Fo, H), cg.conv_f.weight.flatten(1), cg.conv_f.bias).view(B, Fo, cexp)
     g_ct = Linear.apply(h_ct.reshape(B * To, H), cg.conv_t.weight.flatten(1), cg.conv_t.bias).view(B, To, cexp)
+    # The ablated blocks (dy_block.py:269-271) keep the whole context generator above - the reference evaluates it
+    # (and updates joint_norm's running statistics) whatever consumes it - and swap the consumers: static convs on the MN
+    # Functions, the plain activation in BnAct, DyReLU-B / CoordAtt neutralised by constant operands (a1 = a2 = 1:
+    # max(v, v) = v;  gates = +40: sigmoid = 1 and its derivative 0 in fp32).
+    no_dyconv, no_dyrelu, no_ca = blk.no_dyconv, blk.no_dyrelu, blk.no_ca
     if blk.has_expand:
-        z = DynPwConv.apply(x, blk.exp_conv.weight, _attention(blk.exp_conv, h_c), cexp)
+        z = PwConv.apply(x, blk.exp_conv.module.weight) if no_dyconv else \
+            DynPwConv.apply(x, blk.exp_conv.weight, _attention(blk.exp_conv, h_c), cexp)
         x = BnAct.apply(z, blk.exp_norm.weight, blk.exp_norm.bias, blk.exp_norm, act)
-    z = DynDwConv.apply(x, blk.depth_conv.weight, _attention(blk.depth_conv, h_c), k, stride)
-    v = BnAct.apply(z, blk.depth_norm.weight, blk.depth_norm.bias, blk.depth_norm, NONE)
-    da = blk.depth_act
-    theta = 2.0 * torch.sigmoid(Linear.apply(h_c, da.coef_net[0].weight, da.coef_net[0].bias)) - 1.0
-    coef = theta.view(B, cexp, 4) * da.lambdas + da.init_v
-    x = DyReluCoordAtt.apply(v, coef, g_cf, g_ct)
-    z = DynPwConv.apply(x, blk.proj_conv.weight, _attention(blk.proj_conv, h_c), cout)
+    z = DwConv.apply(x, blk.depth_conv.module.weight, k, stride) if no_dyconv else \
+        DynDwConv.apply(x, blk.depth_conv.weight, _attention(blk.depth_conv, h_c), k, stride)
+    v = BnAct.apply(z, blk.depth_norm.weight, blk.depth_norm.bias, blk.depth_norm, act if no_dyrelu else NONE)
+    if no_dyrelu and no_ca:
+        x = v
+    else:
+        if no_dyrelu:
+            coef = torch.tensor([1.0, 1.0, 0.0, 0.0], device=x.device).expand(B, cexp, 4)
+        else:
+            da = blk.depth_act
+            theta = 2.0 * torch.sigmoid(Linear.apply(h_c, da.coef_net[0].weight, da.coef_net[0].bias)) - 1.0
+            coef = theta.view(B, cexp, 4) * da.lambdas + da.init_v
+        if no_ca:
+            g_cf, g_ct = torch.full_like(g_cf, 40.0), torch.full_like(g_ct, 40.0)
+        x = DyReluCoordAtt.apply(v, coef, g_cf, g_ct)
+    z = PwConv.apply(x, blk.proj_conv.module.weight) if no_dyconv else \
+        DynPwConv.apply(x, blk.proj_conv.weight, _attention(blk.proj_conv, h_c), cout)
     x = BnAct.apply(z, blk.proj_norm.weight, blk.proj_norm.bias, blk.proj_norm, NONE)
     return x + inp if blk.use_res_connect else x
 

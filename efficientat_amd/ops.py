@@ -308,6 +308,17 @@ def dw_conv_dyn(x, w_bc, bias, coef, gate_f, gate_t, k, stride):
     return y
 
 
+def dw_conv_dyn_act(x, w_bc, bias, act, coef, gate_f, gate_t, k, stride):
+    """dw_conv_dyn for the block's ablations: plain activation `act` instead of / before DyReLU-B (coef None), no
+    coordinate attention (gates None)."""
+    B, C, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_dyn_act_fwd", _dev(x, "x"), _dev(w_bc, "w_bc"), _dev(bias, "bias"), act, _opt(coef, "coef"),
+              _opt(gate_f, "gate_f"), _opt(gate_t, "gate_t"), y.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
+    return y
+
+
 def fused_expand_dw(x, wp_e, bias_e, w_d, bias_d, Cexp, k, stride, act, pool=None):
     """expand 1x1 + BN + act -> depthwise k x k + BN + act in one kernel (eval; early blocks)."""
     B, Cin, F, T = x.shape

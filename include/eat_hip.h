@@ -196,6 +196,12 @@ int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, co
 int eat_dw_conv_dyn_fwd(const float* x, const float* w_bc, const float* bias, const float* coef,
                         const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
                         int Fo, int To, int k, int stride, eat_stream_t stream);
+/* The same for the block's ablations (dy_block.py:353-356, DY_Block(no_dyrelu=..., no_ca=...)): `act` is the plain
+ * activation that replaces DyReLU-B (dy_block.py:353: applied to the BN output), coef == NULL skips DyReLU-B, gate_f ==
+ * gate_t == NULL skips the coordinate attention. */
+int eat_dw_conv_dyn_act_fwd(const float* x, const float* w_bc, const float* bias, int act, const float* coef,
+                            const float* gate_f, const float* gate_t, float* y, int B, int C, int F, int T,
+                            int Fo, int To, int k, int stride, eat_stream_t stream);
 
 /* ---- DyMN training step: backward of the dynamic pieces -------------------- */
 

@@ -285,8 +285,11 @@ def _dyconv(sd, prefix, x, h_c, cin, cout, k, stride, groups, temperature):
     return y.reshape(b, cout, *y.shape[2:])
 
 
-def _dy_block(sd, prefix, x, c, H, train, stats, temperature):
-    """DY_Block.forward (dy_block.py:390-409)."""
+def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, no_dyconv=False, no_ca=False):
+    """DY_Block.forward (dy_block.py:390-409); the ablation flags follow dy_block.py:291-375: `no_dyconv` replaces the
+    three DynamicConvs by plain bias-free convolutions (state-dict keys `<conv>.module.weight`, DynamicWrapper
+    dy_block.py:204-211), `no_dyrelu` puts the block's plain activation in the place of DyReLU-B, `no_ca` drops the
+    coordinate attention.  The context generator runs in every case (dy_block.py:394)."""
     inp = x
     B, C, Fq, T = x.shape
     # ContextGen (dy_block.py:235-254)
@@ -300,20 +303,30 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature):
         h_ct = F.avg_pool2d(h_ct, (1, 3), (1, c["stride"]), (0, 1))
     g_cf = F.conv2d(h_cf, sd[prefix + ".context_gen.conv_f.weight"], sd[prefix + ".context_gen.conv_f.bias"])
     g_ct = F.conv2d(h_ct, sd[prefix + ".context_gen.conv_t.weight"], sd[prefix + ".context_gen.conv_t.bias"])
+
+    def conv(name, x, cin, cout, k, stride, groups):
+        if no_dyconv:
+            return F.conv2d(x, sd[f"{prefix}.{name}.module.weight"], None, stride, (k - 1) // 2, 1, groups)
+        return _dyconv(sd, f"{prefix}.{name}", x, h_c, cin, cout, k, stride, groups, temperature)
+
     # expand
     if c["cexp"] != c["cin"]:
-        x = _dyconv(sd, prefix + ".exp_conv", x, h_c, c["cin"], c["cexp"], 1, 1, 1, temperature)
+        x = conv("exp_conv", x, c["cin"], c["cexp"], 1, 1, 1)
         x = _act(_bn(sd, prefix + ".exp_norm", x, train, stats), c["hs"])
     # depthwise + DyReLU-B (dy_block.py:172-188) + CoordAtt (195-201)
-    x = _dyconv(sd, prefix + ".depth_conv", x, h_c, c["cexp"], c["cexp"], c["k"], c["stride"], c["cexp"], temperature)
+    x = conv("depth_conv", x, c["cexp"], c["cexp"], c["k"], c["stride"], c["cexp"])
     x = _bn(sd, prefix + ".depth_norm", x, train, stats)
-    theta = 2 * torch.sigmoid(F.linear(h_c, sd[prefix + ".depth_act.coef_net.0.weight"],
-                                       sd[prefix + ".depth_act.coef_net.0.bias"])) - 1
-    co = theta.view(B, c["cexp"], 1, 1, 4) * sd[prefix + ".depth_act.lambdas"] + sd[prefix + ".depth_act.init_v"]
-    x = torch.maximum(x * co[..., 0] + co[..., 2], x * co[..., 1] + co[..., 3])
-    x = x * torch.sigmoid(g_cf) * torch.sigmoid(g_ct)
+    if no_dyrelu:
+        x = _act(x, c["hs"])
+    else:
+        theta = 2 * torch.sigmoid(F.linear(h_c, sd[prefix + ".depth_act.coef_net.0.weight"],
+                                           sd[prefix + ".depth_act.coef_net.0.bias"])) - 1
+        co = theta.view(B, c["cexp"], 1, 1, 4) * sd[prefix + ".depth_act.lambdas"] + sd[prefix + ".depth_act.init_v"]
+        x = torch.maximum(x * co[..., 0] + co[..., 2], x * co[..., 1] + co[..., 3])
+    if not no_ca:
+        x = x * torch.sigmoid(g_cf) * torch.sigmoid(g_ct)
     # project
-    x = _dyconv(sd, prefix + ".proj_conv", x, h_c, c["cexp"], c["cout"], 1, 1, 1, temperature)
+    x = conv("proj_conv", x, c["cexp"], c["cout"], 1, 1, 1)
     x = _bn(sd, prefix + ".proj_norm", x, train, stats)
     if c["stride"] == 1 and c["cin"] == c["cout"]:
         x = x + inp
@@ -324,7 +337,8 @@ REPLACE_SE_DY = (False, False, False, True, True, True, False, False, False, Fal
 
 
 def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, train=False,
-                 stats=None, drop_mask=None, return_fmaps=False, use_dy_blocks="all"):
+                 stats=None, drop_mask=None, return_fmaps=False, use_dy_blocks="all", no_dyrelu=False, no_dyconv=False,
+                 no_ca=False):
     """DyMN (dymn/model.py:157-200); use_dy_blocks "all" or "replace_se" (dymn/model.py:225-231: dynamic blocks only
     where MobileNetV3 has SE, plain SE-less inverted residuals elsewhere, dymn/model.py:102-103)."""
     blocks, _ = block_table(width_mult, strides)
@@ -335,7 +349,7 @@ def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, t
     for i, c in enumerate(blocks):
         H = context_dim(c["cexp"], width_mult)
         if dy[i]:
-            x = _dy_block(sd, f"layers.{i}", x, c, H, train, stats, temperature)
+            x = _dy_block(sd, f"layers.{i}", x, c, H, train, stats, temperature, no_dyrelu, no_dyconv, no_ca)
         else:
             x = _inverted_residual(sd, f"layers.{i}", x, c, train, stats, use_se=False)
         fmaps.append(x)

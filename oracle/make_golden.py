@@ -204,8 +204,12 @@ def golden_variants(mel):
     np.savez_compressed(os.path.join(OUT, "mn_variants_ref.npz"), **res)
 
 
-DYMN_VARIANTS = {   # models/dymn/model.py:225-231
+DYMN_VARIANTS = {   # models/dymn/model.py:225-231; ablations of the dynamic block: models/dymn/dy_block.py:269-271
     "replace_se": dict(use_dy_blocks="replace_se"),
+    "no_dyrelu": dict(no_dyrelu=True),
+    "no_dyconv": dict(no_dyconv=True),
+    "no_ca": dict(no_ca=True),
+    "static": dict(no_dyrelu=True, no_dyconv=True, no_ca=True),
 }
 
 

@@ -184,7 +184,13 @@ def test_oracle_variants_match_reference(tag, golden_dir):
 
 
 # ---------------------------------------------------------------- DyMN variants (use_dy_blocks="replace_se")
-DYMN_VARIANTS = {"replace_se": (dict(use_dy_blocks="replace_se"), dict(use_dy_blocks="replace_se"))}
+DYMN_VARIANTS = {"replace_se": (dict(use_dy_blocks="replace_se"), dict(use_dy_blocks="replace_se")),
+                 # ablations of the dynamic block (models/dymn/dy_block.py:269-271,291-375)
+                 "no_dyrelu": (dict(no_dyrelu=True), dict(no_dyrelu=True)),
+                 "no_dyconv": (dict(no_dyconv=True), dict(no_dyconv=True)),
+                 "no_ca": (dict(no_ca=True), dict(no_ca=True)),
+                 "static": (dict(no_dyrelu=True, no_dyconv=True, no_ca=True),
+                            dict(no_dyrelu=True, no_dyconv=True, no_ca=True))}
 
 
 def dymn_variant_state(tag, golden_dir):
