@@ -91,7 +91,17 @@ def _alg_bytes(name, a):
         chunks = (mt + 7) // 8
         mtw = (mt + chunks - 1) // chunks
         nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + (4 if split else 2) * Co * Ci
-        return f"pw_conv_bf16_kernel<{mtw},{3 if split else 1},*>", nbytes, 2 * B * S * Ci * Co
+        flops, np_ = 2 * B * S * Ci * Co, 3 if split else 1
+        # which kernel the library picks (csrc/conv_pw_stream.hip: try_stream)
+        from efficientat_amd import ops as _ops
+        mode, n_chunks = _ops.pw_stream_mode(), (Ci + 31) // 32
+        if S % 4 == 0 and (mode & 1) and not sc and not res and not pool and y and n_chunks <= 4 and Co >= 2 * Ci \
+                and 4 * B * Co * S < 2 ** 31 - 1:
+            return f"pw_expand_kernel<{n_chunks},{np_},*>", nbytes, flops
+        if S % 4 == 0 and (((mode & 2) and Co <= 2 * Ci) or (mode & 4)):
+            mc = (mt + 5) // 6
+            return f"pw_kstream_kernel<{(mt + mc - 1) // mc},{np_},*>", nbytes, flops
+        return f"pw_conv_bf16_kernel<{mtw},{np_},*>", nbytes, flops
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
         nbytes, flops = 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
@@ -483,6 +493,7 @@ def main():
         "config": {"workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 synthetic "
                                "10 s @ 32 kHz clips per GPU, fp32 [BASELINE.json configs[1]]",
                    "batch_per_gpu": args.batch, "arithmetic": arithmetic, "launch": launch,
+                   "pw_stream_mode": __import__("efficientat_amd.ops", fromlist=["x"]).pw_stream_mode(),
                    "parallelism": f"dp{world} (independent clips, no collective in the forward)"},
         "roofline_e2e": {"bound": "hbm", "achieved": round(clips_per_s / world * ALG_BYTES_PER_CLIP / 1e9, 1),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -529,7 +540,7 @@ def main():
         per_launch_flops = d["flops"] / d["launches"]
         per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
         traffic, tsrc = None, None
-        for tfile in ("pmc_traffic_r2.json", "pmc_traffic_r1.json"):
+        for tfile in ("pmc_traffic_r2b.json", "pmc_traffic_r2.json", "pmc_traffic_r1.json"):
             tpath = os.path.join(ROOT, "profiles", tfile)
             if os.path.exists(tpath):
                 # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
@@ -545,7 +556,7 @@ def main():
         # one of the instruction the kernel issues: fp32 16x16x4 (157 TF), bf16 16x16x32 (2.5 PF dense), and
         # for the bf16x3 split kernel 2.5 PF / 3 because each useful product costs three bf16 MFMAs.
         mfma_peak = MFMA_F32_PEAK
-        if name.startswith("pw_conv_bf16_kernel"):
+        if name.startswith(("pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel")):
             mfma_peak = MFMA_BF16_PEAK / (3 if ",3," in name else 1)
         mfma_bound = per_launch_flops / mfma_peak > per_launch_bytes / HBM_PEAK
         common = {"kernel": name, "traffic": traffic, "launches_per_step": d["launches"],

@@ -17,7 +17,7 @@ import json
 import re
 import sys
 
-WIDE_READERS = ("pw_conv_kernel", "pw_conv_bf16_kernel", "bn_stats_kernel", "bn_act_fwd_kernel", "bn_act_bwd_reduce_kernel",
+WIDE_READERS = ("pw_conv_kernel", "pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel", "bn_stats_kernel", "bn_act_fwd_kernel", "bn_act_bwd_reduce_kernel",
                 "bn_act_bwd_apply_kernel", "pw_wgrad_x3_kernel")
 
 
