@@ -98,7 +98,8 @@ def _alg_bytes(name, a):
         if S % 4 == 0 and (mode & 1) and not sc and not res and not pool and y and n_chunks <= 4 and Co >= 2 * Ci \
                 and 4 * B * Co * S < 2 ** 31 - 1:
             return f"pw_expand_kernel<{n_chunks},{np_},*>", nbytes, flops
-        if S % 4 == 0 and (((mode & 2) and Co <= 2 * Ci) or (mode & 4)):
+        win = Co <= 2 * Ci and Ci >= 160 and (mt + 5) // 6 == (mt + 7) // 8
+        if S % 4 == 0 and (((mode & 2) and win) or (mode & 4)):
             mc = (mt + 5) // 6
             return f"pw_kstream_kernel<{(mt + mc - 1) // mc},{np_},*>", nbytes, flops
         return f"pw_conv_bf16_kernel<{mtw},{np_},*>", nbytes, flops

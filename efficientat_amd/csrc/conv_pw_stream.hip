@@ -168,38 +168,49 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void pw_expand_kernel(
     y_voff[r] = g.col_ok ? (unsigned)((((size_t)g.bc * Co + 4 * kq + r) * S + g.sc_) * 4) : kOOB;
   const int m_full = Co / 16;                               // m-tiles below this have all 16 rows
 
-  // One m-tile: request the NEXT m-tile's fragments first (a whole m-tile of MFMAs ahead of their use), multiply with
-  // the current ones, bias + activation, 4 stores.  Two register sets alternate (the loop is unrolled by two) so that no
-  // fragment is ever copied: a copy at the loop end would wait for the loads it was meant to hide.
-  auto m_tile = [&](int mt, const bf16x8 (&cur)[NCH][NP2], bf16x8 (&nxt)[NCH][NP2]) {
+  // One m-tile: request the NEXT m-tile's fragments and bias first (a whole m-tile of MFMAs ahead of their use),
+  // multiply with the current ones, activation, 4 stores.  Two register sets alternate (the loop is unrolled by two) so
+  // that nothing is copied at the loop end: a copy would wait for the loads it was meant to hide.
+  //   * The accumulators START at the bias (it is the C operand of the first chunk's MFMAs): no add in the epilogue.
+  //   * Every store is followed by 8 wait states.  hipcc assumes that a buffer_store_dwordx4 with an SGPR offset has
+  //     read its 16 bytes of data when it issues (GCNHazardRecognizer: "this hazard only exists if the instruction is
+  //     not using a register in the soffset field") and lets the register allocator's copies for the NEXT row overwrite
+  //     the data registers in the very next slot.  On gfx950 the store then picks up the new values in lanes 12-15 of
+  //     every 16-lane row - measured: the rows whose registers were re-used right away were wrong in exactly those
+  //     lanes, differently from run to run, only under load; with the writers kept away: bit-stable
+  //     (tools/dbg_expand.py).  The 4-/8-byte buffer stores of irb.hip / dw_plane.hip are not affected.
+  auto m_tile = [&](int mt, const bf16x8 (&cur)[NCH][NP2], bf16x8 (&nxt)[NCH][NP2], const f32x4& bcur, f32x4& bnxt) {
     const int mtn = (mt + 1 < mt1) ? mt + 1 : mt;           // the last one re-reads its own (harmless)
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int h = 0; h < NP2; ++h) nxt[c][h] = buf_load_frag(rw, a_voff, frag_soff(c, mtn, h));
+    bnxt = *reinterpret_cast<const f32x4*>(s_bias + (mtn - mt0) * 16 + 4 * kq);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[j] = bcur;               // acc[j][r] = bias of row 4 * kq + r
 #pragma unroll
     for (int c = 0; c < NCH; ++c) mfma_chunk<NPROD>(acc, cur[c][0], cur[c][NP2 - 1], bh[c], bl[c]);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + (mt - mt0) * 16 + 4 * kq);
     const unsigned y_soff = (unsigned)mt * 16u * (unsigned)S * 4u;
     const bool partial = mt >= m_full;                      // wave-uniform: only the last m-tile of a ragged Co
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float4 v;
+      f32x4 v;
       if constexpr (LINEAR)
-        v = make_float4(acc[0][r] + bv[r], acc[1][r] + bv[r], acc[2][r] + bv[r], acc[3][r] + bv[r]);
+        v = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
       else
-        v = make_float4(eat::act_apply(acc[0][r] + bv[r], ac), eat::act_apply(acc[1][r] + bv[r], ac),
-                        eat::act_apply(acc[2][r] + bv[r], ac), eat::act_apply(acc[3][r] + bv[r], ac));
+        v = f32x4{eat::act_apply(acc[0][r], ac), eat::act_apply(acc[1][r], ac), eat::act_apply(acc[2][r], ac),
+                  eat::act_apply(acc[3][r], ac)};
       const unsigned vo = (partial && mt * 16 + 4 * kq + r >= Co) ? kOOB : y_voff[r];
-      buf_store4(v, ry, vo, y_soff);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (int)vo, (int)y_soff, 0);
+      // the 128-bit data tuple is an INPUT of the wait: nothing can overwrite it before 8 wait states have passed
+      asm volatile("s_nop 7" ::"v"(v) : "memory");
     }
   };
 
   bf16x8 a0[NCH][NP2], a1[NCH][NP2];
+  f32x4 b0 = *reinterpret_cast<const f32x4*>(s_bias + 4 * kq), b1;
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -212,10 +223,10 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void pw_expand_kernel(
   __builtin_amdgcn_sched_barrier(0);
   int mt = mt0;
   for (; mt + 1 < mt1; mt += 2) {
-    m_tile(mt, a0, a1);
-    m_tile(mt + 1, a1, a0);
+    m_tile(mt, a0, a1, b0, b1);
+    m_tile(mt + 1, a1, a0, b1, b0);
   }
-  if (mt < mt1) m_tile(mt, a0, a1);
+  if (mt < mt1) m_tile(mt, a0, a1, b0, b1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -362,10 +373,14 @@ int try_stream(hipStream_t s, const float* x, const void* wp, const float* bias,
       default: return launch_expand<4, NPROD>(s, x, wp, bias, y, B, Ci, Co, S, act);
     }
   }
-  // bit 2: expand-shaped layers the x-resident kernel cannot take (C_in > 128, pooled head conv) as row chunks of the
-  // K-streaming kernel (x is re-read from L2 once per 96 output rows: it is the small operand of these layers)
-  if (ci_x != Ci ? (mode & 8) != 0 : (((mode & 2) && Co <= 2 * Ci) || (mode & 4))) {
-    const int MT = (Co + 15) / 16;
+  // bit 1 (the default): project-shaped layers where the K-streaming kernel measured faster in the mn10 forward at
+  // B = 256 - long reductions (C_in >= 160) that need no more row chunks than the LDS-staged kernel (<= 6 m-tiles, or as
+  // many chunks of <= 6 as of <= 8): 240->80 36->28 us, 672->160 41->28, 960->160 59->38; NOT 120->40 @ 16x125 (4
+  // chunks of K: 82 vs 86 us) and NOT 7 m-tiles (4 + 3 against one block of 7: 480->112 76 vs 87 us).
+  // bit 2: every other layer as row chunks of the K-streaming kernel (A/B and tests).
+  const int MT = (Co + 15) / 16;
+  const bool measured_win = Co <= 2 * Ci && Ci >= 160 && (MT + 5) / 6 == (MT + 7) / 8;
+  if (ci_x != Ci ? (mode & 8) != 0 : (((mode & 2) && measured_win) || (mode & 4))) {
     const int MC = (MT + 5) / 6;                             // at most 6 m-tiles of accumulators + fragments per wave
     const int mtw = (MT + MC - 1) / MC;
 #define EAT_CASE(n) \
@@ -383,7 +398,7 @@ int try_stream(hipStream_t s, const float* x, const void* wp, const float* bias,
 
 namespace {
 std::atomic<int>& stream_mode() {
-  static std::atomic<int> mode{getenv("EAT_PW_STREAM") ? atoi(getenv("EAT_PW_STREAM")) : 0};
+  static std::atomic<int> mode{getenv("EAT_PW_STREAM") ? atoi(getenv("EAT_PW_STREAM")) & 15 : 2};
   return mode;
 }
 }  // namespace

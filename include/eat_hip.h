@@ -299,11 +299,13 @@ int eat_pw_prepack_bf16(const float* w, const float* row_scale, void* wp, int Co
 int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, const float* in_scale,
                          const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
                          int split, eat_stream_t stream);
-/* Data-movement variant behind eat_pw_conv_bf16_fwd (same arithmetic and results): bit 0 = expand-shaped layers on the
- * x-resident kernel, bit 1 = project-shaped layers on the K-streaming kernel, bit 2 = every remaining layer on the
- * K-streaming kernel, bit 3 = the K-concat launches of eat_pw_conv_kcat_fwd on it (csrc/conv_pw_stream.hip); 0 = every
- * layer on the LDS-staged kernel.  mode >= 0 sets it process-wide (not per stream; meant for A/B runs and tests), mode < 0
- * only queries.  Returns the mode in effect BEFORE the call.  Default: environment variable EAT_PW_STREAM, else 0. */
+/* Data-movement variant behind eat_pw_conv_bf16_fwd (same arithmetic; results agree to fp32 round-off of the bias add):
+ * bit 0 = expand-shaped layers (C_out >= 2 C_in, C_in <= 128, no SE scale / residual / pool) on the x-resident kernel,
+ * bit 1 = the project-shaped layers on which it measured faster on the K-streaming kernel, bit 2 = every remaining layer
+ * on the K-streaming kernel, bit 3 = the K-concat launches of eat_pw_conv_kcat_fwd on it (csrc/conv_pw_stream.hip);
+ * 0 = every layer on the LDS-staged kernel.  mode >= 0 sets it process-wide (not per stream; meant for A/B runs and
+ * tests), mode < 0 only queries.  Returns the mode in effect BEFORE the call.  Default: environment variable
+ * EAT_PW_STREAM, else 2. */
 int eat_pw_stream_mode(int mode);
 
 /* ================= training-loop glue (ex_audioset.py:142-194) ========================= */

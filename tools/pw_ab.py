@@ -1,7 +1,9 @@
 """A/B of the bf16x3 1x1 kernels on the mn10 layer shapes at B = 256 (tools, not product):
 LDS-staged kernel (conv_pw_bf16.hip) vs the barrier-free kernels (conv_pw_stream.hip), HIP events on one stream.
   python tools/pw_ab.py [B]"""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficientat_amd import ops
 
