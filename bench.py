@@ -103,6 +103,10 @@ def _alg_bytes(name, a):
             mc = (mt + 5) // 6
             return f"pw_kstream_kernel<{(mt + mc - 1) // mc},{np_},*>", nbytes, flops
         return f"pw_conv_bf16_kernel<{mtw},{np_},*>", nbytes, flops
+    if name == "eat_expand_dw_bf16_fwd":
+        x, wp, be, wd, bd, y, pool, B, Ci, Ce, F, T, k, st, act = a[:15]
+        nbytes = 4 * B * F * T * (Ci + Ce) + 4 * Ce * (Ci + k * k)
+        return f"expand_dw_kernel<{(Ci + 31) // 32}>", nbytes, 2 * B * Ce * F * T * (Ci + k * k)
     if name == "eat_dw_conv_fwd":
         x, w, bias, y, pool, B, C, F, T, Fo, To, k, s, act = a[:14]
         nbytes, flops = 4 * B * C * (F * T + Fo * To) + 4 * C * k * k, 2 * B * C * Fo * To * k * k
@@ -557,6 +561,8 @@ def main():
         # one of the instruction the kernel issues: fp32 16x16x4 (157 TF), bf16 16x16x32 (2.5 PF dense), and
         # for the bf16x3 split kernel 2.5 PF / 3 because each useful product costs three bf16 MFMAs.
         mfma_peak = MFMA_F32_PEAK
+        if name.startswith("expand_dw_kernel"):
+            mfma_peak = MFMA_BF16_PEAK / 3
         if name.startswith(("pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel")):
             mfma_peak = MFMA_BF16_PEAK / (3 if ",3," in name else 1)
         mfma_bound = per_launch_flops / mfma_peak > per_launch_bytes / HBM_PEAK

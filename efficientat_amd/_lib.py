@@ -47,6 +47,7 @@ SIGNATURES = {
     "eat_front_fwd": [_P] * 8 + [_I] * 7 + [_P],
     "eat_dw_conv_fwd_tf": [_P, _P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P],
     "eat_dw_conv_wgrad_tf": [_P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
+    "eat_expand_dw_bf16_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_pw_prepack_bf16": [_P, _P, _P, _I, _I, _I, _P],
     "eat_pw_conv_bf16_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_ctx_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],

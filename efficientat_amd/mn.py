@@ -301,6 +301,11 @@ def run_block(blk, w, x, pool=None):
                           cnf.kernel, cnf.stride, act, res=inp if blk.use_res_connect else None)
     if "exp32" in w:
         x = ops.fused_expand_dw(x, *w["exp32"], *w["dw"], cnf.expanded_channels, cnf.kernel, cnf.stride, act, pool)
+    elif (blk.i_expand is not None and w["exp"][2] == "bf16x3" and cnf.dilation == 1
+          and ops.expand_dw_eligible(x.shape[1], x.shape[2], x.shape[3], cnf.kernel, cnf.stride)):
+        # late blocks with small planes: expand + depthwise in one kernel, the expanded tensor stays in LDS
+        x = ops.expand_dw_bf16(x, w["exp"][0], w["exp"][1], w["dw"][0], w["dw"][1], cnf.expanded_channels, cnf.kernel,
+                               cnf.stride, act, pool)
     else:
         if blk.i_expand is not None:
             x = _pw(x, w["exp"], cnf.expanded_channels, act)

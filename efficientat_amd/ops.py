@@ -363,6 +363,26 @@ def pw_prepack_bf16(w2d, row_scale=None, split=True):
     return wp
 
 
+_FUSE_EXPAND_DW = os.environ.get("EAT_FUSE_EXPAND_DW", "1") == "1"   # csrc/expand_dw.hip (A/B switch)
+
+
+def expand_dw_eligible(Ci, F, T, k, stride):
+    """Geometry of eat_expand_dw_bf16_fwd (csrc/expand_dw.hip): small planes, 3x3 / stride 1, C_in <= 128."""
+    S = F * T
+    return (_FUSE_EXPAND_DW and k == 3 and stride == 1 and 1 <= T <= 64 and 1 <= F <= 8 and S % 4 == 0 and S <= 512
+            and Ci % 4 == 0 and 4 <= Ci <= 128)
+
+
+def expand_dw_bf16(x, wp16_e, bias_e, w_d, bias_d, Ce, k, stride, act, pool=None):
+    """expand 1x1 (bf16x3) + BN + act -> depthwise 3x3 + BN + act (+ SE squeeze sums) in one kernel; the expanded tensor
+    never reaches HBM (eval; late blocks with small planes)."""
+    B, Ci, F, T = x.shape
+    y = torch.empty((B, Ce, F, T), device=x.device, dtype=torch.float32)
+    _lib.call("eat_expand_dw_bf16_fwd", _dev(x, "x"), wp16_e.data_ptr(), _dev(bias_e, "bias_e"), _dev(w_d, "w_d"),
+              _dev(bias_d, "bias_d"), y.data_ptr(), _opt(pool, "pool"), B, Ci, Ce, F, T, k, stride, act, _stream())
+    return y
+
+
 def pw_stream_mode(mode=-1):
     """Variant of the bf16 1x1 kernels (eat_pw_stream_mode): bit 0 expand-shaped layers on the x-resident kernel,
     bit 1 project-shaped layers on the K-streaming kernel; returns the previous mode, a negative argument only queries."""

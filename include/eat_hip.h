@@ -288,6 +288,16 @@ int eat_mbconv_fwd(const float* x, const float* wp_e, const float* bias_e, const
                    int B, int Cin, int Cexp, int Cout, int F, int T, int Fo, int To, int k, int stride,
                    int act, eat_stream_t stream);
 
+/* Expand 1x1 conv + BN + act -> depthwise 3x3 (stride 1) conv + BN + act [+ SE squeeze sums] in one kernel for small
+ * planes (models/mn/block_types.py:138-162, :72-73): the expanded tensor stays in LDS (csrc/expand_dw.hip).
+ * x (B,Ci,F,T) -> y (B,Ce,F,T); wp_e = eat_pw_prepack_bf16(split = 1) of the BN-folded expand weights (bf16x3
+ * arithmetic), bias_e (Ce); w_d (Ce,9), bias_d (Ce) BN-folded depthwise taps; pool (B,Ce) accumulates plane sums of y,
+ * or NULL.  Supported: k = 3, stride = 1, T <= 64, F <= 8, F*T % 4 == 0, F*T <= 512, Ci % 4 == 0, Ci <= 128; anything
+ * else returns EAT_EINVAL (use eat_pw_conv_bf16_fwd + eat_dw_conv_fwd). */
+int eat_expand_dw_bf16_fwd(const float* x, const void* wp_e, const float* bias_e, const float* w_d,
+                           const float* bias_d, float* y, float* pool, int B, int Ci, int Ce, int F, int T,
+                           int k, int stride, int act, eat_stream_t stream);
+
 /* ---- 1x1 conv on the bf16 matrix cores (fp32 activations in memory, fp32 accumulation) -----------
  * split != 0: "bf16x3" - x and w are split into bf16 hi + lo parts and y = w_hi x_hi + w_hi x_lo +
  *             w_lo x_hi (~2^-16 relative error per product) at 3/16 of the fp32-MFMA time;

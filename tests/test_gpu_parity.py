@@ -369,6 +369,35 @@ def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
     _close(got, ref.float(), 1e-5, "mbconv block")
 
 
+@pytest.mark.parametrize("B,Ci,Ce,F_,T,act,use_pool", [
+    (3, 80, 200, 8, 63, 2, False), (2, 112, 672, 8, 63, 2, True), (5, 80, 184, 8, 63, 2, False), (3, 80, 480, 8, 63, 1, True),
+    (2, 40, 120, 4, 32, 1, True), (3, 24, 72, 8, 64, 2, False), (2, 128, 256, 8, 13, 0, True), (9, 16, 40, 2, 2, 2, True),
+    (1, 96, 200, 7, 60, 2, False), (17, 112, 100, 3, 28, 1, True)])
+def test_expand_dw_fused_kernel(B, Ci, Ce, F_, T, act, use_pool):
+    """csrc/expand_dw.hip: expand 1x1 (bf16x3) + BN + act -> depthwise 3x3 + BN + act (+ squeeze sums) with the expanded
+    tensor in LDS, against the fp64 composition and against the two separate kernels (same products, same order: only
+    fp32 round-off of the depthwise accumulation may differ).  Every chunk count, ragged C_exp (200, 184, 100, 40), planes
+    narrower than / exactly as wide as a wave, fewer than 8 rows, planes that leave waves without columns, B not a
+    multiple of the 8 XCDs."""
+    x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
+    be, rs = _rand(Ce, seed=3, scale=0.2), torch.rand(Ce, generator=torch.Generator().manual_seed(4)) + 0.5
+    wd, bd = _rand(Ce, 1, 3, 3, seed=5, scale=0.3), _rand(Ce, seed=6, scale=0.1)
+    f = [lambda t: t, F.relu, F.hardswish][act]
+    e = f(F.conv2d(x.double(), (we * rs[:, None]).double().view(Ce, Ci, 1, 1), be.double()))
+    ref = f(F.conv2d(e, wd.double(), bd.double(), 1, 1, 1, Ce)).float()
+    wp = ops.pw_prepack_bf16(we.to(DEV), rs.to(DEV), True)
+    w9 = wd.reshape(Ce, 9).contiguous().to(DEV)
+    pool = torch.zeros(B, Ce, device=DEV) if use_pool else None
+    got = ops.expand_dw_bf16(x.to(DEV), wp, be.to(DEV), w9, bd.to(DEV), Ce, 3, 1, act, pool)
+    _close(got, ref, 3e-5, "fused expand + depthwise")
+    if use_pool:
+        _close(pool, ref.sum(dim=(2, 3)), 6e-4, "fused expand + depthwise: squeeze sums")
+    prev = ops.pw_stream_mode(0)
+    sep = ops.dw_conv(ops.pw_conv_bf16(x.to(DEV), wp, be.to(DEV), Ce, act, True), w9, bd.to(DEV), 3, 1, act)
+    ops.pw_stream_mode(prev)
+    _close(got, sep.cpu(), 3e-6, "fused kernel vs separate kernels")
+
+
 @pytest.fixture
 def pw_stream_all():
     """Route the bf16 1x1 convs through the barrier-free kernels of csrc/conv_pw_stream.hip for one test."""

@@ -2,7 +2,7 @@
 # Round-2 closing call: the whole GPU suite in ONE process (as the driver runs it), bench line + kernel table, rocprofv3
 # kernel stats and PMC passes with the shipped defaults (EAT_PW_STREAM unset = 2), whole-forward A/B of the 1x1 variants.
 set -u
-OUT=gpurun_out/r2f
+OUT=gpurun_out/r2i
 mkdir -p $OUT
 export TMPDIR=/tmp
 T0=$(date +%s)
@@ -14,8 +14,8 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | 
 stamp "bench"
 timeout 500 python bench.py --kernel-table > $OUT/bench.json 2> $OUT/bench_table.log
 tail -c 1500 $OUT/bench.json; grep "^\[bench\]" $OUT/bench_table.log
-stamp "whole-forward A/B"
-timeout 200 python tools/fwd_ab.py 0,2,3,15 2 2>&1 | grep -v amdgpu.ids > $OUT/fwd_ab_2.log; cat $OUT/fwd_ab_2.log
+stamp "fused expand + depthwise A/B"
+timeout 200 python tools/edw_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/edw_ab.log; cat $OUT/edw_ab.log
 stamp "rocprofv3 kernel stats"
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats -o s --output-format csv -- \
     python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.log)
