@@ -545,7 +545,7 @@ def main():
         per_launch_flops = d["flops"] / d["launches"]
         per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
         traffic, tsrc = None, None
-        for tfile in ("pmc_traffic_r2b.json", "pmc_traffic_r2.json", "pmc_traffic_r1.json"):
+        for tfile in ("pmc_traffic_r2c.json", "pmc_traffic_r2b.json", "pmc_traffic_r2.json", "pmc_traffic_r1.json"):
             tpath = os.path.join(ROOT, "profiles", tfile)
             if os.path.exists(tpath):
                 # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
