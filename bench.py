@@ -573,6 +573,9 @@ def main():
                   "mfma_tflops": round(per_launch_flops / per_launch_s / 1e12, 2),
                   "traffic_source": tsrc,
                   "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
+        if name.startswith(("mel_fwd_kernel", "dw_plane_kernel", "dw_conv_kernel", "stem_conv_kernel")):
+            # no MFMA in these kernels: their compute roof is the fp32 VECTOR peak, numerically the fp32-MFMA figure
+            common["compute_roof"] = "fp32 VALU peak (157.3 TFLOP/s); the kernel issues no MFMA instructions"
         if mfma_bound:
             ach = per_launch_flops / per_launch_s
             result["roofline"] = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": round(mfma_peak / 1e12, 1),

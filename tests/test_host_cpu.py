@@ -171,3 +171,18 @@ def test_audio_loader_resamples_like_librosa_load(tmp_path):
     assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3                # away from the filter's edge transients
     y2, sr2 = load_audio(str(tmp_path / "a.wav"), sr=None, mono=False)
     assert sr2 == 44100 and y2.shape == (2, 44100)
+
+
+def test_fused_expand_dw_eligibility_rule():
+    """ops.expand_dw_eligible mirrors the geometry check of eat_expand_dw_bf16_fwd (csrc/expand_dw.hip): mn10's blocks
+    8-12 at 10 s clips qualify, the 16x125 / 4x32-with-C_in-160 / strided / 5x5 blocks do not."""
+    from efficientat_amd import ops
+    if not ops._FUSE_EXPAND_DW:
+        pytest.skip("EAT_FUSE_EXPAND_DW=0")
+    assert ops.expand_dw_eligible(80, 8, 63, 3, 1) and ops.expand_dw_eligible(112, 8, 63, 3, 1)
+    assert ops.expand_dw_eligible(40, 4, 32, 3, 1)
+    assert not ops.expand_dw_eligible(40, 16, 125, 5, 1)      # plane too large, 5x5
+    assert not ops.expand_dw_eligible(112, 8, 63, 5, 2)       # stride 2
+    assert not ops.expand_dw_eligible(160, 4, 32, 3, 1)       # five chunks of x fragments do not fit the registers
+    assert not ops.expand_dw_eligible(80, 8, 63 + 2, 3, 1)    # wider than a wave
+    assert not ops.expand_dw_eligible(80, 7, 9, 3, 1)         # 63 positions: not a multiple of 4
