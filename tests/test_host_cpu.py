@@ -186,3 +186,14 @@ def test_fused_expand_dw_eligibility_rule():
     assert not ops.expand_dw_eligible(160, 4, 32, 3, 1)       # five chunks of x fragments do not fit the registers
     assert not ops.expand_dw_eligible(80, 8, 63 + 2, 3, 1)    # wider than a wave
     assert not ops.expand_dw_eligible(80, 7, 9, 3, 1)         # 63 positions: not a multiple of 4
+
+
+def test_mel_basis_matches_real_torchaudio_when_installed():
+    """The kaldi mel basis is restated from torchaudio 0.13 (not importable in the build image).  Wherever the real
+    library IS installed, the restatement must agree with it bit for bit (models/preprocess.py:52-53 call site)."""
+    kaldi = pytest.importorskip("torchaudio.compliance.kaldi", reason="torchaudio not installed")
+    if "ref_shims" in (getattr(kaldi, "__file__", "") or ""):
+        pytest.skip("oracle/ref_shims stand-in on the path, not the real torchaudio")
+    for fmin, fmax in [(0.0, 15000.0), (3.0, 14001.0), (9.0, 16000.0), (5.0, 15500.0)]:
+        ref, _ = kaldi.get_mel_banks(128, 1024, 32000, fmin, fmax, 100.0, -500.0, 1.0)
+        assert torch.equal(kaldi_mel_basis(128, 1024, 32000, fmin, fmax), ref)
