@@ -13,7 +13,9 @@ copy is the step: a PCIe Gen5 x16 link carries ~40-45 k clips/s of fp32 waveform
     host memcpy that replaces the driver's hidden bounce buffer;
   * the H2D copies run on a dedicated HIP stream, overlapped with the compute stream's kernels of the previous step;
   * `__next__` makes the compute stream wait on the slot's copy event (no host sync) and hands out device tensors; the
-    slot is recycled only after the consumer's stream has passed a "released" event, so nothing is overwritten in flight;
+    slot is recycled only after the consumer's stream has passed a "released" event (recorded when the consumer asks for
+    the next batch), so nothing is overwritten under kernels already enqueued - but the tensors of a batch are only
+    valid UNTIL THE NEXT BATCH IS REQUESTED (clone what must outlive the step);
   * non-tensor entries (file names) pass through untouched.
 
 There is no CPU mode: without a GPU it raises, like the rest of the package.
