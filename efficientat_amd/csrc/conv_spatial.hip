@@ -4,6 +4,7 @@
 // (global-average-pool partial sums) of SqueezeExcitation are fused into the epilogue.
 // Reference call sites: models/mn/model.py:124-133 (stem), models/mn/block_types.py:150-162 (dw),
 // models/mn/block_types.py:72-73 (SE mean).
+#include <cstdlib>
 #include "eat_common.h"
 
 namespace {
@@ -186,7 +187,8 @@ int launch_dw(const float* x, const float* w, const float* bias, float* y, float
 }
 
 int dispatch_dw(const float* x, const float* w, const float* bias, float* y, float* pool, int B, int C, int F, int T,
-                int Fo, int To, int k, int stride, int act, const DwDyn* dyn, hipStream_t s) {
+                int Fo, int To, int k, int stride, int act, const DwDyn* dyn, hipStream_t s,
+                const eat::DwEpi* epi = nullptr) {
   const int p = (k - 1) / 2;
   if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
     return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd: output %dx%d inconsistent with input %dx%d k=%d s=%d", Fo, To, F, T, k, stride);
@@ -194,9 +196,10 @@ int dispatch_dw(const float* x, const float* w, const float* bias, float* y, flo
     // register-resident kernels (dw_plane.hip: whole small planes, tiles of large ones); 1 = geometry not instantiated
     const int rc = eat::dw_plane_try(x, w, bias, dyn ? dyn->res : nullptr, y, pool, B, C, F, T, Fo, To, k, stride, act,
                                      dyn ? dyn->flip : 0, dyn ? dyn->per_plane_w : 0, dyn ? dyn->in_a : nullptr,
-                                     dyn ? dyn->in_b : nullptr, dyn ? dyn->in_act : 0, s);
+                                     dyn ? dyn->in_b : nullptr, dyn ? dyn->in_act : 0, s, epi);
     if (rc != 1) return rc;
   }
+  if (epi) return 1;       // training epilogues exist in the register-resident kernels only: the caller falls back
   if (k == 3 && stride == 1) return launch_dw<3, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
   if (k == 3 && stride == 2) return launch_dw<3, 2>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
   if (k == 5 && stride == 1) return launch_dw<5, 1>(x, w, bias, y, pool, B, C, F, T, Fo, To, act, dyn, s);
@@ -234,12 +237,38 @@ extern "C" int eat_dw_conv_fwd_tf(const float* x, const float* in_a, const float
   return dispatch_dw(x, w, bias, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
 }
 
+// Train-mode depthwise conv (models/mn/block_types.py:150-162 under model.train()): y = conv(act_in(in_a x + in_b)) (in_a
+// NULL: plain x) with the per-wave partial sums of y for the BatchNorm that follows (layout [b][2][C][inner] floats;
+// *h_inner receives inner, which never exceeds inner_cap = eat_dw_partials_inner(...)).  Geometries without a
+// register-resident kernel run the row-ring kernel followed by a one-block-per-plane statistics pass (inner = 1).
+extern "C" int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                                     float* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T,
+                                     int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if ((in_a == nullptr) != (in_b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: in_a and in_b come together");
+  if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: bad in_act %d", in_act);
+  if (!part || !h_inner || inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 0))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: partial buffer too small (inner_cap %d)", inner_cap);
+  const DwDyn dyn{nullptr, nullptr, nullptr, nullptr, 0, 0, in_a, in_b, in_act};
+  static const bool fused = !(getenv("EAT_DW_STATS_FUSED") && atoi(getenv("EAT_DW_STATS_FUSED")) == 0);
+  int inner = 1;
+  if (fused) {
+    const eat::DwEpi epi{part, nullptr, nullptr, nullptr, 0, nullptr, &inner};
+    const int rc = dispatch_dw(x, w, nullptr, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream, &epi);
+    if (rc != 1) { *h_inner = inner; return rc; }
+  }
+  const int rc = dispatch_dw(x, w, nullptr, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream);
+  if (rc != 0) return rc;
+  *h_inner = 1;
+  return eat::bn_stats_partial(y, B, C, Fo * To, part, (hipStream_t)stream);
+}
+
 // stride-1 depthwise data gradient = the same sliding-window kernel with the taps read reversed
 namespace eat {
 int dw_conv_dgrad_s1(const float* dz, const float* w, const float* zero_bias, const float* res, float* dx, int B, int C,
-                     int F, int T, int k, int per_plane_w, hipStream_t s) {
+                     int F, int T, int k, int per_plane_w, hipStream_t s, const DwEpi* epi) {
   const DwDyn dyn{nullptr, nullptr, nullptr, res, 1, per_plane_w};
-  return dispatch_dw(dz, w, zero_bias, dx, nullptr, B, C, F, T, F, T, k, 1, EAT_ACT_NONE, &dyn, s);
+  return dispatch_dw(dz, w, zero_bias, dx, nullptr, B, C, F, T, F, T, k, 1, EAT_ACT_NONE, &dyn, s, epi);
 }
 }  // namespace eat
 

@@ -61,7 +61,15 @@ struct PlaneArgs {
   const float* x; const float* w; const float* bias; const float* res; float* y; float* pool;
   int B, C, T, To, G, flip, act;
   InTf tf;
+  eat::DwEpi epi;
 };
+
+// d act(u) / du, PyTorch conventions (nn.ReLU / nn.Hardswish backward); `act` is wave-uniform
+__device__ __forceinline__ float act_deriv(float u, int act) {
+  if (act == EAT_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
+  if (act == EAT_ACT_HSWISH) return u < -3.0f ? 0.0f : (u <= 3.0f ? fmaf(u, 1.0f / 3.0f, 0.5f) : 1.0f);
+  return 1.0f;
+}
 
 
 // K, S: kernel size / stride; CPL: input columns per lane; LPP: lanes per plane (64, or 32 = two planes per wave);
@@ -91,7 +99,11 @@ __device__ __forceinline__ void buf_store2(float v0, float v1, __amdgpu_buffer_r
 
 // PF: keep the next plane group of the wave loading while the current one is multiplied (small planes; big planes have
 // enough bytes in flight from the waves of the CU alone and need the registers)
-template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, bool RES>
+// EPI: 0 plain, 1 residual add (res), 2 training data gradient: the output is multiplied by act'(ga[c] * gz + gb[c]) of
+// the tensor gz at the output positions and summed per plane (epi.gpart) - the backward of the BatchNorm + activation
+// that FOLLOWS in forward order starts inside the kernel that produces its incoming gradient (mn_train.py);
+// STATS: per-plane sum / sum of squares of the output (epi.stats), the BatchNorm batch statistics of the conv output
+template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS>
 __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const float* __restrict__ w_,
                                                        const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2;
@@ -173,13 +185,15 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
     const float b = bias_ ? bias_[c] : 0.0f;
     const long long y_left = 4 * (y_elems - (long long)p * (Fo * To));
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)p * (Fo * To), y_left);
-    const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((RES ? a.res : a.y) + (size_t)p * (Fo * To), y_left);
+    constexpr bool RES = EPI == 1;
+    const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.y) + (size_t)p * (Fo * To), y_left);
+    const float g_a = EPI == 2 ? a.epi.ga[c] : 0.0f, g_b = EPI == 2 ? a.epi.gb[c] : 0.0f;
     unsigned vo[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) vo[j] = mine ? vout[j] : kOOB;
     const bool has0 = NO * l < To && mine, has1 = NO * l + 1 < To && mine;     // which of the lane's output columns exist
     float ext[F][NE];
-    float psum = 0.0f;
+    float psum = 0.0f, psq = 0.0f;
 #pragma unroll
     for (int i = 0; i < Fo; ++i) {
       __builtin_amdgcn_sched_barrier(0);      // keep the shifted copies of later rows from being hoisted (VGPR pressure)
@@ -220,27 +234,48 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
       if constexpr (NO == 1) {
         float o = eat::activate<ACT>(acc[0]);
         if constexpr (RES) o += buf_load(rr_, vo[0], so);
+        if constexpr (EPI == 2) o *= act_deriv(fmaf(g_a, buf_load(rr_, vo[0], so), g_b), a.epi.gact);
         buf_store(o, ry, vo[0], so);
         psum += has0 ? o : 0.0f;
+        if constexpr (STATS) psq += has0 ? o * o : 0.0f;
       } else {
         float o0 = eat::activate<ACT>(acc[0]), o1 = eat::activate<ACT>(acc[1]);
-        if constexpr (RES) {
+        if constexpr (EPI != 0) {
           const f32x2 rv = buf_load2(rr_, has0 ? 4u * (unsigned)(half * C * (Fo * To) + NO * l) : kOOB, so);
-          o0 += rv[0]; o1 += rv[1];             // (o1 of a lane without a second column is never stored)
+          if constexpr (EPI == 1) {
+            o0 += rv[0]; o1 += rv[1];             // (o1 of a lane without a second column is never stored)
+          } else {
+            o0 *= act_deriv(fmaf(g_a, rv[0], g_b), a.epi.gact);
+            o1 *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
+          }
         }
         buf_store2(o0, o1, ry, vo[0], so);
         buf_store(o0, ry, vo[1], so);
         psum += (has0 ? o0 : 0.0f) + (has1 ? o1 : 0.0f);
+        if constexpr (STATS) psq += (has0 ? o0 * o0 : 0.0f) + (has1 ? o1 * o1 : 0.0f);
       }
     }
-    if (a.pool) {
+    if (a.pool || STATS || EPI == 2) {
       if (LPP == 64) {
         psum = eat::wave_sum(psum);
+        if constexpr (STATS) psq = eat::wave_sum(psq);
       } else {
 #pragma unroll
-        for (int o = LPP >> 1; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+        for (int o = LPP >> 1; o > 0; o >>= 1) {
+          psum += __shfl_xor(psum, o, 64);
+          if constexpr (STATS) psq += __shfl_xor(psq, o, 64);
+        }
       }
-      if (l == 0 && mine) atomicAdd(a.pool + p + half * C, psum);
+      if (l == 0 && mine) {
+        if (a.pool) atomicAdd(a.pool + p + half * C, psum);
+        // plain stores: the wave owns the plane (partials [b][2][C] / [b][C], reduced by the finalize kernels)
+        const int bsm = (p + half * C) / C;
+        if constexpr (STATS) {
+          a.epi.stats[((size_t)bsm * 2 + 0) * C + c] = psum;
+          a.epi.stats[((size_t)bsm * 2 + 1) * C + c] = psq;
+        }
+        if constexpr (EPI == 2) a.epi.gpart[(size_t)bsm * C + c] = psum;
+      }
     }
   };
 
@@ -272,10 +307,15 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   a.G = G;
   const int waves = (n_groups + G - 1) / G;
   const dim3 grid((waves + 3) / 4), blk(256);
-  if (a.res) {
-    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, true>), grid, blk, 0, s, a, a.w, a.bias);
+  if (a.epi.inner) *a.epi.inner = 1;
+  if (a.epi.gz) {
+    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 2, false>), grid, blk, 0, s, a, a.w, a.bias);
+  } else if (a.epi.stats) {
+    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true>), grid, blk, 0, s, a, a.w, a.bias);
+  } else if (a.res) {
+    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 1, false>), grid, blk, 0, s, a, a.w, a.bias);
   } else {
-    EAT_DISPATCH_ACT(a.act, hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, ACT, false>), grid, blk, 0, s, a, a.w, a.bias));
+    EAT_DISPATCH_ACT(a.act, hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, ACT, 0, false>), grid, blk, 0, s, a, a.w, a.bias));
   }
   return eat::check_launch("eat_dw_conv_fwd(plane)");
 }
@@ -290,9 +330,10 @@ struct TileArgs {
   const float* x; const float* res; float* y; float* pool;
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, flip, per_plane_w;
   InTf tf;
+  eat::DwEpi epi;
 };
 
-template <int K, int S, int RO, int ACT, bool RES>
+template <int K, int S, int RO, int ACT, int EPI, bool STATS>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const float* __restrict__ w_,
                                                       const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2, CPL = 2, LPP = 64;
@@ -324,7 +365,9 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
   const long long y_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)p * Fo * To, y_left);
-  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((RES ? a.res : a.y) + (size_t)p * Fo * To, y_left);
+  constexpr bool RES = EPI == 1;
+  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.y) + (size_t)p * Fo * To, y_left);
+  const float g_a = EPI == 2 ? a.epi.ga[c] : 0.0f, g_b = EPI == 2 ? a.epi.gb[c] : 0.0f;
 
   float r[FI][CPL];
 #pragma unroll
@@ -356,7 +399,7 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
   const float b = bias_ ? bias_[c] : 0.0f;
 
   float ext[FI][NE];
-  float psum = 0.0f;
+  float psum = 0.0f, psq = 0.0f;
 #pragma unroll
   for (int i = 0; i < RO; ++i) {
     __builtin_amdgcn_sched_barrier(0);
@@ -392,22 +435,44 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
     if constexpr (NO == 1) {
       float o = eat::activate<ACT>(acc[0]);
       if constexpr (RES) o += buf_load(rr_, v0, so);
+      if constexpr (EPI == 2) o *= act_deriv(fmaf(g_a, buf_load(rr_, v0, so), g_b), a.epi.gact);
       buf_store(o, ry, v0, so);
       psum += (rowok && ok0) ? o : 0.0f;
+      if constexpr (STATS) psq += (rowok && ok0) ? o * o : 0.0f;
     } else {
       float o0 = eat::activate<ACT>(acc[0]), o1 = eat::activate<ACT>(acc[1]);
-      if constexpr (RES) {
+      if constexpr (EPI != 0) {
         const f32x2 rv = buf_load2(rr_, (rowok && ok0) ? 4u * (unsigned)oc : kOOB, so);
-        o0 += rv[0]; o1 += rv[1];
+        if constexpr (EPI == 1) {
+          o0 += rv[0]; o1 += rv[1];
+        } else {
+          o0 *= act_deriv(fmaf(g_a, rv[0], g_b), a.epi.gact);
+          o1 *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
+        }
       }
       buf_store2(o0, o1, ry, v0, so);
       buf_store(o0, ry, v1, so);
       psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
+      if constexpr (STATS) psq += ((rowok && ok0) ? o0 * o0 : 0.0f) + ((rowok && ok1) ? o1 * o1 : 0.0f);
     }
   }
   if (a.pool) {
+    const float ps = eat::wave_sum(psum);
+    if (l == 0) atomicAdd(a.pool + p, ps);
+  }
+  // training epilogues: one partial per wave (= per tile), plain stores; layouts [b][2][C][tpp] and [b][C][tpp]
+  if constexpr (STATS) {
     psum = eat::wave_sum(psum);
-    if (l == 0) atomicAdd(a.pool + p, psum);
+    psq = eat::wave_sum(psq);
+    if (l == 0) {
+      const int bsm = p / a.C;
+      a.epi.stats[(((size_t)bsm * 2 + 0) * a.C + c) * tpp + t] = psum;
+      a.epi.stats[(((size_t)bsm * 2 + 1) * a.C + c) * tpp + t] = psq;
+    }
+  }
+  if constexpr (EPI == 2) {
+    psum = eat::wave_sum(psum);
+    if (l == 0) a.epi.gpart[(size_t)p * tpp + t] = psum;
   }
 }
 
@@ -420,10 +485,15 @@ int launch_tile(TileArgs a, const float* w, const float* bias, int act, hipStrea
   const long long waves = (long long)a.B * a.C * a.n_rc * a.n_cs;
   if (waves > 0x7fffffffLL) return 1;
   const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
-  if (a.res) {
-    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, true>), grid, blk, 0, s, a, w, bias);
+  if (a.epi.inner) *a.epi.inner = a.n_rc * a.n_cs;
+  if (a.epi.gz) {
+    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 2, false>), grid, blk, 0, s, a, w, bias);
+  } else if (a.epi.stats) {
+    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 0, true>), grid, blk, 0, s, a, w, bias);
+  } else if (a.res) {
+    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 1, false>), grid, blk, 0, s, a, w, bias);
   } else {
-    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, ACT, false>), grid, blk, 0, s, a, w, bias));
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, ACT, 0, false>), grid, blk, 0, s, a, w, bias));
   }
   return eat::check_launch("eat_dw_conv_fwd(tile)");
 }
@@ -436,9 +506,10 @@ int launch_tile(TileArgs a, const float* w, const float* bias, int act, hipStrea
 struct TileDgArgs {
   const float* dz; const float* res; float* dx;
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, per_plane_w;
+  eat::DwEpi epi;
 };
 
-template <int K, int RO, bool RES>
+template <int K, int RO, int EPI>
 __global__ __launch_bounds__(256) void dw_tile_dgrad2_kernel(const TileDgArgs a, const float* __restrict__ w_) {
   constexpr int P = (K - 1) / 2, LPP = 64;
   constexpr int FI = RO + 2;                             // dz rows of a tile incl. one halo row above and below
@@ -462,7 +533,10 @@ __global__ __launch_bounds__(256) void dw_tile_dgrad2_kernel(const TileDgArgs a,
   const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
   const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * Fo * To, z_left);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.dx + (size_t)p * F * T, x_left);
-  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((RES ? a.res : a.dx) + (size_t)p * F * T, x_left);
+  constexpr bool RES = EPI == 1;
+  const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.dx) + (size_t)p * F * T, x_left);
+  const float g_a = EPI == 2 ? a.epi.ga[c] : 0.0f, g_b = EPI == 2 ? a.epi.gb[c] : 0.0f;
+  float psum = 0.0f;
   float z[FI][3];                                        // [row][q-1, q, q+1]
 #pragma unroll
   for (int i = 0; i < FI; ++i) {
@@ -509,9 +583,20 @@ __global__ __launch_bounds__(256) void dw_tile_dgrad2_kernel(const TileDgArgs a,
         o[0] += rv[0] + buf_load(rr_, v1, so);
         o[1] += rv[1];
       }
+      if constexpr (EPI == 2) {
+        const f32x2 rv = buf_load2(rr_, v2, so);
+        const float z0 = rv[0] + buf_load(rr_, v1, so);     // one of the two loads is out of range (returns 0)
+        o[0] *= act_deriv(fmaf(g_a, z0, g_b), a.epi.gact);
+        o[1] *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
+        psum += (rowok && mine) ? (o[0] + (two ? o[1] : 0.0f)) : 0.0f;
+      }
       buf_store2(o[0], o[1], rx, v2, so);
       buf_store(o[0], rx, v1, so);
     }
+  }
+  if constexpr (EPI == 2) {
+    psum = eat::wave_sum(psum);
+    if (l == 0) a.epi.gpart[(size_t)p * tpp + t] = psum;
   }
 }
 
@@ -524,8 +609,10 @@ int launch_tile_dgrad2(TileDgArgs a, const float* w, hipStream_t s) {
   const long long waves = (long long)a.B * a.C * a.n_rc * a.n_cs;
   if (waves > 0x7fffffffLL) return 1;
   const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
-  if (a.res) hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, true>), grid, blk, 0, s, a, w);
-  else hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, false>), grid, blk, 0, s, a, w);
+  if (a.epi.inner) *a.epi.inner = a.n_rc * a.n_cs;
+  if (a.epi.gz) hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, 2>), grid, blk, 0, s, a, w);
+  else if (a.res) hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, 1>), grid, blk, 0, s, a, w);
+  else hipLaunchKernelGGL((dw_tile_dgrad2_kernel<K, RO, 0>), grid, blk, 0, s, a, w);
   return eat::check_launch("eat_dw_conv_dgrad(tile)");
 }
 
@@ -830,22 +917,24 @@ namespace eat {
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B, int C,
                  int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
-                 const float* in_b, int in_act, hipStream_t s) {
+                 const float* in_b, int in_act, hipStream_t s, const DwEpi* epi_) {
   static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
   if (off) return 1;
   const long long n_planes = (long long)B * C;
   if (n_planes > 0x3fffffffLL) return 1;                 // plane bases are 64-bit, offsets inside a plane 32-bit
   if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only
+  const DwEpi epi = epi_ ? *epi_ : DwEpi{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  if ((epi.stats || epi.gz) && (res || pool || act != EAT_ACT_NONE || per_plane_w)) return 1;   // training epilogues: plain conv only
   static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
   if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {            // large planes: tiles of rows x column strips
-    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w, InTf{in_a, in_b, in_act}};
+    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w, InTf{in_a, in_b, in_act}, epi};
     if (k == 3 && stride == 1) return launch_tile<3, 1, 16>(ta, w, bias, act, s);
     if (k == 5 && stride == 1) return launch_tile<5, 1, 16>(ta, w, bias, act, s);
     if (k == 3 && stride == 2) return launch_tile<3, 2, 8>(ta, w, bias, act, s);
     if (k == 5 && stride == 2) return launch_tile<5, 2, 8>(ta, w, bias, act, s);
   }
   if (per_plane_w) return 1;                             // whole-plane kernels below: per-channel taps only
-  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}};
+  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}, epi};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane<3, 1, 1, 64, 8, true>(a, s);
   static const int pfb = getenv("EAT_DWP_PFB") ? atoi(getenv("EAT_DWP_PFB")) : 0;
   if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128)
@@ -880,13 +969,27 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
 }
 
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
-                       int To, int k, int per_plane_w, hipStream_t s) {
+                       int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi_) {
   static const int on = getenv("EAT_DWP_DGRAD2") ? atoi(getenv("EAT_DWP_DGRAD2")) : 1;
   if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
-  TileDgArgs a{dz, res, dx, B, C, F, T, Fo, To, 0, 0, 0, per_plane_w};
+  const DwEpi epi = epi_ ? *epi_ : DwEpi{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  if (epi.gz && (res || per_plane_w)) return 1;
+  TileDgArgs a{dz, res, dx, B, C, F, T, Fo, To, 0, 0, 0, per_plane_w, epi};
   if (k == 3) return launch_tile_dgrad2<3>(a, w, s);
   if (k == 5) return launch_tile_dgrad2<5>(a, w, s);
   return 1;
 }
 
 }  // namespace eat
+
+// Upper bound of the partial slots per plane the training epilogues write (the host sizes its buffers with it):
+// dgrad == 0: forward conv (F,T) -> (Fo,To); dgrad == 1: data gradient of that conv (dz (Fo,To) -> dx (F,T)).
+extern "C" int eat_dw_partials_inner(int F, int T, int Fo, int To, int k, int stride, int dgrad) {
+  (void)F;
+  if (dgrad && stride == 2) return ((Fo + 7) / 8) * ((To + 61) / 62);           // launch_tile_dgrad2
+  const int t_in = dgrad ? T : T, t_out = dgrad ? T : To, f_out = dgrad ? F : Fo, s = dgrad ? 1 : stride;
+  if (t_in <= 128) return 1;                                                      // whole-plane kernels / fallback
+  const int wmax = s == 1 ? (k == 3 ? 125 : 124) : (k == 3 ? 63 : 62), ro = s == 1 ? 16 : 8;
+  return ((t_out + wmax - 1) / wmax) * ((f_out + ro - 1) / ro);
+}
+

@@ -43,9 +43,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kWave = 64;
 
+// Training epilogues of the register-resident depthwise kernels (dw_plane.hip), all optional:
+//   stats   forward: per-wave partial sums of the conv output, floats [b][2][C][inner] (sum, sum of squares) - the
+//           BatchNorm batch statistics without a separate pass over the tensor (eat_bn_finalize_partials reduces them);
+//   gz/ga/gb/gact/gpart   data gradient: the output dx is multiplied by act'(ga[c] * gz + gb[c]) (gz: the pre-BN tensor
+//           of the layer below, same shape as dx) and summed per wave into gpart [b][C][inner];
+//   inner   (host pointer) receives the number of partial slots per plane of the kernel that ran.
+struct DwEpi {
+  float* stats;
+  const float* gz; const float* ga; const float* gb; int gact; float* gpart;
+  int* inner;
+};
+
 // conv_spatial.hip: stride-1 depthwise data gradient on the forward sliding-window kernel
+// (epi with gz: the training epilogue; returns 1 when no register-resident kernel covers the geometry)
 int dw_conv_dgrad_s1(const float* dz, const float* w, const float* zero_bias, const float* res, float* dx, int B, int C,
-                     int F, int T, int k, int per_plane_w, hipStream_t s);
+                     int F, int T, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
+
+// train_fuse.hip: generic (any geometry) forms of the two training epilogues, one block per plane, inner = 1
+int bn_stats_partial(const float* z, int B, int C, int S, float* part, hipStream_t s);
+int act_grad_sum(const float* dy, const float* z, const float* a, const float* b, int act, float* g, float* gpart, int B,
+                 int C, int S, hipStream_t s);
 
 // conv_pw_generic.hip: 1x1 conv for plane sizes that are not a multiple of 4 (same packed weights / epilogue contract;
 // wmode 0 = fp32 pack, 1 = bf16 pack, 2 = bf16 hi/lo pack; wp_bstride_bytes != 0 selects per-sample weights)
@@ -65,11 +83,11 @@ int irb_try(const float* x, const float* wp_e, const float* bias_e, const float*
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B,
                  int C, int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
-                 const float* in_b, int in_act, hipStream_t s);
+                 const float* in_b, int in_act, hipStream_t s, const DwEpi* epi = nullptr);
 int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
                        int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s);
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
-                       int To, int k, int per_plane_w, hipStream_t s);
+                       int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
 int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,
               const float* wp_p, const float* bias_p, float* y, int B, int C, int F, int T, int Fo, int To, int act,
               hipStream_t s);

@@ -939,6 +939,32 @@ extern "C" int eat_dw_conv_dgrad(const float* dz, const float* w, const float* r
   return dw_dgrad_impl(dz, w, res, dx, B, C, F, T, Fo, To, k, stride, 0, stream);
 }
 
+// Depthwise data gradient with the backward of the PRECEDING (forward order) BatchNorm + activation started in its
+// epilogue: g = dgrad(dz) * act'(ga[c] * gz + gb[c]) and the per-wave partial sums of g (gpart [b][C][inner]); gz is the
+// pre-BN output of the expand conv (same shape as g).  See train_fuse.hip for what consumes g / gpart.
+extern "C" int eat_dw_conv_dgrad_g(const float* dz, const float* w, const float* gz, const float* ga, const float* gb,
+                                   int gact, float* g, float* gpart, int inner_cap, int* h_inner, int B, int C, int F,
+                                   int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!gz || !ga || !gb || !gpart || !h_inner) return eat::fail(EAT_EINVAL, "eat_dw_conv_dgrad_g: gz, ga, gb, gpart, h_inner are required");
+  if (gact < 0 || gact > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_dgrad_g: bad act %d", gact);
+  if (inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 1))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dgrad_g: partial buffer too small (inner_cap %d)", inner_cap);
+  hipStream_t s = (hipStream_t)stream;
+  static const bool fused = !(getenv("EAT_DW_GEPI_FUSED") && atoi(getenv("EAT_DW_GEPI_FUSED")) == 0);
+  if (fused && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+    int inner = 1;
+    const eat::DwEpi epi{nullptr, gz, ga, gb, gact, gpart, &inner};
+    const int rc = stride == 1 ? eat::dw_conv_dgrad_s1(dz, w, nullptr, nullptr, g, B, C, F, T, k, 0, s, &epi)
+                               : eat::dw_tile_dgrad2_try(dz, w, nullptr, g, B, C, F, T, Fo, To, k, 0, s, &epi);
+    if (rc != 1) { *h_inner = inner; return rc; }
+  }
+  const int rc = dw_dgrad_impl(dz, w, nullptr, g, B, C, F, T, Fo, To, k, stride, 0, stream);
+  if (rc != 0) return rc;
+  *h_inner = 1;
+  return eat::act_grad_sum(g, gz, ga, gb, gact, g, gpart, B, C, F * T, s);
+}
+
 extern "C" int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const float* res, float* dx, int B, int C,
                                      int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();

@@ -1,0 +1,291 @@
+// Training-step kernels, round 3: BatchNorm statistics and BatchNorm-backward reductions WITHOUT their own passes over
+// the expanded tensors (reference: nn.BatchNorm2d(eps=1e-3, momentum=0.01) in train mode, models/mn/model.py:114-115,
+// autograd over models/mn/block_types.py:138-181).
+//
+//  (1) per-wave partial sums written by the producing kernels (dw_plane.hip epilogues) are reduced here, per channel, in
+//      fp64 - no atomics, no zero-filled accumulators, bit-reproducible;
+//  (2) the expand 1x1 conv z = W x has its batch statistics from the Gram matrix of its (3-6x narrower) input:
+//      sum z = W sx, sum z^2 = diag(W G W^T) with sx = sum x, G = sum x x^T - z is never read for statistics;
+//  (3) its BatchNorm backward is linear in xhat = (W x - mu) invstd, so with g = dy * act'(.) (written by the depthwise
+//      data-gradient kernel's epilogue) and Gx = sum g x^T:
+//        dgamma = invstd * (rowsum(W .* Gx) - mu S1),  dbeta = S1 = sum g,  m1 = S1 / N,  m2 = dgamma / N
+//        dW  = diag(a) [Gx - m1 sx^T - diag(m2 invstd)(W G - mu sx^T)]
+//        dx  = (W^T diag(a)) g + M x + c0,   M = -W^T diag(a m2 invstd) W,   c0 = W^T (a (m2 invstd mu - m1))
+//      i.e. the tensor dz = a (g - m1 - xhat m2) is never formed: two 1x1 convs (one over the narrow input) replace the
+//      reduce pass, the apply pass and its re-reads.
+#include <cstdlib>
+#include "eat_common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_deriv(float u, int act) {
+  if (act == EAT_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
+  if (act == EAT_ACT_HSWISH) return u < -3.0f ? 0.0f : (u <= 3.0f ? fmaf(u, 1.0f / 3.0f, 0.5f) : 1.0f);
+  return 1.0f;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of up to 3 doubles (blockDim.x = 256); result valid in every thread
+__device__ __forceinline__ void block_sum_d(double& a, double& b, double& c, double* s_red) {
+  a = wave_sum_d(a); b = wave_sum_d(b); c = wave_sum_d(c);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();                              // s_red may still be read from a previous call
+  if (lane == 0) { s_red[wv] = a; s_red[4 + wv] = b; s_red[8 + wv] = c; }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0, tc = 0.0;
+  for (int i = 0; i < nw; ++i) { ta += s_red[i]; tb += s_red[4 + i]; tc += s_red[8 + i]; }
+  a = ta; b = tb; c = tc;
+}
+
+// ---- generic producers of the partials (any geometry): one block per (b,c) plane, inner = 1 ------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int C, int S,
+                                                               float* __restrict__ part) {
+  __shared__ float s_red[16];
+  const int plane = blockIdx.x, c = plane % C, b = plane / C;
+  const float* p = z + (size_t)plane * S;
+  float s1 = 0.f, s2 = 0.f;
+  if ((S & 3) == 0) {
+#pragma unroll 4
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) { const float v = p[i]; s1 += v; s2 += v * v; }
+  }
+  s1 = eat::wave_sum(s1); s2 = eat::wave_sum(s2);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { s_red[wv] = s1; s_red[8 + wv] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { ta += s_red[i]; tb += s_red[8 + i]; }
+    part[((size_t)b * 2 + 0) * C + c] = ta;
+    part[((size_t)b * 2 + 1) * C + c] = tb;
+  }
+}
+
+// g = dy * act'(a_c z + b_c) (may be written in place of dy); gpart[b*C + c] = sum_s g
+__global__ __launch_bounds__(256) void act_grad_sum_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           int act, float* g, float* __restrict__ gpart, int C, int S) {
+  __shared__ float s_red[8];
+  const int plane = blockIdx.x, c = plane % C;
+  const float av = a[c], bv = b[c];
+  const size_t base = (size_t)plane * S;
+  float s1 = 0.f;
+  if ((S & 3) == 0) {
+#pragma unroll 4
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      const float4 o = make_float4(d.x * act_deriv(fmaf(av, v.x, bv), act), d.y * act_deriv(fmaf(av, v.y, bv), act),
+                                   d.z * act_deriv(fmaf(av, v.z, bv), act), d.w * act_deriv(fmaf(av, v.w, bv), act));
+      *reinterpret_cast<float4*>(g + base + i) = o;
+      s1 += (o.x + o.y) + (o.z + o.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+      const float o = dy[base + i] * act_deriv(fmaf(av, z[base + i], bv), act);
+      g[base + i] = o;
+      s1 += o;
+    }
+  }
+  s1 = eat::wave_sum(s1);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s_red[wv] = s1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
+    gpart[plane] = t;
+  }
+}
+
+// ---- BatchNorm finalize from partials [outer][2][C][inner]: one block per channel ------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
+    const float* __restrict__ part, int outer, int C, int inner, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+    float eps, double n, float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean,
+    float* __restrict__ invstd) {
+  __shared__ double s_red[12];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0, dummy = 0.0;
+  const int total = outer * inner;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int o = e / inner, i = e - o * inner;
+    s1 += (double)part[(((size_t)o * 2 + 0) * C + c) * inner + i];
+    s2 += (double)part[(((size_t)o * 2 + 1) * C + c) * inner + i];
+  }
+  block_sum_d(s1, s2, dummy, s_red);
+  if (threadIdx.x != 0) return;
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[c] * is;
+  a[c] = av;
+  b[c] = beta[c] - (float)mu * av;
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ---- (2) BatchNorm state of z = W x from the Gram matrix of x: T = W G (Co x Ci), sx = sum x (Ci) --------------------
+// one wave per output channel
+__global__ __launch_bounds__(64) void gram_bn_finalize_kernel(
+    const float* __restrict__ Tm, const float* __restrict__ W, const float* __restrict__ sx, int Co, int Ci,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, double n, float* __restrict__ a,
+    float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < Ci; k += 64) {
+    const double w = (double)W[(size_t)c * Ci + k];
+    s1 += w * (double)sx[k];
+    s2 += w * (double)Tm[(size_t)c * Ci + k];
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if (threadIdx.x != 0) return;
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[c] * is;
+  a[c] = av;
+  b[c] = beta[c] - (float)mu * av;
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ---- (3) backward coefficients of conv 1x1 -> BatchNorm(train) -> act, per output channel (one block each) -------------
+//   in : W, Gx = sum g x^T, T = W G (Co x Ci each), sx (Ci), gpart [outer][Co][inner] (partials of sum g), a, mean, invstd
+//   out: dW (Co x Ci), dgamma, dbeta (Co), WaT (Ci x Co) = (diag(a) W)^T, e1 = a (m2 invstd mu - m1), e2 = a m2 invstd
+//   frozen != 0: the layer normalised with fixed (running) statistics: m1 = m2 = 0 in dW / dx, dgamma / dbeta unchanged
+__global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
+    const float* __restrict__ W, const float* __restrict__ Gx, const float* __restrict__ Tm,
+    const float* __restrict__ sx, const float* __restrict__ gpart, int outer, int inner, int Co, int Ci,
+    const float* __restrict__ a, const float* __restrict__ mean, const float* __restrict__ invstd, double n, int frozen,
+    float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ WaT,
+    float* __restrict__ e1, float* __restrict__ e2) {
+  __shared__ double s_red[12];
+  const int c = blockIdx.x;
+  double s1 = 0.0, wg = 0.0, dummy = 0.0;
+  for (int e = threadIdx.x; e < outer * inner; e += blockDim.x) {
+    const int o = e / inner, i = e - o * inner;
+    s1 += (double)gpart[((size_t)o * Co + c) * inner + i];
+  }
+  for (int k = threadIdx.x; k < Ci; k += blockDim.x) wg += (double)W[(size_t)c * Ci + k] * (double)Gx[(size_t)c * Ci + k];
+  block_sum_d(s1, wg, dummy, s_red);
+  const double mu = (double)mean[c], is = (double)invstd[c], av = (double)a[c];
+  const double s2 = is * (wg - mu * s1);                 // sum g xhat
+  const double m1 = frozen ? 0.0 : s1 / n, m2 = frozen ? 0.0 : s2 / n;
+  if (threadIdx.x == 0) {
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+    e1[c] = (float)(av * (m2 * is * mu - m1));
+    e2[c] = (float)(av * m2 * is);
+  }
+  for (int k = threadIdx.x; k < Ci; k += blockDim.x) {
+    const size_t idx = (size_t)c * Ci + k;
+    const double sxk = (double)sx[k];
+    dW[idx] = (float)(av * ((double)Gx[idx] - m1 * sxk - m2 * is * ((double)Tm[idx] - mu * sxk)));
+    WaT[(size_t)k * Co + c] = (float)(av * (double)W[idx]);
+  }
+}
+
+// M (Ci x Ci) = -sum_c e2[c] W[c,i] W[c,j];  c0[i] = sum_c e1[c] W[c,i].  Block = row i, thread = column j (j == Ci: c0)
+__global__ __launch_bounds__(256) void expand_bwd_mix_kernel(const float* __restrict__ W, const float* __restrict__ e1,
+                                                             const float* __restrict__ e2, int Co, int Ci,
+                                                             float* __restrict__ M, float* __restrict__ c0) {
+  const int i = blockIdx.x;
+  for (int j = threadIdx.x; j <= Ci; j += blockDim.x) {
+    float acc = 0.0f;
+    if (j < Ci) {
+      for (int c = 0; c < Co; ++c) acc = fmaf(e2[c] * W[(size_t)c * Ci + i], W[(size_t)c * Ci + j], acc);
+      M[(size_t)i * Ci + j] = -acc;
+    } else {
+      for (int c = 0; c < Co; ++c) acc = fmaf(e1[c], W[(size_t)c * Ci + i], acc);
+      c0[i] = acc;
+    }
+  }
+}
+
+}  // namespace
+
+namespace eat {
+int bn_stats_partial(const float* z, int B, int C, int S, float* part, hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((unsigned)(B * C)), dim3(S >= 1024 ? 256 : 64), 0, s, z, C, S, part);
+  return check_launch("bn_stats_partial");
+}
+int act_grad_sum(const float* dy, const float* z, const float* a, const float* b, int act, float* g, float* gpart, int B,
+                 int C, int S, hipStream_t s) {
+  hipLaunchKernelGGL(act_grad_sum_kernel, dim3((unsigned)(B * C)), dim3(S >= 1024 ? 256 : 64), 0, s, dy, z, a, b, act, g,
+                     gpart, C, S);
+  return check_launch("act_grad_sum");
+}
+}  // namespace eat
+
+extern "C" int eat_bn_stats_partial(const float* z, int B, int C, int S, float* part, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_stats_partial: bad shape");
+  return eat::bn_stats_partial(z, B, C, S, part, (hipStream_t)stream);
+}
+
+extern "C" int eat_act_grad_sum(const float* dy, const float* z, const float* a, const float* b, int act, float* g,
+                                float* gpart, int B, int C, int S, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_act_grad_sum: bad act %d", act);
+  if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_act_grad_sum: bad shape");
+  return eat::act_grad_sum(dy, z, a, b, act, g, gpart, B, C, S, (hipStream_t)stream);
+}
+
+extern "C" int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum,
+                                        float eps, double n, float* a, float* b, float* mean, float* invstd,
+                                        eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (outer < 1 || C < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_bn_finalize_partials: bad shape");
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part, outer, C,
+                     inner, gamma, beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
+  return eat::check_launch("eat_bn_finalize_partials");
+}
+
+extern "C" int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int Co, int Ci, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                    double n, float* a, float* b, float* mean, float* invstd, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Co < 1 || Ci < 1) return eat::fail(EAT_EINVAL, "eat_gram_bn_finalize: bad shape");
+  hipLaunchKernelGGL(gram_bn_finalize_kernel, dim3((unsigned)Co), dim3(64), 0, (hipStream_t)stream, Tm, W, sx, Co, Ci, gamma,
+                     beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
+  return eat::check_launch("eat_gram_bn_finalize");
+}
+
+extern "C" int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart,
+                                   int outer, int inner, int Co, int Ci, const float* a, const float* mean,
+                                   const float* invstd, double n, int frozen, float* dW, float* dgamma, float* dbeta,
+                                   float* WaT, float* M, float* c0, float* e_scratch, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Co < 1 || Ci < 1 || outer < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_expand_bwd_coef: bad shape");
+  float* e1 = e_scratch;
+  float* e2 = e_scratch + Co;
+  hipLaunchKernelGGL(expand_bwd_coef_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, W, Gx, Tm, sx, gpart,
+                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, e1, e2);
+  hipLaunchKernelGGL(expand_bwd_mix_kernel, dim3((unsigned)Ci), dim3(256), 0, (hipStream_t)stream, W, e1, e2, Co, Ci, M, c0);
+  return eat::check_launch("eat_expand_bwd_coef");
+}

@@ -162,7 +162,7 @@ class MNTrainFunction(torch.autograd.Function):
             return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat)
 
     @staticmethod
-    def _backward_impl(ctx, model, sv, dlogits, dfeat):
+    def _backward_impl(ctx, model, sv, dlogits, dfeat, v2=False):
         # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
         # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
         # a model that was never handed to dp.enable_data_parallel keeps its gradients local (no hidden collective)
@@ -248,6 +248,31 @@ class MNTrainFunction(torch.autograd.Function):
                 g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
                 in_shape = tuple(y_e.shape)
             no_expand = blk.i_expand is None
+            if v2 and not no_expand:
+                # expand conv + BN + act without dz_e (csrc/train_fuse.hip): g = dy_e * act'(.) and sum g leave the
+                # depthwise data-gradient kernel; dW / dx follow from Gx = sum g x^T and the forward's Gram products
+                st_e = rec["st_e"]
+                cna_e = blk.block[blk.i_expand]
+                W = cna_e[0].weight.flatten(1)
+                g_e, gparts = ops.dw_conv_dgrad_g(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
+                                                  rec["z_e"], st_e[0], st_e[1], act)
+                del dz_d
+                Gx = ops.pw_conv_wgrad(g_e, inp)
+                frozen = getattr(st_e[2], "_eat_frozen", False)
+                Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
+                n_e = inp.shape[0] * inp.shape[2] * inp.shape[3]
+                dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
+                                                                 frozen=frozen)
+                g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
+                g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
+                t = res_grad
+                if not frozen:                                                      # M x + c0 (+ residual-branch gradient)
+                    t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
+                dout = ops.pw_conv(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
+                                   NONE, res=t)
+                del g_e
+                sv["blocks"][i] = None
+                continue
             dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
                                      res=res_grad if no_expand else None)
             del dz_d
@@ -275,6 +300,124 @@ class MNTrainFunction(torch.autograd.Function):
         return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3 plan (EAT_TRAIN_V=2, default).  Same math as MNTrainFunction, fewer passes over the expanded tensors
+# (csrc/train_fuse.hip has the algebra):
+#   * expand conv: BatchNorm statistics from the Gram matrix of the block input (no pass over z_e); backward through
+#     BN + activation WITHOUT dz_e: the depthwise data-gradient kernel's epilogue writes g = dy_e * act'(.) and sum g,
+#     the weight gradient / data gradient are wgrad(g, x) and two 1x1 convs with corrected weights;
+#   * depthwise conv: sum / sum of squares of its output leave the conv kernel's epilogue as per-wave partials.
+# Expanded-resolution passes per block: forward 3 -> 2, backward 9 -> 5.
+_TRAIN_V = int(os.environ.get("EAT_TRAIN_V", "2"))
+
+
+class MNTrainFunction2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, drop_mask, *params):
+        keep = torch.is_grad_enabled() or any(p.requires_grad for p in params)
+        dev = x.device
+        x = x.contiguous().float()
+        B = x.shape[0]
+        saved = {}
+        blocks = list(model.features[1:-1])
+        exact = ops.precision.mode == "fp32"
+
+        # stem
+        stem = model.features[0]
+        C0 = stem[0].out_channels
+        z0 = ops.stem_conv(x, stem[0].weight.reshape(C0, 9), _zeros.get(C0, dev), NONE)
+        st0 = (ops.bn_state_from_partials(ops.bn_stats_partial(z0), stem[1], z0.numel() // C0) if stem[1].training
+               else ops.bn_frozen_state(stem[1]))
+        need_sx = bool(blocks) and blocks[0].i_expand is not None
+        pool_c = torch.empty((B, C0), device=dev) if need_sx else None
+        cur = ops.bn_act_fwd(z0, st0[0], st0[1], HSWISH, pool=pool_c)
+        sx = ops.col_sum(pool_c) if need_sx else None
+        saved["stem"] = (x, z0, st0)
+
+        blk_saved = []
+        for bi, blk in enumerate(blocks):
+            cnf = blk.cnf
+            act = HSWISH if cnf.use_hs else RELU
+            inp = cur
+            rec = {"inp": inp}
+            k = cnf.kernel
+            cna_d = blk.block[blk.i_dw]
+            w_d = cna_d[0].weight.reshape(-1, k * k)
+            tf = None
+            if blk.i_expand is not None:
+                cna = blk.block[blk.i_expand]
+                W = cna[0].weight.flatten(1)
+                n_e = B * inp.shape[2] * inp.shape[3]
+                if cna[1].training:
+                    G = ops.pw_conv_wgrad(inp, inp, exact=exact)                 # Gram matrix of the block input
+                    Tm = ops.linear(W, G, None, NONE)                             # W G  (G symmetric)
+                    st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e)
+                else:
+                    Tm, st_e = None, ops.bn_frozen_state(cna[1])
+                wp = ops.pw_prepack(W)
+                z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+                rec.update(z_e=z_e, st_e=st_e, Tm=Tm, sx=sx)
+                tf = (st_e[0], st_e[1], act)
+            src = z_e if blk.i_expand is not None else inp
+            if cna_d[1].training:
+                z_d, parts = ops.dw_conv_stats(src, w_d, k, cnf.stride, tf=tf)
+                st_d = ops.bn_state_from_partials(parts, cna_d[1], z_d.numel() // cnf.expanded_channels)
+            else:
+                if tf is not None:
+                    z_d = ops.dw_conv_tf(src, tf[0], tf[1], act, w_d, _zeros.get(cnf.expanded_channels, dev), k, cnf.stride)
+                else:
+                    z_d = ops.dw_conv(src, w_d, _zeros.get(cnf.expanded_channels, dev), k, cnf.stride, NONE)
+                st_d = ops.bn_frozen_state(cna_d[1])
+            S_d = z_d.shape[2] * z_d.shape[3]
+            pool = torch.empty((B, cnf.expanded_channels), device=dev) if blk.i_se is not None else None
+            y_d = ops.bn_act_fwd(z_d, st_d[0], st_d[1], act, pool=pool)
+            rec.update(y_e=None if blk.i_expand is not None else inp, z_d=z_d, st_d=st_d, y_d=y_d)
+            scale = None
+            if blk.i_se is not None:
+                se = blk.block[blk.i_se].conc_se_layers[0]
+                h = ops.linear(pool, se.fc1.weight, se.fc1.bias, RELU, 1.0 / S_d)
+                scale = ops.linear(h, se.fc2.weight, se.fc2.bias, SIGMOID)
+                rec.update(pool=pool, h=h, scale=scale, S_d=S_d)
+            cna = blk.block[blk.i_proj]
+            wp = ops.pw_prepack(cna[0].weight.flatten(1))
+            z_p = ops.pw_conv(y_d, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, in_scale=scale)
+            st_p = _conv_bn_stats(z_p, cna[1])
+            need_sx = bi + 1 < len(blocks) and blocks[bi + 1].i_expand is not None
+            pool_c = torch.empty((B, cnf.out_channels), device=dev) if need_sx else None
+            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None, pool=pool_c)
+            sx = ops.col_sum(pool_c) if need_sx else None
+            rec.update(z_p=z_p, st_p=st_p)
+            blk_saved.append(rec)
+
+        last = model.features[-1]
+        c_feat = last.out_channels
+        wp = ops.pw_prepack(last[0].weight.flatten(1))
+        z_l = ops.pw_conv(cur, wp, _zeros.get(c_feat, dev), c_feat, NONE)
+        st_l = _conv_bn_stats(z_l, last[1])
+        pooled = torch.empty((B, c_feat), device=dev)
+        ops.bn_act_fwd(z_l, st_l[0], st_l[1], HSWISH, pool=pooled, write=False)
+        S_l = z_l.shape[2] * z_l.shape[3]
+        feat = pooled * (1.0 / S_l)
+        fc1, fc2 = model.classifier[2], model.classifier[5]
+        u = ops.linear(feat, fc1.weight, fc1.bias, NONE)
+        h2 = F.hardswish(u)
+        if drop_mask is not None:
+            h2 = h2 * drop_mask
+        logits = ops.linear(h2, fc2.weight, fc2.bias, NONE)
+        if keep:
+            saved.update(blocks=blk_saved, last=(cur, z_l, st_l, S_l), head=(feat, u, h2, drop_mask))
+            ctx.saved, ctx.model = saved, model
+            ctx.names = [n for n, _ in model.named_parameters()]
+        return logits, feat
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeat):
+        model, sv = ctx.model, ctx.saved
+        ctx.saved = None
+        with ops.precision(getattr(model, "train_precision", "fp32")):
+            return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat, v2=True)
+
+
 def forward_train(model, x):
     """Train-mode `(logits, features)` with autograd support (mn/model.py:212-231 in `.train()`)."""
     drop = model.classifier[4]
@@ -286,5 +429,6 @@ def forward_train(model, x):
     if override is not None and drop.training:
         mask = override.to(x.device).float() / (1.0 - drop.p)
     params = [p for _, p in model.named_parameters()]
+    fn = MNTrainFunction2 if _TRAIN_V >= 2 else MNTrainFunction
     with ops.precision(getattr(model, "train_precision", "fp32")):
-        return MNTrainFunction.apply(model, x, mask, *params)
+        return fn.apply(model, x, mask, *params)

@@ -139,6 +139,17 @@ def bn_finalize(sums, bn, n, momentum=None):
     return out[0], out[1], out[2], out[3]
 
 
+def bn_frozen_state(bn):
+    """(a, b, mean, invstd) of a BatchNorm layer in eval mode inside a train-mode pass (running statistics, no buffer
+    update); flagged so that the backward treats the layer as a fixed affine map."""
+    with torch.no_grad():
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        a = (bn.weight * invstd).contiguous()
+        st = (a, (bn.bias - bn.running_mean * a).contiguous(), bn.running_mean.clone(), invstd.contiguous())
+    st[2]._eat_frozen = True
+    return st
+
+
 def bn_train_state(z, bn):
     """(a, b, mean, invstd) of one BatchNorm layer inside a train-mode pass, honouring the layer's OWN mode:
     * bn.training: batch statistics; running buffers updated with `momentum` (None = cumulative moving average
@@ -147,12 +158,7 @@ def bn_train_state(z, bn):
       returned state is flagged so that `bn_act_bwd` treats the layer as a fixed affine map."""
     C = z.shape[1]
     if not bn.training:
-        with torch.no_grad():
-            invstd = torch.rsqrt(bn.running_var + bn.eps)
-            a = (bn.weight * invstd).contiguous()
-            st = (a, (bn.bias - bn.running_mean * a).contiguous(), bn.running_mean.clone(), invstd.contiguous())
-        st[2]._eat_frozen = True
-        return st
+        return bn_frozen_state(bn)
     mom = bn.momentum
     if mom is None:
         mom = 1.0 / (int(bn.num_batches_tracked) + 1)          # host read: this mode is not graph-capturable
@@ -240,6 +246,111 @@ def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
               S, mode, _stream())
     return dW
+
+
+# ------------------------------------------------------------------ round-3 training launchers (csrc/train_fuse.hip)
+import ctypes as _ct
+
+
+def dw_partials_inner(F, T, Fo, To, k, stride, dgrad):
+    """Upper bound of the partial slots per plane the fused training epilogues write (host helper)."""
+    return int(_lib.lib().eat_dw_partials_inner(F, T, Fo, To, k, stride, 1 if dgrad else 0))
+
+
+def dw_conv_stats(x, w, k, stride, tf=None):
+    """Train-mode depthwise conv + the partial sums of its output for the BatchNorm that follows.
+    tf = (in_a, in_b, in_act): the conv input is act(in_a[c] x + in_b[c]) evaluated on load.
+    -> (y, (part, outer, inner)) for `bn_state_from_partials`."""
+    B, C, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    cap = dw_partials_inner(F, T, Fo, To, k, stride, False)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    part = torch.empty((B * 2 * C * cap,), device=x.device, dtype=torch.float32)
+    inner = _ct.c_int(0)
+    a, b, act = tf if tf is not None else (None, None, 0)
+    _lib.call("eat_dw_conv_fwd_stats", _dev(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w, "w"), y.data_ptr(),
+              part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
+    return y, (part, B, inner.value)
+
+
+def bn_stats_partial(z):
+    B, C = z.shape[0], z.shape[1]
+    part = torch.empty((B * 2 * C,), device=z.device, dtype=torch.float32)
+    _lib.call("eat_bn_stats_partial", _dev(z, "z"), B, C, z.numel() // (B * C), part.data_ptr(), _stream())
+    return part, B, 1
+
+
+def _bn_momentum(bn):
+    mom = bn.momentum
+    if mom is None:
+        mom = 1.0 / (int(bn.num_batches_tracked) + 1)          # host read: this mode is not graph-capturable
+    return float(mom)
+
+
+def bn_state_from_partials(parts, bn, n):
+    """(a, b, mean, invstd) of a TRAINING BatchNorm layer from the producer's partial sums; updates the running buffers
+    and num_batches_tracked as `bn_train_state` does."""
+    part, outer, inner = parts
+    C = bn.num_features
+    out = torch.empty((4, C), device=part.device, dtype=torch.float32)
+    _lib.call("eat_bn_finalize_partials", part.data_ptr(), outer, C, inner, _dev(bn.weight, "gamma"), _dev(bn.bias, "beta"),
+              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn), float(bn.eps), float(n),
+              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    bn.num_batches_tracked += 1
+    return out[0], out[1], out[2], out[3]
+
+
+def gram_bn_state(Tm, W, sx, bn, n):
+    """(a, b, mean, invstd) of the TRAINING BatchNorm after the 1x1 conv z = W x from Tm = W G, sx (Gram matrix / sum of
+    the conv input): see csrc/train_fuse.hip."""
+    Co, Ci = W.shape
+    out = torch.empty((4, Co), device=W.device, dtype=torch.float32)
+    _lib.call("eat_gram_bn_finalize", _dev(Tm, "Tm"), _dev(W, "W"), _dev(sx, "sx"), Co, Ci, _dev(bn.weight, "gamma"),
+              _dev(bn.bias, "beta"), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn),
+              float(bn.eps), float(n), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+              _stream())
+    bn.num_batches_tracked += 1
+    return out[0], out[1], out[2], out[3]
+
+
+def act_grad_sum(dy, z, a, b, act, inplace=False):
+    """g = dy * act'(a[c] z + b[c]) and its per-plane sums -> (g, (gpart, B, 1))."""
+    B, C = z.shape[0], z.shape[1]
+    g = dy if inplace else torch.empty_like(dy)
+    gpart = torch.empty((B * C,), device=z.device, dtype=torch.float32)
+    _lib.call("eat_act_grad_sum", _dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), act, g.data_ptr(),
+              gpart.data_ptr(), B, C, z.numel() // (B * C), _stream())
+    return g, (gpart, B, 1)
+
+
+def dw_conv_dgrad_g(dz, w, x_shape, k, stride, gz, ga, gb, gact):
+    """Depthwise data gradient times act'(ga[c] gz + gb[c]) + its partial sums -> (g, (gpart, B, inner))."""
+    B, C, F, T = x_shape
+    Fo, To = dz.shape[2], dz.shape[3]
+    cap = dw_partials_inner(F, T, Fo, To, k, stride, True)
+    g = torch.empty(x_shape, device=dz.device, dtype=torch.float32)
+    gpart = torch.empty((B * C * cap,), device=dz.device, dtype=torch.float32)
+    inner = _ct.c_int(0)
+    _lib.call("eat_dw_conv_dgrad_g", _dev(dz, "dz"), _dev(w, "w"), _dev(gz, "gz"), ga.data_ptr(), gb.data_ptr(), gact,
+              g.data_ptr(), gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
+    return g, (gpart, B, inner.value)
+
+
+def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False):
+    """-> (dW, dgamma, dbeta, WaT (Ci,Co), M (Ci,Ci), c0 (Ci)): backward of conv1x1 -> BN(train) -> act without dz."""
+    gpart, outer, inner = gparts
+    Co, Ci = W.shape
+    dev = W.device
+    dW = torch.empty((Co, Ci), device=dev, dtype=torch.float32)
+    vec = torch.empty((4, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta, e1, e2
+    WaT = torch.empty((Ci, Co), device=dev, dtype=torch.float32)
+    M = torch.empty((Ci, Ci), device=dev, dtype=torch.float32)
+    c0 = torch.empty((Ci,), device=dev, dtype=torch.float32)
+    _lib.call("eat_expand_bwd_coef", _dev(W, "W"), _dev(Gx, "Gx"), _dev(Tm, "Tm"), _dev(sx, "sx"), gpart.data_ptr(),
+              outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 1 if frozen else 0,
+              dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), WaT.data_ptr(), M.data_ptr(), c0.data_ptr(),
+              vec[2].data_ptr(), _stream())
+    return dW, vec[0], vec[1], WaT, M, c0
 
 
 # ------------------------------------------------------------------------- DyMN launchers

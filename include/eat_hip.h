@@ -145,6 +145,63 @@ int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const 
 int eat_plane_dot(const float* u, const float* v, const float* a, const float* b, float* out, int B,
                   int C, int S, int act, eat_stream_t stream);
 
+/* ---- round 3: BatchNorm statistics / backward reductions without their own passes -------------------------
+ * Reference semantics throughout: nn.BatchNorm2d(eps=1e-3, momentum=0.01) in train mode (models/mn/model.py:114-115)
+ * around the convs of InvertedResidual (models/mn/block_types.py:138-171); backward = autograd of those modules
+ * (ex_audioset.py:190-199).  Partial-sum buffers are plain fp32 arrays written with ordinary stores (no atomics, no
+ * zero fill) by the producing kernel and reduced per channel in fp64 by the finalize kernels. */
+
+/* Upper bound of the partial slots per (b,c) plane that eat_dw_conv_fwd_stats (dgrad = 0) / eat_dw_conv_dgrad_g
+ * (dgrad = 1) write for this geometry: size the buffers with it. Host-only helper (no device work). */
+int eat_dw_partials_inner(int F, int T, int Fo, int To, int k, int stride, int dgrad);
+
+/* Train-mode depthwise conv of models/mn/block_types.py:150-162: y = conv(act_in(in_a[c] x + in_b[c])) (in_a == NULL:
+ * plain x; the transform is the BatchNorm + activation of the expand conv evaluated on load) PLUS the batch statistics
+ * of y for the BatchNorm that follows: part [B][2][C][inner] floats (sum, sum of squares per wave);
+ * *h_inner (host int) receives inner <= inner_cap. */
+int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* y,
+                          float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
+                          int stride, eat_stream_t stream);
+
+/* The same partials from a tensor that already exists (any geometry; inner = 1): part [B][2][C]. */
+int eat_bn_stats_partial(const float* z, int B, int C, int S, float* part, eat_stream_t stream);
+
+/* (a, b, mean, invstd) and the running-buffer update of nn.BatchNorm2d from partials [outer][2][C][inner]
+ * (n = elements per channel). Same outputs as eat_bn_finalize. */
+int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, double n, float* a,
+                             float* b, float* mean, float* invstd, eat_stream_t stream);
+
+/* BatchNorm state of the expand conv z = W x (models/mn/block_types.py:138-147) from the Gram matrix of its input:
+ * Tm = W G (Co x Ci) with G = sum_{b,s} x x^T, sx = sum_{b,s} x (Ci): sum z = W sx, sum z^2 = rowsum(Tm .* W).
+ * The (3-6x wider) tensor z is not read for its statistics. Outputs as eat_bn_finalize. */
+int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int Co, int Ci, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         double n, float* a, float* b, float* mean, float* invstd, eat_stream_t stream);
+
+/* g = dy * act'(a[c] z + b[c]) (g may alias dy) and gpart[b*C + c] = sum_s g: the first half of the backward of
+ * act(BatchNorm(z)) as a stand-alone pass (geometries where eat_dw_conv_dgrad_g has no fused kernel). */
+int eat_act_grad_sum(const float* dy, const float* z, const float* a, const float* b, int act, float* g, float* gpart,
+                     int B, int C, int S, eat_stream_t stream);
+
+/* Depthwise data gradient (autograd of block_types.py:150-162) whose epilogue starts the backward of the expand conv's
+ * BatchNorm + activation: g = dgrad(dz) * act'(ga[c] gz + gb[c]), gz = pre-BN output of the expand conv (B,C,F,T);
+ * gpart [B][C][inner] = per-wave sums of g; *h_inner receives inner <= inner_cap. */
+int eat_dw_conv_dgrad_g(const float* dz, const float* w, const float* gz, const float* ga, const float* gb, int gact,
+                        float* g, float* gpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To,
+                        int k, int stride, eat_stream_t stream);
+
+/* Backward of conv1x1 (W: Co x Ci) -> BatchNorm(train) -> act WITHOUT forming dz (autograd of block_types.py:138-147):
+ * with g as above, Gx = sum g x^T (eat_pw_conv_wgrad(g, x)), Tm = W G, sx, the forward's (a, mean, invstd):
+ *   dgamma = invstd (rowsum(W .* Gx) - mean S1), dbeta = S1 = sum gpart, m1 = S1/n, m2 = dgamma/n (0 when frozen)
+ *   dW  = diag(a) [Gx - m1 sx^T - diag(m2 invstd)(Tm - mean sx^T)]
+ *   WaT = (diag(a) W)^T (Ci x Co), M = -W^T diag(a m2 invstd) W (Ci x Ci), c0 = W^T (a (m2 invstd mean - m1)) (Ci)
+ * so that dx = WaT g + M x + c0 (two eat_pw_conv_fwd launches). e_scratch: 2*Co floats. */
+int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart, int outer,
+                        int inner, int Co, int Ci, const float* a, const float* mean, const float* invstd, double n,
+                        int frozen, float* dW, float* dgamma, float* dbeta, float* WaT, float* M, float* c0,
+                        float* e_scratch, eat_stream_t stream);
+
 /* autograd of the depthwise Conv2d of models/mn/block_types.py:150-162 (data gradient):
  * Depthwise conv data gradient dx (B,C,F,T) from dz (B,C,Fo,To), taps w (C,k,k); res (B,C,F,T) or
  * NULL is added (residual branch gradient). */

@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 GPU call: unit tests of the new training kernels, the train-step parity tests, per-entry-point profile of the
+# mn10 train step (old plan vs new plan), bench train leg.   gpurun --timeout 1200 -- 'bash tools/gpu_r3.sh r3a'
+set -u
+TAG=${1:-r3a}; shift || true
+WHAT="${*:-unit train prof bench}"
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+if has unit; then
+  timeout 600 python -m pytest tests/test_gpu_train_fuse.py -q -x 2>&1 | tail -30 > $OUT/unit.log; tail -15 $OUT/unit.log
+fi
+if has train; then
+  timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_configs.py tests/test_gpu_trainloop.py -q 2>&1 | tail -40 > $OUT/train.log; tail -25 $OUT/train.log
+fi
+if has full; then
+  timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40 > $OUT/full.log; tail -25 $OUT/full.log
+fi
+if has prof; then
+  for v in 1 2; do
+    EAT_TRAIN_V=$v timeout 300 python tools/prof_train.py 256 > $OUT/prof_v$v.log 2>&1; head -40 $OUT/prof_v$v.log
+  done
+fi
+if has bench; then
+  for v in 1 2; do
+    EAT_TRAIN_V=$v timeout 300 python bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs --steps 5 --warmup 2 > $OUT/bench_v$v.json 2> $OUT/bench_v$v.err
+    python - <<P
+import json
+d=json.load(open("$OUT/bench_v$v.json")); print("V$v fwd", d["value"], "train", d.get("train_step"))
+P
+  done
+fi
+if has benchfull; then
+  timeout 900 python bench.py --kernel-table > $OUT/bench.json 2> $OUT/bench_table.log
+  tail -c 4000 $OUT/bench.json; grep "^\[bench\]" $OUT/bench_table.log
+fi
+if has rocprof; then
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats -o s --output-format csv -- \
+      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.log)
+  ls $OUT/stats | head
+fi
