@@ -39,15 +39,16 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
 }
 
 // Pack W (Co, Ci) [* row_scale] into wp[(ks * MT + mt) * 64 + lane] = W[mt*16 + (lane&15)][ks*4 + (lane>>4)]
+// trans: w is stored (Ci, Co) and its transpose is packed (the data-gradient GEMM uses W^T: no separate transpose copy)
 __global__ void pw_prepack_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,
-                                  float* __restrict__ wp, int Co, int Ci, int MT) {
+                                  float* __restrict__ wp, int Co, int Ci, int MT, int trans) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = (Ci / 4) * MT * 64;
   if (i >= total) return;
   const int lane = i & 63, mt = (i >> 6) % MT, ks = (i >> 6) / MT;
   const int m = mt * 16 + (lane & 15), k = ks * 4 + (lane >> 4);
   float v = 0.0f;
-  if (m < Co) v = w[(size_t)m * Ci + k] * (row_scale ? row_scale[m] : 1.0f);
+  if (m < Co) v = (trans ? w[(size_t)k * Co + m] : w[(size_t)m * Ci + k]) * (row_scale ? row_scale[m] : 1.0f);
   wp[i] = v;
 }
 
@@ -351,15 +352,25 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
 
 }  // namespace
 
-extern "C" int eat_pw_prepack(const float* w, const float* row_scale, float* wp, int Co, int Ci,
-                              eat_stream_t stream) {
+static int pw_prepack_impl(const float* w, const float* row_scale, float* wp, int Co, int Ci, int trans,
+                           eat_stream_t stream) {
   eat::clear_stale_error();
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_prepack: Ci=%d must be a multiple of 4", Ci);
   const int MT = (Co + 15) / 16;
   const int total = (Ci / 4) * MT * 64;
   hipLaunchKernelGGL(pw_prepack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, row_scale,
-                     wp, Co, Ci, MT);
+                     wp, Co, Ci, MT, trans);
   return eat::check_launch("eat_pw_prepack");
+}
+
+extern "C" int eat_pw_prepack(const float* w, const float* row_scale, float* wp, int Co, int Ci,
+                              eat_stream_t stream) {
+  return pw_prepack_impl(w, row_scale, wp, Co, Ci, 0, stream);
+}
+
+extern "C" int eat_pw_prepack_t(const float* w_t, const float* row_scale, float* wp, int Co, int Ci,
+                                eat_stream_t stream) {
+  return pw_prepack_impl(w_t, row_scale, wp, Co, Ci, 1, stream);
 }
 
 static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,

@@ -42,7 +42,7 @@ __device__ __forceinline__ void glds4_raw(const void* g, void* lds_wave_base) {
 
 // wp16[((kk*MT + mt)*NP2 + h)*512 + lane*8 + i] = bf16 part h of W[mt*16 + (lane&15)][kk*32 + 8*(lane>>4) + i]
 __global__ void pw_prepack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,
-                                       __bf16* __restrict__ wp, int Co, int Ci, int MT, int NP2) {
+                                       __bf16* __restrict__ wp, int Co, int Ci, int MT, int NP2, int trans) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (kk, mt, lane)
   const int KK = (Ci + 31) / 32;
   if (t >= KK * MT * 64) return;
@@ -52,7 +52,7 @@ __global__ void pw_prepack_bf16_kernel(const float* __restrict__ w, const float*
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int k = kb + i;
-    const float v = (m < Co && k < Ci) ? w[(size_t)m * Ci + k] * rs : 0.0f;
+    const float v = (m < Co && k < Ci) ? (trans ? w[(size_t)k * Co + m] : w[(size_t)m * Ci + k]) * rs : 0.0f;
     const __bf16 hi = (__bf16)v;
     wp[((size_t)(kk * MT + mt) * NP2 + 0) * 512 + lane * 8 + i] = hi;
     if (NP2 == 2) wp[((size_t)(kk * MT + mt) * NP2 + 1) * 512 + lane * 8 + i] = (__bf16)(v - (float)hi);
@@ -244,14 +244,24 @@ int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias,
 
 }  // namespace
 
-extern "C" int eat_pw_prepack_bf16(const float* w, const float* row_scale, void* wp, int Co, int Ci, int split,
-                                   eat_stream_t stream) {
+static int pw_prepack_bf16_impl(const float* w, const float* row_scale, void* wp, int Co, int Ci, int split, int trans,
+                                eat_stream_t stream) {
   eat::clear_stale_error();
   const int MT = (Co + 15) / 16, KK = (Ci + 31) / 32;
   const int total = KK * MT * 64;
   hipLaunchKernelGGL(pw_prepack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, row_scale,
-                     reinterpret_cast<__bf16*>(wp), Co, Ci, MT, split ? 2 : 1);
+                     reinterpret_cast<__bf16*>(wp), Co, Ci, MT, split ? 2 : 1, trans);
   return eat::check_launch("eat_pw_prepack_bf16");
+}
+
+extern "C" int eat_pw_prepack_bf16(const float* w, const float* row_scale, void* wp, int Co, int Ci, int split,
+                                   eat_stream_t stream) {
+  return pw_prepack_bf16_impl(w, row_scale, wp, Co, Ci, split, 0, stream);
+}
+
+extern "C" int eat_pw_prepack_bf16_t(const float* w_t, const float* row_scale, void* wp, int Co, int Ci, int split,
+                                     eat_stream_t stream) {
+  return pw_prepack_bf16_impl(w_t, row_scale, wp, Co, Ci, split, 1, stream);
 }
 
 extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, const float* in_scale,

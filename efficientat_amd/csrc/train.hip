@@ -627,6 +627,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
   mt_n = mt_n < 0 ? 0 : (mt_n > 4 ? 4 : mt_n);
   nt_n = nt_n < 0 ? 0 : (nt_n > 4 ? 4 : nt_n);
   const bool active = mt_n > 0 && nt_n > 0;                        // idle waves still help with the loads
+  // Gram matrix (dz == x, train_fuse.hip): a diagonal block's two operand tiles are the same rows - one DMA, one LDS tile
+  const bool same_tile = dz == x && mb == nb && !xscale;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
         if (ra >= Co) ra = Co - 1;
         wg_glds16(dz + ((size_t)bb * Co + ra) * S + sidx, &s_op[stage][0][(32 * wv + 8 * q) * 32]);
       }
-      if (nb + 32 * wv + 8 * q < Ci) {
+      if (!same_tile && nb + 32 * wv + 8 * q < Ci) {
         int rb = nb + row;
         if (rb >= Ci) rb = Ci - 1;
         wg_glds16(x + ((size_t)bb * Ci + rb) * S + sidx, &s_op[stage][1][(32 * wv + 8 * q) * 32]);
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = nw + 16 * j + r;
-        frag(&s_op[stage][1][0], row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j]);
+        frag(&s_op[stage][same_tile ? 0 : 1][0], row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j]);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -744,8 +746,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 // Narrow layers (one side <= 16 channels, the other <= 64: mn10 block 1 and the expand of block 2, planes of 32000
 // positions): dW is a single 64 x 64 wave tile and the gradient is a pure streaming reduction over k.  Here the direct,
 // LDS-free form wins: the 4 waves of a block split the k range, every lane loads the 8 consecutive k of its row straight
-// from HBM (16 rows x 32 B per instruction is a poor pattern for the texture unit, but with <= 5 row tiles per unit it
-// is not the bottleneck).
+// from HBM (one full 128-byte line per row and unit).  Round 3: the tile counts are compile-time (a 16 x 16 product keeps
+// 8, not 128, operand registers), the loads of the NEXT unit are issued before the MFMAs of the current one (the loop
+// was latency-bound: 1.7 TB/s on the 16 x 16 layers), and SAME (dz == x: the Gram matrix of train_fuse.hip) loads once.
+template <int MTN, int NTN, bool SAME>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                     const float* __restrict__ xscale, float* __restrict__ dW,
                                                                     int B, int Co, int Ci, int S, int sps,
@@ -755,74 +759,108 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   const int total = B * sps;
   const int u0 = blockIdx.z * units_per_block;
   const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
-  const int mt_n = (Co + 15) / 16, nt_n = (Ci + 15) / 16;         // <= 4 each
-  f32x4 acc[4][4];
+  f32x4 acc[MTN][NTN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MTN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float sc[4] = {1.f, 1.f, 1.f, 1.f};
+    for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sc[NTN];
+#pragma unroll
+  for (int j = 0; j < NTN; ++j) sc[j] = 1.0f;
   int b_sc = -1;
-  for (int u = u0 + wv; u < u1; u += 4) {
-    const int b = u / sps, st = u - b * sps;
+
+  auto load = [&](int u, float (&av)[MTN][8], float (&bv)[SAME ? 1 : NTN][8]) {
+    const bool live = u < u1;                                   // wave-uniform
+    const int uu = live ? u : u0;
+    const int b = uu / sps, st = uu - b * sps;
     const int s = st * 32 + 8 * kg;
-    if (xscale && b != b_sc) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 16 * j + r;
-        sc[j] = row < Ci ? xscale[(size_t)b * Ci + row] : 0.0f;
-      }
-      b_sc = b;
-    }
-    float av[4][8], bv[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MTN; ++i) {
       const int row = 16 * i + r;
       const float* p = dz + ((size_t)b * Co + (row < Co ? row : Co - 1)) * S + s;
-      const bool ok0 = i < mt_n && row < Co && s < S, ok1 = ok0 && s + 4 < S;
+      const bool ok0 = live && row < Co && s < S, ok1 = ok0 && s + 4 < S;
       const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       av[i][0] = t0.x; av[i][1] = t0.y; av[i][2] = t0.z; av[i][3] = t0.w;
       av[i][4] = t1.x; av[i][5] = t1.y; av[i][6] = t1.z; av[i][7] = t1.w;
     }
+    if constexpr (!SAME) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = 16 * j + r;
-      const float* p = x + ((size_t)b * Ci + (row < Ci ? row : Ci - 1)) * S + s;
-      const bool ok0 = j < nt_n && row < Ci && s < S, ok1 = ok0 && s + 4 < S;
-      const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      bv[j][0] = t0.x * sc[j]; bv[j][1] = t0.y * sc[j]; bv[j][2] = t0.z * sc[j]; bv[j][3] = t0.w * sc[j];
-      bv[j][4] = t1.x * sc[j]; bv[j][5] = t1.y * sc[j]; bv[j][6] = t1.z * sc[j]; bv[j][7] = t1.w * sc[j];
-    }
-    bf16x8_t bh[4], bl[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split8(bv[j], bh[j], bl[j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < mt_n) {
-        bf16x8_t ah, al;
-        split8(av[i], ah, al);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (j < nt_n) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-          }
-        }
+      for (int j = 0; j < NTN; ++j) {
+        const int row = 16 * j + r;
+        const float* p = x + ((size_t)b * Ci + (row < Ci ? row : Ci - 1)) * S + s;
+        const bool ok0 = live && row < Ci && s < S, ok1 = ok0 && s + 4 < S;
+        const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[j][0] = t0.x; bv[j][1] = t0.y; bv[j][2] = t0.z; bv[j][3] = t0.w;
+        bv[j][4] = t1.x; bv[j][5] = t1.y; bv[j][6] = t1.z; bv[j][7] = t1.w;
       }
     }
+  };
+  auto compute = [&](int u, const float (&av)[MTN][8], const float (&bv)[SAME ? 1 : NTN][8]) {
+    if (u >= u1) return;                                        // wave-uniform
+    if (!SAME && xscale) {
+      const int b = u / sps;
+      if (b != b_sc) {
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+          const int row = 16 * j + r;
+          sc[j] = row < Ci ? xscale[(size_t)b * Ci + row] : 0.0f;
+        }
+        b_sc = b;
+      }
+    }
+    bf16x8_t ah[MTN], al[MTN];
+#pragma unroll
+    for (int i = 0; i < MTN; ++i) split8(av[i], ah[i], al[i]);
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+      bf16x8_t bh, bl;
+      if constexpr (SAME) {
+        bh = ah[j]; bl = al[j];                                 // host: MTN == NTN
+      } else {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = bv[j][e] * sc[j];
+        split8(t, bh, bl);
+      }
+#pragma unroll
+      for (int i = 0; i < MTN; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  float a0[MTN][8], a1[MTN][8], b0[SAME ? 1 : NTN][8], b1[SAME ? 1 : NTN][8];
+  load(u0 + wv, a0, b0);
+  for (int u = u0 + wv; u < u1; u += 8) {
+    load(u + 4, a1, b1);
+    compute(u, a0, b0);
+    load(u + 8, a0, b0);
+    compute(u + 4, a1, b1);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MTN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NTN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int m = 16 * i + kg * 4 + q, n = 16 * j + r;
-        if (i < mt_n && j < nt_n && m < Co && n < Ci) atomicAdd(dW + (size_t)m * Ci + n, acc[i][j][q]);
+        if (m < Co && n < Ci) atomicAdd(dW + (size_t)m * Ci + n, acc[i][j][q]);
       }
+}
+
+template <int MTN, int NTN>
+static void launch_narrow(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
+                          int sps, int upb, unsigned nz, hipStream_t s) {
+  if (dz == x && MTN == NTN && !x_scale)
+    hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, (MTN == NTN ? NTN : 1), (MTN == NTN)>), dim3(1, 1, nz), dim3(256), 0, s, dz,
+                       x, x_scale, dW, B, Co, Ci, S, sps, upb);
+  else
+    hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, NTN, false>), dim3(1, 1, nz), dim3(256), 0, s, dz, x, x_scale, dW, B,
+                       Co, Ci, S, sps, upb);
 }
 
 }  // namespace
@@ -1066,12 +1104,19 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
       upb = (int)((total + splits - 1) / splits);
     }
     dim3 grid((Co + 127) / 128, (Ci + 127) / 128, (unsigned)((total + upb - 1) / upb));
-    if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16) && !per_sample) {
+    const bool gram = dz == x && Co == Ci && !x_scale;          // Gram matrix of one tensor (train_fuse.hip): one load per unit
+    if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16 || gram) && !per_sample) {
       // narrow streaming layers: ~2048 single-tile blocks whose 4 waves split the k range
       long long splits = 2048 < total ? 2048 : total;
       upb = (int)((total + splits - 1) / splits);
-      hipLaunchKernelGGL(pw_wgrad_x3_narrow_kernel, dim3(1, 1, (unsigned)((total + upb - 1) / upb)), dim3(256), 0,
-                         (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, sps, upb);
+      const unsigned nz = (unsigned)((total + upb - 1) / upb);
+      const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
+      hipStream_t hs = (hipStream_t)stream;
+#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, dW, B, Co, Ci, S, sps, upb, nz, hs)
+      EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
+      EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
+      EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // Gram mode only (see `gram`)
+#undef EAT_NARROW
     } else {
       if (exact_fp32 == 2)
         hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,

@@ -175,14 +175,16 @@ __global__ __launch_bounds__(64) void gram_bn_finalize_kernel(
 
 // ---- (3) backward coefficients of conv 1x1 -> BatchNorm(train) -> act, per output channel (one block each) -------------
 //   in : W, Gx = sum g x^T, T = W G (Co x Ci each), sx (Ci), gpart [outer][Co][inner] (partials of sum g), a, mean, invstd
-//   out: dW (Co x Ci), dgamma, dbeta (Co), WaT (Ci x Co) = (diag(a) W)^T, e1 = a (m2 invstd mu - m1), e2 = a m2 invstd
+//   out: dW (Co x Ci), dgamma, dbeta (Co), e1 = a (m2 invstd mu - m1) (Co), and three Ci x Co transposes for the MFMA
+//        linear kernel (which contracts over the contiguous axis): WaT = (diag(a) W)^T, WT = W^T,
+//        W2T = -(diag(a m2 invstd) W)^T, so that M = W2T WT^T (Ci x Ci) and c0 = e1 WT^T (Ci)
 //   frozen != 0: the layer normalised with fixed (running) statistics: m1 = m2 = 0 in dW / dx, dgamma / dbeta unchanged
 __global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
     const float* __restrict__ W, const float* __restrict__ Gx, const float* __restrict__ Tm,
     const float* __restrict__ sx, const float* __restrict__ gpart, int outer, int inner, int Co, int Ci,
     const float* __restrict__ a, const float* __restrict__ mean, const float* __restrict__ invstd, double n, int frozen,
     float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ WaT,
-    float* __restrict__ e1, float* __restrict__ e2) {
+    float* __restrict__ WT, float* __restrict__ W2T, float* __restrict__ e1) {
   __shared__ double s_red[12];
   const int c = blockIdx.x;
   double s1 = 0.0, wg = 0.0, dummy = 0.0;
@@ -199,30 +201,16 @@ __global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
     e1[c] = (float)(av * (m2 * is * mu - m1));
-    e2[c] = (float)(av * m2 * is);
   }
+  const double e2 = av * m2 * is;
   for (int k = threadIdx.x; k < Ci; k += blockDim.x) {
     const size_t idx = (size_t)c * Ci + k;
-    const double sxk = (double)sx[k];
+    const double sxk = (double)sx[k], w = (double)W[idx];
     dW[idx] = (float)(av * ((double)Gx[idx] - m1 * sxk - m2 * is * ((double)Tm[idx] - mu * sxk)));
-    WaT[(size_t)k * Co + c] = (float)(av * (double)W[idx]);
-  }
-}
-
-// M (Ci x Ci) = -sum_c e2[c] W[c,i] W[c,j];  c0[i] = sum_c e1[c] W[c,i].  Block = row i, thread = column j (j == Ci: c0)
-__global__ __launch_bounds__(256) void expand_bwd_mix_kernel(const float* __restrict__ W, const float* __restrict__ e1,
-                                                             const float* __restrict__ e2, int Co, int Ci,
-                                                             float* __restrict__ M, float* __restrict__ c0) {
-  const int i = blockIdx.x;
-  for (int j = threadIdx.x; j <= Ci; j += blockDim.x) {
-    float acc = 0.0f;
-    if (j < Ci) {
-      for (int c = 0; c < Co; ++c) acc = fmaf(e2[c] * W[(size_t)c * Ci + i], W[(size_t)c * Ci + j], acc);
-      M[(size_t)i * Ci + j] = -acc;
-    } else {
-      for (int c = 0; c < Co; ++c) acc = fmaf(e1[c], W[(size_t)c * Ci + i], acc);
-      c0[i] = acc;
-    }
+    const size_t tdx = (size_t)k * Co + c;
+    WaT[tdx] = (float)(av * w);
+    WT[tdx] = (float)w;
+    W2T[tdx] = (float)(-e2 * w);
   }
 }
 
@@ -279,13 +267,10 @@ extern "C" int eat_gram_bn_finalize(const float* Tm, const float* W, const float
 extern "C" int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart,
                                    int outer, int inner, int Co, int Ci, const float* a, const float* mean,
                                    const float* invstd, double n, int frozen, float* dW, float* dgamma, float* dbeta,
-                                   float* WaT, float* M, float* c0, float* e_scratch, eat_stream_t stream) {
+                                   float* WaT, float* WT, float* W2T, float* e1, eat_stream_t stream) {
   eat::clear_stale_error();
   if (Co < 1 || Ci < 1 || outer < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_expand_bwd_coef: bad shape");
-  float* e1 = e_scratch;
-  float* e2 = e_scratch + Co;
   hipLaunchKernelGGL(expand_bwd_coef_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, W, Gx, Tm, sx, gpart,
-                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, e1, e2);
-  hipLaunchKernelGGL(expand_bwd_mix_kernel, dim3((unsigned)Ci), dim3(256), 0, (hipStream_t)stream, W, e1, e2, Co, Ci, M, c0);
+                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, WT, W2T, e1);
   return eat::check_launch("eat_expand_bwd_coef");
 }

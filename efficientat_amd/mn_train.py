@@ -158,7 +158,7 @@ class MNTrainFunction(torch.autograd.Function):
     def backward(ctx, dlogits, dfeat):
         model, sv = ctx.model, ctx.saved
         ctx.saved = None
-        with ops.precision(getattr(model, "train_precision", "fp32")):
+        with ops.precision(getattr(model, "train_precision", "fp32")), ops.zero_arena.scope("mn_bwd"):
             return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat)
 
     @staticmethod
@@ -196,7 +196,7 @@ class MNTrainFunction(torch.autograd.Function):
         nm = f"features.{nb + 1}"
         g[nm + ".1.weight"], g[nm + ".1.bias"] = dgam, dbet
         g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
-        wpt = ops.pw_prepack(_t(last[0].weight.flatten(1)))
+        wpt = ops.pw_prepack(last[0].weight.flatten(1), trans=True)
         dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
         del dz, z_l
 
@@ -214,7 +214,7 @@ class MNTrainFunction(torch.autograd.Function):
             g[f"{pre}.{blk.i_proj}.1.weight"], g[f"{pre}.{blk.i_proj}.1.bias"] = dgam, dbet
             scale = rec.get("scale")
             g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale).view_as(cna[0].weight)
-            wpt = ops.pw_prepack(_t(cna[0].weight.flatten(1)))
+            wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
             dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
             del dz_p
             gscale = gadd = None
@@ -284,7 +284,7 @@ class MNTrainFunction(torch.autograd.Function):
                 del dy_e
                 g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
                 g[f"{pre}.{blk.i_expand}.0.weight"] = ops.pw_conv_wgrad(dz_e, inp).view_as(cna[0].weight)
-                wpt = ops.pw_prepack(_t(cna[0].weight.flatten(1)))
+                wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
                 dout = ops.pw_conv(dz_e, wpt, _zeros.get(cnf.input_channels, dev), cnf.input_channels, NONE,
                                    res=res_grad)
                 del dz_e
@@ -414,7 +414,7 @@ class MNTrainFunction2(torch.autograd.Function):
     def backward(ctx, dlogits, dfeat):
         model, sv = ctx.model, ctx.saved
         ctx.saved = None
-        with ops.precision(getattr(model, "train_precision", "fp32")):
+        with ops.precision(getattr(model, "train_precision", "fp32")), ops.zero_arena.scope("mn_bwd"):
             return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat, v2=True)
 
 
@@ -430,5 +430,5 @@ def forward_train(model, x):
         mask = override.to(x.device).float() / (1.0 - drop.p)
     params = [p for _, p in model.named_parameters()]
     fn = MNTrainFunction2 if _TRAIN_V >= 2 else MNTrainFunction
-    with ops.precision(getattr(model, "train_precision", "fp32")):
+    with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters, ops.zero_arena.scope("mn_fwd"):
         return fn.apply(model, x, mask, *params)

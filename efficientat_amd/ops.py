@@ -94,10 +94,12 @@ def dw_conv_tf(x, in_a, in_b, in_act, w, bias, k, stride):
     return y
 
 
-def pw_prepack(w2d, row_scale=None):
-    Co, Ci = w2d.shape
+def pw_prepack(w2d, row_scale=None, trans=False):
+    """trans: pack w2d^T (w2d is the stored (Ci, Co) matrix) - the data-gradient GEMM without a transposed copy."""
+    Co, Ci = (w2d.shape[1], w2d.shape[0]) if trans else w2d.shape
     wp = torch.empty(((Ci // 4) * ((Co + 15) // 16) * 64,), device=w2d.device, dtype=torch.float32)
-    _lib.call("eat_pw_prepack", _dev(w2d, "w"), _opt(row_scale, "row_scale"), wp.data_ptr(), Co, Ci, _stream())
+    _lib.call("eat_pw_prepack_t" if trans else "eat_pw_prepack", _dev(w2d, "w"), _opt(row_scale, "row_scale"),
+              wp.data_ptr(), Co, Ci, _stream())
     return wp
 
 
@@ -120,10 +122,79 @@ def linear(x, w, bias, act, x_scale=1.0):
 
 
 # ------------------------------------------------------------------ training-step launchers
+class _ZeroArena:
+    """One zero-filled allocation per pass instead of ~90 `torch.zeros` launches: the kernels that accumulate with atomics
+    (weight gradients, fp64 BatchNorm sums) carve their zeroed outputs out of it.  `with zero_arena.scope("bwd"):` opens
+    a pass; its size is learnt from the first pass of that name (which falls back to individual `torch.zeros`)."""
+
+    def __init__(self):
+        self.need, self.buf, self.off, self.req, self.name = {}, None, 0, 0, None
+
+    def scope(self, name):
+        arena = self
+
+        class _Scope:
+            def __enter__(self):
+                self.outer = (arena.name, arena.buf, arena.off, arena.req)
+                arena.name, arena.buf, arena.off, arena.req = name, None, 0, 0
+
+            def __exit__(self, *exc):
+                arena.need[name] = max(arena.need.get(name, 0), arena.req)
+                arena.name, arena.buf, arena.off, arena.req = self.outer
+
+        return _Scope()
+
+    def zeros(self, shape, dtype, device):
+        if self.name is None:
+            return torch.zeros(shape, device=device, dtype=dtype)
+        numel = 1
+        for d in shape:
+            numel *= d
+        nbytes = (numel * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+        self.req += nbytes
+        need = self.need.get(self.name, 0)
+        if self.buf is None and need:
+            self.buf = torch.zeros((need,), device=device, dtype=torch.uint8)
+        if self.buf is None or self.off + nbytes > self.buf.numel() or self.buf.device != device:
+            return torch.zeros(shape, device=device, dtype=dtype)
+        v = self.buf[self.off:self.off + nbytes].view(dtype)[:numel].view(shape)
+        self.off += nbytes
+        return v
+
+
+zero_arena = _ZeroArena()
+
+
+class _DeferredCounters:
+    """`bn.num_batches_tracked += 1` of every BatchNorm layer of a forward pass as ONE multi-tensor launch."""
+
+    def __init__(self):
+        self.depth, self.pending = 0, []
+
+    def __enter__(self):
+        self.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        self.depth -= 1
+        if self.depth == 0 and self.pending:
+            torch._foreach_add_(self.pending, 1)
+            self.pending = []
+
+    def bump(self, bn):
+        if self.depth:
+            self.pending.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+
+
+bn_counters = _DeferredCounters()
+
+
 def bn_stats(z):
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
-    sums = torch.zeros((2 * C,), device=z.device, dtype=torch.float64)
+    sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
     _lib.call("eat_bn_stats", _dev(z, "z"), B, C, S, sums.data_ptr(), _stream())
     return sums
 
@@ -163,7 +234,7 @@ def bn_train_state(z, bn):
     if mom is None:
         mom = 1.0 / (int(bn.num_batches_tracked) + 1)          # host read: this mode is not graph-capturable
     st = bn_finalize(bn_stats(z), bn, z.numel() // C, momentum=mom)
-    bn.num_batches_tracked += 1
+    bn_counters.bump(bn)
     return st
 
 
@@ -184,7 +255,7 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=No
         frozen = getattr(mean, "_eat_frozen", False)
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
-    sums = torch.zeros((2 * C,), device=z.device, dtype=torch.float64)
+    sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
     args = (_dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
             _opt(gscale, "gscale"), _opt(gadd, "gadd"))
     _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
@@ -216,7 +287,7 @@ def dw_conv_dgrad(dz, w, x_shape, k, stride, res=None):
 def dw_conv_wgrad(dz, x, k, stride):
     B, C, Fo, To = dz.shape
     XC, F, T = x.shape[1], x.shape[2], x.shape[3]
-    dw = torch.zeros((C, k * k), device=dz.device, dtype=torch.float32)
+    dw = zero_arena.zeros((C, k * k), torch.float32, dz.device)
     _lib.call("eat_dw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), dw.data_ptr(), B, C, XC, F, T, Fo, To, k, stride,
               _stream())
     return dw
@@ -226,7 +297,7 @@ def dw_conv_wgrad_tf(dz, x, in_a, in_b, in_act, k, stride):
     """Depthwise weight gradient whose x operand is act_in(in_a[c] * x + in_b[c]), evaluated on load."""
     B, C, Fo, To = dz.shape
     F, T = x.shape[2], x.shape[3]
-    dw = torch.zeros((C, k * k), device=dz.device, dtype=torch.float32)
+    dw = zero_arena.zeros((C, k * k), torch.float32, dz.device)
     _lib.call("eat_dw_conv_wgrad_tf", _dev(dz, "dz"), _dev(x, "x"), _dev(in_a, "in_a"), _dev(in_b, "in_b"), in_act,
               dw.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
     return dw
@@ -242,7 +313,7 @@ def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
     B, Co = dz.shape[0], dz.shape[1]
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
-    dW = torch.zeros((Co, Ci), device=dz.device, dtype=torch.float32)
+    dW = zero_arena.zeros((Co, Ci), torch.float32, dz.device)
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
               S, mode, _stream())
     return dW
@@ -296,7 +367,7 @@ def bn_state_from_partials(parts, bn, n):
     _lib.call("eat_bn_finalize_partials", part.data_ptr(), outer, C, inner, _dev(bn.weight, "gamma"), _dev(bn.bias, "beta"),
               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn), float(bn.eps), float(n),
               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
-    bn.num_batches_tracked += 1
+    bn_counters.bump(bn)
     return out[0], out[1], out[2], out[3]
 
 
@@ -309,7 +380,7 @@ def gram_bn_state(Tm, W, sx, bn, n):
               _dev(bn.bias, "beta"), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn),
               float(bn.eps), float(n), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
               _stream())
-    bn.num_batches_tracked += 1
+    bn_counters.bump(bn)
     return out[0], out[1], out[2], out[3]
 
 
@@ -342,15 +413,17 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False):
     Co, Ci = W.shape
     dev = W.device
     dW = torch.empty((Co, Ci), device=dev, dtype=torch.float32)
-    vec = torch.empty((4, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta, e1, e2
-    WaT = torch.empty((Ci, Co), device=dev, dtype=torch.float32)
-    M = torch.empty((Ci, Ci), device=dev, dtype=torch.float32)
-    c0 = torch.empty((Ci,), device=dev, dtype=torch.float32)
+    vec = torch.empty((3, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta, e1
+    tr = torch.empty((3, Ci, Co), device=dev, dtype=torch.float32)        # WaT, WT, W2T
     _lib.call("eat_expand_bwd_coef", _dev(W, "W"), _dev(Gx, "Gx"), _dev(Tm, "Tm"), _dev(sx, "sx"), gpart.data_ptr(),
               outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 1 if frozen else 0,
-              dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), WaT.data_ptr(), M.data_ptr(), c0.data_ptr(),
+              dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), tr[0].data_ptr(), tr[1].data_ptr(), tr[2].data_ptr(),
               vec[2].data_ptr(), _stream())
-    return dW, vec[0], vec[1], WaT, M, c0
+    if frozen:
+        return dW, vec[0], vec[1], tr[0], None, None
+    M = linear(tr[2], tr[1], None, ACT_NONE)                               # W2T . WT^T
+    c0 = linear(vec[2:3], tr[1], None, ACT_NONE).view(-1)                  # e1 . WT^T
+    return dW, vec[0], vec[1], tr[0], M, c0
 
 
 # ------------------------------------------------------------------------- DyMN launchers
@@ -465,12 +538,12 @@ def mbconv(x, wp_e, bias_e, w_d, bias_d, wp_p, bias_p, Cexp, Cout, k, stride, ac
     return y
 
 
-def pw_prepack_bf16(w2d, row_scale=None, split=True):
-    Co, Ci = w2d.shape
+def pw_prepack_bf16(w2d, row_scale=None, split=True, trans=False):
+    Co, Ci = (w2d.shape[1], w2d.shape[0]) if trans else w2d.shape
     n = ((Ci + 31) // 32) * ((Co + 15) // 16) * (2 if split else 1) * 512
     wp = torch.empty((n,), device=w2d.device, dtype=torch.bfloat16)
-    _lib.call("eat_pw_prepack_bf16", _dev(w2d, "w"), _opt(row_scale, "row_scale"), wp.data_ptr(), Co, Ci,
-              1 if split else 0, _stream())
+    _lib.call("eat_pw_prepack_bf16_t" if trans else "eat_pw_prepack_bf16", _dev(w2d, "w"), _opt(row_scale, "row_scale"),
+              wp.data_ptr(), Co, Ci, 1 if split else 0, _stream())
     return wp
 
 
@@ -534,15 +607,16 @@ class precision:
 _pw_prepack_fp32, _pw_conv_fp32 = pw_prepack, pw_conv
 
 
-def pw_prepack(w2d, row_scale=None):  # noqa: F811
+def pw_prepack(w2d, row_scale=None, trans=False):  # noqa: F811
     m = precision.mode
+    ci = w2d.shape[0] if trans else w2d.shape[1]
     if m == "bf16":
-        return pw_prepack_bf16(w2d, row_scale, split=False)
-    if m == "bf16x3" or (m == "auto" and w2d.shape[1] >= 40 and w2d.shape[1] % 4 == 0):
-        wp = pw_prepack_bf16(w2d, row_scale, split=True)
+        return pw_prepack_bf16(w2d, row_scale, split=False, trans=trans)
+    if m == "bf16x3" or (m == "auto" and ci >= 40 and ci % 4 == 0):
+        wp = pw_prepack_bf16(w2d, row_scale, split=True, trans=trans)
         wp._eat_split = True                 # both bf16 packs share the dtype: mark the hi/lo one
         return wp
-    return _pw_prepack_fp32(w2d, row_scale)
+    return _pw_prepack_fp32(w2d, row_scale, trans=trans)
 
 
 def pw_conv(x, wp, bias, Co, act, in_scale=None, res=None, pool=None, write=True):  # noqa: F811

@@ -94,6 +94,10 @@ int eat_pw_conv_fwd(const float* x, const float* wp, const float* bias, const fl
  * wp has (Ci/4) * ceil(Co/16) * 64 floats.  Done once per weight update, not per step. */
 int eat_pw_prepack(const float* w, const float* row_scale, float* wp, int Co, int Ci,
                    eat_stream_t stream);
+/* The same pack of the TRANSPOSE of a stored matrix: w_t is (Ci, Co) row-major, the packed matrix is w_t^T (Co, Ci) -
+ * the data-gradient GEMM dx = W^T dz of the 1x1 convs (autograd of block_types.py:138-147,167-171) without a transposed
+ * copy of the weights. */
+int eat_pw_prepack_t(const float* w_t, const float* row_scale, float* wp, int Co, int Ci, eat_stream_t stream);
 
 /* ---- linear: models/mn/model.py:189-193 (classifier Linear layers) and the two Linear layers
  * of SqueezeExcitation (models/mn/block_types.py:64-65,74-79: fc1+ReLU, fc2+Sigmoid) ---------
@@ -195,12 +199,13 @@ int eat_dw_conv_dgrad_g(const float* dz, const float* w, const float* gz, const 
  * with g as above, Gx = sum g x^T (eat_pw_conv_wgrad(g, x)), Tm = W G, sx, the forward's (a, mean, invstd):
  *   dgamma = invstd (rowsum(W .* Gx) - mean S1), dbeta = S1 = sum gpart, m1 = S1/n, m2 = dgamma/n (0 when frozen)
  *   dW  = diag(a) [Gx - m1 sx^T - diag(m2 invstd)(Tm - mean sx^T)]
- *   WaT = (diag(a) W)^T (Ci x Co), M = -W^T diag(a m2 invstd) W (Ci x Ci), c0 = W^T (a (m2 invstd mean - m1)) (Ci)
- * so that dx = WaT g + M x + c0 (two eat_pw_conv_fwd launches). e_scratch: 2*Co floats. */
+ * and the operands of dx = WaT g + M x + c0 (two eat_pw_conv_fwd launches), all Ci x Co transposes so that
+ * eat_linear_fwd (which contracts over the contiguous axis) forms M = W2T . WT^T (Ci x Ci) and c0 = e1 . WT^T (Ci):
+ *   WaT = (diag(a) W)^T,  WT = W^T,  W2T = -(diag(a m2 invstd) W)^T,  e1 = a (m2 invstd mean - m1) (Co). */
 int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart, int outer,
                         int inner, int Co, int Ci, const float* a, const float* mean, const float* invstd, double n,
-                        int frozen, float* dW, float* dgamma, float* dbeta, float* WaT, float* M, float* c0,
-                        float* e_scratch, eat_stream_t stream);
+                        int frozen, float* dW, float* dgamma, float* dbeta, float* WaT, float* WT, float* W2T, float* e1,
+                        eat_stream_t stream);
 
 /* autograd of the depthwise Conv2d of models/mn/block_types.py:150-162 (data gradient):
  * Depthwise conv data gradient dx (B,C,F,T) from dz (B,C,Fo,To), taps w (C,k,k); res (B,C,F,T) or
@@ -363,6 +368,9 @@ int eat_expand_dw_bf16_fwd(const float* x, const void* wp_e, const float* bias_e
  * as eat_pw_conv_fwd. */
 int eat_pw_prepack_bf16(const float* w, const float* row_scale, void* wp, int Co, int Ci, int split,
                         eat_stream_t stream);
+/* bf16 pack of the transpose of a stored (Ci, Co) matrix, see eat_pw_prepack_t. */
+int eat_pw_prepack_bf16_t(const float* w_t, const float* row_scale, void* wp, int Co, int Ci, int split,
+                          eat_stream_t stream);
 int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, const float* in_scale,
                          const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int act,
                          int split, eat_stream_t stream);

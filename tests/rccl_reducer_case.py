@@ -83,4 +83,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:            # the parent test shows stdout: RCCL's teardown warnings flood stderr
+        import traceback
+        print("RCCL_REDUCER_FAILED\n" + traceback.format_exc(), flush=True)
+        raise

@@ -23,7 +23,7 @@ def _rand(*shape, seed=0, scale=1.0):
 
 def _rel(got, ref):
     got = got.detach().cpu().double().reshape(-1)
-    ref = ref.detach().double().reshape(-1)
+    ref = ref.detach().cpu().double().reshape(-1)
     return float((got - ref).norm() / max(1e-30, float(ref.norm())))
 
 
@@ -146,7 +146,8 @@ def test_expand_conv_bn_act_via_gram_matrix(B, Ci, Co, F_, T, act, exact):
     assert _rel(dgam, gr.grad) < tol and _rel(dbet, br.grad) < tol
     assert _rel(dx, xr.grad + res.double()) < tol, _rel(dx, xr.grad + res.double())
     # frozen statistics (the layer in eval mode inside model.train()): dz = a g, no batch-mean terms
-    dWf, dgf, dbf, WaTf, _, _ = ops.expand_bwd_coef(Wd, Gx, Gx, mean, gparts, a, mean, invstd, n, frozen=True)
+    dWf, dgf, dbf, WaTf, Mf, _ = ops.expand_bwd_coef(Wd, Gx, Gx, mean, gparts, a, mean, invstd, n, frozen=True)
+    assert Mf is None
     gd = g.cpu().double()
     assert _rel(dWf, torch.einsum("bcft,bkft->ck", gd * a.cpu().double()[None, :, None, None], x.double())) < tol
     assert _rel(dbf, gd.sum((0, 2, 3))) < tol
