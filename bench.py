@@ -1,23 +1,28 @@
 """bench.py -- hot-path throughput on MI355X.
 
-One "step" = one pass of the hot path (fused log-mel front-end + mn10_as forward, eval, fp32) over one batch of
-synthetic 10 s @ 32 kHz clips already resident in HBM (BASELINE.json configs[1]: "mn10_as forward-only, batch 256
-synthetic 10 s clips, 1xMI355X, fp32").  With --gpus N every rank processes its own batch of the same size (clips are
-independent: no data-path collective), value = N * batch * steps / max-over-ranks time, scaling "weak".
+BASELINE.json's metric is "clips/sec (10 s @ 32 kHz) mn10_as fwd+bwd, 1/2/4/8 MI355X; logit max-abs-err".  One "step" =
+one full training step of mn10_as on one batch of 256 synthetic 10 s @ 32 kHz clips per GPU, already resident in HBM:
+log-mel front-end (train mode) -> forward with batch-statistics BatchNorm -> BCE-with-logits -> hand-written backward ->
+[bucketed RCCL all-reduce of the gradient, overlapped with backward, when N > 1] -> fused Adam (ex_audioset.py:139-199
+without data loading / wandb / teacher).  `value` = N * 256 * steps / max-over-ranks time, scaling "weak".
+(Rounds 1-2 printed the forward-only figure of BASELINE configs[1] as `value`; it is the `forward` object now, so that
+the headline is the metric BASELINE names and the N = 2/4/8 runs exercise the collective.)
 
 `python bench.py --gpus N` started WITHOUT a torchrun environment re-launches itself as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` (one rank per GPU, RCCL); started by torchrun it
 reads RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to print a line when fewer than N ranks / GPUs are available.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
-  roofline       dominant kernel's algorithmic HBM bytes (or flops) per launch / its mean launch duration (HIP events
-                 on the launch stream) against the 8 TB/s HBM3E (or MFMA) peak
-  roofline_e2e   whole forward at SURVEY 8(d)'s 96.37 MB algorithmic bytes per clip
-  fp32_exact     the same forward with EVERY 1x1 conv on the exact fp32 MFMA (EAT_PW_MODE=fp32 arithmetic)
-  train_step     BASELINE's fwd+bwd metric: mel + forward (batch-stat BN) + BCE + backward + [RCCL all-reduce] + Adam,
-                 mn10, 256 clips per GPU, hipGraph replay
+  roofline       the kernel with the largest share of the timed step: algorithmic HBM bytes (or flops) per launch / its
+                 mean launch duration (HIP events on the launch stream) against the 8 TB/s HBM3E (or MFMA) peak;
+                 `traffic` = measured HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic_*.json)
+  roofline_e2e   the whole training step at SURVEY 8(d)'s 285.8 MB algorithmic bytes per clip
+  forward        BASELINE configs[1]: log-mel + mn10 eval forward, batch 256, hipGraph replay: clips/s, ms, fraction of the
+                 HBM roofline at the 96.37 MB/clip contract bytes AND at the bytes the launch plan actually moves
+                 (sum of every kernel's own input + output), `fp32_exact` = every 1x1 conv on the exact fp32 MFMA
   train_step_mn40_bf16 / train_step_dymn20   BASELINE configs[2] / configs[3] (batch 128; N = 1 only)
-  cpu_baseline   the CPU oracle (a port of the reference's torch-CPU path) timed on this host: mel, forward, train step
+  parity         logit max-abs-err of the HIP path vs the CPU oracle (4 clips, same weights)
+  cpu_baseline   the CPU oracle (a port of the reference's torch-CPU path) timed on this host: the same training step
 """
 import argparse
 import contextlib
@@ -135,7 +140,8 @@ def _alg_bytes(name, a):
         return f"stem_conv_kernel<{act}>", 4 * B * (F * T + C * Fo * To), 2 * B * C * Fo * To * 9
     if name == "eat_mel_fwd":
         B, L, n_mels, T = a[1], a[2], a[11], a[14]
-        return "mel_fwd_kernel", 4 * B * (L + n_mels * T), B * T * 60000
+        # the front-end costs ~0.03 GFLOP per 10 s clip (1000 frames: radix FFT-1024 + banded mel)
+        return "mel_fwd_kernel", 4 * B * (L + n_mels * T), int(B * T * 30000)
     if name == "eat_linear_fwd":
         x, w, bias, y, B, K, N = a[:7]
         return "linear_kernel", 4 * (B * K + N * K + B * N), 2 * B * K * N
@@ -145,7 +151,118 @@ def _alg_bytes(name, a):
     if name == "eat_head_fwd":
         pool, w1, b1, w2, b2, out, B, C, H, N = a[:10]
         return "head_kernel", 4 * (B * C + C * H + H * N + B * N), 2 * B * H * (C + N)
+    # ---- training-step entry points (symbols: the dispatch rules of csrc/train.hip / dw_plane.hip)
+    if name == "eat_pw_conv_wgrad":
+        dz, x, xs, dW, B, Co, Ci, S, mode = a[:9]
+        same = dz == x
+        nbytes = 4 * B * S * (Co if same else Co + Ci) + 4 * Co * Ci
+        if mode == 1 or S % 4:
+            sym = "pw_wgrad_kernel"
+        elif Co <= 64 and Ci <= 64 and (Co <= 16 or Ci <= 16 or (same and Co == Ci and not xs)):
+            mt, nt = (Co + 15) // 16, (Ci + 15) // 16
+            gram = same and mt == nt and not xs
+            sym = f"pw_wgrad_x3_narrow_kernel<{mt},{nt},{'true' if gram else 'false'}>"
+        else:
+            sym = f"pw_wgrad_x3_kernel<{1 if mode == 2 else 3}>"
+        return sym, nbytes, 2 * B * S * Co * Ci
+    if name == "eat_dw_conv_fwd_stats":
+        x, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:17]
+        return f"dw_conv_fwd_stats<{k},{s}>", 4 * B * C * (F * T + Fo * To), 2 * B * C * Fo * To * k * k
+    if name == "eat_dw_conv_fwd_tf":
+        x, ia, ib, iact, w, bias, y, B, C, F, T, Fo, To, k, s = a[:15]
+        return f"dw_conv_fwd_tf<{k},{s}>", 4 * B * C * (F * T + Fo * To), 2 * B * C * Fo * To * k * k
+    if name == "eat_dw_conv_dgrad_g":
+        dz, w, gz, ga, gb, gact, g, gp, cap, hin, B, C, F, T, Fo, To, k, s = a[:18]
+        return f"dw_conv_dgrad_g<{k},{s}>", 4 * B * C * (Fo * To + 2 * F * T), 2 * B * C * F * T * k * k // (s * s)
+    if name == "eat_dw_conv_dgrad":
+        dz, w, res, dx, B, C, F, T, Fo, To, k, s = a[:12]
+        return f"dw_conv_dgrad<{k},{s}>", 4 * B * C * (Fo * To + F * T * (2 if res else 1)), 2 * B * C * F * T * k * k // (s * s)
+    if name == "eat_dw_conv_wgrad_tf":
+        dz, x, ia, ib, iact, dw, B, C, F, T, Fo, To, k, s = a[:14]
+        return f"dw_conv_wgrad<{k},{s}>", 4 * B * C * (F * T + Fo * To), 2 * B * C * Fo * To * k * k
+    if name == "eat_dw_conv_wgrad":
+        dz, x, dw, B, C, XC, F, T, Fo, To, k, s = a[:12]
+        return f"dw_conv_wgrad<{k},{s}>", 4 * B * (XC * F * T + C * Fo * To), 2 * B * C * Fo * To * k * k
+    if name == "eat_bn_act_fwd":
+        z, aa, bb, res, y, pool, B, C, S, act = a[:10]
+        return f"bn_act_fwd_kernel<{act}>", 4 * B * C * S * (1 + (1 if y else 0) + (1 if res else 0)), 4 * B * C * S
+    if name == "eat_bn_act_bwd_reduce":
+        B, C, S, act = a[8:12]
+        return f"bn_act_bwd_reduce_kernel<{act}>", 8 * B * C * S, 8 * B * C * S
+    if name == "eat_bn_act_bwd_apply":
+        B, C, S, act = a[10:14]
+        return f"bn_act_bwd_apply_kernel<{act}>", 12 * B * C * S, 10 * B * C * S
+    if name in ("eat_bn_stats", "eat_bn_stats_partial"):
+        B, C, S = a[1:4]
+        return "bn_stats_kernel", 4 * B * C * S, 3 * B * C * S
+    if name == "eat_plane_dot":
+        B, C, S = a[5:8]
+        return "plane_dot_kernel", 8 * B * C * S, 2 * B * C * S
+    if name == "eat_act_grad_sum":
+        B, C, S = a[7:10]
+        return "act_grad_sum_kernel", 12 * B * C * S, 4 * B * C * S
     return name, 0, 0
+
+
+_HAS_MFMA = ("pw_conv_kernel", "pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel", "expand_dw_kernel", "irb_kernel",
+             "pw_wgrad_kernel", "pw_wgrad_x3_kernel", "pw_wgrad_x3_narrow_kernel", "linear_kernel")
+
+
+def roofline_of(name, d, args):
+    """The `roofline` object of one kernel symbol from its event-profile row `d` (launches, total_ms, bytes, flops)."""
+    import fnmatch
+    per_launch_bytes = d["bytes"] / d["launches"]
+    per_launch_flops = d["flops"] / d["launches"]
+    per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
+    traffic, tsrc = None, None
+    for tfile in ("pmc_traffic_r3.json", "pmc_traffic_r2c.json"):
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        if not os.path.exists(tpath):
+            continue
+        ks = json.load(open(tpath))["kernels"]
+        # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
+        hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
+        if hit:
+            n = sum(h["launches_sampled"] for h in hit)
+            fetch = sum(h["fetch_kib"] * h["launches_sampled"] for h in hit) / n * 1024
+            write = sum(h["write_kib"] * h["launches_sampled"] for h in hit) / n * 1024
+            # gfx950: FETCH_SIZE under-reports wide reads by 2x (MI355X_MICROARCH.md).  Calibrated per kernel on a known
+            # byte count instead of a name list: a kernel cannot fetch less than its compulsory input, so a raw reading
+            # below 0.75x the algorithmic read bytes is a halved one.
+            rd = d.get("read_bytes", 0) / d["launches"]
+            x2 = rd > 0 and fetch < 0.75 * rd
+            traffic = int((2 if x2 else 1) * fetch + write)
+            tsrc = (f"profiles/{tfile}: rocprofv3 FETCH_SIZE ({fetch / 1e6:.1f} MB raw, "
+                    + ("x2: below 0.75x the " if x2 else "x1: not below 0.75x the ") + f"{rd / 1e6:.1f} MB of compulsory reads) + "
+                    f"WRITE_SIZE ({write / 1e6:.1f} MB), separate passes, largest-grid launches")
+            break
+    base = name.split("<")[0]
+    mfma_peak = MFMA_F32_PEAK
+    if base in ("pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel"):
+        mfma_peak = MFMA_BF16_PEAK / (3 if ",3," in name else 1)
+    if base in ("expand_dw_kernel", "pw_wgrad_x3_narrow_kernel") or name == "pw_wgrad_x3_kernel<3>":
+        mfma_peak = MFMA_BF16_PEAK / 3            # every useful product costs three bf16 MFMAs
+    if name == "pw_wgrad_x3_kernel<1>":
+        mfma_peak = MFMA_BF16_PEAK
+    # which roof binds: a kernel WITHOUT matrix instructions is priced against HBM only (its fp32 VALU work is reported
+    # as `valu_tflops` for information); an MFMA kernel against the larger of its HBM time and its MFMA time
+    has_mfma = base in _HAS_MFMA
+    mfma_bound = has_mfma and per_launch_flops / mfma_peak > per_launch_bytes / HBM_PEAK
+    common = {"kernel": name, "traffic": traffic, "launches_per_step": d["launches"],
+              "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_bytes_per_launch": int(per_launch_bytes),
+              "alg_flops_per_launch": int(per_launch_flops), "hbm_gbps": round(per_launch_bytes / per_launch_s / 1e9, 1),
+              "traffic_source": tsrc, "share_of_step": round(d["total_ms"] / args["step_ms"], 3)}
+    if has_mfma:
+        common["mfma_tflops"] = round(per_launch_flops / per_launch_s / 1e12, 2)
+    else:
+        common["valu_tflops"] = round(per_launch_flops / per_launch_s / 1e12, 2)
+    if mfma_bound:
+        ach = per_launch_flops / per_launch_s
+        return {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": round(mfma_peak / 1e12, 1),
+                "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4), **common}
+    ach = per_launch_bytes / per_launch_s
+    return {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK, 4), **common}
 
 
 def kernel_profile(step, iters=3):
@@ -177,13 +294,33 @@ def kernel_profile(step, iters=3):
             print(f"[launch] {sym:24s} {us:9.1f} us {nbytes / us / 1e3:8.1f} GB/s  {ints}", file=sys.stderr)
     for name, args, e0, e1 in rec:
         sym, nbytes, flops = _alg_bytes(name, args)
-        d = agg.setdefault(sym, [0, 0.0, 0, 0])
+        d = agg.setdefault(sym, [0, 0.0, 0, 0, 0])
         d[0] += 1
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += nbytes
         d[3] += flops
+        d[4] += _read_bytes(name, args, nbytes)
     return {k: dict(launches=v[0] // iters, total_ms=v[1] / iters * 1e3, bytes=v[2] / iters, flops=v[3] / iters,
-                    gbps=(v[2] / v[1] / 1e9) if v[1] > 0 else 0.0) for k, v in agg.items()}
+                    read_bytes=v[4] / iters, gbps=(v[2] / v[1] / 1e9) if v[1] > 0 else 0.0) for k, v in agg.items()}
+
+
+def _read_bytes(name, a, nbytes):
+    """Compulsory READ bytes of one launch (calibrates the FETCH_SIZE correction); 0 = unknown."""
+    if name == "eat_mel_fwd":
+        return 4 * a[1] * a[2]
+    if name == "eat_pw_conv_wgrad":
+        return nbytes - 4 * a[5] * a[6]
+    if name in ("eat_bn_act_bwd_reduce", "eat_bn_stats", "eat_bn_stats_partial", "eat_plane_dot"):
+        return nbytes
+    if name == "eat_bn_act_bwd_apply":
+        return nbytes * 2 // 3
+    if name in ("eat_pw_conv_fwd", "eat_pw_conv_bf16_fwd"):
+        B, Ci, Co, S = a[7:11]
+        return 4 * B * S * (Ci + (Co if a[4] else 0))
+    if name == "eat_dw_conv_dgrad_g":
+        B, C, F, T, Fo, To = a[10:16]
+        return 4 * B * C * (Fo * To + F * T)
+    return 0
 
 
 # ----------------------------------------------------------------------------- CPU baseline
@@ -237,10 +374,11 @@ def cpu_baseline(budget_s=7.0, batch=32):
     fwd_r, fwd_n = rate(fwd_leg)
     trn_r, trn_n = rate(train_leg)
     both = 1.0 / (1.0 / mel_r + 1.0 / fwd_r)
-    return {"value": round(both, 2), "unit": "clips/s", "cores": cores, "kind": "port",
-            "mel_clips_s": round(mel_r, 2), "fwd_clips_s": round(fwd_r, 2), "train_step_clips_s": round(trn_r, 2),
+    return {"value": round(trn_r, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "mel_clips_s": round(mel_r, 2), "fwd_clips_s": round(fwd_r, 2), "mel_plus_fwd_clips_s": round(both, 2),
+            "train_step_clips_s": round(trn_r, 2),
             "sample": f"batch {batch}, fp32, torch CPU with {cores} threads ({os.cpu_count()} logical CPUs): mel {mel_n} / mn10 fwd {fwd_n} / train step "
-                      f"{trn_n} passes (~{budget_s:.0f} s each); value = mel + fwd, the bench workload"}
+                      f"{trn_n} passes (~{budget_s:.0f} s each); value = the training step (mel + fwd + BCE + bwd + Adam), the bench workload"}
 
 
 def parity_probe(mel, model, dev):
@@ -417,9 +555,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches issued on concurrent HIP streams per step")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-train", action="store_true", help="skip every train-step measurement")
-    ap.add_argument("--train-batch", type=int, default=256, help="clips per GPU per mn10 train step")
-    ap.add_argument("--train-steps", type=int, default=20, help="timed mn10 train steps (>= 20 by default)")
+    ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (configs[1]) measurement")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event profiles (roofline objects)")
     ap.add_argument("--no-train-configs", action="store_true", help="skip the mn40_bf16 / dymn20 train steps (configs 2/3)")
     ap.add_argument("--train-model", default=None, choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20"],
                     help="only this train-step network (debug)")
@@ -485,111 +622,124 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(args.batch, CLIP_SAMPLES, device=dev, generator=g)).clamp_(-1, 1)
 
-    clips_per_s, ms_step, launch = forward_bench(args, mel, model, wave, ranks)
+    # ------------------------------------------------------------------ headline: the training step (fwd + bwd)
+    train_name = args.train_model or "mn10"
+    head = train_bench(train_name, args.batch, args.steps, args.warmup, args, mel, wave, ranks)
     arithmetic = {
-        "auto": "fp32 activations and accumulation; 1x1 convs: exact fp32 MFMA for C_in < 40, split-operand bf16x3 MFMA "
-                "(x = hi + lo, 3 products, ~2^-16 rel. error) for C_in >= 40 [fp32_exact: every 1x1 on the exact fp32 MFMA]",
-        "fp32": "fp32 activations, exact fp32 MFMA / VALU everywhere"}.get(mn_mod._PW_MODE, mn_mod._PW_MODE)
+        "auto": "fp32 activations and accumulation; 1x1 convs and their gradients: exact fp32 MFMA for C_in < 40, "
+                "split-operand bf16x3 MFMA (x = hi + lo, 3 products, ~2^-16 rel. error) from C_in >= 40",
+        "fp32": "fp32 activations, exact fp32 MFMA / VALU everywhere"}.get(os.environ.get("EAT_TRAIN_PRECISION", "auto"),
+                                                                            os.environ.get("EAT_TRAIN_PRECISION", "auto"))
+    alg_train = ALG_TRAIN.get(train_name)
     result = {
-        "metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": round(clips_per_s, 1), "unit": "clips/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 synthetic "
-                               "10 s @ 32 kHz clips per GPU, fp32 [BASELINE.json configs[1]]",
-                   "batch_per_gpu": args.batch, "arithmetic": arithmetic, "launch": launch,
-                   "pw_stream_mode": __import__("efficientat_amd.ops", fromlist=["x"]).pw_stream_mode(),
-                   "parallelism": f"dp{world} (independent clips, no collective in the forward)"},
-        "roofline_e2e": {"bound": "hbm", "achieved": round(clips_per_s / world * ALG_BYTES_PER_CLIP / 1e9, 1),
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(clips_per_s / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
-                         "note": "whole forward: clips/s per GPU x 96.37 MB algorithmic bytes per clip (SURVEY 8d)"},
+        "metric": "clips/sec (10 s @ 32 kHz) mn10_as fwd+bwd, 1/2/4/8 MI355X; logit max-abs-err",
+        "value": head["value"], "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": head["warmup"],
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{train_name}_as training step (log-mel + forward with batch-stat BatchNorm + BCE + backward + "
+                               + ("bucketed RCCL all-reduce + " if world > 1 else "")
+                               + f"fused Adam), batch {args.batch} synthetic 10 s @ 32 kHz clips per GPU, fp32 "
+                               "[BASELINE.json metric; per-GPU shard of configs[4]; forward-only configs[1] in `forward`]",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "arithmetic": arithmetic,
+                   "launch": head["launch"], "train_plan": __import__("efficientat_amd.mn_train", fromlist=["x"])._TRAIN_V,
+                   "parallelism": f"dp{world}" + (" (local BatchNorm statistics, gradients averaged by RCCL all-reduce "
+                                                  "in ~4 MB buckets overlapped with backward)" if world > 1 else "")},
+        "final_loss": head["final_loss"],
+        "roofline_e2e": {"bound": "hbm", "achieved": round(head["value"] / world * alg_train / 1e9, 1) if alg_train else None,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": head["roofline_e2e_frac"],
+                         "note": "whole training step: clips/s per GPU x 285.8 MB algorithmic bytes per clip (SURVEY 8d: "
+                                 "3 x forward activations + 28 B per parameter / batch + mel)"},
     }
 
-    if not args.no_fp32_exact and mn_mod._PW_MODE != "fp32":
-        keep = mn_mod._PW_MODE
-        mn_mod._PW_MODE = "fp32"
-        model._cache.invalidate()
-        try:
-            v, ms, _ = forward_bench(args, mel, model, wave, ranks)
-            result["fp32_exact"] = {"value": round(v, 1), "unit": "clips/s", "ms_per_step": round(ms, 4),
-                                    "roofline_e2e_frac": round(v / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
-                                    "what": "the same forward with every 1x1 conv on v_mfma_f32_16x16x4_f32 (exact fp32 products)"}
-        finally:
-            mn_mod._PW_MODE = keep
+    # ------------------------------------------------------------------ BASELINE configs[1]: forward only
+    if not args.no_forward:
+        clips_per_s, ms_step, launch = forward_bench(args, mel, model, wave, ranks)
+        fwd = {"value": round(clips_per_s, 1), "unit": "clips/s", "ms_per_step": round(ms_step, 4), "steps": args.steps,
+               "warmup": args.warmup, "batch_per_gpu": args.batch, "launch": launch,
+               "workload": "mn10_as forward-only (log-mel front-end + MN eval forward), batch 256 per GPU, fp32 "
+                           "[BASELINE.json configs[1]]; no collective",
+               "pw_stream_mode": __import__("efficientat_amd.ops", fromlist=["x"]).pw_stream_mode(),
+               "roofline_e2e_frac": round(clips_per_s / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
+               "alg_bytes_per_clip": ALG_BYTES_PER_CLIP}
+        if not args.no_fp32_exact and mn_mod._PW_MODE != "fp32":
+            keep = mn_mod._PW_MODE
+            mn_mod._PW_MODE = "fp32"
             model._cache.invalidate()
+            try:
+                v, ms, _ = forward_bench(args, mel, model, wave, ranks)
+                fwd["fp32_exact"] = {"value": round(v, 1), "unit": "clips/s", "ms_per_step": round(ms, 4),
+                                     "roofline_e2e_frac": round(v / world * ALG_BYTES_PER_CLIP / HBM_PEAK, 4),
+                                     "what": "the same forward with every 1x1 conv on v_mfma_f32_16x16x4_f32 (exact fp32 products)"}
+            finally:
+                mn_mod._PW_MODE = keep
+                model._cache.invalidate()
+        result["forward"] = fwd
 
-    if not args.no_train:
-        legs = [("train_step", args.train_model or "mn10", args.train_batch, max(args.train_steps, 1), 3)]
-        if world == 1 and not args.no_train_configs and args.train_model is None:
-            legs += [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2)]
-        for key, name, bt, st, wu in legs:
+    if world == 1 and not args.no_train_configs and args.train_model is None:
+        for key, name, bt, st, wu in [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2)]:
             try:
                 result[key] = train_bench(name, bt, st, wu, args, mel, wave, ranks)
             except Exception as e:  # pragma: no cover - one failing leg must not lose the line
-                if dist is not None:
-                    raise
                 result[key] = {"error": f"{type(e).__name__}: {e}", "model": name}
                 torch.cuda.empty_cache()
-        model.eval()
-        mel.eval()
+    model.eval()
+    mel.eval()
 
-    if rank == 0:
-        def profile_step():      # one stream: concurrent sub-batch streams would time overlapping kernels
-            with torch.no_grad():
-                model(mel(wave).unsqueeze(1))
-        prof = kernel_profile(profile_step)
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        name, d = dom
-        per_launch_bytes = d["bytes"] / d["launches"]
-        per_launch_flops = d["flops"] / d["launches"]
-        per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
-        traffic, tsrc = None, None
-        for tfile in ("pmc_traffic_r2c.json", "pmc_traffic_r2b.json", "pmc_traffic_r2.json", "pmc_traffic_r1.json"):
-            tpath = os.path.join(ROOT, "profiles", tfile)
-            if os.path.exists(tpath):
-                # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
-                import fnmatch
-                ks = json.load(open(tpath))["kernels"]
-                hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
-                if hit:
-                    traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches_sampled"] for h in hit) /
-                                  sum(h["launches_sampled"] for h in hit))
-                    tsrc = f"profiles/{tfile} (rocprofv3 FETCH_SIZE [x2 for 16-byte-lane readers] + WRITE_SIZE, separate passes, B=256 launches only)"
-                    break
-        # which roof binds this kernel: the larger of its HBM time and its MFMA time.  The MFMA peak is the
-        # one of the instruction the kernel issues: fp32 16x16x4 (157 TF), bf16 16x16x32 (2.5 PF dense), and
-        # for the bf16x3 split kernel 2.5 PF / 3 because each useful product costs three bf16 MFMAs.
-        mfma_peak = MFMA_F32_PEAK
-        if name.startswith("expand_dw_kernel"):
-            mfma_peak = MFMA_BF16_PEAK / 3
-        if name.startswith(("pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel")):
-            mfma_peak = MFMA_BF16_PEAK / (3 if ",3," in name else 1)
-        mfma_bound = per_launch_flops / mfma_peak > per_launch_bytes / HBM_PEAK
-        common = {"kernel": name, "traffic": traffic, "launches_per_step": d["launches"],
-                  "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_bytes_per_launch": int(per_launch_bytes),
-                  "alg_flops_per_launch": int(per_launch_flops),
-                  "hbm_gbps": round(per_launch_bytes / per_launch_s / 1e9, 1),
-                  "mfma_tflops": round(per_launch_flops / per_launch_s / 1e12, 2),
-                  "traffic_source": tsrc,
-                  "share_of_step": round(d["total_ms"] / sum(v["total_ms"] for v in prof.values()), 3)}
-        if name.startswith(("mel_fwd_kernel", "dw_plane_kernel", "dw_conv_kernel", "stem_conv_kernel")):
-            # no MFMA in these kernels: their compute roof is the fp32 VECTOR peak, numerically the fp32-MFMA figure
-            common["compute_roof"] = "fp32 VALU peak (157.3 TFLOP/s); the kernel issues no MFMA instructions"
-        if mfma_bound:
-            ach = per_launch_flops / per_launch_s
-            result["roofline"] = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": round(mfma_peak / 1e12, 1),
-                                  "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4), **common}
-        else:
-            ach = per_launch_bytes / per_launch_s
-            result["roofline"] = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), **common}
+    if rank == 0 and not args.no_profile:
+        # ---- dominant kernel of the timed step: one eager training step with a HIP event pair around every launch
+        import torch.nn.functional as F
+        tm = make_train_model(train_name, dev)
+        tm.train()
+        mel.train()
+        bt = min(args.batch, wave.shape[0])
+        gy = torch.Generator(device=dev).manual_seed(99)
+        y = (torch.rand((bt, 527), device=dev, generator=gy) < 2.7 / 527).float()
+        opt = torch.optim.Adam(tm.parameters(), lr=8e-4, fused=True)
+
+        def tstep():
+            opt.zero_grad(set_to_none=True)
+            logits, _ = tm(mel(wave[:bt]).unsqueeze(1))
+            F.binary_cross_entropy_with_logits(logits, y).backward()
+            opt.step()
+        tstep()
+        prof = kernel_profile(tstep, iters=2)
+        mel.eval()
+        del tm, opt
+        torch.cuda.empty_cache()
+        step_ms = sum(v["total_ms"] for v in prof.values())
+        name, d = max(((k, v) for k, v in prof.items() if v["bytes"] > 0), key=lambda kv: kv[1]["total_ms"])
+        result["roofline"] = roofline_of(name, d, {"step_ms": step_ms})
+        result["roofline"]["step"] = "training step, eager launches with a HIP event pair each (one stream)"
+        moved = sum(v["bytes"] for v in prof.values())
+        result["roofline_e2e"]["moved_bytes_per_step"] = int(moved)
+        result["roofline_e2e"]["frac_moved"] = round(moved / (head["ms_per_step"] * 1e-3) / HBM_PEAK, 4)
+        result["roofline_e2e"]["note_moved"] = ("moved = sum over the step's launches of each kernel's own input + output "
+                                                "bytes (what the plan reads and writes), against the same step time")
         if args.kernel_table:
+            print(f"[bench] training step, {sum(v['launches'] for v in prof.values())} library launches, "
+                  f"{step_ms:.2f} ms of kernels", file=sys.stderr)
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
-                print(f"[bench] {k:28s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "
+                print(f"[bench-train] {k:36s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "
                       f"{v['bytes'] / 1e9:7.3f} GB  {v['gbps']:8.1f} GB/s", file=sys.stderr)
+        if not args.no_forward:
+            def profile_step():      # one stream: concurrent sub-batch streams would time overlapping kernels
+                with torch.no_grad():
+                    model(mel(wave).unsqueeze(1))
+            fprof = kernel_profile(profile_step)
+            fmoved = sum(v["bytes"] for v in fprof.values())
+            fms = sum(v["total_ms"] for v in fprof.values())
+            result["forward"]["moved_bytes_per_step"] = int(fmoved)
+            result["forward"]["roofline_moved_frac"] = round(fmoved / (result["forward"]["ms_per_step"] * 1e-3) / HBM_PEAK, 4)
+            result["forward"]["single_stream_kernel_ms"] = round(fms, 3)
+            fname, fd = max(fprof.items(), key=lambda kv: kv[1]["total_ms"])
+            result["forward"]["roofline"] = roofline_of(fname, fd, {"step_ms": fms})
+            if args.kernel_table:
+                for k, v in sorted(fprof.items(), key=lambda kv: -kv[1]["total_ms"]):
+                    print(f"[bench] {k:28s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "
+                          f"{v['bytes'] / 1e9:7.3f} GB  {v['gbps']:8.1f} GB/s", file=sys.stderr)
+    if rank == 0:
         err, scale = parity_probe(mel, model, dev)
-        result["parity"] = {"logit_max_abs_err": err, "logit_abs_max": scale, "vs": "CPU oracle, 4 clips, same weights"}
+        result["parity"] = {"logit_max_abs_err": err, "logit_abs_max": scale, "vs": "CPU oracle, 4 clips, same weights (eval forward)"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), file=json_out, flush=True)

@@ -753,12 +753,19 @@ template <int MTN, int NTN, bool SAME>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                     const float* __restrict__ xscale, float* __restrict__ dW,
                                                                     int B, int Co, int Ci, int S, int sps,
-                                                                    int units_per_block) {
+                                                                    int units_per_block, int n_slots) {
+  // the four waves' tiles are combined in LDS (ds_add_f32) before ONE set of global atomics per block, and the blocks
+  // are spread over n_slots copies of dW (reduced by wgrad_slot_reduce_kernel): atomics on the same address serialise
+  // in L2 at ~40 ns each, which made the 8192 (= 2048 blocks x 4 waves) adds per element the whole cost of this kernel
+  // on the 16 x 16 layers (311 us for 105 us of HBM time)
+  __shared__ float s_tile[MTN * NTN * 256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 15, kg = lane >> 4;
   const int total = B * sps;
   const int u0 = blockIdx.z * units_per_block;
   const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
+  for (int i = threadIdx.x; i < MTN * NTN * 256; i += 256) s_tile[i] = 0.0f;
+  __syncthreads();
   f32x4 acc[MTN][NTN];
 #pragma unroll
   for (int i = 0; i < MTN; ++i)
@@ -846,21 +853,35 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
 #pragma unroll
     for (int j = 0; j < NTN; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = 16 * i + kg * 4 + q, n = 16 * j + r;
-        if (m < Co && n < Ci) atomicAdd(dW + (size_t)m * Ci + n, acc[i][j][q]);
-      }
+      for (int q = 0; q < 4; ++q) atomicAdd(&s_tile[((i * NTN + j) * 4 + q) * 64 + lane], acc[i][j][q]);   // ds_add_f32
+  __syncthreads();
+  float* out = dW + (size_t)(blockIdx.z % n_slots) * Co * Ci;
+  for (int e = threadIdx.x; e < MTN * NTN * 256; e += 256) {
+    const int ln = e & 63, q = (e >> 6) & 3, ij = e >> 8;
+    const int i = ij / NTN, j = ij - i * NTN;
+    const int m = 16 * i + (ln >> 4) * 4 + q, n = 16 * j + (ln & 15);
+    if (m < Co && n < Ci) atomicAdd(out + (size_t)m * Ci + n, s_tile[e]);
+  }
+}
+
+// dW[e] += sum over the slots of ws (plain read-modify-write: one thread per element)
+__global__ void wgrad_slot_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int n, int n_slots) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float t = 0.0f;
+  for (int sidx = 0; sidx < n_slots; ++sidx) t += ws[(size_t)sidx * n + e];
+  dW[e] += t;
 }
 
 template <int MTN, int NTN>
 static void launch_narrow(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                          int sps, int upb, unsigned nz, hipStream_t s) {
+                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s) {
   if (dz == x && MTN == NTN && !x_scale)
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, (MTN == NTN ? NTN : 1), (MTN == NTN)>), dim3(1, 1, nz), dim3(256), 0, s, dz,
-                       x, x_scale, dW, B, Co, Ci, S, sps, upb);
+                       x, x_scale, dW, B, Co, Ci, S, sps, upb, n_slots);
   else
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, NTN, false>), dim3(1, 1, nz), dim3(256), 0, s, dz, x, x_scale, dW, B,
-                       Co, Ci, S, sps, upb);
+                       Co, Ci, S, sps, upb, n_slots);
 }
 
 }  // namespace
@@ -1081,7 +1102,7 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 }
 
 static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                         int per_sample, int exact_fp32, eat_stream_t stream) {
+                         int per_sample, int exact_fp32, eat_stream_t stream, float* ws = nullptr, int n_slots = 0) {
   // default: split-operand bf16 MFMA kernel (fp32-class accuracy); exact_fp32 (the caller's precision choice),
   // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
@@ -1107,16 +1128,22 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
     const bool gram = dz == x && Co == Ci && !x_scale;          // Gram matrix of one tensor (train_fuse.hip): one load per unit
     if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16 || gram) && !per_sample) {
       // narrow streaming layers: ~2048 single-tile blocks whose 4 waves split the k range
-      long long splits = 2048 < total ? 2048 : total;
+      // ~1024 blocks (4 waves each); with a workspace the blocks' atomics go to n_slots copies of dW
+      long long splits = 1024 < total ? 1024 : total;
       upb = (int)((total + splits - 1) / splits);
       const unsigned nz = (unsigned)((total + upb - 1) / upb);
       const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
       hipStream_t hs = (hipStream_t)stream;
-#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, dW, B, Co, Ci, S, sps, upb, nz, hs)
+      const bool use_ws = ws != nullptr && n_slots > 1;
+      float* target = use_ws ? ws : dW;
+      const int slots = use_ws ? n_slots : 1;
+#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, sps, upb, nz, slots, hs)
       EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
       EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
       EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // Gram mode only (see `gram`)
 #undef EAT_NARROW
+      if (use_ws)
+        hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
     } else {
       if (exact_fp32 == 2)
         hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
@@ -1141,6 +1168,15 @@ extern "C" int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x
                                  int Ci, int S, int exact_fp32, eat_stream_t stream) {
   eat::clear_stale_error();
   return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream);
+}
+
+// The same with a zero-filled workspace ws of n_slots * Co * Ci floats: the streaming kernel of the small matrices spreads
+// its atomics over the slots (same-address atomics serialise in L2) and a second kernel adds the slots into dW.
+// Matrices that do not run on that kernel ignore ws.
+extern "C" int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float* x_scale, float* dW, float* ws,
+                                    int n_slots, int B, int Co, int Ci, int S, int exact_fp32, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream, ws, n_slots);
 }
 
 extern "C" int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,

@@ -314,6 +314,12 @@ def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
     dW = zero_arena.zeros((Co, Ci), torch.float32, dz.device)
+    if Co <= 64 and Ci <= 64 and S % 4 == 0 and mode != 1:
+        # small matrices, long reductions: the streaming kernel spreads its atomics over 8 copies of dW (csrc/train.hip)
+        ws = zero_arena.zeros((8, Co, Ci), torch.float32, dz.device)
+        _lib.call("eat_pw_conv_wgrad_ws", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(),
+                  ws.data_ptr(), 8, B, Co, Ci, S, mode, _stream())
+        return dW
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
               S, mode, _stream())
     return dW

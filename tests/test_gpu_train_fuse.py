@@ -31,7 +31,7 @@ def _rel(got, ref):
 GEOMS = [(3, 64, 64, 500, 3, 2, 1), (2, 16, 64, 500, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1), (2, 24, 32, 250, 3, 1, 1),
          (5, 120, 16, 125, 5, 1, 2), (3, 240, 16, 125, 3, 2, 2), (4, 200, 8, 63, 3, 1, 2), (3, 672, 8, 63, 5, 2, 2),
          (5, 96, 4, 32, 5, 1, 2), (2, 40, 9, 21, 3, 1, 1), (3, 9, 33, 71, 3, 2, 2), (2, 8, 64, 200, 5, 1, 1),
-         (1, 3, 1, 2, 3, 2, 0), (70, 24, 8, 63, 3, 1, 2)]
+         (2, 3, 1, 2, 3, 2, 0), (70, 24, 8, 63, 3, 1, 2)]
 
 
 @pytest.mark.parametrize("B,C,F_,T,k,s,act", GEOMS)

@@ -9,7 +9,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has unit; then
-  timeout 600 python -m pytest tests/test_gpu_train_fuse.py -q -x 2>&1 | tail -30 > $OUT/unit.log; tail -15 $OUT/unit.log
+  timeout 600 python -m pytest tests/test_gpu_train_fuse.py -q 2>&1 | tail -60 > $OUT/unit.log; tail -25 $OUT/unit.log
+fi
+if has diag; then
+  timeout 300 python tools/diag_train_v.py tiny 2>&1 | grep -v amdgpu.ids | tee $OUT/diag_tiny.log
+  timeout 300 python tools/diag_train_v.py full 2>&1 | grep -v amdgpu.ids | tee $OUT/diag_full.log
+  EAT_DW_STATS_FUSED=0 EAT_DW_GEPI_FUSED=0 timeout 300 python tools/diag_train_v.py tiny 2>&1 | grep -v amdgpu.ids | tee $OUT/diag_tiny_unfused.log
 fi
 if has train; then
   timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_configs.py tests/test_gpu_trainloop.py -q 2>&1 | tail -40 > $OUT/train.log; tail -25 $OUT/train.log
@@ -24,10 +29,10 @@ if has prof; then
 fi
 if has bench; then
   for v in 1 2; do
-    EAT_TRAIN_V=$v timeout 300 python bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs --steps 5 --warmup 2 > $OUT/bench_v$v.json 2> $OUT/bench_v$v.err
+    EAT_TRAIN_V=$v timeout 300 python bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs --no-profile --steps 10 --warmup 3 > $OUT/bench_v$v.json 2> $OUT/bench_v$v.err
     python - <<P
 import json
-d=json.load(open("$OUT/bench_v$v.json")); print("V$v fwd", d["value"], "train", d.get("train_step"))
+d=json.load(open("$OUT/bench_v$v.json")); print("V$v train", d["value"], d["ms_per_step"], "fwd", d.get("forward", {}).get("value"))
 P
   done
 fi
