@@ -72,6 +72,8 @@ SIGNATURES = {
     "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P],
     "eat_act_grad_sum": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "eat_dw_conv_dgrad_g": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P] + [_I] * 8 + [_P],
+    "eat_se_bn_bwd_partials": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_se_bn_bwd_combine": [_P, _P, _P, _P, _I, _I, _P, _P],
     "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_P],
 }
 

@@ -108,6 +108,78 @@ __global__ __launch_bounds__(256) void act_grad_sum_kernel(const float* __restri
   }
 }
 
+// ---- squeeze-excitation blocks: ONE pass over (d, z) for both the gate gradient and the BatchNorm-backward sums -----
+// Forward: y = act(a z + b), xs = y * s[b,c] (models/mn/block_types.py:72-83).  Backward with d = d(xs):
+//   d s[b,c] = sum_s d y                      -> through the gate MLP -> gadd[b,c] (the squeeze mean's gradient)
+//   g = (d * s + gadd) * act'(u),  BatchNorm backward needs sum g and sum g (z - mu) per channel.
+// gadd depends on d s, so round 2 read (d, z) twice (plane_dot, then the reduce pass).  s and gadd are per-PLANE constants:
+//   sum g = s * P1 + gadd * P2,   sum g (z - mu) = s * P3 + gadd * P4
+// with P0 = sum d y, P1 = sum d act', P2 = sum act', P3 = sum d act' (z - mu), P4 = sum act' (z - mu) per plane - all
+// five taken here in one pass; se_bn_bwd_combine_kernel finishes per channel once the gate gradients are known.
+template <int ACT>
+__global__ __launch_bounds__(256) void se_bn_bwd_partials_kernel(const float* __restrict__ d, const float* __restrict__ z,
+                                                                 const float* __restrict__ a, const float* __restrict__ b,
+                                                                 const float* __restrict__ mean, float* __restrict__ P,
+                                                                 int C, int S, int n_planes) {
+  __shared__ float s_red[5][4];
+  const int plane = blockIdx.x, c = plane % C;
+  const float av = a[c], bv = b[c], mu = mean[c];
+  const size_t base = (size_t)plane * S;
+  float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  auto acc1 = [&](float dv, float zv) {
+    const float u = fmaf(av, zv, bv);
+    const float da = act_deriv(u, ACT), y = eat::activate<ACT>(u), zc = zv - mu;
+    p[0] = fmaf(dv, y, p[0]);
+    p[1] = fmaf(dv, da, p[1]);
+    p[2] += da;
+    p[3] = fmaf(dv * da, zc, p[3]);
+    p[4] = fmaf(da, zc, p[4]);
+  };
+  if ((S & 3) == 0) {
+#pragma unroll 2
+    for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
+      const float4 dv = *reinterpret_cast<const float4*>(d + base + i);
+      const float4 zv = *reinterpret_cast<const float4*>(z + base + i);
+      acc1(dv.x, zv.x); acc1(dv.y, zv.y); acc1(dv.z, zv.z); acc1(dv.w, zv.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) acc1(d[base + i], z[base + i]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const float t = eat::wave_sum(p[q]);
+    if (lane == 0) s_red[q][wv] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += s_red[threadIdx.x][i];
+    P[(size_t)threadIdx.x * n_planes + plane] = t;
+  }
+}
+
+// sums[c] = sum_b (s P1 + gadd P2), sums[C + c] = invstd[c] * sum_b (s P3 + gadd P4)   (fp64, one block per channel)
+__global__ __launch_bounds__(64) void se_bn_bwd_combine_kernel(const float* __restrict__ P, const float* __restrict__ gs,
+                                                               const float* __restrict__ ga,
+                                                               const float* __restrict__ invstd, int B, int C,
+                                                               double* __restrict__ sums) {
+  const int c = blockIdx.x;
+  const size_t np = (size_t)B * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int bb = threadIdx.x; bb < B; bb += 64) {
+    const size_t pl = (size_t)bb * C + c;
+    const double s = (double)gs[pl], g = (double)ga[pl];
+    s1 += s * (double)P[1 * np + pl] + g * (double)P[2 * np + pl];
+    s2 += s * (double)P[3 * np + pl] + g * (double)P[4 * np + pl];
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if (threadIdx.x == 0) {
+    sums[c] = s1;
+    sums[C + c] = s2 * (double)invstd[c];
+  }
+}
+
 // ---- BatchNorm finalize from partials [outer][2][C][inner]: one block per channel ------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
     const float* __restrict__ part, int outer, int C, int inner, const float* __restrict__ gamma,
@@ -241,6 +313,26 @@ extern "C" int eat_act_grad_sum(const float* dy, const float* z, const float* a,
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_act_grad_sum: bad act %d", act);
   if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_act_grad_sum: bad shape");
   return eat::act_grad_sum(dy, z, a, b, act, g, gpart, B, C, S, (hipStream_t)stream);
+}
+
+extern "C" int eat_se_bn_bwd_partials(const float* d, const float* z, const float* a, const float* b, const float* mean,
+                                      float* P, int B, int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad act %d", act);
+  if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad shape");
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_kernel<ACT>), dim3((unsigned)(B * C)), blk, 0,
+                                           (hipStream_t)stream, d, z, a, b, mean, P, C, S, B * C));
+  return eat::check_launch("eat_se_bn_bwd_partials");
+}
+
+extern "C" int eat_se_bn_bwd_combine(const float* P, const float* gscale, const float* gadd, const float* invstd, int B,
+                                     int C, double* sums, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_combine: bad shape");
+  hipLaunchKernelGGL(se_bn_bwd_combine_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, P, gscale, gadd, invstd,
+                     B, C, sums);
+  return eat::check_launch("eat_se_bn_bwd_combine");
 }
 
 extern "C" int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, const float* gamma,

@@ -217,12 +217,18 @@ class MNTrainFunction(torch.autograd.Function):
             wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
             dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
             del dz_p
-            gscale = gadd = None
+            gscale = gadd = se_P = None
             if scale is not None:     # squeeze-excitation gate (mn/block_types.py:72-83)
                 se = blk.block[blk.i_se].conc_se_layers[0]
                 sp = f"{pre}.{blk.i_se}.conc_se_layers.0"
                 h, pool, S_d = rec["h"], rec["pool"], rec["S_d"]
-                ds = ops.plane_dot(dxs, rec["y_d"])
+                if v2 and _FUSE_SE_BWD:
+                    # one pass over (dxs, z_d) for the gate gradient AND the BatchNorm-backward plane sums
+                    st_d = rec["st_d"]
+                    se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
+                    ds = se_P[0]
+                else:
+                    ds = ops.plane_dot(dxs, rec["y_d"])
                 dq = ds * scale * (1.0 - scale)
                 g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
                 g[sp + ".fc2.bias"] = dq.sum(0)
@@ -235,7 +241,10 @@ class MNTrainFunction(torch.autograd.Function):
             # depthwise conv + BN + act
             cna = blk.block[blk.i_dw]
             k = cnf.kernel
-            dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd)
+            if se_P is not None:
+                dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd)
+            else:
+                dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd)
             del dxs
             g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
             y_e = rec["y_e"]
@@ -309,6 +318,7 @@ class MNTrainFunction(torch.autograd.Function):
 #   * depthwise conv: sum / sum of squares of its output leave the conv kernel's epilogue as per-wave partials.
 # Expanded-resolution passes per block: forward 3 -> 2, backward 9 -> 5.
 _TRAIN_V = int(os.environ.get("EAT_TRAIN_V", "2"))
+_FUSE_SE_BWD = os.environ.get("EAT_FUSE_SE_BWD", "1") == "1"     # A/B: gate gradient + BN-backward sums in one pass
 
 
 class MNTrainFunction2(torch.autograd.Function):

@@ -266,6 +266,33 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=No
     return dz, sf[C:], sf[:C]
 
 
+def se_bn_bwd_partials(d, z, a, b, mean, act):
+    """One pass over (d, z) of a squeeze-excitation block -> P (5, B, C): P[0] = d s (the gate gradient, = plane_dot of d
+    with act(a z + b)), P[1..4] the plane sums `bn_act_bwd_se` combines once gadd is known (csrc/train_fuse.hip)."""
+    B, C = z.shape[0], z.shape[1]
+    P = torch.empty((5, B, C), device=z.device, dtype=torch.float32)
+    _lib.call("eat_se_bn_bwd_partials", _dev(d, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+              P.data_ptr(), B, C, z.numel() // (B * C), act, _stream())
+    return P
+
+
+def bn_act_bwd_se(dy, z, a, b, mean, invstd, act, P, gscale, gadd):
+    """bn_act_bwd for a squeeze-excitation block whose plane sums P were taken by `se_bn_bwd_partials`: no reduce pass."""
+    B, C = z.shape[0], z.shape[1]
+    S = z.numel() // (B * C)
+    sums = torch.empty((2 * C,), device=z.device, dtype=torch.float64)
+    _lib.call("eat_se_bn_bwd_combine", P.data_ptr(), _dev(gscale, "gscale"), _dev(gadd, "gadd"), invstd.data_ptr(), B, C,
+              sums.data_ptr(), _stream())
+    frozen = getattr(mean, "_eat_frozen", False)
+    dz = torch.empty_like(z)
+    asums = torch.zeros_like(sums) if frozen else sums
+    _lib.call("eat_bn_act_bwd_apply", _dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+              invstd.data_ptr(), gscale.data_ptr(), gadd.data_ptr(), asums.data_ptr(), dz.data_ptr(), B, C, S, act,
+              _stream())
+    sf = sums.float()
+    return dz, sf[C:], sf[:C]
+
+
 def plane_dot(u, v, a=None, b=None, act=ACT_NONE):
     B, C = u.shape[0], u.shape[1]
     S = u.numel() // (B * C)

@@ -188,6 +188,19 @@ int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int C
 int eat_act_grad_sum(const float* dy, const float* z, const float* a, const float* b, int act, float* g, float* gpart,
                      int B, int C, int S, eat_stream_t stream);
 
+/* Squeeze-excitation blocks (models/mn/block_types.py:72-83 between the depthwise BN + act and the project conv): one
+ * pass over d = d(x * s) and the pre-BN z for BOTH the gate gradient and the BatchNorm-backward sums.  P (5, B*C):
+ * P0 = sum_s d y (= d s, what eat_plane_dot(d, z, a, b) returns), P1 = sum d act', P2 = sum act',
+ * P3 = sum d act' (z - mean), P4 = sum act' (z - mean), with y = act(a z + b), act' at a z + b. */
+int eat_se_bn_bwd_partials(const float* d, const float* z, const float* a, const float* b, const float* mean, float* P,
+                           int B, int C, int S, int act, eat_stream_t stream);
+
+/* ... and, once the gate MLP's backward has produced gadd (B,C) (gscale = the gate s): the per-channel sums that
+ * eat_bn_act_bwd_apply takes, sums[c] = sum_b (s P1 + gadd P2), sums[C+c] = invstd[c] sum_b (s P3 + gadd P4) -
+ * i.e. eat_bn_act_bwd_reduce(d, z, ..., gscale, gadd) without reading d and z again. */
+int eat_se_bn_bwd_combine(const float* P, const float* gscale, const float* gadd, const float* invstd, int B, int C,
+                          double* sums, eat_stream_t stream);
+
 /* Depthwise data gradient (autograd of block_types.py:150-162) whose epilogue starts the backward of the expand conv's
  * BatchNorm + activation: g = dgrad(dz) * act'(ga[c] gz + gb[c]), gz = pre-BN output of the expand conv (B,C,F,T);
  * gpart [B][C][inner] = per-wave sums of g; *h_inner receives inner <= inner_cap. */

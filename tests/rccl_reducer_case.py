@@ -62,9 +62,16 @@ def main():
     enable_data_parallel(dp, bucket_bytes=64 << 10, force_buckets=True)
     assert dp._grad_reducer.bucketed and dp._grad_reducer.world == 1
     F.binary_cross_entropy_with_logits(dp(x)[0], y).backward()
-    worst = max(float((p.grad - q.grad).abs().max()) / (float(q.grad.abs().max()) + 1e-12)
-                for p, q in zip(dp.parameters(), ref.parameters()))
-    assert worst < 1e-5, worst           # atomics in the weight-gradient kernels: not bit-identical between runs
+    # per tensor, relative to max(|tensor|, 1e-3 * the largest gradient of the network): the project-BN biases have a TRUE
+    # gradient of exactly zero (a per-channel shift in front of a train-mode BatchNorm cancels), what is computed for them
+    # is round-off of the weight-gradient atomics and differs from run to run
+    gmax = max(float(q.grad.abs().max()) for q in ref.parameters())
+
+    def worst_of(model):
+        return max(float((p.grad - q.grad).abs().max()) / max(float(q.grad.abs().max()), 1e-3 * gmax)
+                   for p, q in zip(model.parameters(), ref.parameters()))
+    worst = worst_of(dp)
+    assert worst < 1e-4, worst           # atomics in the weight-gradient / Gram-matrix kernels: not bit-identical between runs
     # the same step captured into a hipGraph with the collectives inside
     g = make()
     g.load_state_dict(ref.state_dict())
@@ -74,9 +81,8 @@ def main():
     loss = step(x, y)
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
-    worst = max(float((p.grad - q.grad).abs().max()) / (float(q.grad.abs().max()) + 1e-12)
-                for p, q in zip(g.parameters(), ref.parameters()))
-    assert worst < 1e-5, worst
+    worst = worst_of(g)
+    assert worst < 1e-4, worst
     print("RCCL_REDUCER_OK", flush=True)
     torch.cuda.synchronize()
     dist.destroy_process_group()

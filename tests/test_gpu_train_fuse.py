@@ -151,3 +151,32 @@ def test_expand_conv_bn_act_via_gram_matrix(B, Ci, Co, F_, T, act, exact):
     gd = g.cpu().double()
     assert _rel(dWf, torch.einsum("bcft,bkft->ck", gd * a.cpu().double()[None, :, None, None], x.double())) < tol
     assert _rel(dbf, gd.sum((0, 2, 3))) < tol
+
+
+@pytest.mark.parametrize("B,C,F_,T,act", [(4, 72, 16, 125, 1), (5, 120, 16, 125, 1), (6, 480, 8, 63, 2), (70, 96, 4, 32, 2),
+                                         (3, 24, 9, 21, 2)])
+def test_se_block_bn_backward_in_one_pass(B, C, F_, T, act):
+    """Gate gradient + BatchNorm-backward sums of a squeeze-excitation block from ONE pass over (d, z):
+    against the two-pass composition (eat_plane_dot, eat_bn_act_bwd_reduce + apply) and torch autograd."""
+    z = _rand(B, C, F_, T, seed=1, scale=2.0) + _rand(1, C, 1, 1, seed=2)
+    gamma, beta = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5, _rand(C, seed=4, scale=0.3)
+    d = _rand(B, C, F_, T, seed=6)
+    gs = torch.rand(B, C, generator=torch.Generator().manual_seed(7)) + 0.5
+    ga = _rand(B, C, seed=8, scale=0.1)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    zd, dd = z.to(DEV), d.to(DEV)
+    a, b, mean, invstd = ops.bn_finalize(ops.bn_stats(zd), bn, B * F_ * T)
+    P = ops.se_bn_bwd_partials(dd, zd, a, b, mean, act)
+    y = ops.bn_act_fwd(zd, a, b, act)
+    assert _rel(P[0], ops.plane_dot(dd, y)) < 1e-5
+    dz_ref, dg_ref, db_ref = ops.bn_act_bwd(dd, zd, a, b, mean, invstd, act, gscale=gs.to(DEV), gadd=ga.to(DEV))
+    dz, dg, db = ops.bn_act_bwd_se(dd, zd, a, b, mean, invstd, act, P, gs.to(DEV), ga.to(DEV))
+    assert _rel(dz, dz_ref) < 1e-5 and _rel(dg, dg_ref) < 1e-5 and _rel(db, db_ref) < 1e-5
+    # and against autograd (fp64)
+    zr = z.double().requires_grad_(True)
+    y_ref = ACTS[act](F.batch_norm(zr, None, None, gamma.double(), beta.double(), True, 0.0, 1e-3))
+    (y_ref * (d.double() * gs.double()[:, :, None, None] + ga.double()[:, :, None, None])).sum().backward()
+    assert _rel(dz, zr.grad) < 5e-5
