@@ -63,6 +63,8 @@ SIGNATURES = {
     "eat_dw_conv_dilated_fwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "eat_kd_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P],
     "eat_pw_conv_wgrad_ws": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "eat_pw_conv_tf_fwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eat_pw_conv_wgrad_tf": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_pw_prepack_t": [_P, _P, _P, _I, _I, _P],
     "eat_pw_prepack_bf16_t": [_P, _P, _P, _I, _I, _I, _P],
     "eat_dw_partials_inner": [_I] * 7,

@@ -85,12 +85,16 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // PIPE = false: generic fallback (any kc, any NS): 2 stages, vmcnt(0) + __syncthreads per chunk.
 constexpr int kPipeKC = 16;
 
-template <int MTW, bool PIPE>
+// TF: the conv input is act_in(tf.a[k] * x + tf.b[k]) evaluated between the LDS read and the MFMA (training: BatchNorm +
+// activation of the depthwise conv fused into the project conv; see conv_pw_bf16.hip)
+struct PwTf { const float* a; const float* b; int act; };
+
+template <int MTW, bool PIPE, bool TF>
 __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int kc_arg,
-    int n_stages, int act, int tps, long long wp_bstride) {
+    int n_stages, int act, int tps, long long wp_bstride, PwTf tf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int kc = PIPE ? kPipeKC : kc_arg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -215,6 +219,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     // MFMAs of k-step ks issue
     float4 xv = *reinterpret_cast<const float4*>(Xw);
     float sv = in_scale ? SCs[0] : 1.0f;
+    float tav = TF ? tf.a[k0 + kq] : 1.0f, tbv = TF ? tf.b[k0 + kq] : 0.0f;     // this lane's row k = k0 + 4 ks + kq
+    const eat::ActCoef tac = eat::act_coef(TF ? tf.act : 0);
     float a[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) a[i] = Aw[i * 64];
@@ -222,9 +228,14 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
       const int kn = (ks + 1 < ksteps) ? ks + 1 : ks;
       const float4 xn = *reinterpret_cast<const float4*>(Xw + kn * 4 * kTileN);
       const float sn = in_scale ? SCs[kn * 4 * NS] : 1.0f;
+      const float tan_ = TF ? tf.a[k0 + 4 * kn + kq] : 1.0f, tbn_ = TF ? tf.b[k0 + 4 * kn + kq] : 0.0f;
       float an[MTW];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) an[i] = Aw[(kn * MTW + i) * 64];
+      if constexpr (TF) {
+        xv.x = eat::act_apply(fmaf(tav, xv.x, tbv), tac); xv.y = eat::act_apply(fmaf(tav, xv.y, tbv), tac);
+        xv.z = eat::act_apply(fmaf(tav, xv.z, tbv), tac); xv.w = eat::act_apply(fmaf(tav, xv.w, tbv), tac);
+      }
       const float b0 = xv.x * sv, b1 = xv.y * sv, b2 = xv.z * sv, b3 = xv.w * sv;
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
         acc[i][2] = mfma16(a[i], b2, acc[i][2]);
         acc[i][3] = mfma16(a[i], b3, acc[i][3]);
       }
-      xv = xn; sv = sn;
+      xv = xn; sv = sn; tav = tan_; tbv = tbn_;
 #pragma unroll
       for (int i = 0; i < MTW; ++i) a[i] = an[i];
     }
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 template <int MTW>
 int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias, const float* in_scale,
               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act,
-              bool per_sample) {
+              bool per_sample, PwTf tf) {
   const long long N = (long long)B * S;
   const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
   const int n_tiles = per_sample ? B * tps : (int)((N + kTileN - 1) / kTileN);
@@ -339,14 +350,15 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
     smem = (size_t)n_stages * stage_floats(MTW, kc, NS) * sizeof(float);
   }
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: LDS stage too large (%zu B)", smem);
-  auto kern = pipe ? pw_conv_kernel<MTW, true> : pw_conv_kernel<MTW, false>;
+  auto kern = tf.a ? (pipe ? pw_conv_kernel<MTW, true, true> : pw_conv_kernel<MTW, false, true>)
+                   : (pipe ? pw_conv_kernel<MTW, true, false> : pw_conv_kernel<MTW, false, false>);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_pw_conv_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
-                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride);
+                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf);
   return eat::check_launch("eat_pw_conv_fwd");
 }
 
@@ -374,19 +386,22 @@ extern "C" int eat_pw_prepack_t(const float* w_t, const float* row_scale, float*
 }
 
 static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,
-                       float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s) {
+                       float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s,
+                       PwTf tf = PwTf{nullptr, nullptr, 0}) {
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d must be a multiple of 4", Ci);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
   if (B < 1 || Ci < 4 || Co < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
   const int MT = (Co + 15) / 16;
-  if (S % 4 != 0)      // planes that do not start on 16-byte boundaries (e.g. 40-mel models): plain 4-byte kernel
+  if (S % 4 != 0) {    // planes that do not start on 16-byte boundaries (e.g. 40-mel models): plain 4-byte kernel
+    if (tf.a) return eat::fail(EAT_EINVAL, "eat_pw_conv_tf_fwd: S=%d must be a multiple of 4", S);
     return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, 0,
                                 per_sample ? (long long)(Ci / 4) * MT * 64 * (long long)sizeof(float) : 0, s);
+  }
   // Row chunking.  Every block re-reads its 256-column x tile, and a CU takes in only ~10 B/clk, so
   // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks
   const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block
-#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample);
+#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf);
   switch (mtw) {
     EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4) EAT_PW_CASE(5)
     EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
@@ -400,6 +415,24 @@ extern "C" int eat_pw_conv_fwd(const float* x, const float* wp, const float* bia
                                eat_stream_t stream) {
   eat::clear_stale_error();
   return pw_dispatch(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, false, (hipStream_t)stream);
+}
+
+// Train-mode project conv (models/mn/block_types.py:167-171 after :150-162): the conv input is
+// act_in(tf_a[k] x + tf_b[k]) [* in_scale[b,k]] evaluated on load - BatchNorm + activation (+ SE scale) of the depthwise
+// output are never materialised.  wmode: 0 = fp32 pack (eat_pw_prepack), 1 = bf16 pack, 2 = bf16 hi/lo pack.
+extern "C" int eat_pw_conv_tf_fwd(const float* x, const float* tf_a, const float* tf_b, int tf_act, const void* wp,
+                                  int wmode, const float* bias, const float* in_scale, const float* res, float* y, int B,
+                                  int Ci, int Co, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!tf_a || !tf_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_tf_fwd: tf_a and tf_b are required");
+  if (tf_act < 0 || tf_act > 2 || act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_tf_fwd: bad activation code");
+  if (Ci % 8 != 0 || S % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_tf_fwd: needs Ci %% 8 == 0 and S %% 4 == 0 (Ci=%d, S=%d)", Ci, S);
+  if (B < 1 || Co < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_tf_fwd: bad shape");
+  if (wmode == 0)
+    return pw_dispatch(x, reinterpret_cast<const float*>(wp), bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, false,
+                       (hipStream_t)stream, PwTf{tf_a, tf_b, tf_act});
+  return eat::pw_conv_bf16_tf(x, tf_a, tf_b, tf_act, wp, bias, in_scale, res, y, B, Ci, Co, S, act, wmode == 2 ? 1 : 0,
+                              (hipStream_t)stream);
 }
 
 extern "C" int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, const float* res, float* y,

@@ -59,12 +59,17 @@ __global__ void pw_prepack_bf16_kernel(const float* __restrict__ w, const float*
   }
 }
 
-template <int MTW, int NPROD, int NSTG>
+// TF: the conv input is act_in(tf_a[k] * x + tf_b[k]) evaluated on the way from LDS to the MFMA operand (training: the
+// BatchNorm + activation of the depthwise conv fused into the project conv - the activated tensor is never written;
+// models/mn/block_types.py:150-171 under model.train()); the SE scale (in_scale) multiplies the transformed value.
+struct PwTf { const float* a; const float* b; int act; };
+
+template <int MTW, int NPROD, int NSTG, bool TF>
 __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
-    int sc_bytes, int ci_x) {
+    int sc_bytes, int ci_x, PwTf tf) {
   // ci_x: channels of x.  ci_x == Ci: plain 1x1 conv.  ci_x < Ci ("K-concat", DyMN): the reduction axis is nbank
   // copies of x's channels, k = bank * ci_x + ci - the weights are the banks side by side, the per-(sample, k) input
   // scale carries the attention (host: ci_x % 32 == 0, so a 32-row chunk never straddles two banks)
@@ -146,6 +151,23 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     float4 xr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4*>(Xw + i * kTileN);
+    if constexpr (TF) {
+      // rows kb .. kb+7 of this lane (host: Ci % 8 == 0, so an octet is inside or outside as a whole; rows beyond Ci
+      // meet zero weights: coefficient 0 keeps them finite)
+      const int kb = c * kKC + 8 * kq;
+      const bool in = kb < Ci;
+      const float4 a0 = *reinterpret_cast<const float4*>(tf.a + (in ? kb : 0)), a1 = *reinterpret_cast<const float4*>(tf.a + (in ? kb : 0) + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(tf.b + (in ? kb : 0)), b1 = *reinterpret_cast<const float4*>(tf.b + (in ? kb : 0) + 4);
+      const float ta[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float tb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const eat::ActCoef ac = eat::act_coef(tf.act);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float av = in ? ta[i] : 0.0f, bv = in ? tb[i] : 0.0f;
+        xr[i].x = eat::act_apply(fmaf(av, xr[i].x, bv), ac); xr[i].y = eat::act_apply(fmaf(av, xr[i].y, bv), ac);
+        xr[i].z = eat::act_apply(fmaf(av, xr[i].z, bv), ac); xr[i].w = eat::act_apply(fmaf(av, xr[i].w, bv), ac);
+      }
+    }
     if (in_scale) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 
 template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x) {
+           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf) {
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
   const int n_tiles = (int)((N + kTileN - 1) / kTileN);
@@ -214,7 +236,8 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   const int n_blocks = ((n_tiles + 7) / 8 * 8) * MC;
   const int n_stages = forced ? forced : ((2 * stage <= 78 * 1024 || n_blocks < 2 * 256) ? 2 : 1);
   const size_t smem = n_stages * stage;
-  auto kern = n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2> : pw_conv_bf16_kernel<MTW, NPROD, 1>;
+  auto kern = tf.a ? (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, true> : pw_conv_bf16_kernel<MTW, NPROD, 1, true>)
+                   : (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, false> : pw_conv_bf16_kernel<MTW, NPROD, 1, false>);
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: LDS stage too large (%zu B; planes of %d positions)", smem, S);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -222,19 +245,19 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act, sc_bytes, ci_x);
+                     n_tiles, NS, act, sc_bytes, ci_x, tf);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
 template <int NPROD>
 int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-             float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x) {
+             float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0}) {
   const int MT = (Co + 15) / 16;
   // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
   // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x);
+#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -282,6 +305,18 @@ extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float*
   return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci)
                : dispatch<1>(s, x, w16, bias, in_scale, res, y, pool, B, Ci, Co, S, act, Ci);
 }
+
+// 1x1 conv whose input is act_in(tf_a[k] x + tf_b[k]) [* in_scale[b,k]] evaluated on load (see PwTf above)
+namespace eat {
+int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf_act, const void* wp, const float* bias,
+                    const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S, int act, int split,
+                    hipStream_t s) {
+  const PwTf tf{tf_a, tf_b, tf_act};
+  const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
+  return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, Ci, tf)
+               : dispatch<1>(s, x, w16, bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, Ci, tf);
+}
+}  // namespace eat
 
 // DyMN dynamic 1x1 conv WITHOUT per-sample weights (models/dymn/dy_block.py:103-131):
 //   z_b = (sum_k att[b,k] W_k) x_b = [W_0 | ... | W_{K-1}] [att[b,0] x_b ; ... ; att[b,K-1] x_b]

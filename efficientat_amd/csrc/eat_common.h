@@ -71,6 +71,11 @@ int pw_conv_generic(const float* x, const void* wp, const float* bias, const flo
                     float* pool, int B, int Ci, int Co, int S, int act, int wmode, long long wp_bstride_bytes,
                     hipStream_t s);
 
+// conv_pw_bf16.hip: 1x1 conv on the bf16 packs whose input is act_in(tf_a[k] x + tf_b[k]) evaluated on load
+int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf_act, const void* wp, const float* bias,
+                    const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S, int act, int split,
+                    hipStream_t s);
+
 // conv_pw_stream.hip: barrier-free bf16 1x1 kernels (x or the output tile resident in registers); returns 1 when the
 // shape / the EAT_PW_STREAM switch leaves the layer to conv_pw_bf16.hip
 int pw_stream_try(const float* x, const void* wp, const float* bias, const float* in_scale, const float* res, float* y,

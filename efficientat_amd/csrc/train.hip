@@ -14,6 +14,11 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Optional transform of the x operand of the 1x1 weight gradient: x' = act(a[ci] * x + b[ci]) evaluated on load (training:
+// the project conv read BN + act of the depthwise output on load, so the activated tensor does not exist; mn_train.py)
+struct WgTf { const float* a; const float* b; int act; };
+__device__ __forceinline__ float wg_tf(float v, float a, float b, int act) { return eat::activate_rt(fmaf(a, v, b), act); }
+
 template <int ACT>
 __device__ __forceinline__ float act_grad(float u) {   // d act(u) / du  (PyTorch conventions)
   if constexpr (ACT == EAT_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
@@ -495,7 +500,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_col_kernel(const float* __restri
 // added to dW with one atomic per element per block.
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                        const float* __restrict__ xscale, float* __restrict__ dW,
-                                                       int B, int Co, int Ci, int S, int b_per_block, int per_sample) {
+                                                       int B, int Co, int Ci, int S, int b_per_block, int per_sample,
+                                                       WgTf tf) {
   __shared__ float s_red[3][4][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -520,6 +526,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) if (s + e < S) o[e] = p[e];
     }
   };
+  // x operand transform (zero padding applies to the transformed values: only loaded elements are transformed)
+  const float ta0 = (tf.a && n0 + row < Ci) ? tf.a[n0 + row] : 1.0f, tb0 = (tf.a && n0 + row < Ci) ? tf.b[n0 + row] : 0.0f;
+  const float ta1 = (tf.a && n0 + 16 + row < Ci) ? tf.a[n0 + 16 + row] : 1.0f, tb1 = (tf.a && n0 + 16 + row < Ci) ? tf.b[n0 + 16 + row] : 0.0f;
+  auto tf4 = [&](float (&o)[4], int r, int s, float ta, float tb) {
+    if (!tf.a || r >= Ci) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (s + e < S) o[e] = wg_tf(o[e], ta, tb, tf.act);
+  };
   for (int bb = b0; bb < b1; ++bb) {
     const float* gz = dz + (size_t)bb * Co * S;
     const float* gx = x + (size_t)bb * Ci * S;
@@ -535,6 +549,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
         load4(gz, m0 + 16 + row, Co, S, s, ga[u][1]);
         load4(gx, n0 + row, Ci, S, s, xb[u][0]);
         load4(gx, n0 + 16 + row, Ci, S, s, xb[u][1]);
+        tf4(xb[u][0], n0 + row, s, ta0, tb0);
+        tf4(xb[u][1], n0 + 16 + row, s, ta1, tb1);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -612,7 +628,7 @@ template <int NPROD>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                              const float* __restrict__ xscale, float* __restrict__ dW,
                                                              int B, int Co, int Ci, int S, int sps, int units_per_block,
-                                                             int per_sample) {
+                                                             int per_sample, WgTf tf) {
   // stage = [A: 128 rows x 128 B][B: 128 rows x 128 B] = 32 KB; 2 stages
   __shared__ __attribute__((aligned(16))) float s_op[2][2][128 * 32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -660,6 +676,15 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 
   int b = u0 / sps, st = u0 - b * sps;
   float sc[4] = {1.f, 1.f, 1.f, 1.f};
+  float tfa[4] = {1.f, 1.f, 1.f, 1.f}, tfb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tf.a) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = nb + nw + 16 * j + r;
+      tfa[j] = row < Ci ? tf.a[row] : 0.0f;
+      tfb[j] = row < Ci ? tf.b[row] : 0.0f;
+    }
+  }
   int b_sc = -1;
   issue(b, st, 0);
   int stage = 0;
@@ -680,10 +705,15 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
       // fragment of (row, kg): global chunks 2kg and 2kg+1 of that row, stored at the swizzled slots
       const int s_lo = st * 32 + 8 * kg;
       const bool k0 = s_lo < S, k1 = s_lo + 4 < S;
-      auto frag = [&](const float* tile, int row_in_tile, bool row_ok, float scale, bf16x8_t& hi, bf16x8_t& lo) {
+      auto frag = [&](const float* tile, int row_in_tile, bool row_ok, float scale, bf16x8_t& hi, bf16x8_t& lo,
+                      bool xf = false, float fa = 1.0f, float fb = 0.0f) {
         const int sw = (row_in_tile >> 1) & 7;
-        const float4 t0 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg) ^ sw));
-        const float4 t1 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg + 1) ^ sw));
+        float4 t0 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg) ^ sw));
+        float4 t1 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg + 1) ^ sw));
+        if (xf) {                                                  // block-uniform
+          t0.x = wg_tf(t0.x, fa, fb, tf.act); t0.y = wg_tf(t0.y, fa, fb, tf.act); t0.z = wg_tf(t0.z, fa, fb, tf.act); t0.w = wg_tf(t0.w, fa, fb, tf.act);
+          t1.x = wg_tf(t1.x, fa, fb, tf.act); t1.y = wg_tf(t1.y, fa, fb, tf.act); t1.z = wg_tf(t1.z, fa, fb, tf.act); t1.w = wg_tf(t1.w, fa, fb, tf.act);
+        }
         // row_ok also guards LDS rows that were never loaded (select, not multiply: they may hold anything)
         const bool q0 = row_ok && k0, q1 = row_ok && k1;
         const float v[8] = {q0 ? t0.x * scale : 0.0f, q0 ? t0.y * scale : 0.0f, q0 ? t0.z * scale : 0.0f,
@@ -703,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = nw + 16 * j + r;
-        frag(&s_op[stage][same_tile ? 0 : 1][0], row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j]);
+        frag(&s_op[stage][same_tile ? 0 : 1][0], row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j], tf.a != nullptr, tfa[j], tfb[j]);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -753,7 +783,7 @@ template <int MTN, int NTN, bool SAME>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                     const float* __restrict__ xscale, float* __restrict__ dW,
                                                                     int B, int Co, int Ci, int S, int sps,
-                                                                    int units_per_block, int n_slots) {
+                                                                    int units_per_block, int n_slots, WgTf tf) {
   // the four waves' tiles are combined in LDS (ds_add_f32) before ONE set of global atomics per block, and the blocks
   // are spread over n_slots copies of dW (reduced by wgrad_slot_reduce_kernel): atomics on the same address serialise
   // in L2 at ~40 ns each, which made the 8192 (= 2048 blocks x 4 waves) adds per element the whole cost of this kernel
@@ -771,9 +801,14 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   for (int i = 0; i < MTN; ++i)
 #pragma unroll
     for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float sc[NTN];
+  float sc[NTN], tfa[NTN], tfb[NTN];
 #pragma unroll
-  for (int j = 0; j < NTN; ++j) sc[j] = 1.0f;
+  for (int j = 0; j < NTN; ++j) {
+    sc[j] = 1.0f;
+    const int row = 16 * j + r;
+    tfa[j] = (tf.a && row < Ci) ? tf.a[row] : 1.0f;
+    tfb[j] = (tf.a && row < Ci) ? tf.b[row] : 0.0f;
+  }
   int b_sc = -1;
 
   auto load = [&](int u, float (&av)[MTN][8], float (&bv)[SAME ? 1 : NTN][8]) {
@@ -801,6 +836,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
         const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         bv[j][0] = t0.x; bv[j][1] = t0.y; bv[j][2] = t0.z; bv[j][3] = t0.w;
         bv[j][4] = t1.x; bv[j][5] = t1.y; bv[j][6] = t1.z; bv[j][7] = t1.w;
+        if (tf.a) {                                               // block-uniform; invalid elements stay 0
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[j][e] = (e < 4 ? ok0 : ok1) ? wg_tf(bv[j][e], tfa[j], tfb[j], tf.act) : 0.0f;
+        }
       }
     }
   };
@@ -875,13 +914,13 @@ __global__ void wgrad_slot_reduce_kernel(const float* __restrict__ ws, float* __
 
 template <int MTN, int NTN>
 static void launch_narrow(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s) {
-  if (dz == x && MTN == NTN && !x_scale)
+                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s, WgTf tf) {
+  if (dz == x && MTN == NTN && !x_scale && !tf.a)
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, (MTN == NTN ? NTN : 1), (MTN == NTN)>), dim3(1, 1, nz), dim3(256), 0, s, dz,
-                       x, x_scale, dW, B, Co, Ci, S, sps, upb, n_slots);
+                       x, x_scale, dW, B, Co, Ci, S, sps, upb, n_slots, tf);
   else
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, NTN, false>), dim3(1, 1, nz), dim3(256), 0, s, dz, x, x_scale, dW, B,
-                       Co, Ci, S, sps, upb, n_slots);
+                       Co, Ci, S, sps, upb, n_slots, tf);
 }
 
 }  // namespace
@@ -1102,7 +1141,8 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 }
 
 static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                         int per_sample, int exact_fp32, eat_stream_t stream, float* ws = nullptr, int n_slots = 0) {
+                         int per_sample, int exact_fp32, eat_stream_t stream, float* ws = nullptr, int n_slots = 0,
+                         WgTf tf = WgTf{nullptr, nullptr, 0}) {
   // default: split-operand bf16 MFMA kernel (fp32-class accuracy); exact_fp32 (the caller's precision choice),
   // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
@@ -1125,7 +1165,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
       upb = (int)((total + splits - 1) / splits);
     }
     dim3 grid((Co + 127) / 128, (Ci + 127) / 128, (unsigned)((total + upb - 1) / upb));
-    const bool gram = dz == x && Co == Ci && !x_scale;          // Gram matrix of one tensor (train_fuse.hip): one load per unit
+    const bool gram = dz == x && Co == Ci && !x_scale && !tf.a;   // Gram matrix of one tensor (train_fuse.hip): one load per unit
     if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16 || gram) && !per_sample) {
       // narrow streaming layers: ~2048 single-tile blocks whose 4 waves split the k range
       // ~1024 blocks (4 waves each); with a workspace the blocks' atomics go to n_slots copies of dW
@@ -1137,7 +1177,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
       const bool use_ws = ws != nullptr && n_slots > 1;
       float* target = use_ws ? ws : dW;
       const int slots = use_ws ? n_slots : 1;
-#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, sps, upb, nz, slots, hs)
+#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, sps, upb, nz, slots, hs, tf)
       EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
       EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
       EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // Gram mode only (see `gram`)
@@ -1147,10 +1187,10 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
     } else {
       if (exact_fp32 == 2)
         hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
-                           sps, upb, per_sample);
+                           sps, upb, per_sample, tf);
       else
         hipLaunchKernelGGL(pw_wgrad_x3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
-                           sps, upb, per_sample);
+                           sps, upb, per_sample, tf);
     }
     return eat::check_launch("eat_pw_conv_wgrad");
   }
@@ -1160,7 +1200,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   const int bpb = (B + splits - 1) / splits;
   dim3 grid((Co + 31) / 32, (Ci + 31) / 32, (B + bpb - 1) / bpb);
   hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, bpb,
-                     per_sample);
+                     per_sample, tf);
   return eat::check_launch("eat_pw_conv_wgrad");
 }
 
@@ -1177,6 +1217,17 @@ extern "C" int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float
                                     int n_slots, int B, int Co, int Ci, int S, int exact_fp32, eat_stream_t stream) {
   eat::clear_stale_error();
   return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream, ws, n_slots);
+}
+
+// ... and with the x operand act(tf_a[ci] * x + tf_b[ci]) evaluated on load (x_scale multiplies the transformed value):
+// the weight gradient of a project conv that was run by eat_pw_conv_tf_fwd.  ws / n_slots as above (may be NULL / 0).
+extern "C" int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float* tf_a, const float* tf_b, int tf_act,
+                                    const float* x_scale, float* dW, float* ws, int n_slots, int B, int Co, int Ci, int S,
+                                    int exact_fp32, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!tf_a || !tf_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_tf: tf_a and tf_b are required");
+  if (tf_act < 0 || tf_act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_tf: bad act %d", tf_act);
+  return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream, ws, n_slots, WgTf{tf_a, tf_b, tf_act});
 }
 
 extern "C" int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,

@@ -213,7 +213,12 @@ class MNTrainFunction(torch.autograd.Function):
             dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE)
             g[f"{pre}.{blk.i_proj}.1.weight"], g[f"{pre}.{blk.i_proj}.1.bias"] = dgam, dbet
             scale = rec.get("scale")
-            g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale).view_as(cna[0].weight)
+            if rec["y_d"] is None:         # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
+                st_d = rec["st_d"]
+                g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["z_d"], x_scale=scale,
+                                                                      tf=(st_d[0], st_d[1], act)).view_as(cna[0].weight)
+            else:
+                g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale).view_as(cna[0].weight)
             wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
             dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
             del dz_p
@@ -227,6 +232,9 @@ class MNTrainFunction(torch.autograd.Function):
                     st_d = rec["st_d"]
                     se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
                     ds = se_P[0]
+                elif rec["y_d"] is None:
+                    st_d = rec["st_d"]
+                    ds = ops.plane_dot(dxs, rec["z_d"], st_d[0], st_d[1], act)
                 else:
                     ds = ops.plane_dot(dxs, rec["y_d"])
                 dq = ds * scale * (1.0 - scale)
@@ -319,6 +327,9 @@ class MNTrainFunction(torch.autograd.Function):
 # Expanded-resolution passes per block: forward 3 -> 2, backward 9 -> 5.
 _TRAIN_V = int(os.environ.get("EAT_TRAIN_V", "2"))
 _FUSE_SE_BWD = os.environ.get("EAT_FUSE_SE_BWD", "1") == "1"     # A/B: gate gradient + BN-backward sums in one pass
+# A/B: BatchNorm + activation (+ SE scale) of the depthwise output evaluated on load inside the project conv and its
+# weight gradient - the activated tensor y_d is never written (SE blocks: one read-only pass for the squeeze sums)
+_FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
 
 
 class MNTrainFunction2(torch.autograd.Function):
@@ -380,7 +391,8 @@ class MNTrainFunction2(torch.autograd.Function):
                 st_d = ops.bn_frozen_state(cna_d[1])
             S_d = z_d.shape[2] * z_d.shape[3]
             pool = torch.empty((B, cnf.expanded_channels), device=dev) if blk.i_se is not None else None
-            y_d = ops.bn_act_fwd(z_d, st_d[0], st_d[1], act, pool=pool)
+            on_load = _FUSE_DW_BN and ops.pw_tf_eligible(cnf.expanded_channels, S_d)
+            y_d = ops.bn_act_fwd(z_d, st_d[0], st_d[1], act, pool=pool, write=not on_load) if (pool is not None or not on_load) else None
             rec.update(y_e=None if blk.i_expand is not None else inp, z_d=z_d, st_d=st_d, y_d=y_d)
             scale = None
             if blk.i_se is not None:
@@ -390,7 +402,11 @@ class MNTrainFunction2(torch.autograd.Function):
                 rec.update(pool=pool, h=h, scale=scale, S_d=S_d)
             cna = blk.block[blk.i_proj]
             wp = ops.pw_prepack(cna[0].weight.flatten(1))
-            z_p = ops.pw_conv(y_d, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, in_scale=scale)
+            if on_load:
+                z_p = ops.pw_conv_tf(z_d, (st_d[0], st_d[1], act), wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels,
+                                     NONE, in_scale=scale)
+            else:
+                z_p = ops.pw_conv(y_d, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, in_scale=scale)
             st_p = _conv_bn_stats(z_p, cna[1])
             need_sx = bi + 1 < len(blocks) and blocks[bi + 1].i_expand is not None
             pool_c = torch.empty((B, cnf.out_channels), device=dev) if need_sx else None

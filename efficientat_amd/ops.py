@@ -330,7 +330,23 @@ def dw_conv_wgrad_tf(dz, x, in_a, in_b, in_act, k, stride):
     return dw
 
 
-def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
+def pw_tf_eligible(Ci, S):
+    """Geometry of the on-load BatchNorm + activation of the 1x1 kernels (eat_pw_conv_tf_fwd / eat_pw_conv_wgrad_tf)."""
+    return Ci % 8 == 0 and S % 4 == 0
+
+
+def pw_conv_tf(x, tf, wp, bias, Co, act, in_scale=None, res=None):
+    """1x1 conv of act_in(tf_a[k] x + tf_b[k]) [* in_scale] evaluated on load; tf = (a, b, act_in); wp from `pw_prepack`."""
+    B, Ci, F, T = x.shape
+    wmode = 0 if wp.dtype == torch.float32 else (2 if getattr(wp, "_eat_split", False) else 1)
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_tf_fwd", _dev(x, "x"), tf[0].data_ptr(), tf[1].data_ptr(), tf[2], wp.data_ptr(), wmode,
+              _dev(bias, "bias"), _opt(in_scale, "in_scale"), _opt(res, "res"), y.data_ptr(), B, Ci, Co, F * T, act,
+              _stream())
+    return y
+
+
+def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None):
     """dW (Co, Ci) = sum_b dz[b] (Co,S) . (x[b] * x_scale[b])^T.  exact=True: fp32 MFMA kernel; False: split-operand
     bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact, 'bf16' -> plain bf16
     operands with fp32 accumulation, as autocast does to the conv weight gradient; otherwise bf16x3)."""
@@ -341,6 +357,12 @@ def pw_conv_wgrad(dz, x, x_scale=None, exact=None):
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
     dW = zero_arena.zeros((Co, Ci), torch.float32, dz.device)
+    if tf is not None:
+        ws = zero_arena.zeros((8, Co, Ci), torch.float32, dz.device) if (Co <= 64 and Ci <= 64 and S % 4 == 0 and mode != 1) else None
+        _lib.call("eat_pw_conv_wgrad_tf", _dev(dz, "dz"), _dev(x, "x"), tf[0].data_ptr(), tf[1].data_ptr(), tf[2],
+                  _opt(x_scale, "x_scale"), dW.data_ptr(), None if ws is None else ws.data_ptr(), 0 if ws is None else 8,
+                  B, Co, Ci, S, mode, _stream())
+        return dW
     if Co <= 64 and Ci <= 64 and S % 4 == 0 and mode != 1:
         # small matrices, long reductions: the streaming kernel spreads its atomics over 8 copies of dW (csrc/train.hip)
         ws = zero_arena.zeros((8, Co, Ci), torch.float32, dz.device)

@@ -246,6 +246,19 @@ int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, flo
 int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float* x_scale, float* dW, float* ws, int n_slots, int B,
                          int Co, int Ci, int S, int exact_fp32, eat_stream_t stream);
 
+/* Train-mode project conv, models/mn/block_types.py:167-171 fed by :150-162 (+ the SE scale of :72-83): the conv input is
+ * act_in(tf_a[k] x + tf_b[k]) * in_scale[b,k] evaluated on the way to the matrix cores, i.e. BatchNorm + activation of
+ * the depthwise output z_d are fused into the consumer and the activated tensor is never written.
+ * wp: eat_pw_prepack (wmode 0) / eat_pw_prepack_bf16 plain (1) / split (2).  Needs Ci % 8 == 0, S % 4 == 0. */
+int eat_pw_conv_tf_fwd(const float* x, const float* tf_a, const float* tf_b, int tf_act, const void* wp, int wmode,
+                       const float* bias, const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S,
+                       int act, eat_stream_t stream);
+
+/* Weight gradient of that conv: dW = sum dz (act_in(tf_a x + tf_b) * x_scale)^T with the transform on load. */
+int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float* tf_a, const float* tf_b, int tf_act,
+                         const float* x_scale, float* dW, float* ws, int n_slots, int B, int Co, int Ci, int S,
+                         int exact_fp32, eat_stream_t stream);
+
 /* ================= DyMN dynamic blocks (models/dymn/dy_block.py) ================================ */
 
 /* ContextGen's two average pools (dy_block.py:236-237): x (B,C,F,T) -> seq (B, F+T, C), position-

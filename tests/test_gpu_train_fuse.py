@@ -180,3 +180,36 @@ def test_se_block_bn_backward_in_one_pass(B, C, F_, T, act):
     y_ref = ACTS[act](F.batch_norm(zr, None, None, gamma.double(), beta.double(), True, 0.0, 1e-3))
     (y_ref * (d.double() * gs.double()[:, :, None, None] + ga.double()[:, :, None, None])).sum().backward()
     assert _rel(dz, zr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act,se", [(3, 64, 24, 32, 250, 1, False), (4, 72, 40, 16, 125, 1, True), (5, 240, 80, 8, 63, 2, False),
+                                                 (6, 672, 160, 4, 32, 2, True), (2, 16, 16, 64, 500, 1, False), (3, 200, 80, 8, 63, 2, False),
+                                                 (70, 120, 40, 4, 32, 1, True)])
+@pytest.mark.parametrize("mode", ["fp32", "auto", "bf16"])
+def test_project_conv_with_bn_act_on_load(B, Ci, Co, F_, T, act, se, mode):
+    """1x1 conv (and its weight gradient) whose input act(a z + b) * s is evaluated on load == the explicit composition
+    bn_act_fwd -> pw_conv (models/mn/block_types.py:150-171 in train mode), on the three arithmetic paths."""
+    z = _rand(B, Ci, F_, T, seed=1, scale=2.0) + _rand(1, Ci, 1, 1, seed=2)
+    a, b = torch.rand(Ci, generator=torch.Generator().manual_seed(3)) + 0.5, _rand(Ci, seed=4, scale=0.3)
+    W = _rand(Co, Ci, seed=5, scale=Ci ** -0.5)
+    sc = (torch.rand(B, Ci, generator=torch.Generator().manual_seed(6)) + 0.25) if se else None
+    dz = _rand(B, Co, F_, T, seed=7)
+    zd, ad, bd, Wd = z.to(DEV), a.to(DEV), b.to(DEV), W.to(DEV)
+    scd = sc.to(DEV) if se else None
+    zero = torch.zeros(Co, device=DEV)
+    with ops.precision(mode):
+        wp = ops.pw_prepack(Wd)
+        y_act = ops.bn_act_fwd(zd, ad, bd, act)
+        ref = ops.pw_conv(y_act, wp, zero, Co, ops.ACT_NONE, in_scale=scd)
+        got = ops.pw_conv_tf(zd, (ad, bd, act), wp, zero, Co, ops.ACT_NONE, in_scale=scd)
+        dW_ref = ops.pw_conv_wgrad(dz.to(DEV), y_act, x_scale=scd)
+        dW = ops.pw_conv_wgrad(dz.to(DEV), zd, x_scale=scd, tf=(ad, bd, act))
+    # same arithmetic on both sides (the transform is the same fp32 fma + activation): differences are atomics order
+    assert _rel(got, ref) < 2e-6, _rel(got, ref)
+    assert _rel(dW, dW_ref) < 2e-5, _rel(dW, dW_ref)
+    if mode == "fp32":
+        x64 = ACTS[act](z.double() * a.double()[None, :, None, None] + b.double()[None, :, None, None])
+        if se:
+            x64 = x64 * sc.double()[:, :, None, None]
+        assert _rel(got, F.conv2d(x64, W.double()[:, :, None, None])) < 1e-5
+        assert _rel(dW, torch.einsum("bofs,bifs->oi", dz.double(), x64)) < 2e-5
