@@ -17,7 +17,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // Optional transform of the x operand of the 1x1 weight gradient: x' = act(a[ci] * x + b[ci]) evaluated on load (training:
 // the project conv read BN + act of the depthwise output on load, so the activated tensor does not exist; mn_train.py)
 struct WgTf { const float* a; const float* b; int act; };
-__device__ __forceinline__ float wg_tf(float v, float a, float b, int act) { return eat::activate_rt(fmaf(a, v, b), act); }
+// branch-free: act(u) = max(u, lo) * clamp(u * ca + cb, 0, 1) with (lo, ca, cb) = none (-inf, 0, 1), ReLU (0, 0, 1),
+// Hardswish (-inf, 1/6, 1/2) - the weight-gradient kernels are VALU-bound on the bf16 hi/lo split already
+__device__ __forceinline__ float wg_tf(float v, float a, float b, int act) {
+  const float u = fmaf(a, v, b);
+  const float lo = act == EAT_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+  const float ca = act == EAT_ACT_HSWISH ? (1.0f / 6.0f) : 0.0f, cb = act == EAT_ACT_HSWISH ? 0.5f : 1.0f;
+  return fmaxf(u, lo) * __builtin_amdgcn_fmed3f(fmaf(u, ca, cb), 0.0f, 1.0f);
+}
 
 template <int ACT>
 __device__ __forceinline__ float act_grad(float u) {   // d act(u) / du  (PyTorch conventions)

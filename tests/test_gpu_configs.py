@@ -280,3 +280,108 @@ def test_mn40_train_step_bf16_tracks_oracle(mn40_case):
     assert float(np.median(hv)) < 1.25 * float(np.median(ev)) + 1e-2, (float(np.median(hv)), float(np.median(ev)))
     e_hip, e_emu = float((logits - d["logits"]).abs().max()), float((logits_e - d["logits"]).abs().max())
     assert e_hip < 1.5 * e_emu + 1e-2 * scale, (e_hip, e_emu)
+
+
+# ------------------------------------------------------------------ train-step parity AT THE MEASURED BATCH SIZES
+# bench.py times the mn10 step at 256 clips per GPU and the mn40 / dymn20 steps at 128.  Torch-CPU autograd over the
+# oracle at those sizes needs minutes and tens of GB, so the large batch is built from COPIES of the small one: with the
+# mean-reduced loss, a batch of r copies of n clips has exactly the batch statistics, per-sample activations, loss and
+# parameter gradients of the n-clip batch (BatchNorm couples the samples only through statistics that the copies leave
+# unchanged).  The n-clip step is pinned on the oracle; the r x n step runs every kernel in the regime the bench measures
+# (multi-sample BN reducers, split-K weight gradients, G samples per wave, full-size grids) and must reproduce it.
+def _tiled_step(model, x, y, keep, reps):
+    model._drop_mask_override = keep.repeat(reps, 1)
+    logits, _ = model(x.repeat(reps, 1, 1, 1).to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.repeat(reps, 1).to(DEV))
+    loss.backward()
+    return loss.item(), logits.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+
+
+def _check_tiled(small, large, n, stats_small, stats_large, grad_tol=2e-3):
+    loss_s, logits_s, g_s = small
+    loss_l, logits_l, g_l = large
+    assert abs(loss_l - loss_s) < 2e-6 * max(1.0, abs(loss_s)), (loss_l, loss_s)
+    reps = logits_l.shape[0] // n
+    scale = max(1.0, float(logits_s.abs().max()))
+    for r in (0, reps // 2, reps - 1):                      # first, middle and last copy of the batch
+        assert float((logits_l[r * n:(r + 1) * n] - logits_s).abs().max()) < 2e-5 * scale
+    gmax = max(float(v.norm()) for v in g_s.values())
+    rels = []
+    for name, ref in g_s.items():
+        if float(ref.norm()) < 1e-4 * gmax:                  # zero-gradient project-BN biases: round-off only
+            continue
+        rels.append((_rel(g_l[name], ref), name))
+    worst = max(rels)
+    assert worst[0] < grad_tol, worst
+    assert float(np.median([r for r, _ in rels])) < 2e-5
+    for k, v in stats_small.items():                         # running statistics (unbiased factor n/(n-1) differs by ~1e-6)
+        assert _rel(stats_large[k], v) < 2e-5, k
+
+
+def test_mn10_train_step_at_batch_256_reproduces_the_oracle_pinned_batch(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
+    sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    clips = torch.cat([synth.parity_clips(320000, seed=1234), synth.parity_clips(320000, seed=77)[[0, 2, 4]]])     # 8 clips
+    x = O.mel_forward(clips).unsqueeze(1)
+    y = (torch.rand(8, 527, generator=torch.Generator().manual_seed(2)) < 0.01).float()
+    keep = (torch.rand(8, 1280, generator=torch.Generator().manual_seed(3)) < 0.8).float()
+    # the 8-clip step against torch-CPU autograd over the oracle
+    sdr = _grad_state(sd)
+    stats = {}
+    logits_ref, _ = O.mn_forward(sdr, x, train=True, stats=stats, drop_mask=keep)
+    loss_ref = F.binary_cross_entropy_with_logits(logits_ref, y)
+    loss_ref.backward()
+    runs, bufs = {}, {}
+    for reps in (1, 32):                                     # 8 and 256 clips
+        model = _quiet(mn_mod.get_model, width_mult=1.0)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train()
+        model.train_precision = "auto"                       # the arithmetic bench.py times
+        runs[reps] = _tiled_step(model, x, y, keep, reps)
+        bufs[reps] = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    loss8, logits8, g8 = runs[1]
+    assert abs(loss8 - float(loss_ref)) < 2e-5 * max(1.0, abs(float(loss_ref)))
+    assert float((logits8 - logits_ref.detach()).abs().max()) < 1e-3
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    rels = [_rel(g8[n], sdr[n].grad) for n in g8 if float(sdr[n].grad.norm()) >= 1e-5 * gmax]
+    assert max(rels) < 3e-2 and float(np.median(rels)) < 1e-2, (max(rels), float(np.median(rels)))
+    for k, v in stats.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert _rel(bufs[1][k], v) < 1e-4, k
+    _check_tiled(runs[1], runs[32], 8, bufs[1], bufs[32])
+
+
+@pytest.mark.parametrize("precision", ["auto", "bf16"])
+def test_mn40_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(mn40_case, precision):
+    """configs[2] at its batch size: 16 copies of the 8 clips whose step test_mn40_train_step_* pin on the oracle."""
+    d = mn40_case
+    runs, bufs = {}, {}
+    for reps in (1, 16):
+        model = _quiet(mn_mod.get_model, width_mult=4.0)
+        model.load_state_dict(d["sd"], strict=True)
+        model.to(DEV).train()
+        model.train_precision = precision
+        runs[reps] = _tiled_step(model, d["x"], d["y"], d["keep"], reps)
+        bufs[reps] = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        del model
+        torch.cuda.empty_cache()
+    # bf16 operands: a value within fp32 noise of a bf16 rounding boundary may round the other way in the other regime
+    _check_tiled(runs[1], runs[16], 8, bufs[1], bufs[16], grad_tol=2e-3 if precision == "auto" else 5e-2)
+
+
+def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn20_case):
+    """configs[3] at its batch size: 32 copies of the 4 clips of test_dymn20_train_step_matches_oracle."""
+    d = dymn20_case
+    y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
+    keep = (torch.rand(4, 2560, generator=torch.Generator().manual_seed(6)) < 0.8).float()
+    runs, bufs = {}, {}
+    for reps in (1, 32):
+        model = _dymn20(d["sd"], d["temp"]).train()
+        runs[reps] = _tiled_step(model, d["x"], y, keep, reps)
+        bufs[reps] = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        del model
+        torch.cuda.empty_cache()
+    _check_tiled(runs[1], runs[32], 4, bufs[1], bufs[32])

@@ -205,8 +205,9 @@ def test_project_conv_with_bn_act_on_load(B, Ci, Co, F_, T, act, se, mode):
         dW_ref = ops.pw_conv_wgrad(dz.to(DEV), y_act, x_scale=scd)
         dW = ops.pw_conv_wgrad(dz.to(DEV), zd, x_scale=scd, tf=(ad, bd, act))
     # same arithmetic on both sides (the transform is the same fp32 fma + activation): differences are atomics order
-    assert _rel(got, ref) < 2e-6, _rel(got, ref)
-    assert _rel(dW, dW_ref) < 2e-5, _rel(dW, dW_ref)
+    # (bf16 operands: the two activation formulas differ in the last fp32 bit, which flips a bf16 rounding now and then)
+    assert _rel(got, ref) < (2e-6 if mode != "bf16" else 1e-4), _rel(got, ref)
+    assert _rel(dW, dW_ref) < (2e-5 if mode != "bf16" else 1e-4), _rel(dW, dW_ref)
     if mode == "fp32":
         x64 = ACTS[act](z.double() * a.double()[None, :, None, None] + b.double()[None, :, None, None])
         if se:
