@@ -1,31 +1,66 @@
-"""`datasets.audioset` of the reference (datasets/audioset.py) as a SYNTHETIC stand-in with the same surface.
+"""`datasets.audioset` of the reference (datasets/audioset.py): same public surface, two back-ends.
 
 The reference reads mp3 bytes from three AudioSet HDF5 files (decode with `av`, pad / truncate to 10 s, optional gain /
 roll / waveform mix-up) and hands the training loop tuples
     (waveform float32 (1, clip_samples), audio_name str, target float32 (527,)[, index int])
-(datasets/audioset.py:94-103,138-161).  Neither AudioSet nor h5py / av exist offline, so this module generates clips of
-the same layout on the fly - deterministic per index (numpy PCG64 seeded with the index), a mix of band-limited noise,
-tones and silence so that every mel band is exercised - which is what the benchmarks, the GPU tests and an unmodified
-`ex_audioset.py` run against.  Same public functions, argument names and defaults as the reference:
-`get_test_set`, `get_training_set`, `get_full_training_set`, `get_base_*`, `get_ft_weighted_sampler`,
-`get_ft_cls_balanced_sample_weights`, `MixupDataset`, `AddIndexDataset`, `pad_or_truncate`, `pydub_augment`.
+(datasets/audioset.py:94-103,138-161).  Back-end selection, at import like the reference's `dataset_dir` assertion:
 
-Sizes: EAT_SYNTH_AUDIOSET_TRAIN (default 2048 balanced + 6144 "unbalanced") / EAT_SYNTH_AUDIOSET_TEST (default 1054) clips.
+  * REAL: `dataset_dir` (below; or the environment variable EAT_AUDIOSET_DIR) names a directory holding
+    balanced_train_segments_mp3.hdf / unbalanced_train_segments_mp3.hdf / eval_segments_mp3.hdf -> the HDF5 + mp3 reader
+    (`_Hdf5AudioSet`: h5py rows `audio_name`, `mp3`, bit-packed `target`; PyAV decode; needs h5py and av);
+  * SYNTHETIC: only on the explicit opt-in EAT_SYNTH_AUDIOSET=1 (the benchmarks, the GPU tests and the staged runs of
+    the reference's own scripts set it): clips of the same layout generated on the fly - deterministic per index (numpy
+    PCG64 seeded with the index), band-limited noise + tones + silence so that every mel band is exercised;
+  * neither: AssertionError, as in the reference - nobody trains or reports mAP on noise by accident.
+
+Same public functions, argument names and defaults as the reference: `get_test_set`, `get_training_set`,
+`get_full_training_set`, `get_base_*`, `get_ft_weighted_sampler`, `get_ft_cls_balanced_sample_weights`, `MixupDataset`,
+`AddIndexDataset`, `pad_or_truncate`, `pydub_augment`, `decode_mp3`.
+
+Synthetic sizes: EAT_SYNTH_AUDIOSET_TRAIN (default 2048 balanced + 6144 "unbalanced") / EAT_SYNTH_AUDIOSET_TEST (default
+1054) clips.
 """
+import io
 import os
 
 import numpy as np
 import torch
 from torch.utils.data import ConcatDataset, Dataset as TorchDataset, WeightedRandomSampler
 
-dataset_dir = "synthetic"
-_N_TRAIN = int(os.environ.get("EAT_SYNTH_AUDIOSET_TRAIN", "2048"))
-dataset_config = {
-    "balanced_train_hdf5": ("balanced", _N_TRAIN, 0),
-    "unbalanced_train_hdf5": ("unbalanced", 3 * _N_TRAIN, 1 << 20),
-    "eval_hdf5": ("eval", int(os.environ.get("EAT_SYNTH_AUDIOSET_TEST", "1054")), 527 << 12),
-    "num_of_classes": 527,
-}
+dataset_dir = os.environ.get("EAT_AUDIOSET_DIR")          # or assign the AudioSet location here, as in the reference
+_HDF_NAMES = {"balanced_train_hdf5": "balanced_train_segments_mp3.hdf",
+              "unbalanced_train_hdf5": "unbalanced_train_segments_mp3.hdf", "eval_hdf5": "eval_segments_mp3.hdf"}
+SYNTHETIC = os.environ.get("EAT_SYNTH_AUDIOSET", "0") == "1"
+if not SYNTHETIC:
+    assert dataset_dir is not None, (
+        "Specify the AudioSet location (datasets.audioset.dataset_dir or EAT_AUDIOSET_DIR: the directory with the three "
+        "*_segments_mp3.hdf files of https://github.com/kkoutini/PaSST/tree/main/audioset), or opt in to the SYNTHETIC "
+        "stand-in explicitly with EAT_SYNTH_AUDIOSET=1")
+    _missing = [f for f in _HDF_NAMES.values() if not os.path.isfile(os.path.join(dataset_dir, f))]
+    assert not _missing, f"AudioSet files not found under {dataset_dir}: {_missing} (EAT_SYNTH_AUDIOSET=1 selects the synthetic stand-in)"
+    dataset_config = {k: os.path.join(dataset_dir, f) for k, f in _HDF_NAMES.items()}
+    dataset_config["num_of_classes"] = 527
+else:
+    dataset_dir = "synthetic"
+    _N_TRAIN = int(os.environ.get("EAT_SYNTH_AUDIOSET_TRAIN", "2048"))
+    dataset_config = {
+        "balanced_train_hdf5": ("balanced", _N_TRAIN, 0),
+        "unbalanced_train_hdf5": ("unbalanced", 3 * _N_TRAIN, 1 << 20),
+        "eval_hdf5": ("eval", int(os.environ.get("EAT_SYNTH_AUDIOSET_TEST", "1054")), 527 << 12),
+        "num_of_classes": 527,
+    }
+
+
+def decode_mp3(mp3_arr):
+    """uint8 array holding one mp3 file -> float32 waveform (PyAV; datasets/audioset.py:32-47)."""
+    import av
+    container = av.open(io.BytesIO(mp3_arr.tobytes()))
+    stream = next(s for s in container.streams if s.type == "audio")
+    chunks = [frame.to_ndarray().reshape(-1) for packet in container.demux(stream) for frame in packet.decode()]
+    waveform = np.concatenate(chunks)
+    if waveform.dtype != np.float32:
+        raise RuntimeError("Unexpected wave type")
+    return waveform
 
 
 def pad_or_truncate(x, audio_length):
@@ -53,9 +88,66 @@ def _synth_target(rng, classes_num, g):
     return y                        # (sklearn's per-class ROC / AP of `_test` need a positive and a negative per class)
 
 
-class AudioSetDataset(TorchDataset):
+class _Hdf5AudioSet(TorchDataset):
+    """The reference's reader (datasets/audioset.py:106-177): one HDF5 file with the rows `audio_name` (bytes), `mp3`
+    (variable-length uint8) and `target` (527 labels packed into 66 bytes); the file handle is opened lazily so that
+    every DataLoader worker gets its own."""
+
+    def __init__(self, hdf5_file, sample_rate=32000, resample_rate=32000, classes_num=527, clip_length=10, in_mem=False,
+                 gain_augment=0):
+        import h5py
+        self.sample_rate, self.resample_rate = sample_rate, resample_rate
+        self.hdf5_file = hdf5_file
+        if in_mem:
+            print("\nPreloading in memory\n")
+            with open(hdf5_file, "rb") as f:
+                self.hdf5_file = io.BytesIO(f.read())
+        with h5py.File(hdf5_file, "r") as f:
+            self.length = len(f["audio_name"])
+        print(f"Dataset from {hdf5_file} with length {self.length}.")
+        self.dataset_file = None
+        self.clip_length = clip_length * sample_rate
+        self.classes_num, self.gain_augment = classes_num, gain_augment
+
+    def __len__(self):
+        return self.length
+
+    def __del__(self):
+        if getattr(self, "dataset_file", None) is not None:
+            self.dataset_file.close()
+            self.dataset_file = None
+
+    def _file(self):
+        if self.dataset_file is None:
+            import h5py
+            self.dataset_file = h5py.File(self.hdf5_file, "r")
+        return self.dataset_file
+
+    def targets(self):
+        """(length, classes_num) float32 label matrix (for the class-balancing sampler)."""
+        return np.unpackbits(self._file()["target"][:], axis=-1, count=self.classes_num).astype(np.float32)
+
+    def __getitem__(self, index):
+        f = self._file()
+        # stored names look like "Y<youtube id>.mp3": back to the official file name
+        audio_name = f["audio_name"][index].decode().replace(".mp3", "").split("Y", 1)[1]
+        waveform = pad_or_truncate(pydub_augment(decode_mp3(f["mp3"][index]), self.gain_augment), self.clip_length)
+        target = np.unpackbits(f["target"][index], axis=-1, count=self.classes_num).astype(np.float32)
+        return self.resample(waveform).reshape(1, -1), audio_name, target
+
+    def resample(self, waveform):
+        if self.resample_rate == 32000:
+            return waveform
+        if self.resample_rate == 16000:
+            return waveform[0::2]
+        if self.resample_rate == 8000:
+            return waveform[0::4]
+        raise Exception("Incorrect sample rate!")
+
+
+class _SyntheticAudioSet(TorchDataset):
     """Same constructor and item layout as the reference class (datasets/audioset.py:106-177); `hdf5_file` is one of the
-    `dataset_config` entries (name, length, index offset) instead of a path."""
+    synthetic `dataset_config` entries (name, length, index offset) instead of a path."""
 
     def __init__(self, hdf5_file, sample_rate=32000, resample_rate=32000, classes_num=527, clip_length=10, in_mem=False,
                  gain_augment=0):
@@ -96,6 +188,9 @@ class AudioSetDataset(TorchDataset):
         if self.resample_rate == 8000:
             return waveform[0::4]
         raise Exception("Incorrect sample rate!")
+
+
+AudioSetDataset = _SyntheticAudioSet if SYNTHETIC else _Hdf5AudioSet
 
 
 class MixupDataset(TorchDataset):

@@ -44,7 +44,12 @@ class _Slot:
             if pin is None or pin.shape != item.shape or pin.dtype != item.dtype:
                 pin = torch.empty(item.shape, dtype=item.dtype, pin_memory=True)
                 self.pinned[i] = pin
-                self.device[i] = torch.empty(item.shape, dtype=item.dtype, device=device)
+                # allocated ON the copy stream: the caching allocator orders a recycled block after the work queued on the
+                # stream it is handed out on, so the first copy into it cannot race kernels that still read the block's
+                # previous contents (e.g. an unsynchronised training epoch that just ended on the compute stream is
+                # ordered by the wait_stream in DevicePrefetcher.__iter__)
+                with torch.cuda.stream(stream):
+                    self.device[i] = torch.empty(item.shape, dtype=item.dtype, device=device)
             self.copied.synchronize()                             # the previous H2D out of this pinned buffer is done
             pin.copy_(item)
             with torch.cuda.stream(stream):
@@ -75,6 +80,9 @@ class DevicePrefetcher:
         queue = []                                                # (slot index, staged batch)
         free = list(range(len(self.slots)))
         held = None                                               # slot whose tensors the consumer is using
+        # a new pass may start while kernels of the previous one (or of whatever ran before on the compute stream) still
+        # read the slots' device buffers: order every copy of this pass after the work queued so far
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
         def fill():
             while free and len(queue) < self.depth:
@@ -93,7 +101,15 @@ class DevicePrefetcher:
                 self.slots[held].released = ev
                 free.append(held)
             s, staged = queue.pop(0)
-            torch.cuda.current_stream(self.device).wait_event(self.slots[s].copied)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self.slots[s].copied)
+            for t in staged:                                      # allocated on the copy stream, consumed on this one
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
             held = s
             fill()                                                # next copies overlap with the consumer's kernels
             yield tuple(staged)
+        if held is not None:                                      # the last batch of the pass: its slot gets a fresh event too
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.slots[held].released = ev

@@ -35,9 +35,12 @@ class _KDLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, y, perm, lam, teacher, tidx, kd_lambda, sums):
         logits = logits.contiguous()
-        before = sums[0].clone()
-        ctx.save_for_backward(ops.kd_loss_fwd_bwd(logits, y, perm, lam, teacher, tidx, kd_lambda, sums))
-        return sums[0] - before
+        # the step's three terms go to their own zeroed buffer (the epoch accumulator grows to the hundreds: a difference
+        # of two such fp32 numbers would lose 3-4 digits of the step loss); the accumulator is updated from it
+        step = torch.zeros(3, device=logits.device, dtype=torch.float32)
+        ctx.save_for_backward(ops.kd_loss_fwd_bwd(logits, y, perm, lam, teacher, tidx, kd_lambda, step))
+        sums += step.to(sums.dtype)
+        return step[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -49,7 +52,7 @@ def kd_loss(logits, y, perm=None, lam=None, teacher=None, teacher_idx=None, kd_l
     """Fused loss of ex_audioset.py:149-189 (see include/eat_hip.h: eat_kd_loss_fwd_bwd).  Returns the scalar loss as a
     device tensor that supports .backward(); `sums` (3,) accumulates (loss, label part, KD part) across calls."""
     if sums is None:
-        sums = torch.zeros(3, device=logits.device, dtype=torch.float32)
+        sums = torch.zeros(3, device=logits.device, dtype=torch.float64)
     return _KDLoss.apply(logits, y.contiguous().float(), perm, lam, teacher, teacher_idx, float(kd_lambda), sums)
 
 
@@ -70,7 +73,13 @@ class KDTrainer:
         if teacher_preds is not None and kd_lambda > 0:
             self.teacher = torch.sigmoid(torch.as_tensor(teacher_preds).float() / temperature).to(dev).contiguous()
         self.fname_to_index = fname_to_index or {}
-        self.sums = torch.zeros(3, device=dev, dtype=torch.float32)
+        if self.teacher is not None and self.fname_to_index:
+            # validated once on the host: the loss kernel gathers teacher rows by these indices on the device
+            bad = [(f, i) for f, i in self.fname_to_index.items() if not (-1 <= int(i) < self.teacher.shape[0])]
+            if bad:
+                raise ValueError(f"fname_to_index holds {len(bad)} indices outside the teacher table of {self.teacher.shape[0]} "
+                                 f"rows, e.g. {bad[0]}")
+        self.sums = torch.zeros(3, device=dev, dtype=torch.float64)
         self.steps = 0
 
     def step(self, x, names, y):

@@ -254,6 +254,58 @@ def golden_dymn_variants(mel):
     np.savez_compressed(os.path.join(OUT, "dymn_variants_ref.npz"), **res)
 
 
+WIDTHS = {"mn40": ("mn", 4.0), "dymn20": ("dymn", 2.0)}      # BASELINE.json configs[2] / configs[3]
+
+
+def golden_widths(mel):
+    """The reference at the widths BASELINE.json names (models/mn/model.py:326-367 with width_mult=4.0,
+    models/dymn/model.py:289-361 with width_mult=2.0) on 3 s clips: eval logits / features, and one train-mode step at the
+    reference's initial DynamicConv temperature 30 (Dropout off): logits, loss, gradient norm + 8 samples of every
+    parameter's gradient, BatchNorm buffers after the step."""
+    res = {}
+    with torch.no_grad():
+        x_cal = mel(synth.calibration_clips(96000)).unsqueeze(1)
+        x = mel(synth.parity_clips(96000, seed=45)).unsqueeze(1)
+    y = torch.from_numpy((np.random.Generator(np.random.PCG64(10)).random((x.shape[0], 527)) < 0.01).astype(np.float32))
+    for tag, (kind, width) in WIDTHS.items():
+        model = quiet(get_mn if kind == "mn" else get_dymn, width_mult=width)
+        sd = synth.synth_state(synth.shapes_of(model), seed=6)
+        model.load_state_dict(sd, strict=True)
+
+        def set_temp(t):
+            for m in model.modules():
+                if isinstance(m, DynamicConv):
+                    m.temperature = t
+
+        set_temp(1.0)
+        calibrate_reference(model, x_cal)
+        for k, v in bn_buffers(model).items():
+            res[f"{tag}/bn/{k}"] = v.numpy()
+        res[f"{tag}/keys"] = np.array(list(model.state_dict().keys()))
+        res[f"{tag}/n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+        model.eval()
+        with torch.no_grad():
+            logits, feats = model(x)
+        res[f"{tag}/logits"], res[f"{tag}/features"] = logits.numpy(), feats.numpy()
+        set_temp(30.0)
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        tl, _ = model(x)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(tl, y)
+        loss.backward()
+        res[f"{tag}/train_logits"], res[f"{tag}/train_loss"] = tl.detach().numpy(), np.float64(loss.item())
+        res[f"{tag}/train_labels"] = y.numpy()
+        rng = np.random.Generator(np.random.PCG64(7))
+        for k, v in grad_summary(model, rng).items():
+            res[f"{tag}/{k}"] = v
+        for k, v in bn_buffers(model).items():
+            res[f"{tag}/bn_after/{k}"] = v.numpy()
+        print("width", tag, "params", int(res[f"{tag}/n_params"]), "logits absmax", float(logits.abs().max()), "train loss", loss.item())
+    np.savez_compressed(os.path.join(OUT, "widths_ref.npz"), **res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -261,8 +313,12 @@ if __name__ == "__main__":
     if "--dymn-variants-only" in sys.argv:
         golden_dymn_variants(mel)
         sys.exit(0)
+    if "--widths-only" in sys.argv:
+        golden_widths(mel)
+        sys.exit(0)
     if "--variants-only" not in sys.argv:
         golden_model("mn", mel, 1.0, "mn10")
         golden_model("dymn", mel, 1.0, "dymn10")
     golden_variants(mel)
     golden_dymn_variants(mel)
+    golden_widths(mel)

@@ -74,7 +74,7 @@ def test_evaluate_call_path(callpaths):
     cwd = os.getcwd()
     os.chdir(work)
     try:
-        os.environ["EAT_SYNTH_AUDIOSET_TEST"] = "124"
+        os.environ["EAT_SYNTH_AUDIOSET"], os.environ["EAT_SYNTH_AUDIOSET_TEST"] = "1", "124"
         from datasets.audioset import get_test_set
         ds = get_test_set(resample_rate=32000)
         x = torch.stack([torch.as_tensor(ds[i][0]) for i in range(4)])

@@ -385,3 +385,57 @@ def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn2
         del model
         torch.cuda.empty_cache()
     _check_tiled(runs[1], runs[32], 4, bufs[1], bufs[32])
+
+
+# ------------------------------------------------------------------ BASELINE widths against the reference's own outputs
+@pytest.mark.parametrize("tag", ["mn40", "dymn20"])
+def test_baseline_width_models_match_reference_goldens(tag, golden_dir):
+    """mn40 (configs[2]) and dymn20 (configs[3]) on the HIP path against vectors produced by the UNMODIFIED reference at
+    those widths (oracle/make_golden.py:golden_widths, 3 s clips): eval logits / features, and one training step at the
+    reference's initial DynamicConv temperature 30 - logits, loss, the norm and 8 sampled entries of every gradient."""
+    from tests.test_oracle_golden import WIDTHS, width_state
+    kind, _ = WIDTHS[tag]
+    model, sd, g = width_state(tag, golden_dir)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV)
+    x = O.mel_forward(synth.parity_clips(96000, seed=45)).unsqueeze(1).to(DEV)
+
+    def set_temp(t):
+        for m in model.modules():
+            if hasattr(m, "temperature"):
+                m.temperature = t
+    set_temp(1.0)
+    model.eval()
+    with torch.no_grad():
+        logits, feats = model(x)
+    for got, key in ((logits, "logits"), (feats, "features")):
+        ref = g[f"{tag}/{key}"]
+        assert np.abs(got.cpu().numpy() - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), key
+    set_temp(30.0)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    if kind == "mn":
+        model.train_precision = "fp32"
+    tl, _ = model(x)
+    loss = F.binary_cross_entropy_with_logits(tl, torch.from_numpy(g[f"{tag}/train_labels"]).to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}/train_loss"])) < 1e-4
+    ref_tl = g[f"{tag}/train_logits"]
+    assert np.abs(tl.detach().cpu().numpy() - ref_tl).max() < 1e-3 * max(1.0, np.abs(ref_tl).max())
+    gmax = max(float(g[k]) for k in g.files if k.startswith(f"{tag}/gnorm/"))
+    rels = []
+    for name, p in model.named_parameters():
+        ref = float(g[f"{tag}/gnorm/{name}"])
+        if ref <= 1e-4 * gmax:
+            continue
+        rels.append(abs(float(p.grad.norm()) - ref) / ref)
+        vals, idx = g[f"{tag}/gval/{name}"], g[f"{tag}/gidx/{name}"]
+        got = p.grad.reshape(-1)[torch.from_numpy(idx).to(DEV)].cpu().numpy()
+        assert np.abs(got - vals).max() < 5e-2 * max(np.abs(vals).max(), ref / np.sqrt(p.numel())), name
+    assert max(rels) < 5e-2 and float(np.median(rels)) < 1e-2, (max(rels), float(np.median(rels)))
+    msd = model.state_dict()
+    for k in g.files:
+        if k.startswith(f"{tag}/bn_after/"):
+            assert _rel(msd[k[len(tag) + 10:]], torch.from_numpy(g[k])) < 1e-4, k

@@ -154,6 +154,7 @@ def test_device_prefetcher_delivers_the_loader_batches_in_order():
     import importlib.util
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin", "datasets", "audioset.py")
+    os.environ["EAT_SYNTH_AUDIOSET"] = "1"                                          # explicit opt-in to the synthetic stand-in
     spec = importlib.util.spec_from_file_location("eat_dropin_audioset", path)    # (not `import datasets`: the
     audioset = importlib.util.module_from_spec(spec)                                 #  HuggingFace package has that name)
     spec.loader.exec_module(audioset)

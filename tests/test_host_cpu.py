@@ -133,6 +133,7 @@ def test_synthetic_audioset_standin_matches_reference_tuple_layout(tmp_path, mon
     """dropin/datasets/audioset.py: same public functions and item layout as the reference's datasets/audioset.py
     (:94-103 AddIndexDataset, :138-161 item = (waveform (1, 320000) f32, name, target (527,) f32))."""
     import importlib.util
+    monkeypatch.setenv("EAT_SYNTH_AUDIOSET", "1")
     monkeypatch.setenv("EAT_SYNTH_AUDIOSET_TRAIN", "16")
     monkeypatch.setenv("EAT_SYNTH_AUDIOSET_TEST", "527")
     spec = importlib.util.spec_from_file_location("eat_synth_audioset", os.path.join(ROOT, "dropin", "datasets", "audioset.py"))
@@ -155,6 +156,30 @@ def test_synthetic_audioset_standin_matches_reference_tuple_layout(tmp_path, mon
         mixed = ds.get_training_set(roll=True, wavmix=True, gain_augment=3)
     xm, _, ym, _ = mixed[1]
     assert xm.shape == (1, 320000) and ym.shape == (527,)
+
+
+def test_audioset_dropin_never_falls_back_to_synthetic_silently(tmp_path, monkeypatch):
+    """Without EAT_SYNTH_AUDIOSET=1 the module behaves like the reference's (datasets/audioset.py:19-22): an assertion
+    unless the AudioSet HDF5 files are really there - nobody trains or evaluates on synthetic noise by accident."""
+    import importlib.util
+
+    def load():
+        spec = importlib.util.spec_from_file_location("eat_audioset_mode", os.path.join(ROOT, "dropin", "datasets", "audioset.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    monkeypatch.delenv("EAT_SYNTH_AUDIOSET", raising=False)
+    monkeypatch.delenv("EAT_AUDIOSET_DIR", raising=False)
+    with pytest.raises(AssertionError, match="EAT_SYNTH_AUDIOSET=1"):
+        load()
+    monkeypatch.setenv("EAT_AUDIOSET_DIR", str(tmp_path))
+    with pytest.raises(AssertionError, match="not found"):
+        load()
+    for f in ("balanced_train_segments_mp3.hdf", "unbalanced_train_segments_mp3.hdf", "eval_segments_mp3.hdf"):
+        (tmp_path / f).write_bytes(b"")
+    mod = load()                                                        # real back-end selected (h5py is needed to open it)
+    assert mod.SYNTHETIC is False and mod.AudioSetDataset is mod._Hdf5AudioSet
+    assert mod.dataset_config["eval_hdf5"].endswith("eval_segments_mp3.hdf")
 
 
 def test_audio_loader_resamples_like_librosa_load(tmp_path):

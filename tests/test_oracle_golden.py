@@ -224,3 +224,64 @@ def test_oracle_dymn_variants_match_reference(tag, golden_dir):
     for got, key in ((logits, "logits"), (feats, "features"), (tl, "train_logits"), (tf, "train_features")):
         ref = g[f"{tag}/{key}"]
         assert np.abs(got.numpy() - ref).max() < 5e-5 * max(1.0, np.abs(ref).max()), key
+
+
+# ---------------------------------------------------------------- BASELINE widths: mn40 (configs[2]), dymn20 (configs[3])
+WIDTHS = {"mn40": ("mn", 4.0), "dymn20": ("dymn", 2.0)}
+
+
+def width_state(tag, golden_dir):
+    """(state_dict, golden npz) of the reference-generated fixture of `oracle/make_golden.py:golden_widths`."""
+    import contextlib
+    import io
+    kind, width = WIDTHS[tag]
+    g = np.load(os.path.join(golden_dir, "widths_ref.npz"))
+    if kind == "mn":
+        from efficientat_amd.mn import get_model
+    else:
+        from efficientat_amd.dymn import get_model
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = get_model(width_mult=width)
+    shapes = synth.shapes_of(model)
+    keys = [str(k) for k in g[f"{tag}/keys"]]
+    assert sorted(keys) == sorted(shapes)                        # same state_dict layout as the reference at this width
+    assert sum(p.numel() for p in model.parameters()) == int(g[f"{tag}/n_params"])
+    sd = synth.synth_state({k: shapes[k] for k in keys}, seed=6)
+    for k in g.files:
+        if k.startswith(f"{tag}/bn/"):
+            sd[k[len(tag) + 4:]] = torch.from_numpy(g[k])
+    return model, sd, g
+
+
+@pytest.mark.parametrize("tag", list(WIDTHS))
+def test_oracle_at_baseline_widths_matches_reference(tag, golden_dir):
+    """models/mn/model.py:326-367 (width_mult=4.0) / models/dymn/model.py:289-361 (width_mult=2.0): eval logits and one
+    train-mode step (DynamicConv temperature 30, the reference's initial value) of the unmodified reference."""
+    import torch.nn.functional as F
+    kind, width = WIDTHS[tag]
+    _, sd, g = width_state(tag, golden_dir)
+    x = O.mel_forward(synth.parity_clips(96000, seed=45)).unsqueeze(1)
+    fwd = (lambda s, xm, **k: O.mn_forward(s, xm, width_mult=width, **k)) if kind == "mn" else \
+          (lambda s, xm, temperature=1.0, **k: O.dymn_forward(s, xm, width_mult=width, temperature=temperature, **k))
+    with torch.no_grad():
+        logits, feats = fwd(sd, x)
+    for got, key in ((logits, "logits"), (feats, "features")):
+        ref = g[f"{tag}/{key}"]
+        assert np.abs(got.numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), key
+    sdr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith(
+        ("running_mean", "running_var", "lambdas", "init_v")) else v.clone()) for k, v in sd.items()}
+    kw = dict(train=True, stats={})
+    if kind == "dymn":
+        kw["temperature"] = 30.0
+    tl, _ = fwd(sdr, x, **kw)
+    loss = F.binary_cross_entropy_with_logits(tl, torch.from_numpy(g[f"{tag}/train_labels"]))
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}/train_loss"])) < 1e-5
+    assert np.abs(tl.detach().numpy() - g[f"{tag}/train_logits"]).max() < 1e-4 * max(1.0, np.abs(g[f"{tag}/train_logits"]).max())
+    gmax = max(float(g[k]) for k in g.files if k.startswith(f"{tag}/gnorm/"))
+    for name, v in sdr.items():
+        if getattr(v, "grad", None) is None:
+            continue
+        ref = float(g[f"{tag}/gnorm/{name}"])
+        if ref > 1e-4 * gmax:
+            assert abs(float(v.grad.norm()) - ref) < 2e-2 * ref, name

@@ -16,11 +16,15 @@ if has diag; then
   timeout 300 python tools/diag_train_v.py full 2>&1 | grep -v amdgpu.ids | tee $OUT/diag_full.log
   EAT_DW_STATS_FUSED=0 EAT_DW_GEPI_FUSED=0 timeout 300 python tools/diag_train_v.py tiny 2>&1 | grep -v amdgpu.ids | tee $OUT/diag_tiny_unfused.log
 fi
+if has failing; then
+  timeout 900 python -m pytest tests/test_gpu_call_paths.py "tests/test_gpu_configs.py::test_mn10_train_step_at_batch_256_reproduces_the_oracle_pinned_batch" "tests/test_gpu_configs.py::test_mn40_train_step_at_batch_128_reproduces_the_oracle_pinned_batch" "tests/test_gpu_configs.py::test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch" "tests/test_gpu_configs.py::test_baseline_width_models_match_reference_goldens" -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" > $OUT/failing.log; tail -c 6000 $OUT/failing.log
+  for i in 1 2; do python tests/rccl_reducer_case.py > $OUT/rccl_$i.out 2> $OUT/rccl_$i.err; echo "rccl case rc=$?"; tail -3 $OUT/rccl_$i.out; grep -v "^$" $OUT/rccl_$i.err | head -30; done
+fi
 if has train; then
   timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_configs.py tests/test_gpu_trainloop.py -q 2>&1 | tail -40 > $OUT/train.log; tail -25 $OUT/train.log
 fi
 if has full; then
-  timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40 > $OUT/full.log; tail -25 $OUT/full.log
+  timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 > $OUT/full.log; tail -25 $OUT/full.log
 fi
 if has prof; then
   for v in 1 2; do
@@ -33,6 +37,15 @@ if has bench; then
     python - <<P
 import json
 d=json.load(open("$OUT/bench_v$v.json")); print("V$v train", d["value"], d["ms_per_step"], "fwd", d.get("forward", {}).get("value"))
+P
+  done
+fi
+if has ab; then
+  for combo in "EAT_FUSE_DW_BN=1 EAT_FUSE_SE_BWD=1" "EAT_FUSE_DW_BN=0 EAT_FUSE_SE_BWD=1" "EAT_FUSE_DW_BN=0 EAT_FUSE_SE_BWD=0" "EAT_FUSE_DW_BN=1 EAT_FUSE_SE_BWD=1 EAT_DW_STATS_FUSED=0" "EAT_FUSE_DW_BN=1 EAT_FUSE_SE_BWD=1 EAT_DW_GEPI_FUSED=0"; do
+    env $combo timeout 300 python bench.py --no-cpu-baseline --no-forward --no-train-configs --no-profile --steps 10 --warmup 3 > $OUT/ab.json 2> $OUT/ab.err
+    python - <<P
+import json
+d=json.load(open("$OUT/ab.json")); print("$combo ->", d["value"], "clips/s", d["ms_per_step"], "ms")
 P
   done
 fi

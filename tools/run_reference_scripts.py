@@ -53,6 +53,7 @@ def build_workdir(work, n_train=48, n_test=527):
             model.classifier[5].weight.mul_(0.05)        # keep the sigmoid outputs away from saturation
             model.classifier[5].bias.fill_(-2.0)
         torch.save(model.state_dict(), os.path.join(work, "resources", _CKPT["mn10_as"]))
+        os.environ["EAT_SYNTH_AUDIOSET"] = "1"                        # explicit opt-in to the synthetic AudioSet stand-in
         os.environ["EAT_SYNTH_AUDIOSET_TRAIN"], os.environ["EAT_SYNTH_AUDIOSET_TEST"] = str(n_train), str(n_test)
         from datasets.audioset import dataset_config, synth_name
     finally:
@@ -72,7 +73,7 @@ def build_workdir(work, n_train=48, n_test=527):
             (rng.standard_normal((len(known), 527)) * 2.0 - 5.0).astype(np.float32))
     with open(os.path.join(work, "resources", "fname_to_index.pkl"), "wb") as f:
         pickle.dump({n: i for i, n in enumerate(known)}, f)
-    return dict(EAT_SYNTH_AUDIOSET_TRAIN=str(n_train), EAT_SYNTH_AUDIOSET_TEST=str(n_test))
+    return dict(EAT_SYNTH_AUDIOSET="1", EAT_SYNTH_AUDIOSET_TRAIN=str(n_train), EAT_SYNTH_AUDIOSET_TEST=str(n_test))
 
 
 def _drop_repr(text):
