@@ -517,11 +517,15 @@ def pw_conv_dyn(x, wp_b, bias, Co, act, res=None):
 def kcat_eligible(Co, Ci, S):
     """K-concat form of a dynamic 1x1 conv (no per-sample weights) pays where a sample's aggregated weight matrix is
     larger than its activations: the late, small-plane layers.  (Ci % 32: a k-chunk must not straddle two banks.)"""
-    return _KCAT and Ci % 32 == 0 and S % 4 == 0 and Co * Ci > (Ci + Co) * S
+    # (the K-concat kernel computes on split bf16x3 operands: under precision('fp32') the per-sample path with the exact
+    #  fp32 MFMA is kept, so that `train_precision='fp32'` means what it says for every layer)
+    return _KCAT and precision.mode != "fp32" and Ci % 32 == 0 and S % 4 == 0 and Co * Ci > (Ci + Co) * S
 
 
 def kcat_pack(bank, Co, Ci, row_scale=None):
-    """bank (K, Co*Ci) -> packed bf16 hi/lo fragments of [W_0 | ... | W_{K-1}]  (Co x K*Ci)."""
+    """bank (K, Co*Ci) -> packed bf16 hi/lo fragments of [W_0 | ... | W_{K-1}]  (Co x K*Ci).
+    (Not cached across training steps: fused optimizers and hipGraph replays update the bank without moving its version
+    counter, so a version-keyed cache would serve stale weights; the eval plan caches its packs with the folded weights.)"""
     K = bank.shape[0]
     wcat = bank.view(K, Co, Ci).permute(1, 0, 2).reshape(Co, K * Ci).contiguous()
     return pw_prepack_bf16(wcat, row_scale, split=True)

@@ -71,7 +71,8 @@ def main():
         return max(float((p.grad - q.grad).abs().max()) / max(float(q.grad.abs().max()), 1e-3 * gmax)
                    for p, q in zip(model.parameters(), ref.parameters()))
     worst = worst_of(dp)
-    assert worst < 1e-4, worst           # atomics in the weight-gradient / Gram-matrix kernels: not bit-identical between runs
+    assert worst < 2e-3, worst           # atomics in the weight-gradient / Gram-matrix kernels: not bit-identical between runs
+                                         # (4 clips: a few 10^4 elements per BatchNorm channel amplify the round-off)
     # the same step captured into a hipGraph with the collectives inside
     g = make()
     g.load_state_dict(ref.state_dict())
@@ -82,7 +83,7 @@ def main():
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     worst = worst_of(g)
-    assert worst < 1e-4, worst
+    assert worst < 2e-3, worst
     print("RCCL_REDUCER_OK", flush=True)
     torch.cuda.synchronize()
     dist.destroy_process_group()
