@@ -423,6 +423,67 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 }
 
 
+// Stem weight gradient (models/mn/model.py:124-133: 3x3 / stride 2, ONE input channel, C = 16 w output channels):
+// dW[c][u][v] = sum_{b,i,j} dz[b,c,i,j] x[b,0,2i+u-1,2j+v-1].  The generic kernel above walks one channel per block and
+// gathers 9 predicated x values per dz element (710 us at B = 256 for 655 MB: 0.9 TB/s).  Here a thread owns output
+// columns, keeps the 3x3 x window of a position in registers and applies it to 16 channels at once (16 coalesced dz
+// loads per position, the window is loaded once per position and channel group), 144 accumulators per thread; one
+// wave reduction + 144 atomics per block.
+template <int CG>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                         float* __restrict__ dw, int C, int F, int T, int Fo, int To,
+                                                         int rows_per_block) {
+  __shared__ float s_red[4][CG * 9];
+  const int b = blockIdx.y;
+  const int i0 = blockIdx.x * rows_per_block;
+  const int i1 = (i0 + rows_per_block) < Fo ? (i0 + rows_per_block) : Fo;
+  const float* xb = x + (size_t)b * F * T;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += CG) {
+    float acc[CG][9];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[c][t] = 0.0f;
+    const float* gz = dz + ((size_t)b * C + c0) * Fo * To;
+    for (int i = i0; i < i1; ++i) {
+      for (int j = threadIdx.x; j < To; j += 256) {
+        float xw[9];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int fi = 2 * i + u - 1;
+          const bool rok = fi >= 0 && fi < F;
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            const int ti = 2 * j + v - 1;
+            xw[u * 3 + v] = (rok && ti >= 0 && ti < T) ? xb[(size_t)fi * T + ti] : 0.0f;
+          }
+        }
+        const size_t pos = (size_t)i * To + j;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          const float g = (c0 + c < C) ? gz[(size_t)c * Fo * To + pos] : 0.0f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(g, xw[t], acc[c][t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float v = eat::wave_sum(acc[c][t]);
+        if (lane == 0) s_red[wv][c * 9 + t] = v;
+      }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CG * 9; e += 256) {
+      const int c = e / 9;
+      if (c0 + c < C) atomicAdd(dw + (size_t)(c0 + c) * 9 + (e - c * 9), s_red[0][e] + s_red[1][e] + s_red[2][e] + s_red[3][e]);
+    }
+    __syncthreads();
+  }
+}
+
 // Column-walking variant (depthwise, XC == C): the kernel above loads K*K predicated 4-byte x values per output
 // element (25 narrow loads for a 5x5) and is bound by the texture unit at ~1.4 TB/s.  Here a thread owns one output
 // column of one (b, c) plane and walks down the rows with the K x K input window in a register ring, as the forward
@@ -1109,6 +1170,15 @@ static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int 
     else EAT_WGC(5, 2);
 #undef EAT_WGC
     return eat::check_launch("eat_dw_conv_wgrad");
+  }
+  static const bool stem_new = !(getenv("EAT_STEM_WGRAD_OLD") && atoi(getenv("EAT_STEM_WGRAD_OLD")) != 0);
+  if (XC == 1 && k == 3 && stride == 2 && !per_sample && stem_new) {
+    // ~2048 blocks: (row chunks) x (samples)
+    int rpb = (int)(((long long)Fo * B + 2047) / 2048);
+    if (rpb < 1) rpb = 1;
+    hipLaunchKernelGGL(stem_wgrad_kernel<16>, dim3((Fo + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dz, x, dw, C, F, T,
+                       Fo, To, rpb);
+    return eat::check_launch("eat_dw_conv_wgrad(stem)");
   }
   // enough blocks to fill the chip: split the batch when there are few channels
   int splits = (2048 + C - 1) / C;

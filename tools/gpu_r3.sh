@@ -53,8 +53,24 @@ if has benchfull; then
   timeout 900 python bench.py --kernel-table > $OUT/bench.json 2> $OUT/bench_table.log
   tail -c 4000 $OUT/bench.json; grep "^\[bench\]" $OUT/bench_table.log
 fi
+if has pmc; then
+  PROF_ARGS="--no-cpu-baseline --no-fp32-exact --no-train-configs --no-profile --steps 2 --warmup 1 --no-graph"
+  for pass in "f FETCH_SIZE" "w WRITE_SIZE" "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    set -- $pass; name=$1; shift
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $* -d $GRAFT_REPO_ROOT/$OUT/pmc_$name -o $name --output-format csv -- \
+        python $GRAFT_REPO_ROOT/bench.py $PROF_ARGS > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$name.log) || echo "pmc pass $name failed/timed out"
+  done
+  F=$(find $OUT/pmc_f -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py $F $W $OUT/pmc_traffic_r3.json
+  S=$(find $OUT/pmc_sq1 -name "*counter_collection.csv" | head -1)
+  python tools/pmc_sq.py $OUT/pmc_sq_r3.json $S > $OUT/pmc_sq_r3.txt 2>&1; tail -3 $OUT/pmc_sq_r3.txt
+  # the raw counter CSVs are large: keep only the reductions
+  rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq1
+fi
 if has rocprof; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats -o s --output-format csv -- \
       python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.log)
-  ls $OUT/stats | head
+  find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats.csv \;
+  find $OUT/stats -name "*_kernel_trace.csv" -delete; find $OUT/stats -name "*.db" -delete
+  ls -la $OUT/stats $OUT | head -20
 fi

@@ -4,21 +4,18 @@
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <dir_w> -o w --output-format csv -- python bench.py ...
     python tools/pmc_traffic.py <dir_f>/f_counter_collection.csv <dir_w>/w_counter_collection.csv profiles/pmc_traffic_r2.json
 
-Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half
-of the bytes of WIDE coalesced reads (16 B per lane, `global_load_dwordx4` and `global_load_lds_dwordx4` alike), so it
-is doubled - but ONLY for the kernels that read their activations that way (WIDE_READERS below); kernels that gather
-with 4- / 8-byte lanes (mbconv / front patch gathers, the sliding-window depthwise kernels, the mel front-end) keep the
-raw value (round 1 doubled everything and over-stated e.g. mbconv's traffic 1.65x).  Only the launches with the LARGEST
-grid of each kernel are averaged, i.e. the batch-256 launches of the bench and not its 4-clip parity probe.
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-reports wide reads by 2x (MI355X_MICROARCH.md, HBM
+section) - in practice every kernel of this library that reads with 8- or 16-byte lanes.  The file written here keeps the
+RAW per-launch means; bench.py applies the x2 per kernel by calibration on a known byte count (a kernel cannot fetch less
+than its compulsory input: raw FETCH below 0.75x the algorithmic read bytes => halved reading) instead of a name list.
+Only the launches with the LARGEST grid of each kernel are averaged, i.e. the batch-256 launches of the bench and not its
+4-clip parity probe.
 """
 import collections
 import csv
 import json
 import re
 import sys
-
-WIDE_READERS = ("pw_conv_kernel", "pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel", "bn_stats_kernel", "bn_act_fwd_kernel", "bn_act_bwd_reduce_kernel",
-                "bn_act_bwd_apply_kernel", "pw_wgrad_x3_kernel")
 
 
 def per_kernel(path, counter):
@@ -44,10 +41,10 @@ def main(fetch_csv, write_csv, out_json):
     w, _, _ = per_kernel(write_csv, "WRITE_SIZE")
     out = {}
     for k in sorted(f):
-        wide = k.split("<")[0] in WIDE_READERS
         out[k] = {"launches_sampled": nf[k], "grid_size": grid[k], "fetch_kib": f[k], "write_kib": w.get(k, 0.0),
-                  "fetch_x2": wide, "hbm_bytes_per_launch": int(((2.0 if wide else 1.0) * f[k] + w.get(k, 0.0)) * 1024)}
-    json.dump({"formula": "(FETCH_SIZE [x2 for 16-byte-lane readers] + WRITE_SIZE) * 1024 per launch; largest-grid launches only",
+                  "raw_bytes_per_launch": int((f[k] + w.get(k, 0.0)) * 1024)}
+    json.dump({"formula": "raw FETCH_SIZE / WRITE_SIZE (KiB) per launch, largest-grid launches only; the gfx950 x2 on "
+                          "FETCH_SIZE is applied by bench.py per kernel, calibrated on the kernel's compulsory read bytes",
                "kernels": out}, open(out_json, "w"), indent=1)
     print(f"wrote {out_json}: {len(out)} kernels")
 
