@@ -165,6 +165,36 @@ def _alg_bytes(name, a):
         else:
             sym = f"pw_wgrad_x3_kernel<{1 if mode == 2 else 3}>"
         return sym, nbytes, 2 * B * S * Co * Ci
+    if name in ("eat_pw_conv_wgrad_ws", "eat_pw_conv_wgrad_tf"):
+        if name == "eat_pw_conv_wgrad_ws":
+            dz, x, xs, dW, ws, nsl, B, Co, Ci, S, mode = a[:11]
+            tf = None
+        else:
+            dz, x, tf, tfb, tfact, xs, dW, ws, nsl, B, Co, Ci, S, mode = a[:14]
+        same = dz == x and tf is None
+        nbytes = 4 * B * S * (Co if same else Co + Ci) + 4 * Co * Ci
+        if mode == 1 or S % 4:
+            sym = "pw_wgrad_kernel"
+        elif Co <= 64 and Ci <= 64 and (Co <= 16 or Ci <= 16 or (same and Co == Ci and not xs)):
+            mt, nt = (Co + 15) // 16, (Ci + 15) // 16
+            gram = same and mt == nt and not xs
+            sym = f"pw_wgrad_x3_narrow_kernel<{mt},{nt},{'true' if gram else 'false'}>"
+        else:
+            sym = f"pw_wgrad_x3_kernel<{1 if mode == 2 else 3}>"
+        return sym, nbytes, 2 * B * S * Co * Ci
+    if name == "eat_pw_conv_tf_fwd":
+        x, ta, tb, tact, wp, wmode, bias, sc, res, y, B, Ci, Co, S, act = a[:15]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = 4 * B * S * (Ci + Co + (Co if res else 0)) + (4 if wmode != 1 else 2) * Co * Ci
+        sym = f"pw_conv_kernel<{mtw},*,true>" if wmode == 0 else f"pw_conv_bf16_kernel<{mtw},{3 if wmode == 2 else 1},*,true>"
+        return sym, nbytes, 2 * B * S * Ci * Co
+    if name == "eat_se_bn_bwd_partials":
+        B, C, S = a[6:9]
+        return "se_bn_bwd_partials_kernel", 8 * B * C * S, 12 * B * C * S
+    if name == "eat_col_sum":
+        return "col_sum_kernel", 4 * a[2] * a[3], a[2] * a[3]
     if name == "eat_dw_conv_fwd_stats":
         x, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:17]
         return f"dw_conv_fwd_stats<{k},{s}>", 4 * B * C * (F * T + Fo * To), 2 * B * C * Fo * To * k * k
@@ -310,6 +340,10 @@ def _read_bytes(name, a, nbytes):
         return 4 * a[1] * a[2]
     if name == "eat_pw_conv_wgrad":
         return nbytes - 4 * a[5] * a[6]
+    if name == "eat_pw_conv_wgrad_ws":
+        return nbytes - 4 * a[7] * a[8]
+    if name == "eat_pw_conv_wgrad_tf":
+        return nbytes - 4 * a[10] * a[11]
     if name in ("eat_bn_act_bwd_reduce", "eat_bn_stats", "eat_bn_stats_partial", "eat_plane_dot"):
         return nbytes
     if name == "eat_bn_act_bwd_apply":
