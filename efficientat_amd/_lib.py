@@ -64,6 +64,7 @@ SIGNATURES = {
     "eat_kd_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P],
     "eat_pw_conv_wgrad_ws": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_pw_conv_tf_fwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eat_pw_conv_cat_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_pw_conv_wgrad_tf": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_pw_prepack_t": [_P, _P, _P, _I, _I, _P],
     "eat_pw_prepack_bf16_t": [_P, _P, _P, _I, _I, _I, _P],
@@ -74,6 +75,8 @@ SIGNATURES = {
     "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P],
     "eat_act_grad_sum": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "eat_dw_conv_dgrad_g": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P] + [_I] * 8 + [_P],
+    "eat_dw_bwd_partials_inner": [_I] * 6,
+    "eat_dw_conv_bwd_g": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_se_bn_bwd_partials": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_se_bn_bwd_combine": [_P, _P, _P, _P, _I, _I, _P, _P],
     "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_P],

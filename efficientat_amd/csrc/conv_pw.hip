@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int kc_arg,
-    int n_stages, int act, int tps, long long wp_bstride, PwTf tf) {
+    int n_stages, int act, int tps, long long wp_bstride, PwTf tf, const float* __restrict__ x2, int c1) {
+  // x2 != NULL: channels of x (c1 rows) followed by the channels of x2 (Ci - c1 rows) - see conv_pw_bf16.hip
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int kc = PIPE ? kPipeKC : kc_arg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
   long long nl = n_base + 4 * lane;
   if (nl > N - 4) nl = N - 4;                       // clamp: garbage columns are never stored
   const int bl = (int)(nl / S), sl = (int)(nl - (long long)bl * S);
-  const float* xsrc = x + ((size_t)bl * Ci) * S + sl;
+  const float* xsrc = x + ((size_t)bl * (x2 ? c1 : Ci)) * S + sl;
+  const float* xsrc2 = x2 ? x2 + ((size_t)bl * (Ci - c1)) * S + sl : xsrc;
+  auto xrow = [&](int row) { return (x2 && row >= c1) ? xsrc2 + (size_t)(row - c1) * S : xsrc + (size_t)row * S; };
   // compute role
   const long long nc = n_base + 64 * wv + 4 * (lane & 15);
   const bool col_ok = nc < N;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
       for (int i = 0; i < kPipeKC / 4; ++i) {
         const int r = wv + 4 * i;
         const int rc = r < klen ? r : klen - 1;          // tail chunk: re-load a valid row into an unused slot
-        glds16_raw(xsrc + (size_t)(k0 + rc) * S, Xs + r * kTileN);
+        glds16_raw(xrow(k0 + rc), Xs + r * kTileN);
       }
 #pragma unroll
       for (int i = 0; i < (MTW + 3) / 4; ++i) {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
         glds4_raw(in_scale + (size_t)bb * Ci + k0 + rc, Xs + kc * kTileN);   // 64 floats reserved (NS <= 4)
       }
     } else {
-      for (int r = wv; r < klen; r += 4) glds16(xsrc + (size_t)(k0 + r) * S, Xs + r * kTileN);
+      for (int r = wv; r < klen; r += 4) glds16(xrow(k0 + r), Xs + r * kTileN);
       const int n_inst = (rows + 3) >> 2;
       for (int q = wv; q < n_inst; q += 4) {
         int row = q * 4 + (lane >> 4);
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 template <int MTW>
 int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias, const float* in_scale,
               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act,
-              bool per_sample, PwTf tf) {
+              bool per_sample, PwTf tf, const float* x2, int c1) {
   const long long N = (long long)B * S;
   const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
   const int n_tiles = per_sample ? B * tps : (int)((N + kTileN - 1) / kTileN);
@@ -358,7 +361,7 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
-                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf);
+                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf, x2, c1);
   return eat::check_launch("eat_pw_conv_fwd");
 }
 
@@ -387,7 +390,7 @@ extern "C" int eat_pw_prepack_t(const float* w_t, const float* row_scale, float*
 
 static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,
                        float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s,
-                       PwTf tf = PwTf{nullptr, nullptr, 0}) {
+                       PwTf tf = PwTf{nullptr, nullptr, 0}, const float* x2 = nullptr, int c1 = 0) {
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d must be a multiple of 4", Ci);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
   if (B < 1 || Ci < 4 || Co < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
@@ -401,7 +404,7 @@ static int pw_dispatch(const float* x, const float* wp, const float* bias, const
   // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks
   const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block
-#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf);
+#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf, x2, c1);
   switch (mtw) {
     EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4) EAT_PW_CASE(5)
     EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
@@ -433,6 +436,22 @@ extern "C" int eat_pw_conv_tf_fwd(const float* x, const float* tf_a, const float
                        (hipStream_t)stream, PwTf{tf_a, tf_b, tf_act});
   return eat::pw_conv_bf16_tf(x, tf_a, tf_b, tf_act, wp, bias, in_scale, res, y, B, Ci, Co, S, act, wmode == 2 ? 1 : 0,
                               (hipStream_t)stream);
+}
+
+// 1x1 conv over the channels of TWO tensors of the same (B, *, S) geometry: y = W [x1 ; x2] + bias (+ res), W = (Co,
+// C1 + C2) packed as usual.  Train plan: the data gradient of the expand conv with its BatchNorm correction,
+// dx = (diag(a) W)^T g + M x + c0 (eat_expand_bwd_coef), as ONE GEMM over [g ; x].  C1 % 4 == 0, C2 % 4 == 0, S % 4 == 0.
+extern "C" int eat_pw_conv_cat_fwd(const float* x1, int C1, const float* x2, int C2, const void* wp, int wmode,
+                                   const float* bias, const float* res, float* y, int B, int Co, int S, int act,
+                                   eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x1 || !x2 || C1 < 4 || C2 < 4 || C1 % 4 || C2 % 4 || S % 4)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_cat_fwd: needs C1, C2, S multiples of 4 (C1=%d, C2=%d, S=%d)", C1, C2, S);
+  if (act < 0 || act > 2 || B < 1 || Co < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_cat_fwd: bad arguments");
+  if (wmode == 0)
+    return pw_dispatch(x1, reinterpret_cast<const float*>(wp), bias, nullptr, res, y, nullptr, B, C1 + C2, Co, S, act, false,
+                       (hipStream_t)stream, PwTf{nullptr, nullptr, 0}, x2, C1);
+  return eat::pw_conv_bf16_cat(x1, C1, x2, C2, wp, bias, res, y, B, Co, S, act, wmode == 2 ? 1 : 0, (hipStream_t)stream);
 }
 
 extern "C" int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, const float* res, float* y,

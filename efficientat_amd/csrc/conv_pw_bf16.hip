@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
-    int sc_bytes, int ci_x, PwTf tf) {
+    int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1) {
+  // x2 != NULL ("two-source"): the reduction axis is the channels of x (c1 rows) followed by the channels of x2
+  // (Ci - c1 rows), both (B, *, S) - the data-gradient GEMM of the expand conv with its BatchNorm correction,
+  // dx = [WaT | M] [g ; x] (train_fuse.hip), without a separate M x launch
   // ci_x: channels of x.  ci_x == Ci: plain 1x1 conv.  ci_x < Ci ("K-concat", DyMN): the reduction axis is nbank
   // copies of x's channels, k = bank * ci_x + ci - the weights are the banks side by side, the per-(sample, k) input
   // scale carries the attention (host: ci_x % 32 == 0, so a 32-row chunk never straddles two banks)
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   unsigned nl = n_base + 4 * lane;
   if (nl > N - 4) nl = N - 4;
   const int bl = (int)(nl / (unsigned)S), sl = (int)(nl - (unsigned)bl * (unsigned)S);
-  const float* xsrc = x + ((size_t)bl * ci_x) * S + sl;
+  const float* xsrc = x + ((size_t)bl * (x2 ? c1 : ci_x)) * S + sl;
+  const float* xsrc2 = x2 ? x2 + ((size_t)bl * (Ci - c1)) * S + sl : xsrc;
   const unsigned nc = n_base + 64 * wv + 4 * (lane & 15);
   const bool col_ok = nc < N;
   const unsigned ncc = col_ok ? nc : N - 4;
@@ -109,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     for (int i = 0; i < kKC / 4; ++i) {
       const int r = wv + 4 * i;
       const int rc = r < klen ? r : klen - 1;                // padded k: finite data x zero weight
-      glds16_raw(xsrc + (size_t)(kx0 + rc) * S, Xs + r * kTileN);
+      const int row = kx0 + rc;
+      glds16_raw((x2 && row >= c1) ? xsrc2 + (size_t)(row - c1) * S : xsrc + (size_t)row * S, Xs + r * kTileN);
     }
 #pragma unroll
     for (int i = 0; i < (MTW * NP2 + 3) / 4; ++i) {
@@ -218,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 
 template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf) {
+           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf,
+           const float* x2, int c1) {
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
   const int n_tiles = (int)((N + kTileN - 1) / kTileN);
@@ -245,19 +251,20 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act, sc_bytes, ci_x, tf);
+                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
 template <int NPROD>
 int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-             float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0}) {
+             float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0},
+             const float* x2 = nullptr, int c1 = 0) {
   const int MT = (Co + 15) / 16;
   // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
   // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf);
+#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -315,6 +322,17 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
   const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
   return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, Ci, tf)
                : dispatch<1>(s, x, w16, bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, Ci, tf);
+}
+}  // namespace eat
+
+// 1x1 conv over the concatenated channels of two tensors (see the kernel's x2 / c1)
+namespace eat {
+int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const void* wp, const float* bias, const float* res,
+                     float* y, int B, int Co, int S, int act, int split, hipStream_t s) {
+  const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
+  const PwTf none{nullptr, nullptr, 0};
+  return split ? dispatch<3>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1)
+               : dispatch<1>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1);
 }
 }  // namespace eat
 

@@ -894,6 +894,246 @@ int launch_tile_wgrad(TileWgArgs a, hipStream_t s) {
   return eat::check_launch("eat_dw_conv_wgrad(tile)");
 }
 
+// ---- merged depthwise backward (round 3): weight gradient AND data gradient (+ the activation-derivative epilogue of
+// eat_dw_conv_dgrad_g) of one tile from ONE load of dz and of the pre-BN expand output x.  The two separate kernels
+// (dw_*_wgrad_kernel, dw_tile_kernel<flip> / dw_tile_dgrad2_kernel) share their ownership - lane l holds x / dx columns
+// (c, c+1) and, for stride 2, dz column c/2 - and both read dz and x: 1 pass over the expanded tensor and 1 over the
+// depthwise output less per block.  Any plane size (a small plane is one tile); G samples per wave amortise the K*K
+// cross-lane reduction of the weight gradient.
+//   dw[c][u][v] += sum dz[i][j] * act(a x + b)[i*S+u-P][j*S+v-P]                      (zero padding of the ACTIVATED map)
+//   g[i'][j']   = (sum_{u,v} w[u][v] dz[(i'+P-u)/S][(j'+P-v)/S]) * act'(a x[i'][j'] + b),   gpart = sum g per tile
+struct DwBwdArgs {
+  const float* dz; const float* x; float* g; float* dw; float* gpart;
+  int B, C, F, T, Fo, To, n_rc, n_cs, WO, G;
+  InTf tf;
+};
+
+template <int K, int S, int RO>
+__global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
+  constexpr int P = (K - 1) / 2, LPP = 64, KK = K * K;
+  constexpr int FX = S == 1 ? RO + 2 * P : 2 * RO + 2 * P - 1;     // x rows of a tile (with halo)
+  constexpr int FD = S == 1 ? RO + 2 * P : RO + 2;                 // dz rows of a tile (with halo)
+  constexpr int DOFF = S == 1 ? P : 1;                             // dz-array index of the tile's first dz row
+  constexpr int ND = S == 1 ? 2 : 1;                               // dz columns per lane
+  constexpr int NE = S == 1 ? 2 + 2 * P : K;                       // extended x row: columns under the filter
+  const int l = threadIdx.x & 63;
+  const bool first = l == 0, last = l == 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int tpp = a.n_rc * a.n_cs;
+  const int n_sg = (a.B + a.G - 1) / a.G;
+  if (wave >= n_sg * a.C * tpp) return;
+  const int pc = wave / tpp, t = wave - pc * tpp;
+  const int sg = pc / a.C, c = pc - sg * a.C;
+  const int rc = t / a.n_cs, cs = t - rc * a.n_cs;
+  const int F = a.F, T = a.T, Fo = a.Fo, To = a.To;
+  // strip: S == 1 over dx (= x) columns, S == 2 over dz columns; lane 0 (and 63) are halo lanes
+  const int s_lo = cs * a.WO, s_hi = (s_lo + a.WO) < (S == 1 ? T : To) ? (s_lo + a.WO) : (S == 1 ? T : To);
+  const int q = s_lo - 1 + l;                                       // S == 2: dz column of this lane
+  const int col_in = S == 1 ? s_lo - 2 + 2 * l : 2 * q;             // first of the lane's two x / dx columns
+  const unsigned vin = (col_in >= 0 && col_in < T) ? 4u * (unsigned)col_in : kOOB;
+  const bool in_part = col_in + 1 >= T;
+  const bool v0 = vin != kOOB, v1 = v0 && !in_part;
+  // which of the lane's positions belong to the strip (produce output / contribute to the weight gradient)
+  const bool ok0 = S == 1 ? (col_in >= s_lo && col_in < s_hi) : (q >= s_lo && q < s_hi);
+  const bool ok1 = S == 1 ? (col_in + 1 >= s_lo && col_in + 1 < s_hi) : (ok0 && 2 * q + 1 < T);
+  const unsigned vdz = S == 1 ? vin : ((q >= 0 && q < To) ? 4u * (unsigned)q : kOOB);
+  // dx stores: an 8-byte store when both columns exist, else a single dword for the first
+  const unsigned vo2 = (ok0 && ok1) ? 4u * (unsigned)col_in : kOOB, vo1 = (ok0 && !ok1) ? 4u * (unsigned)col_in : kOOB;
+  const int r0 = rc * RO;                                           // first dx row (S == 1) / dz row (S == 2) of the tile
+  const int x0 = S == 1 ? r0 - P : 2 * r0 - P;                      // global row of x-array index 0
+  const int d0 = r0 - DOFF;                                         // global row of dz-array index 0
+
+  float wk[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) wk[i] = w_[(size_t)c * KK + i];
+  const TfCoef tk = tf_coef(a.tf, c);
+  float acc[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) acc[i] = 0.0f;
+
+  for (int gi = 0; gi < a.G; ++gi) {
+    const int b = sg * a.G + gi;
+    if (b >= a.B) break;                                            // wave-uniform
+    const int p = b * a.C + c;
+    const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
+    const long long z_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * Fo * To, z_left);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.g + (size_t)p * F * T, x_left);
+    float xu[FX][2], dd[FD][ND];
+#pragma unroll
+    for (int i = 0; i < FX; ++i) {
+      const int rin = x0 + i;
+      const bool rok = rin >= 0 && rin < F;                         // wave-uniform
+      const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
+      xu[i][0] = pv[0];
+      xu[i][1] = pv[1];
+    }
+#pragma unroll
+    for (int i = 0; i < FD; ++i) {
+      const int rin = d0 + i;
+      const bool rok = rin >= 0 && rin < Fo;
+      if constexpr (ND == 2) {
+        const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+        dd[i][0] = pv[0];
+        dd[i][1] = in_part ? 0.0f : pv[1];
+      } else {
+        dd[i][0] = buf_load(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+      }
+    }
+    // u = a x + b inside the plane, 0 outside: act(0) = 0 for every supported activation, i.e. the zero padding of the
+    // ACTIVATED map; y = act(u) is evaluated where the extended rows are built, act'(u) in the epilogue
+#pragma unroll
+    for (int i = 0; i < FX; ++i) {
+      const bool rok = x0 + i >= 0 && x0 + i < F;
+      xu[i][0] = (rok && v0) ? fmaf(tk.a, xu[i][0], tk.b) : 0.0f;
+      xu[i][1] = (rok && v1) ? fmaf(tk.a, xu[i][1], tk.b) : 0.0f;
+    }
+
+    // ---- weight gradient: dz of the tile's own rows / strip columns times the extended rows of y
+    {
+      float ext[FX][NE];
+#pragma unroll
+      for (int i = 0; i < RO; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = i == 0 ? 0 : (i - 1) * S + K;
+        const int hi = i * S + K - 1;
+#pragma unroll
+        for (int rr = 0; rr < FX; ++rr) {
+          if (rr < lo || rr > hi) continue;
+#pragma unroll
+          for (int tt = 0; tt < NE; ++tt) {
+            const int o = tt - P;
+            const int qq = o >= 0 ? o / 2 : -((-o + 1) / 2);
+            const int idx = o - qq * 2;
+            float v = xu[rr][idx];
+            v = fmaxf(v, tk.lo) * __builtin_amdgcn_fmed3f(fmaf(v, tk.ca, tk.cb), 0.0f, 1.0f);      // y = act(u)
+            if (qq == -1) v = from_prev<LPP>(v, first);
+            if (qq == 1) v = from_next<LPP>(v, last);
+            ext[rr][tt] = v;
+          }
+        }
+        const bool rowok = r0 + i < Fo;                             // wave-uniform (S == 1: Fo == F)
+        float dm[ND];
+        dm[0] = (rowok && ok0) ? dd[i + DOFF][0] : 0.0f;
+        if constexpr (ND == 2) dm[1] = (rowok && ok1) ? dd[i + DOFF][1] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+#pragma unroll
+          for (int v = 0; v < K; ++v)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) acc[u * K + v] = fmaf(dm[j], ext[i * S + u][j + v], acc[u * K + v]);
+      }
+    }
+
+    // ---- data gradient of the tile + derivative epilogue
+    float psum = 0.0f;
+    if constexpr (S == 1) {
+      float ext[FD][NE];
+#pragma unroll
+      for (int i = 0; i < RO; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = i == 0 ? 0 : (i - 1) + K;
+        const int hi = i + K - 1;
+#pragma unroll
+        for (int rr = 0; rr < FD; ++rr) {
+          if (rr < lo || rr > hi) continue;
+#pragma unroll
+          for (int tt = 0; tt < NE; ++tt) {
+            const int o = tt - P;
+            const int qq = o >= 0 ? o / 2 : -((-o + 1) / 2);
+            const int idx = o - qq * 2;
+            float v = dd[rr][idx];
+            if (qq == -1) v = from_prev<LPP>(v, first);
+            if (qq == 1) v = from_next<LPP>(v, last);
+            ext[rr][tt] = v;
+          }
+        }
+        float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+#pragma unroll
+          for (int v = 0; v < K; ++v) {                             // correlation with the flipped taps
+            o0 = fmaf(wk[KK - 1 - (u * K + v)], ext[i + u][v], o0);
+            o1 = fmaf(wk[KK - 1 - (u * K + v)], ext[i + u][1 + v], o1);
+          }
+        o0 *= act_deriv(xu[i + P][0], a.tf.act);
+        o1 *= act_deriv(xu[i + P][1], a.tf.act);
+        const int row = r0 + i;
+        const bool rowok = row < F;
+        const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
+        buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
+        buf_store(o0, rg, rowok ? vo1 : kOOB, so);
+        psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
+      }
+    } else {
+      float z[FD][3];
+#pragma unroll
+      for (int i = 0; i < FD; ++i) {
+        z[i][1] = dd[i][0];
+        z[i][0] = from_prev<LPP>(dd[i][0], first);
+        z[i][2] = from_next<LPP>(dd[i][0], last);
+      }
+#pragma unroll
+      for (int i = 0; i < RO; ++i) {                                // dz row r0 + i -> dx rows 2 (r0 + i), + 1
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+          float o[2];
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+              if ((pa + P - u) & 1) continue;
+              const int dr = (pa + P - u) / 2;
+#pragma unroll
+              for (int v = 0; v < K; ++v) {
+                if ((pb + P - v) & 1) continue;
+                const int dc = (pb + P - v) / 2;
+                sacc = fmaf(wk[u * K + v], z[i + 1 + dr][1 + dc], sacc);
+              }
+            }
+            o[pb] = sacc * act_deriv(xu[2 * i + pa + P][pb], a.tf.act);
+          }
+          const int row = 2 * (r0 + i) + pa;
+          const bool rowok = row < F;
+          const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
+          buf_store2(o[0], o[1], rg, rowok ? vo2 : kOOB, so);
+          buf_store(o[0], rg, rowok ? vo1 : kOOB, so);
+          psum += ((rowok && ok0) ? o[0] : 0.0f) + ((rowok && ok1) ? o[1] : 0.0f);
+        }
+      }
+    }
+    psum = eat::wave_sum(psum);
+    if (l == 0) a.gpart[(size_t)p * tpp + t] = psum;
+  }
+  // one cross-lane reduction of the K*K weight-gradient sums per wave, then K*K atomics
+  float mine_v = 0.0f;
+#pragma unroll
+  for (int i = 0; i < KK; ++i) {
+    const float v = eat::wave_sum(acc[i]);
+    mine_v = l == i ? v : mine_v;
+  }
+  if (l < KK) atomicAdd(a.dw + (size_t)c * KK + l, mine_v);
+}
+
+template <int K, int S, int RO>
+int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
+  constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : 62;
+  const int n_cols = S == 1 ? a.T : a.To, n_rows = S == 1 ? a.F : a.Fo;
+  a.n_cs = (n_cols + WMAX - 1) / WMAX;
+  a.WO = (n_cols + a.n_cs - 1) / a.n_cs;
+  a.n_rc = (n_rows + RO - 1) / RO;
+  int G = 8;
+  while (G > 1 && (long long)a.C * a.n_rc * a.n_cs * ((a.B + G - 1) / G) < 8192) G >>= 1;
+  a.G = G;
+  const long long waves = (long long)((a.B + G - 1) / G) * a.C * a.n_rc * a.n_cs;
+  if (waves > 0x7fffffffLL) return 1;
+  *h_inner = a.n_rc * a.n_cs;
+  hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, w);
+  return eat::check_launch("eat_dw_conv_bwd_g");
+}
+
 template <int K, int S, int CPL, int LPP, int F>
 int launch_plane_wgrad(const PlaneWgArgs& a0, hipStream_t s) {
   PlaneWgArgs a = a0;
@@ -968,6 +1208,20 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
   return 1;
 }
 
+int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
+               float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
+               hipStream_t s) {
+  static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
+  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
+  DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act}};
+  if (stride == 1 && (Fo != F || To != T)) return 1;
+  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 8>(a, w, h_inner, s);      // (RO = 16 needs 246 VGPRs)
+  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 8>(a, w, h_inner, s);
+  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 8>(a, w, h_inner, s);
+  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 8>(a, w, h_inner, s);
+  return 1;
+}
+
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi_) {
   static const int on = getenv("EAT_DWP_DGRAD2") ? atoi(getenv("EAT_DWP_DGRAD2")) : 1;
@@ -981,6 +1235,14 @@ int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float*
 }
 
 }  // namespace eat
+
+// Partial slots per plane of the merged backward kernel (eat_dw_conv_bwd_g)
+extern "C" int eat_dw_bwd_partials_inner(int F, int T, int Fo, int To, int k, int stride) {
+  const int wmax = stride == 1 ? (k == 3 ? 125 : 124) : 62;
+  const int n_cols = stride == 1 ? T : To, n_rows = stride == 1 ? F : Fo;
+  const int ro = 8;
+  return ((n_cols + wmax - 1) / wmax) * ((n_rows + ro - 1) / ro);
+}
 
 // Upper bound of the partial slots per plane the training epilogues write (the host sizes its buffers with it):
 // dgrad == 0: forward conv (F,T) -> (Fo,To); dgrad == 1: data gradient of that conv (dz (Fo,To) -> dx (F,T)).

@@ -76,6 +76,9 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
                     const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S, int act, int split,
                     hipStream_t s);
 
+int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const void* wp, const float* bias, const float* res,
+                     float* y, int B, int Co, int S, int act, int split, hipStream_t s);
+
 // conv_pw_stream.hip: barrier-free bf16 1x1 kernels (x or the output tile resident in registers); returns 1 when the
 // shape / the EAT_PW_STREAM switch leaves the layer to conv_pw_bf16.hip
 int pw_stream_try(const float* x, const void* wp, const float* bias, const float* in_scale, const float* res, float* y,
@@ -91,6 +94,11 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
                  const float* in_b, int in_act, hipStream_t s, const DwEpi* epi = nullptr);
 int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
                        int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s);
+// merged depthwise backward (dw_plane.hip): weight gradient + data gradient + activation-derivative epilogue in one pass;
+// returns 1 when switched off (EAT_DW_BWD_MERGED=0) or the geometry is out of range
+int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
+               float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
+               hipStream_t s);
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
 int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,

@@ -1211,6 +1211,31 @@ extern "C" int eat_dw_conv_wgrad_tf(const float* dz, const float* x, const float
   return dw_wgrad_impl(dz, x, dw, B, C, C, F, T, Fo, To, k, stride, 0, stream, in_a, in_b, in_act);
 }
 
+// Backward of the depthwise conv of an inverted-residual block in ONE pass (autograd of models/mn/block_types.py:150-162
+// + the first half of the backward of the expand conv's BatchNorm + activation): from dz (B,C,Fo,To) and the pre-BN expand
+// output x (B,C,F,T) with its BN affine (in_a, in_b) and activation in_act
+//   dw (C,k,k) += weight gradient w.r.t. the conv input act(in_a x + in_b)            [dw zeroed by the caller]
+//   g (B,C,F,T) = dgrad(dz) * act'(in_a x + in_b),   gpart [B][C][inner] = per-tile sums of g
+// = eat_dw_conv_wgrad_tf + eat_dw_conv_dgrad_g with dz and x read once.  inner_cap >= eat_dw_bwd_partials_inner(...)
+// AND >= eat_dw_partials_inner(..., 1) (the two-kernel fallback writes its own layout); *h_inner receives inner.
+extern "C" int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act,
+                                 const float* w, float* g, float* dw, float* gpart, int inner_cap, int* h_inner, int B,
+                                 int C, int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!in_a || !in_b || !gpart || !h_inner) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_g: in_a, in_b, gpart, h_inner are required");
+  if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_g: bad act %d", in_act);
+  if (inner_cap < eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride) || inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 1))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_g: partial buffer too small (inner_cap %d)", inner_cap);
+  if ((k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+    const int rc = eat::dw_bwd_try(dz, x, in_a, in_b, in_act, w, g, dw, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
+                                   (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  int rc = dw_wgrad_impl(dz, x, dw, B, C, C, F, T, Fo, To, k, stride, 0, stream, in_a, in_b, in_act);
+  if (rc != 0) return rc;
+  return eat_dw_conv_dgrad_g(dz, w, x, in_a, in_b, in_act, g, gpart, inner_cap, h_inner, B, C, F, T, Fo, To, k, stride, stream);
+}
+
 extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T, int Fo,
                                      int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();

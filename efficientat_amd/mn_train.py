@@ -256,7 +256,14 @@ class MNTrainFunction(torch.autograd.Function):
             del dxs
             g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
             y_e = rec["y_e"]
-            if y_e is None:             # fused expand-BN: the depthwise input is act(a z_e + b), evaluated on load
+            merged = None
+            if y_e is None and v2 and _MERGED_DW_BWD:
+                # weight gradient, data gradient and the activation-derivative epilogue from ONE pass over dz_d and z_e
+                st_e = rec["st_e"]
+                merged = ops.dw_conv_bwd_g(dz_d, cna[0].weight.reshape(-1, k * k), rec["z_e"], st_e[0], st_e[1], act, k, cnf.stride)
+                g[f"{pre}.{blk.i_dw}.0.weight"] = merged[2].view_as(cna[0].weight)
+                in_shape = tuple(rec["z_e"].shape)
+            elif y_e is None:           # fused expand-BN: the depthwise input is act(a z_e + b), evaluated on load
                 st_e = rec["st_e"]
                 g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad_tf(dz_d, rec["z_e"], st_e[0], st_e[1], act, k,
                                                                        cnf.stride).view_as(cna[0].weight)
@@ -271,8 +278,11 @@ class MNTrainFunction(torch.autograd.Function):
                 st_e = rec["st_e"]
                 cna_e = blk.block[blk.i_expand]
                 W = cna_e[0].weight.flatten(1)
-                g_e, gparts = ops.dw_conv_dgrad_g(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
-                                                  rec["z_e"], st_e[0], st_e[1], act)
+                if merged is not None:
+                    g_e, gparts = merged[0], merged[1]
+                else:
+                    g_e, gparts = ops.dw_conv_dgrad_g(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
+                                                      rec["z_e"], st_e[0], st_e[1], act)
                 del dz_d
                 Gx = ops.pw_conv_wgrad(g_e, inp)
                 frozen = getattr(st_e[2], "_eat_frozen", False)
@@ -282,11 +292,17 @@ class MNTrainFunction(torch.autograd.Function):
                                                                  frozen=frozen)
                 g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
                 g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
-                t = res_grad
-                if not frozen:                                                      # M x + c0 (+ residual-branch gradient)
-                    t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
-                dout = ops.pw_conv(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
-                                   NONE, res=t)
+                S_e = inp.shape[2] * inp.shape[3]
+                if not frozen and _CAT_DGRAD and S_e % 4 == 0:
+                    # dx = [WaT | M] [g ; x] + c0 (+ residual-branch gradient): one GEMM over both tensors
+                    wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
+                    dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad)
+                else:
+                    t = res_grad
+                    if not frozen:                                                  # M x + c0 (+ residual-branch gradient)
+                        t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
+                    dout = ops.pw_conv(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
+                                       NONE, res=t)
                 del g_e
                 sv["blocks"][i] = None
                 continue
@@ -330,6 +346,9 @@ _FUSE_SE_BWD = os.environ.get("EAT_FUSE_SE_BWD", "1") == "1"     # A/B: gate gra
 # A/B: BatchNorm + activation (+ SE scale) of the depthwise output evaluated on load inside the project conv and its
 # weight gradient - the activated tensor y_d is never written (SE blocks: one read-only pass for the squeeze sums)
 _FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
+# A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
+_MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
+_CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
 
 
 class MNTrainFunction2(torch.autograd.Function):

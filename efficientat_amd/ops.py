@@ -346,6 +346,18 @@ def pw_conv_tf(x, tf, wp, bias, Co, act, in_scale=None, res=None):
     return y
 
 
+def pw_conv_cat(x1, x2, wp, bias, Co, act, res=None):
+    """1x1 conv over the concatenated channels of x1 (B,C1,F,T) and x2 (B,C2,F,T) without materialising the concatenation;
+    wp = pw_prepack of the (Co, C1 + C2) matrix."""
+    B, C1, F, T = x1.shape
+    C2 = x2.shape[1]
+    wmode = 0 if wp.dtype == torch.float32 else (2 if getattr(wp, "_eat_split", False) else 1)
+    y = torch.empty((B, Co, F, T), device=x1.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_cat_fwd", _dev(x1, "x"), C1, _dev(x2, "x2"), C2, wp.data_ptr(), wmode, _dev(bias, "bias"),
+              _opt(res, "res"), y.data_ptr(), B, Co, F * T, act, _stream())
+    return y
+
+
 def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None):
     """dW (Co, Ci) = sum_b dz[b] (Co,S) . (x[b] * x_scale[b])^T.  exact=True: fp32 MFMA kernel; False: split-operand
     bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact, 'bf16' -> plain bf16
@@ -460,6 +472,23 @@ def dw_conv_dgrad_g(dz, w, x_shape, k, stride, gz, ga, gb, gact):
     _lib.call("eat_dw_conv_dgrad_g", _dev(dz, "dz"), _dev(w, "w"), _dev(gz, "gz"), ga.data_ptr(), gb.data_ptr(), gact,
               g.data_ptr(), gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
     return g, (gpart, B, inner.value)
+
+
+def dw_conv_bwd_g(dz, w, x, in_a, in_b, in_act, k, stride):
+    """Merged depthwise backward: -> (g, (gpart, B, inner), dw) with g = dgrad(dz) * act'(in_a x + in_b) and dw the weight
+    gradient w.r.t. the conv input act(in_a x + in_b); dz and x are read once (csrc/dw_plane.hip: dw_bwd_tile_kernel)."""
+    B, C, F, T = x.shape
+    Fo, To = dz.shape[2], dz.shape[3]
+    h = _lib.lib()
+    cap = max(int(h.eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride)), dw_partials_inner(F, T, Fo, To, k, stride, True))
+    g = torch.empty((B, C, F, T), device=dz.device, dtype=torch.float32)
+    gpart = torch.empty((B * C * cap,), device=dz.device, dtype=torch.float32)
+    dw = zero_arena.zeros((C, k * k), torch.float32, dz.device)
+    inner = _ct.c_int(0)
+    _lib.call("eat_dw_conv_bwd_g", _dev(dz, "dz"), _dev(x, "x"), in_a.data_ptr(), in_b.data_ptr(), in_act, _dev(w, "w"),
+              g.data_ptr(), dw.data_ptr(), gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride,
+              _stream())
+    return g, (gpart, B, inner.value), dw
 
 
 def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False):

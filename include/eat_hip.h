@@ -208,6 +208,17 @@ int eat_dw_conv_dgrad_g(const float* dz, const float* w, const float* gz, const 
                         float* g, float* gpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To,
                         int k, int stride, eat_stream_t stream);
 
+/* Partial slots per plane of eat_dw_conv_bwd_g's merged kernel (host helper). */
+int eat_dw_bwd_partials_inner(int F, int T, int Fo, int To, int k, int stride);
+
+/* Backward of the depthwise conv (autograd of models/mn/block_types.py:150-162) in ONE pass over dz (B,C,Fo,To) and the
+ * pre-BN expand output x (B,C,F,T): dw (C,k,k) += weight gradient w.r.t. act(in_a x + in_b) [dw zeroed by the caller],
+ * g = dgrad(dz) * act'(in_a x + in_b) and its per-tile sums gpart [B][C][inner] - i.e. eat_dw_conv_wgrad_tf +
+ * eat_dw_conv_dgrad_g with every tensor read once.  inner_cap >= max(eat_dw_bwd_partials_inner, eat_dw_partials_inner(.., 1)). */
+int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                      float* g, float* dw, float* gpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo,
+                      int To, int k, int stride, eat_stream_t stream);
+
 /* Backward of conv1x1 (W: Co x Ci) -> BatchNorm(train) -> act WITHOUT forming dz (autograd of block_types.py:138-147):
  * with g as above, Gx = sum g x^T (eat_pw_conv_wgrad(g, x)), Tm = W G, sx, the forward's (a, mean, invstd):
  *   dgamma = invstd (rowsum(W .* Gx) - mean S1), dbeta = S1 = sum gpart, m1 = S1/n, m2 = dgamma/n (0 when frozen)
@@ -253,6 +264,12 @@ int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float* x_scale, 
 int eat_pw_conv_tf_fwd(const float* x, const float* tf_a, const float* tf_b, int tf_act, const void* wp, int wmode,
                        const float* bias, const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S,
                        int act, eat_stream_t stream);
+
+/* 1x1 conv over the channels of TWO tensors x1 (B,C1,S), x2 (B,C2,S): y = W [x1 ; x2] + bias (+ res), W (Co, C1+C2) packed
+ * by eat_pw_prepack / eat_pw_prepack_bf16 (wmode as in eat_pw_conv_tf_fwd).  Train plan: autograd of the expand conv
+ * (models/mn/block_types.py:138-147) with its BatchNorm correction, dx = [WaT | M] [g ; x] + c0, as one GEMM. */
+int eat_pw_conv_cat_fwd(const float* x1, int C1, const float* x2, int C2, const void* wp, int wmode, const float* bias,
+                        const float* res, float* y, int B, int Co, int S, int act, eat_stream_t stream);
 
 /* Weight gradient of that conv: dW = sum dz (act_in(tf_a x + tf_b) * x_scale)^T with the transform on load. */
 int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float* tf_a, const float* tf_b, int tf_act,

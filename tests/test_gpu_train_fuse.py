@@ -214,3 +214,47 @@ def test_project_conv_with_bn_act_on_load(B, Ci, Co, F_, T, act, se, mode):
             x64 = x64 * sc.double()[:, :, None, None]
         assert _rel(got, F.conv2d(x64, W.double()[:, :, None, None])) < 1e-5
         assert _rel(dW, torch.einsum("bofs,bifs->oi", dz.double(), x64)) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s,act", [g for g in GEOMS if g[6] != 0] + [(9, 40, 16, 125, 5, 1, 2), (3, 8, 64, 500, 5, 2, 1)])
+def test_dw_conv_backward_merged_kernel(B, C, F_, T, k, s, act):
+    """eat_dw_conv_bwd_g: weight gradient w.r.t. act(a x + b), data gradient times act'(a x + b) and its sums from one
+    pass, against fp64 autograd of F.conv2d over the activated map (models/mn/block_types.py:138-162 in train mode)."""
+    p = (k - 1) // 2
+    Fo, To = (F_ + 2 * p - k) // s + 1, (T + 2 * p - k) // s + 1
+    x = _rand(B, C, F_, T, seed=1, scale=2.5)                              # pre-BN expand output (spans the kinks)
+    ia, ib = torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5, _rand(C, seed=6, scale=0.3)
+    w = _rand(C, 1, k, k, seed=2, scale=0.3)
+    dz = _rand(B, C, Fo, To, seed=3)
+    u = (x.double() * ia.double()[None, :, None, None] + ib.double()[None, :, None, None]).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    y = ACTS[act](u)
+    F.conv2d(y, wr, None, s, p, 1, C).backward(dz.double())
+    g_ref = u.grad                                                          # = dgrad(dz) * act'(u)
+    dw_ref = wr.grad.reshape(C, k * k)
+    g, (gpart, outer, inner), dw = ops.dw_conv_bwd_g(dz.to(DEV), w.reshape(C, k * k).contiguous().to(DEV), x.to(DEV),
+                                                     ia.to(DEV), ib.to(DEV), act, k, s)
+    assert _rel(g, g_ref) < 3e-6
+    assert _rel(dw, dw_ref) < 2e-5
+    sums = gpart[:B * C * inner].view(B, C, inner).sum(2)
+    ref_s = g_ref.sum((2, 3))
+    assert float((sums.cpu().double() - ref_s).abs().max()) < 1e-4 * max(1.0, float(ref_s.abs().max()))
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,F_,T", [(3, 64, 16, 16, 64, 500), (4, 72, 24, 24, 32, 250), (5, 120, 40, 40, 16, 125),
+                                             (6, 672, 112, 112, 8, 63), (70, 960, 160, 160, 4, 32), (2, 24, 8, 8, 9, 20)])
+@pytest.mark.parametrize("mode", ["fp32", "auto", "bf16"])
+def test_two_source_pointwise_conv(B, C1, C2, Co, F_, T, mode):
+    """eat_pw_conv_cat_fwd: W [x1 ; x2] + bias + res == the 1x1 conv over the materialised concatenation."""
+    x1, x2 = _rand(B, C1, F_, T, seed=1), _rand(B, C2, F_, T, seed=2)
+    W = _rand(Co, C1 + C2, seed=3, scale=(C1 + C2) ** -0.5)
+    bias, res = _rand(Co, seed=4, scale=0.3), _rand(B, Co, F_, T, seed=5)
+    x1d, x2d, Wd, bd, rd = x1.to(DEV), x2.to(DEV), W.to(DEV), bias.to(DEV), res.to(DEV)
+    with ops.precision(mode):
+        wp = ops.pw_prepack(Wd)
+        ref = ops.pw_conv(torch.cat([x1d, x2d], 1).contiguous(), wp, bd, Co, ops.ACT_NONE, res=rd)
+        got = ops.pw_conv_cat(x1d, x2d, wp, bd, Co, ops.ACT_NONE, res=rd)
+    assert _rel(got, ref) < 1e-6, _rel(got, ref)
+    if mode == "fp32":
+        ref64 = F.conv2d(torch.cat([x1, x2], 1).double(), W.double()[:, :, None, None], bias.double()) + res.double()
+        assert _rel(got, ref64) < 1e-5
