@@ -1213,6 +1213,11 @@ int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* 
                hipStream_t s) {
   static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
   if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
+  // Measured (MI355X, B = 256): the merged kernel wins on the LARGE planes (64x500 -> 32x250: 1.03 vs 1.47 ms, 32x250:
+  // 0.35 vs 0.53 ms) and loses on the small late-layer planes, where the whole-plane kernels pack one or two planes per
+  // wave with every lane busy (4x32 planes: 0.69 vs 0.35 ms; a wave of this kernel would use 18 of its 64 lanes)
+  static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
+  if (T <= t_min) return 1;
   DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act}};
   if (stride == 1 && (Fo != F || To != T)) return 1;
   if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 8>(a, w, h_inner, s);      // (RO = 16 needs 246 VGPRs)

@@ -17,6 +17,12 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // Optional transform of the x operand of the 1x1 weight gradient: x' = act(a[ci] * x + b[ci]) evaluated on load (training:
 // the project conv read BN + act of the depthwise output on load, so the activated tensor does not exist; mn_train.py)
 struct WgTf { const float* a; const float* b; int act; };
+// atomic add on a pointer KNOWN to be global memory (hipcc cannot always infer the address space of a pointer offset by a
+// run-time slot index, and its expansion of a flat fp32 atomic fails on gfx950: "Operand has incorrect register class")
+__device__ __forceinline__ void global_atomic_add(float* p, float v) {
+  typedef __attribute__((address_space(1))) float gfloat;
+  __hip_atomic_fetch_add((gfloat*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // branch-free: act(u) = max(u, lo) * clamp(u * ca + cb, 0, 1) with (lo, ca, cb) = none (-inf, 0, 1), ReLU (0, 0, 1),
 // Hardswish (-inf, 1/6, 1/2) - the weight-gradient kernels are VALU-bound on the bf16 hi/lo split already
 __device__ __forceinline__ float wg_tf(float v, float a, float b, int act) {
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_col_kernel(const float* __restri
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                        const float* __restrict__ xscale, float* __restrict__ dW,
                                                        int B, int Co, int Ci, int S, int b_per_block, int per_sample,
-                                                       WgTf tf) {
+                                                       WgTf tf, int n_slots) {
   __shared__ float s_red[3][4][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
         const int m = m0 + 16 * i + kq * 4 + r, n = n0 + 16 * j + row;   // C/D: col = lane&15, row = kq*4+r
         if (m < Co && n < Ci) {
           const int q = i * 2 + j;
-          atomicAdd(dW + (per_sample ? (size_t)b0 * Co * Ci : 0) + (size_t)m * Ci + n,
+          global_atomic_add(dW + (size_t)(per_sample ? (unsigned)b0 : blockIdx.z % (unsigned)(n_slots > 0 ? n_slots : 1)) * Co * Ci + (size_t)m * Ci + n,
                     acc[i][j][r] + s_red[0][q][r][lane] + s_red[1][q][r][lane] + s_red[2][q][r][lane]);
         }
       }
@@ -696,7 +702,7 @@ template <int NPROD>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                              const float* __restrict__ xscale, float* __restrict__ dW,
                                                              int B, int Co, int Ci, int S, int sps, int units_per_block,
-                                                             int per_sample, WgTf tf) {
+                                                             int per_sample, WgTf tf, int n_slots) {
   // stage = [A: 128 rows x 128 B][B: 128 rows x 128 B] = 32 KB; 2 stages
   __shared__ __attribute__((aligned(16))) float s_op[2][2][128 * 32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -713,6 +719,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
   const bool active = mt_n > 0 && nt_n > 0;                        // idle waves still help with the loads
   // Gram matrix (dz == x, train_fuse.hip): a diagonal block's two operand tiles are the same rows - one DMA, one LDS tile
   const bool same_tile = dz == x && mb == nb && !xscale;
+  // n_slots > 0: dW is a zero-filled workspace of n_slots copies, block z adds into copy z % n_slots (one block per copy
+  // when n_slots == gridDim.z: bit-reproducible, reduced in a fixed order by wgrad_slot_reduce_kernel)
+  const unsigned out_slot = per_sample ? (unsigned)(blockIdx.z * units_per_block / sps) : blockIdx.z % (unsigned)(n_slots > 0 ? n_slots : 1);
+  const size_t out_off = (size_t)__builtin_amdgcn_readfirstlane((int)out_slot) * Co * Ci;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -773,11 +783,13 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
       // fragment of (row, kg): global chunks 2kg and 2kg+1 of that row, stored at the swizzled slots
       const int s_lo = st * 32 + 8 * kg;
       const bool k0 = s_lo < S, k1 = s_lo + 4 < S;
-      auto frag = [&](const float* tile, int row_in_tile, bool row_ok, float scale, bf16x8_t& hi, bf16x8_t& lo,
+      auto frag = [&](int which, int row_in_tile, bool row_ok, float scale, bf16x8_t& hi, bf16x8_t& lo,
                       bool xf = false, float fa = 1.0f, float fb = 0.0f) {
+        // (indexed, not passed as a pointer: a generic pointer to LDS makes hipcc emit a flat-address check that its gfx950
+        //  back end rejects - "Operand has incorrect register class")
         const int sw = (row_in_tile >> 1) & 7;
-        float4 t0 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg) ^ sw));
-        float4 t1 = *reinterpret_cast<const float4*>(tile + row_in_tile * 32 + 4 * ((2 * kg + 1) ^ sw));
+        float4 t0 = *reinterpret_cast<const float4*>(&s_op[stage][which][row_in_tile * 32 + 4 * ((2 * kg) ^ sw)]);
+        float4 t1 = *reinterpret_cast<const float4*>(&s_op[stage][which][row_in_tile * 32 + 4 * ((2 * kg + 1) ^ sw)]);
         if (xf) {                                                  // block-uniform
           t0.x = wg_tf(t0.x, fa, fb, tf.act); t0.y = wg_tf(t0.y, fa, fb, tf.act); t0.z = wg_tf(t0.z, fa, fb, tf.act); t0.w = wg_tf(t0.w, fa, fb, tf.act);
           t1.x = wg_tf(t1.x, fa, fb, tf.act); t1.y = wg_tf(t1.y, fa, fb, tf.act); t1.z = wg_tf(t1.z, fa, fb, tf.act); t1.w = wg_tf(t1.w, fa, fb, tf.act);
@@ -801,14 +813,14 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = nw + 16 * j + r;
-        frag(&s_op[stage][same_tile ? 0 : 1][0], row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j], tf.a != nullptr, tfa[j], tfb[j]);
+        frag(same_tile ? 0 : 1, row, j < nt_n && nb + row < Ci, sc[j], bh[j], bl[j], tf.a != nullptr, tfa[j], tfb[j]);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < mt_n) {
           const int row = mw + 16 * i + r;
           bf16x8_t ah, al;
-          frag(&s_op[stage][0][0], row, mb + row < Co, 1.0f, ah, al);
+          frag(0, row, mb + row < Co, 1.0f, ah, al);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (j < nt_n) {
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
     b = bn; st = stn; stage ^= 1;
   }
   if (!active) return;
-  float* out = dW + (per_sample ? (size_t)(u0 / sps) * Co * Ci : 0);
+  float* out = dW + out_off;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
         if (i < mt_n && j < nt_n && m < Co && n < Ci) {
           // per-sample gradients: the block covered the sample's whole k range - a plain store, no read-modify-write
           if (per_sample) out[(size_t)m * Ci + n] = acc[i][j][q];
-          else atomicAdd(out + (size_t)m * Ci + n, acc[i][j][q]);
+          else global_atomic_add(out + (size_t)m * Ci + n, acc[i][j][q]);
         }
       }
 }
@@ -955,13 +967,19 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
     load(u + 8, a0, b0);
     compute(u + 4, a1, b1);
   }
+  // the four waves add their tiles in a FIXED order (wave 0, 1, 2, 3): with one slot per block the result is then
+  // bit-reproducible from run to run - needed for the Gram matrix, whose round-off reaches the BatchNorm statistics
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int i = 0; i < MTN; ++i)
+      for (int i = 0; i < MTN; ++i)
 #pragma unroll
-    for (int j = 0; j < NTN; ++j)
+        for (int j = 0; j < NTN; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomicAdd(&s_tile[((i * NTN + j) * 4 + q) * 64 + lane], acc[i][j][q]);   // ds_add_f32
-  __syncthreads();
+          for (int q = 0; q < 4; ++q) s_tile[((i * NTN + j) * 4 + q) * 64 + lane] += acc[i][j][q];
+    }
+    __syncthreads();
+  }
   float* out = dW + (size_t)(blockIdx.z % n_slots) * Co * Ci;
   for (int e = threadIdx.x; e < MTN * NTN * 256; e += 256) {
     const int ln = e & 63, q = (e >> 6) & 3, ij = e >> 8;
@@ -1242,68 +1260,98 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
   return dw_wgrad_impl(dz, x, dw_bc, B, C, C, F, T, Fo, To, k, stride, 1, stream);
 }
 
-static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                         int per_sample, int exact_fp32, eat_stream_t stream, float* ws = nullptr, int n_slots = 0,
-                         WgTf tf = WgTf{nullptr, nullptr, 0}) {
-  // default: split-operand bf16 MFMA kernel (fp32-class accuracy); exact_fp32 (the caller's precision choice),
-  // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel
+// Launch plan of the 1x1 weight gradient: which kernel, how the k range is cut (also exported through
+// eat_pw_wgrad_slots so that a caller can size a one-slot-per-block workspace)
+struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; };   // kind: 0 narrow streaming, 1 LDS-staged x3, 2 exact fp32
+static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact_fp32, bool same, bool has_scale_or_tf) {
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
   const bool force_fp32 = env_fp32 || exact_fp32 == 1;      // exact_fp32: 0 = bf16x3, 1 = exact fp32, 2 = plain bf16
-  // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs): the bf16x3 kernel with one block per (tile, sample)
-  // and plain stores from Co, Ci >= 64 on (round 1 measured it with atomics on every sample's tile: 163 vs 115 ms per
-  // dymn20 step; EAT_DYN_WGRAD_X3=0 restores the 32 x 32-tile fp32 kernel)
   static const bool dyn_x3 = !(getenv("EAT_DYN_WGRAD_X3") && atoi(getenv("EAT_DYN_WGRAD_X3")) == 0);
   const bool ps_x3 = per_sample && dyn_x3 && Co >= 64 && Ci >= 64;
+  WgPlan p{2, 0, 0, (S + 31) / 32, 0};
   if (!force_fp32 && (!per_sample || ps_x3) && (S & 3) == 0) {
-    const int sps = (S + 31) / 32;
+    const int sps = p.sps;
     const int tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
     const long long total = (long long)B * sps;
-    int upb = sps;                                             // per-sample gradients: one sample per block
+    const bool gram = same && Co == Ci && !has_scale_or_tf;
+    if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16 || gram) && !per_sample) {
+      long long splits = 1024 < total ? 1024 : total;
+      p.kind = 0;
+      p.upb = (int)((total + splits - 1) / splits);
+      p.nz = (unsigned)((total + p.upb - 1) / p.upb);
+      return p;
+    }
+    p.kind = 1;
+    p.upb = sps;                                             // per-sample gradients: one sample per block
     if (!per_sample) {
       // ~1024 blocks, but at least 16 units (512 k) of MFMA work in front of a block's Co x Ci atomics
       long long splits = (1024 + tiles - 1) / tiles;
       if (splits > total / 16) splits = total / 16;
       if (splits < 1) splits = 1;
-      upb = (int)((total + splits - 1) / splits);
+      p.upb = (int)((total + splits - 1) / splits);
     }
-    dim3 grid((Co + 127) / 128, (Ci + 127) / 128, (unsigned)((total + upb - 1) / upb));
-    const bool gram = dz == x && Co == Ci && !x_scale && !tf.a;   // Gram matrix of one tensor (train_fuse.hip): one load per unit
-    if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16 || gram) && !per_sample) {
-      // narrow streaming layers: ~2048 single-tile blocks whose 4 waves split the k range
-      // ~1024 blocks (4 waves each); with a workspace the blocks' atomics go to n_slots copies of dW
-      long long splits = 1024 < total ? 1024 : total;
-      upb = (int)((total + splits - 1) / splits);
-      const unsigned nz = (unsigned)((total + upb - 1) / upb);
-      const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
-      hipStream_t hs = (hipStream_t)stream;
-      const bool use_ws = ws != nullptr && n_slots > 1;
-      float* target = use_ws ? ws : dW;
-      const int slots = use_ws ? n_slots : 1;
-#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, sps, upb, nz, slots, hs, tf)
-      EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
-      EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
-      EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // Gram mode only (see `gram`)
-#undef EAT_NARROW
-      if (use_ws)
-        hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
-    } else {
-      if (exact_fp32 == 2)
-        hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
-                           sps, upb, per_sample, tf);
-      else
-        hipLaunchKernelGGL(pw_wgrad_x3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S,
-                           sps, upb, per_sample, tf);
-    }
-    return eat::check_launch("eat_pw_conv_wgrad");
+    p.nz = (unsigned)((total + p.upb - 1) / p.upb);
+    return p;
   }
   const int tiles = ((Co + 31) / 32) * ((Ci + 31) / 32);
   int splits = (1024 + tiles - 1) / tiles;
   if (splits > B || per_sample) splits = B;
-  const int bpb = (B + splits - 1) / splits;
-  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, (B + bpb - 1) / bpb);
-  hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, x, x_scale, dW, B, Co, Ci, S, bpb,
-                     per_sample, tf);
+  p.bpb = (B + splits - 1) / splits;
+  p.nz = (unsigned)((B + p.bpb - 1) / p.bpb);
+  return p;
+}
+
+static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
+                         int per_sample, int exact_fp32, eat_stream_t stream, float* ws = nullptr, int n_slots = 0,
+                         WgTf tf = WgTf{nullptr, nullptr, 0}) {
+  // default: split-operand bf16 MFMA kernel (fp32-class accuracy); exact_fp32 (the caller's precision choice),
+  // EAT_WGRAD_FP32=1 (process-wide debug override) or S % 4 != 0: exact fp32 MFMA kernel.
+  // per-sample gradients (DyMN: K = one plane, B x Co x Ci outputs): the bf16x3 kernel with one block per (tile, sample)
+  // and plain stores from Co, Ci >= 64 on (EAT_DYN_WGRAD_X3=0 restores the 32 x 32-tile fp32 kernel).
+  // ws / n_slots (zero-filled, n_slots * Co * Ci floats): the blocks' atomics go to copy blockIdx.z % n_slots and a
+  // second kernel adds the copies into dW in a fixed order; n_slots >= eat_pw_wgrad_slots(...) gives every block its own
+  // copy (bit-reproducible result).  The LDS-staged and exact kernels use the workspace only in that one-per-block form.
+  const WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || tf.a != nullptr);
+  hipStream_t hs = (hipStream_t)stream;
+  const bool priv = ws != nullptr && !per_sample && n_slots >= (int)p.nz;     // one copy per block
+  if (p.kind == 0) {
+    const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
+    const bool use_ws = ws != nullptr && n_slots > 1;
+    float* target = use_ws ? ws : dW;
+    const int slots = use_ws ? (n_slots < (int)p.nz ? n_slots : (int)p.nz) : 1;
+#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.nz, slots, hs, tf)
+    EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
+    EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
+    EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // Gram mode only (dz == x, Co == Ci)
+#undef EAT_NARROW
+    if (use_ws)
+      hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
+    return eat::check_launch("eat_pw_conv_wgrad");
+  }
+  float* target = priv ? ws : dW;
+  const int slots = priv ? (int)p.nz : 0;
+  if (p.kind == 1) {
+    dim3 grid((Co + 127) / 128, (Ci + 127) / 128, p.nz);
+    if (exact_fp32 == 2)
+      hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb,
+                         per_sample, tf, slots);
+    else
+      hipLaunchKernelGGL(pw_wgrad_x3_kernel<3>, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb,
+                         per_sample, tf, slots);
+  } else {
+    dim3 grid((Co + 31) / 32, (Ci + 31) / 32, p.nz);
+    hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.bpb, per_sample, tf,
+                       slots);
+  }
+  if (priv)
+    hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
   return eat::check_launch("eat_pw_conv_wgrad");
+}
+
+// Number of workspace copies that gives every block of eat_pw_conv_wgrad_ws its own (bit-reproducible result); `same`: the
+// two operands are the same tensor (Gram matrix).  Host helper.
+extern "C" int eat_pw_wgrad_slots(int B, int Co, int Ci, int S, int exact_fp32, int same) {
+  return (int)wgrad_plan(B, Co, Ci, S, 0, exact_fp32, same != 0, false).nz;
 }
 
 extern "C" int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,

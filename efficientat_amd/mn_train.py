@@ -389,7 +389,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 W = cna[0].weight.flatten(1)
                 n_e = B * inp.shape[2] * inp.shape[3]
                 if cna[1].training:
-                    G = ops.pw_conv_wgrad(inp, inp, exact=exact)                 # Gram matrix of the block input
+                    G = ops.gram(inp, exact=exact)                               # Gram matrix of the block input (reproducible)
                     Tm = ops.linear(W, G, None, NONE)                             # W G  (G symmetric)
                     st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e)
                 else:

@@ -358,6 +358,21 @@ def pw_conv_cat(x1, x2, wp, bias, Co, act, res=None):
     return y
 
 
+def gram(x, exact=False):
+    """G (C, C) = sum_{b,s} x x^T, bit-reproducible from run to run: every block of the weight-gradient kernel adds into
+    its own zeroed copy and the copies are summed in a fixed order (the BatchNorm statistics of the expand conv follow
+    from G - csrc/train_fuse.hip - so its round-off decides on which side of a ReLU / Hardswish kink activations fall)."""
+    B, C = x.shape[0], x.shape[1]
+    S = x.numel() // (B * C)
+    mode = 1 if exact else 0
+    slots = int(_lib.lib().eat_pw_wgrad_slots(B, C, C, S, mode, 1))
+    G = zero_arena.zeros((C, C), torch.float32, x.device)
+    ws = zero_arena.zeros((slots, C, C), torch.float32, x.device)
+    _lib.call("eat_pw_conv_wgrad_ws", _dev(x, "x"), _dev(x, "x"), None, G.data_ptr(), ws.data_ptr(), slots, B, C, C, S, mode,
+              _stream())
+    return G
+
+
 def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None):
     """dW (Co, Ci) = sum_b dz[b] (Co,S) . (x[b] * x_scale[b])^T.  exact=True: fp32 MFMA kernel; False: split-operand
     bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact, 'bf16' -> plain bf16

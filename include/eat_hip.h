@@ -256,6 +256,10 @@ int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, flo
  * and a second kernel adds them into dW; other shapes ignore ws. */
 int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float* x_scale, float* dW, float* ws, int n_slots, int B,
                          int Co, int Ci, int S, int exact_fp32, eat_stream_t stream);
+/* Copies of dW that give every block of eat_pw_conv_wgrad_ws its own slot: the result is then bit-reproducible from
+ * run to run (the copies are added in a fixed order).  same != 0: dz and x are the same tensor (the Gram matrix of
+ * eat_gram_bn_finalize, whose round-off reaches the BatchNorm statistics).  Host helper. */
+int eat_pw_wgrad_slots(int B, int Co, int Ci, int S, int exact_fp32, int same);
 
 /* Train-mode project conv, models/mn/block_types.py:167-171 fed by :150-162 (+ the SE scale of :72-83): the conv input is
  * act_in(tf_a[k] x + tf_b[k]) * in_scale[b,k] evaluated on the way to the matrix cores, i.e. BatchNorm + activation of

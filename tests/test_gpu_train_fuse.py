@@ -128,7 +128,9 @@ def test_expand_conv_bn_act_via_gram_matrix(B, Ci, Co, F_, T, act, exact):
         bn.bias.copy_(beta)
     n = B * F_ * T
     sx = xd.sum((0, 2, 3)).contiguous()
-    G = ops.pw_conv_wgrad(xd, xd, exact=exact)
+    G = ops.gram(xd, exact=exact)
+    assert torch.equal(G, ops.gram(xd, exact=exact))                      # bit-reproducible (one slot per block, fixed order)
+    assert _rel(G, torch.einsum("bift,bjft->ij", x.double(), x.double())) < (2e-6 if exact else 2e-5)
     Tm = ops.linear(Wd, G, None, ops.ACT_NONE)
     a, b, mean, invstd = ops.gram_bn_state(Tm, Wd, sx, bn, n)
     assert _rel(mean, z_ref.mean((0, 2, 3))) < 1e-5

@@ -41,7 +41,7 @@ P
   done
 fi
 if has ab; then
-  for combo in "EAT_FUSE_DW_BN=1 EAT_FUSE_SE_BWD=1" "EAT_FUSE_DW_BN=0 EAT_FUSE_SE_BWD=1" "EAT_FUSE_DW_BN=0 EAT_FUSE_SE_BWD=0" "EAT_FUSE_DW_BN=1 EAT_FUSE_SE_BWD=1 EAT_DW_STATS_FUSED=0" "EAT_FUSE_DW_BN=1 EAT_FUSE_SE_BWD=1 EAT_DW_GEPI_FUSED=0"; do
+  for combo in "EAT_X=1" "EAT_MERGED_DW_BWD=0" "EAT_CAT_DGRAD=0" "EAT_STEM_WGRAD_OLD=1" "EAT_MERGED_DW_BWD=0 EAT_CAT_DGRAD=0"; do
     env $combo timeout 300 python bench.py --no-cpu-baseline --no-forward --no-train-configs --no-profile --steps 10 --warmup 3 > $OUT/ab.json 2> $OUT/ab.err
     python - <<P
 import json
