@@ -871,6 +871,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   __shared__ float s_tile[MTN * NTN * 256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 15, kg = lane >> 4;
+  // round 3: blockIdx.x / blockIdx.y select a group of MTN / NTN row tiles ("thin" matrices: up to ~8 x 8 tiles over a
+  // long k axis stream faster through this LDS-free kernel than through the barrier-per-32-positions LDS pipeline)
+  const int m0 = blockIdx.x * (16 * MTN), n0 = SAME ? m0 : blockIdx.y * (16 * NTN);
   const int total = B * sps;
   const int u0 = blockIdx.z * units_per_block;
   const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
 #pragma unroll
   for (int j = 0; j < NTN; ++j) {
     sc[j] = 1.0f;
-    const int row = 16 * j + r;
+    const int row = n0 + 16 * j + r;
     tfa[j] = (tf.a && row < Ci) ? tf.a[row] : 1.0f;
     tfb[j] = (tf.a && row < Ci) ? tf.b[row] : 0.0f;
   }
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
     const int s = st * 32 + 8 * kg;
 #pragma unroll
     for (int i = 0; i < MTN; ++i) {
-      const int row = 16 * i + r;
+      const int row = m0 + 16 * i + r;
       const float* p = dz + ((size_t)b * Co + (row < Co ? row : Co - 1)) * S + s;
       const bool ok0 = live && row < Co && s < S, ok1 = ok0 && s + 4 < S;
       const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -909,7 +912,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
     if constexpr (!SAME) {
 #pragma unroll
       for (int j = 0; j < NTN; ++j) {
-        const int row = 16 * j + r;
+        const int row = n0 + 16 * j + r;
         const float* p = x + ((size_t)b * Ci + (row < Ci ? row : Ci - 1)) * S + s;
         const bool ok0 = live && row < Ci && s < S, ok1 = ok0 && s + 4 < S;
         const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
       if (b != b_sc) {
 #pragma unroll
         for (int j = 0; j < NTN; ++j) {
-          const int row = 16 * j + r;
+          const int row = n0 + 16 * j + r;
           sc[j] = row < Ci ? xscale[(size_t)b * Ci + row] : 0.0f;
         }
         b_sc = b;
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   for (int e = threadIdx.x; e < MTN * NTN * 256; e += 256) {
     const int ln = e & 63, q = (e >> 6) & 3, ij = e >> 8;
     const int i = ij / NTN, j = ij - i * NTN;
-    const int m = 16 * i + (ln >> 4) * 4 + q, n = 16 * j + (ln & 15);
+    const int m = m0 + 16 * i + (ln >> 4) * 4 + q, n = n0 + 16 * j + (ln & 15);
     if (m < Co && n < Ci) atomicAdd(out + (size_t)m * Ci + n, s_tile[e]);
   }
 }
@@ -1000,12 +1003,12 @@ __global__ void wgrad_slot_reduce_kernel(const float* __restrict__ ws, float* __
 
 template <int MTN, int NTN>
 static void launch_narrow(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s, WgTf tf) {
-  if (dz == x && MTN == NTN && !x_scale && !tf.a)
+                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s, WgTf tf, int mg, int ng, bool gram) {
+  if (gram && MTN == NTN)
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, (MTN == NTN ? NTN : 1), (MTN == NTN)>), dim3(1, 1, nz), dim3(256), 0, s, dz,
                        x, x_scale, dW, B, Co, Ci, S, sps, upb, n_slots, tf);
   else
-    hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, NTN, false>), dim3(1, 1, nz), dim3(256), 0, s, dz, x, x_scale, dW, B,
+    hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, NTN, false>), dim3(mg, ng, nz), dim3(256), 0, s, dz, x, x_scale, dW, B,
                        Co, Ci, S, sps, upb, n_slots, tf);
 }
 
@@ -1262,20 +1265,41 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 
 // Launch plan of the 1x1 weight gradient: which kernel, how the k range is cut (also exported through
 // eat_pw_wgrad_slots so that a caller can size a one-slot-per-block workspace)
-struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; };   // kind: 0 narrow streaming, 1 LDS-staged x3, 2 exact fp32
+struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; int mtb, ntb, mg, ng; bool gram; };
+// kind: 0 LDS-free streaming kernel (thin matrices), 1 LDS-staged x3, 2 exact fp32; mtb / ntb: row tiles per block, mg / ng groups
+
+// (row tiles per block) pairs the streaming kernel is instantiated for
+// (the x side carries the SE scale / BatchNorm transform and costs more registers per tile: <= 3 tiles there, <= 4 on the dz side)
+static bool thin_pair(int m, int n) { return m >= 1 && m <= 4 && n >= 1 && n <= 3; }
 static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact_fp32, bool same, bool has_scale_or_tf) {
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
   const bool force_fp32 = env_fp32 || exact_fp32 == 1;      // exact_fp32: 0 = bf16x3, 1 = exact fp32, 2 = plain bf16
   static const bool dyn_x3 = !(getenv("EAT_DYN_WGRAD_X3") && atoi(getenv("EAT_DYN_WGRAD_X3")) == 0);
   const bool ps_x3 = per_sample && dyn_x3 && Co >= 64 && Ci >= 64;
-  WgPlan p{2, 0, 0, (S + 31) / 32, 0};
+  WgPlan p{2, 0, 0, (S + 31) / 32, 0, 0, 0, 1, 1, false};
   if (!force_fp32 && (!per_sample || ps_x3) && (S & 3) == 0) {
     const int sps = p.sps;
     const int tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
     const long long total = (long long)B * sps;
     const bool gram = same && Co == Ci && !has_scale_or_tf;
-    if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16 || gram) && !per_sample) {
-      long long splits = 1024 < total ? 1024 : total;
+    const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
+    static const bool thin_on = !(getenv("EAT_WGRAD_THIN") && atoi(getenv("EAT_WGRAD_THIN")) == 0);
+    bool thin = false;
+    if (!per_sample) {
+      if (gram && Co <= 64) {                                  // Gram matrix: the operand is loaded once
+        thin = true; p.mtb = p.ntb = mtn; p.mg = p.ng = 1; p.gram = true;
+      } else if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16)) {
+        thin = true; p.mtb = mtn; p.ntb = ntn; p.mg = p.ng = 1;
+      } else if (thin_on && total * 32 >= (1 << 19)) {
+        // a long k axis (>= 512 k positions) over few rows: groups of <= 4 row tiles per block, at most 4 groups (the other
+        // operand is re-read once per group, from L2)
+        const int mg = (mtn + 3) / 4, ng = (ntn + 2) / 3;
+        const int mtb = (mtn + mg - 1) / mg, ntb = (ntn + ng - 1) / ng;
+        if (mg * ng <= 4 && thin_pair(mtb, ntb)) { thin = true; p.mtb = mtb; p.ntb = ntb; p.mg = mg; p.ng = ng; }
+      }
+    }
+    if (thin) {
+      long long splits = (1024 / (p.mg * p.ng)) < total ? (1024 / (p.mg * p.ng)) : total;
       p.kind = 0;
       p.upb = (int)((total + splits - 1) / splits);
       p.nz = (unsigned)((total + p.upb - 1) / p.upb);
@@ -1315,14 +1339,14 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   hipStream_t hs = (hipStream_t)stream;
   const bool priv = ws != nullptr && !per_sample && n_slots >= (int)p.nz;     // one copy per block
   if (p.kind == 0) {
-    const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
     const bool use_ws = ws != nullptr && n_slots > 1;
     float* target = use_ws ? ws : dW;
     const int slots = use_ws ? (n_slots < (int)p.nz ? n_slots : (int)p.nz) : 1;
-#define EAT_NARROW(M_, N_) if (mtn == M_ && ntn == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.nz, slots, hs, tf)
+#define EAT_NARROW(M_, N_) if (p.mtb == M_ && p.ntb == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.nz, slots, hs, tf, p.mg, p.ng, p.gram)
     EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
     EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
-    EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // Gram mode only (dz == x, Co == Ci)
+    EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // (2,2), (4,4): Gram mode only (dz == x, Co == Ci)
+    EAT_NARROW(2, 3); EAT_NARROW(3, 2); EAT_NARROW(4, 2); EAT_NARROW(4, 3);
 #undef EAT_NARROW
     if (use_ws)
       hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);

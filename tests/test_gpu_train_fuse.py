@@ -260,3 +260,24 @@ def test_two_source_pointwise_conv(B, C1, C2, Co, F_, T, mode):
     if mode == "fp32":
         ref64 = F.conv2d(torch.cat([x1, x2], 1).double(), W.double()[:, :, None, None], bias.double()) + res.double()
         assert _rel(got, ref64) < 1e-5
+
+
+@pytest.mark.parametrize("B,Co,Ci,F_,T,se,tf_act", [(70, 24, 72, 32, 250, True, 1), (70, 72, 24, 32, 250, False, None),
+                                                    (280, 40, 120, 16, 125, True, 2), (280, 120, 40, 16, 125, False, None),
+                                                    (300, 240, 40, 16, 125, False, None), (70, 24, 64, 32, 250, False, 1)])
+def test_thin_weight_gradient_streaming_kernel(B, Co, Ci, F_, T, se, tf_act):
+    """1x1 weight gradients of the early / middle layers (few rows, >= 512 k positions) run on the LDS-free streaming kernel
+    in groups of row tiles: against fp64 einsum, with the SE scale and the on-load BatchNorm + activation of the x operand."""
+    dz = _rand(B, Co, F_, T, seed=1)
+    x = _rand(B, Ci, F_, T, seed=2, scale=1.5)
+    sc = (torch.rand(B, Ci, generator=torch.Generator().manual_seed(3)) + 0.25) if se else None
+    a, b = torch.rand(Ci, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(Ci, seed=5, scale=0.3)
+    x64 = x.double()
+    if tf_act is not None:
+        x64 = ACTS[tf_act](x64 * a.double()[None, :, None, None] + b.double()[None, :, None, None])
+    if se:
+        x64 = x64 * sc.double()[:, :, None, None]
+    ref = torch.einsum("bofs,bifs->oi", dz.double(), x64)
+    tf = (a.to(DEV), b.to(DEV), tf_act) if tf_act is not None else None
+    dW = ops.pw_conv_wgrad(dz.to(DEV), x.to(DEV), x_scale=sc.to(DEV) if se else None, exact=False, tf=tf)
+    assert _rel(dW, ref) < 3e-5, _rel(dW, ref)
