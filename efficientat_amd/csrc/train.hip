@@ -992,13 +992,29 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   }
 }
 
-// dW[e] += sum over the slots of ws (plain read-modify-write: one thread per element)
-__global__ void wgrad_slot_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int n, int n_slots) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+// dW[e] += sum over the slots of ws, in a fixed order (bit-reproducible): a block owns 64 consecutive elements, its four
+// waves split the slots (wave w: slots w, w+4, ...; the loads of 16 slots are in flight together), the four partial
+// sums are added in wave order.  (One thread per element walking up to 1024 slots took ~250 us: a serial latency chain.)
+__global__ __launch_bounds__(256) void wgrad_slot_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int n,
+                                                                int n_slots) {
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   float t = 0.0f;
-  for (int sidx = 0; sidx < n_slots; ++sidx) t += ws[(size_t)sidx * n + e];
-  dW[e] += t;
+  if (e < n) {
+    int sidx = wv;
+    for (; sidx + 60 < n_slots; sidx += 64) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = ws[(size_t)(sidx + 4 * q) * n + e];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += v[q];
+    }
+    for (; sidx < n_slots; sidx += 4) t += ws[(size_t)sidx * n + e];
+  }
+  s_part[wv][lane] = t;
+  __syncthreads();
+  if (wv == 0 && e < n) dW[e] += ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
 }
 
 template <int MTN, int NTN>
@@ -1349,7 +1365,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
     EAT_NARROW(2, 3); EAT_NARROW(3, 2); EAT_NARROW(4, 2); EAT_NARROW(4, 3);
 #undef EAT_NARROW
     if (use_ws)
-      hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
+      hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
     return eat::check_launch("eat_pw_conv_wgrad");
   }
   float* target = priv ? ws : dW;
@@ -1368,7 +1384,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
                        slots);
   }
   if (priv)
-    hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
+    hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
   return eat::check_launch("eat_pw_conv_wgrad");
 }
 

@@ -107,6 +107,22 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(out + i, s_acc[i]);
 }
 
+// Few rows (R <= 4096: the per-(b,c) plane sums of the train plan, R = batch): one thread per column adds the rows in
+// index order - no atomics, bit-reproducible (these column sums feed BatchNorm statistics: a last-bit difference decides
+// on which side of an activation kink some element falls, so run-to-run noise here becomes 1e-3-level gradient noise)
+__global__ __launch_bounds__(256) void col_sum_det_kernel(const float* __restrict__ m, float* __restrict__ out, int R, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {
+    a0 += m[(size_t)r * C + c]; a1 += m[(size_t)(r + 1) * C + c];
+    a2 += m[(size_t)(r + 2) * C + c]; a3 += m[(size_t)(r + 3) * C + c];
+  }
+  for (; r < R; ++r) a0 += m[(size_t)r * C + c];
+  out[c] = (a0 + a1) + (a2 + a3);
+}
+
 }  // namespace
 
 extern "C" int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n,
@@ -144,6 +160,10 @@ extern "C" int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_
   eat::clear_stale_error();
   if (R < 1 || C < 1 || C > 8192) return eat::fail(EAT_EINVAL, "eat_col_sum: bad shape (%d x %d)", R, C);
   hipStream_t s = (hipStream_t)stream;
+  if (R <= 4096) {
+    hipLaunchKernelGGL(col_sum_det_kernel, dim3((C + 255) / 256), dim3(256), 0, s, m, out, R, C);
+    return eat::check_launch("eat_col_sum");
+  }
   if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_col_sum: memset failed");
   const long long n = (long long)R * C;
   long long rows_pb = (R + 1023) / 1024;                              // ~1024 blocks

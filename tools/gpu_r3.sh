@@ -41,7 +41,7 @@ P
   done
 fi
 if has ab; then
-  for combo in "EAT_X=1" "EAT_MERGED_DW_BWD=0" "EAT_CAT_DGRAD=0" "EAT_STEM_WGRAD_OLD=1" "EAT_MERGED_DW_BWD=0 EAT_CAT_DGRAD=0"; do
+  for combo in "EAT_X=1" "EAT_WGRAD_THIN=0" "EAT_DW_BWD_TMIN=100000" "EAT_DW_BWD_TMIN=64"; do
     env $combo timeout 300 python bench.py --no-cpu-baseline --no-forward --no-train-configs --no-profile --steps 10 --warmup 3 > $OUT/ab.json 2> $OUT/ab.err
     python - <<P
 import json
