@@ -410,7 +410,10 @@ class MNTrainFunction2(torch.autograd.Function):
                 st_d = ops.bn_frozen_state(cna_d[1])
             S_d = z_d.shape[2] * z_d.shape[3]
             pool = torch.empty((B, cnf.expanded_channels), device=dev) if blk.i_se is not None else None
-            on_load = _FUSE_DW_BN and ops.pw_tf_eligible(cnf.expanded_channels, S_d)
+            # on-load BatchNorm + activation in the project conv: saves the write AND the read of y_d in blocks without
+            # SE, only the write in SE blocks (the squeeze needs a pass anyway) - there it pays on the large planes only
+            # (measured: on the 8x63 / 4x32 SE blocks the transformed GEMM and weight gradient cost more than the write)
+            on_load = _FUSE_DW_BN and ops.pw_tf_eligible(cnf.expanded_channels, S_d) and (blk.i_se is None or S_d >= 2000)
             y_d = ops.bn_act_fwd(z_d, st_d[0], st_d[1], act, pool=pool, write=not on_load) if (pool is not None or not on_load) else None
             rec.update(y_e=None if blk.i_expand is not None else inp, z_d=z_d, st_d=st_d, y_d=y_d)
             scale = None
