@@ -213,14 +213,16 @@ class DyMN(nn.Module):
         c_last = inverted_residual_setting[-1].out_channels
         self.out_c = _conv_bn_act(c_last, 6 * c_last, 1, act=nn.Hardswish)
         self.head_type = head_type
-        if head_type != "mlp":
-            if head_type == "fully_convolutional":
-                raise NotImplementedError("Head 'fully_convolutional' is not on the HIP path yet (only 'mlp')")
+        if head_type == "fully_convolutional":               # models/dymn/model.py:119-130
+            self.classifier = nn.Sequential(nn.Conv2d(6 * c_last, num_classes, (1, 1), bias=False),
+                                            nn.BatchNorm2d(num_classes), nn.AdaptiveAvgPool2d((1, 1)))
+        elif head_type == "mlp":
+            self.classifier = nn.Sequential(
+                nn.AdaptiveAvgPool2d(1), nn.Flatten(start_dim=1), nn.Linear(6 * c_last, last_channel),
+                nn.Hardswish(inplace=True), nn.Dropout(p=dropout, inplace=True), nn.Linear(last_channel, num_classes))
+        else:
             raise NotImplementedError(f"Head '{head_type}' unknown. Must be one of: 'mlp', "
                                       f"'fully_convolutional', 'multihead_attention_pooling'")
-        self.classifier = nn.Sequential(
-            nn.AdaptiveAvgPool2d(1), nn.Flatten(start_dim=1), nn.Linear(6 * c_last, last_channel),
-            nn.Hardswish(inplace=True), nn.Dropout(p=dropout, inplace=True), nn.Linear(last_channel, num_classes))
         for m in self.modules():   # models/dymn/model.py:144-155
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out")
@@ -360,10 +362,8 @@ class DyMN(nn.Module):
         if not x.is_cuda:
             raise ops._lib.EatHipError("DyMN.forward needs a GPU tensor: efficientat_amd has no CPU path")
         if self.training:
-            if return_fmaps:
-                raise NotImplementedError("return_fmaps is only available in eval mode on the HIP path")
             from .dymn_train import forward_train
-            return forward_train(self, x)
+            return forward_train(self, x, return_fmaps)
         W = self._cache.get(self._fold_sources(), self._build_folded)
         x = x.contiguous().float()
         B = x.shape[0]
@@ -386,9 +386,18 @@ class DyMN(nn.Module):
         pooled = torch.zeros((B, c_feat), device=x.device, dtype=torch.float32)
         S = x.shape[2] * x.shape[3]
         y = ops.pw_conv(x, W["last"][0], W["last"][1], c_feat, ops.ACT_HSWISH, pool=pooled, write=return_fmaps)
-        fc1, fc2 = self.classifier[2], self.classifier[5]
-        h = ops.linear(pooled, fc1.weight, fc1.bias, ops.ACT_HSWISH, 1.0 / S)
-        logits = ops.linear(h, fc2.weight, fc2.bias, ops.ACT_NONE)
+        if self.head_type == "fully_convolutional":
+            # eval: mean_s BN(conv1x1(x)) = (scale * W) mean_s(x) + bias - the head collapses onto the pooled features
+            conv, bn = self.classifier[0], self.classifier[1]
+            with torch.no_grad():
+                sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                wf = (conv.weight.flatten(1) * sc.view(-1, 1)).contiguous()
+                bf = (bn.bias - bn.running_mean * sc).contiguous()
+            logits = ops.linear(pooled, wf, bf, ops.ACT_NONE, 1.0 / S)
+        else:
+            fc1, fc2 = self.classifier[2], self.classifier[5]
+            h = ops.linear(pooled, fc1.weight, fc1.bias, ops.ACT_HSWISH, 1.0 / S)
+            logits = ops.linear(h, fc2.weight, fc2.bias, ops.ACT_NONE)
         if return_fmaps:
             return logits, fmaps + [y]
         return logits, pooled * (1.0 / S)

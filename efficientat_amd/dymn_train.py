@@ -332,16 +332,24 @@ def _static_block_train(blk, x):
     return x + inp if blk.use_res_connect else x
 
 
-def forward_train(model, x):
-    """Train-mode `(logits, embedding)` of DyMN with autograd support (models/dymn/model.py:185-200)."""
+def forward_train(model, x, return_fmaps=False):
+    """Train-mode `(logits, embedding)` - or `(logits, fmaps)`, models/dymn/model.py:157-195 - of DyMN with autograd
+    support (models/dymn/model.py:185-200).  The fully-convolutional head (:119-130) runs as torch ops on the last 4 x 32
+    map (its class count, 527, is not a multiple of 4, which the library's data-gradient GEMM needs)."""
     x = x.contiguous().float()
     z = StemConv.apply(x, model.in_c[0].weight)
     x = BnAct.apply(z, model.in_c[1].weight, model.in_c[1].bias, model.in_c[1], HSWISH)
+    fmaps = [x]
     for blk in model.layers:
         x = _block_train(blk, x) if hasattr(blk, "context_gen") else _static_block_train(blk, x)
+        fmaps.append(x)
     z = PwConv.apply(x, model.out_c[0].weight)
     x = BnAct.apply(z, model.out_c[1].weight, model.out_c[1].bias, model.out_c[1], HSWISH)
+    fmaps.append(x)
     feat = x.mean(dim=(2, 3))
+    if model.head_type == "fully_convolutional":
+        logits = model.classifier(x).reshape(x.shape[0], -1)
+        return (logits, fmaps) if return_fmaps else (logits, feat)
     fc1, fc2, drop = model.classifier[2], model.classifier[5], model.classifier[4]
     h = F.hardswish(Linear.apply(feat, fc1.weight, fc1.bias))
     override = getattr(model, "_drop_mask_override", None)
@@ -351,4 +359,5 @@ def forward_train(model, x):
         h = h * (override.to(h.device).float() / (1.0 - drop.p))
     elif drop.p > 0:
         h = F.dropout(h, drop.p, True)
-    return Linear.apply(h, fc2.weight, fc2.bias), feat
+    logits = Linear.apply(h, fc2.weight, fc2.bias)
+    return (logits, fmaps) if return_fmaps else (logits, feat)

@@ -435,14 +435,11 @@ class MN(nn.Module):
         if not x.is_cuda:
             raise ops._lib.EatHipError("MN.forward needs a GPU tensor: efficientat_amd has no CPU path")
         if self.training:
-            if return_fmaps:
-                raise NotImplementedError("return_fmaps is only available in eval mode on the HIP path")
-            if self.head_type != "mlp" or any(b.cnf.dilation > 1 or (b.i_se is not None and not b.block[b.i_se].channel_only)
-                                              for b in self.features[1:-1]):
-                raise NotImplementedError("training on the HIP path covers the default configuration (head_type='mlp', "
-                                          "se_dims='c', dilation 1); the other variants are eval-only")
+            if any(b.cnf.dilation > 1 or (b.i_se is not None and not b.block[b.i_se].channel_only) for b in self.features[1:-1]):
+                raise NotImplementedError("training on the HIP path covers se_dims='c' and dilation 1 (every head_type); "
+                                          "squeeze-excitation over t / dilated blocks are eval-only")
             from .mn_train import forward_train
-            return forward_train(self, x)
+            return forward_train(self, x, return_fmaps)
         W = self._cache.get(self._fold_sources(), self._build_folded)
         x = x.contiguous().float()
         B = x.shape[0]

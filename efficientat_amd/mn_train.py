@@ -162,7 +162,7 @@ class MNTrainFunction(torch.autograd.Function):
             return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat)
 
     @staticmethod
-    def _backward_impl(ctx, model, sv, dlogits, dfeat, v2=False):
+    def _backward_impl(ctx, model, sv, dlogits, dfeat, v2=False, n_lead=3):
         # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
         # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
         # a model that was never handed to dp.enable_data_parallel keeps its gradients local (no hidden collective)
@@ -173,26 +173,29 @@ class MNTrainFunction(torch.autograd.Function):
         blocks = list(model.features[1:-1])
         nb = len(blocks)
 
-        # ---- head (mn/model.py:186-194)
-        feat, u, h2, drop_mask = sv["head"]
-        fc1, fc2 = model.classifier[2], model.classifier[5]
-        g["classifier.5.weight"] = _mm_nt(_t(dlogits), _t(h2))
-        g["classifier.5.bias"] = dlogits.sum(0)
-        dh2 = _mm_nt(dlogits, _t(fc2.weight))
-        if drop_mask is not None:
-            dh2 = dh2 * drop_mask
-        du = dh2 * torch.where(u < -3, torch.zeros_like(u), torch.where(u <= 3, u / 3 + 0.5, torch.ones_like(u)))
-        g["classifier.2.weight"] = _mm_nt(_t(du), _t(feat))
-        g["classifier.2.bias"] = du.sum(0)
-        dft = _mm_nt(du, _t(fc1.weight))
-        if dfeat is not None:
-            dft = dft + dfeat
-
-        # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
         x_l, z_l, st_l, S_l = sv["last"]
         last = model.features[-1]
-        zeros_bc = torch.zeros((B, z_l.shape[1]), device=dev)
-        dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l))
+        if sv["head"] is None:
+            # trunk mode: the head ran outside (torch autograd); dlogits is the gradient w.r.t. the last feature map
+            dz, dgam, dbet = ops.bn_act_bwd(dlogits.view_as(z_l), z_l, *st_l, HSWISH)
+        else:
+            # ---- head (mn/model.py:186-194)
+            feat, u, h2, drop_mask = sv["head"]
+            fc1, fc2 = model.classifier[2], model.classifier[5]
+            g["classifier.5.weight"] = _mm_nt(_t(dlogits), _t(h2))
+            g["classifier.5.bias"] = dlogits.sum(0)
+            dh2 = _mm_nt(dlogits, _t(fc2.weight))
+            if drop_mask is not None:
+                dh2 = dh2 * drop_mask
+            du = dh2 * torch.where(u < -3, torch.zeros_like(u), torch.where(u <= 3, u / 3 + 0.5, torch.ones_like(u)))
+            g["classifier.2.weight"] = _mm_nt(_t(du), _t(feat))
+            g["classifier.2.bias"] = du.sum(0)
+            dft = _mm_nt(du, _t(fc1.weight))
+            if dfeat is not None:
+                dft = dft + dfeat
+            # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
+            zeros_bc = torch.zeros((B, z_l.shape[1]), device=dev)
+            dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l))
         nm = f"features.{nb + 1}"
         g[nm + ".1.weight"], g[nm + ".1.bias"] = dgam, dbet
         g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
@@ -330,7 +333,7 @@ class MNTrainFunction(torch.autograd.Function):
         g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
         g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
         grads = g.finish()
-        return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        return (None,) * n_lead + tuple(grads.get(n) for n in ctx.names)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -352,8 +355,12 @@ _CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand da
 
 
 class MNTrainFunction2(torch.autograd.Function):
+    """mode 0: the whole network incl. the mlp head -> (logits, features).  mode 1 ("trunk"): up to the last feature map
+    -> (y_last, fmap_0 ... fmap_15): the caller runs the head on y_last (non-default heads, `return_fmaps`); the block
+    outputs are handed out as non-differentiable tensors."""
+
     @staticmethod
-    def forward(ctx, model, x, drop_mask, *params):
+    def forward(ctx, model, x, drop_mask, mode, *params):
         keep = torch.is_grad_enabled() or any(p.requires_grad for p in params)
         dev = x.device
         x = x.contiguous().float()
@@ -373,6 +380,7 @@ class MNTrainFunction2(torch.autograd.Function):
         cur = ops.bn_act_fwd(z0, st0[0], st0[1], HSWISH, pool=pool_c)
         sx = ops.col_sum(pool_c) if need_sx else None
         saved["stem"] = (x, z0, st0)
+        fmaps = [cur]
 
         blk_saved = []
         for bi, blk in enumerate(blocks):
@@ -436,15 +444,25 @@ class MNTrainFunction2(torch.autograd.Function):
             sx = ops.col_sum(pool_c) if need_sx else None
             rec.update(z_p=z_p, st_p=st_p)
             blk_saved.append(rec)
+            fmaps.append(cur)
 
         last = model.features[-1]
         c_feat = last.out_channels
         wp = ops.pw_prepack(last[0].weight.flatten(1))
         z_l = ops.pw_conv(cur, wp, _zeros.get(c_feat, dev), c_feat, NONE)
         st_l = _conv_bn_stats(z_l, last[1])
+        S_l = z_l.shape[2] * z_l.shape[3]
+        ctx.mode = mode
+        if mode == 1:
+            y_l = ops.bn_act_fwd(z_l, st_l[0], st_l[1], HSWISH)
+            if keep:
+                saved.update(blocks=blk_saved, last=(cur, z_l, st_l, S_l), head=None)
+                ctx.saved, ctx.model = saved, model
+                ctx.names = [n for n, _ in model.named_parameters()]
+            ctx.mark_non_differentiable(*fmaps)
+            return (y_l,) + tuple(fmaps)
         pooled = torch.empty((B, c_feat), device=dev)
         ops.bn_act_fwd(z_l, st_l[0], st_l[1], HSWISH, pool=pooled, write=False)
-        S_l = z_l.shape[2] * z_l.shape[3]
         feat = pooled * (1.0 / S_l)
         fc1, fc2 = model.classifier[2], model.classifier[5]
         u = ops.linear(feat, fc1.weight, fc1.bias, NONE)
@@ -459,24 +477,50 @@ class MNTrainFunction2(torch.autograd.Function):
         return logits, feat
 
     @staticmethod
-    def backward(ctx, dlogits, dfeat):
+    def backward(ctx, dout0, *rest):
         model, sv = ctx.model, ctx.saved
         ctx.saved = None
+        dfeat = rest[0] if ctx.mode == 0 else None
         with ops.precision(getattr(model, "train_precision", "fp32")), ops.zero_arena.scope("mn_bwd"):
-            return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat, v2=True)
+            return MNTrainFunction._backward_impl(ctx, model, sv, dout0, dfeat, v2=True, n_lead=4)
 
 
-def forward_train(model, x):
-    """Train-mode `(logits, features)` with autograd support (mn/model.py:212-231 in `.train()`)."""
-    drop = model.classifier[4]
+def forward_train(model, x, return_fmaps=False):
+    """Train-mode `(logits, features)` - or `(logits, fmaps)` - with autograd support (mn/model.py:212-231 in `.train()`).
+
+    The default network (mlp head) is one Function incl. the head.  Non-default heads (`fully_convolutional`,
+    `multihead_attention_pooling`; mn/model.py:170-185) and `return_fmaps=True` run the trunk Function up to the last
+    feature map and the head module on top of it under torch autograd (both heads act on the 960 x 4 x 32 map only).  The 17 feature maps of
+    `return_fmaps` are values only (no gradient flows back through them; the logits are differentiable as usual)."""
+    drop = model.classifier[4] if model.head_type == "mlp" else None
     mask = None
-    if drop.p > 0 and drop.training:
+    if drop is not None and drop.p > 0 and drop.training:
         n_hidden = model.classifier[2].out_features
         mask = torch.empty((x.shape[0], n_hidden), device=x.device).bernoulli_(1.0 - drop.p) / (1.0 - drop.p)
     override = getattr(model, "_drop_mask_override", None)       # tests replay the reference's mask
-    if override is not None and drop.training:
+    if override is not None and drop is not None and drop.training:
         mask = override.to(x.device).float() / (1.0 - drop.p)
     params = [p for _, p in model.named_parameters()]
-    fn = MNTrainFunction2 if _TRAIN_V >= 2 else MNTrainFunction
+    trunk = return_fmaps or model.head_type != "mlp"
     with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters, ops.zero_arena.scope("mn_fwd"):
-        return fn.apply(model, x, mask, *params)
+        if not trunk:
+            if _TRAIN_V >= 2:
+                return MNTrainFunction2.apply(model, x, mask, 0, *params)
+            return MNTrainFunction.apply(model, x, mask, *params)
+        if _TRAIN_V < 2:
+            raise NotImplementedError("non-default heads / return_fmaps in train mode need the round-3 plan (EAT_TRAIN_V=2)")
+        outs = MNTrainFunction2.apply(model, x, None, 1, *params)
+        y_l, fmaps = outs[0], list(outs[1:])
+        feat = y_l.mean(dim=(2, 3))
+        if model.head_type == "mlp":
+            fc1, fc2 = model.classifier[2], model.classifier[5]
+            h = F.hardswish(F.linear(feat, fc1.weight, fc1.bias))
+            if mask is not None:
+                h = h * mask
+            logits = F.linear(h, fc2.weight, fc2.bias)
+        else:
+            # fully-convolutional head (1x1 conv to the classes + BatchNorm + mean: the class count, 527, is not a
+            # multiple of 4, which the library's data-gradient GEMM needs) and the attention-pooling module: a few MB of
+            # torch ops on the 4 x 32 map under torch autograd
+            logits = model.classifier(y_l).reshape(x.shape[0], -1)
+    return (logits, fmaps + [y_l]) if return_fmaps else (logits, feat)

@@ -338,7 +338,7 @@ REPLACE_SE_DY = (False, False, False, True, True, True, False, False, False, Fal
 
 def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, train=False,
                  stats=None, drop_mask=None, return_fmaps=False, use_dy_blocks="all", no_dyrelu=False, no_dyconv=False,
-                 no_ca=False):
+                 no_ca=False, head_type="mlp"):
     """DyMN (dymn/model.py:157-200); use_dy_blocks "all" or "replace_se" (dymn/model.py:225-231: dynamic blocks only
     where MobileNetV3 has SE, plain SE-less inverted residuals elsewhere, dymn/model.py:102-103)."""
     blocks, _ = block_table(width_mult, strides)
@@ -355,7 +355,10 @@ def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, t
         fmaps.append(x)
     x = _cna(sd, "out_c", x, train, stats, 1, 1, 1, "hs")
     fmaps.append(x)
-    logits, pooled = _mlp_head(sd, x, train, drop_mask)
+    if head_type == "fully_convolutional":                 # dymn/model.py:119-130
+        logits, pooled = _fc_head(sd, x, train, stats)
+    else:
+        logits, pooled = _mlp_head(sd, x, train, drop_mask)
     return (logits, fmaps) if return_fmaps else (logits, pooled)
 
 

@@ -29,6 +29,7 @@ from models.preprocess import AugmentMelSTFT  # noqa: E402
 with contextlib.redirect_stdout(io.StringIO()):
     from models.mn.model import get_model as get_mn  # noqa: E402
     from models.dymn.model import get_model as get_dymn  # noqa: E402
+    from models.dymn.model import dymn as dymn_factory  # noqa: E402
     from models.dymn.dy_block import DynamicConv  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -210,6 +211,9 @@ DYMN_VARIANTS = {   # models/dymn/model.py:225-231; ablations of the dynamic blo
     "no_dyconv": dict(no_dyconv=True),
     "no_ca": dict(no_ca=True),
     "static": dict(no_dyrelu=True, no_dyconv=True, no_ca=True),
+    # the fully-convolutional head of models/dymn/model.py:119-130 is reachable through the `dymn` factory only
+    # (get_model has no head_type argument)
+    "fc_head": dict(head_type="fully_convolutional"),
 }
 
 
@@ -221,7 +225,7 @@ def golden_dymn_variants(mel):
         x_cal = mel(synth.calibration_clips(96000)).unsqueeze(1)
         x = mel(synth.parity_clips(96000, seed=43)).unsqueeze(1)
     for tag, kw in DYMN_VARIANTS.items():
-        model = quiet(get_dymn, width_mult=1.0, **kw)
+        model = quiet(dymn_factory, width_mult=1.0, **kw) if "head_type" in kw else quiet(get_dymn, width_mult=1.0, **kw)
         sd = synth.synth_state(synth.shapes_of(model), seed=4)
         model.load_state_dict(sd, strict=True)
 

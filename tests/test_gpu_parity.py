@@ -557,10 +557,47 @@ def test_mn_variants_match_reference_and_oracle(tag, golden_dir):
     assert float((got.cpu() - ref).abs().max()) < 1e-3 * scale
     assert np.abs(got.cpu().numpy() - g[f"{tag}/logits"]).max() < 1e-3 * scale
     assert np.abs(feat.cpu().numpy() - g[f"{tag}/features"]).max() < 1e-3 * max(1.0, np.abs(g[f"{tag}/features"]).max())
-    if tag != "se_none":
-        model.train()
+    model.train()
+    if tag.startswith("se_ct") or tag.startswith("se_t") or tag == "dilated_reduced":
         with pytest.raises(NotImplementedError):
-            model(x.to(DEV))          # the training plan covers the default configuration only: fails loudly
+            model(x.to(DEV))          # SE over t / dilated blocks: eval only on the HIP path, fails loudly
+        return
+    # heads (and se_dims='none'): one training step vs torch-CPU autograd over the oracle, and train-mode return_fmaps
+    B = x.shape[0]
+    y = (torch.rand(B, 527, generator=torch.Generator().manual_seed(8)) < 0.01).float()
+    keep = torch.ones(B, 1280)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    stats = {}
+    logits_ref, _ = O.mn_forward(sdr, x, train=True, stats=stats, drop_mask=keep * 0.8, **VARIANTS[tag][1])
+    loss_ref = F.binary_cross_entropy_with_logits(logits_ref, y)
+    loss_ref.backward()
+    model.train_precision = "fp32"
+    model._drop_mask_override = (keep * 0.8).to(DEV)          # h * 0.8 / (1 - 0.2): Dropout off
+    logits, feats = model(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    assert float((logits.detach().cpu() - logits_ref.detach()).abs().max()) < 1e-3 * max(1.0, float(logits_ref.abs().max()))
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    rels = []
+    for name, p in model.named_parameters():
+        ref_g = sdr[name].grad
+        assert p.grad is not None, name
+        if float(ref_g.norm()) < 1e-4 * gmax:
+            continue
+        rels.append(float((p.grad.cpu().double() - ref_g.double()).norm() / ref_g.double().norm()))
+    assert max(rels) < 5e-2 and float(np.median(rels)) < 1.5e-2, (max(rels), float(np.median(rels)))
+    with torch.no_grad():
+        model2 = variant_state(tag, golden_dir)[0]
+        model2.load_state_dict(sd, strict=True)
+        model2.to(DEV).train()
+        model2._drop_mask_override = (keep * 0.8).to(DEV)
+        lf, fmaps = model2._forward_impl(x.to(DEV), return_fmaps=True)      # mn/model.py:212-231 in train mode
+        _, ref_fmaps = O.mn_forward(sd, x, train=True, stats={}, drop_mask=keep * 0.8, return_fmaps=True, **VARIANTS[tag][1])
+    assert len(fmaps) == 17 == len(ref_fmaps)
+    for i, (a, b) in enumerate(zip(fmaps, ref_fmaps)):
+        assert a.shape == b.shape and float((a.cpu() - b).norm() / b.norm()) < 2e-4, i
+    assert float((lf.cpu() - logits_ref.detach()).abs().max()) < 1e-3 * max(1.0, float(logits_ref.abs().max()))
 
 
 from tests.test_oracle_golden import DYMN_VARIANTS, dymn_variant_state  # noqa: E402
@@ -603,8 +640,9 @@ def test_dymn_variants_match_reference_and_oracle(tag, golden_dir):
     set_temp(30.0)
     model.train()
     B = x.shape[0]
-    keep = torch.ones(B, model.classifier[2].out_features)
-    model._drop_mask_override = (keep * 0.8).to(DEV)          # h * 0.8 / (1 - 0.2): Dropout off, as in the golden run
+    if model.head_type == "mlp":
+        keep = torch.ones(B, model.classifier[2].out_features)
+        model._drop_mask_override = (keep * 0.8).to(DEV)      # h * 0.8 / (1 - 0.2): Dropout off, as in the golden run
     y = (torch.rand(B, 527, generator=torch.Generator().manual_seed(8)) < 0.01).float()
     sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
            for k, v in sd.items()}

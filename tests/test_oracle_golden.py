@@ -190,16 +190,19 @@ DYMN_VARIANTS = {"replace_se": (dict(use_dy_blocks="replace_se"), dict(use_dy_bl
                  "no_dyconv": (dict(no_dyconv=True), dict(no_dyconv=True)),
                  "no_ca": (dict(no_ca=True), dict(no_ca=True)),
                  "static": (dict(no_dyrelu=True, no_dyconv=True, no_ca=True),
-                            dict(no_dyrelu=True, no_dyconv=True, no_ca=True))}
+                            dict(no_dyrelu=True, no_dyconv=True, no_ca=True)),
+                 # fully-convolutional head (models/dymn/model.py:119-130): through the `dymn` factory, as in the reference
+                 "fc_head": (dict(head_type="fully_convolutional"), dict(head_type="fully_convolutional"))}
 
 
 def dymn_variant_state(tag, golden_dir):
     import contextlib
     import io
-    from efficientat_amd.dymn import get_model
+    from efficientat_amd.dymn import dymn, get_model
     g = np.load(os.path.join(golden_dir, "dymn_variants_ref.npz"))
+    kw = DYMN_VARIANTS[tag][0]
     with contextlib.redirect_stdout(io.StringIO()):
-        model = get_model(width_mult=1.0, **DYMN_VARIANTS[tag][0])
+        model = dymn(width_mult=1.0, **kw) if "head_type" in kw else get_model(width_mult=1.0, **kw)
     shapes = synth.shapes_of(model)
     keys = [str(k) for k in g[f"{tag}/keys"]]                   # the reference's state_dict order (seeded draws follow it)
     assert sorted(keys) == sorted(shapes) and len(keys) == int(g[f"{tag}/n_state"])   # same state_dict layout
