@@ -19,6 +19,7 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from .utils import make_divisible, cnn_out_size, NAME_TO_WIDTH  # noqa: F401
@@ -141,7 +142,12 @@ class MultiHeadAttentionPooling(nn.Module):
         b, c = x.shape[0], x.shape[1]
         xm = x.mean(dim=2).transpose(1, 2).contiguous()                  # collapse_dim(x, 2) -> (B, T, C)
         n = xm.shape[1]
-        p = ops.linear(xm.view(b * n, c), self.subspace_proj.weight, self.subspace_proj.bias, ops.ACT_NONE)
+        if torch.is_grad_enabled() and (xm.requires_grad or self.subspace_proj.weight.requires_grad):
+            # training: the (B T, C) x (C, 2 heads classes) GEMM under torch autograd (the class count is not a multiple of 4,
+            # which the library's data-gradient GEMM needs; 128 rows per clip)
+            p = F.linear(xm.view(b * n, c), self.subspace_proj.weight, self.subspace_proj.bias)
+        else:
+            p = ops.linear(xm.view(b * n, c), self.subspace_proj.weight, self.subspace_proj.bias, ops.ACT_NONE)
         p = p.view(b, n, 2, self.num_heads, self.out_dim).permute(2, 0, 3, 1, 4)
         att, val = torch.sigmoid(p[0]).clamp(self.epsilon, 1.0 - self.epsilon), p[1]
         att = att / att.sum(dim=2, keepdim=True)
