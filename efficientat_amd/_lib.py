@@ -81,6 +81,12 @@ SIGNATURES = {
     "eat_se_bn_bwd_partials": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_se_bn_bwd_combine": [_P, _P, _P, _P, _I, _I, _P, _P],
     "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_P],
+    "eat_stem_gram_blocks": [_I, _I],
+    "eat_dw_bwd_merged_ok": [_I] * 8,
+    "eat_dw_conv_bwd_bn_g": [_P] * 9 + [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
+    "eat_stem_gram": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_stem_bwd_blocks": [_I, _I],
+    "eat_stem_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 
 _lib = None

@@ -65,9 +65,14 @@ struct PlaneArgs {
 };
 
 // d act(u) / du, PyTorch conventions (nn.ReLU / nn.Hardswish backward); `act` is wave-uniform
+// (selects between constants only: written as `u < -3 ? 0 : (u <= 3 ? fma : 1)` hipcc emits nested exec-masked branches
+// that skip the fma, and every branch splits the basic block the surrounding loads could have been batched in)
 __device__ __forceinline__ float act_deriv(float u, int act) {
   if (act == EAT_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
-  if (act == EAT_ACT_HSWISH) return u < -3.0f ? 0.0f : (u <= 3.0f ? fmaf(u, 1.0f / 3.0f, 0.5f) : 1.0f);
+  if (act == EAT_ACT_HSWISH) {
+    const float m_in = (u >= -3.0f && u <= 3.0f) ? 1.0f : 0.0f, m_hi = u > 3.0f ? 1.0f : 0.0f;
+    return fmaf(fmaf(u, 1.0f / 3.0f, 0.5f), m_in, m_hi);
+  }
   return 1.0f;
 }
 
@@ -902,13 +907,22 @@ int launch_tile_wgrad(TileWgArgs a, hipStream_t s) {
 // cross-lane reduction of the weight gradient.
 //   dw[c][u][v] += sum dz[i][j] * act(a x + b)[i*S+u-P][j*S+v-P]                      (zero padding of the ACTIVATED map)
 //   g[i'][j']   = (sum_{u,v} w[u][v] dz[(i'+P-u)/S][(j'+P-v)/S]) * act'(a x[i'][j'] + b),   gpart = sum g per tile
+// BN = true: `dz` is the gradient w.r.t. the ACTIVATED BatchNorm output of this conv (times gscale[b,c] plus gadd[b,c]: the
+// squeeze-excitation gate) and the BatchNorm + activation backward  dz = a (g - m1 - xhat m2),  g = (d gs + ga) act'(a z + b)
+// is evaluated on load from (d, z) with the channel sums of the reduce pass - bn_act_bwd_apply's pass (2 reads + 1 write of
+// the conv-output-sized tensor) becomes one more read here.
+struct DzBn {
+  const float* z; const float* a; const float* b; const float* mean; const float* invstd;
+  const float* gscale; const float* gadd; const double* sums; double n; int act; int frozen;
+};
 struct DwBwdArgs {
   const float* dz; const float* x; float* g; float* dw; float* gpart;
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, G;
   InTf tf;
+  DzBn bn;
 };
 
-template <int K, int S, int RO>
+template <int K, int S, int RO, bool BN>
 __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
   constexpr int P = (K - 1) / 2, LPP = 64, KK = K * K;
   constexpr int FX = S == 1 ? RO + 2 * P : 2 * RO + 2 * P - 1;     // x rows of a tile (with halo)
@@ -950,6 +964,17 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   float acc[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) acc[i] = 0.0f;
+  // BatchNorm-backward constants of channel c:  dz = za g - zc2 z + zc3
+  float za = 1.0f, zb = 0.0f, zc2 = 0.0f, zc3 = 0.0f;
+  if constexpr (BN) {
+    za = a.bn.a[c]; zb = a.bn.b[c];
+    if (!a.bn.frozen) {
+      const float mu = a.bn.mean[c], is = a.bn.invstd[c];
+      const float m1 = (float)(a.bn.sums[c] / a.bn.n), m2 = (float)(a.bn.sums[a.C + c] / a.bn.n);
+      zc2 = za * is * m2;
+      zc3 = za * (mu * is * m2 - m1);
+    }
+  }
 
   for (int gi = 0; gi < a.G; ++gi) {
     const int b = sg * a.G + gi;
@@ -969,16 +994,50 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       xu[i][0] = pv[0];
       xu[i][1] = pv[1];
     }
+    if constexpr (BN) {
+      const __amdgpu_buffer_rsrc_t rzz = make_rsrc(a.bn.z + (size_t)p * Fo * To, z_left);
+      const float gs = a.bn.gscale ? a.bn.gscale[p] : 1.0f, ga = a.bn.gadd ? a.bn.gadd[p] : 0.0f;
+      // validity as a 0 / 1 factor (operands are 0 outside the plane, so every term is finite): a select around dzf would
+      // pull the loads into exec-masked blocks with a wait each
+      const float m0 = eat::opaque((S == 1 ? v0 : vdz != kOOB) ? 1.0f : 0.0f), m1v = eat::opaque((S == 1 && v1) ? 1.0f : 0.0f);
+      const bool hs = a.bn.act == EAT_ACT_HSWISH, re = a.bn.act == EAT_ACT_RELU;
+      auto dzf = [&](float d, float v, float m) {
+        const float u = fmaf(za, v, zb);
+        const float m_in = (u >= -3.0f && u <= 3.0f) ? 1.0f : 0.0f, m_hi = u > 3.0f ? 1.0f : 0.0f;
+        const float dhs = fmaf(fmaf(u, 1.0f / 3.0f, 0.5f), m_in, m_hi);
+        const float dre = u > 0.0f ? 1.0f : 0.0f;
+        const float gg = fmaf(d, gs, ga) * (hs ? dhs : (re ? dre : 1.0f));
+        return fmaf(za, gg, fmaf(-zc2, v, zc3)) * m;
+      };
 #pragma unroll
-    for (int i = 0; i < FD; ++i) {
-      const int rin = d0 + i;
-      const bool rok = rin >= 0 && rin < Fo;
-      if constexpr (ND == 2) {
-        const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
-        dd[i][0] = pv[0];
-        dd[i][1] = in_part ? 0.0f : pv[1];
-      } else {
-        dd[i][0] = buf_load(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+      for (int i = 0; i < FD; ++i) {
+        const int rin = d0 + i;
+        const bool rok = rin >= 0 && rin < Fo;                    // wave-uniform
+        const unsigned so = rok ? 4u * (unsigned)(rin * To) : 0u;
+        if constexpr (ND == 2) {
+          const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, so);
+          const f32x2 zv = buf_load2(rzz, rok ? vdz : kOOB, so);
+          const float mr = eat::opaque(rok ? 1.0f : 0.0f);
+          dd[i][0] = dzf(pv[0], zv[0], m0 * mr);
+          dd[i][1] = dzf(pv[1], zv[1], m1v * mr);
+        } else {
+          const float pv = buf_load(rz, rok ? vdz : kOOB, so);
+          const float zv = buf_load(rzz, rok ? vdz : kOOB, so);
+          dd[i][0] = dzf(pv, zv, m0 * eat::opaque(rok ? 1.0f : 0.0f));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FD; ++i) {
+        const int rin = d0 + i;
+        const bool rok = rin >= 0 && rin < Fo;
+        if constexpr (ND == 2) {
+          const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+          dd[i][0] = pv[0];
+          dd[i][1] = in_part ? 0.0f : pv[1];
+        } else {
+          dd[i][0] = buf_load(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+        }
       }
     }
     // u = a x + b inside the plane, 0 outside: act(0) = 0 for every supported activation, i.e. the zero padding of the
@@ -1104,8 +1163,10 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
         }
       }
     }
-    psum = eat::wave_sum(psum);
-    if (l == 0) a.gpart[(size_t)p * tpp + t] = psum;
+    if (a.gpart) {
+      psum = eat::wave_sum(psum);
+      if (l == 0) a.gpart[(size_t)p * tpp + t] = psum;
+    }
   }
   // one cross-lane reduction of the K*K weight-gradient sums per wave, then K*K atomics
   float mine_v = 0.0f;
@@ -1119,6 +1180,7 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
 
 template <int K, int S, int RO>
 int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
+  const bool bn = a.bn.z != nullptr;
   constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : 62;
   const int n_cols = S == 1 ? a.T : a.To, n_rows = S == 1 ? a.F : a.Fo;
   a.n_cs = (n_cols + WMAX - 1) / WMAX;
@@ -1129,8 +1191,9 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
   a.G = G;
   const long long waves = (long long)((a.B + G - 1) / G) * a.C * a.n_rc * a.n_cs;
   if (waves > 0x7fffffffLL) return 1;
-  *h_inner = a.n_rc * a.n_cs;
-  hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, w);
+  if (h_inner) *h_inner = a.n_rc * a.n_cs;
+  if (bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, w);
+  else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, w);
   return eat::check_launch("eat_dw_conv_bwd_g");
 }
 
@@ -1210,7 +1273,7 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
 
 int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
                float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
-               hipStream_t s) {
+               hipStream_t s, const DwBnBwd* bn) {
   static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
   if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
   // Measured (MI355X, B = 256): the merged kernel wins on the LARGE planes (64x500 -> 32x250: 1.03 vs 1.47 ms, 32x250:
@@ -1218,7 +1281,9 @@ int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* 
   // wave with every lane busy (4x32 planes: 0.69 vs 0.35 ms; a wave of this kernel would use 18 of its 64 lanes)
   static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
   if (T <= t_min) return 1;
-  DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act}};
+  DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act},
+              DzBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0}};
+  if (bn) a.bn = DzBn{bn->z, bn->a, bn->b, bn->mean, bn->invstd, bn->gscale, bn->gadd, bn->sums, (double)B * Fo * To, bn->act, bn->frozen};
   if (stride == 1 && (Fo != F || To != T)) return 1;
   if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 8>(a, w, h_inner, s);      // (RO = 16 needs 246 VGPRs)
   if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 8>(a, w, h_inner, s);

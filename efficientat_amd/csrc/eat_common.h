@@ -43,6 +43,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kWave = 64;
 
+// A value the optimiser cannot see through (no instruction is emitted).  Used for 0 / 1 validity factors: LLVM rewrites
+// `x * (cond ? 1 : 0)` into `cond ? x : 0` and then sinks the loads x depends on into an exec-masked block with its own
+// s_waitcnt - one exposed memory latency per element instead of one per batch of loads.
+// (not `volatile`: a volatile asm is a scheduling boundary and would itself keep loads from being batched)
+__device__ __forceinline__ float opaque(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float opaque_uniform(float v) {       // wave-uniform value, stays in a scalar register
+  asm("" : "+s"(v));
+  return v;
+}
+
 // Training epilogues of the register-resident depthwise kernels (dw_plane.hip), all optional:
 //   stats   forward: per-wave partial sums of the conv output, floats [b][2][C][inner] (sum, sum of squares) - the
 //           BatchNorm batch statistics without a separate pass over the tensor (eat_bn_finalize_partials reduces them);
@@ -96,9 +109,15 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
                        int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s);
 // merged depthwise backward (dw_plane.hip): weight gradient + data gradient + activation-derivative epilogue in one pass;
 // returns 1 when switched off (EAT_DW_BWD_MERGED=0) or the geometry is out of range
+// bn != NULL: dz is the gradient w.r.t. the activated BatchNorm output of this conv; the BatchNorm + activation backward is
+// evaluated on load from (dz, bn->z) with the channel sums of the reduce pass (sums[0..C) = sum g, [C..2C) = sum g xhat)
+struct DwBnBwd {
+  const float* z; const float* a; const float* b; const float* mean; const float* invstd;
+  const float* gscale; const float* gadd; const double* sums; int act; int frozen;
+};
 int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
                float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
-               hipStream_t s);
+               hipStream_t s, const DwBnBwd* bn = nullptr);
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
 int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,

@@ -1273,6 +1273,49 @@ extern "C" int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* i
   return eat_dw_conv_dgrad_g(dz, w, x, in_a, in_b, in_act, g, gpart, inner_cap, h_inner, B, C, F, T, Fo, To, k, stride, stream);
 }
 
+// The same with the BatchNorm + activation backward of THIS conv's output evaluated on load (dw_plane.hip, DzBn): dy is the
+// gradient w.r.t. act(BN(z)) (times gscale[b,c] plus gadd[b,c] for a squeeze-excitation block), sums the fp64 channel sums
+// of eat_bn_act_bwd_reduce / eat_se_bn_bwd_combine.  Blocks without an expand conv: in_a = 1, in_b = 0, in_act = none,
+// gpart may be NULL.  Only the geometries of the merged kernel:
+// eat_dw_bwd_merged_ok(...) != 0, else EAT_EINVAL.
+static int dw_bwd_bn_geometry_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
+  static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
+  static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
+  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28) || T <= t_min) return 0;
+  if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return 0;
+  if (stride == 1 && (Fo != F || To != T)) return 0;
+  return 1;
+}
+
+// Host helper: 1 where eat_dw_conv_bwd_bn_g runs AND is the faster plan (EAT_DW_BN_K5=0: 5x5 convs keep the apply pass +
+// eat_dw_conv_bwd_g - their on-load instances sit at 240 registers and gain 4 % only).
+extern "C" int eat_dw_bwd_merged_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
+  static const int k5 = getenv("EAT_DW_BN_K5") ? atoi(getenv("EAT_DW_BN_K5")) : 1;
+  if (k == 5 && !k5) return 0;
+  return dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride);
+}
+
+extern "C" int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float* bn_a, const float* bn_b,
+                                    const float* bn_mean, const float* bn_invstd, const float* gscale, const float* gadd,
+                                    const double* sums, int bn_act, int frozen, const float* x, const float* in_a,
+                                    const float* in_b, int in_act, const float* w, float* g, float* dw,
+                                    float* gpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To,
+                                    int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dy || !z || !bn_a || !bn_b || !bn_mean || !bn_invstd || !sums || !in_a || !in_b)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g: missing operand");
+  if (in_act < 0 || in_act > 2 || bn_act < 0 || bn_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g: bad act");
+  if (!dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g: geometry not covered by the merged kernel (F=%d T=%d k=%d stride=%d)", F, T, k, stride);
+  if (gpart && inner_cap < eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g: partial buffer too small (inner_cap %d)", inner_cap);
+  const eat::DwBnBwd bn{z, bn_a, bn_b, bn_mean, bn_invstd, gscale, gadd, sums, bn_act, frozen};
+  const int rc = eat::dw_bwd_try(dy, x, in_a, in_b, in_act, w, g, dw, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
+                                 (hipStream_t)stream, &bn);
+  if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g: merged kernel unavailable");
+  return rc;
+}
+
 extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T, int Fo,
                                      int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();

@@ -47,6 +47,16 @@ class _Zeros:
 _zeros = _Zeros()
 
 
+class _Ones(_Zeros):
+    def get(self, n, device):
+        if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            self.buf = torch.ones((max(n, 4096),), device=device, dtype=torch.float32)
+        return self.buf[:n]
+
+
+_ones = _Ones()
+
+
 # expand conv's BN + activation evaluated inside the depthwise conv / its weight gradient instead of a separate
 # bn_act_fwd pass (saves writing + re-reading the activated tensor: 2 of the 10 forward passes over expanded tensors).
 # Round 1 measured this SLOWER (25.8 vs 24.6 ms per mn10 step): the row-ring depthwise kernels load every element K
@@ -204,6 +214,7 @@ class MNTrainFunction(torch.autograd.Function):
         del dz, z_l
 
         # ---- inverted residual blocks, last to first (mn/block_types.py:177-181)
+        dout2 = None                   # second summand of the gradient w.r.t. the stem output (see res_ok below)
         for i in range(nb - 1, -1, -1):
             blk, rec = blocks[i], sv["blocks"][i]
             cnf = blk.cnf
@@ -252,15 +263,48 @@ class MNTrainFunction(torch.autograd.Function):
             # depthwise conv + BN + act
             cna = blk.block[blk.i_dw]
             k = cnf.kernel
-            if se_P is not None:
-                dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd)
-            else:
-                dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd)
-            del dxs
-            g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
             y_e = rec["y_e"]
             merged = None
-            if y_e is None and v2 and _MERGED_DW_BWD:
+            no_expand = blk.i_expand is None
+            src_shape = tuple((y_e if y_e is not None else rec["z_e"]).shape)
+            # a block without expand conv hands its residual-branch gradient to the stem's backward kernel, which adds the
+            # two on load (the merged kernel has no residual input)
+            res_ok = not no_expand or res_grad is None or (i == 0 and sv["stem"][1] is None)
+            if (v2 and _MERGED_DW_BWD and _DW_BN_ON_LOAD and (y_e is None or no_expand) and res_ok
+                    and ops.dw_bwd_merged_ok(rec["z_d"].shape, src_shape, k, cnf.stride)):
+                # large planes: dz_d is never written - the merged backward kernel evaluates the BatchNorm + activation
+                # backward of the depthwise output on load from (dxs, z_d) and the channel sums of the reduce pass
+                st_d = rec["st_d"]
+                sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P)
+                g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
+                w_d = cna[0].weight.reshape(-1, k * k)
+                if no_expand:
+                    C_d = cnf.expanded_channels
+                    dout, _, dw_d = ops.dw_conv_bwd_bn_g(dxs, rec["z_d"], st_d, act, sums, w_d, y_e, _ones.get(C_d, dev),
+                                                         _zeros.get(C_d, dev), NONE, k, cnf.stride, gscale=gscale,
+                                                         gadd=gadd, want_gsum=False)
+                    dout2 = res_grad
+                    g[f"{pre}.{blk.i_dw}.0.weight"] = dw_d.view_as(cna[0].weight)
+                    del dxs
+                    sv["blocks"][i] = None
+                    continue
+                st_e = rec["st_e"]
+                merged = ops.dw_conv_bwd_bn_g(dxs, rec["z_d"], st_d, act, sums, w_d, rec["z_e"], st_e[0], st_e[1], act, k,
+                                              cnf.stride, gscale=gscale, gadd=gadd)
+                g[f"{pre}.{blk.i_dw}.0.weight"] = merged[2].view_as(cna[0].weight)
+                in_shape = src_shape
+                dz_d = None
+                del dxs
+            else:
+                if se_P is not None:
+                    dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd)
+                else:
+                    dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd)
+                del dxs
+                g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
+            if merged is not None:
+                pass
+            elif y_e is None and v2 and _MERGED_DW_BWD:
                 # weight gradient, data gradient and the activation-derivative epilogue from ONE pass over dz_d and z_e
                 st_e = rec["st_e"]
                 merged = ops.dw_conv_bwd_g(dz_d, cna[0].weight.reshape(-1, k * k), rec["z_e"], st_e[0], st_e[1], act, k, cnf.stride)
@@ -274,7 +318,6 @@ class MNTrainFunction(torch.autograd.Function):
             else:
                 g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
                 in_shape = tuple(y_e.shape)
-            no_expand = blk.i_expand is None
             if v2 and not no_expand:
                 # expand conv + BN + act without dz_e (csrc/train_fuse.hip): g = dy_e * act'(.) and sum g leave the
                 # depthwise data-gradient kernel; dW / dx follow from Gx = sum g x^T and the forward's Gram products
@@ -327,11 +370,24 @@ class MNTrainFunction(torch.autograd.Function):
             sv["blocks"][i] = None
 
         # ---- stem
-        x, z0, st0 = sv["stem"]
+        x, z0, st0 = sv["stem"][:3]
         stem = model.features[0]
-        dz0, dgam, dbet = ops.bn_act_bwd(dout, z0, *st0, HSWISH)
-        g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
-        g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
+        if z0 is None:
+            # one pass over the block-0 gradient: g = dout * hswish'(.) from the log-mel window, Gx = sum g p^T, sum g
+            Tm0, sp0 = sv["stem"][3:]
+            W0 = stem[0].weight.reshape(-1, 9)
+            Gx, gparts = ops.stem_bwd(dout, x, W0, st0[0], st0[1], HSWISH, dy2=dout2)
+            frozen = getattr(st0[2], "_eat_frozen", False)
+            if frozen:
+                Tm0, sp0 = Gx, _zeros.get(9, dev)                                         # not read (m1 = m2 = 0)
+            dW, dgam, dbet = ops.expand_bwd_coef(W0, Gx, Tm0, sp0, gparts, st0[0], st0[2], st0[3], dout.numel() // W0.shape[0],
+                                                 frozen=frozen, need_dx=False)[:3]
+            g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
+            g["features.0.0.weight"] = dW.view_as(stem[0].weight)
+        else:
+            dz0, dgam, dbet = ops.bn_act_bwd(dout, z0, *st0, HSWISH)
+            g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
+            g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
         grads = g.finish()
         return (None,) * n_lead + tuple(grads.get(n) for n in ctx.names)
 
@@ -351,6 +407,8 @@ _FUSE_SE_BWD = os.environ.get("EAT_FUSE_SE_BWD", "1") == "1"     # A/B: gate gra
 _FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
 # A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
 _MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
+_DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthwise BN backward evaluated on load in the merged backward kernel
+_FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem without its pre-activation tensor (csrc/stem_train.hip)
 _CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
 
 
@@ -372,14 +430,28 @@ class MNTrainFunction2(torch.autograd.Function):
         # stem
         stem = model.features[0]
         C0 = stem[0].out_channels
-        z0 = ops.stem_conv(x, stem[0].weight.reshape(C0, 9), _zeros.get(C0, dev), NONE)
-        st0 = (ops.bn_state_from_partials(ops.bn_stats_partial(z0), stem[1], z0.numel() // C0) if stem[1].training
-               else ops.bn_frozen_state(stem[1]))
+        W0 = stem[0].weight.reshape(C0, 9)
         need_sx = bool(blocks) and blocks[0].i_expand is not None
-        pool_c = torch.empty((B, C0), device=dev) if need_sx else None
-        cur = ops.bn_act_fwd(z0, st0[0], st0[1], HSWISH, pool=pool_c)
-        sx = ops.col_sum(pool_c) if need_sx else None
-        saved["stem"] = (x, z0, st0)
+        if _FUSE_STEM and not need_sx:
+            # the pre-activation stem tensor never exists: statistics from the Gram matrix of the log-mel's 3x3 patches,
+            # BatchNorm + Hardswish in the conv's epilogue (csrc/stem_train.hip)
+            Fo, To = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1
+            if stem[1].training:
+                Tm0, sp0 = ops.stem_gram(x, W0)
+                st0 = ops.gram_bn_state(Tm0, W0, sp0, stem[1], B * Fo * To)
+            else:
+                Tm0, sp0, st0 = None, None, ops.bn_frozen_state(stem[1])
+            cur = ops.stem_conv(x, W0 * st0[0].unsqueeze(1), st0[1], HSWISH)
+            sx = None
+            saved["stem"] = (x, None, st0, Tm0, sp0)
+        else:
+            z0 = ops.stem_conv(x, W0, _zeros.get(C0, dev), NONE)
+            st0 = (ops.bn_state_from_partials(ops.bn_stats_partial(z0), stem[1], z0.numel() // C0) if stem[1].training
+                   else ops.bn_frozen_state(stem[1]))
+            pool_c = torch.empty((B, C0), device=dev) if need_sx else None
+            cur = ops.bn_act_fwd(z0, st0[0], st0[1], HSWISH, pool=pool_c)
+            sx = ops.col_sum(pool_c) if need_sx else None
+            saved["stem"] = (x, z0, st0)
         fmaps = [cur]
 
         blk_saved = []

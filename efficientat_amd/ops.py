@@ -506,7 +506,79 @@ def dw_conv_bwd_g(dz, w, x, in_a, in_b, in_act, k, stride):
     return g, (gpart, B, inner.value), dw
 
 
-def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False):
+def dw_bwd_merged_ok(dy_shape, x_shape, k, stride):
+    """True where the merged depthwise backward kernel runs (large planes): `dw_conv_bwd_bn_g` is available there."""
+    B, C, F, T = x_shape
+    return bool(_lib.lib().eat_dw_bwd_merged_ok(B, C, F, T, dy_shape[2], dy_shape[3], k, stride))
+
+
+def bn_act_bwd_sums(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, se_P=None):
+    """The reduce half of `bn_act_bwd` / `bn_act_bwd_se`: -> (sums (2C,) float64, dgamma, dbeta); dz is left to the consumer
+    (`dw_conv_bwd_bn_g` evaluates it on load)."""
+    B, C = z.shape[0], z.shape[1]
+    S = z.numel() // (B * C)
+    if se_P is not None:
+        sums = torch.empty((2 * C,), device=z.device, dtype=torch.float64)
+        _lib.call("eat_se_bn_bwd_combine", se_P.data_ptr(), _dev(gscale, "gscale"), _dev(gadd, "gadd"), invstd.data_ptr(), B,
+                  C, sums.data_ptr(), _stream())
+    else:
+        sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
+        _lib.call("eat_bn_act_bwd_reduce", _dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                  invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), B, C, S, act, sums.data_ptr(), _stream())
+    sf = sums.float()
+    return sums, sf[C:], sf[:C]
+
+
+def dw_conv_bwd_bn_g(dy, z, st, act, sums, w, x, in_a, in_b, in_act, k, stride, gscale=None, gadd=None, want_gsum=True):
+    """Merged depthwise backward with the BatchNorm + activation backward of the conv's own output evaluated on load from
+    (dy, z): -> (g, (gpart, B, inner) or None, dw).  st = the forward's (a, b, mean, invstd); only where `dw_bwd_merged_ok`."""
+    B, C, F, T = x.shape
+    Fo, To = z.shape[2], z.shape[3]
+    h = _lib.lib()
+    cap = int(h.eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
+    g = torch.empty((B, C, F, T), device=z.device, dtype=torch.float32)
+    gpart = torch.empty((B * C * cap,), device=z.device, dtype=torch.float32) if want_gsum else None
+    dw = zero_arena.zeros((C, k * k), torch.float32, z.device)
+    inner = _ct.c_int(0)
+    frozen = 1 if getattr(st[2], "_eat_frozen", False) else 0
+    _lib.call("eat_dw_conv_bwd_bn_g", _dev(dy, "dy"), _dev(z, "z"), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
+              st[3].data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), sums.data_ptr(), act, frozen, _dev(x, "x"),
+              in_a.data_ptr(), in_b.data_ptr(), in_act, _dev(w, "w"), g.data_ptr(), dw.data_ptr(),
+              None if gpart is None else gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride,
+              _stream())
+    return g, ((gpart, B, inner.value) if want_gsum else None), dw
+
+
+def stem_gram(x, W):
+    """(Tm = W G9 (C, 9), sp (9)) of the stem conv's 3x3 / stride-2 patches of the log-mel x (B, 1, F, T): feeds
+    `gram_bn_state` (csrc/stem_train.hip).  Bit-reproducible."""
+    B, _, F, T = x.shape
+    C = W.shape[0]
+    Fo = (F - 1) // 2 + 1
+    nblk = int(_lib.lib().eat_stem_gram_blocks(B, Fo))
+    part = torch.empty((nblk, 54), device=x.device, dtype=torch.float32)
+    out = torch.empty((C * 9 + 9,), device=x.device, dtype=torch.float32)
+    Tm, sp = out[:C * 9].view(C, 9), out[C * 9:]
+    _lib.call("eat_stem_gram", _dev(x, "x"), _dev(W, "W"), part.data_ptr(), Tm.data_ptr(), sp.data_ptr(), B, C, F, T,
+              _stream())
+    return Tm, sp
+
+
+def stem_bwd(dy, x, W, a, b, act, dy2=None):
+    """-> (Gx (C, 9) = sum g p^T, (s1, 1, 1)) with g = dy * act'(a (W p) + b): the stem's weight-gradient pass with the
+    BatchNorm + activation backward folded in (`expand_bwd_coef` finishes)."""
+    B, _, F, T = x.shape
+    C = W.shape[0]
+    buf = torch.empty((C * 10,), device=x.device, dtype=torch.float32)
+    gx, s1 = buf[:C * 9].view(C, 9), buf[C * 9:]
+    nblk = int(_lib.lib().eat_stem_bwd_blocks(B, (F - 1) // 2 + 1))
+    part = torch.empty((nblk, C, 10), device=x.device, dtype=torch.float32)
+    _lib.call("eat_stem_bwd", _dev(dy, "dy"), _opt(dy2, "dy2"), _dev(x, "x"), _dev(W, "W"), a.data_ptr(), b.data_ptr(), act,
+              part.data_ptr(), gx.data_ptr(), s1.data_ptr(), B, C, F, T, _stream())
+    return gx, (s1, 1, 1)
+
+
+def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, need_dx=True):
     """-> (dW, dgamma, dbeta, WaT (Ci,Co), M (Ci,Ci), c0 (Ci)): backward of conv1x1 -> BN(train) -> act without dz."""
     gpart, outer, inner = gparts
     Co, Ci = W.shape
@@ -518,7 +590,7 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False):
               outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 1 if frozen else 0,
               dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), tr[0].data_ptr(), tr[1].data_ptr(), tr[2].data_ptr(),
               vec[2].data_ptr(), _stream())
-    if frozen:
+    if frozen or not need_dx:
         return dW, vec[0], vec[1], tr[0], None, None
     M = linear(tr[2], tr[1], None, ACT_NONE)                               # W2T . WT^T
     c0 = linear(vec[2:3], tr[1], None, ACT_NONE).view(-1)                  # e1 . WT^T

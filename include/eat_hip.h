@@ -231,6 +231,35 @@ int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const 
                         int frozen, float* dW, float* dgamma, float* dbeta, float* WaT, float* WT, float* W2T, float* e1,
                         eat_stream_t stream);
 
+/* eat_dw_conv_bwd_g with the BatchNorm + activation backward of the depthwise conv's OWN output evaluated on load
+ * (autograd through models/mn/block_types.py:150-162 -> :72-83): dy (B,C,Fo,To) is the gradient w.r.t. act(BN(z)) - for a
+ * squeeze-excitation block the incoming gradient is dy * gscale[b,c] + gadd[b,c] -, z the conv output, bn_* the forward's
+ * (a, b, mean, invstd), sums (2C doubles) the channel sums of eat_bn_act_bwd_reduce / eat_se_bn_bwd_combine; frozen != 0:
+ * running statistics were used (no batch-mean terms).  dz is never written.  gpart may be NULL.  Only where eat_dw_bwd_merged_ok(...) != 0 (host helper), else EAT_EINVAL. */
+int eat_dw_bwd_merged_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride);
+int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float* bn_a, const float* bn_b, const float* bn_mean,
+                         const float* bn_invstd, const float* gscale, const float* gadd, const double* sums, int bn_act,
+                         int frozen, const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                         float* g, float* dw, float* gpart, int inner_cap, int* h_inner, int B, int C,
+                         int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
+
+/* Stem of the training step without its pre-activation tensor (models/mn/model.py:124-133 in train mode: Conv2d(1, C, 3,
+ * stride 2, padding 1) -> BatchNorm2d -> Hardswish; csrc/stem_train.hip).  The conv is linear in the 9-tap patch p of the
+ * log-mel x (B,1,F,T), so its batch statistics follow from G9 = sum p p^T and sp = sum p:
+ * eat_stem_gram writes Tm = W G9 (C x 9) and sp (9) (feed them to eat_gram_bn_finalize with Ci = 9), using
+ * part (eat_stem_gram_blocks(B, Fo) x 54 floats) as scratch; reduction order fixed (bit-reproducible). */
+int eat_stem_gram_blocks(int B, int Fo);
+int eat_stem_gram(const float* x, const float* W, float* part, float* Tm, float* sp, int B, int C, int F, int T,
+                  eat_stream_t stream);
+/* Backward of the same: with g = (dy + dy2) * act'(a[c] (W_c . p) + b[c]) recomputed from the log-mel window,
+ * gx (C x 9) = sum g p^T and s1 (C) = sum g; eat_expand_bwd_coef(Ci = 9, inner = outer = 1) turns them into dW, dgamma,
+ * dbeta.  dy (B,C,Fo,To); dy2 (same shape) or NULL is added on load (the gradient of the first block's residual branch:
+ * its add never needs a pass of its own).  part: scratch of eat_stem_bwd_blocks(B, Fo) x C x 10 floats (per-block sums,
+ * added in a fixed order: no atomics). */
+int eat_stem_bwd_blocks(int B, int Fo);
+int eat_stem_bwd(const float* dy, const float* dy2, const float* x, const float* W, const float* a, const float* b, int act,
+                 float* part, float* gx, float* s1, int B, int C, int F, int T, eat_stream_t stream);
+
 /* autograd of the depthwise Conv2d of models/mn/block_types.py:150-162 (data gradient):
  * Depthwise conv data gradient dx (B,C,F,T) from dz (B,C,Fo,To), taps w (C,k,k); res (B,C,F,T) or
  * NULL is added (residual branch gradient). */

@@ -281,3 +281,112 @@ def test_thin_weight_gradient_streaming_kernel(B, Co, Ci, F_, T, se, tf_act):
     tf = (a.to(DEV), b.to(DEV), tf_act) if tf_act is not None else None
     dW = ops.pw_conv_wgrad(dz.to(DEV), x.to(DEV), x_scale=sc.to(DEV) if se else None, exact=False, tf=tf)
     assert _rel(dW, ref) < 3e-5, _rel(dW, ref)
+
+
+@pytest.mark.parametrize("B,C,F_,T", [(3, 16, 128, 1000), (2, 64, 128, 1000), (5, 16, 40, 301), (2, 8, 64, 99), (1, 24, 7, 5)])
+def test_stem_without_its_preactivation_tensor(B, C, F_, T):
+    """Conv2d(1, C, 3, stride 2, padding 1) -> BatchNorm2d(train) -> Hardswish (models/mn/model.py:124-133): statistics from
+    the Gram matrix of the log-mel's 3x3 patches, BN + act in the conv epilogue, backward (dW, dgamma, dbeta) in one pass
+    over the incoming gradient - against fp64 autograd of the same op sequence."""
+    x = _rand(B, 1, F_, T, seed=1) * 0.6 + 0.1
+    W = _rand(C, 1, 3, 3, seed=2, scale=1.0 / 3)
+    gamma, beta = torch.rand(C, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(C, seed=5, scale=0.5)
+    Wr = W.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    bn_ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).double().train()
+    z_ref = F.conv2d(x.double(), Wr, stride=2, padding=1)
+    u_ref = F.batch_norm(z_ref, bn_ref.running_mean, bn_ref.running_var, gr, br, True, 0.01, 1e-3)
+    dy = _rand(*z_ref.shape, seed=6)
+    near = (u_ref.detach().abs() - 3.0).abs() < 1e-3            # Hardswish' jumps at +-3: round-off of u flips a few elements
+    dy = dy * (~near).float()
+    y_ref = F.hardswish(u_ref)
+    (y_ref * dy.double()).sum().backward()
+
+    xd, Wd = x.to(DEV), W.reshape(C, 9).to(DEV)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    n = z_ref.numel() // C
+    Tm, sp = ops.stem_gram(xd, Wd)
+    Tm2, sp2 = ops.stem_gram(xd, Wd)
+    assert torch.equal(Tm, Tm2) and torch.equal(sp, sp2)                      # fixed reduction order
+    patches = F.unfold(x.double(), 3, padding=1, stride=2)                    # (B, 9, L)
+    G9 = torch.einsum("bil,bjl->ij", patches, patches)
+    assert _rel(Tm, W.reshape(C, 9).double() @ G9) < 1e-5 and _rel(sp, patches.sum((0, 2))) < 1e-5
+    a, b, mean, invstd = ops.gram_bn_state(Tm, Wd, sp, bn, n)
+    assert _rel(mean, z_ref.mean((0, 2, 3))) < 1e-5
+    assert _rel(invstd, (z_ref.var((0, 2, 3), unbiased=False) + 1e-3).rsqrt()) < 2e-5
+    assert _rel(bn.running_mean, bn_ref.running_mean) < 1e-5 and _rel(bn.running_var, bn_ref.running_var) < 2e-5
+    y = ops.stem_conv(xd, Wd * a.unsqueeze(1), b, ops.ACT_HSWISH)
+    assert _rel(y, y_ref) < 1e-5
+    dy2 = _rand(*dy.shape, seed=9)
+    Gx, gparts = ops.stem_bwd((dy - dy2).to(DEV), xd, Wd, a, b, ops.ACT_HSWISH, dy2=dy2.to(DEV))    # two summands, added on load
+    dW, dgam, dbet = ops.expand_bwd_coef(Wd, Gx, Tm, sp, gparts, a, mean, invstd, n, need_dx=False)[:3]
+    assert _rel(dW, Wr.grad) < 2e-5, _rel(dW, Wr.grad)
+    assert _rel(dgam, gr.grad) < 2e-5 and _rel(dbet, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s,act", [(3, 64, 64, 500, 3, 2, 1), (2, 16, 64, 500, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1),
+                                               (2, 24, 32, 250, 3, 1, 2), (2, 8, 64, 200, 5, 1, 1), (3, 9, 33, 171, 3, 2, 2)])
+@pytest.mark.parametrize("variant", ["plain", "se", "frozen", "no_expand"])
+def test_dw_conv_backward_with_its_batchnorm_backward_on_load(B, C, F_, T, k, s, act, variant):
+    """eat_dw_conv_bwd_bn_g: act(BN_train(dwconv(act(a x + b)))) backward from (dy, z) without writing dz - against fp64
+    autograd of the op sequence (models/mn/block_types.py:138-162 + the SE gate's per-plane scale / add of :72-83);
+    `no_expand`: the conv input is the block input itself (first block)."""
+    p = (k - 1) // 2
+    x = _rand(B, C, F_, T, seed=1, scale=2.5)
+    ia, ib = torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5, _rand(C, seed=6, scale=0.3)
+    in_act = act
+    if variant == "no_expand":
+        ia, ib, in_act = torch.ones(C), torch.zeros(C), 0
+    w = _rand(C, 1, k, k, seed=2, scale=0.3)
+    gamma, beta = torch.rand(C, generator=torch.Generator().manual_seed(7)) + 0.5, _rand(C, seed=8, scale=0.3)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y_in = ACTS[in_act](xr * ia.double()[None, :, None, None] + ib.double()[None, :, None, None])
+    z_ref = F.conv2d(y_in, wr, None, s, p, 1, C)
+    rm, rv = torch.zeros(C).double() + 0.1, torch.ones(C).double() * 1.3
+    train = variant != "frozen"
+    u_ref = F.batch_norm(z_ref, rm.clone(), rv.clone(), gr, br, train, 0.01, 1e-3)
+    dy = _rand(*z_ref.shape, seed=3)
+    near = (u_ref.detach().abs() < 2e-3) if act == 1 else ((u_ref.detach().abs() - 3.0).abs() < 2e-3)
+    dy = dy * (~near).float()
+    gs = ga = None
+    if variant == "se":
+        gs = torch.rand(B, C, generator=torch.Generator().manual_seed(9)) + 0.2
+        ga = _rand(B, C, seed=10, scale=0.05)
+        d_eff = dy.double() * gs.double()[:, :, None, None] + ga.double()[:, :, None, None]
+    else:
+        d_eff = dy.double()
+    (ACTS[act](u_ref) * d_eff).sum().backward()
+
+    # forward state on the device (the statistics kernels have their own tests)
+    zd = z_ref.detach().float().to(DEV)
+    if train:
+        mean = z_ref.detach().mean((0, 2, 3))
+        invstd = (z_ref.detach().var((0, 2, 3), unbiased=False) + 1e-3).rsqrt()
+    else:
+        mean, invstd = rm, (rv + 1e-3).rsqrt()
+    a = (gamma.double() * invstd).float().to(DEV)
+    b = (beta.double() - mean * gamma.double() * invstd).float().to(DEV)
+    mean_d, invstd_d = mean.float().to(DEV), invstd.float().to(DEV)
+    if not train:
+        mean_d._eat_frozen = True
+    st = (a, b, mean_d, invstd_d)
+    dyd = dy.to(DEV)
+    gsd, gad = (None, None) if gs is None else (gs.to(DEV), ga.to(DEV))
+    assert ops.dw_bwd_merged_ok(zd.shape, x.shape, k, s)
+    sums, dgam, dbet = ops.bn_act_bwd_sums(dyd, zd, *st, act, gscale=gsd, gadd=gad)
+    g, gparts, dw = ops.dw_conv_bwd_bn_g(dyd, zd, st, act, sums, w.reshape(C, k * k).contiguous().to(DEV), x.to(DEV), ia.to(DEV),
+                                         ib.to(DEV), in_act, k, s, gscale=gsd, gadd=gad, want_gsum=variant != "no_expand")
+    g_ref = xr.grad / ia.double()[None, :, None, None]                     # gradient w.r.t. u = a x + b
+    assert _rel(dgam, gr.grad) < 2e-5 and _rel(dbet, br.grad) < 2e-5
+    assert _rel(g, g_ref) < 1e-5, _rel(g, g_ref)
+    assert _rel(dw, wr.grad.reshape(C, k * k)) < 5e-5, _rel(dw, wr.grad.reshape(C, k * k))
+    if gparts is not None:
+        gpart, outer, inner = gparts
+        sums_g = gpart[:B * C * inner].view(B, C, inner).sum(2)
+        ref_s = g_ref.sum((2, 3))
+        assert float((sums_g.cpu().double() - ref_s).abs().max()) < 2e-4 * max(1.0, float(ref_s.abs().max()))

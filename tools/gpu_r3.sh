@@ -27,9 +27,7 @@ if has full; then
   timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 > $OUT/full.log; tail -25 $OUT/full.log
 fi
 if has prof; then
-  for v in 1 2; do
-    EAT_TRAIN_V=$v timeout 300 python tools/prof_train.py 256 > $OUT/prof_v$v.log 2>&1; head -40 $OUT/prof_v$v.log
-  done
+  EAT_PROF_ALL=eat_ timeout 300 python tools/prof_train.py 256 > $OUT/prof.log 2>&1; head -36 $OUT/prof.log
 fi
 if has bench; then
   for v in 1 2; do
@@ -41,7 +39,8 @@ P
   done
 fi
 if has ab; then
-  for combo in "EAT_X=1" "EAT_WGRAD_THIN=0" "EAT_DW_BWD_TMIN=100000" "EAT_DW_BWD_TMIN=64"; do
+  IFS=';' read -ra COMBOS <<< "${AB:-EAT_X=1;EAT_FUSE_STEM=0;EAT_DW_BN_ON_LOAD=0}"
+  for combo in "${COMBOS[@]}"; do
     env $combo timeout 300 python bench.py --no-cpu-baseline --no-forward --no-train-configs --no-profile --steps 10 --warmup 3 > $OUT/ab.json 2> $OUT/ab.err
     python - <<P
 import json
