@@ -922,37 +922,43 @@ struct DwBwdArgs {
   DzBn bn;
 };
 
-template <int K, int S, int RO, bool BN>
+// LPP = 64: a wave owns one tile of one plane (column strips with halo lanes).  LPP = 32 / 16 (small planes, T <= 2 LPP): a
+// lane group owns the whole row of ITS plane - 64 / LPP samples of the same channel per wave, every lane busy, no halo
+// lanes (the zero padding of the conv is the group edge of from_prev / from_next).
+template <int K, int S, int RO, bool BN, int LPP>
 __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
-  constexpr int P = (K - 1) / 2, LPP = 64, KK = K * K;
+  constexpr int P = (K - 1) / 2, KK = K * K, NPW = 64 / LPP;
+  constexpr bool WR = LPP < 64;                                    // whole-row mode
   constexpr int FX = S == 1 ? RO + 2 * P : 2 * RO + 2 * P - 1;     // x rows of a tile (with halo)
   constexpr int FD = S == 1 ? RO + 2 * P : RO + 2;                 // dz rows of a tile (with halo)
   constexpr int DOFF = S == 1 ? P : 1;                             // dz-array index of the tile's first dz row
   constexpr int ND = S == 1 ? 2 : 1;                               // dz columns per lane
   constexpr int NE = S == 1 ? 2 + 2 * P : K;                       // extended x row: columns under the filter
-  const int l = threadIdx.x & 63;
-  const bool first = l == 0, last = l == 63;
+  const int lane = threadIdx.x & 63;
+  const int l = WR ? (lane & (LPP - 1)) : lane;
+  const int half = WR ? lane / LPP : 0;                            // which of the wave's NPW planes (samples)
+  const bool first = l == 0, last = l == LPP - 1;
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int tpp = a.n_rc * a.n_cs;
-  const int n_sg = (a.B + a.G - 1) / a.G;
+  const int n_sg = ((a.B + NPW - 1) / NPW + a.G - 1) / a.G;        // groups of G x NPW samples
   if (wave >= n_sg * a.C * tpp) return;
   const int pc = wave / tpp, t = wave - pc * tpp;
   const int sg = pc / a.C, c = pc - sg * a.C;
   const int rc = t / a.n_cs, cs = t - rc * a.n_cs;
   const int F = a.F, T = a.T, Fo = a.Fo, To = a.To;
   // strip: S == 1 over dx (= x) columns, S == 2 over dz columns; lane 0 (and 63) are halo lanes
-  const int s_lo = cs * a.WO, s_hi = (s_lo + a.WO) < (S == 1 ? T : To) ? (s_lo + a.WO) : (S == 1 ? T : To);
-  const int q = s_lo - 1 + l;                                       // S == 2: dz column of this lane
-  const int col_in = S == 1 ? s_lo - 2 + 2 * l : 2 * q;             // first of the lane's two x / dx columns
-  const unsigned vin = (col_in >= 0 && col_in < T) ? 4u * (unsigned)col_in : kOOB;
+  const int s_lo = WR ? 0 : cs * a.WO;
+  const int s_hi = WR ? (S == 1 ? T : To) : ((s_lo + a.WO) < (S == 1 ? T : To) ? (s_lo + a.WO) : (S == 1 ? T : To));
+  const int q = WR ? l : s_lo - 1 + l;                              // S == 2: dz column of this lane
+  const int col_in = S == 1 ? (WR ? 2 * l : s_lo - 2 + 2 * l) : 2 * q;   // first of the lane's two x / dx columns
+  // byte offsets inside the wave's first plane; the lane group's own plane lies `half` samples (C planes each) further on
+  const unsigned hx = 4u * (unsigned)(half * a.C * (F * T)), hz = 4u * (unsigned)(half * a.C * (Fo * To));
+  const unsigned vin_b = (col_in >= 0 && col_in < T) ? hx + 4u * (unsigned)col_in : kOOB;
   const bool in_part = col_in + 1 >= T;
-  const bool v0 = vin != kOOB, v1 = v0 && !in_part;
   // which of the lane's positions belong to the strip (produce output / contribute to the weight gradient)
-  const bool ok0 = S == 1 ? (col_in >= s_lo && col_in < s_hi) : (q >= s_lo && q < s_hi);
-  const bool ok1 = S == 1 ? (col_in + 1 >= s_lo && col_in + 1 < s_hi) : (ok0 && 2 * q + 1 < T);
-  const unsigned vdz = S == 1 ? vin : ((q >= 0 && q < To) ? 4u * (unsigned)q : kOOB);
-  // dx stores: an 8-byte store when both columns exist, else a single dword for the first
-  const unsigned vo2 = (ok0 && ok1) ? 4u * (unsigned)col_in : kOOB, vo1 = (ok0 && !ok1) ? 4u * (unsigned)col_in : kOOB;
+  const bool ok0_b = S == 1 ? (col_in >= s_lo && col_in < s_hi) : (q >= s_lo && q < s_hi);
+  const bool ok1_b = S == 1 ? (col_in + 1 >= s_lo && col_in + 1 < s_hi) : (ok0_b && 2 * q + 1 < T);
+  const unsigned vdz_b = S == 1 ? vin_b : ((q >= 0 && q < To) ? hz + 4u * (unsigned)q : kOOB);
   const int r0 = rc * RO;                                           // first dx row (S == 1) / dz row (S == 2) of the tile
   const int x0 = S == 1 ? r0 - P : 2 * r0 - P;                      // global row of x-array index 0
   const int d0 = r0 - DOFF;                                         // global row of dz-array index 0
@@ -977,9 +983,15 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   }
 
   for (int gi = 0; gi < a.G; ++gi) {
-    const int b = sg * a.G + gi;
-    if (b >= a.B) break;                                            // wave-uniform
-    const int p = b * a.C + c;
+    const int b0 = (sg * a.G + gi) * NPW;                           // first sample of the wave's NPW
+    if (b0 >= a.B) break;                                           // wave-uniform
+    const bool mine = b0 + half < a.B;                              // this lane group has a sample
+    const int p = b0 * a.C + c;                                     // plane of lane group 0 (descriptor base)
+    const unsigned vin = mine ? vin_b : kOOB, vdz = mine ? vdz_b : kOOB;
+    const bool v0 = vin != kOOB, v1 = v0 && !in_part;
+    const bool ok0 = ok0_b && mine, ok1 = ok1_b && mine;
+    // dx stores: an 8-byte store when both columns exist, else a single dword for the first
+    const unsigned vo2 = (ok0 && ok1) ? hx + 4u * (unsigned)col_in : kOOB, vo1 = (ok0 && !ok1) ? hx + 4u * (unsigned)col_in : kOOB;
     const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
     const long long z_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
@@ -996,7 +1008,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
     }
     if constexpr (BN) {
       const __amdgpu_buffer_rsrc_t rzz = make_rsrc(a.bn.z + (size_t)p * Fo * To, z_left);
-      const float gs = a.bn.gscale ? a.bn.gscale[p] : 1.0f, ga = a.bn.gadd ? a.bn.gadd[p] : 0.0f;
+      const int pm = mine ? p + half * a.C : p;                     // this lane group's plane (per-plane SE constants)
+      const float gs = a.bn.gscale ? a.bn.gscale[pm] : 1.0f, ga = a.bn.gadd ? a.bn.gadd[pm] : 0.0f;
       // validity as a 0 / 1 factor (operands are 0 outside the plane, so every term is finite): a select around dzf would
       // pull the loads into exec-masked blocks with a wait each
       const float m0 = eat::opaque((S == 1 ? v0 : vdz != kOOB) ? 1.0f : 0.0f), m1v = eat::opaque((S == 1 && v1) ? 1.0f : 0.0f);
@@ -1164,8 +1177,13 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       }
     }
     if (a.gpart) {
-      psum = eat::wave_sum(psum);
-      if (l == 0) a.gpart[(size_t)p * tpp + t] = psum;
+      if constexpr (WR) {
+#pragma unroll
+        for (int o = LPP >> 1; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+      } else {
+        psum = eat::wave_sum(psum);
+      }
+      if (l == 0 && mine) a.gpart[(size_t)(p + half * a.C) * tpp + t] = psum;
     }
   }
   // one cross-lane reduction of the K*K weight-gradient sums per wave, then K*K atomics
@@ -1173,9 +1191,9 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
 #pragma unroll
   for (int i = 0; i < KK; ++i) {
     const float v = eat::wave_sum(acc[i]);
-    mine_v = l == i ? v : mine_v;
+    mine_v = lane == i ? v : mine_v;
   }
-  if (l < KK) atomicAdd(a.dw + (size_t)c * KK + l, mine_v);
+  if (lane < KK) atomicAdd(a.dw + (size_t)c * KK + lane, mine_v);
 }
 
 template <int K, int S, int RO>
@@ -1183,17 +1201,24 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
   const bool bn = a.bn.z != nullptr;
   constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : 62;
   const int n_cols = S == 1 ? a.T : a.To, n_rows = S == 1 ? a.F : a.Fo;
-  a.n_cs = (n_cols + WMAX - 1) / WMAX;
+  // small planes (BN instances only): whole rows per lane group, 2 or 4 samples per wave
+  const int lpp = !bn ? 64 : (a.T <= 32 ? 16 : (a.T <= 64 ? 32 : 64));
+  const int npw = 64 / lpp;
+  a.n_cs = lpp < 64 ? 1 : (n_cols + WMAX - 1) / WMAX;
   a.WO = (n_cols + a.n_cs - 1) / a.n_cs;
   a.n_rc = (n_rows + RO - 1) / RO;
+  const int nb = (a.B + npw - 1) / npw;
   int G = 8;
-  while (G > 1 && (long long)a.C * a.n_rc * a.n_cs * ((a.B + G - 1) / G) < 8192) G >>= 1;
+  while (G > 1 && (long long)a.C * a.n_rc * a.n_cs * ((nb + G - 1) / G) < 8192) G >>= 1;
   a.G = G;
-  const long long waves = (long long)((a.B + G - 1) / G) * a.C * a.n_rc * a.n_cs;
+  const long long waves = (long long)((nb + G - 1) / G) * a.C * a.n_rc * a.n_cs;
   if (waves > 0x7fffffffLL) return 1;
   if (h_inner) *h_inner = a.n_rc * a.n_cs;
-  if (bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, w);
-  else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, w);
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  if (!bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false, 64>), grid, dim3(256), 0, s, a, w);
+  else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64>), grid, dim3(256), 0, s, a, w);
+  else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32>), grid, dim3(256), 0, s, a, w);
+  else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16>), grid, dim3(256), 0, s, a, w);
   return eat::check_launch("eat_dw_conv_bwd_g");
 }
 
@@ -1280,11 +1305,14 @@ int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* 
   // 0.35 vs 0.53 ms) and loses on the small late-layer planes, where the whole-plane kernels pack one or two planes per
   // wave with every lane busy (4x32 planes: 0.69 vs 0.35 ms; a wave of this kernel would use 18 of its 64 lanes)
   static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
-  if (T <= t_min) return 1;
+  if (!bn && T <= t_min) return 1;                       // (with the BatchNorm backward on load the small planes gain: fewer passes)
   DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act},
               DzBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0}};
   if (bn) a.bn = DzBn{bn->z, bn->a, bn->b, bn->mean, bn->invstd, bn->gscale, bn->gadd, bn->sums, (double)B * Fo * To, bn->act, bn->frozen};
   if (stride == 1 && (Fo != F || To != T)) return 1;
+  // 5x5 on planes of <= 4 (output) rows, the last stage of the network: tiles of 4 rows (half the multiply work of RO = 8)
+  if (bn && k == 5 && stride == 1 && F <= 4 && T <= 64) return launch_dw_bwd<5, 1, 4>(a, w, h_inner, s);
+  if (bn && k == 5 && stride == 2 && Fo <= 4 && T <= 64) return launch_dw_bwd<5, 2, 4>(a, w, h_inner, s);
   if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 8>(a, w, h_inner, s);      // (RO = 16 needs 246 VGPRs)
   if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 8>(a, w, h_inner, s);
   if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 8>(a, w, h_inner, s);

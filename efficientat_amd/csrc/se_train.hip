@@ -1,0 +1,153 @@
+// Backward of the squeeze-excitation gate MLP in two launches (round 3).
+//   reference: autograd through models/mn/block_types.py:72-83 - scale = sigmoid(fc2(relu(fc1(mean_{f,t} y)))), out = y * scale.
+//
+// Given ds[b,c] = sum_{f,t} d_out * y (the gate's incoming gradient, taken by eat_se_bn_bwd_partials / eat_plane_dot):
+//   dq  = ds * s * (1 - s)                                   (B, C)
+//   dW2 = dq^T h,  db2 = sum_b dq                            (C, Cr), (C)
+//   dh  = (dq W2) * [h > 0]                                  (B, Cr)
+//   dW1 = dh^T zmean,  db1 = sum_b dh,  zmean = pool / S     (Cr, C), (Cr)
+//   gadd = (dh W1) / S                                       (B, C)   - the gradient w.r.t. y through the squeeze
+// As torch ops this was ~25 launches per block (transposes for the contraction-contiguous GEMM kernel, elementwise
+// products, sums, masks) of 3-6 us each on KB-sized tensors: 8 SE blocks = ~0.9 ms of a 27 ms step spent on launch
+// latency.  Here: stage 1 = {dW2, db2, dh}, stage 2 = {dW1, db1, gadd}, each ONE launch whose blocks pick their problem
+// from blockIdx.x; plain fp32 FMA on 32 x 32 tiles staged through LDS (the GEMMs are <= 120 MFLOP; operands stay in L2),
+// operands addressed by strides so that no transposed copy is ever made.  Every output element is produced by one block
+// (full contraction): no atomics, bit-reproducible.
+#include "eat_common.h"
+
+namespace {
+
+// one 32 x 32 output tile: out(m, n) = sum_k A(m, k) B(k, n); A_MFAST: A is contiguous along m (else along k); B is
+// contiguous along n.  256 threads, 4 outputs per thread (rows ty, ty + 8, ty + 16, ty + 24 of column tx).  The k axis
+// goes through LDS in chunks of 128: 16 + 16 loads per thread in flight per barrier pair (chunks of 32 left the kernel
+// waiting on one memory latency per 32 k: 55 us for K = 960).
+constexpr int kKC = 128;
+template <bool A_MFAST, class FA, class FB, class FS>
+__device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, FA a_at, FB b_at, FS store) {
+  __shared__ float sA[kKC][33], sB[kKC][33];        // sA[k][m], sB[k][n]
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += kKC) {
+    float av[16], bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      // A: fast index tx, slow index ty + 8 i over (m: 32) x (k: 128)
+      int mm, kk;
+      if (A_MFAST) { mm = tx; kk = ty + 8 * i; }
+      else { kk = tx + 32 * (i & 3); mm = ty + 8 * (i >> 2); }
+      av[i] = (m0 + mm < M && k0 + kk < K) ? a_at(m0 + mm, k0 + kk) : 0.0f;
+      const int kb = ty + 8 * i;
+      bv[i] = (k0 + kb < K && n0 + tx < N) ? b_at(k0 + kb, n0 + tx) : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int mm, kk;
+      if (A_MFAST) { mm = tx; kk = ty + 8 * i; }
+      else { kk = tx + 32 * (i & 3); mm = ty + 8 * (i >> 2); }
+      sA[kk][mm] = av[i];
+      sB[ty + 8 * i][tx] = bv[i];
+    }
+    __syncthreads();
+    const int kn = (K - k0) < kKC ? (K - k0) : kKC;
+    for (int kk = 0; kk < kn; ++kk) {
+      const float b = sB[kk][tx];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = fmaf(sA[kk][ty + 8 * i], b, acc[i]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + 8 * i, n = n0 + tx;
+    if (m < M && n < N) store(m, n, acc[i]);
+  }
+}
+
+// column sums out[n] = sum_m f(m, n) for 32 columns per block: 8 row groups x 32 columns, LDS reduction
+template <class F>
+__device__ __forceinline__ void col_sum_tile(int M, int N, int n0, F f, float* __restrict__ out) {
+  __shared__ float s_cs[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float s = 0.0f;
+  if (n0 + tx < N)
+    for (int m = ty; m < M; m += 8) s += f(m, n0 + tx);
+  s_cs[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n0 + tx < N) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += s_cs[i][tx];
+    out[n0 + tx] = t;
+  }
+}
+
+__device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// stage 1: blocks [0, nA) -> dW2 tiles, [nA, nA + nB) -> dh tiles, then cdiv(C, 32) blocks -> db2
+__global__ __launch_bounds__(256) void se_bwd_stage1_kernel(const float* __restrict__ ds, const float* __restrict__ sc,
+                                                            const float* __restrict__ h, const float* __restrict__ W2,
+                                                            float* __restrict__ dW2, float* __restrict__ db2,
+                                                            float* __restrict__ dh, int B, int C, int Cr) {
+  auto dq = [&](int b, int c) { const float s = sc[(size_t)b * C + c]; return ds[(size_t)b * C + c] * s * (1.0f - s); };
+  const int tA_n = cdiv(Cr, 32), nA = cdiv(C, 32) * tA_n;
+  const int tB_n = cdiv(Cr, 32), nB = cdiv(B, 32) * tB_n;
+  int id = blockIdx.x;
+  if (id < nA) {                      // dW2 (C x Cr): A(m = c, k = b) = dq[b, c], B(k = b, n = r) = h[b, r]
+    gemm_tile<true>(C, Cr, B, (id / tA_n) * 32, (id % tA_n) * 32, [&](int m, int k) { return dq(k, m); },
+                    [&](int k, int n) { return h[(size_t)k * Cr + n]; },
+                    [&](int m, int n, float v) { dW2[(size_t)m * Cr + n] = v; });
+    return;
+  }
+  id -= nA;
+  if (id < nB) {                      // dh (B x Cr): A(m = b, k = c) = dq[b, c], B(k = c, n = r) = W2[c, r]
+    gemm_tile<false>(B, Cr, C, (id / tB_n) * 32, (id % tB_n) * 32, [&](int m, int k) { return dq(m, k); },
+                     [&](int k, int n) { return W2[(size_t)k * Cr + n]; },
+                     [&](int m, int n, float v) { dh[(size_t)m * Cr + n] = h[(size_t)m * Cr + n] > 0.0f ? v : 0.0f; });
+    return;
+  }
+  id -= nB;
+  col_sum_tile(B, C, id * 32, dq, db2);
+}
+
+// stage 2: blocks [0, nC) -> dW1 tiles, [nC, nC + nD) -> gadd tiles, then cdiv(Cr, 32) blocks -> db1
+__global__ __launch_bounds__(256) void se_bwd_stage2_kernel(const float* __restrict__ dh, const float* __restrict__ pool,
+                                                            const float* __restrict__ W1, float inv_s,
+                                                            float* __restrict__ dW1, float* __restrict__ db1,
+                                                            float* __restrict__ gadd, int B, int C, int Cr) {
+  const int tC_n = cdiv(C, 32), nC = cdiv(Cr, 32) * tC_n;
+  const int tD_n = cdiv(C, 32), nD = cdiv(B, 32) * tD_n;
+  int id = blockIdx.x;
+  if (id < nC) {                      // dW1 (Cr x C): A(m = r, k = b) = dh[b, r], B(k = b, n = c) = pool[b, c] / S
+    gemm_tile<true>(Cr, C, B, (id / tC_n) * 32, (id % tC_n) * 32, [&](int m, int k) { return dh[(size_t)k * Cr + m]; },
+                    [&](int k, int n) { return pool[(size_t)k * C + n] * inv_s; },
+                    [&](int m, int n, float v) { dW1[(size_t)m * C + n] = v; });
+    return;
+  }
+  id -= nC;
+  if (id < nD) {                      // gadd (B x C): A(m = b, k = r) = dh[b, r], B(k = r, n = c) = W1[r, c]
+    gemm_tile<false>(B, C, Cr, (id / tD_n) * 32, (id % tD_n) * 32, [&](int m, int k) { return dh[(size_t)m * Cr + k]; },
+                     [&](int k, int n) { return W1[(size_t)k * C + n]; },
+                     [&](int m, int n, float v) { gadd[(size_t)m * C + n] = v * inv_s; });
+    return;
+  }
+  id -= nD;
+  col_sum_tile(B, Cr, id * 32, [&](int b, int r) { return dh[(size_t)b * Cr + r]; }, db1);
+}
+
+}  // namespace
+
+static int cdiv_host(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int eat_se_mlp_bwd(const float* ds, const float* scale, const float* h, const float* pool, const float* W1,
+                              const float* W2, float inv_s, float* dW1, float* db1, float* dW2, float* db2, float* dh,
+                              float* gadd, int B, int C, int Cr, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Cr < 1) return eat::fail(EAT_EINVAL, "eat_se_mlp_bwd: bad shape");
+  const int n1 = cdiv_host(C, 32) * cdiv_host(Cr, 32) + cdiv_host(B, 32) * cdiv_host(Cr, 32) + cdiv_host(C, 32);
+  const int n2 = cdiv_host(Cr, 32) * cdiv_host(C, 32) + cdiv_host(B, 32) * cdiv_host(C, 32) + cdiv_host(Cr, 32);
+  hipLaunchKernelGGL(se_bwd_stage1_kernel, dim3((unsigned)n1), dim3(256), 0, (hipStream_t)stream, ds, scale, h, W2, dW2, db2,
+                     dh, B, C, Cr);
+  hipLaunchKernelGGL(se_bwd_stage2_kernel, dim3((unsigned)n2), dim3(256), 0, (hipStream_t)stream, dh, pool, W1, inv_s, dW1,
+                     db1, gadd, B, C, Cr);
+  return eat::check_launch("eat_se_mlp_bwd");
+}

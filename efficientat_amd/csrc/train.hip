@@ -1280,10 +1280,10 @@ extern "C" int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* i
 // eat_dw_bwd_merged_ok(...) != 0, else EAT_EINVAL.
 static int dw_bwd_bn_geometry_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
   static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
-  static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
-  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28) || T <= t_min) return 0;
+  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 0;
   if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return 0;
   if (stride == 1 && (Fo != F || To != T)) return 0;
+  if ((long long)4 * C * F * T * 4 >= 0x7fffffffLL) return 0;         // lane-group offsets inside a wave's samples are 32-bit
   return 1;
 }
 
@@ -1292,6 +1292,12 @@ static int dw_bwd_bn_geometry_ok(int B, int C, int F, int T, int Fo, int To, int
 extern "C" int eat_dw_bwd_merged_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
   static const int k5 = getenv("EAT_DW_BN_K5") ? atoi(getenv("EAT_DW_BN_K5")) : 1;
   if (k == 5 && !k5) return 0;
+  static const int t_min = getenv("EAT_DW_BN_TMIN") ? atoi(getenv("EAT_DW_BN_TMIN")) : 0;      // A/B: large planes only
+  if (T <= t_min) return 0;
+  // measured (B = 256): 5x5 / stride 1 on 16 x 125 planes 446 us against 139 (apply) + 270 (plane kernels): 25 taps x 2 on
+  // tiles whose halo rows are half of the loads; the 4-row planes run the RO = 4 instance
+  static const int k5s1 = getenv("EAT_DW_BN_K5S1") ? atoi(getenv("EAT_DW_BN_K5S1")) : 0;
+  if (k == 5 && stride == 1 && T <= 128 && !(F <= 4 && T <= 64) && !k5s1) return 0;
   return dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride);
 }
 
@@ -1367,8 +1373,11 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
     p.kind = 1;
     p.upb = sps;                                             // per-sample gradients: one sample per block
     if (!per_sample) {
-      // ~1024 blocks, but at least 16 units (512 k) of MFMA work in front of a block's Co x Ci atomics
-      long long splits = (1024 + tiles - 1) / tiles;
+      // ~512 blocks, but at least 16 units (512 k) of MFMA work in front of a block's Co x Ci atomics
+      // (512 = one round of two resident blocks per CU; 1024 measured 0.26 ms slower per mn10 step: the second round pays
+      // prologue, tail and the Co x Ci atomics again)
+      static const int target = getenv("EAT_WGRAD_BLOCKS") ? atoi(getenv("EAT_WGRAD_BLOCKS")) : 512;
+      long long splits = (target + tiles - 1) / tiles;
       if (splits > total / 16) splits = total / 16;
       if (splits < 1) splits = 1;
       p.upb = (int)((total + splits - 1) / splits);

@@ -183,11 +183,30 @@ class MNTrainFunction(torch.autograd.Function):
         blocks = list(model.features[1:-1])
         nb = len(blocks)
 
+        # the fp64 channel sums of every BatchNorm backward of the pass live in ONE zeroed buffer: dgamma / dbeta of all
+        # layers are converted to fp32 by one launch at the end (31 conversions before) and handed to the sink together
+        bn_total = 2 * sum(m.num_features for m in model.features.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        bn_buf = ops.zero_arena.zeros((bn_total,), torch.float64, dev) if v2 else None
+        bn_reg = []
+
+        def bn_sums(C, wname, bname):
+            if bn_buf is None:
+                return None
+            off = sum(2 * r[2] for r in bn_reg)
+            bn_reg.append((wname, bname, C, off))
+            return bn_buf[off:off + 2 * C]
+
+        def bn_grads(dgam, dbet, wname, bname):
+            if dgam is not None:
+                g[wname], g[bname] = dgam, dbet
+
         x_l, z_l, st_l, S_l = sv["last"]
         last = model.features[-1]
+        nm = f"features.{nb + 1}"
         if sv["head"] is None:
             # trunk mode: the head ran outside (torch autograd); dlogits is the gradient w.r.t. the last feature map
-            dz, dgam, dbet = ops.bn_act_bwd(dlogits.view_as(z_l), z_l, *st_l, HSWISH)
+            dz, dgam, dbet = ops.bn_act_bwd(dlogits.view_as(z_l), z_l, *st_l, HSWISH,
+                                            sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
         else:
             # ---- head (mn/model.py:186-194)
             feat, u, h2, drop_mask = sv["head"]
@@ -205,9 +224,9 @@ class MNTrainFunction(torch.autograd.Function):
                 dft = dft + dfeat
             # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
             zeros_bc = torch.zeros((B, z_l.shape[1]), device=dev)
-            dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l))
-        nm = f"features.{nb + 1}"
-        g[nm + ".1.weight"], g[nm + ".1.bias"] = dgam, dbet
+            dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l),
+                                            sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
+        bn_grads(dgam, dbet, nm + ".1.weight", nm + ".1.bias")
         g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
         wpt = ops.pw_prepack(last[0].weight.flatten(1), trans=True)
         dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
@@ -224,8 +243,9 @@ class MNTrainFunction(torch.autograd.Function):
             res_grad = dout if blk.use_res_connect else None
             # project conv + BN (no activation); the residual branch passes dout through unchanged
             cna = blk.block[blk.i_proj]
-            dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE)
-            g[f"{pre}.{blk.i_proj}.1.weight"], g[f"{pre}.{blk.i_proj}.1.bias"] = dgam, dbet
+            nw, nbias = f"{pre}.{blk.i_proj}.1.weight", f"{pre}.{blk.i_proj}.1.bias"
+            dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias))
+            bn_grads(dgam, dbet, nw, nbias)
             scale = rec.get("scale")
             if rec["y_d"] is None:         # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
                 st_d = rec["st_d"]
@@ -251,14 +271,20 @@ class MNTrainFunction(torch.autograd.Function):
                     ds = ops.plane_dot(dxs, rec["z_d"], st_d[0], st_d[1], act)
                 else:
                     ds = ops.plane_dot(dxs, rec["y_d"])
-                dq = ds * scale * (1.0 - scale)
-                g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
-                g[sp + ".fc2.bias"] = dq.sum(0)
-                dh = _mm_nt(dq, _t(se.fc2.weight)) * (h > 0).float()
-                zmean = pool * (1.0 / S_d)
-                g[sp + ".fc1.weight"] = _mm_nt(_t(dh), _t(zmean))
-                g[sp + ".fc1.bias"] = dh.sum(0)
-                gadd = _mm_nt(dh, _t(se.fc1.weight)) * (1.0 / S_d)
+                if v2 and _FUSE_SE_MLP:
+                    # the gate MLP's backward as two launches (csrc/se_train.hip) instead of ~25 KB-sized torch ops
+                    dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d)
+                    g[sp + ".fc2.weight"], g[sp + ".fc2.bias"] = dW2, db2
+                    g[sp + ".fc1.weight"], g[sp + ".fc1.bias"] = dW1, db1
+                else:
+                    dq = ds * scale * (1.0 - scale)
+                    g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
+                    g[sp + ".fc2.bias"] = dq.sum(0)
+                    dh = _mm_nt(dq, _t(se.fc2.weight)) * (h > 0).float()
+                    zmean = pool * (1.0 / S_d)
+                    g[sp + ".fc1.weight"] = _mm_nt(_t(dh), _t(zmean))
+                    g[sp + ".fc1.bias"] = dh.sum(0)
+                    gadd = _mm_nt(dh, _t(se.fc1.weight)) * (1.0 / S_d)
                 gscale = scale
             # depthwise conv + BN + act
             cna = blk.block[blk.i_dw]
@@ -275,8 +301,10 @@ class MNTrainFunction(torch.autograd.Function):
                 # large planes: dz_d is never written - the merged backward kernel evaluates the BatchNorm + activation
                 # backward of the depthwise output on load from (dxs, z_d) and the channel sums of the reduce pass
                 st_d = rec["st_d"]
-                sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P)
-                g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
+                nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
+                sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P,
+                                                       sums=bn_sums(cnf.expanded_channels, nw, nbias))
+                bn_grads(dgam, dbet, nw, nbias)
                 w_d = cna[0].weight.reshape(-1, k * k)
                 if no_expand:
                     C_d = cnf.expanded_channels
@@ -296,12 +324,15 @@ class MNTrainFunction(torch.autograd.Function):
                 dz_d = None
                 del dxs
             else:
+                nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
                 if se_P is not None:
-                    dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd)
+                    dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd,
+                                                         sums=bn_sums(cnf.expanded_channels, nw, nbias))
                 else:
-                    dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd)
+                    dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd,
+                                                      sums=bn_sums(cnf.expanded_channels, nw, nbias))
                 del dxs
-                g[f"{pre}.{blk.i_dw}.1.weight"], g[f"{pre}.{blk.i_dw}.1.bias"] = dgam, dbet
+                bn_grads(dgam, dbet, nw, nbias)
             if merged is not None:
                 pass
             elif y_e is None and v2 and _MERGED_DW_BWD:
@@ -388,6 +419,10 @@ class MNTrainFunction(torch.autograd.Function):
             dz0, dgam, dbet = ops.bn_act_bwd(dout, z0, *st0, HSWISH)
             g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
             g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
+        if bn_reg:
+            sf = bn_buf.float()
+            for wname, bname, C, off in bn_reg:
+                g[wname], g[bname] = sf[off + C:off + 2 * C], sf[off:off + C]
         grads = g.finish()
         return (None,) * n_lead + tuple(grads.get(n) for n in ctx.names)
 
@@ -408,6 +443,7 @@ _FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
 # A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
 _MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
 _DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthwise BN backward evaluated on load in the merged backward kernel
+_FUSE_SE_MLP = os.environ.get("EAT_FUSE_SE_MLP", "1") == "1"        # A/B: SE gate MLP backward as two launches (csrc/se_train.hip)
 _FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem without its pre-activation tensor (csrc/stem_train.hip)
 _CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
 

@@ -247,7 +247,7 @@ def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True):
     return y
 
 
-def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None):
+def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None, sums=None):
     """-> (dz, dgamma, dbeta) for y = act(BN_batch(z)); incoming grad = dy*gscale[b,c] + gadd[b,c].
     frozen (default: the flag `bn_train_state` left on `mean`): the layer normalised with its running statistics,
     i.e. dz = a * g without the batch-mean terms (dgamma / dbeta are the same reductions)."""
@@ -255,13 +255,17 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=No
         frozen = getattr(mean, "_eat_frozen", False)
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
-    sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
+    own = sums is None            # sums: a zeroed (2C,) float64 slice of the caller's arena (one fp32 conversion per pass)
+    if own:
+        sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
     args = (_dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
             _opt(gscale, "gscale"), _opt(gadd, "gadd"))
     _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
     dz = torch.empty_like(z)
     asums = torch.zeros_like(sums) if frozen else sums
     _lib.call("eat_bn_act_bwd_apply", *args, asums.data_ptr(), dz.data_ptr(), B, C, S, act, _stream())
+    if not own:
+        return dz, None, None
     sf = sums.float()
     return dz, sf[C:], sf[:C]
 
@@ -276,11 +280,13 @@ def se_bn_bwd_partials(d, z, a, b, mean, act):
     return P
 
 
-def bn_act_bwd_se(dy, z, a, b, mean, invstd, act, P, gscale, gadd):
+def bn_act_bwd_se(dy, z, a, b, mean, invstd, act, P, gscale, gadd, sums=None):
     """bn_act_bwd for a squeeze-excitation block whose plane sums P were taken by `se_bn_bwd_partials`: no reduce pass."""
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
-    sums = torch.empty((2 * C,), device=z.device, dtype=torch.float64)
+    own = sums is None
+    if own:
+        sums = torch.empty((2 * C,), device=z.device, dtype=torch.float64)
     _lib.call("eat_se_bn_bwd_combine", P.data_ptr(), _dev(gscale, "gscale"), _dev(gadd, "gadd"), invstd.data_ptr(), B, C,
               sums.data_ptr(), _stream())
     frozen = getattr(mean, "_eat_frozen", False)
@@ -289,6 +295,8 @@ def bn_act_bwd_se(dy, z, a, b, mean, invstd, act, P, gscale, gadd):
     _lib.call("eat_bn_act_bwd_apply", _dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
               invstd.data_ptr(), gscale.data_ptr(), gadd.data_ptr(), asums.data_ptr(), dz.data_ptr(), B, C, S, act,
               _stream())
+    if not own:
+        return dz, None, None
     sf = sums.float()
     return dz, sf[C:], sf[:C]
 
@@ -512,19 +520,24 @@ def dw_bwd_merged_ok(dy_shape, x_shape, k, stride):
     return bool(_lib.lib().eat_dw_bwd_merged_ok(B, C, F, T, dy_shape[2], dy_shape[3], k, stride))
 
 
-def bn_act_bwd_sums(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, se_P=None):
+def bn_act_bwd_sums(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, se_P=None, sums=None):
     """The reduce half of `bn_act_bwd` / `bn_act_bwd_se`: -> (sums (2C,) float64, dgamma, dbeta); dz is left to the consumer
     (`dw_conv_bwd_bn_g` evaluates it on load)."""
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
+    own = sums is None
     if se_P is not None:
-        sums = torch.empty((2 * C,), device=z.device, dtype=torch.float64)
+        if own:
+            sums = torch.empty((2 * C,), device=z.device, dtype=torch.float64)
         _lib.call("eat_se_bn_bwd_combine", se_P.data_ptr(), _dev(gscale, "gscale"), _dev(gadd, "gadd"), invstd.data_ptr(), B,
                   C, sums.data_ptr(), _stream())
     else:
-        sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
+        if own:
+            sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
         _lib.call("eat_bn_act_bwd_reduce", _dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
                   invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), B, C, S, act, sums.data_ptr(), _stream())
+    if not own:
+        return sums, None, None
     sf = sums.float()
     return sums, sf[C:], sf[:C]
 
@@ -547,6 +560,25 @@ def dw_conv_bwd_bn_g(dy, z, st, act, sums, w, x, in_a, in_b, in_act, k, stride, 
               None if gpart is None else gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride,
               _stream())
     return g, ((gpart, B, inner.value) if want_gsum else None), dw
+
+
+def se_mlp_bwd(ds, scale, h, pool, W1, W2, S):
+    """Backward of the SE gate MLP in two launches -> (dW1, db1, dW2, db2, gadd); see csrc/se_train.hip."""
+    B, C = ds.shape
+    Cr = h.shape[1]
+    dev = ds.device
+    buf = torch.empty((2 * C * Cr + C + Cr + B * Cr + B * C,), device=dev, dtype=torch.float32)
+    o = 0
+    dW1 = buf[o:o + Cr * C].view(Cr, C); o += Cr * C
+    dW2 = buf[o:o + C * Cr].view(C, Cr); o += C * Cr
+    db1 = buf[o:o + Cr]; o += Cr
+    db2 = buf[o:o + C]; o += C
+    dh = buf[o:o + B * Cr]; o += B * Cr
+    gadd = buf[o:o + B * C].view(B, C)
+    _lib.call("eat_se_mlp_bwd", _dev(ds, "ds"), _dev(scale, "scale"), _dev(h, "h"), _dev(pool, "pool"), _dev(W1, "W1"),
+              _dev(W2, "W2"), 1.0 / S, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), dh.data_ptr(),
+              gadd.data_ptr(), B, C, Cr, _stream())
+    return dW1, db1, dW2, db2, gadd
 
 
 def stem_gram(x, W):
@@ -584,17 +616,18 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, nee
     Co, Ci = W.shape
     dev = W.device
     dW = torch.empty((Co, Ci), device=dev, dtype=torch.float32)
-    vec = torch.empty((3, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta, e1
-    tr = torch.empty((3, Ci, Co), device=dev, dtype=torch.float32)        # WaT, WT, W2T
+    vec = torch.empty((2, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta
+    tr = torch.empty((3 * Ci + 1, Co), device=dev, dtype=torch.float32)   # WaT, WT, [W2T ; e1]: M and c0 from ONE GEMM
+    w2e = tr[2 * Ci:]
+    tr = (tr[:Ci], tr[Ci:2 * Ci], w2e[:Ci])
     _lib.call("eat_expand_bwd_coef", _dev(W, "W"), _dev(Gx, "Gx"), _dev(Tm, "Tm"), _dev(sx, "sx"), gpart.data_ptr(),
               outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 1 if frozen else 0,
               dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), tr[0].data_ptr(), tr[1].data_ptr(), tr[2].data_ptr(),
-              vec[2].data_ptr(), _stream())
+              w2e[Ci].data_ptr(), _stream())
     if frozen or not need_dx:
         return dW, vec[0], vec[1], tr[0], None, None
-    M = linear(tr[2], tr[1], None, ACT_NONE)                               # W2T . WT^T
-    c0 = linear(vec[2:3], tr[1], None, ACT_NONE).view(-1)                  # e1 . WT^T
-    return dW, vec[0], vec[1], tr[0], M, c0
+    Mc = linear(w2e, tr[1], None, ACT_NONE)                                # [W2T ; e1] . WT^T -> (Ci + 1, Ci)
+    return dW, vec[0], vec[1], tr[0], Mc[:Ci], Mc[Ci]
 
 
 # ------------------------------------------------------------------------- DyMN launchers

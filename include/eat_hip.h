@@ -243,6 +243,16 @@ int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float* bn_a, con
                          float* g, float* dw, float* gpart, int inner_cap, int* h_inner, int B, int C,
                          int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
 
+/* Backward of the squeeze-excitation gate MLP (autograd through models/mn/block_types.py:72-83:
+ * scale = sigmoid(fc2(relu(fc1(mean y))))) in two launches, operands addressed by strides (no transposed copies):
+ *   in : ds (B,C) = sum_{f,t} d_out * y, scale (B,C), h (B,Cr) = relu(fc1(..)), pool (B,C) = sum_{f,t} y, W1 (Cr,C), W2 (C,Cr),
+ *        inv_s = 1 / (F T)
+ *   out: dW1 (Cr,C), db1 (Cr), dW2 (C,Cr), db2 (C), gadd (B,C) = the gradient w.r.t. y through the squeeze;
+ *        dh (B,Cr) scratch.  Plain fp32, every output element written by one block (bit-reproducible). */
+int eat_se_mlp_bwd(const float* ds, const float* scale, const float* h, const float* pool, const float* W1, const float* W2,
+                   float inv_s, float* dW1, float* db1, float* dW2, float* db2, float* dh, float* gadd, int B, int C, int Cr,
+                   eat_stream_t stream);
+
 /* Stem of the training step without its pre-activation tensor (models/mn/model.py:124-133 in train mode: Conv2d(1, C, 3,
  * stride 2, padding 1) -> BatchNorm2d -> Hardswish; csrc/stem_train.hip).  The conv is linear in the 9-tap patch p of the
  * log-mel x (B,1,F,T), so its batch statistics follow from G9 = sum p p^T and sp = sum p:

@@ -328,7 +328,13 @@ def test_stem_without_its_preactivation_tensor(B, C, F_, T):
 
 
 @pytest.mark.parametrize("B,C,F_,T,k,s,act", [(3, 64, 64, 500, 3, 2, 1), (2, 16, 64, 500, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1),
-                                               (2, 24, 32, 250, 3, 1, 2), (2, 8, 64, 200, 5, 1, 1), (3, 9, 33, 171, 3, 2, 2)])
+                                               (2, 24, 32, 250, 3, 1, 2), (2, 8, 64, 200, 5, 1, 1), (3, 9, 33, 171, 3, 2, 2),
+                                               # small planes: whole rows per lane group, 2 / 4 samples per wave (odd batches:
+                                               # lane groups without a sample), one plane per wave at 16 x 125
+                                               (5, 120, 16, 125, 5, 1, 2), (3, 240, 16, 125, 3, 2, 2), (5, 200, 8, 63, 3, 1, 2),
+                                               (3, 672, 8, 63, 5, 2, 2), (5, 96, 4, 32, 5, 1, 2), (7, 12, 4, 32, 3, 2, 1),
+                                               (70, 24, 8, 63, 3, 1, 2), (3, 40, 9, 21, 3, 1, 1), (2, 3, 1, 2, 3, 2, 1),
+                                               (9, 5, 17, 64, 5, 1, 1), (6, 7, 20, 33, 3, 2, 2)])
 @pytest.mark.parametrize("variant", ["plain", "se", "frozen", "no_expand"])
 def test_dw_conv_backward_with_its_batchnorm_backward_on_load(B, C, F_, T, k, s, act, variant):
     """eat_dw_conv_bwd_bn_g: act(BN_train(dwconv(act(a x + b)))) backward from (dy, z) without writing dz - against fp64
@@ -377,7 +383,6 @@ def test_dw_conv_backward_with_its_batchnorm_backward_on_load(B, C, F_, T, k, s,
     st = (a, b, mean_d, invstd_d)
     dyd = dy.to(DEV)
     gsd, gad = (None, None) if gs is None else (gs.to(DEV), ga.to(DEV))
-    assert ops.dw_bwd_merged_ok(zd.shape, x.shape, k, s)
     sums, dgam, dbet = ops.bn_act_bwd_sums(dyd, zd, *st, act, gscale=gsd, gadd=gad)
     g, gparts, dw = ops.dw_conv_bwd_bn_g(dyd, zd, st, act, sums, w.reshape(C, k * k).contiguous().to(DEV), x.to(DEV), ia.to(DEV),
                                          ib.to(DEV), in_act, k, s, gscale=gsd, gadd=gad, want_gsum=variant != "no_expand")
@@ -390,3 +395,23 @@ def test_dw_conv_backward_with_its_batchnorm_backward_on_load(B, C, F_, T, k, s,
         sums_g = gpart[:B * C * inner].view(B, C, inner).sum(2)
         ref_s = g_ref.sum((2, 3))
         assert float((sums_g.cpu().double() - ref_s).abs().max()) < 2e-4 * max(1.0, float(ref_s.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,Cr,S", [(256, 72, 24, 2000), (37, 120, 32, 504), (5, 960, 240, 128), (3, 33, 7, 10), (64, 672, 168, 504)])
+def test_se_gate_mlp_backward_in_two_launches(B, C, Cr, S):
+    """eat_se_mlp_bwd against fp64 autograd of scale = sigmoid(fc2(relu(fc1(mean y)))), loss = sum_b,c ds * scale
+    (models/mn/block_types.py:72-83; ds = the gate's incoming gradient)."""
+    pool = _rand(B, C, seed=1) * S * 0.5
+    W1, b1 = _rand(Cr, C, seed=2, scale=C ** -0.5), _rand(Cr, seed=3, scale=0.1)
+    W2, b2 = _rand(C, Cr, seed=4, scale=Cr ** -0.5), _rand(C, seed=5, scale=0.1)
+    ds = _rand(B, C, seed=6)
+    pr = pool.double().requires_grad_(True)
+    W1r, b1r, W2r, b2r = (t.double().requires_grad_(True) for t in (W1, b1, W2, b2))
+    h_ref = F.relu(F.linear(pr / S, W1r, b1r))
+    s_ref = torch.sigmoid(F.linear(h_ref, W2r, b2r))
+    (s_ref * ds.double()).sum().backward()
+    h = ops.linear(pool.to(DEV), W1.to(DEV), b1.to(DEV), ops.ACT_RELU, 1.0 / S)
+    scale = ops.linear(h, W2.to(DEV), b2.to(DEV), ops.ACT_SIGMOID)
+    dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds.to(DEV), scale, h, pool.to(DEV), W1.to(DEV), W2.to(DEV), S)
+    for got, ref in ((dW1, W1r.grad), (db1, b1r.grad), (dW2, W2r.grad), (db2, b2r.grad), (gadd, pr.grad)):
+        assert _rel(got, ref) < 2e-5, _rel(got, ref)

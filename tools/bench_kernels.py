@@ -6,7 +6,7 @@ import torch
 from efficientat_amd import ops
 
 dev = torch.device("cuda:0")
-what = sys.argv[1:] or ["stem", "dwbn"]
+what = sys.argv[1:] or ["stem", "dwbn", "se"]
 
 
 def timeit(fn, n=10):
@@ -35,7 +35,9 @@ if "stem" in what:
         print("stem wgrad (old) %8.1f us" % timeit(lambda: ops.dw_conv_wgrad(dy, x, 3, 2)))
 if "dwbn" in what:
     for (C, F, T, k, s, act, noexp) in [(16, 64, 500, 3, 1, 1, True), (64, 64, 500, 3, 2, 1, False), (72, 32, 250, 3, 1, 1, False),
-                                        (72, 32, 250, 5, 2, 1, False)]:
+                                        (72, 32, 250, 5, 2, 1, False), (120, 16, 125, 5, 1, 1, False), (240, 16, 125, 3, 2, 2, False),
+                                        (200, 8, 63, 3, 1, 2, False), (672, 8, 63, 3, 1, 2, False), (672, 8, 63, 5, 2, 2, False),
+                                        (960, 4, 32, 5, 1, 2, False)]:
         p = (k - 1) // 2
         Fo, To = (F + 2 * p - k) // s + 1, (T + 2 * p - k) // s + 1
         x = torch.randn(B, C, F, T, device=dev)
@@ -58,3 +60,10 @@ if "dwbn" in what:
             else:
                 t_old = timeit(lambda: ops.dw_conv_bwd_g(dz, w, x, ia, ib, in_act, k, s))
         print(f"C={C} {F}x{T} k{k} s{s}: on-load {t_new:8.1f} us | apply {t_app:8.1f} + old backward {t_old:8.1f} = {t_app + t_old:8.1f} us (reduce {t_red:.1f})")
+
+if "se" in what:
+    for (C, Cr, S) in [(72, 24, 2000), (120, 32, 2000), (480, 120, 504), (672, 168, 504), (960, 240, 128)]:
+        ds, sc = torch.randn(B, C, device=dev), torch.rand(B, C, device=dev)
+        h, pool = torch.relu(torch.randn(B, Cr, device=dev)), torch.randn(B, C, device=dev) * S
+        W1, W2 = torch.randn(Cr, C, device=dev) * 0.1, torch.randn(C, Cr, device=dev) * 0.1
+        print(f"se_mlp_bwd C={C} Cr={Cr}: %8.1f us" % timeit(lambda: ops.se_mlp_bwd(ds, sc, h, pool, W1, W2, S)))
