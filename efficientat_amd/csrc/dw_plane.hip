@@ -925,18 +925,20 @@ struct DwBwdArgs {
 // LPP = 64: a wave owns one tile of one plane (column strips with halo lanes).  LPP = 32 / 16 (small planes, T <= 2 LPP): a
 // lane group owns the whole row of ITS plane - 64 / LPP samples of the same channel per wave, every lane busy, no halo
 // lanes (the zero padding of the conv is the group edge of from_prev / from_next).
-template <int K, int S, int RO, bool BN, int LPP>
+// WR with LPP = 64: one plane per wave, rows of <= 128 columns without halo lanes (a 125-column row of a 5 x 5 conv needs two
+// strips of the strip mode - 124 columns + 2 halo lanes - with half of the lanes idle in each).
+template <int K, int S, int RO, bool BN, int LPP, bool WR>
 __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
   constexpr int P = (K - 1) / 2, KK = K * K, NPW = 64 / LPP;
-  constexpr bool WR = LPP < 64;                                    // whole-row mode
+  static_assert(WR || LPP == 64, "strip mode owns the whole wave");
   constexpr int FX = S == 1 ? RO + 2 * P : 2 * RO + 2 * P - 1;     // x rows of a tile (with halo)
   constexpr int FD = S == 1 ? RO + 2 * P : RO + 2;                 // dz rows of a tile (with halo)
   constexpr int DOFF = S == 1 ? P : 1;                             // dz-array index of the tile's first dz row
   constexpr int ND = S == 1 ? 2 : 1;                               // dz columns per lane
   constexpr int NE = S == 1 ? 2 + 2 * P : K;                       // extended x row: columns under the filter
   const int lane = threadIdx.x & 63;
-  const int l = WR ? (lane & (LPP - 1)) : lane;
-  const int half = WR ? lane / LPP : 0;                            // which of the wave's NPW planes (samples)
+  const int l = lane & (LPP - 1);
+  const int half = lane / LPP;                                     // which of the wave's NPW planes (samples)
   const bool first = l == 0, last = l == LPP - 1;
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int tpp = a.n_rc * a.n_cs;
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       }
     }
     if (a.gpart) {
-      if constexpr (WR) {
+      if constexpr (LPP < 64) {
 #pragma unroll
         for (int o = LPP >> 1; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
       } else {
@@ -1201,10 +1203,13 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
   const bool bn = a.bn.z != nullptr;
   constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : 62;
   const int n_cols = S == 1 ? a.T : a.To, n_rows = S == 1 ? a.F : a.Fo;
-  // small planes (BN instances only): whole rows per lane group, 2 or 4 samples per wave
+  // small planes (BN instances only): whole rows per lane group, 2 or 4 samples per wave; up to 128 columns: one plane per
+  // wave without halo lanes
+  static const int wr64 = getenv("EAT_DW_BWD_WR64") ? atoi(getenv("EAT_DW_BWD_WR64")) : 1;
   const int lpp = !bn ? 64 : (a.T <= 32 ? 16 : (a.T <= 64 ? 32 : 64));
+  const bool wr = lpp < 64 || (bn && wr64 && a.T <= 128);
   const int npw = 64 / lpp;
-  a.n_cs = lpp < 64 ? 1 : (n_cols + WMAX - 1) / WMAX;
+  a.n_cs = wr ? 1 : (n_cols + WMAX - 1) / WMAX;
   a.WO = (n_cols + a.n_cs - 1) / a.n_cs;
   a.n_rc = (n_rows + RO - 1) / RO;
   const int nb = (a.B + npw - 1) / npw;
@@ -1215,10 +1220,11 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
   if (waves > 0x7fffffffLL) return 1;
   if (h_inner) *h_inner = a.n_rc * a.n_cs;
   const dim3 grid((unsigned)((waves + 3) / 4));
-  if (!bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false, 64>), grid, dim3(256), 0, s, a, w);
-  else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64>), grid, dim3(256), 0, s, a, w);
-  else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32>), grid, dim3(256), 0, s, a, w);
-  else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16>), grid, dim3(256), 0, s, a, w);
+  if (!bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false, 64, false>), grid, dim3(256), 0, s, a, w);
+  else if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true>), grid, dim3(256), 0, s, a, w);
+  else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false>), grid, dim3(256), 0, s, a, w);
+  else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32, true>), grid, dim3(256), 0, s, a, w);
+  else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true>), grid, dim3(256), 0, s, a, w);
   return eat::check_launch("eat_dw_conv_bwd_g");
 }
 

@@ -1294,10 +1294,10 @@ extern "C" int eat_dw_bwd_merged_ok(int B, int C, int F, int T, int Fo, int To, 
   if (k == 5 && !k5) return 0;
   static const int t_min = getenv("EAT_DW_BN_TMIN") ? atoi(getenv("EAT_DW_BN_TMIN")) : 0;      // A/B: large planes only
   if (T <= t_min) return 0;
-  // measured (B = 256): 5x5 / stride 1 on 16 x 125 planes 446 us against 139 (apply) + 270 (plane kernels): 25 taps x 2 on
-  // tiles whose halo rows are half of the loads; the 4-row planes run the RO = 4 instance
-  static const int k5s1 = getenv("EAT_DW_BN_K5S1") ? atoi(getenv("EAT_DW_BN_K5S1")) : 0;
-  if (k == 5 && stride == 1 && T <= 128 && !(F <= 4 && T <= 64) && !k5s1) return 0;
+  // (A/B switch: EAT_DW_BN_K5S1=0 keeps the 5x5 / stride-1 layers of <= 128 columns on the apply pass + the two plane
+  //  kernels - they lost there until the whole-row mode: 16 x 125 planes 446 -> 268 us against 137 + 269)
+  static const int k5s1 = getenv("EAT_DW_BN_K5S1") ? atoi(getenv("EAT_DW_BN_K5S1")) : 1;
+  if (k == 5 && stride == 1 && T <= 128 && !k5s1) return 0;
   return dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride);
 }
 
