@@ -46,6 +46,18 @@ class _Zeros:
 
 _zeros = _Zeros()
 
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """Second HIP stream of the train step: work that is off the critical path (the Gram-matrix chain of the forward, the
+    project convs' weight gradients of the backward) runs on it next to the main chain's latency-bound small kernels.
+    Fork / join with wait_stream, so the dependencies are recorded when the step is captured into a hipGraph."""
+    key = (dev.type, dev.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
 
 class _Ones(_Zeros):
     def get(self, n, device):
@@ -247,12 +259,32 @@ class MNTrainFunction(torch.autograd.Function):
             dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias))
             bn_grads(dgam, dbet, nw, nbias)
             scale = rec.get("scale")
-            if rec["y_d"] is None:         # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
-                st_d = rec["st_d"]
-                g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["z_d"], x_scale=scale,
-                                                                      tf=(st_d[0], st_d[1], act)).view_as(cna[0].weight)
+            pend = None                    # (name, gradient, stream, inputs kept alive) of a launch on the side stream
+            if v2 and _OVERLAP:
+                # the project conv's weight gradient is needed only at the end of the pass: on the side stream it fills the
+                # gaps the main chain's small kernels (gate MLP, BatchNorm sums, coefficient GEMMs) leave on the chip
+                main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
+                side_s.wait_stream(main_s)
+                torch.cuda.set_stream(side_s)
+            try:
+                if rec["y_d"] is None:     # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
+                    st_d = rec["st_d"]
+                    dWp = ops.pw_conv_wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act))
+                else:
+                    dWp = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale)
+            finally:
+                if v2 and _OVERLAP:
+                    torch.cuda.set_stream(main_s)
+            if v2 and _OVERLAP:
+                dWp.record_stream(main_s)
+                pend = (f"{pre}.{blk.i_proj}.0.weight", dWp.view_as(cna[0].weight), side_s, (dz_p, rec["z_d"], rec["y_d"], scale))
             else:
-                g[f"{pre}.{blk.i_proj}.0.weight"] = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale).view_as(cna[0].weight)
+                g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
+
+            def join_side(pend=pend):
+                if pend is not None:
+                    torch.cuda.current_stream(dev).wait_stream(pend[2])
+                    g[pend[0]] = pend[1]
             wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
             dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
             del dz_p
@@ -314,6 +346,7 @@ class MNTrainFunction(torch.autograd.Function):
                     dout2 = res_grad
                     g[f"{pre}.{blk.i_dw}.0.weight"] = dw_d.view_as(cna[0].weight)
                     del dxs
+                    join_side()
                     sv["blocks"][i] = None
                     continue
                 st_e = rec["st_e"]
@@ -381,6 +414,7 @@ class MNTrainFunction(torch.autograd.Function):
                     dout = ops.pw_conv(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
                                        NONE, res=t)
                 del g_e
+                join_side()
                 sv["blocks"][i] = None
                 continue
             dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
@@ -398,6 +432,7 @@ class MNTrainFunction(torch.autograd.Function):
                 dout = ops.pw_conv(dz_e, wpt, _zeros.get(cnf.input_channels, dev), cnf.input_channels, NONE,
                                    res=res_grad)
                 del dz_e
+            join_side()
             sv["blocks"][i] = None
 
         # ---- stem
@@ -443,6 +478,7 @@ _FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
 # A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
 _MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
 _DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthwise BN backward evaluated on load in the merged backward kernel
+_OVERLAP = os.environ.get("EAT_TRAIN_OVERLAP", "1") == "1"          # A/B: side stream for off-critical-path launches
 _FUSE_SE_MLP = os.environ.get("EAT_FUSE_SE_MLP", "1") == "1"        # A/B: SE gate MLP backward as two launches (csrc/se_train.hip)
 _FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem without its pre-activation tensor (csrc/stem_train.hip)
 _CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
@@ -504,14 +540,30 @@ class MNTrainFunction2(torch.autograd.Function):
                 cna = blk.block[blk.i_expand]
                 W = cna[0].weight.flatten(1)
                 n_e = B * inp.shape[2] * inp.shape[3]
+                forked = False
                 if cna[1].training:
-                    G = ops.gram(inp, exact=exact)                               # Gram matrix of the block input (reproducible)
-                    Tm = ops.linear(W, G, None, NONE)                             # W G  (G symmetric)
-                    st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e)
+                    if _OVERLAP:
+                        # the Gram chain (three latency-bound launches) next to the expand conv, which does not need its result
+                        main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
+                        side_s.wait_stream(main_s)
+                        forked = True
+                        torch.cuda.set_stream(side_s)
+                    try:
+                        G = ops.gram(inp, exact=exact)                           # Gram matrix of the block input (reproducible)
+                        Tm = ops.linear(W, G, None, NONE)                         # W G  (G symmetric)
+                        st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e)
+                    finally:
+                        if forked:
+                            torch.cuda.set_stream(main_s)
+                    if forked:
+                        for t_ in (Tm,) + tuple(st_e):
+                            t_.record_stream(main_s)
                 else:
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
                 wp = ops.pw_prepack(W)
                 z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+                if forked:
+                    main_s.wait_stream(side_s)
                 rec.update(z_e=z_e, st_e=st_e, Tm=Tm, sx=sx)
                 tf = (st_e[0], st_e[1], act)
             src = z_e if blk.i_expand is not None else inp
