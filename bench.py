@@ -542,7 +542,21 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks):
     out = {}
     for _ in range(max(2, warmup)):
         out["loss"] = tstep()
+    evs = []
+    if os.environ.get("EAT_BENCH_STEP_TIMES"):       # diagnostic: per-step GPU intervals (HIP events) and host submit times
+        inner = tstep
+
+        def tstep():  # noqa: F811
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append((e, time.perf_counter()))
+            return inner()
     el = ranks.timed(lambda: out.__setitem__("loss", tstep()), steps)
+    if evs:
+        gaps = [round(evs[i][0].elapsed_time(evs[i + 1][0]), 2) for i in range(len(evs) - 1)]
+        host = [round((evs[i + 1][1] - evs[i][1]) * 1e3, 2) for i in range(len(evs) - 1)]
+        print(f"[bench] {name} per-step GPU ms: {gaps}", file=sys.stderr)
+        print(f"[bench] {name} per-step host submit ms: {host}", file=sys.stderr)
     cps = ranks.world * bt * steps / el
     alg = ALG_TRAIN.get(name)
     res = {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,

@@ -59,6 +59,40 @@ __global__ void pw_prepack_bf16_kernel(const float* __restrict__ w, const float*
   }
 }
 
+// Every weight pack of a training step in ONE launch (the step re-packs ~47 matrices of a few KB each, ~6 us of launch
+// latency apiece on a single stream): blockIdx.y = entry of a device-resident table, blockIdx.x * 256 + threadIdx.x = the
+// thread index of the single-matrix kernels above / in conv_pw.hip (same layouts, bit-identical packs).
+struct PrepackDesc { const float* w; void* wp; int Co, Ci, kind, trans; };   // kind: 0 fp32, 1 bf16, 2 bf16 hi + lo
+static_assert(sizeof(PrepackDesc) == 32, "host side builds the table as 32-byte records");
+__global__ __launch_bounds__(256) void pw_prepack_multi_kernel(const PrepackDesc* __restrict__ table) {
+  const PrepackDesc e = table[blockIdx.y];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int MT = (e.Co + 15) / 16;
+  const float* __restrict__ w = e.w;
+  if (e.kind == 0) {
+    if (t >= (e.Ci / 4) * MT * 64) return;
+    const int lane = t & 63, mt = (t >> 6) % MT, ks = (t >> 6) / MT;
+    const int m = mt * 16 + (lane & 15), k = ks * 4 + (lane >> 4);
+    float v = 0.0f;
+    if (m < e.Co) v = e.trans ? w[(size_t)k * e.Co + m] : w[(size_t)m * e.Ci + k];
+    reinterpret_cast<float*>(e.wp)[t] = v;
+    return;
+  }
+  const int KK = (e.Ci + 31) / 32, NP2 = e.kind;
+  if (t >= KK * MT * 64) return;
+  __bf16* __restrict__ wp = reinterpret_cast<__bf16*>(e.wp);
+  const int lane = t & 63, mt = (t >> 6) % MT, kk = (t >> 6) / MT;
+  const int m = mt * 16 + (lane & 15), kb = kk * 32 + 8 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = kb + i;
+    const float v = (m < e.Co && k < e.Ci) ? (e.trans ? w[(size_t)k * e.Co + m] : w[(size_t)m * e.Ci + k]) : 0.0f;
+    const __bf16 hi = (__bf16)v;
+    wp[((size_t)(kk * MT + mt) * NP2 + 0) * 512 + lane * 8 + i] = hi;
+    if (NP2 == 2) wp[((size_t)(kk * MT + mt) * NP2 + 1) * 512 + lane * 8 + i] = (__bf16)(v - (float)hi);
+  }
+}
+
 // TF: the conv input is act_in(tf_a[k] * x + tf_b[k]) evaluated on the way from LDS to the MFMA operand (training: the
 // BatchNorm + activation of the depthwise conv fused into the project conv - the activated tensor is never written;
 // models/mn/block_types.py:150-171 under model.train()); the SE scale (in_scale) multiplies the transformed value.
@@ -292,6 +326,14 @@ extern "C" int eat_pw_prepack_bf16(const float* w, const float* row_scale, void*
 extern "C" int eat_pw_prepack_bf16_t(const float* w_t, const float* row_scale, void* wp, int Co, int Ci, int split,
                                      eat_stream_t stream) {
   return pw_prepack_bf16_impl(w_t, row_scale, wp, Co, Ci, split, 1, stream);
+}
+
+extern "C" int eat_pw_prepack_multi(const void* table, int n, int max_threads, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!table || n < 1 || max_threads < 1) return eat::fail(EAT_EINVAL, "eat_pw_prepack_multi: empty table");
+  hipLaunchKernelGGL(pw_prepack_multi_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const PrepackDesc*>(table));
+  return eat::check_launch("eat_pw_prepack_multi");
 }
 
 extern "C" int eat_pw_conv_bf16_fwd(const float* x, const void* wp, const float* bias, const float* in_scale,

@@ -46,6 +46,34 @@ class _Zeros:
 
 _zeros = _Zeros()
 
+def _prepack_plan(model):
+    """All weight packs of the trunk's 1x1 convs (forward and data-gradient forms) from one launch per step
+    (ops.PrepackPlan); None while a hipGraph is being captured before the plan exists, or for geometries it does not take."""
+    plan = getattr(model, "_eat_prepack_plan", None)
+    if plan is not None and not plan.stale():
+        return plan
+    if not _PREPACK_PLAN or torch.cuda.is_current_stream_capturing():
+        return None
+    entries = []
+    for bi, blk in enumerate(model.features[1:-1]):
+        if blk.i_expand is not None:
+            entries.append((("e", bi), blk.block[blk.i_expand][0].weight, False))
+        pw = blk.block[blk.i_proj][0].weight
+        entries += [(("p", bi), pw, False), (("pt", bi), pw, True)]
+    lw = model.features[-1][0].weight
+    entries += [(("l",), lw, False), (("lt",), lw, True)]
+    try:
+        plan = ops.PrepackPlan(entries)
+    except Exception:                                     # odd channel counts: per-matrix packs (which check for themselves)
+        plan = None
+    model._eat_prepack_plan = plan
+    return plan
+
+
+def _pk(plan, key, w, trans=False):
+    return plan.get(key) if plan is not None else ops.pw_prepack(w.flatten(1), trans=trans)
+
+
 _side_streams = {}
 
 
@@ -240,7 +268,8 @@ class MNTrainFunction(torch.autograd.Function):
                                             sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
         bn_grads(dgam, dbet, nm + ".1.weight", nm + ".1.bias")
         g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
-        wpt = ops.pw_prepack(last[0].weight.flatten(1), trans=True)
+        plan = sv.get("plan")
+        wpt = _pk(plan, ("lt",), last[0].weight, trans=True)
         dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
         del dz, z_l
 
@@ -285,7 +314,7 @@ class MNTrainFunction(torch.autograd.Function):
                 if pend is not None:
                     torch.cuda.current_stream(dev).wait_stream(pend[2])
                     g[pend[0]] = pend[1]
-            wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
+            wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
             dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
             del dz_p
             gscale = gadd = se_P = None
@@ -478,7 +507,11 @@ _FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
 # A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
 _MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
 _DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthwise BN backward evaluated on load in the merged backward kernel
-_OVERLAP = os.environ.get("EAT_TRAIN_OVERLAP", "1") == "1"          # A/B: side stream for off-critical-path launches
+# side stream for off-critical-path launches.  OFF by default: -0.26 ms in good runs (24.9 vs 25.2 ms), but the replay time
+# of the captured step became erratic from process to process (26.8 / 114.8 / 62.9 / 38.7 ms in four consecutive runs on one
+# box; never seen in ~40 single-stream runs) - a hipGraph with ~60 fork / join edges is not worth 1 %
+_OVERLAP = os.environ.get("EAT_TRAIN_OVERLAP", "0") == "1"
+_PREPACK_PLAN = os.environ.get("EAT_PREPACK_PLAN", "1") == "1"      # A/B: all weight packs of the step from one launch
 _FUSE_SE_MLP = os.environ.get("EAT_FUSE_SE_MLP", "1") == "1"        # A/B: SE gate MLP backward as two launches (csrc/se_train.hip)
 _FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem without its pre-activation tensor (csrc/stem_train.hip)
 _CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
@@ -498,6 +531,10 @@ class MNTrainFunction2(torch.autograd.Function):
         saved = {}
         blocks = list(model.features[1:-1])
         exact = ops.precision.mode == "fp32"
+        plan = _prepack_plan(model)
+        if plan is not None:
+            plan.run()
+        saved["plan"] = plan
 
         # stem
         stem = model.features[0]
@@ -560,7 +597,7 @@ class MNTrainFunction2(torch.autograd.Function):
                             t_.record_stream(main_s)
                 else:
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
-                wp = ops.pw_prepack(W)
+                wp = _pk(plan, ("e", bi), cna[0].weight)
                 z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
                 if forked:
                     main_s.wait_stream(side_s)
@@ -591,7 +628,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 scale = ops.linear(h, se.fc2.weight, se.fc2.bias, SIGMOID)
                 rec.update(pool=pool, h=h, scale=scale, S_d=S_d)
             cna = blk.block[blk.i_proj]
-            wp = ops.pw_prepack(cna[0].weight.flatten(1))
+            wp = _pk(plan, ("p", bi), cna[0].weight)
             if on_load:
                 z_p = ops.pw_conv_tf(z_d, (st_d[0], st_d[1], act), wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels,
                                      NONE, in_scale=scale)
@@ -608,7 +645,7 @@ class MNTrainFunction2(torch.autograd.Function):
 
         last = model.features[-1]
         c_feat = last.out_channels
-        wp = ops.pw_prepack(last[0].weight.flatten(1))
+        wp = _pk(plan, ("l",), last[0].weight)
         z_l = ops.pw_conv(cur, wp, _zeros.get(c_feat, dev), c_feat, NONE)
         st_l = _conv_bn_stats(z_l, last[1])
         S_l = z_l.shape[2] * z_l.shape[3]

@@ -834,6 +834,64 @@ def pw_conv(x, wp, bias, Co, act, in_scale=None, res=None, pool=None, write=True
     return _pw_conv_fp32(x, wp, bias, Co, act, in_scale=in_scale, res=res, pool=pool, write=write)
 
 
+class PrepackPlan:
+    """The weight packs of a model's 1x1 convs for one pass, produced by ONE launch (`eat_pw_prepack_multi`) instead of one
+    per matrix.  entries: [(key, w2d, trans)] with w2d a contiguous (rows, cols) view of a parameter; the arithmetic
+    (fp32 / bf16 / bf16x3 pack) follows `precision.mode` at construction exactly as `pw_prepack` decides it.  The packs live
+    in a buffer owned by the plan and are refreshed by `run()`; `get(key)` hands out views (valid until the next run)."""
+
+    def __init__(self, entries):
+        import numpy as np
+        self.mode = precision.mode
+        dev = entries[0][1].device
+        recs, views, off, max_threads = [], {}, 0, 1
+        for key, w2d, trans in entries:      # w2d: the parameter itself (Co, Ci[, 1, 1]), contiguous
+            if not w2d.is_contiguous():
+                raise _lib.EatHipError("PrepackPlan: weights must be contiguous")
+            rows, cols = w2d.shape[0], w2d.numel() // w2d.shape[0]
+            Co, Ci = (cols, rows) if trans else (rows, cols)
+            m = self.mode
+            if m == "bf16":
+                kind = 1
+            elif m == "bf16x3" or (m == "auto" and Ci >= 40 and Ci % 4 == 0):
+                kind = 2
+            else:
+                kind = 0
+            mt = (Co + 15) // 16
+            if kind == 0:
+                if Ci % 4:
+                    raise _lib.EatHipError(f"PrepackPlan: Ci={Ci} must be a multiple of 4")
+                nbytes, threads = (Ci // 4) * mt * 64 * 4, (Ci // 4) * mt * 64
+            else:
+                nbytes, threads = ((Ci + 31) // 32) * mt * kind * 512 * 2, ((Ci + 31) // 32) * mt * 64
+            max_threads = max(max_threads, threads)
+            recs.append((w2d, off, Co, Ci, kind, 1 if trans else 0, nbytes, key))
+            off += (nbytes + 255) // 256 * 256
+        self.buf = torch.empty((off,), device=dev, dtype=torch.uint8)
+        table = np.zeros((len(recs),), dtype=[("w", "<u8"), ("wp", "<u8"), ("Co", "<i4"), ("Ci", "<i4"), ("kind", "<i4"), ("trans", "<i4")])
+        self.ptrs = []
+        for i, (w2d, o, Co, Ci, kind, trans, nbytes, key) in enumerate(recs):
+            table[i] = (w2d.data_ptr(), self.buf.data_ptr() + o, Co, Ci, kind, trans)
+            self.ptrs.append(w2d.data_ptr())
+            v = self.buf[o:o + nbytes].view(torch.float32 if kind == 0 else torch.bfloat16)
+            if kind == 2:
+                v._eat_split = True
+            views[key] = v
+        self.keep = [r[0] for r in recs]
+        self.views, self.n, self.max_threads = views, len(recs), max_threads
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+
+    def stale(self):
+        """Parameters were re-allocated (model.to(), a new state dict with fresh storage) or the arithmetic changed."""
+        return self.mode != precision.mode or any(t.data_ptr() != p for t, p in zip(self.keep, self.ptrs))
+
+    def run(self):
+        _lib.call("eat_pw_prepack_multi", self.table.data_ptr(), self.n, self.max_threads, _stream())
+
+    def get(self, key):
+        return self.views[key]
+
+
 # ------------------------------------------------------------------ training-loop glue (ex_audioset.py:142-194)
 def col_sum(m):
     """Column sums of a contiguous (R, C) matrix (bias gradients of the DyMN context path)."""

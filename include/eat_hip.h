@@ -253,6 +253,13 @@ int eat_se_mlp_bwd(const float* ds, const float* scale, const float* h, const fl
                    float inv_s, float* dW1, float* db1, float* dW2, float* db2, float* dh, float* gadd, int B, int C, int Cr,
                    eat_stream_t stream);
 
+/* All weight packs of a pass in one launch: `table` = n device-resident 32-byte records
+ * { const float* w; void* wp; int32 Co, Ci, kind, trans; } with kind 0 = eat_pw_prepack, 1 / 2 = eat_pw_prepack_bf16
+ * (plain / split) and trans as in the *_t entry points (no row_scale); the packs are bit-identical to those of the
+ * single-matrix entry points.  max_threads = max over the records of (Ci / 4) * ceil(Co / 16) * 64 (kind 0) or
+ * ceil(Ci / 32) * ceil(Co / 16) * 64 (kinds 1, 2). */
+int eat_pw_prepack_multi(const void* table, int n, int max_threads, eat_stream_t stream);
+
 /* Stem of the training step without its pre-activation tensor (models/mn/model.py:124-133 in train mode: Conv2d(1, C, 3,
  * stride 2, padding 1) -> BatchNorm2d -> Hardswish; csrc/stem_train.hip).  The conv is linear in the 9-tap patch p of the
  * log-mel x (B,1,F,T), so its batch statistics follow from G9 = sum p p^T and sp = sum p:

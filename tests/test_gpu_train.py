@@ -375,5 +375,11 @@ def test_mn_backward_through_bucketed_rccl_reducer_matches_local():
     import subprocess
     import sys
     case = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_reducer_case.py")
-    r = subprocess.run([sys.executable, case], capture_output=True, text=True, timeout=600)
+    # RCCL (2.26.6 of this image) aborts the interpreter (SIGABRT inside librccl, before any of our checks ran) in roughly
+    # one of 30 single-rank runs next to a busy pytest parent: a run that died from a signal is repeated once; a run that
+    # completed with a wrong result (exit code >= 0) is a failure at once
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, case], capture_output=True, text=True, timeout=600)
+        if "RCCL_REDUCER_OK" in r.stdout or r.returncode >= 0:
+            break
     assert "RCCL_REDUCER_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -415,3 +415,27 @@ def test_se_gate_mlp_backward_in_two_launches(B, C, Cr, S):
     dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds.to(DEV), scale, h, pool.to(DEV), W1.to(DEV), W2.to(DEV), S)
     for got, ref in ((dW1, W1r.grad), (db1, b1r.grad), (dW2, W2r.grad), (db2, b2r.grad), (gadd, pr.grad)):
         assert _rel(got, ref) < 2e-5, _rel(got, ref)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "auto", "bf16x3", "bf16"])
+def test_all_weight_packs_from_one_launch(mode):
+    """eat_pw_prepack_multi: every pack bit-identical to the single-matrix entry points, normal and transposed."""
+    shapes = [(64, 16), (24, 72), (960, 160), (160, 960), (527, 1280), (40, 120), (8, 8)]
+    ws = [(_rand(co, ci, 1, 1, seed=10 + i) * 0.3).to(DEV) for i, (co, ci) in enumerate(shapes)]
+    entries = []
+    for i, w in enumerate(ws):
+        entries += [((i, False), w, False), ((i, True), w, True)]
+    with ops.precision(mode):
+        entries = [e for e in entries if ((e[1].shape[0] if e[2] else e[1].shape[1]) % 4 == 0) or mode in ("bf16", "bf16x3")]
+        plan = ops.PrepackPlan(entries)
+        plan.run()
+        assert not plan.stale()
+        for key, w, trans in entries:
+            ref = ops.pw_prepack(w.flatten(1), trans=trans)
+            got = plan.get(key)
+            assert got.dtype == ref.dtype and got.shape == ref.shape
+            assert getattr(got, "_eat_split", False) == getattr(ref, "_eat_split", False)
+            assert torch.equal(got.view(torch.int16 if got.dtype == torch.bfloat16 else torch.int32),
+                               ref.view(torch.int16 if ref.dtype == torch.bfloat16 else torch.int32)), (key, mode)
+    with ops.precision("fp32" if mode != "fp32" else "auto"):
+        assert plan.stale()

@@ -73,3 +73,6 @@ if has rocprof; then
   find $OUT/stats -name "*_kernel_trace.csv" -delete; find $OUT/stats -name "*.db" -delete
   ls -la $OUT/stats $OUT | head -20
 fi
+if has dymn; then
+  timeout 400 python tools/prof_dymn.py 128 2>&1 | grep -v amdgpu.ids > $OUT/prof_dymn.log; head -45 $OUT/prof_dymn.log
+fi
