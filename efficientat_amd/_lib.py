@@ -12,7 +12,8 @@ import torch  # noqa: F401  -- must be imported BEFORE libeat_hip.so is loaded: 
 #                Loading our library first binds it to /opt/rocm's copy, which sees no device.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeat_hip.so")
+# EAT_LIB: another build of the same library (A/B of kernel changes; must export the same symbols)
+LIB_PATH = os.environ.get("EAT_LIB") or os.path.join(_HERE, "libeat_hip.so")
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

@@ -150,6 +150,11 @@ __global__ __launch_bounds__(512, 1) void expand_dw_kernel(
     {
       const int t = lane;
       const bool t_ok = t < T;
+      // column validity as a 0 / 1 factor the optimiser cannot see through, row stores through a range-checked buffer
+      // descriptor: with `(t_ok && f < F) ? E[..] : 0` and `if (t_ok) store` hipcc put each of the 8 LDS row reads of a plane
+      // into its own exec-masked block with its own s_waitcnt, and a branch around every row store (round-2 ISA finding)
+      const float t_mask = eat::opaque(t_ok ? 1.0f : 0.0f);
+      const unsigned t_off = t_ok ? 4u * (unsigned)t : 0x80000000u;
       const int n_planes = (mt1 - mt0) * 16;
       // two planes per trip: the scalar tap loads and the LDS reads of one overlap the FMAs of the other (more would not
       // fit next to the 128 registers of x fragments when C_in > 96).  (A packed-fp32 version - the two planes as the
@@ -173,12 +178,12 @@ __global__ __launch_bounds__(512, 1) void expand_dw_kernel(
               int idx = f * T + t;
               if (idx > S - 1) idx = S - 1;                   // masked below; keeps the address inside the plane
               const float v = ep[idx];
-              e[f] = (t_ok && f < F) ? v : 0.0f;
+              e[f] = v * (t_mask * eat::opaque(f < F ? 1.0f : 0.0f));
             }
 #pragma unroll
             for (int f = 0; f < kMaxRows; ++f) { l[f] = from_prev(e[f]); r[f] = from_next(e[f]); }
             float psum = 0.0f;
-            float* yp = y + ((size_t)b * Ce + c) * S + t;
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + ((size_t)b * Ce + c) * S, 0, 4 * S, 0x00020000);
 #pragma unroll
             for (int f = 0; f < kMaxRows; ++f) {
               if (f < F) {                                    // wave-uniform
@@ -193,10 +198,8 @@ __global__ __launch_bounds__(512, 1) void expand_dw_kernel(
                   }
                 }
                 o = eat::act_apply(o, ac);
-                if (t_ok) {
-                  yp[(size_t)f * T] = o;
-                  psum += o;
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), yr, (int)t_off, 4 * f * T, 0);
+                psum = fmaf(o, t_mask, psum);
               }
             }
             if (pool) {                                       // DPP adds at VALU rate (no LDS crossbar): total in lane 63

@@ -60,6 +60,20 @@ __device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], 
                          act_apply(acc[i][2][r] + bm, ac), act_apply(acc[i][3][r] + bm, ac));
   };
   auto row_of = [&](int i, int r) { return (mt0 + i) * 16 + kq * 4 + r; };
+  auto store_tile = [&](int i, const float4 (&v)[4]) {
+    const bool full = (mt0 + i + 1) * 16 <= Co;                      // wave-uniform
+    float* yr = y + base + (size_t)row_of(i, 0) * plane;
+    if (full) {
+      if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(yr + (size_t)r * plane) = v[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col_ok && row_of(i, r) < Co) *reinterpret_cast<float4*>(yr + (size_t)r * plane) = v[r];
+    }
+  };
 
   if (!pool) {
     if (res) {
@@ -78,24 +92,28 @@ __device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], 
             rn[r] = *reinterpret_cast<const float4*>(res + base + (size_t)(m < Co ? m : Co - 1) * plane);
           }
         }
+        // values first (no branch around the activation math), then ONE exec-masked region per m-tile: a tile whose 16
+        // rows all exist (wave-uniform test) stores under the column mask only; the ragged last tile adds the row test.
+        // (With `if (col_ok && m < Co) store(value)` per row hipcc emitted a saveexec / branch pair around every store
+        // AND its activation math: 32 of them per wave at 8 m-tiles.)
+        float4 v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = row_of(i, r);
-          float4 v = value(i, r);
-          v.x += rv[r].x; v.y += rv[r].y; v.z += rv[r].z; v.w += rv[r].w;
-          if (col_ok && m < Co) *reinterpret_cast<float4*>(y + base + (size_t)m * plane) = v;
+          v[r] = value(i, r);
+          v[r].x += rv[r].x; v[r].y += rv[r].y; v[r].z += rv[r].z; v[r].w += rv[r].w;
         }
+        store_tile(i, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = rn[r];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < MTW; ++i)
+      for (int i = 0; i < MTW; ++i) {
+        float4 v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = row_of(i, r);
-          if (col_ok && m < Co) *reinterpret_cast<float4*>(y + base + (size_t)m * plane) = value(i, r);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = value(i, r);
+        store_tile(i, v);
+      }
     }
     return;
   }
