@@ -705,7 +705,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
                                                              int per_sample, WgTf tf, int n_slots) {
   // stage = [A: 128 rows x 128 B][B: 128 rows x 128 B] = 32 KB; 2 stages
   __shared__ __attribute__((aligned(16))) float s_op[2][2][128 * 32];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // wv through readfirstlane: the compiler then knows it (and the tile counts derived from it) to be wave-uniform - scalar
+  // branches instead of exec-masked blocks around the loads and MFMAs of rows beyond the matrix
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 15, kg = lane >> 4;
   const int mb = blockIdx.x * 128, nb = blockIdx.y * 128;         // block tile origin
   const int mw = (wv & 1) * 64, nw = (wv >> 1) * 64;              // wave sub-tile inside the block tile
@@ -841,16 +843,25 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (!(i < mt_n && j < nt_n)) continue;                        // wave-uniform
+      // a 16 x 16 tile that lies inside the matrix (wave-uniform test) adds without per-lane tests: the 64 guarded
+      // atomics of a wave were 64 exec-masked blocks
+      const bool full = mb + mw + 16 * i + 16 <= Co && nb + nw + 16 * j + 16 <= Ci;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int m = mb + mw + 16 * i + kg * 4 + q, n = nb + nw + 16 * j + r;   // C/D: row = kg*4+q, col = lane&15
-        if (i < mt_n && j < nt_n && m < Co && n < Ci) {
+        float* o = out + (size_t)m * Ci + n;
+        if (full) {
+          if (per_sample) *o = acc[i][j][q];
+          else global_atomic_add(o, acc[i][j][q]);
+        } else if (m < Co && n < Ci) {
           // per-sample gradients: the block covered the sample's whole k range - a plain store, no read-modify-write
-          if (per_sample) out[(size_t)m * Ci + n] = acc[i][j][q];
-          else global_atomic_add(out + (size_t)m * Ci + n, acc[i][j][q]);
+          if (per_sample) *o = acc[i][j][q];
+          else global_atomic_add(o, acc[i][j][q]);
         }
       }
+    }
 }
 
 // Narrow layers (one side <= 16 channels, the other <= 64: mn10 block 1 and the expand of block 2, planes of 32000
@@ -869,7 +880,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   // in L2 at ~40 ns each, which made the 8192 (= 2048 blocks x 4 waves) adds per element the whole cost of this kernel
   // on the 16 x 16 layers (311 us for 105 us of HBM time)
   __shared__ float s_tile[MTN * NTN * 256];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // wv through readfirstlane: the compiler then knows it (and the tile counts derived from it) to be wave-uniform - scalar
+  // branches instead of exec-masked blocks around the loads and MFMAs of rows beyond the matrix
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 15, kg = lane >> 4;
   // round 3: blockIdx.x / blockIdx.y select a group of MTN / NTN row tiles ("thin" matrices: up to ~8 x 8 tiles over a
   // long k axis stream faster through this LDS-free kernel than through the barrier-per-32-positions LDS pipeline)
