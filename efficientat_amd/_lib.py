@@ -83,6 +83,7 @@ SIGNATURES = {
     "eat_se_bn_bwd_combine": [_P, _P, _P, _P, _I, _I, _P, _P],
     "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_P],
     "eat_stem_gram_blocks": [_I, _I],
+    "eat_gram_bn_finalize_g": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P, _P],
     "eat_pw_prepack_multi": [_P, _I, _I, _P],
     "eat_se_mlp_bwd": [_P] * 6 + [_F] + [_P] * 6 + [_I, _I, _I, _P],
     "eat_dw_bwd_merged_ok": [_I] * 8,

@@ -245,6 +245,51 @@ __global__ __launch_bounds__(64) void gram_bn_finalize_kernel(
   }
 }
 
+// The same from the Gram matrix itself: row c of T = W G is formed here (fp64 accumulation; G is symmetric, so thread k walks
+// column k of G with coalesced row reads) and written out for the backward - the separate W G GEMM launch disappears.
+// 256 threads = 64 columns x 4 slices of the j axis; dynamic LDS: 4 * Ci doubles.
+__global__ __launch_bounds__(256) void gram_bn_finalize_g_kernel(
+    const float* __restrict__ G, const float* __restrict__ W, const float* __restrict__ sx, int Co, int Ci,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, double n, float* __restrict__ Tm, float* __restrict__ a,
+    float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd) {
+  extern __shared__ double s_part[];                      // [4][Ci]
+  __shared__ double s_red[12];
+  const int c = blockIdx.x, kx = threadIdx.x & 63, jp = threadIdx.x >> 6;
+  const float* wr = W + (size_t)c * Ci;
+  const int jn = (Ci + 3) / 4, j0 = jp * jn, j1 = (j0 + jn) < Ci ? (j0 + jn) : Ci;
+  for (int k = kx; k < Ci; k += 64) {
+    double t = 0.0;
+    for (int j = j0; j < j1; ++j) t += (double)wr[j] * (double)G[(size_t)j * Ci + k];
+    s_part[jp * Ci + k] = t;
+  }
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0, dummy = 0.0;
+  for (int k = threadIdx.x; k < Ci; k += 256) {
+    const double t = (s_part[k] + s_part[Ci + k]) + (s_part[2 * Ci + k] + s_part[3 * Ci + k]);
+    Tm[(size_t)c * Ci + k] = (float)t;
+    const double w = (double)wr[k];
+    s1 += w * (double)sx[k];
+    s2 += w * t;
+  }
+  block_sum_d(s1, s2, dummy, s_red);
+  if (threadIdx.x != 0) return;
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[c] * is;
+  a[c] = av;
+  b[c] = beta[c] - (float)mu * av;
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
 // ---- (3) backward coefficients of conv 1x1 -> BatchNorm(train) -> act, per output channel (one block each) -------------
 //   in : W, Gx = sum g x^T, T = W G (Co x Ci each), sx (Ci), gpart [outer][Co][inner] (partials of sum g), a, mean, invstd
 //   out: dW (Co x Ci), dgamma, dbeta (Co), e1 = a (m2 invstd mu - m1) (Co), and three Ci x Co transposes for the MFMA
@@ -354,6 +399,18 @@ extern "C" int eat_gram_bn_finalize(const float* Tm, const float* W, const float
   hipLaunchKernelGGL(gram_bn_finalize_kernel, dim3((unsigned)Co), dim3(64), 0, (hipStream_t)stream, Tm, W, sx, Co, Ci, gamma,
                      beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
   return eat::check_launch("eat_gram_bn_finalize");
+}
+
+extern "C" int eat_gram_bn_finalize_g(const float* G, const float* W, const float* sx, int Co, int Ci, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                      double n, float* Tm, float* a, float* b, float* mean, float* invstd,
+                                      eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Co < 1 || Ci < 1 || Ci > 2048) return eat::fail(EAT_EINVAL, "eat_gram_bn_finalize_g: bad shape (%d x %d)", Co, Ci);
+  hipLaunchKernelGGL(gram_bn_finalize_g_kernel, dim3((unsigned)Co), dim3(256), (size_t)4 * Ci * sizeof(double),
+                     (hipStream_t)stream, G, W, sx, Co, Ci, gamma, beta, running_mean, running_var, momentum, eps, n, Tm, a, b,
+                     mean, invstd);
+  return eat::check_launch("eat_gram_bn_finalize_g");
 }
 
 extern "C" int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart,

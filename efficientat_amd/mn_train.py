@@ -251,15 +251,28 @@ class MNTrainFunction(torch.autograd.Function):
             # ---- head (mn/model.py:186-194)
             feat, u, h2, drop_mask = sv["head"]
             fc1, fc2 = model.classifier[2], model.classifier[5]
-            g["classifier.5.weight"] = _mm_nt(_t(dlogits), _t(h2))
-            g["classifier.5.bias"] = dlogits.sum(0)
-            dh2 = _mm_nt(dlogits, _t(fc2.weight))
-            if drop_mask is not None:
-                dh2 = dh2 * drop_mask
-            du = dh2 * torch.where(u < -3, torch.zeros_like(u), torch.where(u <= 3, u / 3 + 0.5, torch.ones_like(u)))
-            g["classifier.2.weight"] = _mm_nt(_t(du), _t(feat))
-            g["classifier.2.bias"] = du.sum(0)
-            dft = _mm_nt(du, _t(fc1.weight))
+            if v2:
+                # plain library GEMMs on the transposed VIEWS (rocBLAS takes the transposition as a flag: no transposed copies)
+                # and torch's fused Hardswish backward: 9 launches where the round-2 form took 25
+                g["classifier.5.weight"] = torch.mm(dlogits.t(), h2)
+                g["classifier.5.bias"] = dlogits.sum(0)
+                dh2 = torch.mm(dlogits, fc2.weight)
+                if drop_mask is not None:
+                    dh2 = dh2 * drop_mask
+                du = torch.ops.aten.hardswish_backward(dh2, u)
+                g["classifier.2.weight"] = torch.mm(du.t(), feat)
+                g["classifier.2.bias"] = du.sum(0)
+                dft = torch.mm(du, fc1.weight)
+            else:
+                g["classifier.5.weight"] = _mm_nt(_t(dlogits), _t(h2))
+                g["classifier.5.bias"] = dlogits.sum(0)
+                dh2 = _mm_nt(dlogits, _t(fc2.weight))
+                if drop_mask is not None:
+                    dh2 = dh2 * drop_mask
+                du = dh2 * torch.where(u < -3, torch.zeros_like(u), torch.where(u <= 3, u / 3 + 0.5, torch.ones_like(u)))
+                g["classifier.2.weight"] = _mm_nt(_t(du), _t(feat))
+                g["classifier.2.bias"] = du.sum(0)
+                dft = _mm_nt(du, _t(fc1.weight))
             if dfeat is not None:
                 dft = dft + dfeat
             # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
@@ -587,8 +600,7 @@ class MNTrainFunction2(torch.autograd.Function):
                         torch.cuda.set_stream(side_s)
                     try:
                         G = ops.gram(inp, exact=exact)                           # Gram matrix of the block input (reproducible)
-                        Tm = ops.linear(W, G, None, NONE)                         # W G  (G symmetric)
-                        st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e)
+                        Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e)     # T = W G and the BatchNorm state, one launch
                     finally:
                         if forked:
                             torch.cuda.set_stream(main_s)

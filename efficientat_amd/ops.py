@@ -474,6 +474,19 @@ def gram_bn_state(Tm, W, sx, bn, n):
     return out[0], out[1], out[2], out[3]
 
 
+def gram_bn_state_g(G, W, sx, bn, n):
+    """`gram_bn_state` straight from the Gram matrix G: -> (Tm = W G, (a, b, mean, invstd)); one launch, fp64 inside."""
+    Co, Ci = W.shape
+    out = torch.empty((4 * Co + Co * Ci,), device=W.device, dtype=torch.float32)
+    st, Tm = out[:4 * Co].view(4, Co), out[4 * Co:].view(Co, Ci)
+    _lib.call("eat_gram_bn_finalize_g", _dev(G, "G"), _dev(W, "W"), _dev(sx, "sx"), Co, Ci, _dev(bn.weight, "gamma"),
+              _dev(bn.bias, "beta"), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn),
+              float(bn.eps), float(n), Tm.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
+              st[3].data_ptr(), _stream())
+    bn_counters.bump(bn)
+    return Tm, (st[0], st[1], st[2], st[3])
+
+
 def act_grad_sum(dy, z, a, b, act, inplace=False):
     """g = dy * act'(a[c] z + b[c]) and its per-plane sums -> (g, (gpart, B, 1))."""
     B, C = z.shape[0], z.shape[1]

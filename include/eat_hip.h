@@ -183,6 +183,12 @@ int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int C
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          double n, float* a, float* b, float* mean, float* invstd, eat_stream_t stream);
 
+/* The same from G itself (Ci x Ci, symmetric): Tm = W G (Co x Ci) is formed in fp64 inside and written out (the backward's
+ * eat_expand_bwd_coef reads it) - no separate GEMM launch for W G. */
+int eat_gram_bn_finalize_g(const float* G, const float* W, const float* sx, int Co, int Ci, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, float momentum, float eps, double n,
+                           float* Tm, float* a, float* b, float* mean, float* invstd, eat_stream_t stream);
+
 /* g = dy * act'(a[c] z + b[c]) (g may alias dy) and gpart[b*C + c] = sum_s g: the first half of the backward of
  * act(BatchNorm(z)) as a stand-alone pass (geometries where eat_dw_conv_dgrad_g has no fused kernel). */
 int eat_act_grad_sum(const float* dy, const float* z, const float* a, const float* b, int act, float* g, float* gpart,

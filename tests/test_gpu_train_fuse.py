@@ -136,6 +136,15 @@ def test_expand_conv_bn_act_via_gram_matrix(B, Ci, Co, F_, T, act, exact):
     assert _rel(mean, z_ref.mean((0, 2, 3))) < 1e-5
     assert _rel(invstd, (z_ref.var((0, 2, 3), unbiased=False) + 1e-3).rsqrt()) < 2e-5
     assert _rel(bn.running_mean, bn_ref.running_mean) < 1e-5 and _rel(bn.running_var, bn_ref.running_var) < 2e-5
+    # the one-launch form (W G formed inside, in fp64)
+    bn2 = torch.nn.BatchNorm2d(Co, eps=1e-3, momentum=0.01).to(DEV).train()
+    with torch.no_grad():
+        bn2.weight.copy_(gamma)
+        bn2.bias.copy_(beta)
+    Tm2, st2 = ops.gram_bn_state_g(G, Wd, sx, bn2, n)
+    assert _rel(Tm2, W.double() @ G.cpu().double()) < 1e-6
+    assert _rel(st2[2], z_ref.mean((0, 2, 3))) < 1e-5 and _rel(st2[3], (z_ref.var((0, 2, 3), unbiased=False) + 1e-3).rsqrt()) < 2e-5
+    assert _rel(st2[0], a) < 1e-5 and _rel(st2[1], b) < 1e-4 and _rel(bn2.running_var, bn_ref.running_var) < 2e-5
     with ops.precision("fp32" if exact else "auto"):
         z = ops.pw_conv(xd, ops.pw_prepack(Wd), torch.zeros(Co, device=DEV), Co, ops.ACT_NONE)
         g, gparts = ops.act_grad_sum(dy.to(DEV), z, a, b, act)
