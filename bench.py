@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                  HBM roofline at the 96.37 MB/clip contract bytes AND at the bytes the launch plan actually moves
                  (sum of every kernel's own input + output), `fp32_exact` = every 1x1 conv on the exact fp32 MFMA
   train_step_mn40_bf16 / train_step_dymn20   BASELINE configs[2] / configs[3] (batch 128; N = 1 only)
+  forward_mn40 / forward_dymn20   eval forward of the same two models (batch 128, one stream; N = 1 only)
   parity         logit max-abs-err of the HIP path vs the CPU oracle (4 clips, same weights)
   cpu_baseline   the CPU oracle (a port of the reference's torch-CPU path) timed on this host: the same training step
 """
@@ -729,6 +730,20 @@ def main():
                 result[key] = train_bench(name, bt, st, wu, args, mel, wave, ranks)
             except Exception as e:  # pragma: no cover - one failing leg must not lose the line
                 result[key] = {"error": f"{type(e).__name__}: {e}", "model": name}
+                torch.cuda.empty_cache()
+        if not args.no_forward:
+            # the eval forward of the other BASELINE widths (configs[2] / [3] models), batch 128: hipGraph replay, one stream
+            for key, name in [("forward_mn40", "mn40"), ("forward_dymn20", "dymn20")]:
+                try:
+                    fm = make_train_model(name, dev).eval()
+                    fargs = argparse.Namespace(**{**vars(args), "streams": 1, "steps": 10, "warmup": 2})
+                    v, ms, launch = forward_bench(fargs, mel, fm, wave[:128], ranks)
+                    result[key] = {"value": round(v, 1), "unit": "clips/s", "ms_per_step": round(ms, 4), "batch_per_gpu": 128,
+                                   "steps": 10, "warmup": 2, "launch": launch,
+                                   "workload": f"{name}_as forward-only (log-mel + eval forward), batch 128, fp32 activations"}
+                    del fm
+                except Exception as e:  # pragma: no cover
+                    result[key] = {"error": f"{type(e).__name__}: {e}", "model": name}
                 torch.cuda.empty_cache()
     model.eval()
     mel.eval()
