@@ -5,6 +5,8 @@ import bench
 from efficientat_amd import _lib
 dev=torch.device('cuda:0')
 mel,model=bench.build_model(dev)
+import os
+if os.environ.get('MODEL'): model=bench.make_train_model(os.environ['MODEL'], dev)   # e.g. MODEL=mn40_bf16
 B=int(sys.argv[1]) if len(sys.argv)>1 else 128
 wave=(0.1*torch.randn(B,320000,device=dev)).clamp_(-1,1)
 y=(torch.rand(B,527,device=dev)<0.005).float()
