@@ -222,3 +222,31 @@ def test_mel_basis_matches_real_torchaudio_when_installed():
     for fmin, fmax in [(0.0, 15000.0), (3.0, 14001.0), (9.0, 16000.0), (5.0, 15500.0)]:
         ref, _ = kaldi.get_mel_banks(128, 1024, 32000, fmin, fmax, 100.0, -500.0, 1.0)
         assert torch.equal(kaldi_mel_basis(128, 1024, 32000, fmin, fmax), ref)
+
+
+def test_prepack_plan_builds_the_32_byte_records_the_kernel_reads():
+    """ops.PrepackPlan (host side of eat_pw_prepack_multi): one 32-byte record {w, wp, Co, Ci, kind, trans} per matrix,
+    pack kinds chosen as pw_prepack chooses them, destinations 256-byte aligned inside one buffer (no launch: CPU tensors)."""
+    import numpy as np
+    import torch
+    from efficientat_amd import ops
+    ws = [torch.randn(64, 16, 1, 1), torch.randn(24, 72, 1, 1), torch.randn(960, 160, 1, 1)]
+    entries = []
+    for i, w in enumerate(ws):
+        entries += [((i, "n"), w, False), ((i, "t"), w, True)]
+    with ops.precision("auto"):
+        plan = ops.PrepackPlan(entries)
+        assert not plan.stale()
+    rec = plan.table.numpy().view([("w", "<u8"), ("wp", "<u8"), ("Co", "<i4"), ("Ci", "<i4"), ("kind", "<i4"), ("trans", "<i4")])
+    assert plan.table.numel() == 32 * 6 and len(rec) == 6
+    # (Co, Ci) as the GEMM sees them; 'auto': fp32 pack below 40 input channels, split bf16 pack from there on
+    want = [(64, 16, 0, 0), (16, 64, 2, 1), (24, 72, 2, 0), (72, 24, 0, 1), (960, 160, 2, 0), (160, 960, 2, 1)]
+    assert [(int(r["Co"]), int(r["Ci"]), int(r["kind"]), int(r["trans"])) for r in rec] == want
+    base = plan.buf.data_ptr()
+    for r, (key, w, _) in zip(rec, entries):
+        assert int(r["w"]) == w.data_ptr() and (int(r["wp"]) - base) % 256 == 0
+        v = plan.get(key)
+        assert v.data_ptr() == int(r["wp"]) and v.dtype == (torch.float32 if int(r["kind"]) == 0 else torch.bfloat16)
+        assert getattr(v, "_eat_split", False) == (int(r["kind"]) == 2)
+    with ops.precision("fp32"):
+        assert plan.stale()                                    # another arithmetic: the plan must be rebuilt
