@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
-    int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1) {
+    int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1, int tps, long long wp_bstride) {
+  // tps > 0: per-sample weights (DyMN dynamic conv, models/dymn/dy_block.py:111-127, on split bf16 operands): a tile lies
+  //          inside one sample (tps tiles per sample) and reads that sample's packed weights (wp_bstride elements apart)
   // x2 != NULL ("two-source"): the reduction axis is the channels of x (c1 rows) followed by the channels of x2
   // (Ci - c1 rows), both (B, *, S) - the data-gradient GEMM of the expand conv with its BatchNorm correction,
   // dx = [WaT | M] [g ; x] (train_fuse.hip), without a separate M x launch
@@ -122,9 +124,10 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   if (tile >= n_tiles) return;
   const int mt0 = mchunk * MTW;
   // 32-bit index math: the host checks B*S < 2^31 (64-bit divisions cost ~150 VALU instructions each)
-  const unsigned N = (unsigned)B * (unsigned)S;
-  const unsigned n_base = (unsigned)tile * kTileN;
+  const unsigned n_base = tps ? (unsigned)(tile / tps) * (unsigned)S + (unsigned)(tile % tps) * kTileN : (unsigned)tile * kTileN;
   const int b_first = (int)(n_base / (unsigned)S);
+  const unsigned N = tps ? (unsigned)(b_first + 1) * (unsigned)S : (unsigned)B * (unsigned)S;   // first column this tile must not touch
+  wp += tps ? (size_t)b_first * (size_t)wp_bstride : 0;
   unsigned nl = n_base + 4 * lane;
   if (nl > N - 4) nl = N - 4;
   const int bl = (int)(nl / (unsigned)S), sl = (int)(nl - (unsigned)bl * (unsigned)S);
@@ -258,15 +261,17 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
            float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf,
-           const float* x2, int c1) {
+           const float* x2, int c1, bool per_sample) {
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
-  const int n_tiles = (int)((N + kTileN - 1) / kTileN);
+  const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
+  const int n_tiles = per_sample ? B * tps : (int)((N + kTileN - 1) / kTileN);
   int NS = kTileN / S + 2;
   if (NS > B) NS = B;
   if (!in_scale) NS = 0;
   const int sc_bytes = in_scale ? ((kKC * NS + 63) / 64) * 256 : 0;
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
+  const long long wp_bstride = (long long)((Ci + kKC - 1) / kKC) * MT * NP2 * 512;
   // Two LDS stages (chunk c+1 in flight under the MFMAs of chunk c) when two such blocks fit a CU or when
   // there are not enough blocks for two per CU anyway; otherwise ONE stage, so that a second resident
   // block hides the load latency and the store phase instead (measured on MI355X, B=256: 80->480 95 vs
@@ -285,20 +290,20 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1);
+                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1, tps, wp_bstride);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
 template <int NPROD>
 int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
              float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0},
-             const float* x2 = nullptr, int c1 = 0) {
+             const float* x2 = nullptr, int c1 = 0, bool per_sample = false) {
   const int MT = (Co + 15) / 16;
   // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
   // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1);
+#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -377,6 +382,18 @@ int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const voi
                : dispatch<1>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1);
 }
 }  // namespace eat
+
+// DyMN dynamic 1x1 conv with per-sample weights on split bf16 operands: wp_b = eat_dyn_pw_pack_bf16's (B, KK*MT*2*512)
+// hi / lo fragments (models/dymn/dy_block.py:111-127; the fp32-fragment form is eat_pw_conv_dyn_fwd).  Ci % 4 == 0, S % 4 == 0.
+extern "C" int eat_pw_conv_dyn_bf16_fwd(const float* x, const void* wp_b, const float* bias, const float* res, float* y,
+                                        int B, int Ci, int Co, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Ci % 4 != 0 || S % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_bf16_fwd: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_bf16_fwd: bad act %d", act);
+  if (B < 1 || Co < 1 || !wp_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_bf16_fwd: bad arguments");
+  return dispatch<3>((hipStream_t)stream, x, reinterpret_cast<const __bf16*>(wp_b), bias, nullptr, res, y, nullptr, B, Ci, Co,
+                     S, act, Ci, PwTf{nullptr, nullptr, 0}, nullptr, 0, true);
+}
 
 // DyMN dynamic 1x1 conv WITHOUT per-sample weights (models/dymn/dy_block.py:103-131):
 //   z_b = (sum_k att[b,k] W_k) x_b = [W_0 | ... | W_{K-1}] [att[b,0] x_b ; ... ; att[b,K-1] x_b]

@@ -246,15 +246,14 @@ extern "C" int eat_dw_conv_fwd_tf(const float* x, const float* in_a, const float
 // NULL: plain x) with the per-wave partial sums of y for the BatchNorm that follows (layout [b][2][C][inner] floats;
 // *h_inner receives inner, which never exceeds inner_cap = eat_dw_partials_inner(...)).  Geometries without a
 // register-resident kernel run the row-ring kernel followed by a one-block-per-plane statistics pass (inner = 1).
-extern "C" int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+static int dw_conv_fwd_stats_impl(int per_plane_w, const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
                                      float* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T,
                                      int Fo, int To, int k, int stride, eat_stream_t stream) {
-  eat::clear_stale_error();
   if ((in_a == nullptr) != (in_b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: in_a and in_b come together");
   if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: bad in_act %d", in_act);
   if (!part || !h_inner || inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 0))
     return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: partial buffer too small (inner_cap %d)", inner_cap);
-  const DwDyn dyn{nullptr, nullptr, nullptr, nullptr, 0, 0, in_a, in_b, in_act};
+  const DwDyn dyn{nullptr, nullptr, nullptr, nullptr, 0, per_plane_w, in_a, in_b, in_act};
   static const bool fused = !(getenv("EAT_DW_STATS_FUSED") && atoi(getenv("EAT_DW_STATS_FUSED")) == 0);
   int inner = 1;
   if (fused) {
@@ -266,6 +265,24 @@ extern "C" int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const fl
   if (rc != 0) return rc;
   *h_inner = 1;
   return eat::bn_stats_partial(y, B, C, Fo * To, part, (hipStream_t)stream);
+}
+
+extern "C" int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                                     float* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T,
+                                     int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return dw_conv_fwd_stats_impl(0, x, in_a, in_b, in_act, w, y, part, inner_cap, h_inner, B, C, F, T, Fo, To, k, stride, stream);
+}
+
+// The same with per-(b,c) taps w_bc (B, C, k*k): DyMN's dynamic depthwise conv in train mode (models/dymn/dy_block.py:
+// 103-131 with groups = channels) - the expand BatchNorm + activation evaluated on load, the statistics of depth_norm in
+// the epilogue.
+extern "C" int eat_dw_conv_dyn_fwd_stats(const float* x, const float* in_a, const float* in_b, int in_act, const float* w_bc,
+                                         float* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T,
+                                         int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return dw_conv_fwd_stats_impl(1, x, in_a, in_b, in_act, w_bc, y, part, inner_cap, h_inner, B, C, F, T, Fo, To, k, stride,
+                                stream);
 }
 
 // stride-1 depthwise data gradient = the same sliding-window kernel with the taps read reversed

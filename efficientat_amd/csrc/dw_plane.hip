@@ -62,6 +62,7 @@ struct PlaneArgs {
   int B, C, T, To, G, flip, act;
   InTf tf;
   eat::DwEpi epi;
+  int per_plane_w;
 };
 
 // d act(u) / du, PyTorch conventions (nn.ReLU / nn.Hardswish backward); `act` is wave-uniform
@@ -108,7 +109,9 @@ __device__ __forceinline__ void buf_store2(float v0, float v1, __amdgpu_buffer_r
 // the tensor gz at the output positions and summed per plane (epi.gpart) - the backward of the BatchNorm + activation
 // that FOLLOWS in forward order starts inside the kernel that produces its incoming gradient (mn_train.py);
 // STATS: per-plane sum / sum of squares of the output (epi.stats), the BatchNorm batch statistics of the conv output
-template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS>
+// PPW: taps per (b,c) plane (DyMN's dynamic depthwise conv in train mode, models/dymn/dy_block.py:103-131): wave-uniform
+// scalar loads for one plane per wave, per-lane loads (one address per half-wave) for two
+template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS, bool PPW = false>
 __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const float* __restrict__ w_,
                                                        const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2;
@@ -181,8 +184,14 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
     }
     // taps and bias of the (wave-uniform) channel: scalar loads, issued while the rows of the plane are still in flight
     float wk[K * K];
+    if constexpr (PPW) {
+      const float* wsrc = w_ + (size_t)(mine && NPW > 1 ? p + half * C : p) * (K * K);
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) wk[i] = w_[c * (K * K) + i];                   // __restrict__ kernel args: s_load
+      for (int i = 0; i < K * K; ++i) wk[i] = wsrc[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < K * K; ++i) wk[i] = w_[c * (K * K) + i];                 // __restrict__ kernel args: s_load
+    }
     if (a.flip) {                                                                   // data gradient: correlate with reversed taps
 #pragma unroll
       for (int i = 0; i < K * K / 2; ++i) { const float t = wk[i]; wk[i] = wk[K * K - 1 - i]; wk[K * K - 1 - i] = t; }
@@ -313,6 +322,14 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   const int waves = (n_groups + G - 1) / G;
   const dim3 grid((waves + 3) / 4), blk(256);
   if (a.epi.inner) *a.epi.inner = 1;
+  if (a.per_plane_w) {                                    // DyMN train mode: plain conv (forward / flipped data gradient) or + statistics
+    if (a.epi.gz || a.res || a.act != EAT_ACT_NONE) return 1;
+    if (a.epi.stats)
+      hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, true>), grid, blk, 0, s, a, a.w, a.bias);
+    else
+      hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, false, true>), grid, blk, 0, s, a, a.w, a.bias);
+    return eat::check_launch("eat_dw_conv_fwd(plane, per-plane taps)");
+  }
   if (a.epi.gz) {
     hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 2, false>), grid, blk, 0, s, a, a.w, a.bias);
   } else if (a.epi.stats) {
@@ -920,6 +937,8 @@ struct DwBwdArgs {
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, G;
   InTf tf;
   DzBn bn;
+  const float* res;      // PPW: added to g (the gradient of a skip connection that ends at the conv input), or NULL
+  float* gzpart;         // PPW: per-tile partials of sum g * x (x = the raw conv input), layout of gpart, or NULL
 };
 
 // LPP = 64: a wave owns one tile of one plane (column strips with halo lanes).  LPP = 32 / 16 (small planes, T <= 2 LPP): a
@@ -927,7 +946,35 @@ struct DwBwdArgs {
 // lanes (the zero padding of the conv is the group edge of from_prev / from_next).
 // WR with LPP = 64: one plane per wave, rows of <= 128 columns without halo lanes (a 125-column row of a 5 x 5 conv needs two
 // strips of the strip mode - 124 columns + 2 halo lanes - with half of the lanes idle in each).
-template <int K, int S, int RO, bool BN, int LPP, bool WR>
+// Sum N values per lane over the lanes of a group: at the step with lane distance O a lane keeps one half of its values and
+// hands the other half to lane ^ O (all indices compile-time: a run-time half size turns v[] into a waterfall of
+// indexed-register moves); once one value is left the remaining steps are plain sums.  vidx: index of the first value the
+// lane ends up with.
+template <int NV, int N, int O>
+__device__ __forceinline__ void tap_reduce(float (&v)[NV], int l, int& vidx) {
+  if constexpr (O > 0) {
+    if constexpr (N > 1) {
+      constexpr int H = N / 2;
+      const bool up = (l & O) != 0;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const float keep = up ? v[i + H] : v[i];
+        const float send = up ? v[i] : v[i + H];
+        v[i] = keep + __shfl_xor(send, O, 64);
+      }
+      vidx += up ? H : 0;
+      tap_reduce<NV, H, O / 2>(v, l, vidx);
+    } else {
+      v[0] += __shfl_xor(v[0], O, 64);
+      tap_reduce<NV, 1, O / 2>(v, l, vidx);
+    }
+  }
+}
+
+// PPW: taps and weight gradient per (b,c) plane (DyMN's dynamic depthwise conv, models/dymn/dy_block.py:103-131): the taps
+// of the lane group's own plane are loaded per sample, the K*K sums are reduced over the lane group after every sample and
+// stored (one tile per plane) or added (several) to dw (B, C, K*K)
+template <int K, int S, int RO, bool BN, int LPP, bool WR, bool PPW = false>
 __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
   constexpr int P = (K - 1) / 2, KK = K * K, NPW = 64 / LPP;
   static_assert(WR || LPP == 64, "strip mode owns the whole wave");
@@ -966,8 +1013,10 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   const int d0 = r0 - DOFF;                                         // global row of dz-array index 0
 
   float wk[KK];
+  if constexpr (!PPW) {
 #pragma unroll
-  for (int i = 0; i < KK; ++i) wk[i] = w_[(size_t)c * KK + i];
+    for (int i = 0; i < KK; ++i) wk[i] = w_[(size_t)c * KK + i];
+  }
   const TfCoef tk = tf_coef(a.tf, c);
   float acc[KK];
 #pragma unroll
@@ -999,6 +1048,11 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * Fo * To, z_left);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.g + (size_t)p * F * T, x_left);
+    if constexpr (PPW) {
+      const float* wsrc = w_ + (size_t)(mine ? p + half * a.C : p) * KK;
+#pragma unroll
+      for (int i = 0; i < KK; ++i) { wk[i] = wsrc[i]; acc[i] = 0.0f; }
+    }
     float xu[FX][2], dd[FD][ND];
 #pragma unroll
     for (int i = 0; i < FX; ++i) {
@@ -1007,6 +1061,13 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
       xu[i][0] = pv[0];
       xu[i][1] = pv[1];
+    }
+    // PPW: the raw conv input at the tile's own (output) positions, for sum g * x
+    constexpr int NZR = PPW ? (S == 1 ? RO : 2 * RO) : 1;
+    float xraw[NZR][2];
+    if constexpr (PPW) {
+#pragma unroll
+      for (int i = 0; i < NZR; ++i) { xraw[i][0] = xu[i + P][0]; xraw[i][1] = xu[i + P][1]; }
     }
     if constexpr (BN) {
       const __amdgpu_buffer_rsrc_t rzz = make_rsrc(a.bn.z + (size_t)p * Fo * To, z_left);
@@ -1101,7 +1162,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
     }
 
     // ---- data gradient of the tile + derivative epilogue
-    float psum = 0.0f;
+    float psum = 0.0f, pgz = 0.0f;
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc((PPW && a.res ? a.res : a.g) + (size_t)p * F * T, x_left);
     if constexpr (S == 1) {
       float ext[FD][NE];
 #pragma unroll
@@ -1136,9 +1198,20 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
         const int row = r0 + i;
         const bool rowok = row < F;
         const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
-        buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
-        buf_store(o0, rg, rowok ? vo1 : kOOB, so);
-        psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
+        if constexpr (PPW) {
+          psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
+          pgz += ((rowok && ok0) ? o0 * xraw[i][0] : 0.0f) + ((rowok && ok1) ? o1 * xraw[i][1] : 0.0f);
+          if (a.res) {                                            // wave-uniform
+            const f32x2 rv = buf_load2(rres, (rowok && ok0) ? hx + 4u * (unsigned)col_in : kOOB, so);
+            o0 += rv[0]; o1 += rv[1];
+          }
+          buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
+          buf_store(o0, rg, rowok ? vo1 : kOOB, so);
+        } else {
+          buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
+          buf_store(o0, rg, rowok ? vo1 : kOOB, so);
+          psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
+        }
       }
     } else {
       float z[FD][3];
@@ -1172,9 +1245,16 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
           const int row = 2 * (r0 + i) + pa;
           const bool rowok = row < F;
           const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
+          psum += ((rowok && ok0) ? o[0] : 0.0f) + ((rowok && ok1) ? o[1] : 0.0f);
+          if constexpr (PPW) {
+            pgz += ((rowok && ok0) ? o[0] * xraw[2 * i + pa][0] : 0.0f) + ((rowok && ok1) ? o[1] * xraw[2 * i + pa][1] : 0.0f);
+            if (a.res) {                                          // wave-uniform
+              const f32x2 rv = buf_load2(rres, (rowok && ok0) ? hx + 4u * (unsigned)col_in : kOOB, so);
+              o[0] += rv[0]; o[1] += rv[1];
+            }
+          }
           buf_store2(o[0], o[1], rg, rowok ? vo2 : kOOB, so);
           buf_store(o[0], rg, rowok ? vo1 : kOOB, so);
-          psum += ((rowok && ok0) ? o[0] : 0.0f) + ((rowok && ok1) ? o[1] : 0.0f);
         }
       }
     }
@@ -1187,19 +1267,51 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       }
       if (l == 0 && mine) a.gpart[(size_t)(p + half * a.C) * tpp + t] = psum;
     }
-  }
-  // one cross-lane reduction of the K*K weight-gradient sums per wave, then K*K atomics
-  float mine_v = 0.0f;
+    if constexpr (PPW) {
+      if (a.gzpart) {
+        if constexpr (LPP < 64) {
 #pragma unroll
-  for (int i = 0; i < KK; ++i) {
-    const float v = eat::wave_sum(acc[i]);
-    mine_v = lane == i ? v : mine_v;
+          for (int o = LPP >> 1; o > 0; o >>= 1) pgz += __shfl_xor(pgz, o, 64);
+        } else {
+          pgz = eat::wave_sum(pgz);
+        }
+        if (l == 0 && mine) a.gzpart[(size_t)(p + half * a.C) * tpp + t] = pgz;
+      }
+      // the plane's K*K sums over the lane group by a halving butterfly (tap_reduce): 32 shuffles for 25 sums over 64
+      // lanes instead of 25 x 6; afterwards lane l holds NFIN consecutive values starting at index vidx
+      constexpr int NV0 = KK <= 16 ? 16 : 32;                       // padded value count (power of two)
+      constexpr int NFIN = NV0 > LPP ? NV0 / LPP : 1;               // values left per lane (LPP = 16 with 25 taps: 2)
+      constexpr int DUP = NV0 >= LPP ? 0 : LPP / NV0 - 1;           // lanes l, l ^ d (d & DUP) end up with the same value
+      float v[NV0];
+#pragma unroll
+      for (int i = 0; i < NV0; ++i) v[i] = i < KK ? acc[i] : 0.0f;
+      int vidx = 0;
+      tap_reduce<NV0, NV0, (LPP >> 1)>(v, l, vidx);
+      float* d = a.dw + (size_t)(mine ? p + half * a.C : p) * KK;
+      const bool writer = mine && (l & DUP) == 0;
+#pragma unroll
+      for (int i = 0; i < NFIN; ++i) {
+        const int vi = vidx + i;
+        if (writer && vi < KK) {
+          if (tpp == 1) d[vi] = v[i]; else atomicAdd(d + vi, v[i]);
+        }
+      }
+    }
   }
-  if (lane < KK) atomicAdd(a.dw + (size_t)c * KK + lane, mine_v);
+  if constexpr (!PPW) {
+    // one cross-lane reduction of the K*K weight-gradient sums per wave, then K*K atomics
+    float mine_v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) {
+      const float v = eat::wave_sum(acc[i]);
+      mine_v = lane == i ? v : mine_v;
+    }
+    if (lane < KK) atomicAdd(a.dw + (size_t)c * KK + lane, mine_v);
+  }
 }
 
 template <int K, int S, int RO>
-int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
+int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s, bool ppw = false) {
   const bool bn = a.bn.z != nullptr;
   constexpr int WMAX = S == 1 ? (K == 3 ? 125 : 124) : 62;
   const int n_cols = S == 1 ? a.T : a.To, n_rows = S == 1 ? a.F : a.Fo;
@@ -1220,6 +1332,14 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s) {
   if (waves > 0x7fffffffLL) return 1;
   if (h_inner) *h_inner = a.n_rc * a.n_cs;
   const dim3 grid((unsigned)((waves + 3) / 4));
+  if (ppw) {                                             // per-plane taps (DyMN): the BatchNorm-on-load instances only
+    if (!bn) return 1;
+    if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true, true>), grid, dim3(256), 0, s, a, w);
+    else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false, true>), grid, dim3(256), 0, s, a, w);
+    else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32, true, true>), grid, dim3(256), 0, s, a, w);
+    else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true, true>), grid, dim3(256), 0, s, a, w);
+    return eat::check_launch("eat_dw_conv_dyn_bwd_bn_g");
+  }
   if (!bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false, 64, false>), grid, dim3(256), 0, s, a, w);
   else if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true>), grid, dim3(256), 0, s, a, w);
   else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false>), grid, dim3(256), 0, s, a, w);
@@ -1258,7 +1378,8 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
   if (n_planes > 0x3fffffffLL) return 1;                 // plane bases are 64-bit, offsets inside a plane 32-bit
   if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only
   const DwEpi epi = epi_ ? *epi_ : DwEpi{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-  if ((epi.stats || epi.gz) && (res || pool || act != EAT_ACT_NONE || per_plane_w)) return 1;   // training epilogues: plain conv only
+  if ((epi.stats || epi.gz) && (res || pool || act != EAT_ACT_NONE)) return 1;   // training epilogues: plain conv only
+  if (epi.gz && per_plane_w) return 1;
   static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
   if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {            // large planes: tiles of rows x column strips
     TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w, InTf{in_a, in_b, in_act}, epi};
@@ -1267,8 +1388,8 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
     if (k == 3 && stride == 2) return launch_tile<3, 2, 8>(ta, w, bias, act, s);
     if (k == 5 && stride == 2) return launch_tile<5, 2, 8>(ta, w, bias, act, s);
   }
-  if (per_plane_w) return 1;                             // whole-plane kernels below: per-channel taps only
-  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}, epi};
+  if (per_plane_w && (res || pool || act != EAT_ACT_NONE)) return 1;     // per-plane taps: the plain conv (+ statistics) only
+  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}, epi, per_plane_w};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane<3, 1, 1, 64, 8, true>(a, s);
   static const int pfb = getenv("EAT_DWP_PFB") ? atoi(getenv("EAT_DWP_PFB")) : 0;
   if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128)
@@ -1304,7 +1425,7 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
 
 int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
                float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
-               hipStream_t s, const DwBnBwd* bn) {
+               hipStream_t s, const DwBnBwd* bn, int per_plane_w, const float* res, float* gzpart) {
   static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
   if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
   // Measured (MI355X, B = 256): the merged kernel wins on the LARGE planes (64x500 -> 32x250: 1.03 vs 1.47 ms, 32x250:
@@ -1313,16 +1434,18 @@ int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* 
   static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
   if (!bn && T <= t_min) return 1;                       // (with the BatchNorm backward on load the small planes gain: fewer passes)
   DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act},
-              DzBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0}};
+              DzBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0}, res, gzpart};
+  const bool ppw = per_plane_w != 0;
+  if (ppw && !bn) return 1;
   if (bn) a.bn = DzBn{bn->z, bn->a, bn->b, bn->mean, bn->invstd, bn->gscale, bn->gadd, bn->sums, (double)B * Fo * To, bn->act, bn->frozen};
   if (stride == 1 && (Fo != F || To != T)) return 1;
   // 5x5 on planes of <= 4 (output) rows, the last stage of the network: tiles of 4 rows (half the multiply work of RO = 8)
-  if (bn && k == 5 && stride == 1 && F <= 4 && T <= 64) return launch_dw_bwd<5, 1, 4>(a, w, h_inner, s);
-  if (bn && k == 5 && stride == 2 && Fo <= 4 && T <= 64) return launch_dw_bwd<5, 2, 4>(a, w, h_inner, s);
-  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 8>(a, w, h_inner, s);      // (RO = 16 needs 246 VGPRs)
-  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 8>(a, w, h_inner, s);
-  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 8>(a, w, h_inner, s);
-  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 8>(a, w, h_inner, s);
+  if (bn && k == 5 && stride == 1 && F <= 4 && T <= 64) return launch_dw_bwd<5, 1, 4>(a, w, h_inner, s, ppw);
+  if (bn && k == 5 && stride == 2 && Fo <= 4 && T <= 64) return launch_dw_bwd<5, 2, 4>(a, w, h_inner, s, ppw);
+  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 8>(a, w, h_inner, s, ppw);      // (RO = 16 needs 246 VGPRs)
+  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 8>(a, w, h_inner, s, ppw);
+  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 8>(a, w, h_inner, s, ppw);
+  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 8>(a, w, h_inner, s, ppw);
   return 1;
 }
 

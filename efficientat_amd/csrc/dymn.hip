@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void dyn_aggregate_kernel(const float* __restr
 constexpr int kPackCols = 256;
 __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restrict__ bank, const float* __restrict__ att,
                                                           const float* __restrict__ row_scale, float* __restrict__ wp,
-                                                          int K, int Co, int Ci, int MT) {
+                                                          int K, int Co, int Ci, int MT, int trans) {
   __shared__ float s_w[16 * (kPackCols + 1)];
   const int mt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int m0 = mt * 16;
@@ -74,6 +74,23 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restric
   for (int c0 = 0; c0 < Ci; c0 += kPackCols) {
     const int cols = (Ci - c0) < kPackCols ? (Ci - c0) : kPackCols;     // multiple of 4
     // phase 1: 16 x cols aggregated weights -> LDS (thread = (row, 4 columns))
+    if (trans) {
+      // the bank stores W_k^T ((Ci, Co) row-major): packed row m = stored column, 16 consecutive m are one 64-byte run
+      for (int e = tid; e < 4 * cols; e += 256) {
+        const int col = e >> 2, q = e & 3;                          // (packed column, group of 4 packed rows)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * q < rows) {                                         // host: Co % 4 == 0
+          const size_t n = (size_t)(c0 + col) * Co + m0 + 4 * q;
+          for (int k = 0; k < K; ++k) {
+            const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + n);
+            const float ak = a[k];
+            v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
+          }
+        }
+        s_w[(4 * q + 0) * (kPackCols + 1) + col] = v.x; s_w[(4 * q + 1) * (kPackCols + 1) + col] = v.y;
+        s_w[(4 * q + 2) * (kPackCols + 1) + col] = v.z; s_w[(4 * q + 3) * (kPackCols + 1) + col] = v.w;
+      }
+    } else
     for (int e = tid; e < 16 * (cols >> 2); e += 256) {
       const int r = e / (cols >> 2), q = e - r * (cols >> 2);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -93,6 +110,72 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restric
     for (int ks = wv; ks < (cols >> 2); ks += 4) {
       const int kc = ks * 4 + (lane >> 4);
       out[((size_t)((c0 >> 2) + ks) * MT + mt) * 64 + lane] = s_w[m * (kPackCols + 1) + kc] * rs;
+    }
+    __syncthreads();
+  }
+}
+
+// The same aggregation as bf16 hi / lo fragments of v_mfma_f32_16x16x32_bf16 (eat_pw_prepack_bf16's layout, one pack per
+// sample):  wp[b][((kk*MT + mt)*2 + h)*512 + lane*8 + i] = part h of W_b[mt*16 + (lane&15)][kk*32 + 8*(lane>>4) + i].
+// Block = (16-row m-tile, sample); 16 x 256 aggregated weights through LDS as above, then every lane writes its 8
+// consecutive k of one (kk, h) fragment as ONE 16-byte store (a wave = one 1 KiB fragment).
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+__global__ __launch_bounds__(256) void dyn_pw_pack_bf16_kernel(const float* __restrict__ bank, const float* __restrict__ att,
+                                                               __bf16* __restrict__ wp, int K, int Co, int Ci, int MT, int KK,
+                                                               int trans) {
+  __shared__ float s_w[16 * (kPackCols + 1)];
+  const int mt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int m0 = mt * 16;
+  const int rows = (Co - m0) < 16 ? (Co - m0) : 16;
+  const float* a = att + (size_t)b * K;
+  const size_t N = (size_t)Co * Ci;
+  __bf16* out = wp + (size_t)b * KK * MT * 1024;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  for (int c0 = 0; c0 < Ci; c0 += kPackCols) {
+    const int cols = (Ci - c0) < kPackCols ? (Ci - c0) : kPackCols;     // multiple of 4
+    if (trans) {
+      for (int e = tid; e < 4 * kPackCols; e += 256) {
+        const int col = e >> 2, q = e & 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * q < rows && col < cols) {
+          const size_t n = (size_t)(c0 + col) * Co + m0 + 4 * q;
+          for (int k = 0; k < K; ++k) {
+            const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + n);
+            const float ak = a[k];
+            v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
+          }
+        }
+        s_w[(4 * q + 0) * (kPackCols + 1) + col] = v.x; s_w[(4 * q + 1) * (kPackCols + 1) + col] = v.y;
+        s_w[(4 * q + 2) * (kPackCols + 1) + col] = v.z; s_w[(4 * q + 3) * (kPackCols + 1) + col] = v.w;
+      }
+    } else
+    for (int e = tid; e < 16 * (kPackCols >> 2); e += 256) {
+      const int r = e / (kPackCols >> 2), q = e - r * (kPackCols >> 2);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows && 4 * q < cols) {
+        const size_t n = (size_t)(m0 + r) * Ci + c0 + 4 * q;
+        for (int k = 0; k < K; ++k) {
+          const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + n);
+          const float ak = a[k];
+          v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
+        }
+      }
+      float* d = s_w + r * (kPackCols + 1) + 4 * q;               // columns beyond Ci / rows beyond Co: zeros
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int nkk = (cols + 31) >> 5;
+    for (int j = wv; j < nkk * 2; j += 4) {                        // (32-column chunk, hi / lo) fragments of this piece
+      const int kl = j >> 1, h = j & 1;
+      bf16x8_t o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = s_w[m * (kPackCols + 1) + kl * 32 + 8 * kq + i];
+        const __bf16 hi = (__bf16)v;
+        o[i] = h ? (__bf16)(v - (float)hi) : hi;
+      }
+      *reinterpret_cast<bf16x8_t*>(out + (((size_t)((c0 >> 5) + kl) * MT + mt) * 2 + h) * 512 + lane * 8) = o;
     }
     __syncthreads();
   }
@@ -315,6 +398,249 @@ __global__ __launch_bounds__(256) void dyn_bank_grad_fused_kernel(const float* _
   for (int i = b_begin * K + threadIdx.x; i < b_end * K; i += 256) atomicAdd(datt + i, s_da[i]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: DyReLU-B * CoordAtt of the training step, second form.  The kernels above take the gates position-major
+// ((B, L, C): every plane gathers its Fo + To gate values with stride C - on the 4 x 32 planes of the last stage the 36
+// gathered cache lines outweigh the plane's own 512 bytes, 1 TB/s) and give one 256-thread block to every plane.  Here
+//   * the sigmoids of the gates are laid out channel-major once per block by gate_table_kernel: sg (B, C, Fo + To) - a
+//     plane's gate row is one contiguous run;
+//   * a wave owns a whole plane (two planes of consecutive channels' ... of the same sample for <= 32 columns): lane l holds
+//     columns l, l + LPP, ... of every row - coalesced row segments, the column sums of the backward stay in registers,
+//     row sums / coefficient sums / BatchNorm sums are lane-group reductions;
+//   * the backward also emits the two per-plane sums the BatchNorm backward of depth_norm needs (sum dv, sum dv * z): its
+//     reduce pass over (dv, z) disappears (dyn_bn_bwd_combine_kernel turns them into the fp64 channel sums).
+// Reference: models/dymn/dy_block.py:172-188 (DyReLU-B), :195-201 (CoordAtt), :399-403 (order inside DY_Block).
+
+// sg[b][c][l] = sigmoid(l < Fo ? gf[b][l][c] : gt[b][l - Fo][c]); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void gate_table_kernel(const float* __restrict__ gf, const float* __restrict__ gt,
+                                                         float* __restrict__ sg, int C, int Fo, int To) {
+  __shared__ float s_t[32][33];
+  const int L = Fo + To;
+  const int b = blockIdx.z, c0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int l = l0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.0f;
+    if (l < L && c < C) v = l < Fo ? gf[((size_t)b * Fo + l) * C + c] : gt[((size_t)b * To + (l - Fo)) * C + c];
+    s_t[ty + 8 * i][tx] = 1.0f / (1.0f + expf(-v));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, l = l0 + tx;
+    if (c < C && l < L) sg[((size_t)b * C + c) * L + l] = s_t[tx][ty + 8 * i];
+  }
+}
+
+// dgf[b][l][c] / dgt[b][l - Fo][c] = dsg[b][c][l] * s (1 - s), s = sg[b][c][l]  (gradient w.r.t. the PRE-sigmoid gates)
+__global__ __launch_bounds__(256) void gate_table_bwd_kernel(const float* __restrict__ dsg, const float* __restrict__ sg,
+                                                             float* __restrict__ dgf, float* __restrict__ dgt, int C, int Fo,
+                                                             int To) {
+  __shared__ float s_t[32][33];
+  const int L = Fo + To;
+  const int b = blockIdx.z, c0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, l = l0 + tx;
+    float v = 0.0f;
+    if (c < C && l < L) {
+      const size_t e = ((size_t)b * C + c) * L + l;
+      const float sv = sg[e];
+      v = dsg[e] * sv * (1.0f - sv);
+    }
+    s_t[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int l = l0 + ty + 8 * i, c = c0 + tx;
+    if (l < L && c < C) {
+      const float v = s_t[tx][ty + 8 * i];
+      if (l < Fo) dgf[((size_t)b * Fo + l) * C + c] = v; else dgt[((size_t)b * To + (l - Fo)) * C + c] = v;
+    }
+  }
+}
+
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPP >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LPP lanes per plane (64 / LPP planes of consecutive channels per wave), NC columns per lane (To <= LPP * NC)
+template <int LPP, int NC>
+__global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                             const float* __restrict__ b, const float* __restrict__ coef,
+                                                             const float* __restrict__ sg, float* __restrict__ out,
+                                                             int n_planes, int C, int Fo, int To) {
+  constexpr int NPW = 64 / LPP;
+  const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int plane = wave * NPW + lane / LPP;
+  const bool mine = plane < n_planes;
+  if (!mine) plane = n_planes - 1;
+  const int c = plane % C;
+  const float av = a ? a[c] : 1.0f, bv = a ? b[c] : 0.0f;
+  const float4 cf = *reinterpret_cast<const float4*>(coef + (size_t)plane * 4);
+  const float* sgp = sg + (size_t)plane * (Fo + To);
+  const float* zp = z + (size_t)plane * Fo * To;
+  float* op = out + (size_t)plane * Fo * To;
+  float at[NC];
+  bool ok[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int t = l + LPP * j;
+    ok[j] = mine && t < To;
+    at[j] = sgp[Fo + (t < To ? t : 0)];
+  }
+  constexpr int RU = NC >= 4 ? 2 : 4;                              // rows in flight
+  for (int f0 = 0; f0 < Fo; f0 += RU) {
+    float v[RU][NC], af[RU];
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      const int f = f0 + r < Fo ? f0 + r : Fo - 1;
+      af[r] = sgp[f];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int t = l + LPP * j;
+        v[r][j] = zp[(size_t)f * To + (t < To ? t : 0)];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      if (f0 + r >= Fo) break;                                      // wave-uniform
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const float u = fmaf(av, v[r][j], bv);
+        const float o = fmaxf(fmaf(cf.x, u, cf.z), fmaf(cf.y, u, cf.w)) * (af[r] * at[j]);
+        if (ok[j]) op[(size_t)(f0 + r) * To + l + LPP * j] = o;
+      }
+    }
+  }
+}
+
+template <int LPP, int NC>
+__global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                             const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ coef, const float* __restrict__ sg,
+                                                             float* __restrict__ dv, float* __restrict__ dcoef,
+                                                             float* __restrict__ dsg, float* __restrict__ bnpart,
+                                                             int n_planes, int C, int Fo, int To) {
+  constexpr int NPW = 64 / LPP;
+  const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int plane = wave * NPW + lane / LPP;
+  const bool mine = plane < n_planes;
+  if (!mine) plane = n_planes - 1;
+  const int c = plane % C;
+  const float av = a ? a[c] : 1.0f, bv = a ? b[c] : 0.0f;
+  const float4 cf = *reinterpret_cast<const float4*>(coef + (size_t)plane * 4);
+  const int L = Fo + To;
+  const float* sgp = sg + (size_t)plane * L;
+  float* dsgp = dsg + (size_t)plane * L;
+  const size_t base = (size_t)plane * Fo * To;
+  float at[NC], cs[NC];
+  bool ok[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int t = l + LPP * j;
+    ok[j] = t < To;
+    at[j] = sgp[Fo + (t < To ? t : 0)];
+    cs[j] = 0.0f;
+  }
+  float da1 = 0.f, da2 = 0.f, db1 = 0.f, db2 = 0.f, s1 = 0.f, s2 = 0.f;
+  constexpr int RU = NC >= 4 ? 2 : 4;
+  for (int f0 = 0; f0 < Fo; f0 += RU) {
+    float zv[RU][NC], dd[RU][NC], af[RU];
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      const int f = f0 + r < Fo ? f0 + r : Fo - 1;
+      af[r] = sgp[f];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int t = l + LPP * j;
+        const size_t e = base + (size_t)f * To + (t < To ? t : 0);
+        zv[r][j] = z[e];
+        dd[r][j] = dout[e];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      if (f0 + r >= Fo) break;                                      // wave-uniform
+      float rs = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const float zr = zv[r][j];
+        const float u = fmaf(av, zr, bv);
+        const float l1 = fmaf(cf.x, u, cf.z), l2 = fmaf(cf.y, u, cf.w);
+        const bool sel = l1 >= l2;
+        const float m = sel ? l1 : l2;
+        const float d = ok[j] ? dd[r][j] : 0.0f;
+        const float dm = d * (af[r] * at[j]);
+        const float g = dm * (sel ? cf.x : cf.y);
+        if (ok[j] && mine) dv[base + (size_t)(f0 + r) * To + l + LPP * j] = g;
+        const float dmv = dm * u;
+        da1 += sel ? dmv : 0.0f; db1 += sel ? dm : 0.0f;
+        da2 += sel ? 0.0f : dmv; db2 += sel ? 0.0f : dm;
+        s1 += g;
+        s2 = fmaf(g, zr, s2);
+        const float dmm = d * m;
+        rs = fmaf(dmm, at[j], rs);
+        cs[j] = fmaf(dmm, af[r], cs[j]);
+      }
+      rs = group_sum<LPP>(rs);
+      if (l == 0 && mine) dsgp[f0 + r] = rs;
+    }
+  }
+  if (mine) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) if (ok[j]) dsgp[Fo + l + LPP * j] = cs[j];
+  }
+  da1 = group_sum<LPP>(da1); da2 = group_sum<LPP>(da2); db1 = group_sum<LPP>(db1); db2 = group_sum<LPP>(db2);
+  s1 = group_sum<LPP>(s1); s2 = group_sum<LPP>(s2);
+  if (l == 0 && mine) {
+    *reinterpret_cast<float4*>(dcoef + (size_t)plane * 4) = make_float4(da1, da2, db1, db2);
+    if (bnpart) { bnpart[(size_t)plane * 2] = s1; bnpart[(size_t)plane * 2 + 1] = s2; }
+  }
+}
+
+// sums[c] = sum_b part[b][c][0], sums[C + c] = invstd[c] * (sum_b part[b][c][1] - mean[c] * sums[c])   (fp64): the channel
+// sums (sum dv, sum dv * xhat) of the BatchNorm backward from the per-plane (sum dv, sum dv * z) of dyrelu_ca_bwd2 /
+// the merged depthwise backward; parts may carry `inner` slots per plane: part0[(b*C + c)*inner + i] (two arrays)
+__global__ __launch_bounds__(256) void dyn_bn_bwd_combine_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                                 int stride_e, int B, int C, int inner,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 double* __restrict__ sums, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = threadIdx.x; i < B * inner; i += 256) {
+    const int bb = i / inner, q = i - bb * inner;
+    const size_t e = (((size_t)bb * C + c) * inner + q) * stride_e;
+    a0 += (double)p0[e];
+    a1 += (double)p1[e];
+  }
+  __shared__ double s_r[2][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+  if (lane == 0) { s_r[0][wv] = a0; s_r[1][wv] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t0 = (s_r[0][0] + s_r[0][1]) + (s_r[0][2] + s_r[0][3]);
+    const double t1 = (s_r[1][0] + s_r[1][1]) + (s_r[1][2] + s_r[1][3]);
+    const double gx = (double)invstd[c] * (t1 - (double)mean[c] * t0);
+    sums[c] = t0;
+    sums[C + c] = gx;
+    dbeta[c] = (float)t0;
+    dgamma[c] = (float)gx;
+  }
+}
+
 }  // namespace
 
 extern "C" int eat_ctx_pool(const float* x, float* seq, int B, int C, int F, int T, eat_stream_t stream) {
@@ -336,14 +662,49 @@ extern "C" int eat_dyn_aggregate(const float* bank, const float* att, const floa
   return eat::check_launch("eat_dyn_aggregate");
 }
 
-extern "C" int eat_dyn_pw_pack(const float* bank, const float* att, const float* row_scale, float* wp, int B, int K,
-                               int Co, int Ci, eat_stream_t stream) {
+static int dyn_pw_pack_impl(const float* bank, const float* att, const float* row_scale, float* wp, int B, int K, int Co,
+                            int Ci, int trans, eat_stream_t stream) {
   eat::clear_stale_error();
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack: Ci=%d must be a multiple of 4", Ci);
+  if (trans && Co % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_t: Co=%d must be a multiple of 4", Co);
   const int MT = (Co + 15) / 16;
   hipLaunchKernelGGL(dyn_pw_pack_kernel, dim3(MT, B), dim3(256), 0, (hipStream_t)stream, bank, att, row_scale, wp, K, Co,
-                     Ci, MT);
+                     Ci, MT, trans);
   return eat::check_launch("eat_dyn_pw_pack");
+}
+
+extern "C" int eat_dyn_pw_pack(const float* bank, const float* att, const float* row_scale, float* wp, int B, int K,
+                               int Co, int Ci, eat_stream_t stream) {
+  return dyn_pw_pack_impl(bank, att, row_scale, wp, B, K, Co, Ci, 0, stream);
+}
+
+// ... from the bank of the TRANSPOSED matrices: bank_t (K, Ci*Co) holds W_k^T row-major, i.e. the parameter of the conv
+// whose data gradient this is - packs sum_k att[b,k] W_k (Co x Ci) without a transposed copy of the bank
+extern "C" int eat_dyn_pw_pack_t(const float* bank_t, const float* att, const float* row_scale, float* wp, int B, int K,
+                                 int Co, int Ci, eat_stream_t stream) {
+  return dyn_pw_pack_impl(bank_t, att, row_scale, wp, B, K, Co, Ci, 1, stream);
+}
+
+static int dyn_pw_pack_bf16_impl(const float* bank, const float* att, void* wp, int B, int K, int Co, int Ci, int trans,
+                                 eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16: Ci=%d must be a multiple of 4", Ci);
+  if (trans && Co % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16_t: Co=%d must be a multiple of 4", Co);
+  if (B < 1 || K < 1 || Co < 1) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16: bad shape");
+  const int MT = (Co + 15) / 16, KK = (Ci + 31) / 32;
+  hipLaunchKernelGGL(dyn_pw_pack_bf16_kernel, dim3(MT, B), dim3(256), 0, (hipStream_t)stream, bank, att,
+                     reinterpret_cast<__bf16*>(wp), K, Co, Ci, MT, KK, trans);
+  return eat::check_launch("eat_dyn_pw_pack_bf16");
+}
+
+extern "C" int eat_dyn_pw_pack_bf16(const float* bank, const float* att, void* wp, int B, int K, int Co, int Ci,
+                                    eat_stream_t stream) {
+  return dyn_pw_pack_bf16_impl(bank, att, wp, B, K, Co, Ci, 0, stream);
+}
+
+extern "C" int eat_dyn_pw_pack_bf16_t(const float* bank_t, const float* att, void* wp, int B, int K, int Co, int Ci,
+                                      eat_stream_t stream) {
+  return dyn_pw_pack_bf16_impl(bank_t, att, wp, B, K, Co, Ci, 1, stream);
 }
 
 extern "C" int eat_ctx_pool_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T,
@@ -403,4 +764,74 @@ extern "C" int eat_dyn_bank_grad(const float* G, const float* att, const float* 
   if (gy < 1) gy = 1;
   hipLaunchKernelGGL(dyn_datt_kernel, dim3(gy, B), dim3(256), 0, (hipStream_t)stream, G, bank, datt, K, N);
   return eat::check_launch("eat_dyn_bank_grad");
+}
+
+// ---- round 4: channel-major gate table + one-wave-per-plane DyReLU-B * CoordAtt (see the kernels)
+extern "C" int eat_gate_table(const float* gate_f, const float* gate_t, float* sg, int B, int C, int Fo, int To,
+                              eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Fo < 1 || To < 1 || B > 65535) return eat::fail(EAT_EINVAL, "eat_gate_table: bad shape");
+  hipLaunchKernelGGL(gate_table_kernel, dim3((C + 31) / 32, (Fo + To + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, gate_f,
+                     gate_t, sg, C, Fo, To);
+  return eat::check_launch("eat_gate_table");
+}
+
+extern "C" int eat_gate_table_bwd(const float* dsg, const float* sg, float* dgate_f, float* dgate_t, int B, int C, int Fo,
+                                  int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Fo < 1 || To < 1 || B > 65535) return eat::fail(EAT_EINVAL, "eat_gate_table_bwd: bad shape");
+  hipLaunchKernelGGL(gate_table_bwd_kernel, dim3((C + 31) / 32, (Fo + To + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dsg,
+                     sg, dgate_f, dgate_t, C, Fo, To);
+  return eat::check_launch("eat_gate_table_bwd");
+}
+
+#define EAT_DYRELU2_DISPATCH(KERNEL, ...)                                                                             \
+  do {                                                                                                                \
+    const int n_planes = B * C;                                                                                       \
+    if (To <= 32) {                                                                                                   \
+      hipLaunchKernelGGL((KERNEL<32, 1>), dim3((n_planes / 2 + 1 + 3) / 4), dim3(256), 0, hs, __VA_ARGS__);            \
+    } else {                                                                                                          \
+      const dim3 grid((n_planes + 3) / 4);                                                                            \
+      if (To <= 64) hipLaunchKernelGGL((KERNEL<64, 1>), grid, dim3(256), 0, hs, __VA_ARGS__);                          \
+      else if (To <= 128) hipLaunchKernelGGL((KERNEL<64, 2>), grid, dim3(256), 0, hs, __VA_ARGS__);                    \
+      else if (To <= 256) hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(256), 0, hs, __VA_ARGS__);                    \
+      else hipLaunchKernelGGL((KERNEL<64, 8>), grid, dim3(256), 0, hs, __VA_ARGS__);                                   \
+    }                                                                                                                 \
+  } while (0)
+
+// out = max(a1 v + b1, a2 v + b2) * sg[b,c,f] * sg[b,c,Fo+t], v = a_c z + b_c (a, b NULL: v = z); sg from eat_gate_table.
+extern "C" int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b, const float* coef, const float* sg,
+                                  float* out, int B, int C, int Fo, int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2: bad shape (To <= 512)");
+  if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2: a and b come together");
+  hipStream_t hs = (hipStream_t)stream;
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_fwd2_kernel, z, a, b, coef, sg, out, n_planes, C, Fo, To);
+  return eat::check_launch("eat_dyrelu_ca_fwd2");
+}
+
+// backward: dv (w.r.t. v), dcoef (B,C,4), dsg (B,C,Fo+To) (w.r.t. the sigmoids: eat_gate_table_bwd finishes), bnpart
+// (B,C,2) = per-plane (sum dv, sum dv * z) or NULL
+extern "C" int eat_dyrelu_ca_bwd2(const float* dout, const float* z, const float* a, const float* b, const float* coef,
+                                  const float* sg, float* dv, float* dcoef, float* dsg, float* bnpart, int B, int C, int Fo,
+                                  int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2: bad shape (To <= 512)");
+  if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2: a and b come together");
+  hipStream_t hs = (hipStream_t)stream;
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_bwd2_kernel, dout, z, a, b, coef, sg, dv, dcoef, dsg, bnpart, n_planes, C, Fo, To);
+  return eat::check_launch("eat_dyrelu_ca_bwd2");
+}
+#undef EAT_DYRELU2_DISPATCH
+
+// Channel sums of a BatchNorm backward from per-plane partials (see dyn_bn_bwd_combine_kernel): p0 / p1 point at the first
+// element of the two partial arrays, element (b, c, i) lies stride_e * ((b*C + c)*inner + i) floats further on.
+extern "C" int eat_bn_bwd_combine_partials(const float* p0, const float* p1, int stride_e, int B, int C, int inner,
+                                           const float* mean, const float* invstd, double* sums, float* dgamma, float* dbeta,
+                                           eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!p0 || !p1 || stride_e < 1 || B < 1 || C < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_bn_bwd_combine_partials: bad arguments");
+  hipLaunchKernelGGL(dyn_bn_bwd_combine_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, p0, p1, stride_e, B, C, inner, mean,
+                     invstd, sums, dgamma, dbeta);
+  return eat::check_launch("eat_bn_bwd_combine_partials");
 }

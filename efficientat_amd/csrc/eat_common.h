@@ -117,7 +117,8 @@ struct DwBnBwd {
 };
 int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
                float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
-               hipStream_t s, const DwBnBwd* bn = nullptr);
+               hipStream_t s, const DwBnBwd* bn = nullptr, int per_plane_w = 0, const float* res = nullptr,
+               float* gzpart = nullptr);
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
 int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,

@@ -887,7 +887,7 @@ template <int MTN, int NTN, bool SAME>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                     const float* __restrict__ xscale, float* __restrict__ dW,
                                                                     int B, int Co, int Ci, int S, int sps,
-                                                                    int units_per_block, int n_slots, WgTf tf) {
+                                                                    int units_per_block, int n_slots, WgTf tf, int ps_spl) {
   // the four waves' tiles are combined in LDS (ds_add_f32) before ONE set of global atomics per block, and the blocks
   // are spread over n_slots copies of dW (reduced by wgrad_slot_reduce_kernel): atomics on the same address serialise
   // in L2 at ~40 ns each, which made the 8192 (= 2048 blocks x 4 waves) adds per element the whole cost of this kernel
@@ -900,8 +900,11 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   // round 3: blockIdx.x / blockIdx.y select a group of MTN / NTN row tiles ("thin" matrices: up to ~8 x 8 tiles over a
   // long k axis stream faster through this LDS-free kernel than through the barrier-per-32-positions LDS pipeline)
   const int m0 = blockIdx.x * (16 * MTN), n0 = SAME ? m0 : blockIdx.y * (16 * NTN);
-  const int total = B * sps;
-  const int u0 = blockIdx.z * units_per_block;
+  // ps_spl > 0: per-sample gradients (DyMN, models/dymn/dy_block.py:120-127 backward): ps_spl blocks share a sample's k
+  // range and add into that sample's own Co x Ci matrix
+  const int ps_b = ps_spl > 0 ? (int)blockIdx.z / ps_spl : 0;
+  const int total = ps_spl > 0 ? (ps_b + 1) * sps : B * sps;
+  const int u0 = ps_spl > 0 ? ps_b * sps + ((int)blockIdx.z - ps_b * ps_spl) * units_per_block : (int)blockIdx.z * units_per_block;
   const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
   for (int i = threadIdx.x; i < MTN * NTN * 256; i += 256) s_tile[i] = 0.0f;
   __syncthreads();
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
     }
     __syncthreads();
   }
-  float* out = dW + (size_t)(blockIdx.z % n_slots) * Co * Ci;
+  float* out = dW + (size_t)(ps_spl > 0 ? ps_b : (int)(blockIdx.z % n_slots)) * Co * Ci;
   for (int e = threadIdx.x; e < MTN * NTN * 256; e += 256) {
     const int ln = e & 63, q = (e >> 6) & 3, ij = e >> 8;
     const int i = ij / NTN, j = ij - i * NTN;
@@ -1045,13 +1048,14 @@ __global__ __launch_bounds__(256) void wgrad_slot_reduce_kernel(const float* __r
 
 template <int MTN, int NTN>
 static void launch_narrow(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co, int Ci, int S,
-                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s, WgTf tf, int mg, int ng, bool gram) {
+                          int sps, int upb, unsigned nz, int n_slots, hipStream_t s, WgTf tf, int mg, int ng, bool gram,
+                          int ps_spl = 0) {
   if (gram && MTN == NTN)
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, (MTN == NTN ? NTN : 1), (MTN == NTN)>), dim3(1, 1, nz), dim3(256), 0, s, dz,
-                       x, x_scale, dW, B, Co, Ci, S, sps, upb, n_slots, tf);
+                       x, x_scale, dW, B, Co, Ci, S, sps, upb, n_slots, tf, 0);
   else
     hipLaunchKernelGGL((pw_wgrad_x3_narrow_kernel<MTN, NTN, false>), dim3(mg, ng, nz), dim3(256), 0, s, dz, x, x_scale, dW, B,
-                       Co, Ci, S, sps, upb, n_slots, tf);
+                       Co, Ci, S, sps, upb, n_slots, tf, ps_spl);
 }
 
 }  // namespace
@@ -1348,6 +1352,32 @@ extern "C" int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float
   return rc;
 }
 
+// The same for DyMN's dynamic depthwise conv (per-(b,c) taps w_bc (B, C, k*k), models/dymn/dy_block.py:103-131 backward):
+// dw_bc (B, C, k*k) receives the per-plane tap gradients (zero-filled by the caller: planes of several tiles are added),
+// res (shape of g) or NULL is added to g after the partial sums are taken (the skip connection of a block without expand
+// conv), gzpart (layout of gpart) or NULL receives the per-tile sums of g * x (x raw): with gpart the two sums the
+// BatchNorm backward of the expand conv needs - no reduce pass over (g, x).
+extern "C" int eat_dw_conv_dyn_bwd_bn_g(const float* dy, const float* z, const float* bn_a, const float* bn_b,
+                                        const float* bn_mean, const float* bn_invstd, const double* sums, int bn_act,
+                                        int frozen, const float* x, const float* in_a, const float* in_b, int in_act,
+                                        const float* w_bc, const float* res, float* g, float* dw_bc, float* gpart,
+                                        float* gzpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo,
+                                        int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dy || !z || !bn_a || !bn_b || !bn_mean || !bn_invstd || !sums || !in_a || !in_b || !w_bc || !g || !dw_bc)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g: missing operand");
+  if (in_act < 0 || in_act > 2 || bn_act < 0 || bn_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g: bad act");
+  if (!dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g: geometry not covered by the merged kernel (F=%d T=%d k=%d stride=%d)", F, T, k, stride);
+  if ((gpart || gzpart) && inner_cap < eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g: partial buffer too small (inner_cap %d)", inner_cap);
+  const eat::DwBnBwd bn{z, bn_a, bn_b, bn_mean, bn_invstd, nullptr, nullptr, sums, bn_act, frozen};
+  const int rc = eat::dw_bwd_try(dy, x, in_a, in_b, in_act, w_bc, g, dw_bc, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
+                                 (hipStream_t)stream, &bn, 1, res, gzpart);
+  if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g: merged kernel unavailable");
+  return rc;
+}
+
 extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T, int Fo,
                                      int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();
@@ -1356,7 +1386,7 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 
 // Launch plan of the 1x1 weight gradient: which kernel, how the k range is cut (also exported through
 // eat_pw_wgrad_slots so that a caller can size a one-slot-per-block workspace)
-struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; int mtb, ntb, mg, ng; bool gram; };
+struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; int mtb, ntb, mg, ng; bool gram; int ps_spl; };
 // kind: 0 LDS-free streaming kernel (thin matrices), 1 LDS-staged x3, 2 exact fp32; mtb / ntb: row tiles per block, mg / ng groups
 
 // (row tiles per block) pairs the streaming kernel is instantiated for
@@ -1367,14 +1397,34 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
   const bool force_fp32 = env_fp32 || exact_fp32 == 1;      // exact_fp32: 0 = bf16x3, 1 = exact fp32, 2 = plain bf16
   static const bool dyn_x3 = !(getenv("EAT_DYN_WGRAD_X3") && atoi(getenv("EAT_DYN_WGRAD_X3")) == 0);
   const bool ps_x3 = per_sample && dyn_x3 && Co >= 64 && Ci >= 64;
-  WgPlan p{2, 0, 0, (S + 31) / 32, 0, 0, 0, 1, 1, false};
+  WgPlan p{2, 0, 0, (S + 31) / 32, 0, 0, 0, 1, 1, false, 0};
+  static const bool thin_on = !(getenv("EAT_WGRAD_THIN") && atoi(getenv("EAT_WGRAD_THIN")) == 0);
+  if (!force_fp32 && (S & 3) == 0) {
+    const int sps = p.sps;
+    const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
+    if (per_sample && !ps_x3 && thin_on && sps >= 32) {
+      // per-sample gradients of the thin early-layer matrices (one side < 64 channels, planes of >= 1024 positions):
+      // the same streaming kernel, a few blocks per sample adding into the sample's own matrix
+      const int mg = (mtn + 3) / 4, ng = (ntn + 2) / 3;
+      const int mtb = (mtn + mg - 1) / mg, ntb = (ntn + ng - 1) / ng;
+      if (mg * ng <= 4 && thin_pair(mtb, ntb)) {
+        int spl = 1024 / (mg * ng * B);
+        if (spl > sps / 16) spl = sps / 16;
+        if (spl < 1) spl = 1;
+        p.kind = 0; p.mtb = mtb; p.ntb = ntb; p.mg = mg; p.ng = ng;
+        p.upb = (sps + spl - 1) / spl;
+        p.ps_spl = (sps + p.upb - 1) / p.upb;
+        p.nz = (unsigned)(B * p.ps_spl);
+        return p;
+      }
+    }
+  }
   if (!force_fp32 && (!per_sample || ps_x3) && (S & 3) == 0) {
     const int sps = p.sps;
     const int tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
     const long long total = (long long)B * sps;
     const bool gram = same && Co == Ci && !has_scale_or_tf;
     const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
-    static const bool thin_on = !(getenv("EAT_WGRAD_THIN") && atoi(getenv("EAT_WGRAD_THIN")) == 0);
     bool thin = false;
     if (!per_sample) {
       if (gram && Co <= 64) {                                  // Gram matrix: the operand is loaded once
@@ -1436,7 +1486,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
     const bool use_ws = ws != nullptr && n_slots > 1;
     float* target = use_ws ? ws : dW;
     const int slots = use_ws ? (n_slots < (int)p.nz ? n_slots : (int)p.nz) : 1;
-#define EAT_NARROW(M_, N_) if (p.mtb == M_ && p.ntb == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.nz, slots, hs, tf, p.mg, p.ng, p.gram)
+#define EAT_NARROW(M_, N_) if (p.mtb == M_ && p.ntb == N_) launch_narrow<M_, N_>(dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.nz, slots, hs, tf, p.mg, p.ng, p.gram, p.ps_spl)
     EAT_NARROW(1, 1); EAT_NARROW(1, 2); EAT_NARROW(1, 3); EAT_NARROW(1, 4);
     EAT_NARROW(2, 1); EAT_NARROW(3, 1); EAT_NARROW(4, 1);
     EAT_NARROW(2, 2); EAT_NARROW(3, 3); EAT_NARROW(4, 4);       // (2,2), (4,4): Gram mode only (dz == x, Co == Ci)
@@ -1504,6 +1554,11 @@ extern "C" int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float
   if (!tf_a || !tf_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_tf: tf_a and tf_b are required");
   if (tf_act < 0 || tf_act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_tf: bad act %d", tf_act);
   return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream, ws, n_slots, WgTf{tf_a, tf_b, tf_act});
+}
+
+// 1 where eat_pw_conv_dyn_wgrad adds into dW_b (the caller zero-fills it), 0 where it stores.  Host helper.
+extern "C" int eat_pw_dyn_wgrad_accumulates(int Co, int Ci, int S) {
+  return wgrad_plan(1, Co, Ci, S, 1, 0, false, false).kind == 1 ? 0 : 1;
 }
 
 extern "C" int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,

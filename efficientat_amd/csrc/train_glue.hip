@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   if (ty == 0 && c < C) atomicAdd(out + c, (s_red[0][tx] + s_red[1][tx]) + (s_red[2][tx] + s_red[3][tx]));
 }
 
-// Few rows (R <= 4096: the per-(b,c) plane sums of the train plan, R = batch): one thread per column adds the rows in
+// Few rows (R <= 512: the per-(b,c) plane sums of the train plan, R = batch): one thread per column adds the rows in
 // index order - no atomics, bit-reproducible (these column sums feed BatchNorm statistics: a last-bit difference decides
 // on which side of an activation kink some element falls, so run-to-run noise here becomes 1e-3-level gradient noise)
 __global__ __launch_bounds__(256) void col_sum_det_kernel(const float* __restrict__ m, float* __restrict__ out, int R, int C) {
@@ -166,7 +166,7 @@ extern "C" int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_
   eat::clear_stale_error();
   if (R < 1 || C < 1 || C > 8192) return eat::fail(EAT_EINVAL, "eat_col_sum: bad shape (%d x %d)", R, C);
   hipStream_t s = (hipStream_t)stream;
-  if (R <= 4096) {
+  if (R <= 512) {                  // the train plan's per-(b,c) plane sums (R = batch): fixed order, no atomics
     hipLaunchKernelGGL(col_sum_det_kernel, dim3((C + 255) / 256), dim3(256), 0, s, m, out, R, C);
     return eat::check_launch("eat_col_sum");
   }

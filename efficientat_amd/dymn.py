@@ -21,6 +21,7 @@ The reference materialises (B*Cout, Cin/g, k, k) weights and runs a grouped conv
 pool, softmax over K=4, sigmoid of the DyReLU coefficients) uses torch ops; every pass over a
 feature map and every GEMM runs in the library.  Train mode: dymn_train.py.
 """
+import os
 from functools import partial
 
 import numpy as np
@@ -235,6 +236,8 @@ class DyMN(nn.Module):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.zeros_(m.bias)
         self._cache = _FoldCache()
+        # arithmetic of the 1x1 convs of a train-mode pass (ops.precision; same switch and default as MN)
+        self.train_precision = os.environ.get("EAT_TRAIN_PRECISION", "auto")
 
     # ----------------------------------------------------------------------- folded BN (eval)
     def _fold_sources(self):

@@ -38,6 +38,20 @@ def _col_sum(m):
     return ops.col_sum(m.contiguous())
 
 
+class _in_precision:
+    """Re-enter, in a backward, the 1x1-conv arithmetic (`ops.precision`) the forward of the same Function ran under:
+    autograd calls backward() outside `forward_train`'s context manager."""
+
+    def __init__(self, ctx):
+        self.p = ops.precision(ctx.prec)
+
+    def __enter__(self):
+        self.p.__enter__()
+
+    def __exit__(self, *exc):
+        self.p.__exit__(*exc)
+
+
 # ------------------------------------------------------------------------------- Functions
 class CtxPool(torch.autograd.Function):
     @staticmethod
@@ -60,18 +74,21 @@ class Linear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.prec = ops.precision.mode
         return ops.linear(x.contiguous(), w.contiguous(), b, NONE)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.linear(dy, _t(w), None, NONE)
+        dx = ops.linear(dy, _t(w), None, NONE) if ctx.needs_input_grad[0] else None
         M = dy.shape[0]
         if M >= 4096 and M % 4 == 0 and x.shape[1] % 4 == 0:
             # long reductions (M = B * (F + T) rows of the context sequence): dW = dy^T x is the 1x1 weight-gradient
             # GEMM with one "sample" of M positions - split-K over many blocks instead of 4 waves of the linear kernel
-            dw = ops.pw_conv_wgrad(_t(dy).view(1, dy.shape[1], M, 1), _t(x).view(1, x.shape[1], M, 1), exact=False)
+            with _in_precision(ctx):
+                dw = ops.pw_conv_wgrad(_t(dy).view(1, dy.shape[1], M, 1), _t(x).view(1, x.shape[1], M, 1),
+                                       exact=None)
         else:
             dw = ops.linear(_t(dy), _t(x), None, NONE)
         db = _col_sum(dy) if ctx.has_bias else None
@@ -117,6 +134,7 @@ class PwConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        ctx.prec = ops.precision.mode
         Co = w.shape[0]
         return ops.pw_conv(x.contiguous(), ops.pw_prepack(w.flatten(1)), _zeros.get(Co, x.device), Co, NONE)
 
@@ -125,8 +143,9 @@ class PwConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dz = dz.contiguous()
         Ci = x.shape[1]
-        dx = ops.pw_conv(dz, ops.pw_prepack(_t(w.flatten(1))), _zeros.get(Ci, x.device), Ci, NONE)
-        return dx, ops.pw_conv_wgrad(dz, x, exact=False).view_as(w)
+        with _in_precision(ctx):
+            dx = ops.pw_conv(dz, ops.pw_prepack(w.flatten(1), trans=True), _zeros.get(Ci, x.device), Ci, NONE)
+            return dx, ops.pw_conv_wgrad(dz, x, exact=None).view_as(w)
 
 
 class DwConv(torch.autograd.Function):
@@ -152,10 +171,49 @@ class DwConv(torch.autograd.Function):
 def _bank_grad(G, att, bank):
     B, K, N = att.shape[0], bank.shape[0], bank.shape[1]
     dbank = torch.empty_like(bank)
-    datt = torch.zeros_like(att)
+    datt = ops.zero_arena.zeros(tuple(att.shape), torch.float32, att.device)
     _lib.call("eat_dyn_bank_grad", G.data_ptr(), att.data_ptr(), bank.data_ptr(), dbank.data_ptr(), datt.data_ptr(),
               B, K, N, _s())
     return dbank, datt
+
+
+def _dyn_pw(x, bank, att, transposed, res=None):
+    """z_b = W_b x_b (+ res), W_b = sum_k att[b,k] bank[k] (Co, Ci) - or, `transposed`, W_b^T (the data gradient) - of a
+    dynamic 1x1 conv (models/dymn/dy_block.py:103-131), in the arithmetic of the active `ops.precision`:
+    late small-plane layers as ONE GEMM over the K-concatenated banks (no per-sample weights, ops.kcat_*), elsewhere
+    aggregate + pack per sample (bf16 hi / lo fragments from C_in >= 40 on under 'auto', fp32 fragments otherwise)."""
+    K, Co, Ci = bank.shape
+    if transposed:
+        Co, Ci = Ci, Co
+    bank2 = bank.reshape(K, Co * Ci)                 # transposed: rows of W_k^T (the packs read it in place)
+    S = x.shape[2] * x.shape[3]
+    zero = _zeros.get(Co, x.device)
+    tr = transposed and Co % 4 == 0
+    if transposed and not tr:
+        bank2 = bank.transpose(1, 2).contiguous().view(K, Co * Ci)
+    # (measured, dymn20 at B = 128: with per-sample weights as bf16 hi / lo fragments the aggregate-and-pack form beats the
+    #  K-concat GEMM - 4x the MFMA work - on every layer, 54.4 vs 55.3 ms per step; K-concat stays for geometries the
+    #  bf16 pack does not take)
+    if ops.dyn_bf16_eligible(Co, Ci, S):
+        return ops.pw_conv_dyn_bf16(x, ops.dyn_pw_pack_bf16(bank2, att, Co, Ci, trans=tr), zero, Co, NONE, res=res)
+    if ops.kcat_eligible(Co, Ci, S):
+        if tr:
+            bank2 = bank.transpose(1, 2).contiguous().view(K, Co * Ci)
+        return ops.pw_conv_kcat(x, ops.kcat_pack(bank2, Co, Ci), zero, att, Co, NONE, res=res)
+    return ops.pw_conv_dyn(x, ops.dyn_pw_pack(bank2, att, Co, Ci, trans=tr), zero, Co, NONE, res=res)
+
+
+def _dyn_pw_wgrad(dz, x, bank, att):
+    """-> (dbank (K, Co*Ci), datt (B, K)): per-sample weight gradients G_b = dz_b x_b^T, then dbank = att^T G,
+    datt = G bank^T."""
+    K, Co, Ci = bank.shape
+    B, S = x.shape[0], x.shape[2] * x.shape[3]
+    if ops.dyn_wgrad_needs_zero(Co, Ci, S):
+        G = ops.zero_arena.zeros((B, Co * Ci), torch.float32, x.device)
+    else:                                       # bf16x3 kernel in per-sample mode: plain stores
+        G = torch.empty((B, Co * Ci), device=x.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_dyn_wgrad", dz.data_ptr(), x.data_ptr(), G.data_ptr(), B, Co, Ci, S, _s())
+    return _bank_grad(G, att, bank.reshape(K, Co * Ci))
 
 
 class DynPwConv(torch.autograd.Function):
@@ -166,32 +224,20 @@ class DynPwConv(torch.autograd.Function):
         x, att = x.contiguous(), att.contiguous()
         K = weight.shape[2]
         Ci = x.shape[1]
-        bank = weight.view(K, Co * Ci)
         ctx.save_for_backward(x, weight, att)
         ctx.Co = Co
-        if ops.kcat_eligible(Co, Ci, x.shape[2] * x.shape[3]):       # late layers: no per-sample weights (ops.kcat_*)
-            return ops.pw_conv_kcat(x, ops.kcat_pack(bank, Co, Ci), _zeros.get(Co, x.device), att, Co, NONE)
-        wp = ops.dyn_pw_pack(bank, att, Co, Ci)
-        return ops.pw_conv_dyn(x, wp, _zeros.get(Co, x.device), Co, NONE)
+        ctx.prec = ops.precision.mode
+        return _dyn_pw(x, weight.view(K, Co, Ci), att, False)
 
     @staticmethod
     def backward(ctx, dz):
         x, weight, att = ctx.saved_tensors
         dz = dz.contiguous()
-        B, Ci, Fq, T = x.shape
         Co, K = ctx.Co, weight.shape[2]
-        bank = weight.view(K, Co, Ci)
-        # data gradient: per-sample W_b^T, packed from the transposed bank
-        bank_t = bank.transpose(1, 2).contiguous().view(K, Ci * Co)
-        if ops.kcat_eligible(Ci, Co, Fq * T):
-            dx = ops.pw_conv_kcat(dz, ops.kcat_pack(bank_t, Ci, Co), _zeros.get(Ci, x.device), att, Ci, NONE)
-        else:
-            wpt = ops.dyn_pw_pack(bank_t, att, Ci, Co)
-            dx = ops.pw_conv_dyn(dz, wpt, _zeros.get(Ci, x.device), Ci, NONE)
-        # per-sample weight gradient G_b, then the gradients of the aggregation
-        G = torch.zeros((B, Co * Ci), device=x.device, dtype=torch.float32)
-        _lib.call("eat_pw_conv_dyn_wgrad", dz.data_ptr(), x.data_ptr(), G.data_ptr(), B, Co, Ci, Fq * T, _s())
-        dbank, datt = _bank_grad(G, att, weight.view(K, Co * Ci))
+        bank = weight.view(K, Co, x.shape[1])
+        with _in_precision(ctx):
+            dx = _dyn_pw(dz, bank, att, True)
+            dbank, datt = _dyn_pw_wgrad(dz, x, bank, att)
         return dx, dbank.view_as(weight), datt, None
 
 
@@ -259,12 +305,11 @@ def _attention(conv, h_c):
     return F.softmax(logits / conv.temperature, dim=-1)
 
 
-def _block_train(blk, x):
+def _context(blk, x):
+    """ContextGen (models/dymn/dy_block.py:235-254) in train mode -> (h_c (B,H), g_cf (B,Fo,cexp), g_ct (B,To,cexp))."""
     cnf = blk.cnf
     B, cin, Fq, T = x.shape
-    H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
-    act = HSWISH if cnf.use_hs else RELU
-    inp = x
+    H, cexp, stride = blk.context_dim, cnf.expanded_channels, cnf.stride
     cg = blk.context_gen
     L = Fq + T
     seq = CtxPool.apply(x)                                                            # (B, L, cin)
@@ -274,7 +319,7 @@ def _block_train(blk, x):
     if bn.training:
         gj = F.batch_norm(gj, bn.running_mean, bn.running_var, bn.weight, bn.bias, True,
                           bn.momentum if bn.momentum is not None else 1.0 / (int(bn.num_batches_tracked) + 1), bn.eps)
-        bn.num_batches_tracked += 1
+        ops.bn_counters.bump(bn)
     else:                                    # frozen BatchNorm inside a train-mode pass: running statistics
         gj = F.batch_norm(gj, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
     g = F.hardswish(gj).view(B, L, H)
@@ -285,6 +330,18 @@ def _block_train(blk, x):
     Fo, To = h_cf.shape[1], h_ct.shape[1]
     g_cf = Linear.apply(h_cf.reshape(B * Fo, H), cg.conv_f.weight.flatten(1), cg.conv_f.bias).view(B, Fo, cexp)
     g_ct = Linear.apply(h_ct.reshape(B * To, H), cg.conv_t.weight.flatten(1), cg.conv_t.bias).view(B, To, cexp)
+    return h_c, g_cf, g_ct
+
+
+def _block_train(blk, x):
+    if not (blk.no_dyconv or blk.no_dyrelu or blk.no_ca) and _FUSED_BLOCK:
+        return _block_train_fused(blk, x)
+    cnf = blk.cnf
+    B, cin, Fq, T = x.shape
+    H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
+    act = HSWISH if cnf.use_hs else RELU
+    inp = x
+    h_c, g_cf, g_ct = _context(blk, x)
     # The ablated blocks (dy_block.py:269-271) keep the whole context generator above - the reference evaluates it
     # (and updates joint_norm's running statistics) whatever consumes it - and swap the consumers: static convs on the MN
     # Functions, the plain activation in BnAct, DyReLU-B / CoordAtt neutralised by constant operands (a1 = a2 = 1:
@@ -315,6 +372,222 @@ def _block_train(blk, x):
     return x + inp if blk.use_res_connect else x
 
 
+# ------------------------------------------------------------------ the fully dynamic block as ONE autograd Function
+import os as _os
+
+_FUSED_BLOCK = _os.environ.get("EAT_DYMN_FUSED", "1") != "0"
+_FUSED_DW = _os.environ.get("EAT_DYMN_FUSED_DW", "1") != "0"      # A/B: the round-4 depthwise / DyReLU kernels of the block
+
+
+class _Ones:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, n, device):
+        if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            self.buf = torch.ones((max(n, 4096),), device=device, dtype=torch.float32)
+        return self.buf[:n]
+
+
+_ones = _Ones()
+
+
+class _HcHeads(torch.autograd.Function):
+    """The four Linear layers that read h_c (the kernel attentions of the three dynamic convs, dy_block.py:106-109, and
+    DyReLU-B's coefficient net, :176-181) as ONE GEMM over the row-concatenated weights, with their pointwise tails:
+    -> att (3 or 2, B, K) = softmax(logits / T), coef (B, cexp, 4) = (2 sigmoid(.) - 1) * lambdas + init_v."""
+
+    @staticmethod
+    def forward(ctx, h_c, lambdas, init_v, temps, cexp, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        W = torch.cat(ws, 0)
+        bias = torch.cat(bs, 0)
+        y = ops.linear(h_c.contiguous(), W, bias, NONE)                       # (B, n_att * K + 4 cexp)
+        B = h_c.shape[0]
+        n_att = len(ws) - 1
+        K = ws[0].shape[0]
+        logits = y[:, :n_att * K].reshape(B, n_att, K)
+        if len(set(temps)) == 1:                                              # one schedule for every DynamicConv (the usual case)
+            att = torch.softmax(logits * (1.0 / temps[0]), dim=-1)            # (B, n_att, K)
+        else:
+            att = torch.stack([torch.softmax(logits[:, i] * (1.0 / t), dim=-1) for i, t in enumerate(temps)], 1)
+        sg = torch.sigmoid(y[:, n_att * K:])
+        coef = (2.0 * sg - 1.0).view(B, cexp, 4) * lambdas + init_v
+        ctx.save_for_backward(h_c, W, att, sg, lambdas)
+        ctx.sizes, ctx.temps = [w.shape[0] for w in ws], temps
+        return att.transpose(0, 1).contiguous(), coef
+
+    @staticmethod
+    def backward(ctx, datt, dcoef):
+        h_c, W, att, sg, lambdas = ctx.saved_tensors
+        temps = ctx.temps
+        B, n_att, K = att.shape
+        datt = datt.transpose(0, 1)                                           # (B, n_att, K)
+        dlog = att * (datt - (datt * att).sum(-1, keepdim=True))
+        if len(set(temps)) == 1:
+            dlog = dlog * (1.0 / temps[0])
+        else:
+            dlog = torch.stack([dlog[:, i] * (1.0 / t) for i, t in enumerate(temps)], 1)
+        dsg = (dcoef * lambdas).reshape(B, -1) * (2.0 * sg * (1.0 - sg))
+        dy = torch.cat([dlog.reshape(B, n_att * K), dsg], 1).contiguous()
+        dh = ops.linear(dy, _t(W), None, NONE)
+        dW = ops.linear(_t(dy), _t(h_c), None, NONE)
+        db = _col_sum(dy)
+        outs = []
+        o = 0
+        for n in ctx.sizes:
+            outs += [dW[o:o + n], db[o:o + n]]
+            o += n
+        return (dh, None, None, None, None, *outs)
+
+
+class DyBlockMain(torch.autograd.Function):
+    """Feature-map path of a fully dynamic DY_Block (models/dymn/dy_block.py:390-409) as one Function: dynamic expand
+    1x1 -> BN -> act -> dynamic depthwise -> BN -> DyReLU-B * CoordAtt -> dynamic project 1x1 -> BN (+ residual).
+    The context generator (CtxPool / Linear / _HcHeads) stays on autograd and hands in att_*, coef and the gates.
+    Passes this form removes against the per-op Functions: the normalised depthwise output v is never written (DyReLU /
+    CoordAtt and their backward evaluate the BatchNorm affine on load), the residual is added by the last BatchNorm
+    pass and enters the expand data-gradient GEMM as its `res` operand."""
+
+    @staticmethod
+    def forward(ctx, blk, x, att, coef, g_cf, g_ct, w_e, w_d, w_p, ge, be, gd, bd, gp, bp):
+        cnf = blk.cnf
+        x = x.contiguous()
+        B, cin, Fq, T = x.shape
+        cexp, cout, k, stride = cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
+        act = HSWISH if cnf.use_hs else RELU
+        K = w_d.shape[2]
+        has_e = w_e is not None
+        att = att.contiguous()
+        att_e, att_d, att_p = (att[0], att[1], att[2]) if has_e else (None, att[0], att[1])
+        coef, g_cf, g_ct = coef.contiguous(), g_cf.contiguous(), g_ct.contiguous()
+        Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
+        # round-4 kernels (per-plane taps in the register-resident depthwise kernels, one-wave-per-plane DyReLU): every
+        # geometry the merged depthwise backward covers; otherwise the separate passes
+        fused = _FUSED_DW and To <= 512 and ops.dw_bwd_merged_ok((B, cexp, Fo, To), (B, cexp, Fq, T), k, stride)
+        sv = {"fused": fused}
+        taps = ops.dyn_aggregate(w_d.view(K, cexp * k * k), att_d)
+        if has_e:
+            z_e = _dyn_pw(x, w_e.view(K, cexp, cin), att_e, False)
+            st_e = ops.bn_train_state(z_e, blk.exp_norm)
+            sv.update(z_e=z_e, st_e=st_e)
+        if fused:
+            # expand BatchNorm + activation on load, depth_norm's statistics in the epilogue: y_e is never written
+            z_d, parts = ops.dw_conv_dyn_stats(z_e if has_e else x, taps, k, stride,
+                                               tf=(st_e[0], st_e[1], act) if has_e else None)
+            st_d = ops.bn_state_from_partials(parts, blk.depth_norm, B * Fo * To) if blk.depth_norm.training else \
+                ops.bn_frozen_state(blk.depth_norm)
+            sg = ops.gate_table(g_cf, g_ct)
+            x2 = ops.dyrelu_ca_fwd2(z_d, st_d[0], st_d[1], coef, sg)
+            sv.update(sg=sg)
+        else:
+            y_e = ops.bn_act_fwd(z_e, st_e[0], st_e[1], act) if has_e else x
+            z_d = torch.empty((B, cexp, Fo, To), device=x.device, dtype=torch.float32)
+            _lib.call("eat_dw_conv_dyn_fwd", y_e.data_ptr(), taps.data_ptr(), _zeros.get(cexp, x.device).data_ptr(), None,
+                      None, None, z_d.data_ptr(), B, cexp, Fq, T, Fo, To, k, stride, _s())
+            st_d = ops.bn_train_state(z_d, blk.depth_norm)
+            x2 = torch.empty_like(z_d)
+            _lib.call("eat_dyrelu_ca_fwd", z_d.data_ptr(), st_d[0].data_ptr(), st_d[1].data_ptr(), coef.data_ptr(),
+                      g_cf.data_ptr(), g_ct.data_ptr(), x2.data_ptr(), B, cexp, Fo, To, _s())
+            sv.update(y_e=y_e if has_e else None)
+        z_p = _dyn_pw(x2, w_p.view(K, cout, cexp), att_p, False)
+        st_p = ops.bn_train_state(z_p, blk.proj_norm)
+        out = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=x if blk.use_res_connect else None)
+        sv.update(x=x, taps=taps, z_d=z_d, st_d=st_d, x2=x2, z_p=z_p, st_p=st_p, att=att, coef=coef, g_cf=g_cf, g_ct=g_ct,
+                  w_e=w_e, w_d=w_d, w_p=w_p)
+        ctx.sv, ctx.blk, ctx.act, ctx.prec = sv, blk, act, ops.precision.mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sv, blk, act = ctx.sv, ctx.blk, ctx.act
+        ctx.sv = None
+        cnf = blk.cnf
+        x = sv["x"]
+        B, cin, Fq, T = x.shape
+        cexp, cout, k, stride = cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
+        w_e, w_d, w_p = sv["w_e"], sv["w_d"], sv["w_p"]
+        K = w_d.shape[2]
+        has_e = w_e is not None
+        att = sv["att"]
+        att_e, att_d, att_p = (att[0], att[1], att[2]) if has_e else (None, att[0], att[1])
+        dout = dout.contiguous()
+        z_d, st_d = sv["z_d"], sv["st_d"]
+        Fo, To = z_d.shape[2], z_d.shape[3]
+        res = dout if blk.use_res_connect else None
+        dge = dbe = None
+        with _in_precision(ctx):
+            # project: BN backward, data gradient, per-sample weight gradients
+            dz_p, dgp, dbp = ops.bn_act_bwd(dout, sv["z_p"], *sv["st_p"], NONE)
+            bank_p = w_p.view(K, cout, cexp)
+            dx2 = _dyn_pw(dz_p, bank_p, att_p, True)
+            dbank_p, datt_p = _dyn_pw_wgrad(dz_p, sv["x2"], bank_p, att_p)
+            if sv["fused"]:
+                # DyReLU-B * CoordAtt on the BatchNorm affine of z_d; the sums of depth_norm's backward leave its epilogue
+                dv, dcoef, dsg, bnpart = ops.dyrelu_ca_bwd2(dx2, z_d, st_d[0], st_d[1], sv["coef"], sv["sg"])
+                dgf, dgt = ops.gate_table_bwd(dsg, sv["sg"], Fo)
+                sums_d, dgd, dbd = ops.bn_bwd_combine_partials(bnpart, bnpart.view(-1)[1:], 2, B, cexp, 1, st_d[2], st_d[3])
+                # merged depthwise backward: depth_norm's backward on load, tap gradients per plane, g_e = dy_e act'(.)
+                if has_e:
+                    st_e = sv["st_e"]
+                    g_e, G, parts = ops.dw_conv_dyn_bwd_bn_g(dv, z_d, st_d, NONE, sums_d, sv["taps"], sv["z_e"], st_e[0],
+                                                             st_e[1], act, k, stride)
+                    sums_e, dge, dbe = ops.bn_bwd_combine_partials(parts[0], parts[1], 1, B, cexp, parts[2], st_e[2], st_e[3])
+                    dz_e = ops.bn_bwd_apply(g_e, sv["z_e"], *st_e, sums_e)
+                else:
+                    one, zero = _ones.get(cexp, x.device), _zeros.get(cexp, x.device)
+                    dx, G, _ = ops.dw_conv_dyn_bwd_bn_g(dv, z_d, st_d, NONE, sums_d, sv["taps"], x, one, zero, NONE, k, stride,
+                                                        res=res, want_sums=False)
+            else:
+                dv, dcoef = torch.empty_like(z_d), torch.empty_like(sv["coef"])
+                dgf, dgt = torch.empty_like(sv["g_cf"]), torch.empty_like(sv["g_ct"])
+                _lib.call("eat_dyrelu_ca_bwd", dx2.data_ptr(), z_d.data_ptr(), st_d[0].data_ptr(), st_d[1].data_ptr(),
+                          sv["coef"].data_ptr(), sv["g_cf"].data_ptr(), sv["g_ct"].data_ptr(), dv.data_ptr(),
+                          dcoef.data_ptr(), dgf.data_ptr(), dgt.data_ptr(), B, cexp, Fo, To, _s())
+                dz_d, dgd, dbd = ops.bn_act_bwd(dv, z_d, *st_d, NONE)
+                y_e = sv["y_e"] if has_e else x
+                dy_e = torch.empty_like(y_e)
+                _lib.call("eat_dw_conv_dyn_dgrad", dz_d.data_ptr(), sv["taps"].data_ptr(),
+                          None if (has_e or res is None) else res.data_ptr(), dy_e.data_ptr(), B, cexp, Fq, T, Fo, To, k,
+                          stride, _s())
+                G = ops.zero_arena.zeros((B, cexp * k * k), torch.float32, x.device)
+                _lib.call("eat_dw_conv_dyn_wgrad", dz_d.data_ptr(), y_e.data_ptr(), G.data_ptr(), B, cexp, Fq, T, Fo, To, k,
+                          stride, _s())
+                if has_e:
+                    dz_e, dge, dbe = ops.bn_act_bwd(dy_e, sv["z_e"], *sv["st_e"], act)
+                else:
+                    dx = dy_e                        # (the skip connection's gradient entered the data gradient as `res`)
+            dbank_d, datt_d = _bank_grad(G, att_d, w_d.view(K, cexp * k * k))
+            if has_e:
+                bank_e = w_e.view(K, cexp, cin)
+                dx = _dyn_pw(dz_e, bank_e, att_e, True, res=res)
+                dbank_e, datt_e = _dyn_pw_wgrad(dz_e, x, bank_e, att_e)
+                datt = torch.stack([datt_e, datt_d, datt_p])
+                dwe = dbank_e.view_as(w_e)
+            else:
+                datt = torch.stack([datt_d, datt_p])
+                dwe = None
+        return (None, dx, datt, dcoef, dgf, dgt, dwe, dbank_d.view_as(w_d), dbank_p.view_as(w_p), dge, dbe, dgd, dbd,
+                dgp, dbp)
+
+
+def _block_train_fused(blk, x):
+    cnf = blk.cnf
+    h_c, g_cf, g_ct = _context(blk, x)
+    convs = ([blk.exp_conv] if blk.has_expand else []) + [blk.depth_conv, blk.proj_conv]
+    da = blk.depth_act
+    wb = []
+    for cv in convs:
+        wb += [cv.residuals[0].weight, cv.residuals[0].bias]
+    wb += [da.coef_net[0].weight, da.coef_net[0].bias]
+    temps = tuple(float(cv.temperature) for cv in convs)
+    att, coef = _HcHeads.apply(h_c, da.lambdas, da.init_v, temps, cnf.expanded_channels, *wb)
+    e = blk.has_expand
+    return DyBlockMain.apply(blk, x, att, coef, g_cf, g_ct, blk.exp_conv.weight if e else None, blk.depth_conv.weight,
+                             blk.proj_conv.weight, blk.exp_norm.weight if e else None, blk.exp_norm.bias if e else None,
+                             blk.depth_norm.weight, blk.depth_norm.bias, blk.proj_norm.weight, blk.proj_norm.bias)
+
+
 def _static_block_train(blk, x):
     """SE-less InvertedResidual in train mode (models/mn/block_types.py:138-181 with se_cnf None)."""
     cnf = blk.cnf
@@ -336,6 +609,12 @@ def forward_train(model, x, return_fmaps=False):
     """Train-mode `(logits, embedding)` - or `(logits, fmaps)`, models/dymn/model.py:157-195 - of DyMN with autograd
     support (models/dymn/model.py:185-200).  The fully-convolutional head (:119-130) runs as torch ops on the last 4 x 32
     map (its class count, 527, is not a multiple of 4, which the library's data-gradient GEMM needs)."""
+    ops.zero_arena.begin("dymn_step")          # one zero-filled arena per step (forward + the backward autograd runs later)
+    with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters:
+        return _forward_train(model, x, return_fmaps)
+
+
+def _forward_train(model, x, return_fmaps):
     x = x.contiguous().float()
     z = StemConv.apply(x, model.in_c[0].weight)
     x = BnAct.apply(z, model.in_c[1].weight, model.in_c[1].bias, model.in_c[1], HSWISH)

@@ -144,6 +144,13 @@ class _ZeroArena:
 
         return _Scope()
 
+    def begin(self, name):
+        """Open a pass that stays open until the next `begin` of the same name (DyMN: the backward runs inside autograd,
+        after `forward_train` has returned, so no `with` block can span the step)."""
+        if self.name == name:
+            self.need[name] = max(self.need.get(name, 0), self.req)
+        self.name, self.buf, self.off, self.req = name, None, 0, 0
+
     def zeros(self, shape, dtype, device):
         if self.name is None:
             return torch.zeros(shape, device=device, dtype=dtype)
@@ -660,11 +667,12 @@ def dyn_aggregate(bank, att, gscale=None, group=1):
     return out
 
 
-def dyn_pw_pack(bank, att, Co, Ci, row_scale=None):
+def dyn_pw_pack(bank, att, Co, Ci, row_scale=None, trans=False):
+    """trans: `bank` (K, Ci*Co) stores the TRANSPOSED matrices (the data-gradient pack without a transposed bank copy)."""
     K, B = bank.shape[0], att.shape[0]
     wp = torch.empty((B, (Ci // 4) * ((Co + 15) // 16) * 64), device=bank.device, dtype=torch.float32)
-    _lib.call("eat_dyn_pw_pack", _dev(bank, "bank"), _dev(att, "att"), _opt(row_scale, "row_scale"), wp.data_ptr(), B,
-              K, Co, Ci, _stream())
+    _lib.call("eat_dyn_pw_pack_t" if trans else "eat_dyn_pw_pack", _dev(bank, "bank"), _dev(att, "att"),
+              _opt(row_scale, "row_scale"), wp.data_ptr(), B, K, Co, Ci, _stream())
     return wp
 
 
@@ -672,6 +680,39 @@ def pw_conv_dyn(x, wp_b, bias, Co, act, res=None):
     B, Ci, F, T = x.shape
     y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
     _lib.call("eat_pw_conv_dyn_fwd", _dev(x, "x"), _dev(wp_b, "wp_b"), _dev(bias, "bias"), _opt(res, "res"),
+              y.data_ptr(), B, Ci, Co, F * T, act, _stream())
+    return y
+
+
+def dyn_bf16_eligible(Co, Ci, S):
+    """Per-sample-weight dynamic 1x1 conv on split bf16 operands (bf16x3) - the rule `pw_prepack` applies to the static
+    convs ('auto': from C_in = 40 on; 'bf16x3': everywhere; never under 'fp32' / plain 'bf16')."""
+    m = precision.mode
+    return S % 4 == 0 and Ci % 4 == 0 and (m == "bf16x3" or (m == "auto" and Ci >= 40))
+
+
+def dyn_wgrad_needs_zero(Co, Ci, S):
+    """True where `eat_pw_conv_dyn_wgrad` accumulates its per-sample output with atomics (the exact-fp32 tile kernel); the
+    bf16x3 kernel covers a sample's whole reduction in one block and stores."""
+    return bool(_lib.lib().eat_pw_dyn_wgrad_accumulates(Co, Ci, S))
+
+
+def dyn_pw_pack_bf16(bank, att, Co, Ci, trans=False):
+    """Aggregated per-sample weights sum_k att[b,k] bank[k] as bf16 hi / lo MFMA fragments (the per-sample form of
+    `pw_prepack_bf16(split=True)`) -> (B, KK*MT*2*512) bfloat16.  trans: as in `dyn_pw_pack`."""
+    K, B = bank.shape[0], att.shape[0]
+    n = ((Ci + 31) // 32) * ((Co + 15) // 16) * 2 * 512
+    wp = torch.empty((B, n), device=bank.device, dtype=torch.bfloat16)
+    _lib.call("eat_dyn_pw_pack_bf16_t" if trans else "eat_dyn_pw_pack_bf16", _dev(bank, "bank"), _dev(att, "att"),
+              wp.data_ptr(), B, K, Co, Ci, _stream())
+    return wp
+
+
+def pw_conv_dyn_bf16(x, wp_b, bias, Co, act, res=None):
+    """Per-sample-weight 1x1 conv on the bf16x3 kernel (csrc/conv_pw_bf16.hip, tiles inside one sample)."""
+    B, Ci, F, T = x.shape
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_dyn_bf16_fwd", _dev(x, "x"), wp_b.data_ptr(), _dev(bias, "bias"), _opt(res, "res"),
               y.data_ptr(), B, Ci, Co, F * T, act, _stream())
     return y
 
@@ -722,6 +763,102 @@ def dw_conv_dyn_act(x, w_bc, bias, act, coef, gate_f, gate_t, k, stride):
     _lib.call("eat_dw_conv_dyn_act_fwd", _dev(x, "x"), _dev(w_bc, "w_bc"), _dev(bias, "bias"), act, _opt(coef, "coef"),
               _opt(gate_f, "gate_f"), _opt(gate_t, "gate_t"), y.data_ptr(), B, C, F, T, Fo, To, k, stride, _stream())
     return y
+
+
+# ---- round 4: fused training passes of the dynamic block (csrc/dymn.hip, csrc/dw_plane.hip)
+def dw_conv_dyn_stats(x, w_bc, k, stride, tf=None):
+    """`dw_conv_stats` with per-(b,c) taps w_bc (B, C*k*k): -> (y, (part, outer, inner))."""
+    B, C, F, T = x.shape
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    cap = dw_partials_inner(F, T, Fo, To, k, stride, False)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    part = torch.empty((B * 2 * C * cap,), device=x.device, dtype=torch.float32)
+    inner = _ct.c_int(0)
+    a, b, act = tf if tf is not None else (None, None, 0)
+    _lib.call("eat_dw_conv_dyn_fwd_stats", _dev(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w_bc, "w_bc"),
+              y.data_ptr(), part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
+    return y, (part, B, inner.value)
+
+
+def gate_table(gate_f, gate_t):
+    """sigmoid of CoordAtt's gates (B, Fo, C) / (B, To, C), laid out channel-major: -> sg (B, C, Fo + To)."""
+    B, Fo, C = gate_f.shape
+    To = gate_t.shape[1]
+    sg = torch.empty((B, C, Fo + To), device=gate_f.device, dtype=torch.float32)
+    _lib.call("eat_gate_table", _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), sg.data_ptr(), B, C, Fo, To, _stream())
+    return sg
+
+
+def gate_table_bwd(dsg, sg, Fo):
+    """-> (dgate_f (B, Fo, C), dgate_t (B, To, C)): gradients w.r.t. the pre-sigmoid gates from dsg (B, C, Fo + To)."""
+    B, C, L = sg.shape
+    To = L - Fo
+    buf = torch.empty((B * L * C,), device=sg.device, dtype=torch.float32)
+    dgf, dgt = buf[:B * Fo * C].view(B, Fo, C), buf[B * Fo * C:].view(B, To, C)
+    _lib.call("eat_gate_table_bwd", _dev(dsg, "dsg"), _dev(sg, "sg"), dgf.data_ptr(), dgt.data_ptr(), B, C, Fo, To, _stream())
+    return dgf, dgt
+
+
+def dyrelu_ca_fwd2(z, a, b, coef, sg):
+    B, C, Fo, To = z.shape
+    out = torch.empty_like(z)
+    _lib.call("eat_dyrelu_ca_fwd2", _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"), _dev(sg, "sg"),
+              out.data_ptr(), B, C, Fo, To, _stream())
+    return out
+
+
+def dyrelu_ca_bwd2(dout, z, a, b, coef, sg, want_bn=True):
+    """-> (dv, dcoef (B,C,4), dsg (B,C,Fo+To), bnpart (B,C,2) or None)."""
+    B, C, Fo, To = z.shape
+    dv = torch.empty_like(z)
+    buf = torch.empty((B * C * (4 + Fo + To + (2 if want_bn else 0)),), device=z.device, dtype=torch.float32)
+    dcoef = buf[:B * C * 4].view(B, C, 4)
+    dsg = buf[B * C * 4:B * C * (4 + Fo + To)].view(B, C, Fo + To)
+    bnpart = buf[B * C * (4 + Fo + To):].view(B, C, 2) if want_bn else None
+    _lib.call("eat_dyrelu_ca_bwd2", _dev(dout, "dout"), _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"),
+              _dev(sg, "sg"), dv.data_ptr(), dcoef.data_ptr(), dsg.data_ptr(), None if bnpart is None else bnpart.data_ptr(),
+              B, C, Fo, To, _stream())
+    return dv, dcoef, dsg, bnpart
+
+
+def bn_bwd_combine_partials(p0, p1, stride_e, B, C, inner, mean, invstd):
+    """Channel sums of a BatchNorm backward from per-plane partials -> (sums (2C,) float64, dgamma, dbeta)."""
+    sums = torch.empty((2 * C,), device=mean.device, dtype=torch.float64)
+    vec = torch.empty((2, C), device=mean.device, dtype=torch.float32)
+    _lib.call("eat_bn_bwd_combine_partials", p0.data_ptr(), p1.data_ptr(), stride_e, B, C, inner, mean.data_ptr(),
+              invstd.data_ptr(), sums.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), _stream())
+    return sums, vec[0], vec[1]
+
+
+def dw_conv_dyn_bwd_bn_g(dy, z, st, bn_act, sums, w_bc, x, in_a, in_b, in_act, k, stride, res=None, want_sums=True):
+    """Merged backward of a dynamic depthwise conv with its own BatchNorm backward on load (`dw_conv_bwd_bn_g` with
+    per-plane taps): -> (g, dw_bc (B, C*k*k), (gpart, gzpart, inner) or None)."""
+    B, C, F, T = x.shape
+    Fo, To = z.shape[2], z.shape[3]
+    cap = int(_lib.lib().eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
+    g = torch.empty((B, C, F, T), device=z.device, dtype=torch.float32)
+    parts = torch.empty((2, B * C * cap), device=z.device, dtype=torch.float32) if want_sums else None
+    dw = zero_arena.zeros((B, C * k * k), torch.float32, z.device)
+    inner = _ct.c_int(0)
+    frozen = 1 if getattr(st[2], "_eat_frozen", False) else 0
+    _lib.call("eat_dw_conv_dyn_bwd_bn_g", _dev(dy, "dy"), _dev(z, "z"), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
+              st[3].data_ptr(), sums.data_ptr(), bn_act, frozen, _dev(x, "x"), in_a.data_ptr(), in_b.data_ptr(), in_act,
+              _dev(w_bc, "w_bc"), _opt(res, "res"), g.data_ptr(), dw.data_ptr(),
+              None if parts is None else parts[0].data_ptr(), None if parts is None else parts[1].data_ptr(), cap,
+              _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
+    return g, dw, ((parts[0], parts[1], inner.value) if want_sums else None)
+
+
+def bn_bwd_apply(g, z, a, b, mean, invstd, sums, inplace=True):
+    """dz = a (g - m1 - xhat m2) from the channel sums (g already carries the activation derivative); frozen statistics:
+    dz = a g.  In place by default."""
+    B, C = z.shape[0], z.shape[1]
+    S = z.numel() // (B * C)
+    dz = g if inplace else torch.empty_like(g)
+    asums = torch.zeros_like(sums) if getattr(mean, "_eat_frozen", False) else sums
+    _lib.call("eat_bn_act_bwd_apply", _dev(g, "g"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+              invstd.data_ptr(), None, None, asums.data_ptr(), dz.data_ptr(), B, C, S, ACT_NONE, _stream())
+    return dz
 
 
 def fused_expand_dw(x, wp_e, bias_e, w_d, bias_d, Cexp, k, stride, act, pool=None):

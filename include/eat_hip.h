@@ -350,10 +350,28 @@ int eat_dyn_aggregate(const float* bank, const float* att, const float* gscale, 
 int eat_dyn_pw_pack(const float* bank, const float* att, const float* row_scale, float* wp, int B,
                     int K, int Co, int Ci, eat_stream_t stream);
 
+/* The same aggregation (models/dymn/dy_block.py:111-119) as split bf16 hi / lo MFMA fragments - eat_pw_prepack_bf16's
+ * layout with split = 1, one pack of ceil(Ci/32)*ceil(Co/16)*2*512 bf16 per sample (input of eat_pw_conv_dyn_bf16_fwd). */
+int eat_dyn_pw_pack_bf16(const float* bank, const float* att, void* wp, int B, int K, int Co, int Ci,
+                         eat_stream_t stream);
+
+/* Both packs from the bank of the TRANSPOSED matrices (bank_t (K, Ci*Co): W_k^T row-major = the parameter of the conv whose
+ * data gradient is being formed, models/dymn/dy_block.py:111-127 backward): sum_k att[b,k] W_k (Co x Ci) without a
+ * transposed copy of the bank.  Co % 4 == 0. */
+int eat_dyn_pw_pack_t(const float* bank_t, const float* att, const float* row_scale, float* wp, int B, int K, int Co,
+                      int Ci, eat_stream_t stream);
+int eat_dyn_pw_pack_bf16_t(const float* bank_t, const float* att, void* wp, int B, int K, int Co, int Ci,
+                           eat_stream_t stream);
+
 /* 1x1 conv with per-sample weights (dy_block.py:120-127 for kernel_size 1): like eat_pw_conv_fwd
  * but sample b multiplies by wp_b[b]. */
 int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, const float* res,
                         float* y, int B, int Ci, int Co, int S, int act, eat_stream_t stream);
+
+/* ... and on split bf16 operands (bf16x3, fp32-class accuracy at a multiple of the fp32 MFMA rate; the grouped
+ * F.conv2d of models/dymn/dy_block.py:120-127 for kernel_size 1): wp_b from eat_dyn_pw_pack_bf16.  Ci % 4 == 0, S % 4 == 0. */
+int eat_pw_conv_dyn_bf16_fwd(const float* x, const void* wp_b, const float* bias, const float* res, float* y,
+                             int B, int Ci, int Co, int S, int act, eat_stream_t stream);
 
 /* Depthwise conv with per-(b,c) taps w_bc (B,C,k*k) + bias (C), followed in the epilogue by
  * DyReLU-B max(a1 v + b1, a2 v + b2) with coef (B,C,4) = (a1,a2,b1,b2) (dy_block.py:172-188) and
@@ -388,6 +406,27 @@ int eat_dyrelu_ca_bwd(const float* dout, const float* z, const float* a, const f
                       const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
                       float* dgate_t, int B, int C, int Fo, int To, eat_stream_t stream);
 
+/* Round 4 forms of the same pair (models/dymn/dy_block.py:172-188, :195-201; order inside DY_Block.forward :399-403) for
+ * the training step.  eat_gate_table: sg (B, C, Fo+To) = sigmoid of the gates, channel-major (a plane's gate row is one
+ * contiguous run; the position-major gates cost a strided gather per plane).  eat_dyrelu_ca_fwd2 / _bwd2: one wave per
+ * plane, To <= 512; the backward returns dv, dcoef, dsg (gradient w.r.t. the SIGMOIDS, (B, C, Fo+To)) and, when bnpart
+ * (B, C, 2) != NULL, the per-plane sums (sum dv, sum dv * z) of the BatchNorm backward of depth_norm (:345-348).
+ * eat_gate_table_bwd: dsg, sg -> the pre-sigmoid gate gradients in the position-major layout of gate_f / gate_t. */
+int eat_gate_table(const float* gate_f, const float* gate_t, float* sg, int B, int C, int Fo, int To, eat_stream_t stream);
+int eat_gate_table_bwd(const float* dsg, const float* sg, float* dgate_f, float* dgate_t, int B, int C, int Fo, int To,
+                       eat_stream_t stream);
+int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b, const float* coef, const float* sg, float* out,
+                       int B, int C, int Fo, int To, eat_stream_t stream);
+int eat_dyrelu_ca_bwd2(const float* dout, const float* z, const float* a, const float* b, const float* coef,
+                       const float* sg, float* dv, float* dcoef, float* dsg, float* bnpart, int B, int C, int Fo, int To,
+                       eat_stream_t stream);
+/* Channel sums of a train-mode BatchNorm backward (nn.BatchNorm2d autograd, models/dymn/dy_block.py:313-316,345-348) from
+ * per-plane partial sums: sums[c] = sum p0, sums[C+c] = invstd[c] (sum p1 - mean[c] sum p0) in fp64 (the layout
+ * eat_bn_act_bwd_apply / eat_dw_conv_dyn_bwd_bn_g read), dbeta = sums[0..C), dgamma = sums[C..2C) in fp32.  Element
+ * (b, c, i) of a partial array lies stride_e * ((b*C + c)*inner + i) floats after its base pointer. */
+int eat_bn_bwd_combine_partials(const float* p0, const float* p1, int stride_e, int B, int C, int inner, const float* mean,
+                                const float* invstd, double* sums, float* dgamma, float* dbeta, eat_stream_t stream);
+
 /* DyMN dynamic 1x1 conv without per-sample weights (models/dymn/dy_block.py:103-131, DynamicConv.forward with a 1x1
  * kernel): z_b = (sum_k att[b,k] W_k) x_b evaluated as ONE GEMM over the K-concatenated banks [W_0|...|W_{nbank-1}]
  * (wp = eat_pw_prepack_bf16 of the Co x (nbank*Ci) matrix, split form) with the attention as a per-(sample, k) scale of
@@ -407,10 +446,29 @@ int eat_dyn_bank_grad(const float* G, const float* att, const float* bank, float
  * (zeroed), dw_bc (B,C,k*k) (zeroed), and the depthwise data gradient with per-plane taps. */
 int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,
                           eat_stream_t stream);
+/* host helper for the call above (models/dymn/dy_block.py:120-127 backward): 1 where it ADDS into dW_b (zero-fill it),
+ * 0 where every element of dW_b is stored */
+int eat_pw_dyn_wgrad_accumulates(int Co, int Ci, int S);
 int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_bc, int B, int C, int F, int T,
                           int Fo, int To, int k, int stride, eat_stream_t stream);
 int eat_dw_conv_dyn_dgrad(const float* dz, const float* w_bc, const float* res, float* dx, int B, int C,
                           int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream);
+
+/* Train-mode dynamic depthwise conv (models/dymn/dy_block.py:103-131 with groups = channels, under model.train()):
+ * eat_dw_conv_fwd_stats with per-(b,c) taps w_bc (B, C, k*k) - the expand BatchNorm + activation (:313-318) evaluated on
+ * load, the partial sums of depth_norm's batch statistics (:345) in the epilogue. */
+int eat_dw_conv_dyn_fwd_stats(const float* x, const float* in_a, const float* in_b, int in_act, const float* w_bc, float* y,
+                              float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
+                              int stride, eat_stream_t stream);
+/* ... and its merged backward (autograd of :345-348 and :320-343 in one pass): eat_dw_conv_bwd_bn_g with per-plane taps.
+ * dy = gradient w.r.t. the BatchNorm output of this conv, z its pre-BN output, sums from eat_bn_bwd_combine_partials;
+ * g = dgrad * act_in'(in_a x + in_b) [+ res], dw_bc (B, C, k*k) zero-filled by the caller, gpart / gzpart: per-tile sums
+ * of g and g * x (before res is added), inner_cap >= eat_dw_bwd_partials_inner(...) slots per plane. */
+int eat_dw_conv_dyn_bwd_bn_g(const float* dy, const float* z, const float* bn_a, const float* bn_b, const float* bn_mean,
+                             const float* bn_invstd, const double* sums, int bn_act, int frozen, const float* x,
+                             const float* in_a, const float* in_b, int in_act, const float* w_bc, const float* res, float* g,
+                             float* dw_bc, float* gpart, float* gzpart, int inner_cap, int* h_inner, int B, int C, int F,
+                             int T, int Fo, int To, int k, int stride, eat_stream_t stream);
 
 /* ---- fused expand 1x1 + depthwise k x k (eval): models/mn/block_types.py:138-162 (+ :72-73) ------
  * y (B,Cexp,Fo,To) = act(dw_k,s( act(W_e x + bias_e) ) + bias_d) without materialising the expanded

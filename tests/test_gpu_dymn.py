@@ -126,6 +126,107 @@ def test_dyrelu_coordatt_backward():
         assert _rel(a.grad, b.grad) < 2e-5
 
 
+@pytest.mark.parametrize("B,C,Fo,To", [(3, 24, 8, 63), (3, 7, 4, 32), (2, 5, 16, 125), (2, 6, 32, 250), (1, 3, 64, 500), (2, 9, 5, 20)])
+def test_dyrelu_coordatt_wave_per_plane_forms(B, C, Fo, To):
+    """Round-4 forms (channel-major gate table, one wave per plane, BatchNorm affine on load, BatchNorm-backward sums in the
+    epilogue) against fp64 autograd of models/dymn/dy_block.py:172-201 applied to v = a z + b."""
+    z, coef = _rand(B, C, Fo, To, seed=1), _rand(B, C, 4, seed=2)
+    gf, gt, dout = _rand(B, Fo, C, seed=3), _rand(B, To, C, seed=4), _rand(B, C, Fo, To, seed=5)
+    a, b = _rand(C, seed=6).abs() + 0.5, _rand(C, seed=7)
+    zr, cr, gfr, gtr = (t.double().clone().requires_grad_(True) for t in (z, coef, gf, gt))
+    v = zr * a.double().view(1, C, 1, 1) + b.double().view(1, C, 1, 1)
+    v.retain_grad()
+    c = cr[:, :, None, None, :]
+    ref = torch.maximum(v * c[..., 0] + c[..., 2], v * c[..., 1] + c[..., 3])
+    ref = ref * torch.sigmoid(gfr.permute(0, 2, 1))[:, :, :, None] * torch.sigmoid(gtr.permute(0, 2, 1))[:, :, None, :]
+    ref.backward(dout.double())
+    zd, cd, gfd, gtd, ad, bd, dd = (t.to(DEV) for t in (z, coef, gf, gt, a, b, dout))
+    sg = ops.gate_table(gfd, gtd)
+    sg_ref = torch.cat([torch.sigmoid(gf), torch.sigmoid(gt)], 1).permute(0, 2, 1)
+    assert _rel(sg, sg_ref) < 2e-6
+    out = ops.dyrelu_ca_fwd2(zd, ad, bd, cd, sg)
+    assert _rel(out, ref) < 5e-6
+    dv, dcoef, dsg, bnpart = ops.dyrelu_ca_bwd2(dd, zd, ad, bd, cd, sg)
+    dgf, dgt = ops.gate_table_bwd(dsg, sg, Fo)
+    assert _rel(dv, v.grad) < 2e-5 and _rel(dcoef, cr.grad) < 2e-5
+    assert _rel(dgf, gfr.grad) < 2e-5 and _rel(dgt, gtr.grad) < 2e-5
+    assert _rel(bnpart[..., 0], v.grad.sum((2, 3))) < 2e-5
+    assert _rel(bnpart[..., 1], (v.grad * z.double()).sum((2, 3))) < 2e-5
+    # channel sums of the BatchNorm backward from the partials
+    mean, invstd = _rand(C, seed=8), _rand(C, seed=9).abs() + 0.5
+    sums, dgam, dbet = ops.bn_bwd_combine_partials(bnpart, bnpart.view(-1)[1:], 2, B, C, 1, mean.to(DEV), invstd.to(DEV))
+    xhat = (z.double() - mean.double().view(1, C, 1, 1)) * invstd.double().view(1, C, 1, 1)
+    assert _rel(sums[:C], v.grad.sum((0, 2, 3))) < 2e-5 and _rel(sums[C:], (v.grad * xhat).sum((0, 2, 3))) < 2e-5
+    assert _rel(dgam, (v.grad * xhat).sum((0, 2, 3))) < 2e-5 and _rel(dbet, v.grad.sum((0, 2, 3))) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,Fq,T,k,s,act", [(3, 8, 64, 500, 3, 1, 1), (2, 8, 64, 500, 3, 2, 1), (3, 12, 32, 250, 5, 2, 1),
+                                              (5, 20, 16, 125, 5, 1, 2), (3, 24, 16, 125, 3, 2, 2), (5, 20, 8, 63, 3, 1, 2),
+                                              (3, 16, 8, 63, 5, 2, 2), (7, 12, 4, 32, 5, 1, 2), (2, 6, 6, 40, 3, 1, 0)])
+def test_dynamic_depthwise_train_kernels(B, C, Fq, T, k, s, act):
+    """Round-4 train-mode passes of the dynamic depthwise conv (per-(b,c) taps): forward with the expand BatchNorm +
+    activation on load and depth_norm's statistics in the epilogue; merged backward with depth_norm's backward on load -
+    against fp64 autograd of  z_d = conv_bc(act(a_e z_e + b_e)),  v = BN_batch(z_d)  (dy_block.py:313-348)."""
+    KK = k * k
+    z_e, taps = _rand(B, C, Fq, T, seed=1), _rand(B, C * KK, seed=2, scale=0.3)
+    a_e, b_e = _rand(C, seed=3).abs() + 0.5, _rand(C, seed=4, scale=0.3)
+    gam, bet = _rand(C, seed=5).abs() + 0.5, _rand(C, seed=6)
+    actf = {0: lambda t: t, 1: torch.relu, 2: F.hardswish}[act]
+    zr, tr = z_e.double().clone().requires_grad_(True), taps.double().clone().requires_grad_(True)
+    u = zr * a_e.double().view(1, C, 1, 1) + b_e.double().view(1, C, 1, 1)
+    y = actf(u)
+    zd_ref = F.conv2d(y.reshape(1, B * C, Fq, T), tr.reshape(B * C, 1, k, k), None, s, (k - 1) // 2, 1, B * C)
+    zd_ref = zd_ref.reshape(B, C, *zd_ref.shape[2:])
+    Fo, To = zd_ref.shape[2], zd_ref.shape[3]
+    mu, var = zd_ref.mean((0, 2, 3)), zd_ref.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    v = (zd_ref - mu.view(1, C, 1, 1)) * (invstd * gam.double()).view(1, C, 1, 1) + bet.double().view(1, C, 1, 1)
+    dv = _rand(B, C, Fo, To, seed=7)
+    # keep the incoming gradient away from activation kinks of u (SURVEY 8c)
+    kink = torch.zeros_like(u, dtype=torch.bool)
+    for kp in ({1: [0.0], 2: [-3.0, 3.0]}.get(act, [])):
+        kink |= (u.detach() - kp).abs() < 1e-3
+    v.backward(dv.double())
+    # ---- forward
+    zd, parts = ops.dw_conv_dyn_stats(z_e.to(DEV), taps.to(DEV), k, s, tf=(a_e.to(DEV), b_e.to(DEV), act))
+    assert _rel(zd, zd_ref) < 5e-6
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(gam); bn.bias.copy_(bet)
+    st = ops.bn_state_from_partials(parts, bn, B * Fo * To)
+    assert _rel(st[2], mu) < 1e-5 and _rel(st[3], invstd.detach()) < 1e-5
+    # ---- backward: the channel sums as the DyReLU kernel would hand them over, then the merged kernel
+    vg = dv.double()
+    xhat = ((zd_ref - mu.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)).detach()
+    sums = torch.cat([vg.sum((0, 2, 3)), (vg * xhat).sum((0, 2, 3))]).to(DEV)
+    g, dw, p3 = ops.dw_conv_dyn_bwd_bn_g(dv.to(DEV), zd, st, ops.ACT_NONE, sums, taps.to(DEV), z_e.to(DEV), a_e.to(DEV),
+                                         b_e.to(DEV), act, k, s)
+    gu = (zr.grad / a_e.double().view(1, C, 1, 1)).masked_fill(kink, 0.0)            # gradient w.r.t. u
+    assert _rel(g.cpu().double().masked_fill(kink, 0.0), gu) < 3e-5
+    assert _rel(dw, tr.grad) < 3e-5
+    gp = p3[0][:B * C * p3[2]].view(B, C, p3[2]).sum(-1).cpu().double()
+    gz = p3[1][:B * C * p3[2]].view(B, C, p3[2]).sum(-1).cpu().double()
+    gfull = g.cpu().double()
+    assert _rel(gp, gfull.sum((2, 3))) < 1e-5 and _rel(gz, (gfull * z_e.double()).sum((2, 3))) < 1e-5
+    # no expand conv: identity transform, the skip connection's gradient added to g
+    if s == 1:
+        res = _rand(B, C, Fq, T, seed=8)
+        one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        zr2 = z_e.double().clone().requires_grad_(True)
+        zd2 = F.conv2d(zr2.reshape(1, B * C, Fq, T), taps.double().reshape(B * C, 1, k, k), None, s, (k - 1) // 2, 1, B * C)
+        zd2 = zd2.reshape(B, C, Fo, To)
+        mu2, var2 = zd2.mean((0, 2, 3)), zd2.var((0, 2, 3), unbiased=False)
+        v2 = (zd2 - mu2.view(1, C, 1, 1)) * (gam.double() / torch.sqrt(var2 + 1e-3)).view(1, C, 1, 1)
+        v2.backward(dv.double())
+        zd2g, parts2 = ops.dw_conv_dyn_stats(z_e.to(DEV), taps.to(DEV), k, s)
+        st2 = ops.bn_state_from_partials(parts2, bn, B * Fo * To)
+        xh2 = ((zd2 - mu2.view(1, C, 1, 1)) / torch.sqrt(var2 + 1e-3).view(1, C, 1, 1)).detach()
+        sums2 = torch.cat([vg.sum((0, 2, 3)), (vg * xh2).sum((0, 2, 3))]).to(DEV)
+        dx, _, _ = ops.dw_conv_dyn_bwd_bn_g(dv.to(DEV), zd2g, st2, ops.ACT_NONE, sums2, taps.to(DEV), z_e.to(DEV), one, zero,
+                                            ops.ACT_NONE, k, s, res=res.to(DEV), want_sums=False)
+        assert _rel(dx, zr2.grad + res.double()) < 3e-5
+
+
 # dw shapes: a generic one plus every geometry of the register-resident plane kernels (dw_plane.hip: forward, data and
 # per-plane weight gradient), with odd sample counts for the two-planes-per-wave forms
 @pytest.mark.parametrize("kind", ["pw", "dw", (7, 8, 63, 3, 1), (5, 16, 125, 5, 1), (6, 8, 63, 5, 2), (9, 16, 125, 3, 2),
@@ -157,7 +258,14 @@ def test_dynamic_conv_backward(kind):
     assert _rel(xd.grad, xr.grad) < 2e-5 and _rel(wd.grad, wr.grad) < 2e-5 and _rel(ad.grad, ar.grad) < 2e-5
 
 
-def test_dymn10_train_step_matches_oracle(golden_dir):
+@pytest.mark.parametrize("prec", ["fp32", "auto"])
+def test_dymn10_train_step_matches_oracle(golden_dir, prec):
+    """One training step of dymn10 against torch-CPU autograd over the oracle (and the reference's stored loss / logits).
+    'fp32': every GEMM on the exact fp32 MFMA - the arithmetic of the reference's CPU path; gradient bars = SURVEY 8c
+    (rel-L2 <= 1e-2 per tensor: activation-kink flips).  'auto' (the default of a training step, what bench.py times):
+    split bf16 operands from C_in = 40 on put ~1e-5 of relative noise on every such GEMM - about 100x the fp32
+    re-association noise, so about 100x as many pre-activations change side at a ReLU / Hardswish kink and the per-tensor
+    differences grow from ~1e-3 to ~1e-2 (same mechanism): 5e-2 per tensor, 2e-2 median."""
     g = np.load(os.path.join(golden_dir, "dymn10_ref.npz"))
     sd = synth.synth_state(synth.dymn_shapes(1.0), seed=0)
     for k in g.files:
@@ -179,6 +287,7 @@ def test_dymn10_train_step_matches_oracle(golden_dir):
         if hasattr(m, "temperature"):
             m.temperature = temp
     model.to(DEV).train()
+    model.train_precision = prec
     model._drop_mask_override = keep
     logits, emb = model(x.to(DEV))
     loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
@@ -194,20 +303,54 @@ def test_dymn10_train_step_matches_oracle(golden_dir):
             continue
         r = _rel(p.grad, ref)
         rels.append(r)
-        if r > 5e-2:
+        if r > (1e-2 if prec == "fp32" else 5e-2):
             bad.append((name, r))
+    print(f"dymn10 train step [{prec}]: gradient rel-L2 median {np.median(rels):.2e}, max {max(rels):.2e}")
     assert not bad, bad[:8]
-    assert float(np.median(rels)) < 1e-2
+    assert float(np.median(rels)) < (3e-3 if prec == "fp32" else 2e-2)
     msd = model.state_dict()
     for k, v in stats.items():
         assert _rel(msd[k], v) < 1e-4, k
 
 
+@pytest.mark.parametrize("B,Ci,Co,Fq,T,res", [(3, 48, 144, 8, 63, False), (5, 160, 96, 4, 32, True), (2, 40, 20, 16, 125, False),
+                                               (3, 224, 1344, 8, 63, False), (2, 44, 72, 3, 100, True)])
+def test_pw_conv_dyn_bf16x3(B, Ci, Co, Fq, T, res):
+    """Per-sample-weight 1x1 conv on split bf16 operands (eat_dyn_pw_pack_bf16 + eat_pw_conv_dyn_bf16_fwd) against an
+    fp64 evaluation of models/dymn/dy_block.py:111-127 and against the exact-fp32 per-sample kernel."""
+    K = 4
+    x, bank = _rand(B, Ci, Fq, T, seed=1), _rand(K, Co * Ci, seed=2, scale=Ci ** -0.5)
+    att = torch.softmax(_rand(B, K, seed=3), dim=-1)
+    r = _rand(B, Co, Fq, T, seed=4) if res else None
+    W = (att.double() @ bank.double()).view(B, Co, Ci)
+    ref = torch.einsum("boi,bis->bos", W, x.double().flatten(2)).view(B, Co, Fq, T)
+    if res:
+        ref = ref + r.double()
+    xd, bd, ad = x.to(DEV), bank.to(DEV), att.to(DEV)
+    zero = torch.zeros(Co, device=DEV)
+    rd = r.to(DEV) if res else None
+    got = ops.pw_conv_dyn_bf16(xd, ops.dyn_pw_pack_bf16(bd, ad, Co, Ci), zero, Co, ops.ACT_NONE, res=rd)
+    exact = ops.pw_conv_dyn(xd, ops.dyn_pw_pack(bd, ad, Co, Ci), zero, Co, ops.ACT_NONE, res=rd)
+    assert _rel(got, ref) < 3e-5
+    assert _rel(got, exact.cpu()) < 3e-5
+    # the packs from the bank of the transposed matrices (the data-gradient form: no transposed bank copy) are the same bits
+    if Co % 4 == 0:
+        bank_t = bank.view(K, Co, Ci).transpose(1, 2).contiguous().view(K, Ci * Co).to(DEV)
+        assert torch.equal(ops.dyn_pw_pack_bf16(bank_t, ad, Co, Ci, trans=True), ops.dyn_pw_pack_bf16(bd, ad, Co, Ci))
+        assert torch.equal(ops.dyn_pw_pack(bank_t, ad, Co, Ci, trans=True), ops.dyn_pw_pack(bd, ad, Co, Ci))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "auto"])
 @pytest.mark.parametrize("i,Fq,T", [(0, 64, 500), (1, 64, 500), (3, 32, 250), (5, 16, 125), (12, 8, 63), (13, 4, 32)])
-def test_dy_block_train_forward_backward(i, Fq, T):
+def test_dy_block_train_forward_backward(i, Fq, T, prec):
     """One DY_Block in train mode (stride 1 and 2, with/without expand, with/without residual): output,
-    input gradient and every parameter gradient vs torch-CPU autograd over the oracle block."""
-    from efficientat_amd.dymn_train import _block_train
+    input gradient and every parameter gradient vs torch-CPU autograd over the oracle block; in the exact fp32
+    arithmetic and in the default 'auto' arithmetic of a training step (bf16x3 from C_in = 40 on, K-concat late layers)."""
+    from efficientat_amd.dymn_train import _block_train as _bt
+
+    def _block_train(blk, x):
+        with ops.precision(prec):
+            return _bt(blk, x)
     sd = synth.synth_state(synth.dymn_shapes(1.0), seed=0)
     model = _quiet(get_model, width_mult=1.0)
     model.load_state_dict(sd)
@@ -230,7 +373,7 @@ def test_dy_block_train_forward_backward(i, Fq, T):
     xd = x.to(DEV).requires_grad_(True)
     out = _block_train(blk, xd)
     out.backward(dout.to(DEV))
-    assert _rel(out, out_ref) < 5e-6
+    assert _rel(out, out_ref) < (5e-6 if prec == "fp32" else 5e-5)
     # random inputs put a few pre-activations next to a ReLU/Hardswish kink: allow 1 % there
     assert _rel(xd.grad, xr.grad) < 1e-2
     gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-4 GPU call driver: gpurun --timeout 1200 -- 'bash tools/gpu_r4.sh <tag> <sections...>'
+set -u
+TAG=${1:-r4a}; shift || true
+WHAT="${*:-full}"
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+if has dymnprof; then
+  EAT_PROF_ALL=eat_ timeout 400 python tools/prof_dymn.py 128 2>&1 | grep -v amdgpu.ids > $OUT/prof_dymn.log; head -40 $OUT/prof_dymn.log
+fi
+if has dymnstats; then
+  (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats_dymn -o s --output-format csv -- \
+      python $GRAFT_REPO_ROOT/bench.py --train-model dymn20 --batch 128 --no-forward --no-profile --no-cpu-baseline --no-train-configs --steps 5 --warmup 2 > $GRAFT_REPO_ROOT/$OUT/rocprof_dymn.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof_dymn.log)
+  find $OUT/stats_dymn -name "*kernel_stats.csv" -exec cp {} $OUT/dymn20_rocprof_kernel_stats.csv \;
+  rm -rf $OUT/stats_dymn
+  head -45 $OUT/dymn20_rocprof_kernel_stats.csv; cat $OUT/rocprof_dymn.json
+fi
+if has unit; then
+  timeout 900 python -m pytest ${UNIT:-tests/test_gpu_train_fuse.py} -q -x --tb=short 2>&1 | grep -v "^  /usr\|Warning" | tail -60 > $OUT/unit.log; tail -40 $OUT/unit.log
+fi
+if has full; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" > $OUT/full.log; tail -40 $OUT/full.log
+fi
+if has ab; then
+  IFS=';' read -ra COMBOS <<< "${AB:-EAT_X=1}"
+  for combo in "${COMBOS[@]}"; do
+    env $combo timeout 400 python bench.py ${ABARGS:---no-cpu-baseline --no-forward --no-train-configs --no-profile --steps 10 --warmup 3} > $OUT/ab.json 2> $OUT/ab.err
+    python - <<P
+import json
+try:
+    d=json.load(open("$OUT/ab.json")); print("$combo ->", d["value"], "clips/s", d["ms_per_step"], "ms")
+except Exception as e:
+    print("$combo -> FAILED", e); print(open("$OUT/ab.err").read()[-3000:])
+P
+  done
+fi
+if has benchfull; then
+  timeout 1200 python bench.py --kernel-table > $OUT/bench.json 2> $OUT/bench_table.log
+  tail -c 6000 $OUT/bench.json; grep "^\[bench\]" $OUT/bench_table.log | tail -20
+fi
+if has prof; then
+  EAT_PROF_ALL=eat_ timeout 300 python tools/prof_train.py ${PROF_B:-256} > $OUT/prof_${MODEL:-mn10}.log 2>&1; head -40 $OUT/prof_${MODEL:-mn10}.log
+fi
+if has rocprof; then
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats -o s --output-format csv -- \
+      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.log)
+  find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats.csv \;
+  rm -rf $OUT/stats
+  head -30 $OUT/rocprof_kernel_stats.csv
+fi
+if has script; then
+  timeout ${SCRIPT_TIMEOUT:-600} bash -c "$SCRIPT" > $OUT/script.log 2>&1; tail -60 $OUT/script.log
+fi
