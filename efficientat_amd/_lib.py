@@ -95,10 +95,12 @@ SIGNATURES = {
     "eat_pw_dyn_wgrad_accumulates": [_I, _I, _I],
     "eat_dyn_pw_pack_t": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dyn_pw_pack_bf16_t": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "eat_gate_table": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "eat_gate_table_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "eat_dyrelu_ca_fwd2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "eat_dyrelu_ca_bwd2": [_P] * 10 + [_I, _I, _I, _I, _P],
+    "eat_ctx_pool_cm": [_P, _P, _I, _I, _I, _I, _P],
+    "eat_ctx_pool_cm_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_ctx_split": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eat_ctx_split_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eat_dyrelu_ca_fwd2": [_P] * 7 + [_I, _I, _I, _I, _P],
+    "eat_dyrelu_ca_bwd2": [_P] * 12 + [_I, _I, _I, _I, _P],
     "eat_bn_bwd_combine_partials": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "eat_dw_conv_dyn_fwd_stats": [_P, _P, _P, _I, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_dw_conv_dyn_bwd_bn_g": [_P] * 7 + [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],

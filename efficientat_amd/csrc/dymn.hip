@@ -14,13 +14,16 @@
 namespace {
 
 // one block per (b,c) plane; wave w takes rows w, w+4, ...
+// cm != 0 (round 4): channel-major sequence seq[c][b][l] (a 1x1 conv input of ONE sample with B * (F + T) positions: the
+// context generator then runs on the conv / BatchNorm kernels of the feature maps, no transposed copies anywhere)
 __global__ __launch_bounds__(256) void ctx_pool_kernel(const float* __restrict__ x, float* __restrict__ seq,
-                                                       int C, int F, int T) {
+                                                       int C, int F, int T, int cm, int B) {
   extern __shared__ float s_col[];                       // [4][T]
   const int plane = blockIdx.x, b = plane / C, c = plane % C;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* xp = x + (size_t)plane * F * T;
-  float* out = seq + (size_t)b * (F + T) * C + c;
+  float* out = cm ? seq + ((size_t)c * B + b) * (F + T) : seq + (size_t)b * (F + T) * C + c;
+  const size_t ls = cm ? 1 : (size_t)C;
   float* mycol = s_col + wv * T;
   for (int t = lane; t < T; t += 64) mycol[t] = 0.0f;
   for (int f = wv; f < F; f += 4) {
@@ -31,11 +34,11 @@ __global__ __launch_bounds__(256) void ctx_pool_kernel(const float* __restrict__
       mycol[t] += v;                                       // lane-private slot: no race
     }
     rs = eat::wave_sum(rs);
-    if (lane == 0) out[(size_t)f * C] = rs / (float)T;
+    if (lane == 0) out[(size_t)f * ls] = rs / (float)T;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += 256)
-    out[(size_t)(F + t) * C] = (s_col[t] + s_col[T + t] + s_col[2 * T + t] + s_col[3 * T + t]) / (float)F;
+    out[(size_t)(F + t) * ls] = (s_col[t] + s_col[T + t] + s_col[2 * T + t] + s_col[3 * T + t]) / (float)F;
 }
 
 // out[b, n] = gscale[n / group] * sum_k att[b,k] * bank[k, n]
@@ -183,11 +186,12 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_bf16_kernel(const float* __re
 
 // backward of ctx_pool: dx[b,c,f,t] = dseq[b,f,c]/T + dseq[b,F+t,c]/F  (+ add[b,c,f,t])
 __global__ __launch_bounds__(256) void ctx_pool_bwd_kernel(const float* __restrict__ dseq, const float* __restrict__ add,
-                                                           float* __restrict__ dx, int C, int F, int T) {
+                                                           float* __restrict__ dx, int C, int F, int T, int cm, int B) {
   extern __shared__ float s_g[];                         // [F + T]
   const int plane = blockIdx.x, b = plane / C, c = plane % C;
-  const float* g = dseq + (size_t)b * (F + T) * C + c;
-  for (int i = threadIdx.x; i < F + T; i += 256) s_g[i] = g[(size_t)i * C] / (float)(i < F ? T : F);
+  const float* g = cm ? dseq + ((size_t)c * B + b) * (F + T) : dseq + (size_t)b * (F + T) * C + c;
+  const size_t ls = cm ? 1 : (size_t)C;
+  for (int i = threadIdx.x; i < F + T; i += 256) s_g[i] = g[(size_t)i * ls] / (float)(i < F ? T : F);
   __syncthreads();
   const size_t base = (size_t)plane * F * T;
   for (int e = threadIdx.x; e < F * T; e += 256) {
@@ -400,69 +404,64 @@ __global__ __launch_bounds__(256) void dyn_bank_grad_fused_kernel(const float* _
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 4: DyReLU-B * CoordAtt of the training step, second form.  The kernels above take the gates position-major
-// ((B, L, C): every plane gathers its Fo + To gate values with stride C - on the 4 x 32 planes of the last stage the 36
-// gathered cache lines outweigh the plane's own 512 bytes, 1 TB/s) and give one 256-thread block to every plane.  Here
-//   * the sigmoids of the gates are laid out channel-major once per block by gate_table_kernel: sg (B, C, Fo + To) - a
-//     plane's gate row is one contiguous run;
-//   * a wave owns a whole plane (two planes of consecutive channels' ... of the same sample for <= 32 columns): lane l holds
-//     columns l, l + LPP, ... of every row - coalesced row segments, the column sums of the backward stay in registers,
-//     row sums / coefficient sums / BatchNorm sums are lane-group reductions;
+// Round 4: the context generator and DyReLU-B * CoordAtt of the training step, second form.  The kernels above keep the
+// context sequence position-major ((B, L, C): every plane of the DyReLU kernels gathers its Fo + To gate values with
+// stride C - on the 4 x 32 planes of the last stage the 36 gathered cache lines outweigh the plane's own 512 bytes, 1 TB/s
+// - and every Linear backward of the context path needs transposed copies of its operands) and give one 256-thread block
+// to every plane.  Here
+//   * the context sequence is channel-major with the batch folded into the position axis, seq (C, B, F + T): joint_conv /
+//     conv_f / conv_t are 1x1 convs of ONE sample of B * L positions (B * L is a multiple of 4 whenever B is: no padding)
+//     on the MFMA conv kernels, joint_norm is the BatchNorm of the feature maps, their backward the conv backward - no
+//     transposed copy anywhere; the gates come out as (C, B, Fo) / (C, B, To): a plane's gate row is one contiguous run;
+//   * a wave owns a whole plane (two planes for <= 32 columns): lane l holds columns l, l + LPP, ... of every row -
+//     coalesced row segments, the column sums of the backward stay in registers, row sums / coefficient sums /
+//     BatchNorm sums are lane-group reductions; the sigmoids are evaluated on load, their derivative on store;
 //   * the backward also emits the two per-plane sums the BatchNorm backward of depth_norm needs (sum dv, sum dv * z): its
 //     reduce pass over (dv, z) disappears (dyn_bn_bwd_combine_kernel turns them into the fp64 channel sums).
 // Reference: models/dymn/dy_block.py:172-188 (DyReLU-B), :195-201 (CoordAtt), :399-403 (order inside DY_Block).
 
-// sg[b][c][l] = sigmoid(l < Fo ? gf[b][l][c] : gt[b][l - Fo][c]); 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void gate_table_kernel(const float* __restrict__ gf, const float* __restrict__ gt,
-                                                         float* __restrict__ sg, int C, int Fo, int To) {
-  __shared__ float s_t[32][33];
-  const int L = Fo + To;
-  const int b = blockIdx.z, c0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int l = l0 + ty + 8 * i, c = c0 + tx;
-    float v = 0.0f;
-    if (l < L && c < C) v = l < Fo ? gf[((size_t)b * Fo + l) * C + c] : gt[((size_t)b * To + (l - Fo)) * C + c];
-    s_t[ty + 8 * i][tx] = 1.0f / (1.0f + expf(-v));
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, l = l0 + tx;
-    if (c < C && l < L) sg[((size_t)b * C + c) * L + l] = s_t[tx][ty + 8 * i];
-  }
+// ctx_split: the context sequence after joint_norm + Hardswish, g (H, B, L = F + T) channel-major, is cut into the inputs
+// of conv_f / conv_t (models/dymn/dy_block.py:240-252): h_cf (H, B, Fo) = [AvgPool(3, stride, pad 1) of] g[.., :F],
+// h_ct (H, B, To) likewise of g[.., F:], and h_c (B, H) = mean over L (:244).  One wave per (h, b) row.
+__device__ __forceinline__ float pool3_at(const float* __restrict__ r, int i, int n, int stride) {
+  if (stride == 1) return r[i];
+  const int j = 2 * i;
+  return ((j - 1 >= 0 ? r[j - 1] : 0.0f) + r[j] + (j + 1 < n ? r[j + 1] : 0.0f)) * (1.0f / 3.0f);
+}
+__global__ __launch_bounds__(256) void ctx_split_kernel(const float* __restrict__ g, float* __restrict__ hcf,
+                                                        float* __restrict__ hct, float* __restrict__ hc, int H, int B, int F,
+                                                        int T, int Fo, int To, int stride) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= H * B) return;
+  const int h = row / B, b = row - h * B;
+  const float* r = g + (size_t)row * (F + T);
+  float s = 0.0f;
+  for (int l = lane; l < F + T; l += 64) s += r[l];
+  s = eat::wave_sum(s);
+  if (lane == 0) hc[(size_t)b * H + h] = s / (float)(F + T);
+  for (int i = lane; i < Fo; i += 64) hcf[(size_t)row * Fo + i] = pool3_at(r, i, F, stride);
+  for (int i = lane; i < To; i += 64) hct[(size_t)row * To + i] = pool3_at(r + F, i, T, stride);
+}
+// backward: dg[h][b][l] = dhc[b][h] / L + pool^T(dhcf)[l] (l < F) or pool^T(dhct)[l - F]
+__device__ __forceinline__ float pool3_t_at(const float* __restrict__ d, int j, int no, int stride) {
+  if (stride == 1) return d[j];
+  if ((j & 1) == 0) return (j >> 1) < no ? d[j >> 1] * (1.0f / 3.0f) : 0.0f;
+  const int i0 = (j - 1) >> 1, i1 = (j + 1) >> 1;
+  return ((i0 < no ? d[i0] : 0.0f) + (i1 < no ? d[i1] : 0.0f)) * (1.0f / 3.0f);
+}
+__global__ __launch_bounds__(256) void ctx_split_bwd_kernel(const float* __restrict__ dhcf, const float* __restrict__ dhct,
+                                                            const float* __restrict__ dhc, float* __restrict__ dg, int H, int B,
+                                                            int F, int T, int Fo, int To, int stride) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= H * B) return;
+  const int h = row / B, b = row - h * B;
+  const float m = dhc ? dhc[(size_t)b * H + h] / (float)(F + T) : 0.0f;
+  float* o = dg + (size_t)row * (F + T);
+  for (int j = lane; j < F; j += 64) o[j] = m + pool3_t_at(dhcf + (size_t)row * Fo, j, Fo, stride);
+  for (int j = lane; j < T; j += 64) o[F + j] = m + pool3_t_at(dhct + (size_t)row * To, j, To, stride);
 }
 
-// dgf[b][l][c] / dgt[b][l - Fo][c] = dsg[b][c][l] * s (1 - s), s = sg[b][c][l]  (gradient w.r.t. the PRE-sigmoid gates)
-__global__ __launch_bounds__(256) void gate_table_bwd_kernel(const float* __restrict__ dsg, const float* __restrict__ sg,
-                                                             float* __restrict__ dgf, float* __restrict__ dgt, int C, int Fo,
-                                                             int To) {
-  __shared__ float s_t[32][33];
-  const int L = Fo + To;
-  const int b = blockIdx.z, c0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, l = l0 + tx;
-    float v = 0.0f;
-    if (c < C && l < L) {
-      const size_t e = ((size_t)b * C + c) * L + l;
-      const float sv = sg[e];
-      v = dsg[e] * sv * (1.0f - sv);
-    }
-    s_t[ty + 8 * i][tx] = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int l = l0 + ty + 8 * i, c = c0 + tx;
-    if (l < L && c < C) {
-      const float v = s_t[tx][ty + 8 * i];
-      if (l < Fo) dgf[((size_t)b * Fo + l) * C + c] = v; else dgt[((size_t)b * To + (l - Fo)) * C + c] = v;
-    }
-  }
-}
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 template <int LPP>
 __device__ __forceinline__ float group_sum(float v) {
@@ -475,8 +474,8 @@ __device__ __forceinline__ float group_sum(float v) {
 template <int LPP, int NC>
 __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __restrict__ z, const float* __restrict__ a,
                                                              const float* __restrict__ b, const float* __restrict__ coef,
-                                                             const float* __restrict__ sg, float* __restrict__ out,
-                                                             int n_planes, int C, int Fo, int To) {
+                                                             const float* __restrict__ gf, const float* __restrict__ gt,
+                                                             float* __restrict__ out, int n_planes, int C, int Fo, int To) {
   constexpr int NPW = 64 / LPP;
   const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -486,7 +485,10 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
   const int c = plane % C;
   const float av = a ? a[c] : 1.0f, bv = a ? b[c] : 0.0f;
   const float4 cf = *reinterpret_cast<const float4*>(coef + (size_t)plane * 4);
-  const float* sgp = sg + (size_t)plane * (Fo + To);
+  const int Bn = n_planes / C;
+  const size_t grow = (size_t)c * Bn + plane / C;                  // gate row of plane (b, c) in the (C, B, .) tables
+  const float* gfp = gf + grow * Fo;
+  const float* gtp = gt + grow * To;
   const float* zp = z + (size_t)plane * Fo * To;
   float* op = out + (size_t)plane * Fo * To;
   float at[NC];
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
   for (int j = 0; j < NC; ++j) {
     const int t = l + LPP * j;
     ok[j] = mine && t < To;
-    at[j] = sgp[Fo + (t < To ? t : 0)];
+    at[j] = sigm(gtp[t < To ? t : 0]);
   }
   constexpr int RU = NC >= 4 ? 2 : 4;                              // rows in flight
   for (int f0 = 0; f0 < Fo; f0 += RU) {
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       const int f = f0 + r < Fo ? f0 + r : Fo - 1;
-      af[r] = sgp[f];
+      af[r] = sigm(gfp[f]);
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int t = l + LPP * j;
@@ -526,9 +528,10 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
 template <int LPP, int NC>
 __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                              const float* __restrict__ a, const float* __restrict__ b,
-                                                             const float* __restrict__ coef, const float* __restrict__ sg,
-                                                             float* __restrict__ dv, float* __restrict__ dcoef,
-                                                             float* __restrict__ dsg, float* __restrict__ bnpart,
+                                                             const float* __restrict__ coef, const float* __restrict__ gf,
+                                                             const float* __restrict__ gt, float* __restrict__ dv,
+                                                             float* __restrict__ dcoef, float* __restrict__ dgf,
+                                                             float* __restrict__ dgt, float* __restrict__ bnpart,
                                                              int n_planes, int C, int Fo, int To) {
   constexpr int NPW = 64 / LPP;
   const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
@@ -539,9 +542,12 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __rest
   const int c = plane % C;
   const float av = a ? a[c] : 1.0f, bv = a ? b[c] : 0.0f;
   const float4 cf = *reinterpret_cast<const float4*>(coef + (size_t)plane * 4);
-  const int L = Fo + To;
-  const float* sgp = sg + (size_t)plane * L;
-  float* dsgp = dsg + (size_t)plane * L;
+  const int Bn = n_planes / C;
+  const size_t grow = (size_t)c * Bn + plane / C;
+  const float* gfp = gf + grow * Fo;
+  const float* gtp = gt + grow * To;
+  float* dgfp = dgf + grow * Fo;
+  float* dgtp = dgt + grow * To;
   const size_t base = (size_t)plane * Fo * To;
   float at[NC], cs[NC];
   bool ok[NC];
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __rest
   for (int j = 0; j < NC; ++j) {
     const int t = l + LPP * j;
     ok[j] = t < To;
-    at[j] = sgp[Fo + (t < To ? t : 0)];
+    at[j] = sigm(gtp[t < To ? t : 0]);
     cs[j] = 0.0f;
   }
   float da1 = 0.f, da2 = 0.f, db1 = 0.f, db2 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       const int f = f0 + r < Fo ? f0 + r : Fo - 1;
-      af[r] = sgp[f];
+      af[r] = sigm(gfp[f]);
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int t = l + LPP * j;
@@ -593,12 +599,12 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __rest
         cs[j] = fmaf(dmm, af[r], cs[j]);
       }
       rs = group_sum<LPP>(rs);
-      if (l == 0 && mine) dsgp[f0 + r] = rs;
+      if (l == 0 && mine) dgfp[f0 + r] = rs * af[r] * (1.0f - af[r]);       // gradient w.r.t. the PRE-sigmoid gate
     }
   }
   if (mine) {
 #pragma unroll
-    for (int j = 0; j < NC; ++j) if (ok[j]) dsgp[Fo + l + LPP * j] = cs[j];
+    for (int j = 0; j < NC; ++j) if (ok[j]) dgtp[l + LPP * j] = cs[j] * at[j] * (1.0f - at[j]);
   }
   da1 = group_sum<LPP>(da1); da2 = group_sum<LPP>(da2); db1 = group_sum<LPP>(db1); db2 = group_sum<LPP>(db2);
   s1 = group_sum<LPP>(s1); s2 = group_sum<LPP>(s2);
@@ -647,8 +653,17 @@ extern "C" int eat_ctx_pool(const float* x, float* seq, int B, int C, int F, int
   eat::clear_stale_error();
   const size_t smem = (size_t)4 * T * sizeof(float);
   if (smem > 64 * 1024) return eat::fail(EAT_EINVAL, "eat_ctx_pool: T=%d too wide", T);
-  hipLaunchKernelGGL(ctx_pool_kernel, dim3(B * C), dim3(256), smem, (hipStream_t)stream, x, seq, C, F, T);
+  hipLaunchKernelGGL(ctx_pool_kernel, dim3(B * C), dim3(256), smem, (hipStream_t)stream, x, seq, C, F, T, 0, B);
   return eat::check_launch("eat_ctx_pool");
+}
+
+// channel-major form: seq (C, B, F+T) (see the kernel)
+extern "C" int eat_ctx_pool_cm(const float* x, float* seq, int B, int C, int F, int T, eat_stream_t stream) {
+  eat::clear_stale_error();
+  const size_t smem = (size_t)4 * T * sizeof(float);
+  if (smem > 64 * 1024) return eat::fail(EAT_EINVAL, "eat_ctx_pool_cm: T=%d too wide", T);
+  hipLaunchKernelGGL(ctx_pool_kernel, dim3(B * C), dim3(256), smem, (hipStream_t)stream, x, seq, C, F, T, 1, B);
+  return eat::check_launch("eat_ctx_pool_cm");
 }
 
 extern "C" int eat_dyn_aggregate(const float* bank, const float* att, const float* gscale, float* out, int B, int K,
@@ -711,8 +726,16 @@ extern "C" int eat_ctx_pool_bwd(const float* dseq, const float* add, float* dx, 
                                 eat_stream_t stream) {
   eat::clear_stale_error();
   hipLaunchKernelGGL(ctx_pool_bwd_kernel, dim3(B * C), dim3(256), (size_t)(F + T) * sizeof(float), (hipStream_t)stream,
-                     dseq, add, dx, C, F, T);
+                     dseq, add, dx, C, F, T, 0, B);
   return eat::check_launch("eat_ctx_pool_bwd");
+}
+
+extern "C" int eat_ctx_pool_cm_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T,
+                                   eat_stream_t stream) {
+  eat::clear_stale_error();
+  hipLaunchKernelGGL(ctx_pool_bwd_kernel, dim3(B * C), dim3(256), (size_t)(F + T) * sizeof(float), (hipStream_t)stream,
+                     dseq, add, dx, C, F, T, 1, B);
+  return eat::check_launch("eat_ctx_pool_cm_bwd");
 }
 
 extern "C" int eat_dyrelu_ca_fwd(const float* z, const float* a, const float* b, const float* coef, const float* gate_f,
@@ -767,22 +790,24 @@ extern "C" int eat_dyn_bank_grad(const float* G, const float* att, const float* 
 }
 
 // ---- round 4: channel-major gate table + one-wave-per-plane DyReLU-B * CoordAtt (see the kernels)
-extern "C" int eat_gate_table(const float* gate_f, const float* gate_t, float* sg, int B, int C, int Fo, int To,
-                              eat_stream_t stream) {
+extern "C" int eat_ctx_split(const float* g, float* hcf, float* hct, float* hc, int H, int B, int F, int T, int stride,
+                             eat_stream_t stream) {
   eat::clear_stale_error();
-  if (B < 1 || C < 1 || Fo < 1 || To < 1 || B > 65535) return eat::fail(EAT_EINVAL, "eat_gate_table: bad shape");
-  hipLaunchKernelGGL(gate_table_kernel, dim3((C + 31) / 32, (Fo + To + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, gate_f,
-                     gate_t, sg, C, Fo, To);
-  return eat::check_launch("eat_gate_table");
+  if (stride != 1 && stride != 2) return eat::fail(EAT_EINVAL, "eat_ctx_split: stride %d", stride);
+  const int Fo = (F - 1) / stride + 1, To = (T - 1) / stride + 1;
+  hipLaunchKernelGGL(ctx_split_kernel, dim3((H * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, g, hcf, hct, hc, H, B, F, T, Fo,
+                     To, stride);
+  return eat::check_launch("eat_ctx_split");
 }
 
-extern "C" int eat_gate_table_bwd(const float* dsg, const float* sg, float* dgate_f, float* dgate_t, int B, int C, int Fo,
-                                  int To, eat_stream_t stream) {
+extern "C" int eat_ctx_split_bwd(const float* dhcf, const float* dhct, const float* dhc, float* dg, int H, int B, int F, int T,
+                                 int stride, eat_stream_t stream) {
   eat::clear_stale_error();
-  if (B < 1 || C < 1 || Fo < 1 || To < 1 || B > 65535) return eat::fail(EAT_EINVAL, "eat_gate_table_bwd: bad shape");
-  hipLaunchKernelGGL(gate_table_bwd_kernel, dim3((C + 31) / 32, (Fo + To + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dsg,
-                     sg, dgate_f, dgate_t, C, Fo, To);
-  return eat::check_launch("eat_gate_table_bwd");
+  if (stride != 1 && stride != 2) return eat::fail(EAT_EINVAL, "eat_ctx_split_bwd: stride %d", stride);
+  const int Fo = (F - 1) / stride + 1, To = (T - 1) / stride + 1;
+  hipLaunchKernelGGL(ctx_split_bwd_kernel, dim3((H * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dhcf, dhct, dhc, dg, H, B,
+                     F, T, Fo, To, stride);
+  return eat::check_launch("eat_ctx_split_bwd");
 }
 
 #define EAT_DYRELU2_DISPATCH(KERNEL, ...)                                                                             \
@@ -799,27 +824,28 @@ extern "C" int eat_gate_table_bwd(const float* dsg, const float* sg, float* dgat
     }                                                                                                                 \
   } while (0)
 
-// out = max(a1 v + b1, a2 v + b2) * sg[b,c,f] * sg[b,c,Fo+t], v = a_c z + b_c (a, b NULL: v = z); sg from eat_gate_table.
-extern "C" int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b, const float* coef, const float* sg,
-                                  float* out, int B, int C, int Fo, int To, eat_stream_t stream) {
+// out = max(a1 v + b1, a2 v + b2) * sigmoid(gate_f[c,b,f]) * sigmoid(gate_t[c,b,t]), v = a_c z + b_c (a, b NULL: v = z);
+// gates channel-major (C, B, Fo) / (C, B, To), pre-sigmoid: the outputs of conv_f / conv_t on the channel-major context
+extern "C" int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b, const float* coef, const float* gate_f,
+                                  const float* gate_t, float* out, int B, int C, int Fo, int To, eat_stream_t stream) {
   eat::clear_stale_error();
   if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2: bad shape (To <= 512)");
   if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2: a and b come together");
   hipStream_t hs = (hipStream_t)stream;
-  EAT_DYRELU2_DISPATCH(dyrelu_ca_fwd2_kernel, z, a, b, coef, sg, out, n_planes, C, Fo, To);
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_fwd2_kernel, z, a, b, coef, gate_f, gate_t, out, n_planes, C, Fo, To);
   return eat::check_launch("eat_dyrelu_ca_fwd2");
 }
 
-// backward: dv (w.r.t. v), dcoef (B,C,4), dsg (B,C,Fo+To) (w.r.t. the sigmoids: eat_gate_table_bwd finishes), bnpart
-// (B,C,2) = per-plane (sum dv, sum dv * z) or NULL
+// backward: dv (w.r.t. v), dcoef (B,C,4), dgate_f / dgate_t (pre-sigmoid, layouts of the gates), bnpart (B,C,2) = per-plane
+// (sum dv, sum dv * z) or NULL
 extern "C" int eat_dyrelu_ca_bwd2(const float* dout, const float* z, const float* a, const float* b, const float* coef,
-                                  const float* sg, float* dv, float* dcoef, float* dsg, float* bnpart, int B, int C, int Fo,
-                                  int To, eat_stream_t stream) {
+                                  const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
+                                  float* dgate_t, float* bnpart, int B, int C, int Fo, int To, eat_stream_t stream) {
   eat::clear_stale_error();
   if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2: bad shape (To <= 512)");
   if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2: a and b come together");
   hipStream_t hs = (hipStream_t)stream;
-  EAT_DYRELU2_DISPATCH(dyrelu_ca_bwd2_kernel, dout, z, a, b, coef, sg, dv, dcoef, dsg, bnpart, n_planes, C, Fo, To);
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_bwd2_kernel, dout, z, a, b, coef, gate_f, gate_t, dv, dcoef, dgate_f, dgate_t, bnpart, n_planes, C, Fo, To);
   return eat::check_launch("eat_dyrelu_ca_bwd2");
 }
 #undef EAT_DYRELU2_DISPATCH

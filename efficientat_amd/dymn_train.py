@@ -67,6 +67,40 @@ class CtxPool(torch.autograd.Function):
         return dx
 
 
+class CtxPoolCm(torch.autograd.Function):
+    """ContextGen's pools with the sequence channel-major, batch folded into the positions: -> (1, C, B*(F+T), 1)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return ops.ctx_pool_cm(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dseq):
+        return ops.ctx_pool_cm_bwd(dseq.contiguous(), ctx.shape)
+
+
+class CtxSplit(torch.autograd.Function):
+    """g (1, H, B*(F+T), 1) -> h_cf (1, H, B*Fo, 1), h_ct (1, H, B*To, 1) [AvgPool(3, stride, 1) for stride 2], h_c (B, H)."""
+
+    @staticmethod
+    def forward(ctx, g, B, F_, T, stride):
+        ctx.geo = (g.shape[1], B, F_, T, stride)
+        return ops.ctx_split(g.contiguous(), B, F_, T, stride)
+
+    @staticmethod
+    def backward(ctx, dhcf, dhct, dhc):
+        H, B, F_, T, stride = ctx.geo
+        Fo, To = (F_ - 1) // stride + 1, (T - 1) // stride + 1
+        if dhcf is None:
+            dhcf = torch.zeros((1, H, B * Fo, 1), device=dhc.device)
+        if dhct is None:
+            dhct = torch.zeros((1, H, B * To, 1), device=dhc.device)
+        dg = ops.ctx_split_bwd(dhcf.contiguous(), dhct.contiguous(), None if dhc is None else dhc.contiguous(), H, B, F_, T,
+                               stride)
+        return dg, None, None, None, None
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T + b on the MFMA linear kernel (activation applied by the caller through torch)."""
 
@@ -146,6 +180,28 @@ class PwConv(torch.autograd.Function):
         with _in_precision(ctx):
             dx = ops.pw_conv(dz, ops.pw_prepack(w.flatten(1), trans=True), _zeros.get(Ci, x.device), Ci, NONE)
             return dx, ops.pw_conv_wgrad(dz, x, exact=None).view_as(w)
+
+
+class PwConvB(torch.autograd.Function):
+    """Static 1x1 conv WITH bias (conv_f / conv_t of the context generator on the channel-major sequence)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.prec = ops.precision.mode
+        Co = w.shape[0]
+        return ops.pw_conv(x.contiguous(), ops.pw_prepack(w.flatten(1)), b, Co, NONE)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        Ci, Co = x.shape[1], w.shape[0]
+        with _in_precision(ctx):
+            dx = ops.pw_conv(dz, ops.pw_prepack(w.flatten(1), trans=True), _zeros.get(Ci, x.device), Ci, NONE)
+            dw = ops.pw_conv_wgrad(dz, x, exact=None).view_as(w)
+        db = ops.bn_stats(dz)[:Co].float()                   # per-channel sums over (batch, positions), fp64 accumulation
+        return dx, dw, db
 
 
 class DwConv(torch.autograd.Function):
@@ -333,6 +389,21 @@ def _context(blk, x):
     return h_c, g_cf, g_ct
 
 
+def _context_cm(blk, x):
+    """The same with the sequence channel-major and the batch folded into the position axis (csrc/dymn.hip, round 4):
+    -> (h_c (B, H), g_cf (1, cexp, B*Fo, 1) = [c][b][f], g_ct (1, cexp, B*To, 1)); every conv / BatchNorm of the context
+    generator runs on the kernels (and autograd Functions) of the feature maps, no transposed copies."""
+    B, cin, Fq, T = x.shape
+    cg = blk.context_gen
+    seq = CtxPoolCm.apply(x)                                                          # (1, cin, B*L, 1)
+    gj = PwConv.apply(seq, cg.joint_conv.weight)
+    g = BnAct.apply(gj, cg.joint_norm.weight, cg.joint_norm.bias, cg.joint_norm, HSWISH)
+    h_cf, h_ct, h_c = CtxSplit.apply(g, B, Fq, T, blk.cnf.stride)
+    g_cf = PwConvB.apply(h_cf, cg.conv_f.weight, cg.conv_f.bias)
+    g_ct = PwConvB.apply(h_ct, cg.conv_t.weight, cg.conv_t.bias)
+    return h_c, g_cf, g_ct
+
+
 def _block_train(blk, x):
     if not (blk.no_dyconv or blk.no_dyrelu or blk.no_ca) and _FUSED_BLOCK:
         return _block_train_fused(blk, x)
@@ -450,7 +521,7 @@ class DyBlockMain(torch.autograd.Function):
     pass and enters the expand data-gradient GEMM as its `res` operand."""
 
     @staticmethod
-    def forward(ctx, blk, x, att, coef, g_cf, g_ct, w_e, w_d, w_p, ge, be, gd, bd, gp, bp):
+    def forward(ctx, blk, fused, x, att, coef, g_cf, g_ct, w_e, w_d, w_p, ge, be, gd, bd, gp, bp):
         cnf = blk.cnf
         x = x.contiguous()
         B, cin, Fq, T = x.shape
@@ -462,9 +533,8 @@ class DyBlockMain(torch.autograd.Function):
         att_e, att_d, att_p = (att[0], att[1], att[2]) if has_e else (None, att[0], att[1])
         coef, g_cf, g_ct = coef.contiguous(), g_cf.contiguous(), g_ct.contiguous()
         Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
-        # round-4 kernels (per-plane taps in the register-resident depthwise kernels, one-wave-per-plane DyReLU): every
-        # geometry the merged depthwise backward covers; otherwise the separate passes
-        fused = _FUSED_DW and To <= 512 and ops.dw_bwd_merged_ok((B, cexp, Fo, To), (B, cexp, Fq, T), k, stride)
+        # fused: round-4 kernels (per-plane taps in the register-resident depthwise kernels, one-wave-per-plane DyReLU on
+        # channel-major gates); otherwise the separate passes on position-major gates
         sv = {"fused": fused}
         taps = ops.dyn_aggregate(w_d.view(K, cexp * k * k), att_d)
         if has_e:
@@ -477,9 +547,7 @@ class DyBlockMain(torch.autograd.Function):
                                                tf=(st_e[0], st_e[1], act) if has_e else None)
             st_d = ops.bn_state_from_partials(parts, blk.depth_norm, B * Fo * To) if blk.depth_norm.training else \
                 ops.bn_frozen_state(blk.depth_norm)
-            sg = ops.gate_table(g_cf, g_ct)
-            x2 = ops.dyrelu_ca_fwd2(z_d, st_d[0], st_d[1], coef, sg)
-            sv.update(sg=sg)
+            x2 = ops.dyrelu_ca_fwd2(z_d, st_d[0], st_d[1], coef, g_cf, g_ct)
         else:
             y_e = ops.bn_act_fwd(z_e, st_e[0], st_e[1], act) if has_e else x
             z_d = torch.empty((B, cexp, Fo, To), device=x.device, dtype=torch.float32)
@@ -524,8 +592,7 @@ class DyBlockMain(torch.autograd.Function):
             dbank_p, datt_p = _dyn_pw_wgrad(dz_p, sv["x2"], bank_p, att_p)
             if sv["fused"]:
                 # DyReLU-B * CoordAtt on the BatchNorm affine of z_d; the sums of depth_norm's backward leave its epilogue
-                dv, dcoef, dsg, bnpart = ops.dyrelu_ca_bwd2(dx2, z_d, st_d[0], st_d[1], sv["coef"], sv["sg"])
-                dgf, dgt = ops.gate_table_bwd(dsg, sv["sg"], Fo)
+                dv, dcoef, dgf, dgt, bnpart = ops.dyrelu_ca_bwd2(dx2, z_d, st_d[0], st_d[1], sv["coef"], sv["g_cf"], sv["g_ct"])
                 sums_d, dgd, dbd = ops.bn_bwd_combine_partials(bnpart, bnpart.view(-1)[1:], 2, B, cexp, 1, st_d[2], st_d[3])
                 # merged depthwise backward: depth_norm's backward on load, tap gradients per plane, g_e = dy_e act'(.)
                 if has_e:
@@ -567,13 +634,17 @@ class DyBlockMain(torch.autograd.Function):
             else:
                 datt = torch.stack([datt_d, datt_p])
                 dwe = None
-        return (None, dx, datt, dcoef, dgf, dgt, dwe, dbank_d.view_as(w_d), dbank_p.view_as(w_p), dge, dbe, dgd, dbd,
+        return (None, None, dx, datt, dcoef, dgf, dgt, dwe, dbank_d.view_as(w_d), dbank_p.view_as(w_p), dge, dbe, dgd, dbd,
                 dgp, dbp)
 
 
 def _block_train_fused(blk, x):
     cnf = blk.cnf
-    h_c, g_cf, g_ct = _context(blk, x)
+    B, _, Fq, T = x.shape
+    k, stride, cexp = cnf.kernel, cnf.stride, cnf.expanded_channels
+    Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
+    fused = _FUSED_DW and To <= 512 and ops.dw_bwd_merged_ok((B, cexp, Fo, To), (B, cexp, Fq, T), k, stride)
+    h_c, g_cf, g_ct = _context_cm(blk, x) if fused else _context(blk, x)
     convs = ([blk.exp_conv] if blk.has_expand else []) + [blk.depth_conv, blk.proj_conv]
     da = blk.depth_act
     wb = []
@@ -583,7 +654,7 @@ def _block_train_fused(blk, x):
     temps = tuple(float(cv.temperature) for cv in convs)
     att, coef = _HcHeads.apply(h_c, da.lambdas, da.init_v, temps, cnf.expanded_channels, *wb)
     e = blk.has_expand
-    return DyBlockMain.apply(blk, x, att, coef, g_cf, g_ct, blk.exp_conv.weight if e else None, blk.depth_conv.weight,
+    return DyBlockMain.apply(blk, fused, x, att, coef, g_cf, g_ct, blk.exp_conv.weight if e else None, blk.depth_conv.weight,
                              blk.proj_conv.weight, blk.exp_norm.weight if e else None, blk.exp_norm.bias if e else None,
                              blk.depth_norm.weight, blk.depth_norm.bias, blk.proj_norm.weight, blk.proj_norm.bias)
 

@@ -780,45 +780,60 @@ def dw_conv_dyn_stats(x, w_bc, k, stride, tf=None):
     return y, (part, B, inner.value)
 
 
-def gate_table(gate_f, gate_t):
-    """sigmoid of CoordAtt's gates (B, Fo, C) / (B, To, C), laid out channel-major: -> sg (B, C, Fo + To)."""
-    B, Fo, C = gate_f.shape
-    To = gate_t.shape[1]
-    sg = torch.empty((B, C, Fo + To), device=gate_f.device, dtype=torch.float32)
-    _lib.call("eat_gate_table", _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), sg.data_ptr(), B, C, Fo, To, _stream())
-    return sg
+def ctx_pool_cm(x):
+    """ContextGen's two average pools, channel-major: x (B, C, F, T) -> seq (1, C, B*(F+T), 1) = [c][b][l]."""
+    B, C, F, T = x.shape
+    seq = torch.empty((1, C, B * (F + T), 1), device=x.device, dtype=torch.float32)
+    _lib.call("eat_ctx_pool_cm", _dev(x, "x"), seq.data_ptr(), B, C, F, T, _stream())
+    return seq
 
 
-def gate_table_bwd(dsg, sg, Fo):
-    """-> (dgate_f (B, Fo, C), dgate_t (B, To, C)): gradients w.r.t. the pre-sigmoid gates from dsg (B, C, Fo + To)."""
-    B, C, L = sg.shape
-    To = L - Fo
-    buf = torch.empty((B * L * C,), device=sg.device, dtype=torch.float32)
-    dgf, dgt = buf[:B * Fo * C].view(B, Fo, C), buf[B * Fo * C:].view(B, To, C)
-    _lib.call("eat_gate_table_bwd", _dev(dsg, "dsg"), _dev(sg, "sg"), dgf.data_ptr(), dgt.data_ptr(), B, C, Fo, To, _stream())
-    return dgf, dgt
+def ctx_pool_cm_bwd(dseq, shape, add=None):
+    B, C, F, T = shape
+    dx = torch.empty(shape, device=dseq.device, dtype=torch.float32)
+    _lib.call("eat_ctx_pool_cm_bwd", _dev(dseq, "dseq"), _opt(add, "add"), dx.data_ptr(), B, C, F, T, _stream())
+    return dx
 
 
-def dyrelu_ca_fwd2(z, a, b, coef, sg):
+def ctx_split(g, B, F, T, stride):
+    """g (1, H, B*(F+T), 1) -> (h_cf (1, H, B*Fo, 1), h_ct (1, H, B*To, 1), h_c (B, H))."""
+    H = g.shape[1]
+    Fo, To = (F - 1) // stride + 1, (T - 1) // stride + 1
+    hcf = torch.empty((1, H, B * Fo, 1), device=g.device, dtype=torch.float32)
+    hct = torch.empty((1, H, B * To, 1), device=g.device, dtype=torch.float32)
+    hc = torch.empty((B, H), device=g.device, dtype=torch.float32)
+    _lib.call("eat_ctx_split", _dev(g, "g"), hcf.data_ptr(), hct.data_ptr(), hc.data_ptr(), H, B, F, T, stride, _stream())
+    return hcf, hct, hc
+
+
+def ctx_split_bwd(dhcf, dhct, dhc, H, B, F, T, stride):
+    dg = torch.empty((1, H, B * (F + T), 1), device=dhcf.device, dtype=torch.float32)
+    _lib.call("eat_ctx_split_bwd", _dev(dhcf, "dhcf"), _dev(dhct, "dhct"), _opt(dhc, "dhc"), dg.data_ptr(), H, B, F, T, stride,
+              _stream())
+    return dg
+
+
+def dyrelu_ca_fwd2(z, a, b, coef, gate_f, gate_t):
+    """gate_f (C, B, Fo) / gate_t (C, B, To): channel-major pre-sigmoid gates (any shape with that memory layout)."""
     B, C, Fo, To = z.shape
     out = torch.empty_like(z)
-    _lib.call("eat_dyrelu_ca_fwd2", _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"), _dev(sg, "sg"),
-              out.data_ptr(), B, C, Fo, To, _stream())
+    _lib.call("eat_dyrelu_ca_fwd2", _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"), _dev(gate_f, "gate_f"),
+              _dev(gate_t, "gate_t"), out.data_ptr(), B, C, Fo, To, _stream())
     return out
 
 
-def dyrelu_ca_bwd2(dout, z, a, b, coef, sg, want_bn=True):
-    """-> (dv, dcoef (B,C,4), dsg (B,C,Fo+To), bnpart (B,C,2) or None)."""
+def dyrelu_ca_bwd2(dout, z, a, b, coef, gate_f, gate_t, want_bn=True):
+    """-> (dv, dcoef (B,C,4), dgate_f, dgate_t (layouts of the gates), bnpart (B,C,2) or None)."""
     B, C, Fo, To = z.shape
     dv = torch.empty_like(z)
-    buf = torch.empty((B * C * (4 + Fo + To + (2 if want_bn else 0)),), device=z.device, dtype=torch.float32)
+    buf = torch.empty((B * C * (4 + (2 if want_bn else 0)),), device=z.device, dtype=torch.float32)
     dcoef = buf[:B * C * 4].view(B, C, 4)
-    dsg = buf[B * C * 4:B * C * (4 + Fo + To)].view(B, C, Fo + To)
-    bnpart = buf[B * C * (4 + Fo + To):].view(B, C, 2) if want_bn else None
+    bnpart = buf[B * C * 4:].view(B, C, 2) if want_bn else None
+    dgf, dgt = torch.empty_like(gate_f), torch.empty_like(gate_t)
     _lib.call("eat_dyrelu_ca_bwd2", _dev(dout, "dout"), _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"),
-              _dev(sg, "sg"), dv.data_ptr(), dcoef.data_ptr(), dsg.data_ptr(), None if bnpart is None else bnpart.data_ptr(),
-              B, C, Fo, To, _stream())
-    return dv, dcoef, dsg, bnpart
+              _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), dv.data_ptr(), dcoef.data_ptr(), dgf.data_ptr(), dgt.data_ptr(),
+              None if bnpart is None else bnpart.data_ptr(), B, C, Fo, To, _stream())
+    return dv, dcoef, dgf, dgt, bnpart
 
 
 def bn_bwd_combine_partials(p0, p1, stride_e, B, C, inner, mean, invstd):

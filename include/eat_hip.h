@@ -406,20 +406,28 @@ int eat_dyrelu_ca_bwd(const float* dout, const float* z, const float* a, const f
                       const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f,
                       float* dgate_t, int B, int C, int Fo, int To, eat_stream_t stream);
 
-/* Round 4 forms of the same pair (models/dymn/dy_block.py:172-188, :195-201; order inside DY_Block.forward :399-403) for
- * the training step.  eat_gate_table: sg (B, C, Fo+To) = sigmoid of the gates, channel-major (a plane's gate row is one
- * contiguous run; the position-major gates cost a strided gather per plane).  eat_dyrelu_ca_fwd2 / _bwd2: one wave per
- * plane, To <= 512; the backward returns dv, dcoef, dsg (gradient w.r.t. the SIGMOIDS, (B, C, Fo+To)) and, when bnpart
- * (B, C, 2) != NULL, the per-plane sums (sum dv, sum dv * z) of the BatchNorm backward of depth_norm (:345-348).
- * eat_gate_table_bwd: dsg, sg -> the pre-sigmoid gate gradients in the position-major layout of gate_f / gate_t. */
-int eat_gate_table(const float* gate_f, const float* gate_t, float* sg, int B, int C, int Fo, int To, eat_stream_t stream);
-int eat_gate_table_bwd(const float* dsg, const float* sg, float* dgate_f, float* dgate_t, int B, int C, int Fo, int To,
-                       eat_stream_t stream);
-int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b, const float* coef, const float* sg, float* out,
-                       int B, int C, int Fo, int To, eat_stream_t stream);
+/* Round 4: channel-major context generator of the training step (models/dymn/dy_block.py:235-254).
+ * eat_ctx_pool_cm / _bwd: the two average pools (:236-237) with the sequence laid out seq (C, B, F+T) - the input of a
+ * 1x1 conv over ONE sample of B*(F+T) positions, so that joint_conv / joint_norm / conv_f / conv_t (:238-252) run on the conv
+ * and BatchNorm kernels of the feature maps.  eat_ctx_split / _bwd: g (H, B, F+T) after joint_norm + Hardswish ->
+ * h_cf (H, B, Fo), h_ct (H, B, To) (the AvgPool(3, stride, pad 1) of :227-229 for stride 2) and h_c (B, H) = mean over L
+ * (:244); the backward takes dh_c = NULL as zero. */
+int eat_ctx_pool_cm(const float* x, float* seq, int B, int C, int F, int T, eat_stream_t stream);
+int eat_ctx_pool_cm_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T, eat_stream_t stream);
+int eat_ctx_split(const float* g, float* hcf, float* hct, float* hc, int H, int B, int F, int T, int stride,
+                  eat_stream_t stream);
+int eat_ctx_split_bwd(const float* dhcf, const float* dhct, const float* dhc, float* dg, int H, int B, int F, int T,
+                      int stride, eat_stream_t stream);
+/* Round 4 forms of DyReLU-B + CoordAtt (models/dymn/dy_block.py:172-188, :195-201; order inside DY_Block.forward :399-403)
+ * for the training step: one wave per plane, To <= 512, gates channel-major and PRE-sigmoid, gate_f (C, B, Fo) / gate_t
+ * (C, B, To) - the outputs of conv_f / conv_t on the channel-major context.  The backward returns dv, dcoef, the
+ * pre-sigmoid gate gradients in the layouts of the gates and, when bnpart (B, C, 2) != NULL, the per-plane sums
+ * (sum dv, sum dv * z) of the BatchNorm backward of depth_norm (:345-348). */
+int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b, const float* coef, const float* gate_f,
+                       const float* gate_t, float* out, int B, int C, int Fo, int To, eat_stream_t stream);
 int eat_dyrelu_ca_bwd2(const float* dout, const float* z, const float* a, const float* b, const float* coef,
-                       const float* sg, float* dv, float* dcoef, float* dsg, float* bnpart, int B, int C, int Fo, int To,
-                       eat_stream_t stream);
+                       const float* gate_f, const float* gate_t, float* dv, float* dcoef, float* dgate_f, float* dgate_t,
+                       float* bnpart, int B, int C, int Fo, int To, eat_stream_t stream);
 /* Channel sums of a train-mode BatchNorm backward (nn.BatchNorm2d autograd, models/dymn/dy_block.py:313-316,345-348) from
  * per-plane partial sums: sums[c] = sum p0, sums[C+c] = invstd[c] (sum p1 - mean[c] sum p0) in fp64 (the layout
  * eat_bn_act_bwd_apply / eat_dw_conv_dyn_bwd_bn_g read), dbeta = sums[0..C), dgamma = sums[C..2C) in fp32.  Element

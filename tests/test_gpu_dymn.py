@@ -128,8 +128,8 @@ def test_dyrelu_coordatt_backward():
 
 @pytest.mark.parametrize("B,C,Fo,To", [(3, 24, 8, 63), (3, 7, 4, 32), (2, 5, 16, 125), (2, 6, 32, 250), (1, 3, 64, 500), (2, 9, 5, 20)])
 def test_dyrelu_coordatt_wave_per_plane_forms(B, C, Fo, To):
-    """Round-4 forms (channel-major gate table, one wave per plane, BatchNorm affine on load, BatchNorm-backward sums in the
-    epilogue) against fp64 autograd of models/dymn/dy_block.py:172-201 applied to v = a z + b."""
+    """Round-4 forms (channel-major pre-sigmoid gates, one wave per plane, BatchNorm affine on load, BatchNorm-backward sums
+    in the epilogue) against fp64 autograd of models/dymn/dy_block.py:172-201 applied to v = a z + b."""
     z, coef = _rand(B, C, Fo, To, seed=1), _rand(B, C, 4, seed=2)
     gf, gt, dout = _rand(B, Fo, C, seed=3), _rand(B, To, C, seed=4), _rand(B, C, Fo, To, seed=5)
     a, b = _rand(C, seed=6).abs() + 0.5, _rand(C, seed=7)
@@ -140,16 +140,13 @@ def test_dyrelu_coordatt_wave_per_plane_forms(B, C, Fo, To):
     ref = torch.maximum(v * c[..., 0] + c[..., 2], v * c[..., 1] + c[..., 3])
     ref = ref * torch.sigmoid(gfr.permute(0, 2, 1))[:, :, :, None] * torch.sigmoid(gtr.permute(0, 2, 1))[:, :, None, :]
     ref.backward(dout.double())
-    zd, cd, gfd, gtd, ad, bd, dd = (t.to(DEV) for t in (z, coef, gf, gt, a, b, dout))
-    sg = ops.gate_table(gfd, gtd)
-    sg_ref = torch.cat([torch.sigmoid(gf), torch.sigmoid(gt)], 1).permute(0, 2, 1)
-    assert _rel(sg, sg_ref) < 2e-6
-    out = ops.dyrelu_ca_fwd2(zd, ad, bd, cd, sg)
+    zd, cd, ad, bd, dd = (t.to(DEV) for t in (z, coef, a, b, dout))
+    gfd, gtd = gf.permute(2, 0, 1).contiguous().to(DEV), gt.permute(2, 0, 1).contiguous().to(DEV)     # (C, B, Fo) / (C, B, To)
+    out = ops.dyrelu_ca_fwd2(zd, ad, bd, cd, gfd, gtd)
     assert _rel(out, ref) < 5e-6
-    dv, dcoef, dsg, bnpart = ops.dyrelu_ca_bwd2(dd, zd, ad, bd, cd, sg)
-    dgf, dgt = ops.gate_table_bwd(dsg, sg, Fo)
+    dv, dcoef, dgf, dgt, bnpart = ops.dyrelu_ca_bwd2(dd, zd, ad, bd, cd, gfd, gtd)
     assert _rel(dv, v.grad) < 2e-5 and _rel(dcoef, cr.grad) < 2e-5
-    assert _rel(dgf, gfr.grad) < 2e-5 and _rel(dgt, gtr.grad) < 2e-5
+    assert _rel(dgf, gfr.grad.permute(2, 0, 1)) < 2e-5 and _rel(dgt, gtr.grad.permute(2, 0, 1)) < 2e-5
     assert _rel(bnpart[..., 0], v.grad.sum((2, 3))) < 2e-5
     assert _rel(bnpart[..., 1], (v.grad * z.double()).sum((2, 3))) < 2e-5
     # channel sums of the BatchNorm backward from the partials
@@ -311,6 +308,51 @@ def test_dymn10_train_step_matches_oracle(golden_dir, prec):
     msd = model.state_dict()
     for k, v in stats.items():
         assert _rel(msd[k], v) < 1e-4, k
+
+
+@pytest.mark.parametrize("B,C,Fq,T,stride", [(4, 16, 64, 500, 1), (4, 24, 32, 250, 2), (3, 40, 16, 125, 2), (4, 80, 8, 63, 1),
+                                             (5, 112, 8, 63, 2), (4, 160, 4, 32, 1)])
+def test_context_generator_channel_major(B, C, Fq, T, stride):
+    """Round-4 context generator (pools, joint conv + BatchNorm + Hardswish, h_c, pooled halves, conv_f / conv_t) on the
+    channel-major sequence against fp64 autograd of models/dymn/dy_block.py:235-254 - outputs, input gradient and every
+    parameter gradient."""
+    from types import SimpleNamespace
+    from efficientat_amd.dymn import ContextGen
+    from efficientat_amd.dymn_train import _context_cm
+    H, cexp = 32, 48
+    torch.manual_seed(0)
+    cg = ContextGen(H, C, cexp, stride=stride)
+    with torch.no_grad():
+        for prm in cg.parameters():
+            prm.copy_(_rand(*prm.shape, seed=prm.numel() % 97, scale=0.3) + (1.0 if prm.dim() == 1 and prm.numel() == H else 0.0))
+    x = _rand(B, C, Fq, T, seed=1)
+    cgr = ContextGen(H, C, cexp, stride=stride).double()
+    cgr.load_state_dict({k_: v.double() for k_, v in cg.state_dict().items()})
+    cgr.train()
+    xr = x.double().clone().requires_grad_(True)
+    seq = torch.cat([xr.mean(3), xr.mean(2)], 2).unsqueeze(-1)                         # (B, C, F+T, 1)
+    g = F.hardswish(cgr.joint_norm(cgr.joint_conv(seq)))
+    h_c = g.mean((2, 3))
+    pool = torch.nn.AvgPool2d((3, 1), (stride, 1), (1, 0)) if stride > 1 else torch.nn.Identity()
+    g_cf, g_ct = cgr.conv_f(pool(g[:, :, :Fq])), cgr.conv_t(pool(g[:, :, Fq:]))
+    d_hc, d_f, d_t = _rand(*h_c.shape, seed=2), _rand(*g_cf.shape, seed=3), _rand(*g_ct.shape, seed=4)
+    ((h_c * d_hc).sum() + (g_cf * d_f).sum() + (g_ct * d_t).sum()).backward()
+    cg.to(DEV).train()
+    blk = SimpleNamespace(context_gen=cg, cnf=SimpleNamespace(stride=stride))
+    xd = x.to(DEV).requires_grad_(True)
+    with ops.precision("fp32"):
+        hc, gf, gt = _context_cm(blk, xd)
+    Fo, To = g_cf.shape[2], g_ct.shape[2]
+    assert _rel(hc, h_c) < 5e-6
+    assert _rel(gf.view(cexp, B, Fo), g_cf[..., 0].permute(1, 0, 2)) < 5e-6
+    assert _rel(gt.view(cexp, B, To), g_ct[..., 0].permute(1, 0, 2)) < 5e-6
+    loss = (hc * d_hc.to(DEV)).sum() + (gf.view(cexp, B, Fo) * d_f[..., 0].permute(1, 0, 2).to(DEV)).sum() + \
+        (gt.view(cexp, B, To) * d_t[..., 0].permute(1, 0, 2).to(DEV)).sum()
+    loss.backward()
+    assert _rel(xd.grad, xr.grad) < 2e-3                     # Hardswish kinks of the context sequence
+    for (n, prm), (_, ref) in zip(cg.named_parameters(), cgr.named_parameters()):
+        assert _rel(prm.grad, ref.grad) < 2e-3, n
+    assert _rel(cg.joint_norm.running_var, cgr.joint_norm.running_var) < 1e-5
 
 
 @pytest.mark.parametrize("B,Ci,Co,Fq,T,res", [(3, 48, 144, 8, 63, False), (5, 160, 96, 4, 32, True), (2, 40, 20, 16, 125, False),
