@@ -232,8 +232,126 @@ def _alg_bytes(name, a):
     if name == "eat_act_grad_sum":
         B, C, S = a[7:10]
         return "act_grad_sum_kernel", 12 * B * C * S, 4 * B * C * S
+    # ---- round 4: every entry point of the training steps has a byte model (argument order = include/eat_hip.h)
+    if name in ("eat_dw_conv_bwd_bn_g", "eat_dw_conv_dyn_bwd_bn_g"):
+        B, C, F, T, Fo, To, k, s = a[-9:-1]
+        dyn = name.endswith("dyn_bwd_bn_g")
+        has_res = dyn and a[14] is not None
+        # reads dy + z (conv-output sized) and x (input sized) [+ res], writes g (input sized) [+ per-plane tap gradients]
+        nbytes = 4 * B * C * (2 * Fo * To + (3 if has_res else 2) * F * T) + (4 * B * C * k * k if dyn else 0)
+        return f"dw_bwd_tile_kernel<{k},{s},*,true,*,{'true' if dyn else 'false'}>", nbytes, 4 * B * C * F * T * k * k // (s * s) + 2 * B * C * Fo * To * k * k
+    if name == "eat_dw_conv_bwd_g":
+        B, C, F, T, Fo, To, k, s = a[-9:-1]
+        return f"dw_bwd_tile_kernel<{k},{s},*,false,*>", 4 * B * C * (Fo * To + 2 * F * T), 4 * B * C * Fo * To * k * k
+    if name == "eat_dw_conv_dyn_fwd_stats":
+        x, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:17]
+        return f"dw_conv_fwd_stats<{k},{s},dyn>", 4 * B * C * (F * T + Fo * To + k * k), 2 * B * C * Fo * To * k * k
+    if name == "eat_pw_conv_cat_fwd":
+        x1, C1, x2, C2, wp, wmode, bias, res, y, B, Co, S, act = a[:13]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = 4 * B * S * (C1 + C2 + Co + (Co if res else 0)) + (4 if wmode != 1 else 2) * Co * (C1 + C2)
+        sym = f"pw_conv_kernel<{mtw},*,cat>" if wmode == 0 else f"pw_conv_bf16_kernel<{mtw},{3 if wmode == 2 else 1},*,cat>"
+        return sym, nbytes, 2 * B * S * (C1 + C2) * Co
+    if name == "eat_se_mlp_bwd":
+        B, C, Cr = a[13:16]
+        return "se_mlp_bwd_kernels", 4 * (4 * B * C + 2 * B * Cr + 4 * C * Cr + C + Cr), 8 * B * C * Cr
+    if name == "eat_stem_bwd":
+        B, C, F, T = a[10:14]
+        Fo, To = (F - 1) // 2 + 1, (T - 1) // 2 + 1
+        n_dy = 2 if a[1] is not None else 1
+        return "stem_bwd_kernel", 4 * B * (F * T + n_dy * C * Fo * To), 2 * B * C * Fo * To * 9 * 2
+    if name == "eat_stem_gram":
+        B, C, F, T = a[5:9]
+        return "stem_gram_kernel", 4 * B * F * T, 2 * B * ((F - 1) // 2 + 1) * ((T - 1) // 2 + 1) * 54
+    if name in ("eat_gram_bn_finalize_g", "eat_gram_bn_finalize"):
+        Co, Ci = a[3:5]
+        per_row = Ci * Ci if name.endswith("_g") else Ci           # the one-launch form streams G once per output channel (L2)
+        return name.replace("eat_", "") + "_kernel", 4 * (Ci * Ci + 3 * Co * Ci + 8 * Co) if name.endswith("_g") else 4 * (2 * Co * Ci + 8 * Co), 2 * Co * (per_row + Ci)
+    if name == "eat_gram_centered":
+        B, C, S = a[6:9]
+        mt = (C + 15) // 16
+        sym = f"pw_wgrad_x3_narrow_kernel<{mt},{mt},true>" if C <= 64 else ("pw_wgrad_kernel" if a[9] == 1 else "pw_wgrad_x3_kernel<3>")
+        return sym, 4 * B * S * C + 4 * C * C, 2 * B * S * C * C
+    if name == "eat_expand_bwd_coef":
+        Co, Ci = a[7:9]
+        return "expand_bwd_coef_kernel", 4 * 7 * Co * Ci, 12 * Co * Ci
+    if name in ("eat_bn_finalize", "eat_bn_finalize_partials", "eat_se_bn_bwd_combine", "eat_bn_bwd_combine_partials"):
+        if name == "eat_bn_finalize":
+            n_in = 16 * a[8]
+        elif name == "eat_bn_finalize_partials":
+            n_in = 8 * a[1] * a[2] * a[3]
+        elif name == "eat_se_bn_bwd_combine":
+            n_in = 4 * 7 * a[4] * a[5]
+        else:
+            n_in = 8 * a[3] * a[4] * a[5]
+        return name.replace("eat_", "") + "_kernel", n_in + 64, n_in // 2
+    if name in ("eat_pw_prepack", "eat_pw_prepack_t", "eat_pw_prepack_bf16", "eat_pw_prepack_bf16_t"):
+        Co, Ci = a[3:5]
+        return "pw_prepack_kernel", 8 * Co * Ci, Co * Ci
+    if name == "eat_pw_prepack_multi":
+        return "pw_prepack_multi_kernel", 8 * a[1] * a[2], a[1] * a[2]          # n matrices x max_threads elements: upper bound
+    if name in ("eat_pw_conv_dyn_fwd", "eat_pw_conv_dyn_bf16_fwd"):
+        x, wp, bias, res, y, B, Ci, Co, S, act = a[:10]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = 4 * B * S * (Ci + Co + (Co if res else 0)) + 4 * B * Co * Ci            # + the sample's own packed weights
+        sym = f"pw_conv_kernel<{mtw},*,dyn>" if name == "eat_pw_conv_dyn_fwd" else f"pw_conv_bf16_kernel<{mtw},3,*,dyn>"
+        return sym, nbytes, 2 * B * S * Ci * Co
+    if name == "eat_pw_conv_kcat_fwd":
+        x, wp, bias, att, res, y, B, Ci, nb, Co, S, act = a[:12]
+        return "pw_conv_bf16_kernel<kcat>", 4 * B * S * (Ci + Co + (Co if res else 0)) + 4 * nb * Co * Ci, 2 * B * S * nb * Ci * Co
+    if name == "eat_pw_conv_dyn_wgrad":
+        dz, x, dW, B, Co, Ci, S = a[:7]
+        return "pw_wgrad_dyn", 4 * B * (S * (Co + Ci) + Co * Ci), 2 * B * S * Co * Ci
+    if name in ("eat_dyn_pw_pack", "eat_dyn_pw_pack_t", "eat_dyn_pw_pack_bf16", "eat_dyn_pw_pack_bf16_t"):
+        if "bf16" in name:
+            B, K, Co, Ci = a[3:7]
+        else:
+            B, K, Co, Ci = a[4:8]
+        return "dyn_pw_pack_kernel", 4 * Co * Ci * (K + B), 2 * B * K * Co * Ci         # banks once (L2-resident), packs written
+    if name == "eat_dyn_aggregate":
+        B, K, N = a[4:7]
+        return "dyn_aggregate_kernel", 4 * N * (K + B), 2 * B * K * N
+    if name == "eat_dyn_bank_grad":
+        B, K, N = a[5:8]
+        return "dyn_bank_grad_fused_kernel", 4 * N * (B + 2 * K), 4 * B * K * N
+    if name in ("eat_dyrelu_ca_fwd2", "eat_dyrelu_ca_fwd"):
+        B, C, Fo, To = a[-5:-1]
+        return "dyrelu_ca_fwd_kernel", 4 * B * C * (2 * Fo * To + Fo + To + 4), 10 * B * C * Fo * To
+    if name in ("eat_dyrelu_ca_bwd2", "eat_dyrelu_ca_bwd"):
+        B, C, Fo, To = a[-5:-1]
+        return "dyrelu_ca_bwd_kernel", 4 * B * C * (3 * Fo * To + 2 * (Fo + To) + 10), 24 * B * C * Fo * To
+    if name in ("eat_ctx_pool", "eat_ctx_pool_cm"):
+        B, C, F, T = a[2:6]
+        return "ctx_pool_kernel", 4 * B * C * (F * T + F + T), 2 * B * C * F * T
+    if name in ("eat_ctx_pool_bwd", "eat_ctx_pool_cm_bwd"):
+        B, C, F, T = a[3:7]
+        return "ctx_pool_bwd_kernel", 4 * B * C * ((2 if a[1] is not None else 1) * F * T + F + T), 2 * B * C * F * T
+    if name in ("eat_ctx_split", "eat_ctx_split_bwd"):
+        H, B, F, T = a[4:8]
+        return name.replace("eat_", "") + "_kernel", 8 * H * B * (F + T), 4 * H * B * (F + T)
+    if name in ("eat_dw_conv_dyn_fwd", "eat_dw_conv_dyn_act_fwd"):
+        B, C, F, T, Fo, To, k, s = a[-9:-1]
+        return f"dw_conv_dyn<{k},{s}>", 4 * B * C * (F * T + Fo * To + k * k), 2 * B * C * Fo * To * k * k
+    if name in ("eat_dw_conv_dyn_wgrad", "eat_dw_conv_dyn_dgrad"):
+        B, C, F, T, Fo, To, k, s = a[-9:-1]
+        return name.replace("eat_", "") + f"<{k},{s}>", 4 * B * C * (F * T + Fo * To + k * k), 2 * B * C * Fo * To * k * k
+    if name in ("eat_mixup_fwd", "eat_kd_loss_fwd_bwd", "eat_calib_copy"):
+        n = a[4] * a[5] if name == "eat_mixup_fwd" else (a[8] * a[9] if name == "eat_kd_loss_fwd_bwd" else a[2])
+        return name.replace("eat_", "") + "_kernel", 12 * n, 4 * n
     return name, 0, 0
 
+
+# access width of a kernel's global loads -> which calibration copy corrects its FETCH_SIZE reading
+_ACCESS_CLASS = {"pw_conv_kernel": "lds16", "pw_conv_bf16_kernel": "lds16", "pw_wgrad_x3_kernel": "lds16",
+                 "dw_plane_kernel": "b8", "dw_tile_kernel": "b8", "dw_bwd_tile_kernel": "b8", "dw_conv_fwd_stats": "b8",
+                 "dw_conv_kernel": "b4", "irb_kernel": "b4", "stem_conv_kernel": "b4", "dyrelu_ca_fwd_kernel": "b4",
+                 "dyrelu_ca_bwd_kernel": "b4", "ctx_pool_kernel": "b4", "col_sum_kernel": "b4"}
+# byte-model labels (an entry point runs one of several kernels) -> kernel family in the PMC file
+_PMC_FAMILY = {"dw_conv_fwd_stats": "dw_tile_kernel", "se_mlp_bwd_kernels": "se_mlp_bwd_kernel", "pw_wgrad_dyn": "pw_wgrad_x3_kernel"}
 
 _HAS_MFMA = ("pw_conv_kernel", "pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel", "expand_dw_kernel", "irb_kernel",
              "pw_wgrad_kernel", "pw_wgrad_x3_kernel", "pw_wgrad_x3_narrow_kernel", "linear_kernel")
@@ -246,26 +364,36 @@ def roofline_of(name, d, args):
     per_launch_flops = d["flops"] / d["launches"]
     per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
     traffic, tsrc = None, None
-    for tfile in ("pmc_traffic_r3.json", "pmc_traffic_r2c.json"):
+    for tfile in ("pmc_traffic_r4.json", "pmc_traffic_r3.json"):
         tpath = os.path.join(ROOT, "profiles", tfile)
         if not os.path.exists(tpath):
             continue
-        ks = json.load(open(tpath))["kernels"]
+        doc = json.load(open(tpath))
+        ks = doc["kernels"]
         # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
         hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
+        if not hit:                                         # byte-model labels that are not kernel symbols: the family
+            hit = [v for kk, v in ks.items() if kk.split("<")[0] == _PMC_FAMILY.get(name.split("<")[0], name.split("<")[0])]
         if hit:
             n = sum(h["launches_sampled"] for h in hit)
             fetch = sum(h["fetch_kib"] * h["launches_sampled"] for h in hit) / n * 1024
             write = sum(h["write_kib"] * h["launches_sampled"] for h in hit) / n * 1024
-            # gfx950: FETCH_SIZE under-reports wide reads by 2x (MI355X_MICROARCH.md).  Calibrated per kernel on a known
-            # byte count instead of a name list: a kernel cannot fetch less than its compulsory input, so a raw reading
-            # below 0.75x the algorithmic read bytes is a halved one.
-            rd = d.get("read_bytes", 0) / d["launches"]
-            x2 = rd > 0 and fetch < 0.75 * rd
-            traffic = int((2 if x2 else 1) * fetch + write)
-            tsrc = (f"profiles/{tfile}: rocprofv3 FETCH_SIZE ({fetch / 1e6:.1f} MB raw, "
-                    + ("x2: below 0.75x the " if x2 else "x1: not below 0.75x the ") + f"{rd / 1e6:.1f} MB of compulsory reads) + "
-                    f"WRITE_SIZE ({write / 1e6:.1f} MB), separate passes, largest-grid launches")
+            cal = doc.get("calibration")
+            if cal:
+                # counter readings corrected by the copies of a KNOWN byte count that ran in the same rocprofv3 passes, per
+                # access width of the kernel's loads (gfx950 reports wide coalesced reads at half size)
+                cls = _ACCESS_CLASS.get(name.split("<")[0], "b16")
+                ff, fw = cal["fetch_factor"][cls], cal["write_factor"][cls]
+                traffic = int(ff * fetch + fw * write)
+                tsrc = (f"profiles/{tfile}: rocprofv3 FETCH_SIZE {fetch / 1e6:.1f} MB x {ff:.2f} + WRITE_SIZE {write / 1e6:.1f} MB x "
+                        f"{fw:.2f} per launch (largest-grid launches, separate passes); factors = known bytes / counter of "
+                        f"eat_calib_copy ({cls} loads) in the same passes")
+            else:
+                rd = d.get("read_bytes", 0) / d["launches"]
+                x2 = rd > 0 and fetch < 0.75 * rd
+                traffic = int((2 if x2 else 1) * fetch + write)
+                tsrc = (f"profiles/{tfile} (no calibration pass): FETCH_SIZE {fetch / 1e6:.1f} MB raw "
+                        + ("x2" if x2 else "x1") + f" + WRITE_SIZE {write / 1e6:.1f} MB")
             break
     base = name.split("<")[0]
     mfma_peak = MFMA_F32_PEAK
@@ -394,7 +522,7 @@ def cpu_baseline(budget_s=7.0, batch=32):
         F.binary_cross_entropy_with_logits(logits, y).backward()
         opt.step()
 
-    def rate(fn, max_iters=50):
+    def rate(fn, max_iters=50, min_iters=3):
         fn()
         t0 = time.perf_counter()
         n = 0
@@ -402,7 +530,7 @@ def cpu_baseline(budget_s=7.0, batch=32):
             fn()
             n += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s or n >= max_iters:
+            if (dt > budget_s and n >= min_iters) or n >= max_iters:
                 return batch * n / dt, n
 
     mel_r, mel_n = rate(mel_leg)
@@ -477,20 +605,22 @@ def forward_bench(args, mel, model, wave, ranks):
     return ranks.world * wave.shape[0] * args.steps / el, el / args.steps * 1e3, launch
 
 
-def make_train_model(name, dev):
+def make_train_model(name, dev, precision=None):
     torch.manual_seed(0)
     if name.startswith("dymn"):
         from efficientat_amd.dymn import get_model as gm
         model = quiet(gm, width_mult=2.0 if name == "dymn20" else 1.0)
+        if precision:
+            model.train_precision = precision
     else:
         from efficientat_amd.mn import get_model as gm
         model = quiet(gm, width_mult=4.0 if name.startswith("mn40") else 1.0)
-        model.train_precision = "bf16" if name.endswith("bf16") else os.environ.get("EAT_TRAIN_PRECISION", "auto")
+        model.train_precision = precision or ("bf16" if name.endswith("bf16") else os.environ.get("EAT_TRAIN_PRECISION", "auto"))
     _fan_in_init(model, head_scale=0.05 if name == "mn10" else None)
     return model.to(dev)
 
 
-def train_bench(name, batch, steps, warmup, args, mel, wave, ranks):
+def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=None):
     """Full training step per GPU: log-mel (train mode) -> forward (batch-stat BN) -> BCE-with-logits ->
     hand-written backward -> [bucketed RCCL all-reduce of the gradient, overlapped with backward] -> fused Adam.
     Mirrors ex_audioset.py:139-199 without data loading / wandb / KD teacher.  The step (incl. the collectives when
@@ -498,7 +628,7 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks):
     import torch.nn.functional as F
     from efficientat_amd.dp import enable_data_parallel
     dev = ranks.dev
-    model = make_train_model(name, dev)
+    model = make_train_model(name, dev, precision)
     bt = min(batch, wave.shape[0])
     w = wave[:bt]
     g = torch.Generator(device=dev).manual_seed(99)
@@ -523,7 +653,7 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks):
         except Exception as e:  # pragma: no cover
             print(f"[bench] train-step graph capture failed for {name} ({type(e).__name__}: {e}); eager", file=sys.stderr)
             graphed = False
-            model = make_train_model(name, dev)
+            model = make_train_model(name, dev, precision)
             if use_dp:
                 enable_data_parallel(model, force_buckets=ranks.world == 1)
             model.train()
@@ -612,6 +742,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the exact-fp32 forward measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event profile to stderr")
+    ap.add_argument("--calibrate-traffic", action="store_true",
+                    help="run the known-byte copies (eat_calib_copy) first: under `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` they "
+                         "calibrate the counters of that pass (tools/pmc_traffic.py)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank plumbing only (gloo, CPU, no kernels): used by the CPU test of the N-rank launch path")
     return ap.parse_args(argv)
@@ -667,6 +800,17 @@ def main():
     ranks = Ranks(dist, world, dev)
 
     from efficientat_amd import mn as mn_mod
+    if args.calibrate_traffic and rank == 0:
+        from efficientat_amd import _lib
+        n = 1 << 28                                             # 1 GiB per buffer: past the 256 MiB Infinity Cache
+        src = torch.rand(n, device=dev)
+        dst = torch.empty(n, device=dev)
+        for mode in range(4):
+            for _ in range(3):
+                _lib.call("eat_calib_copy", src.data_ptr(), dst.data_ptr(), n, mode, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        del src, dst
+        torch.cuda.empty_cache()
     mel, model = build_model(dev)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     wave = (0.1 * torch.randn(args.batch, CLIP_SAMPLES, device=dev, generator=g)).clamp_(-1, 1)
@@ -724,6 +868,20 @@ def main():
                 model._cache.invalidate()
         result["forward"] = fwd
 
+    if not args.no_fp32_exact and os.environ.get("EAT_TRAIN_PRECISION", "auto") != "fp32":
+        # the same training step with every GEMM on the exact fp32 MFMA (the reference CPU path's arithmetic)
+        try:
+            ex = train_bench(train_name, args.batch, max(5, args.steps // 3), 2, args, mel, wave, ranks, precision="fp32")
+            alg = ALG_TRAIN.get(train_name)
+            result["train_step_fp32_exact"] = {
+                "value": ex["value"], "unit": "clips/s", "ms_per_step": ex["ms_per_step"], "steps": ex["steps"],
+                "roofline_e2e_frac": ex["roofline_e2e_frac"], "alg_bytes_per_clip": alg,
+                "what": "the headline step with train_precision = 'fp32': every 1x1 conv, data gradient and weight gradient on "
+                        "v_mfma_f32_16x16x4_f32 (exact fp32 products)"}
+        except Exception as e:  # pragma: no cover
+            result["train_step_fp32_exact"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+
     if world == 1 and not args.no_train_configs and args.train_model is None:
         for key, name, bt, st, wu in [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2)]:
             try:
@@ -770,7 +928,13 @@ def main():
         del tm, opt
         torch.cuda.empty_cache()
         step_ms = sum(v["total_ms"] for v in prof.values())
-        name, d = max(((k, v) for k, v in prof.items() if v["bytes"] > 0), key=lambda kv: kv[1]["total_ms"])
+        # every launch carries a byte model (a launch priced at 0 bytes would drop out of `moved_bytes` and of the
+        # dominant-kernel pick): listed - and reported - if one ever does not
+        unmodelled = sorted(k for k, v in prof.items() if v["bytes"] <= 0)
+        if unmodelled:
+            print(f"[bench] ERROR: launches without a byte model: {unmodelled}", file=sys.stderr)
+        result["roofline_e2e"]["launches_without_byte_model"] = unmodelled
+        name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])        # largest time share over ALL launches
         result["roofline"] = roofline_of(name, d, {"step_ms": step_ms})
         result["roofline"]["step"] = "training step, eager launches with a HIP event pair each (one stream)"
         moved = sum(v["bytes"] for v in prof.values())

@@ -60,6 +60,7 @@ SIGNATURES = {
     "eat_dw_conv_dyn_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_mixup_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "eat_col_sum": [_P, _P, _I, _I, _P],
+    "eat_calib_copy": [_P, _P, ctypes.c_longlong, _I, _P],
     "eat_pw_conv_kcat_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dilated_fwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "eat_kd_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P],
@@ -74,16 +75,17 @@ SIGNATURES = {
     "eat_dw_conv_fwd_stats": [_P, _P, _P, _I, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_bn_stats_partial": [_P, _I, _I, _I, _P, _P],
     "eat_bn_finalize_partials": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P],
-    "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P],
+    "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _I, _P],
+    "eat_gram_centered": [_P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_act_grad_sum": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "eat_dw_conv_dgrad_g": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_dw_bwd_partials_inner": [_I] * 6,
     "eat_dw_conv_bwd_g": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_se_bn_bwd_partials": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_se_bn_bwd_combine": [_P, _P, _P, _P, _I, _I, _P, _P],
-    "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_P],
+    "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_I, _P],
     "eat_stem_gram_blocks": [_I, _I],
-    "eat_gram_bn_finalize_g": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P, _P],
+    "eat_gram_bn_finalize_g": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P, _I, _P],
     "eat_pw_prepack_multi": [_P, _I, _I, _P],
     "eat_se_mlp_bwd": [_P] * 6 + [_F] + [_P] * 6 + [_I, _I, _I, _P],
     "eat_dw_bwd_merged_ok": [_I] * 8,

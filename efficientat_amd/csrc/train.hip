@@ -16,7 +16,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // Optional transform of the x operand of the 1x1 weight gradient: x' = act(a[ci] * x + b[ci]) evaluated on load (training:
 // the project conv read BN + act of the depthwise output on load, so the activated tensor does not exist; mn_train.py)
-struct WgTf { const float* a; const float* b; int act; };
+// actr (Co) or NULL: additive constant of the dz operand, per row, applied to loaded elements only - with a = 1, b = actr =
+// -mean and dz == x the kernels form the CENTRED Gram matrix sum (x - m)(x - m)^T (eat_gram_centered)
+struct WgTf { const float* a; const float* b; int act; const float* actr = nullptr; };
 // atomic add on a pointer KNOWN to be global memory (hipcc cannot always infer the address space of a pointer offset by a
 // run-time slot index, and its expansion of a flat fp32 atomic fails on gfx950: "Operand has incorrect register class")
 __device__ __forceinline__ void global_atomic_add(float* p, float v) {
@@ -27,6 +29,7 @@ __device__ __forceinline__ void global_atomic_add(float* p, float v) {
 // Hardswish (-inf, 1/6, 1/2) - the weight-gradient kernels are VALU-bound on the bf16 hi/lo split already
 __device__ __forceinline__ float wg_tf(float v, float a, float b, int act) {
   const float u = fmaf(a, v, b);
+  if (act == EAT_ACT_NONE) return u;                       // (wave-uniform) the centring transform of the Gram / Gx launches
   const float lo = act == EAT_ACT_RELU ? 0.0f : -__builtin_huge_valf();
   const float ca = act == EAT_ACT_HSWISH ? (1.0f / 6.0f) : 0.0f, cb = act == EAT_ACT_HSWISH ? 0.5f : 1.0f;
   return fmaxf(u, lo) * __builtin_amdgcn_fmed3f(fmaf(u, ca, cb), 0.0f, 1.0f);
@@ -608,6 +611,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (s + e < S) o[e] = wg_tf(o[e], ta, tb, tf.act);
   };
+  const float ac0 = (tf.actr && m0 + row < Co) ? tf.actr[m0 + row] : 0.0f;
+  const float ac1 = (tf.actr && m0 + 16 + row < Co) ? tf.actr[m0 + 16 + row] : 0.0f;
+  auto ctr4 = [&](float (&o)[4], int r, int s, float c) {
+    if (!tf.actr || r >= Co) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (s + e < S) o[e] += c;
+  };
   for (int bb = b0; bb < b1; ++bb) {
     const float* gz = dz + (size_t)bb * Co * S;
     const float* gx = x + (size_t)bb * Ci * S;
@@ -625,6 +635,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
         load4(gx, n0 + 16 + row, Ci, S, s, xb[u][1]);
         tf4(xb[u][0], n0 + row, s, ta0, tb0);
         tf4(xb[u][1], n0 + 16 + row, s, ta1, tb1);
+        ctr4(ga[u][0], m0 + row, s, ac0);
+        ctr4(ga[u][1], m0 + 16 + row, s, ac1);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -769,13 +781,20 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
 
   int b = u0 / sps, st = u0 - b * sps;
   float sc[4] = {1.f, 1.f, 1.f, 1.f};
-  float tfa[4] = {1.f, 1.f, 1.f, 1.f}, tfb[4] = {0.f, 0.f, 0.f, 0.f};
+  float tfa[4] = {1.f, 1.f, 1.f, 1.f}, tfb[4] = {0.f, 0.f, 0.f, 0.f}, actr[4] = {0.f, 0.f, 0.f, 0.f};
   if (tf.a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = nb + nw + 16 * j + r;
       tfa[j] = row < Ci ? tf.a[row] : 0.0f;
       tfb[j] = row < Ci ? tf.b[row] : 0.0f;
+    }
+  }
+  if (tf.actr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = mb + mw + 16 * i + r;
+      actr[i] = row < Co ? tf.actr[row] : 0.0f;
     }
   }
   int b_sc = -1;
@@ -835,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
         if (i < mt_n) {
           const int row = mw + 16 * i + r;
           bf16x8_t ah, al;
-          frag(0, row, mb + row < Co, 1.0f, ah, al);
+          frag(0, row, mb + row < Co, 1.0f, ah, al, tf.actr != nullptr, 1.0f, actr[i]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (j < nt_n) {
@@ -913,13 +932,18 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
   for (int i = 0; i < MTN; ++i)
 #pragma unroll
     for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float sc[NTN], tfa[NTN], tfb[NTN];
+  float sc[NTN], tfa[NTN], tfb[NTN], actr[MTN];
 #pragma unroll
   for (int j = 0; j < NTN; ++j) {
     sc[j] = 1.0f;
     const int row = n0 + 16 * j + r;
     tfa[j] = (tf.a && row < Ci) ? tf.a[row] : 1.0f;
     tfb[j] = (tf.a && row < Ci) ? tf.b[row] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < MTN; ++i) {
+    const int row = m0 + 16 * i + r;
+    actr[i] = (tf.actr && row < Co) ? tf.actr[row] : 0.0f;
   }
   int b_sc = -1;
 
@@ -935,8 +959,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_narrow_kernel(const float*
       const bool ok0 = live && row < Co && s < S, ok1 = ok0 && s + 4 < S;
       const float4 t0 = ok0 ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 t1 = ok1 ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      av[i][0] = t0.x; av[i][1] = t0.y; av[i][2] = t0.z; av[i][3] = t0.w;
-      av[i][4] = t1.x; av[i][5] = t1.y; av[i][6] = t1.z; av[i][7] = t1.w;
+      const float c0 = ok0 ? actr[i] : 0.0f, c1 = ok1 ? actr[i] : 0.0f;      // (0 without centring: elements unchanged)
+      av[i][0] = t0.x + c0; av[i][1] = t0.y + c0; av[i][2] = t0.z + c0; av[i][3] = t0.w + c0;
+      av[i][4] = t1.x + c1; av[i][5] = t1.y + c1; av[i][6] = t1.z + c1; av[i][7] = t1.w + c1;
     }
     if constexpr (!SAME) {
 #pragma unroll
@@ -1479,7 +1504,8 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   // ws / n_slots (zero-filled, n_slots * Co * Ci floats): the blocks' atomics go to copy blockIdx.z % n_slots and a
   // second kernel adds the copies into dW in a fixed order; n_slots >= eat_pw_wgrad_slots(...) gives every block its own
   // copy (bit-reproducible result).  The LDS-staged and exact kernels use the workspace only in that one-per-block form.
-  const WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || tf.a != nullptr);
+  // (a centring transform - tf.actr set - keeps the Gram plan: both operands are the same centred rows)
+  const WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr));
   hipStream_t hs = (hipStream_t)stream;
   const bool priv = ws != nullptr && !per_sample && n_slots >= (int)p.nz;     // one copy per block
   if (p.kind == 0) {
@@ -1559,6 +1585,26 @@ extern "C" int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float
 // 1 where eat_pw_conv_dyn_wgrad adds into dW_b (the caller zero-fills it), 0 where it stores.  Host helper.
 extern "C" int eat_pw_dyn_wgrad_accumulates(int Co, int Ci, int S) {
   return wgrad_plan(1, Co, Ci, S, 1, 0, false, false).kind == 1 ? 0 : 1;
+}
+
+// Centred Gram matrix Gc = sum (x - m)(x - m)^T, m = sx * inv_n (see include/eat_hip.h): both operands are centred on
+// load (operand transform a = 1, b = -m on the x side, additive row constant -m on the dz side; elements beyond the k
+// range stay zero).
+namespace {
+__global__ void gram_center_coef_kernel(const float* __restrict__ sx, float inv_n, float* __restrict__ ab, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { ab[c] = 1.0f; ab[C + c] = -sx[c] * inv_n; }
+}
+}  // namespace
+extern "C" int eat_gram_centered(const float* x, const float* sx, float inv_n, float* G, float* ws, int n_slots, int B, int C,
+                                 int S, int exact_fp32, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !sx || !G || !ws || n_slots < 1) return eat::fail(EAT_EINVAL, "eat_gram_centered: missing operand (ws holds the (1, -m) coefficients first)");
+  // ws: [2 C floats of transform coefficients][n_slots copies of G]
+  float* ab = ws;
+  hipLaunchKernelGGL(gram_center_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sx, inv_n, ab, C);
+  return pw_wgrad_impl(x, x, nullptr, G, B, C, C, S, 0, exact_fp32, stream, ws + 2 * (size_t)C, n_slots,
+                       WgTf{ab, ab + C, EAT_ACT_NONE, ab + C});
 }
 
 extern "C" int eat_pw_conv_dyn_wgrad(const float* dz, const float* x, float* dW_b, int B, int Co, int Ci, int S,

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(64) void gram_bn_finalize_kernel(
     const float* __restrict__ Tm, const float* __restrict__ W, const float* __restrict__ sx, int Co, int Ci,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, double n, float* __restrict__ a,
-    float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd) {
+    float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd, int centered) {
+  // centered: Tm = W Gc with the centred Gram matrix Gc = sum (x - m)(x - m)^T, m = sx / n (eat_gram_centered): then
+  // w^T Gc w = sum (z - mu)^2 = n var directly - no mu^2 subtracted from a sum of squares that is (mu/sigma)^2 larger
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < Ci; k += 64) {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64) void gram_bn_finalize_kernel(
   s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
   if (threadIdx.x != 0) return;
   const double mu = s1 / n;
-  double var = s2 / n - mu * mu;
+  double var = centered ? s2 / n : s2 / n - mu * mu;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float av = gamma[c] * is;
@@ -245,14 +247,14 @@ __global__ __launch_bounds__(64) void gram_bn_finalize_kernel(
   }
 }
 
-// The same from the Gram matrix itself: row c of T = W G is formed here (fp64 accumulation; G is symmetric, so thread k walks
-// column k of G with coalesced row reads) and written out for the backward - the separate W G GEMM launch disappears.
+// The same from the Gram matrix itself: row c of T = W G is formed here (fp64 accumulation; thread k walks column k of G
+// with coalesced row reads - G need not be symmetric: any square matrix) and written out for the backward - the separate W G GEMM launch disappears.
 // 256 threads = 64 columns x 4 slices of the j axis; dynamic LDS: 4 * Ci doubles.
 __global__ __launch_bounds__(256) void gram_bn_finalize_g_kernel(
     const float* __restrict__ G, const float* __restrict__ W, const float* __restrict__ sx, int Co, int Ci,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, double n, float* __restrict__ Tm, float* __restrict__ a,
-    float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd) {
+    float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd, int centered) {
   extern __shared__ double s_part[];                      // [4][Ci]
   __shared__ double s_red[12];
   const int c = blockIdx.x, kx = threadIdx.x & 63, jp = threadIdx.x >> 6;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void gram_bn_finalize_g_kernel(
   block_sum_d(s1, s2, dummy, s_red);
   if (threadIdx.x != 0) return;
   const double mu = s1 / n;
-  double var = s2 / n - mu * mu;
+  double var = centered ? s2 / n : s2 / n - mu * mu;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float av = gamma[c] * is;
@@ -301,7 +303,10 @@ __global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
     const float* __restrict__ sx, const float* __restrict__ gpart, int outer, int inner, int Co, int Ci,
     const float* __restrict__ a, const float* __restrict__ mean, const float* __restrict__ invstd, double n, int frozen,
     float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ WaT,
-    float* __restrict__ WT, float* __restrict__ W2T, float* __restrict__ e1) {
+    float* __restrict__ WT, float* __restrict__ W2T, float* __restrict__ e1, int centered) {
+  // centered: Tm = W Gc with the centred Gram matrix Gc = sum (x - m)(x - m)^T (eat_gram_centered): T - mu sx^T IS W Gc -
+  // the difference is taken term by term at accumulation time instead of between two (mu/sigma)^2-times larger sums.
+  // (Gx - m1 sx^T and w.Gx - mu S1 lose only one factor mu/sigma, in fp64 here: Gx stays the plain sum g x^T.)
   __shared__ double s_red[12];
   const int c = blockIdx.x;
   double s1 = 0.0, wg = 0.0, dummy = 0.0;
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
   for (int k = threadIdx.x; k < Ci; k += blockDim.x) {
     const size_t idx = (size_t)c * Ci + k;
     const double sxk = (double)sx[k], w = (double)W[idx];
-    dW[idx] = (float)(av * ((double)Gx[idx] - m1 * sxk - m2 * is * ((double)Tm[idx] - mu * sxk)));
+    const double tc = centered ? (double)Tm[idx] : (double)Tm[idx] - mu * sxk;
+    dW[idx] = (float)(av * ((double)Gx[idx] - m1 * sxk - m2 * is * tc));
     const size_t tdx = (size_t)k * Co + c;
     WaT[tdx] = (float)(av * w);
     WT[tdx] = (float)w;
@@ -393,33 +399,34 @@ extern "C" int eat_bn_finalize_partials(const float* part, int outer, int C, int
 
 extern "C" int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int Co, int Ci, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                    double n, float* a, float* b, float* mean, float* invstd, eat_stream_t stream) {
+                                    double n, float* a, float* b, float* mean, float* invstd, int centered,
+                                    eat_stream_t stream) {
   eat::clear_stale_error();
   if (Co < 1 || Ci < 1) return eat::fail(EAT_EINVAL, "eat_gram_bn_finalize: bad shape");
   hipLaunchKernelGGL(gram_bn_finalize_kernel, dim3((unsigned)Co), dim3(64), 0, (hipStream_t)stream, Tm, W, sx, Co, Ci, gamma,
-                     beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
+                     beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd, centered);
   return eat::check_launch("eat_gram_bn_finalize");
 }
 
 extern "C" int eat_gram_bn_finalize_g(const float* G, const float* W, const float* sx, int Co, int Ci, const float* gamma,
                                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                      double n, float* Tm, float* a, float* b, float* mean, float* invstd,
+                                      double n, float* Tm, float* a, float* b, float* mean, float* invstd, int centered,
                                       eat_stream_t stream) {
   eat::clear_stale_error();
   if (Co < 1 || Ci < 1 || Ci > 2048) return eat::fail(EAT_EINVAL, "eat_gram_bn_finalize_g: bad shape (%d x %d)", Co, Ci);
   hipLaunchKernelGGL(gram_bn_finalize_g_kernel, dim3((unsigned)Co), dim3(256), (size_t)4 * Ci * sizeof(double),
                      (hipStream_t)stream, G, W, sx, Co, Ci, gamma, beta, running_mean, running_var, momentum, eps, n, Tm, a, b,
-                     mean, invstd);
+                     mean, invstd, centered);
   return eat::check_launch("eat_gram_bn_finalize_g");
 }
 
 extern "C" int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart,
                                    int outer, int inner, int Co, int Ci, const float* a, const float* mean,
                                    const float* invstd, double n, int frozen, float* dW, float* dgamma, float* dbeta,
-                                   float* WaT, float* WT, float* W2T, float* e1, eat_stream_t stream) {
+                                   float* WaT, float* WT, float* W2T, float* e1, int centered, eat_stream_t stream) {
   eat::clear_stale_error();
   if (Co < 1 || Ci < 1 || outer < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_expand_bwd_coef: bad shape");
   hipLaunchKernelGGL(expand_bwd_coef_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, W, Gx, Tm, sx, gpart,
-                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, WT, W2T, e1);
+                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, WT, W2T, e1, centered);
   return eat::check_launch("eat_expand_bwd_coef");
 }

@@ -129,7 +129,51 @@ __global__ __launch_bounds__(256) void col_sum_det_kernel(const float* __restric
   out[c] = (a0 + a1) + (a2 + a3);
 }
 
+// ---- calibration of the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (measurement support, not on the hot path): copies of
+// a KNOWN byte count with the access widths the library's kernels use.  On gfx950 FETCH_SIZE reports half the bytes of wide
+// coalesced reads (MI355X_MICROARCH.md, HBM section); bench.py divides the known bytes of these launches by the counter
+// reading taken in the SAME rocprofv3 pass as the kernels it corrects.
+//   MODE 0: 16 B per lane global loads     1: 16 B per lane LDS-DMA loads (global_load_lds_dwordx4)
+//        2: 4 B per lane loads              3: 8 B per lane loads           (stores: same width as the loads; LDS-DMA: 16 B)
+typedef __attribute__((address_space(3))) void calib_lds_void;
+template <int MODE>
+__global__ __launch_bounds__(256) void calib_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if constexpr (MODE == 0) {
+    for (long long i = t; i * 4 + 3 < n; i += stride)
+      reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  } else if constexpr (MODE == 1) {
+    __shared__ __attribute__((aligned(16))) float s_buf[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (long long i = t; i * 4 + 3 < n; i += stride) {
+      const unsigned dstl = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(calib_lds_void*)&s_buf[wv][0]);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_waitcnt vmcnt(0)"
+                   ::"s"(dstl), "v"(reinterpret_cast<const float4*>(src) + i) : "memory", "m0");
+      reinterpret_cast<float4*>(dst)[i] = *reinterpret_cast<const float4*>(&s_buf[wv][lane * 4]);
+    }
+  } else if constexpr (MODE == 2) {
+    for (long long i = t; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (long long i = t; i * 2 + 1 < n; i += stride)
+      reinterpret_cast<float2*>(dst)[i] = reinterpret_cast<const float2*>(src)[i];
+  }
+}
+
 }  // namespace
+
+// n floats (a multiple of 4) from src to dst with the access width of `mode` (see calib_copy_kernel): 4 n bytes read, 4 n written
+extern "C" int eat_calib_copy(const float* src, float* dst, long long n, int mode, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!src || !dst || n < 4 || (n & 3) || mode < 0 || mode > 3) return eat::fail(EAT_EINVAL, "eat_calib_copy: bad arguments");
+  const dim3 grid(256 * 16), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) hipLaunchKernelGGL(calib_copy_kernel<0>, grid, blk, 0, s, src, dst, n);
+  else if (mode == 1) hipLaunchKernelGGL(calib_copy_kernel<1>, grid, blk, 0, s, src, dst, n);
+  else if (mode == 2) hipLaunchKernelGGL(calib_copy_kernel<2>, grid, blk, 0, s, src, dst, n);
+  else hipLaunchKernelGGL(calib_copy_kernel<3>, grid, blk, 0, s, src, dst, n);
+  return eat::check_launch("eat_calib_copy");
+}
 
 extern "C" int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n,
                              eat_stream_t stream) {

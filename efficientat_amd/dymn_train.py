@@ -67,17 +67,26 @@ class CtxPool(torch.autograd.Function):
         return dx
 
 
+_pending = set()          # hand-overs of dx a DyBlockMain.backward has filled and no CtxPoolCm.backward has collected yet
+
+
 class CtxPoolCm(torch.autograd.Function):
     """ContextGen's pools with the sequence channel-major, batch folded into the positions: -> (1, C, B*(F+T), 1)."""
 
     @staticmethod
-    def forward(ctx, x):
-        ctx.shape = x.shape
+    def forward(ctx, x, hand_over=None):
+        ctx.shape, ctx.hand_over = x.shape, hand_over
         return ops.ctx_pool_cm(x.contiguous())
 
     @staticmethod
     def backward(ctx, dseq):
-        return ops.ctx_pool_cm_bwd(dseq.contiguous(), ctx.shape)
+        # hand_over: the block's main path left its own input gradient here instead of returning it to autograd (it runs
+        # first - everything the context path's backward consumes comes out of it): the two contributions to dx are summed
+        # inside this kernel instead of by a separate pass over the block input
+        add = ctx.hand_over.pop("dx", None) if ctx.hand_over is not None else None
+        if ctx.hand_over is not None:
+            _pending.discard(id(ctx.hand_over))
+        return ops.ctx_pool_cm_bwd(dseq.contiguous(), ctx.shape, add=add), None
 
 
 class CtxSplit(torch.autograd.Function):
@@ -389,13 +398,13 @@ def _context(blk, x):
     return h_c, g_cf, g_ct
 
 
-def _context_cm(blk, x):
+def _context_cm(blk, x, hand_over=None):
     """The same with the sequence channel-major and the batch folded into the position axis (csrc/dymn.hip, round 4):
     -> (h_c (B, H), g_cf (1, cexp, B*Fo, 1) = [c][b][f], g_ct (1, cexp, B*To, 1)); every conv / BatchNorm of the context
     generator runs on the kernels (and autograd Functions) of the feature maps, no transposed copies."""
     B, cin, Fq, T = x.shape
     cg = blk.context_gen
-    seq = CtxPoolCm.apply(x)                                                          # (1, cin, B*L, 1)
+    seq = CtxPoolCm.apply(x, hand_over)                                               # (1, cin, B*L, 1)
     gj = PwConv.apply(seq, cg.joint_conv.weight)
     g = BnAct.apply(gj, cg.joint_norm.weight, cg.joint_norm.bias, cg.joint_norm, HSWISH)
     h_cf, h_ct, h_c = CtxSplit.apply(g, B, Fq, T, blk.cnf.stride)
@@ -521,8 +530,9 @@ class DyBlockMain(torch.autograd.Function):
     pass and enters the expand data-gradient GEMM as its `res` operand."""
 
     @staticmethod
-    def forward(ctx, blk, fused, x, att, coef, g_cf, g_ct, w_e, w_d, w_p, ge, be, gd, bd, gp, bp):
+    def forward(ctx, blk, fused, hand_over, x, att, coef, g_cf, g_ct, w_e, w_d, w_p, ge, be, gd, bd, gp, bp):
         cnf = blk.cnf
+        ctx.hand_over = hand_over
         x = x.contiguous()
         B, cin, Fq, T = x.shape
         cexp, cout, k, stride = cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
@@ -634,8 +644,12 @@ class DyBlockMain(torch.autograd.Function):
             else:
                 datt = torch.stack([datt_d, datt_p])
                 dwe = None
-        return (None, None, dx, datt, dcoef, dgf, dgt, dwe, dbank_d.view_as(w_d), dbank_p.view_as(w_p), dge, dbe, dgd, dbd,
-                dgp, dbp)
+        if ctx.hand_over is not None and ctx.needs_input_grad[3]:
+            ctx.hand_over["dx"] = dx                  # collected (and added to the pools' gradient) by CtxPoolCm.backward
+            _pending.add(id(ctx.hand_over))
+            dx = None
+        return (None, None, None, dx, datt, dcoef, dgf, dgt, dwe, dbank_d.view_as(w_d), dbank_p.view_as(w_p), dge, dbe, dgd,
+                dbd, dgp, dbp)
 
 
 def _block_train_fused(blk, x):
@@ -644,7 +658,9 @@ def _block_train_fused(blk, x):
     k, stride, cexp = cnf.kernel, cnf.stride, cnf.expanded_channels
     Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
     fused = _FUSED_DW and To <= 512 and ops.dw_bwd_merged_ok((B, cexp, Fo, To), (B, cexp, Fq, T), k, stride)
-    h_c, g_cf, g_ct = _context_cm(blk, x) if fused else _context(blk, x)
+    # (x needs a gradient: then the context path's backward always runs after the main path's and collects its dx)
+    hand_over = {} if (fused and x.requires_grad) else None
+    h_c, g_cf, g_ct = _context_cm(blk, x, hand_over) if fused else _context(blk, x)
     convs = ([blk.exp_conv] if blk.has_expand else []) + [blk.depth_conv, blk.proj_conv]
     da = blk.depth_act
     wb = []
@@ -654,7 +670,7 @@ def _block_train_fused(blk, x):
     temps = tuple(float(cv.temperature) for cv in convs)
     att, coef = _HcHeads.apply(h_c, da.lambdas, da.init_v, temps, cnf.expanded_channels, *wb)
     e = blk.has_expand
-    return DyBlockMain.apply(blk, fused, x, att, coef, g_cf, g_ct, blk.exp_conv.weight if e else None, blk.depth_conv.weight,
+    return DyBlockMain.apply(blk, fused, hand_over, x, att, coef, g_cf, g_ct, blk.exp_conv.weight if e else None, blk.depth_conv.weight,
                              blk.proj_conv.weight, blk.exp_norm.weight if e else None, blk.exp_norm.bias if e else None,
                              blk.depth_norm.weight, blk.depth_norm.bias, blk.proj_norm.weight, blk.proj_norm.bias)
 
@@ -680,6 +696,9 @@ def forward_train(model, x, return_fmaps=False):
     """Train-mode `(logits, embedding)` - or `(logits, fmaps)`, models/dymn/model.py:157-195 - of DyMN with autograd
     support (models/dymn/model.py:185-200).  The fully-convolutional head (:119-130) runs as torch ops on the last 4 x 32
     map (its class count, 527, is not a multiple of 4, which the library's data-gradient GEMM needs)."""
+    if _pending:
+        _pending.clear()
+        raise _lib.EatHipError("DyMN backward: a block's input gradient was handed over but never collected")
     ops.zero_arena.begin("dymn_step")          # one zero-filled arena per step (forward + the backward autograd runs later)
     with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters:
         return _forward_train(model, x, return_fmaps)

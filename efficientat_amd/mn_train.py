@@ -436,12 +436,12 @@ class MNTrainFunction(torch.autograd.Function):
                     g_e, gparts = ops.dw_conv_dgrad_g(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
                                                       rec["z_e"], st_e[0], st_e[1], act)
                 del dz_d
-                Gx = ops.pw_conv_wgrad(g_e, inp)
                 frozen = getattr(st_e[2], "_eat_frozen", False)
-                Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
                 n_e = inp.shape[0] * inp.shape[2] * inp.shape[3]
+                Gx = ops.pw_conv_wgrad(g_e, inp)
+                Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
                 dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
-                                                                 frozen=frozen)
+                                                                 frozen=frozen, centered=not frozen)
                 g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
                 g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
                 S_e = inp.shape[2] * inp.shape[3]
@@ -599,14 +599,16 @@ class MNTrainFunction2(torch.autograd.Function):
                         forked = True
                         torch.cuda.set_stream(side_s)
                     try:
-                        G = ops.gram(inp, exact=exact)                           # Gram matrix of the block input (reproducible)
+                        # centred Gram matrix of the block input (reproducible; x - mean on load: the variance is not a
+                        # difference of two (mean / std)^2-times larger sums)
+                        G = ops.gram(inp, exact=exact, sx=sx)
                         if W.shape[1] <= 192:
-                            Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e)   # T = W G and the BatchNorm state, one launch
+                            Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e, centered=True)   # T = W Gc and the BatchNorm state, one launch
                         else:
                             # wide inputs (mn40: up to 640 channels): every block of the one-launch form would stream the whole
                             # G from L2 (C_out x C_in^2 floats: 0.79 ms at 3840 x 640) - W G on the matrix cores instead
                             Tm = ops.linear(W, G, None, NONE)
-                            st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e)
+                            st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e, centered=True)
                     finally:
                         if forked:
                             torch.cuda.set_stream(main_s)

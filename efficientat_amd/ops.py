@@ -373,13 +373,22 @@ def pw_conv_cat(x1, x2, wp, bias, Co, act, res=None):
     return y
 
 
-def gram(x, exact=False):
+def gram(x, exact=False, sx=None):
     """G (C, C) = sum_{b,s} x x^T, bit-reproducible from run to run: every block of the weight-gradient kernel adds into
     its own zeroed copy and the copies are summed in a fixed order (the BatchNorm statistics of the expand conv follow
-    from G - csrc/train_fuse.hip - so its round-off decides on which side of a ReLU / Hardswish kink activations fall)."""
+    from G - csrc/train_fuse.hip - so its round-off decides on which side of a ReLU / Hardswish kink activations fall).
+    sx (C,) = sum_{b,s} x: the CENTRED matrix Gc = sum (x - m)(x - m)^T, m = sx / n, instead (`centered=True` in
+    `gram_bn_state*` / `expand_bwd_coef`): the variance w^T Gc w / n is then not a difference of two large sums."""
     B, C = x.shape[0], x.shape[1]
     S = x.numel() // (B * C)
     mode = 1 if exact else 0
+    if sx is not None:
+        slots = int(_lib.lib().eat_pw_wgrad_slots(B, C, C, S, mode, 1))
+        G = zero_arena.zeros((C, C), torch.float32, x.device)
+        ws = zero_arena.zeros((2 * C + slots * C * C,), torch.float32, x.device)
+        _lib.call("eat_gram_centered", _dev(x, "x"), _dev(sx, "sx"), 1.0 / (B * S), G.data_ptr(), ws.data_ptr(), slots, B, C,
+                  S, mode, _stream())
+        return G
     slots = int(_lib.lib().eat_pw_wgrad_slots(B, C, C, S, mode, 1))
     G = zero_arena.zeros((C, C), torch.float32, x.device)
     ws = zero_arena.zeros((slots, C, C), torch.float32, x.device)
@@ -468,7 +477,7 @@ def bn_state_from_partials(parts, bn, n):
     return out[0], out[1], out[2], out[3]
 
 
-def gram_bn_state(Tm, W, sx, bn, n):
+def gram_bn_state(Tm, W, sx, bn, n, centered=False):
     """(a, b, mean, invstd) of the TRAINING BatchNorm after the 1x1 conv z = W x from Tm = W G, sx (Gram matrix / sum of
     the conv input): see csrc/train_fuse.hip."""
     Co, Ci = W.shape
@@ -476,12 +485,12 @@ def gram_bn_state(Tm, W, sx, bn, n):
     _lib.call("eat_gram_bn_finalize", _dev(Tm, "Tm"), _dev(W, "W"), _dev(sx, "sx"), Co, Ci, _dev(bn.weight, "gamma"),
               _dev(bn.bias, "beta"), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn),
               float(bn.eps), float(n), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
-              _stream())
+              1 if centered else 0, _stream())
     bn_counters.bump(bn)
     return out[0], out[1], out[2], out[3]
 
 
-def gram_bn_state_g(G, W, sx, bn, n):
+def gram_bn_state_g(G, W, sx, bn, n, centered=False):
     """`gram_bn_state` straight from the Gram matrix G: -> (Tm = W G, (a, b, mean, invstd)); one launch, fp64 inside."""
     Co, Ci = W.shape
     out = torch.empty((4 * Co + Co * Ci,), device=W.device, dtype=torch.float32)
@@ -489,7 +498,7 @@ def gram_bn_state_g(G, W, sx, bn, n):
     _lib.call("eat_gram_bn_finalize_g", _dev(G, "G"), _dev(W, "W"), _dev(sx, "sx"), Co, Ci, _dev(bn.weight, "gamma"),
               _dev(bn.bias, "beta"), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn),
               float(bn.eps), float(n), Tm.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
-              st[3].data_ptr(), _stream())
+              st[3].data_ptr(), 1 if centered else 0, _stream())
     bn_counters.bump(bn)
     return Tm, (st[0], st[1], st[2], st[3])
 
@@ -630,7 +639,7 @@ def stem_bwd(dy, x, W, a, b, act, dy2=None):
     return gx, (s1, 1, 1)
 
 
-def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, need_dx=True):
+def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, need_dx=True, centered=False):
     """-> (dW, dgamma, dbeta, WaT (Ci,Co), M (Ci,Ci), c0 (Ci)): backward of conv1x1 -> BN(train) -> act without dz."""
     gpart, outer, inner = gparts
     Co, Ci = W.shape
@@ -643,7 +652,7 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, nee
     _lib.call("eat_expand_bwd_coef", _dev(W, "W"), _dev(Gx, "Gx"), _dev(Tm, "Tm"), _dev(sx, "sx"), gpart.data_ptr(),
               outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 1 if frozen else 0,
               dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), tr[0].data_ptr(), tr[1].data_ptr(), tr[2].data_ptr(),
-              w2e[Ci].data_ptr(), _stream())
+              w2e[Ci].data_ptr(), 1 if centered else 0, _stream())
     if frozen or not need_dx:
         return dW, vec[0], vec[1], tr[0], None, None
     Mc = linear(w2e, tr[1], None, ACT_NONE)                                # [W2T ; e1] . WT^T -> (Ci + 1, Ci)

@@ -176,18 +176,29 @@ int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, con
                              float* running_mean, float* running_var, float momentum, float eps, double n, float* a,
                              float* b, float* mean, float* invstd, eat_stream_t stream);
 
+/* Centred Gram matrix of a conv input x (B, C, S) (the statistics of the conv1x1 -> nn.BatchNorm2d pair of
+ * models/mn/block_types.py:138-147 without reading the conv output): Gc = sum_{b,s} (x - m)(x - m)^T, m = sx * inv_n the
+ * channel means - both operands of the weight-gradient kernel are centred on load.  w^T Gc w = sum (z - w.m)^2 is n var(z)
+ * DIRECTLY: with the plain Gram matrix the variance is the difference of two sums (mu/sigma)^2 times larger (a channel
+ * with |mean| = 30 std loses 3 digits), and an error of the mean enters only in second order.  ws / n_slots as
+ * eat_pw_conv_wgrad_ws (n_slots >= eat_pw_wgrad_slots(B, C, C, S, exact, 1): bit-reproducible). */
+int eat_gram_centered(const float* x, const float* sx, float inv_n, float* G, float* ws, int n_slots, int B, int C, int S,
+                      int exact_fp32, eat_stream_t stream);     /* ws: 2*C + n_slots*C*C floats, zero-filled */
+
+
 /* BatchNorm state of the expand conv z = W x (models/mn/block_types.py:138-147) from the Gram matrix of its input:
  * Tm = W G (Co x Ci) with G = sum_{b,s} x x^T, sx = sum_{b,s} x (Ci): sum z = W sx, sum z^2 = rowsum(Tm .* W).
+ * centered != 0: G is eat_gram_centered's Gc: var = rowsum(Tm .* W) / n.
  * The (3-6x wider) tensor z is not read for its statistics. Outputs as eat_bn_finalize. */
 int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int Co, int Ci, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                         double n, float* a, float* b, float* mean, float* invstd, eat_stream_t stream);
+                         double n, float* a, float* b, float* mean, float* invstd, int centered, eat_stream_t stream);
 
-/* The same from G itself (Ci x Ci, symmetric): Tm = W G (Co x Ci) is formed in fp64 inside and written out (the backward's
+/* The same from G itself (Ci x Ci): Tm = W G (Co x Ci) is formed in fp64 inside and written out (the backward's
  * eat_expand_bwd_coef reads it) - no separate GEMM launch for W G. */
 int eat_gram_bn_finalize_g(const float* G, const float* W, const float* sx, int Co, int Ci, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, double n,
-                           float* Tm, float* a, float* b, float* mean, float* invstd, eat_stream_t stream);
+                           float* Tm, float* a, float* b, float* mean, float* invstd, int centered, eat_stream_t stream);
 
 /* g = dy * act'(a[c] z + b[c]) (g may alias dy) and gpart[b*C + c] = sum_s g: the first half of the backward of
  * act(BatchNorm(z)) as a stand-alone pass (geometries where eat_dw_conv_dgrad_g has no fused kernel). */
@@ -231,11 +242,12 @@ int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* in_a, const 
  *   dW  = diag(a) [Gx - m1 sx^T - diag(m2 invstd)(Tm - mean sx^T)]
  * and the operands of dx = WaT g + M x + c0 (two eat_pw_conv_fwd launches), all Ci x Co transposes so that
  * eat_linear_fwd (which contracts over the contiguous axis) forms M = W2T . WT^T (Ci x Ci) and c0 = e1 . WT^T (Ci):
- *   WaT = (diag(a) W)^T,  WT = W^T,  W2T = -(diag(a m2 invstd) W)^T,  e1 = a (m2 invstd mean - m1) (Co). */
+ *   WaT = (diag(a) W)^T,  WT = W^T,  W2T = -(diag(a m2 invstd) W)^T,  e1 = a (m2 invstd mean - m1) (Co).
+ * centered != 0: Tm = W Gc (eat_gram_centered), i.e. "Tm - mean sx^T" is already inside the operand. */
 int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart, int outer,
                         int inner, int Co, int Ci, const float* a, const float* mean, const float* invstd, double n,
                         int frozen, float* dW, float* dgamma, float* dbeta, float* WaT, float* WT, float* W2T, float* e1,
-                        eat_stream_t stream);
+                        int centered, eat_stream_t stream);
 
 /* eat_dw_conv_bwd_g with the BatchNorm + activation backward of the depthwise conv's OWN output evaluated on load
  * (autograd through models/mn/block_types.py:150-162 -> :72-83): dy (B,C,Fo,To) is the gradient w.r.t. act(BN(z)) - for a
@@ -559,6 +571,12 @@ int eat_pw_stream_mode(int mode);
  * gradients autograd computes for the context-path Linear / 1x1-conv layers of DyMN (models/dymn/dy_block.py:235-254,
  * `conv_f`, `conv_t`, `joint_conv` biases; ex_audioset.py:150-153 `loss.backward()`). */
 int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_t stream);
+
+/* Measurement support (bench.py --calibrate-traffic; not on the hot path - the reference has no counterpart): copy n
+ * floats (n % 4 == 0) with a chosen access width, mode 0 = 16 B / lane global loads, 1 = 16 B / lane LDS-DMA loads,
+ * 2 = 4 B / lane, 3 = 8 B / lane.  4 n bytes are read and 4 n written: the known byte count against which the
+ * rocprofv3 FETCH_SIZE / WRITE_SIZE readings of the same pass are calibrated (gfx950 reports wide reads at half size). */
+int eat_calib_copy(const float* src, float* dst, long long n, int mode, eat_stream_t stream);
 
 /* Mix-up of a batch with itself (ex_audioset.py:142-148, helpers/utils.py:90-95): out[b] = x[b]*lam[b] + x[perm[b]]*(1-lam[b]);
  * x, out (B, n) fp32 (n = the flattened per-sample size), perm (B) int32, lam (B) fp32.  out must not alias x. */

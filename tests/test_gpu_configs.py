@@ -136,12 +136,17 @@ def test_dymn20_eval_matches_oracle(dymn20_case):
     for i, (a, b) in enumerate(zip(fmaps, ref_fmaps)):
         assert a.shape == b.shape
         assert _rel(a, b) < 2e-4, (i, _rel(a, b))
-    scale = np.maximum(1.0, np.abs(ref_logits.numpy()).max(axis=1, keepdims=True))   # per-sample logit scale
-    assert (np.abs(logits.cpu().numpy() - ref_logits.numpy()) / scale).max() < 1e-3
-    assert (np.abs(logits2.cpu().numpy() - ref_logits.numpy()) / scale).max() < 1e-3
+    # north_star: logits within 1e-3 ABSOLUTE of the reference CPU path (|logit| reaches ~12 on this model)
+    e1, e2 = np.abs(logits.cpu().numpy() - ref_logits.numpy()).max(), np.abs(logits2.cpu().numpy() - ref_logits.numpy()).max()
+    print(f"dymn20 eval logits: max abs err {e1:.2e} / {e2:.2e} on |logit| <= {np.abs(ref_logits.numpy()).max():.1f}")
+    assert e1 < 1e-3 and e2 < 1e-3, (e1, e2)
 
 
-def test_dymn20_train_step_matches_oracle(dymn20_case):
+@pytest.mark.parametrize("prec", ["fp32", "auto"])
+def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
+    """fp32: exact fp32 GEMMs - SURVEY 8c's gradient bar (rel-L2 <= 1e-2 per tensor).  auto (what bench.py times): split
+    bf16 operands from C_in = 40 on, ~1e-5 relative noise per GEMM, i.e. ~100x as many activation-kink flips as fp32
+    re-association: 5e-2 per tensor, 2e-2 median (see test_gpu_dymn.py::test_dymn10_train_step_matches_oracle)."""
     d = dymn20_case
     y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
     keep = (torch.rand(4, 2560, generator=torch.Generator().manual_seed(6)) < 0.8).float()
@@ -152,13 +157,14 @@ def test_dymn20_train_step_matches_oracle(dymn20_case):
     loss_ref.backward()
 
     model = _dymn20(d["sd"], d["temp"]).train()
+    model.train_precision = prec
     model._drop_mask_override = keep
     logits, emb = model(d["x"].to(DEV))
     loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
     loss.backward()
     assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
-    scale = max(1.0, float(logits_ref.abs().max()))
-    assert float((logits.detach().cpu() - logits_ref.detach()).abs().max()) < 1e-3 * scale
+    lerr = float((logits.detach().cpu() - logits_ref.detach()).abs().max())
+    assert lerr < 1e-3, lerr                                           # absolute, |logit| up to ~12
     gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
     rels, bad = [], []
     for name, p in model.named_parameters():
@@ -168,10 +174,11 @@ def test_dymn20_train_step_matches_oracle(dymn20_case):
             continue
         r = _rel(p.grad, ref)
         rels.append(r)
-        if r > 5e-2:
+        if r > (1e-2 if prec == "fp32" else 5e-2):
             bad.append((name, r))
+    print(f"dymn20 train step [{prec}]: logits max abs err {lerr:.2e}, gradient rel-L2 median {np.median(rels):.2e}, max {max(rels):.2e}")
     assert not bad, bad[:8]
-    assert float(np.median(rels)) < 1e-2, float(np.median(rels))
+    assert float(np.median(rels)) < (3e-3 if prec == "fp32" else 2e-2), float(np.median(rels))
     msd = model.state_dict()
     for k, v in stats.items():
         assert _rel(msd[k], v) < 1e-4, k
@@ -382,7 +389,8 @@ def test_mn40_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(mn40_ca
         _check_tiled(runs[1], runs[16], 8, bufs[1], bufs[16], grad_tol=1.0, fwd_tol=1e-3, med_tol=0.25)
 
 
-def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn20_case):
+@pytest.mark.parametrize("prec", ["fp32", "auto"])
+def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn20_case, prec):
     """configs[3] at its batch size: 32 copies of the 4 clips of test_dymn20_train_step_matches_oracle."""
     d = dymn20_case
     y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
@@ -390,11 +398,113 @@ def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn2
     runs, bufs = {}, {}
     for reps in (1, 32):
         model = _dymn20(d["sd"], d["temp"]).train()
+        model.train_precision = prec
         runs[reps] = _tiled_step(model, d["x"], y, keep, reps)
         bufs[reps] = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
         del model
         torch.cuda.empty_cache()
-    _check_tiled(runs[1], runs[32], 4, bufs[1], bufs[32])
+    # per-tensor bar 5e-2 as in the dymn10 / dymn20 oracle tests of the default arithmetic: the 4-value bias gradients of
+    # the kernel-attention Linears are sums over the batch of softmax-Jacobian rows (which sum to zero over K) - the
+    # tensors with the least signal per kink flip
+    # (auto: the ~1e-5 noise of the split-operand GEMMs differs between the two regimes' tilings - more kink flips)
+    _check_tiled(runs[1], runs[32], 4, bufs[1], bufs[32], grad_tol=5e-2, med_tol=5e-3 if prec == "fp32" else 1e-2)
+
+
+# ------------------------------------------------------------------ DISTINCT clips at the measured batch sizes: permutation
+# The tiled tests above fill the batch with copies, so an indexing error whose period divides the copy length (a kernel
+# reading sample b +- 8, a wrong plane stride inside a several-samples-per-wave mode, a split-K slot mixing samples) returns
+# the right values and stays invisible.  Here every clip of the batch is different: a permutation of the batch must permute
+# the logits and leave the loss, every parameter gradient and every BatchNorm running statistic unchanged up to the order
+# of the floating-point sums (plus, rarely, an activation within ~1e-7 of a kink changing side: SURVEY 8c).
+def _distinct_batch(B, n_out, seed):
+    g = torch.Generator().manual_seed(seed)
+    amp = 10.0 ** (-2.0 + 2.0 * torch.rand(B, 1, generator=g))                    # 0.01 ... 1 per clip
+    wave = (amp * torch.randn(B, 320000, generator=g)).clamp_(-1, 1)
+    tone = torch.sin(torch.arange(320000)[None, :] * (2 * 3.14159265 * (50.0 + 200.0 * torch.arange(B)[:, None]) / 32000.0))
+    wave = (0.7 * wave + 0.05 * tone * (torch.arange(B)[:, None] % 3 == 0)).clamp_(-1, 1)
+    mel = AugmentMelSTFT(n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, freqm=0, timem=0).to(DEV).eval()
+    with torch.no_grad():
+        x = mel(wave.to(DEV)).unsqueeze(1)
+    y = (torch.rand(B, 527, generator=g) < 0.01).float().to(DEV)
+    keep = (torch.rand(B, n_out, generator=g) < 0.8).float()
+    return x, y, keep
+
+
+def _permutation_check(make_model, B, n_hidden, seed):
+    """Three steps from the same weights: the batch as it is, the batch permuted, and (control) the batch as it is with
+    one-ulp noise on the input (x * (1 + 2^-23 * N(0,1))).  The synthetic networks amplify round-off by 10^3 ... 10^4
+    (i.i.d. 1e-5 on the mel moves logits by up to 5e-4; batch statistics are perturbed coherently), so the
+    absolute size of the permutation's effect says little; what it must NOT exceed is the effect of round-off-sized noise
+    (x 5 + a floor).  A sample-indexing error puts a different clip's data into some sum: an O(1) error in the affected
+    tensors, orders of magnitude above either."""
+    x, y, keep = _distinct_batch(B, n_hidden, seed)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(seed + 1))
+    ident = torch.arange(B)
+    noise = 1.0 + 2.0 ** -23 * torch.randn(x.shape, generator=torch.Generator().manual_seed(seed + 2)).to(DEV)
+    outs = []
+    for order, xin in ((ident, x), (perm, x), (ident, x * noise)):
+        model = make_model()
+        model._drop_mask_override = keep[order]
+        logits, _ = model(xin[order.to(DEV)].contiguous())
+        loss = F.binary_cross_entropy_with_logits(logits, y[order.to(DEV)])
+        loss.backward()
+        grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+        bufs = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        outs.append((loss.item(), logits.detach().cpu(), grads, bufs))
+        del model
+        torch.cuda.empty_cache()
+    (l0, lg0, g0, b0), (l1, lg1, g1, b1), (l2, lg2, g2, b2) = outs
+    scale = max(1.0, float(lg0.abs().max()))
+    gmax = max(float(v.norm()) for v in g0.values())
+    names = [n for n, v in g0.items() if float(v.norm()) >= 1e-4 * gmax]
+
+    def dev(lg, g, order):
+        rels = [_rel(g[n], g0[n]) for n in names]
+        return float((lg - lg0[order]).abs().max()), max(rels), float(np.median(rels))
+
+    p_log, p_max, p_med = dev(lg1, g1, perm)
+    c_log, c_max, c_med = dev(lg2, g2, ident)
+    print(f"{B} distinct clips - permutation: logits {p_log:.1e}, gradient rel-L2 median {p_med:.1e} / max {p_max:.1e};  "
+          f"one-ulp input noise (control): logits {c_log:.1e}, median {c_med:.1e} / max {c_max:.1e}")
+    assert abs(l1 - l0) < 5 * abs(l2 - l0) + 2e-6 * max(1.0, abs(l0)), (l0, l1, l2)
+    assert p_log < 5 * c_log + 1e-5 * scale, (p_log, c_log)          # every clip keeps ITS logits wherever it sits in the batch
+    assert p_max < 5 * c_max + 1e-3, (p_max, c_max)
+    assert p_med < 5 * c_med + 1e-4, (p_med, c_med)
+    for k, v in b0.items():
+        assert _rel(b1[k], v) < 5 * _rel(b2[k], v) + 1e-5, k
+
+
+def test_mn10_train_step_batch_256_distinct_clips_permutation(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
+    sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+
+    def make():
+        model = _quiet(mn_mod.get_model, width_mult=1.0)
+        model.load_state_dict(sd, strict=True)
+        model.train_precision = "auto"                       # the arithmetic bench.py times
+        return model.to(DEV).train()
+
+    _permutation_check(make, 256, 1280, seed=101)
+
+
+def test_mn40_train_step_batch_128_distinct_clips_permutation(mn40_case):
+    d = mn40_case
+
+    def make():
+        model = _quiet(mn_mod.get_model, width_mult=4.0)
+        model.load_state_dict(d["sd"], strict=True)
+        model.train_precision = "auto"
+        return model.to(DEV).train()
+
+    _permutation_check(make, 128, 5120, seed=202)
+
+
+def test_dymn20_train_step_batch_128_distinct_clips_permutation(dymn20_case):
+    d = dymn20_case
+    _permutation_check(lambda: _dymn20(d["sd"], d["temp"]).train(), 128, 2560, seed=303)
 
 
 # ------------------------------------------------------------------ BASELINE widths against the reference's own outputs

@@ -18,7 +18,7 @@ if has dymnstats; then
   head -45 $OUT/dymn20_rocprof_kernel_stats.csv; cat $OUT/rocprof_dymn.json
 fi
 if has unit; then
-  timeout 900 python -m pytest ${UNIT:-tests/test_gpu_train_fuse.py} -q -x --tb=short 2>&1 | grep -v "^  /usr\|Warning" | tail -60 > $OUT/unit.log; tail -40 $OUT/unit.log
+  timeout 1500 python -m pytest ${UNIT:-tests/test_gpu_train_fuse.py} -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" | tail -60 > $OUT/unit.log; tail -40 $OUT/unit.log
 fi
 if has full; then
   timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" > $OUT/full.log; tail -40 $OUT/full.log
@@ -49,6 +49,19 @@ if has rocprof; then
   find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats.csv \;
   rm -rf $OUT/stats
   head -30 $OUT/rocprof_kernel_stats.csv
+fi
+if has pmc; then
+  PROF_ARGS="--calibrate-traffic --no-cpu-baseline --no-fp32-exact --no-train-configs --no-profile --steps 2 --warmup 1 --no-graph ${PMC_EXTRA:-}"
+  for pass in "f FETCH_SIZE" "w WRITE_SIZE" "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    set -- $pass; name=$1; shift
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $* -d $GRAFT_REPO_ROOT/$OUT/pmc_$name -o $name --output-format csv -- \
+        python $GRAFT_REPO_ROOT/bench.py $PROF_ARGS > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$name.log) || echo "pmc pass $name failed/timed out"
+  done
+  F=$(find $OUT/pmc_f -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py $F $W $OUT/pmc_traffic_${PMC_TAG:-r4}.json
+  S=$(find $OUT/pmc_sq1 -name "*counter_collection.csv" | head -1)
+  python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r4}.json $S > $OUT/pmc_sq_${PMC_TAG:-r4}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r4}.txt
+  rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq1
 fi
 if has script; then
   timeout ${SCRIPT_TIMEOUT:-600} bash -c "$SCRIPT" > $OUT/script.log 2>&1; tail -60 $OUT/script.log

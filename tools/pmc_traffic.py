@@ -43,9 +43,20 @@ def main(fetch_csv, write_csv, out_json):
     for k in sorted(f):
         out[k] = {"launches_sampled": nf[k], "grid_size": grid[k], "fetch_kib": f[k], "write_kib": w.get(k, 0.0),
                   "raw_bytes_per_launch": int((f[k] + w.get(k, 0.0)) * 1024)}
-    json.dump({"formula": "raw FETCH_SIZE / WRITE_SIZE (KiB) per launch, largest-grid launches only; the gfx950 x2 on "
-                          "FETCH_SIZE is applied by bench.py per kernel, calibrated on the kernel's compulsory read bytes",
-               "kernels": out}, open(out_json, "w"), indent=1)
+    doc = {"formula": "raw FETCH_SIZE / WRITE_SIZE (KiB) per launch, largest-grid launches only; bench.py multiplies them by the "
+                      "calibration factors below (known bytes of eat_calib_copy / its counter reading in the SAME pass), chosen "
+                      "by the access width of the kernel's loads",
+           "kernels": out}
+    # calibration copies (bench.py --calibrate-traffic): 2^28 floats = 1 GiB read and 1 GiB written per launch
+    known = float(1 << 30)
+    cls = {"calib_copy_kernel<0>": "b16", "calib_copy_kernel<1>": "lds16", "calib_copy_kernel<2>": "b4", "calib_copy_kernel<3>": "b8"}
+    if all(k in out for k in cls):
+        doc["calibration"] = {
+            "known_bytes_read_and_written_per_launch": int(known),
+            "fetch_factor": {c: known / (out[k]["fetch_kib"] * 1024) for k, c in cls.items()},
+            "write_factor": {c: known / (out[k]["write_kib"] * 1024) for k, c in cls.items()},
+            "raw": {c: {"fetch_kib": out[k]["fetch_kib"], "write_kib": out[k]["write_kib"]} for k, c in cls.items()}}
+    json.dump(doc, open(out_json, "w"), indent=1)
     print(f"wrote {out_json}: {len(out)} kernels")
 
 
