@@ -88,8 +88,15 @@ def enable_data_parallel(model, process_group=None, bucket_bytes=4 << 20, broadc
                 dist.broadcast(t, src=0, group=process_group)
     reducer = GradReducer(process_group, bucket_bytes, force_buckets=force_buckets)
     if getattr(model, "_monolithic_backward", False):
-        # MN: the single backward Function pushes gradients itself as it produces them (mn_train.py)
+        # MN: the single backward Function pushes gradients itself as it produces them (mn_train.py) ...
         model._grad_reducer = reducer
+        # ... except in trunk mode (non-default heads, train-mode return_fmaps), where the head runs under torch autograd
+        # on top of the trunk Function: its parameters get post-accumulate hooks feeding a reducer of their own, active
+        # only while `forward_train` has flagged trunk mode (in the default mode the Function returns - and has already
+        # reduced - the head's gradients: a second reduction would average twice)
+        head = [n for n, _ in model.named_parameters() if n.startswith("classifier.")]
+        install_grad_hooks(model, GradReducer(process_group, bucket_bytes, force_buckets=force_buckets), only=head,
+                           active=lambda: getattr(model, "_eat_trunk_active", False))
     else:
         # DyMN and any autograd-driven module: per-parameter post-accumulate hooks feed the same
         # bucketed reducer; a callback queued on the autograd engine averages at the end of backward
@@ -97,9 +104,11 @@ def enable_data_parallel(model, process_group=None, bucket_bytes=4 << 20, broadc
     return model
 
 
-def install_grad_hooks(model, reducer):
+def install_grad_hooks(model, reducer, only=None, active=None):
+    """only: restrict the hooks to these parameter names; active: callable - the hooks pass while it returns False."""
     names = {p: n for n, p in model.named_parameters()}
     state = {"pending": False}
+    only = set(only) if only is not None else None
 
     def finalize():
         out = reducer.finish()
@@ -111,15 +120,15 @@ def install_grad_hooks(model, reducer):
                     p.grad.copy_(g)
 
     def hook(p):
-        if not reducer.bucketed:
+        if not reducer.bucketed or (active is not None and not active()):
             return
         if not state["pending"]:
             state["pending"] = True
             torch.autograd.Variable._execution_engine.queue_callback(finalize)
         reducer.push(names[p], p.grad)
 
-    for p in model.parameters():
-        if p.requires_grad:
+    for n, p in model.named_parameters():
+        if p.requires_grad and (only is None or n in only):
             p.register_post_accumulate_grad_hook(hook)
     model._grad_hooks_reducer = reducer
     return model

@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 from .dp import GradReducer
 
 NONE, RELU, HSWISH, SIGMOID = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_HSWISH, ops.ACT_SIGMOID
@@ -64,7 +64,7 @@ def _prepack_plan(model):
     entries += [(("l",), lw, False), (("lt",), lw, True)]
     try:
         plan = ops.PrepackPlan(entries)
-    except Exception:                                     # odd channel counts: per-matrix packs (which check for themselves)
+    except _lib.EatHipError:                              # odd channel counts: per-matrix packs (which check for themselves)
         plan = None
     model._eat_prepack_plan = plan
     return plan
@@ -282,6 +282,10 @@ class MNTrainFunction(torch.autograd.Function):
         bn_grads(dgam, dbet, nm + ".1.weight", nm + ".1.bias")
         g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
         plan = sv.get("plan")
+        if plan is not None and plan.runs != sv.get("plan_run"):
+            # another forward of the model re-packed the plan's views since this pass's forward (two forwards before one
+            # backward): the views hold the CURRENT weights - pack this backward's operands matrix by matrix instead
+            plan = None
         wpt = _pk(plan, ("lt",), last[0].weight, trans=True)
         dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
         del dz, z_l
@@ -547,7 +551,7 @@ class MNTrainFunction2(torch.autograd.Function):
         plan = _prepack_plan(model)
         if plan is not None:
             plan.run()
-        saved["plan"] = plan
+        saved["plan"], saved["plan_run"] = plan, (plan.runs if plan is not None else 0)
 
         # stem
         stem = model.features[0]
@@ -719,6 +723,7 @@ def forward_train(model, x, return_fmaps=False):
         mask = override.to(x.device).float() / (1.0 - drop.p)
     params = [p for _, p in model.named_parameters()]
     trunk = return_fmaps or model.head_type != "mlp"
+    model._eat_trunk_active = trunk       # dp.py: the head's gradients come from torch autograd then (their own reducer hooks)
     with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters, ops.zero_arena.scope("mn_fwd"):
         if not trunk:
             if _TRAIN_V >= 2:

@@ -1059,7 +1059,10 @@ class PrepackPlan:
         """Parameters were re-allocated (model.to(), a new state dict with fresh storage) or the arithmetic changed."""
         return self.mode != precision.mode or any(t.data_ptr() != p for t, p in zip(self.keep, self.ptrs))
 
+    runs = 0          # number of `run()` calls: a backward that finds it changed knows its views were re-packed since
+
     def run(self):
+        self.runs += 1
         _lib.call("eat_pw_prepack_multi", self.table.data_ptr(), self.n, self.max_threads, _stream())
 
     def get(self, key):

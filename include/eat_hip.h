@@ -20,6 +20,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#pragma GCC visibility push(default)
 
 typedef void* eat_stream_t; /* hipStream_t */
 
@@ -595,6 +597,7 @@ int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, co
                         const long long* teacher_idx, int n_teacher, float kd_lambda, int B, int C, float* sums,
                         float* dlogits, eat_stream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

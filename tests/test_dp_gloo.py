@@ -52,6 +52,52 @@ def test_grad_reducer_world2_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _hook_worker(rank, world, port, ret):
+    """install_grad_hooks(only=..., active=...): the head of an MN in trunk mode (its gradients come from torch autograd,
+    not from the trunk Function) is averaged across ranks while the flag is up, and left alone while it is down."""
+    import torch.nn as nn
+    from efficientat_amd.dp import install_grad_hooks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        m = nn.Module()
+        m.features = nn.Linear(6, 5)
+        m.classifier = nn.Sequential(nn.Linear(5, 4), nn.Linear(4, 3))
+        flag = {"on": True}
+        only = [n for n, _ in m.named_parameters() if n.startswith("classifier.")]
+        install_grad_hooks(m, GradReducer(bucket_bytes=64), only=only, active=lambda: flag["on"])
+        x = torch.randn(8, 6, generator=torch.Generator().manual_seed(10 + rank))
+
+        def grads():
+            m.zero_grad(set_to_none=True)
+            m.classifier(m.features(x)).square().sum().backward()
+            return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+        on = grads()
+        flag["on"] = False
+        off = grads()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: v for k, v in off.items()})
+        ok = True
+        for n in on:
+            mean = sum(g[n] for g in gathered) / world
+            if n in only:
+                ok = ok and torch.allclose(on[n], mean, atol=1e-5) and (world == 1 or not torch.allclose(off[n], mean, atol=1e-5))
+            else:
+                ok = ok and torch.allclose(on[n], off[n])           # the trunk's parameters are not this reducer's business
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_hooks_reduce_only_in_trunk_mode_world2_gloo():
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_hook_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_grad_reducer_single_process_passthrough():
     red = GradReducer()
     t = torch.arange(6.0).view(2, 3)
