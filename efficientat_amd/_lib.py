@@ -95,6 +95,8 @@ SIGNATURES = {
     "eat_dyn_pw_pack_bf16": [_P, _P, _P, _I, _I, _I, _I, _P],
     "eat_pw_conv_dyn_bf16_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_pw_dyn_wgrad_accumulates": [_I, _I, _I],
+    "eat_pw_conv_stat_tiles": [_I, _I, _I],
+    "eat_pw_conv_stats_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dyn_pw_pack_t": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dyn_pw_pack_bf16_t": [_P, _P, _P, _I, _I, _I, _I, _P],
     "eat_ctx_pool_cm": [_P, _P, _I, _I, _I, _I, _P],
@@ -142,6 +144,15 @@ def call(name, *args):
     rc = getattr(h, name)(*args)
     if rc != 0:
         raise EatHipError(f"{name} failed ({rc}): {h.eat_last_error_string().decode()}")
+
+
+def call_rc(name, *args):
+    """Like `call` for the entry points that answer 1 = "not applicable, nothing launched" (the caller takes another path)."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc not in (0, 1):
+        raise EatHipError(f"{name} failed ({rc}): {h.eat_last_error_string().decode()}")
+    return rc
 
 
 def exported_symbols():

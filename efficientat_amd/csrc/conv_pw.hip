@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int kc_arg,
-    int n_stages, int act, int tps, long long wp_bstride, PwTf tf, const float* __restrict__ x2, int c1) {
+    int n_stages, int act, int tps, long long wp_bstride, PwTf tf, const float* __restrict__ x2, int c1,
+    float* __restrict__ stats) {
   // x2 != NULL: channels of x (c1 rows) followed by the channels of x2 (Ci - c1 rows) - see conv_pw_bf16.hip
+  // stats != NULL: per-tile partial sums of the output for the BatchNorm that follows (pw_epilogue_stats)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int kc = PIPE ? kPipeKC : kc_arg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -254,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
   }
 
   eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
+  if (stats) {                                             // block-uniform
+    __syncthreads();                                       // every wave is done with the operand stages: LDS is free
+    eat::pw_epilogue_stats<MTW>(acc, s_bias, smem, stats, tile, mt0, kq, lane, wv, col_ok, Co);
+  }
 }
 
 // y (M,N) = act((x (M,K) * xs) . w (N,K)^T + bias): both operands K-contiguous; each lane loads 4
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 template <int MTW>
 int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias, const float* in_scale,
               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act,
-              bool per_sample, PwTf tf, const float* x2, int c1) {
+              bool per_sample, PwTf tf, const float* x2, int c1, float* stats) {
   const long long N = (long long)B * S;
   const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
   const int n_tiles = per_sample ? B * tps : (int)((N + kTileN - 1) / kTileN);
@@ -352,6 +358,7 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
     n_stages = ((Ci + kc - 1) / kc) > 1 ? 2 : 1;
     smem = (size_t)n_stages * stage_floats(MTW, kc, NS) * sizeof(float);
   }
+  if (stats && smem < (size_t)4 * MTW * 16 * 2 * sizeof(float)) smem = (size_t)4 * MTW * 16 * 2 * sizeof(float);
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: LDS stage too large (%zu B)", smem);
   auto kern = tf.a ? (pipe ? pw_conv_kernel<MTW, true, true> : pw_conv_kernel<MTW, false, true>)
                    : (pipe ? pw_conv_kernel<MTW, true, false> : pw_conv_kernel<MTW, false, false>);
@@ -361,7 +368,7 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
-                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf, x2, c1);
+                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf, x2, c1, stats);
   return eat::check_launch("eat_pw_conv_fwd");
 }
 
@@ -390,13 +397,14 @@ extern "C" int eat_pw_prepack_t(const float* w_t, const float* row_scale, float*
 
 static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,
                        float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s,
-                       PwTf tf = PwTf{nullptr, nullptr, 0}, const float* x2 = nullptr, int c1 = 0) {
+                       PwTf tf = PwTf{nullptr, nullptr, 0}, const float* x2 = nullptr, int c1 = 0, float* stats = nullptr) {
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d must be a multiple of 4", Ci);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
   if (B < 1 || Ci < 4 || Co < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
   const int MT = (Co + 15) / 16;
   if (S % 4 != 0) {    // planes that do not start on 16-byte boundaries (e.g. 40-mel models): plain 4-byte kernel
     if (tf.a) return eat::fail(EAT_EINVAL, "eat_pw_conv_tf_fwd: S=%d must be a multiple of 4", S);
+    if (stats) return 1;                           // no epilogue statistics there: the caller runs the separate pass
     return eat::pw_conv_generic(x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, act, 0,
                                 per_sample ? (long long)(Ci / 4) * MT * 64 * (long long)sizeof(float) : 0, s);
   }
@@ -404,7 +412,7 @@ static int pw_dispatch(const float* x, const float* wp, const float* bias, const
   // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks
   const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block
-#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf, x2, c1);
+#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf, x2, c1, stats);
   switch (mtw) {
     EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4) EAT_PW_CASE(5)
     EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
@@ -458,6 +466,30 @@ extern "C" int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const floa
                                    int B, int Ci, int Co, int S, int act, eat_stream_t stream) {
   eat::clear_stale_error();
   return pw_dispatch(x, wp_b, bias, nullptr, res, y, nullptr, B, Ci, Co, S, act, true, (hipStream_t)stream);
+}
+
+// Train-mode 1x1 conv (no bias / activation / residual: z = W x) with the partial sums of z for the BatchNorm that follows
+// in its epilogue - see pw_epilogue_stats.  wmode: 0 = fp32 pack, 1 = bf16, 2 = bf16 hi / lo; per_sample: wp holds one
+// pack per sample (eat_dyn_pw_pack / eat_dyn_pw_pack_bf16); tf_a / tf_b / tf_act, in_scale: as eat_pw_conv_tf_fwd (NULL:
+// none).  part: eat_pw_conv_stat_tiles(B, S, per_sample) * 2 * Co floats, layout [tile][2][Co] = eat_bn_finalize_partials
+// with outer = tiles, inner = 1.  Returns 1 (and launches nothing) for geometries without the epilogue (S % 4 != 0).
+extern "C" int eat_pw_conv_stat_tiles(int B, int S, int per_sample) {
+  return per_sample ? B * ((S + kTileN - 1) / kTileN) : (int)(((long long)B * S + kTileN - 1) / kTileN);
+}
+
+extern "C" int eat_pw_conv_stats_fwd(const float* x, const void* wp, int wmode, int per_sample, const float* tf_a,
+                                     const float* tf_b, int tf_act, const float* in_scale, const float* zero_bias, float* y,
+                                     float* part, int B, int Ci, int Co, int S, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !wp || !y || !part || !zero_bias) return eat::fail(EAT_EINVAL, "eat_pw_conv_stats_fwd: missing operand");
+  if ((tf_a == nullptr) != (tf_b == nullptr) || tf_act < 0 || tf_act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_stats_fwd: bad transform");
+  if (tf_a && Ci % 8 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_stats_fwd: the on-load transform needs Ci %% 8 == 0");
+  if (S % 4 != 0) return 1;
+  if (wmode == 0)
+    return pw_dispatch(x, reinterpret_cast<const float*>(wp), zero_bias, in_scale, nullptr, y, nullptr, B, Ci, Co, S, EAT_ACT_NONE,
+                       per_sample != 0, (hipStream_t)stream, PwTf{tf_a, tf_b, tf_act}, nullptr, 0, part);
+  return eat::pw_conv_bf16_stats(x, wp, wmode == 2 ? 1 : 0, per_sample, tf_a, tf_b, tf_act, in_scale, zero_bias, y, part, B, Ci,
+                                 Co, S, (hipStream_t)stream);
 }
 
 extern "C" int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,

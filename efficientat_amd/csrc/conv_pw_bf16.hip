@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
-    int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1, int tps, long long wp_bstride) {
+    int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1, int tps, long long wp_bstride,
+    float* __restrict__ stats) {
   // tps > 0: per-sample weights (DyMN dynamic conv, models/dymn/dy_block.py:111-127, on split bf16 operands): a tile lies
   //          inside one sample (tps tiles per sample) and reads that sample's packed weights (wp_bstride elements apart)
   // x2 != NULL ("two-source"): the reduction axis is the channels of x (c1 rows) followed by the channels of x2
@@ -255,13 +256,17 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   }
 
   eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
+  if (stats) {                                             // block-uniform: train-mode statistics of the output (pw_epilogue.h)
+    __syncthreads();                                       // every wave is done with the operand stages: LDS is free
+    eat::pw_epilogue_stats<MTW>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, tile, mt0, kq, lane, wv, col_ok, Co);
+  }
 }
 
 
 template <int MTW, int NPROD>
 int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
            float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf,
-           const float* x2, int c1, bool per_sample) {
+           const float* x2, int c1, bool per_sample, float* stats) {
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
   const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
@@ -290,20 +295,20 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1, tps, wp_bstride);
+                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1, tps, wp_bstride, stats);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
 template <int NPROD>
 int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
              float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0},
-             const float* x2 = nullptr, int c1 = 0, bool per_sample = false) {
+             const float* x2 = nullptr, int c1 = 0, bool per_sample = false, float* stats = nullptr) {
   const int MT = (Co + 15) / 16;
   // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
   // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample);
+#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample, stats);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -369,6 +374,20 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
   const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
   return split ? dispatch<3>(s, x, w16, bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, Ci, tf)
                : dispatch<1>(s, x, w16, bias, in_scale, res, y, nullptr, B, Ci, Co, S, act, Ci, tf);
+}
+}  // namespace eat
+
+// train-mode conv z = W x with the statistics epilogue (eat_pw_conv_stats_fwd, conv_pw.hip)
+namespace eat {
+int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample, const float* tf_a, const float* tf_b,
+                       int tf_act, const float* in_scale, const float* zero_bias, float* y, float* part, int B, int Ci, int Co,
+                       int S, hipStream_t s) {
+  const PwTf tf{tf_a, tf_b, tf_act};
+  const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
+  return split ? dispatch<3>(s, x, w16, zero_bias, in_scale, nullptr, y, nullptr, B, Ci, Co, S, EAT_ACT_NONE, Ci, tf, nullptr, 0,
+                             per_sample != 0, part)
+               : dispatch<1>(s, x, w16, zero_bias, in_scale, nullptr, y, nullptr, B, Ci, Co, S, EAT_ACT_NONE, Ci, tf, nullptr, 0,
+                             per_sample != 0, part);
 }
 }  // namespace eat
 

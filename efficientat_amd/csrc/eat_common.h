@@ -89,6 +89,10 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
                     const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S, int act, int split,
                     hipStream_t s);
 
+int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample, const float* tf_a, const float* tf_b,
+                       int tf_act, const float* in_scale, const float* zero_bias, float* y, float* part, int B, int Ci, int Co,
+                       int S, hipStream_t s);
+
 int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const void* wp, const float* bias, const float* res,
                      float* y, int B, int Co, int S, int act, int split, hipStream_t s);
 

@@ -148,6 +148,52 @@ __device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], 
     }
 }
 
+// Train-mode statistics of the conv output z = acc + bias for the BatchNorm that follows (models/mn/block_types.py:167-171,
+// 177-181 / models/dymn/dy_block.py:313-316, 386-388 under model.train()): per output channel the sum and the sum of squares
+// over the block's 256 columns, written as ONE partial per (column tile, channel): part[(tile * 2 + k) * Co + m] - plain
+// stores, no atomics, reduced in fp64 by eat_bn_finalize_partials (outer = column tiles, inner = 1).  The standalone
+// statistics pass over z (a full read of the conv output) disappears.
+//   lane (kq, c): rows (mt0 + i) * 16 + kq * 4 + r, 4 columns -> 16-lane DPP row reduction (the 16 lanes of a kq group hold
+//   the 64 columns of the wave), then the 4 waves are combined through LDS (`scratch`: >= 4 * MTW * 16 * 2 floats, free
+//   after the k loop - the caller has put a barrier between the loop and this call).
+__device__ __forceinline__ float row16_sum_lane15(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));   // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));   // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));   // row_shr:8
+  return v;                                                // lane 15 of every 16-lane row holds the row's sum
+}
+template <int MTW>
+__device__ __forceinline__ void pw_epilogue_stats(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, float* scratch,
+                                                  float* __restrict__ part, int tile, int mt0, int kq, int lane, int wv,
+                                                  bool col_ok, int Co) {
+  const float ok = col_ok ? 1.0f : 0.0f;
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float bm = s_bias[i * 16 + kq * 4 + r];
+      const float v0 = acc[i][0][r] + bm, v1 = acc[i][1][r] + bm, v2 = acc[i][2][r] + bm, v3 = acc[i][3][r] + bm;
+      float sm = ((v0 + v1) + (v2 + v3)) * ok;
+      float sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, v3 * v3))) * ok;
+      sm = row16_sum_lane15(sm);
+      sq = row16_sum_lane15(sq);
+      if ((lane & 15) == 15) {
+        float* d = scratch + ((wv * MTW + i) * 16 + kq * 4 + r) * 2;
+        d[0] = sm; d[1] = sq;
+      }
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < MTW * 16 * 2; e += 256) {
+    const int row = e >> 1, k = e & 1, m = mt0 * 16 + row;
+    if (m < Co) {
+      const float t = (scratch[(0 * MTW * 16 + row) * 2 + k] + scratch[(1 * MTW * 16 + row) * 2 + k]) +
+                      (scratch[(2 * MTW * 16 + row) * 2 + k] + scratch[(3 * MTW * 16 + row) * 2 + k]);
+      part[((size_t)tile * 2 + k) * Co + m] = t;
+    }
+  }
+}
+
 // `act` is wave-uniform: the project layers (no activation) take a branch without any activation math,
 // ReLU / Hardswish share the branch-free 4-op form (a third specialisation pushed the 7-8 m-tile kernels
 // over 256 VGPRs).

@@ -1478,7 +1478,9 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
       // (512 = one round of two resident blocks per CU; 1024 measured 0.26 ms slower per mn10 step: the second round pays
       // prologue, tail and the Co x Ci atomics again)
       static const int target = getenv("EAT_WGRAD_BLOCKS") ? atoi(getenv("EAT_WGRAD_BLOCKS")) : 512;
-      long long splits = (target + tiles - 1) / tiles;
+      // never MORE than `target` blocks: 516 blocks (6 tiles x 86 slices, the 672 x 112 layers) ran as a full round of 512
+      // resident blocks plus a second round of 4 (183 -> 158 us with 510)
+      long long splits = tiles >= target ? 1 : target / tiles;
       if (splits > total / 16) splits = total / 16;
       if (splits < 1) splits = 1;
       p.upb = (int)((total + splits - 1) / splits);

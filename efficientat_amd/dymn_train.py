@@ -242,7 +242,7 @@ def _bank_grad(G, att, bank):
     return dbank, datt
 
 
-def _dyn_pw(x, bank, att, transposed, res=None):
+def _dyn_pw(x, bank, att, transposed, res=None, stats_bn=None):
     """z_b = W_b x_b (+ res), W_b = sum_k att[b,k] bank[k] (Co, Ci) - or, `transposed`, W_b^T (the data gradient) - of a
     dynamic 1x1 conv (models/dymn/dy_block.py:103-131), in the arithmetic of the active `ops.precision`:
     late small-plane layers as ONE GEMM over the K-concatenated banks (no per-sample weights, ops.kcat_*), elsewhere
@@ -259,7 +259,17 @@ def _dyn_pw(x, bank, att, transposed, res=None):
     # (measured, dymn20 at B = 128: with per-sample weights as bf16 hi / lo fragments the aggregate-and-pack form beats the
     #  K-concat GEMM - 4x the MFMA work - on every layer, 54.4 vs 55.3 ms per step; K-concat stays for geometries the
     #  bf16 pack does not take)
-    if ops.dyn_bf16_eligible(Co, Ci, S):
+    bf16 = ops.dyn_bf16_eligible(Co, Ci, S)
+    if stats_bn is not None:
+        # forward conv followed by a BatchNorm: -> (z, BatchNorm state); the batch statistics leave the conv's epilogue
+        if stats_bn.training and _EPI_STATS and (bf16 or not ops.kcat_eligible(Co, Ci, S)):
+            wp = ops.dyn_pw_pack_bf16(bank2, att, Co, Ci) if bf16 else ops.dyn_pw_pack(bank2, att, Co, Ci)
+            z, parts = ops.pw_conv_stats(x, wp, Co, per_sample=True)
+            if z is not None:
+                return z, ops.bn_state_from_partials(parts, stats_bn, z.numel() // Co)
+        z = _dyn_pw(x, bank, att, transposed)
+        return z, ops.bn_train_state(z, stats_bn)
+    if bf16:
         return ops.pw_conv_dyn_bf16(x, ops.dyn_pw_pack_bf16(bank2, att, Co, Ci, trans=tr), zero, Co, NONE, res=res)
     if ops.kcat_eligible(Co, Ci, S):
         if tr:
@@ -456,6 +466,7 @@ def _block_train(blk, x):
 import os as _os
 
 _FUSED_BLOCK = _os.environ.get("EAT_DYMN_FUSED", "1") != "0"
+_EPI_STATS = _os.environ.get("EAT_PW_EPI_STATS", "1") != "0"      # BatchNorm statistics in the dynamic 1x1 convs' epilogue
 _FUSED_DW = _os.environ.get("EAT_DYMN_FUSED_DW", "1") != "0"      # A/B: the round-4 depthwise / DyReLU kernels of the block
 
 
@@ -548,8 +559,7 @@ class DyBlockMain(torch.autograd.Function):
         sv = {"fused": fused}
         taps = ops.dyn_aggregate(w_d.view(K, cexp * k * k), att_d)
         if has_e:
-            z_e = _dyn_pw(x, w_e.view(K, cexp, cin), att_e, False)
-            st_e = ops.bn_train_state(z_e, blk.exp_norm)
+            z_e, st_e = _dyn_pw(x, w_e.view(K, cexp, cin), att_e, False, stats_bn=blk.exp_norm)
             sv.update(z_e=z_e, st_e=st_e)
         if fused:
             # expand BatchNorm + activation on load, depth_norm's statistics in the epilogue: y_e is never written
@@ -568,8 +578,7 @@ class DyBlockMain(torch.autograd.Function):
             _lib.call("eat_dyrelu_ca_fwd", z_d.data_ptr(), st_d[0].data_ptr(), st_d[1].data_ptr(), coef.data_ptr(),
                       g_cf.data_ptr(), g_ct.data_ptr(), x2.data_ptr(), B, cexp, Fo, To, _s())
             sv.update(y_e=y_e if has_e else None)
-        z_p = _dyn_pw(x2, w_p.view(K, cout, cexp), att_p, False)
-        st_p = ops.bn_train_state(z_p, blk.proj_norm)
+        z_p, st_p = _dyn_pw(x2, w_p.view(K, cout, cexp), att_p, False, stats_bn=blk.proj_norm)
         out = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=x if blk.use_res_connect else None)
         sv.update(x=x, taps=taps, z_d=z_d, st_d=st_d, x2=x2, z_p=z_p, st_p=st_p, att=att, coef=coef, g_cf=g_cf, g_ct=g_ct,
                   w_e=w_e, w_d=w_d, w_p=w_p)

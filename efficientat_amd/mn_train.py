@@ -122,6 +122,20 @@ def _conv_bn_stats(z, bn):
     return ops.bn_train_state(z, bn)
 
 
+def _pw_conv_bn(x, wp, Co, bn, dev, tf=None, in_scale=None):
+    """z = W x [of act(tf_a x + tf_b) * in_scale] and the state of the BatchNorm that follows: the batch statistics leave
+    the conv's epilogue (ops.pw_conv_stats: no pass over z) where that exists and the layer is in training mode."""
+    if _EPI_STATS and bn.training:
+        z, parts = ops.pw_conv_stats(x, wp, Co, tf=tf, in_scale=in_scale)
+        if z is not None:
+            return z, ops.bn_state_from_partials(parts, bn, z.numel() // Co)
+    if tf is not None:
+        z = ops.pw_conv_tf(x, tf, wp, _zeros.get(Co, dev), Co, NONE, in_scale=in_scale)
+    else:
+        z = ops.pw_conv(x, wp, _zeros.get(Co, dev), Co, NONE, in_scale=in_scale)
+    return z, _conv_bn_stats(z, bn)
+
+
 class MNTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, drop_mask, *params):
@@ -528,6 +542,7 @@ _DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthw
 # of the captured step became erratic from process to process (26.8 / 114.8 / 62.9 / 38.7 ms in four consecutive runs on one
 # box; never seen in ~40 single-stream runs) - a hipGraph with ~60 fork / join edges is not worth 1 %
 _OVERLAP = os.environ.get("EAT_TRAIN_OVERLAP", "0") == "1"
+_EPI_STATS = os.environ.get("EAT_PW_EPI_STATS", "1") != "0"      # project / last conv: BatchNorm statistics in the 1x1 epilogue
 _PREPACK_PLAN = os.environ.get("EAT_PREPACK_PLAN", "1") == "1"      # A/B: all weight packs of the step from one launch
 _FUSE_SE_MLP = os.environ.get("EAT_FUSE_SE_MLP", "1") == "1"        # A/B: SE gate MLP backward as two launches (csrc/se_train.hip)
 _FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem without its pre-activation tensor (csrc/stem_train.hip)
@@ -654,11 +669,9 @@ class MNTrainFunction2(torch.autograd.Function):
             cna = blk.block[blk.i_proj]
             wp = _pk(plan, ("p", bi), cna[0].weight)
             if on_load:
-                z_p = ops.pw_conv_tf(z_d, (st_d[0], st_d[1], act), wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels,
-                                     NONE, in_scale=scale)
+                z_p, st_p = _pw_conv_bn(z_d, wp, cnf.out_channels, cna[1], dev, tf=(st_d[0], st_d[1], act), in_scale=scale)
             else:
-                z_p = ops.pw_conv(y_d, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, in_scale=scale)
-            st_p = _conv_bn_stats(z_p, cna[1])
+                z_p, st_p = _pw_conv_bn(y_d, wp, cnf.out_channels, cna[1], dev, in_scale=scale)
             need_sx = bi + 1 < len(blocks) and blocks[bi + 1].i_expand is not None
             pool_c = torch.empty((B, cnf.out_channels), device=dev) if need_sx else None
             cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None, pool=pool_c)
@@ -670,8 +683,7 @@ class MNTrainFunction2(torch.autograd.Function):
         last = model.features[-1]
         c_feat = last.out_channels
         wp = _pk(plan, ("l",), last[0].weight)
-        z_l = ops.pw_conv(cur, wp, _zeros.get(c_feat, dev), c_feat, NONE)
-        st_l = _conv_bn_stats(z_l, last[1])
+        z_l, st_l = _pw_conv_bn(cur, wp, c_feat, last[1], dev)
         S_l = z_l.shape[2] * z_l.shape[3]
         ctx.mode = mode
         if mode == 1:

@@ -774,6 +774,35 @@ def dw_conv_dyn_act(x, w_bc, bias, act, coef, gate_f, gate_t, k, stride):
     return y
 
 
+def pw_conv_stats(x, wp, Co, per_sample=False, tf=None, in_scale=None):
+    """Train-mode 1x1 conv z = W x with the batch statistics of z in the conv's epilogue: -> (z, (part, outer, inner)) for
+    `bn_state_from_partials`, or (z, None) where the epilogue does not exist (the caller runs `bn_stats`).  wp: any pack of
+    `pw_prepack` / `dyn_pw_pack*` (per_sample=True: one pack per sample); tf = (a, b, act): input transform on load."""
+    B, Ci, F, T = x.shape
+    S = F * T
+    wmode = 0 if wp.dtype == torch.float32 else (2 if (per_sample or getattr(wp, "_eat_split", False)) else 1)   # (per-sample bf16 packs are hi / lo)
+    tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, S, 1 if per_sample else 0))
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
+    part = torch.empty((tiles * 2 * Co,), device=x.device, dtype=torch.float32)
+    a, b, act = tf if tf is not None else (None, None, 0)
+    rc = _lib.call_rc("eat_pw_conv_stats_fwd", _dev(x, "x"), wp.data_ptr(), wmode, 1 if per_sample else 0, _opt(a, "tf_a"),
+                      _opt(b, "tf_b"), act, _opt(in_scale, "in_scale"), _zero_bias(Co, x.device).data_ptr(), y.data_ptr(),
+                      part.data_ptr(), B, Ci, Co, S, _stream())
+    if rc == 1:
+        return None, None
+    return y, (part, tiles, 1)
+
+
+_zb = {}
+
+
+def _zero_bias(n, device):
+    buf = _zb.get(device)
+    if buf is None or buf.numel() < n:
+        buf = _zb[device] = torch.zeros((max(n, 4096),), device=device, dtype=torch.float32)
+    return buf[:n]
+
+
 # ---- round 4: fused training passes of the dynamic block (csrc/dymn.hip, csrc/dw_plane.hip)
 def dw_conv_dyn_stats(x, w_bc, k, stride, tf=None):
     """`dw_conv_stats` with per-(b,c) taps w_bc (B, C*k*k): -> (y, (part, outer, inner))."""

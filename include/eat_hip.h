@@ -341,6 +341,20 @@ int eat_pw_conv_tf_fwd(const float* x, const float* tf_a, const float* tf_b, int
 int eat_pw_conv_cat_fwd(const float* x1, int C1, const float* x2, int C2, const void* wp, int wmode, const float* bias,
                         const float* res, float* y, int B, int Co, int S, int act, eat_stream_t stream);
 
+/* Train-mode 1x1 conv z = W x (no bias / activation / residual) WITH the batch statistics of z for the BatchNorm that
+ * follows (models/mn/block_types.py:167-171,177-181; models/dymn/dy_block.py:313-316,386-388 under model.train()) in its
+ * epilogue: part [tiles][2][Co] = per column tile (256 flattened (b, s) columns) the sum and the sum of squares of every
+ * output channel - plain stores; eat_bn_finalize_partials(part, outer = tiles, C = Co, inner = 1) finishes.  The separate
+ * statistics pass over z disappears.  wmode: 0 = eat_pw_prepack, 1 / 2 = eat_pw_prepack_bf16 (plain / split);
+ * per_sample != 0: wp holds one pack per sample (eat_dyn_pw_pack / eat_dyn_pw_pack_bf16) and tiles lie inside samples;
+ * tf_a / tf_b / tf_act and in_scale as eat_pw_conv_tf_fwd (NULL: none); zero_bias: Co zeros.
+ * tiles = eat_pw_conv_stat_tiles(B, S, per_sample).  Returns 1 without launching where the epilogue does not exist
+ * (S % 4 != 0): run eat_pw_conv_fwd + eat_bn_stats instead. */
+int eat_pw_conv_stat_tiles(int B, int S, int per_sample);
+int eat_pw_conv_stats_fwd(const float* x, const void* wp, int wmode, int per_sample, const float* tf_a, const float* tf_b,
+                          int tf_act, const float* in_scale, const float* zero_bias, float* y, float* part, int B, int Ci,
+                          int Co, int S, eat_stream_t stream);
+
 /* Weight gradient of that conv: dW = sum dz (act_in(tf_a x + tf_b) * x_scale)^T with the transform on load. */
 int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float* tf_a, const float* tf_b, int tf_act,
                          const float* x_scale, float* dW, float* ws, int n_slots, int B, int Co, int Ci, int S,

@@ -118,6 +118,35 @@ def _quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+@pytest.mark.parametrize("B,Co,Ci,S", [(5, 672, 112, 504), (5, 112, 672, 504), (7, 960, 160, 128), (3, 160, 960, 128),
+                                       (4, 480, 80, 504), (3, 200, 80, 504), (3, 184, 80, 500), (2, 1344, 224, 504),
+                                       (2, 320, 1920, 128), (3, 130, 70, 36), (2, 96, 200, 72), (9, 240, 40, 2000)])
+@pytest.mark.parametrize("mode", ["x3", "bf16"])
+def test_pw_wgrad_wide_and_thin_shapes(B, Co, Ci, S, mode):
+    """1x1 weight gradients at the late-layer shapes of mn10 / mn40 / dymn20 (both operand orders, ragged tile counts, planes
+    that are not a multiple of 8 / 32 positions) against fp64 (models/mn/block_types.py:138-147,167-171 backward:
+    dW = sum_b dz_b x_b^T); per-sample form (DyMN, dy_block.py:120-127): stores where the library says so."""
+    dz, x = _rand(B, Co, S, 1, seed=1), _rand(B, Ci, S, 1, seed=2)
+    ref = torch.einsum("bos,bis->oi", dz[..., 0].double(), x[..., 0].double())
+    dzd, xd = dz.to(DEV), x.to(DEV)
+    with ops.precision("bf16" if mode == "bf16" else "auto"):
+        got = ops.pw_conv_wgrad(dzd, xd, exact=None)
+    if mode == "bf16":
+        refb = torch.einsum("bos,bis->oi", dz[..., 0].bfloat16().double(), x[..., 0].bfloat16().double())
+        assert _rel(got, refb) < 2e-5
+    else:
+        assert _rel(got, ref) < 2e-5
+    if mode == "x3" and Co >= 64 and Ci >= 64:
+        from efficientat_amd import _lib
+        G = torch.full((B, Co * Ci), float("nan"), device=DEV)         # stores, not accumulation: poison must vanish
+        if ops.dyn_wgrad_needs_zero(Co, Ci, S):
+            G.zero_()
+        _lib.call("eat_pw_conv_dyn_wgrad", dzd.data_ptr(), xd.data_ptr(), G.data_ptr(), B, Co, Ci, S,
+                  torch.cuda.current_stream().cuda_stream)
+        refp = torch.einsum("bos,bis->boi", dz[..., 0].double(), x[..., 0].double()).reshape(B, -1)
+        assert _rel(G, refp) < 2e-5
+
+
 def test_mn10_train_step_matches_oracle(golden_dir):
     g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
     sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)

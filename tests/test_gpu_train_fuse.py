@@ -98,6 +98,49 @@ def test_dw_conv_dgrad_with_activation_epilogue(B, C, F_, T, k, s, act):
     assert float((gp2.view(B, C).cpu().double() - g_ref.sum((2, 3))).abs().max()) < 1e-4 * max(1.0, float(g_ref.sum((2, 3)).abs().max()))
 
 
+@pytest.mark.parametrize("B,Ci,Co,F_,T,mode,per_sample,tf", [(3, 64, 16, 64, 500, "fp32", False, True), (5, 240, 40, 16, 125, "auto", False, True),
+                                                             (7, 672, 112, 8, 63, "auto", False, False), (9, 960, 160, 4, 32, "auto", False, False),
+                                                             (4, 96, 24, 32, 250, "bf16", False, False), (3, 32, 128, 16, 125, "fp32", True, False),
+                                                             (5, 160, 400, 8, 63, "auto", True, False), (3, 1344, 224, 4, 32, "auto", True, False),
+                                                             (2, 48, 20, 5, 20, "auto", False, False)])
+def test_pw_conv_with_statistics_epilogue(B, Ci, Co, F_, T, mode, per_sample, tf):
+    """Train-mode 1x1 conv z = W x (static or per-sample weights, optional on-load BatchNorm + activation + SE scale of the
+    input) with the batch statistics of z in the conv's epilogue: z against the plain conv (identical arithmetic), the
+    BatchNorm state against fp64 statistics of z (models/mn/block_types.py:167-171, models/dymn/dy_block.py:313-316)."""
+    x = _rand(B, Ci, F_, T, seed=1) + 0.3 * _rand(1, Ci, 1, 1, seed=2)
+    xd = x.to(DEV)
+    S = F_ * T
+    bn = torch.nn.BatchNorm2d(Co, eps=1e-3, momentum=0.01).to(DEV).train()
+    with ops.precision(mode):
+        if per_sample:
+            K = 4
+            bank = _rand(K, Co * Ci, seed=3, scale=Ci ** -0.5).to(DEV)
+            att = torch.softmax(_rand(B, K, seed=4), dim=-1).to(DEV)
+            wp = ops.dyn_pw_pack_bf16(bank, att, Co, Ci) if ops.dyn_bf16_eligible(Co, Ci, S) else ops.dyn_pw_pack(bank, att, Co, Ci)
+            z, parts = ops.pw_conv_stats(xd, wp, Co, per_sample=True)
+            zero = torch.zeros(Co, device=DEV)
+            z_plain = ops.pw_conv_dyn_bf16(xd, wp, zero, Co, ops.ACT_NONE) if wp.dtype == torch.bfloat16 else \
+                ops.pw_conv_dyn(xd, wp, zero, Co, ops.ACT_NONE)
+        else:
+            W = _rand(Co, Ci, seed=3, scale=Ci ** -0.5).to(DEV)
+            wp = ops.pw_prepack(W)
+            tfs = (torch.rand(Ci, device=DEV) + 0.5, torch.randn(Ci, device=DEV) * 0.2, 2) if tf else None
+            sc = torch.rand(B, Ci, device=DEV) if tf else None
+            z, parts = ops.pw_conv_stats(xd, wp, Co, tf=tfs, in_scale=sc)
+            zero = torch.zeros(Co, device=DEV)
+            z_plain = ops.pw_conv_tf(xd, tfs, wp, zero, Co, ops.ACT_NONE, in_scale=sc) if tf else \
+                ops.pw_conv(xd, wp, zero, Co, ops.ACT_NONE)
+    if S % 4 != 0:
+        assert z is None and parts is None                   # no epilogue there: the caller runs the separate pass
+        return
+    assert torch.equal(z, z_plain)
+    st = ops.bn_state_from_partials(parts, bn, B * S)
+    zd = z.cpu().double()
+    mu, var = zd.mean((0, 2, 3)), zd.var((0, 2, 3), unbiased=False)
+    assert _rel(st[2], mu) < 1e-5 and _rel(st[3], (var + 1e-3).rsqrt()) < 1e-5
+    assert _rel(bn.running_var, 0.99 + 0.01 * var * (B * S) / (B * S - 1)) < 1e-5
+
+
 @pytest.mark.parametrize("shift", [0.5, 10.0, 30.0])
 @pytest.mark.parametrize("B,Ci,Co,F_,T,act,exact", [(3, 16, 64, 64, 500, 1, True), (3, 16, 64, 64, 500, 1, False),
                                                      (4, 40, 120, 16, 125, 1, False), (5, 112, 672, 8, 63, 2, False),
