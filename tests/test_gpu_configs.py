@@ -44,6 +44,17 @@ def _rel(got, ref):
     return float((got - ref).norm() / max(1e-30, float(ref.norm())))
 
 
+def _ulp_noise(x, seed=4321):
+    """x * (1 + 2^-23 N(0,1)): one-ulp input noise.  These synthetic networks amplify round-off by 10^3 ... 10^5 (activation
+    kinks, batch statistics, DyMN's softmax attention at temperature 1: SURVEY 8c) - a second step on such an input measures
+    the round-off floor of a gradient comparison on THIS network, tensor by tensor."""
+    return x * (1.0 + 2.0 ** -23 * torch.randn(x.shape, generator=torch.Generator().manual_seed(seed)))
+
+
+def _floor(noise, name, k=4.0):
+    return k * noise.get(name, 0.0) if noise else 0.0
+
+
 def _grad_state(sd, skip=("running_mean", "running_var", "num_batches_tracked", "lambdas", "init_v")):
     return {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith(skip) else v.clone())
             for k, v in sd.items()}
@@ -146,7 +157,9 @@ def test_dymn20_eval_matches_oracle(dymn20_case):
 def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
     """fp32: exact fp32 GEMMs - SURVEY 8c's gradient bar (rel-L2 <= 1e-2 per tensor).  auto (what bench.py times): split
     bf16 operands from C_in = 40 on, ~1e-5 relative noise per GEMM, i.e. ~100x as many activation-kink flips as fp32
-    re-association: 5e-2 per tensor, 2e-2 median (see test_gpu_dymn.py::test_dymn10_train_step_matches_oracle)."""
+    re-association: 5e-2 per tensor, 2e-2 median (see test_gpu_dymn.py::test_dymn10_train_step_matches_oracle).  Either bar
+    yields to 4x the round-off floor of the tensor (`_ulp_noise`): at temperature 1 the kernel attention of this network
+    turns one-ulp input noise into percent-level changes of the 4-value attention-bias gradients."""
     d = dymn20_case
     y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
     keep = (torch.rand(4, 2560, generator=torch.Generator().manual_seed(6)) < 0.8).float()
@@ -162,6 +175,13 @@ def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
     logits, emb = model(d["x"].to(DEV))
     loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
     loss.backward()
+    # round-off floor of this network: the same step on the input with one-ulp noise, against the step above
+    ctrl = _dymn20(d["sd"], d["temp"]).train()
+    ctrl.train_precision = prec
+    ctrl._drop_mask_override = keep
+    F.binary_cross_entropy_with_logits(ctrl(_ulp_noise(d["x"]).to(DEV))[0], y.to(DEV)).backward()
+    noise = {n: _rel(pc.grad, p.grad.cpu()) for (n, p), (_, pc) in zip(model.named_parameters(), ctrl.named_parameters())}
+    del ctrl
     assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
     lerr = float((logits.detach().cpu() - logits_ref.detach()).abs().max())
     assert lerr < 1e-3, lerr                                           # absolute, |logit| up to ~12
@@ -174,11 +194,13 @@ def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
             continue
         r = _rel(p.grad, ref)
         rels.append(r)
-        if r > (1e-2 if prec == "fp32" else 5e-2):
-            bad.append((name, r))
-    print(f"dymn20 train step [{prec}]: logits max abs err {lerr:.2e}, gradient rel-L2 median {np.median(rels):.2e}, max {max(rels):.2e}")
+        if r > max(1e-2 if prec == "fp32" else 5e-2, _floor(noise, name)):
+            bad.append((name, r, noise[name]))
+    nmed = float(np.median(list(noise.values())))
+    print(f"dymn20 train step [{prec}]: logits max abs err {lerr:.2e}, gradient rel-L2 median {np.median(rels):.2e}, max {max(rels):.2e}"
+          f"  (one-ulp input noise on the same step: median {nmed:.2e}, max {max(noise.values()):.2e})")
     assert not bad, bad[:8]
-    assert float(np.median(rels)) < (3e-3 if prec == "fp32" else 2e-2), float(np.median(rels))
+    assert float(np.median(rels)) < max(3e-3 if prec == "fp32" else 2e-2, 4 * nmed), float(np.median(rels))
     msd = model.state_dict()
     for k, v in stats.items():
         assert _rel(msd[k], v) < 1e-4, k
@@ -304,7 +326,7 @@ def _tiled_step(model, x, y, keep, reps):
     return loss.item(), logits.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
 
 
-def _check_tiled(small, large, n, stats_small, stats_large, grad_tol=3e-2, fwd_tol=2e-5, med_tol=5e-3):
+def _check_tiled(small, large, n, stats_small, stats_large, grad_tol=3e-2, fwd_tol=2e-5, med_tol=5e-3, noise=None):
     """Forward quantities (loss, logits, running statistics) must agree to round-off.  Gradients: the two runs sum in
     different orders (split-K, atomics, Gram-matrix statistics), so an activation within ~1e-7 of a ReLU / Hardswish kink
     may take the other branch in ALL copies at once - the same mechanism, and the same size (1e-3 ... 1e-2 of a tensor's
@@ -322,9 +344,11 @@ def _check_tiled(small, large, n, stats_small, stats_large, grad_tol=3e-2, fwd_t
         if float(ref.norm()) < 1e-4 * gmax:                  # zero-gradient project-BN biases: round-off only
             continue
         rels.append((_rel(g_l[name], ref), name))
-    worst = max(rels)
-    assert worst[0] < grad_tol, worst
-    assert float(np.median([r for r, _ in rels])) < med_tol, float(np.median([r for r, _ in rels]))
+    # noise: {name: rel} of a second small-batch step on one-ulp-noisy input (`_ulp_noise`) - the bars yield to 4x that
+    bad = [(r, nm) for r, nm in rels if r >= max(grad_tol, _floor(noise, nm))]
+    assert not bad, max(bad)
+    nmed = float(np.median([noise[nm] for _, nm in rels])) if noise else 0.0
+    assert float(np.median([r for r, _ in rels])) < max(med_tol, 4 * nmed), (float(np.median([r for r, _ in rels])), nmed)
     for k, v in stats_small.items():                         # running statistics (unbiased factor n/(n-1) differs by ~1e-6;
         assert _rel(stats_large[k], v) < 10 * fwd_tol, k     #  the context-generator norms of DyMN see n = 4 x 8 values per channel)
 
@@ -346,12 +370,12 @@ def test_mn10_train_step_at_batch_256_reproduces_the_oracle_pinned_batch(golden_
     loss_ref = F.binary_cross_entropy_with_logits(logits_ref, y)
     loss_ref.backward()
     runs, bufs = {}, {}
-    for reps in (1, 32):                                     # 8 and 256 clips
+    for reps in (1, 32, "ctrl"):                             # 8 and 256 clips; 8 clips with one-ulp input noise
         model = _quiet(mn_mod.get_model, width_mult=1.0)
         model.load_state_dict(sd, strict=True)
         model.to(DEV).train()
         model.train_precision = "auto"                       # the arithmetic bench.py times
-        runs[reps] = _tiled_step(model, x, y, keep, reps)
+        runs[reps] = _tiled_step(model, _ulp_noise(x) if reps == "ctrl" else x, y, keep, 1 if reps == "ctrl" else reps)
         bufs[reps] = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
     loss8, logits8, g8 = runs[1]
     assert abs(loss8 - float(loss_ref)) < 2e-5 * max(1.0, abs(float(loss_ref)))
@@ -362,7 +386,8 @@ def test_mn10_train_step_at_batch_256_reproduces_the_oracle_pinned_batch(golden_
     for k, v in stats.items():
         if k.endswith(("running_mean", "running_var")):
             assert _rel(bufs[1][k], v) < 1e-4, k
-    _check_tiled(runs[1], runs[32], 8, bufs[1], bufs[32])
+    noise = {n: _rel(runs["ctrl"][2][n], g) for n, g in g8.items()}
+    _check_tiled(runs[1], runs[32], 8, bufs[1], bufs[32], noise=noise)
 
 
 @pytest.mark.parametrize("precision", ["auto", "bf16"])
@@ -396,10 +421,10 @@ def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn2
     y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
     keep = (torch.rand(4, 2560, generator=torch.Generator().manual_seed(6)) < 0.8).float()
     runs, bufs = {}, {}
-    for reps in (1, 32):
+    for reps in (1, 32, "ctrl"):
         model = _dymn20(d["sd"], d["temp"]).train()
         model.train_precision = prec
-        runs[reps] = _tiled_step(model, d["x"], y, keep, reps)
+        runs[reps] = _tiled_step(model, _ulp_noise(d["x"]) if reps == "ctrl" else d["x"], y, keep, 1 if reps == "ctrl" else reps)
         bufs[reps] = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
         del model
         torch.cuda.empty_cache()
@@ -407,7 +432,8 @@ def test_dymn20_train_step_at_batch_128_reproduces_the_oracle_pinned_batch(dymn2
     # the kernel-attention Linears are sums over the batch of softmax-Jacobian rows (which sum to zero over K) - the
     # tensors with the least signal per kink flip
     # (auto: the ~1e-5 noise of the split-operand GEMMs differs between the two regimes' tilings - more kink flips)
-    _check_tiled(runs[1], runs[32], 4, bufs[1], bufs[32], grad_tol=5e-2, med_tol=5e-3 if prec == "fp32" else 1e-2)
+    noise = {n: _rel(runs["ctrl"][2][n], g) for n, g in runs[1][2].items()}
+    _check_tiled(runs[1], runs[32], 4, bufs[1], bufs[32], grad_tol=5e-2, med_tol=5e-3 if prec == "fp32" else 1e-2, noise=noise)
 
 
 # ------------------------------------------------------------------ DISTINCT clips at the measured batch sizes: permutation

@@ -63,6 +63,9 @@ if has pmc; then
   python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r4}.json $S > $OUT/pmc_sq_${PMC_TAG:-r4}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r4}.txt
   rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq1
 fi
+if has smoke; then
+  timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; grep "smoke:" $OUT/smoke.log; tail -2 $OUT/smoke.log
+fi
 if has script; then
   timeout ${SCRIPT_TIMEOUT:-600} bash -c "$SCRIPT" > $OUT/script.log 2>&1; tail -60 $OUT/script.log
 fi
