@@ -896,6 +896,289 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __rest
     }
 }
 
+// ---- "wide-tile" weight gradient with producer / consumer waves (round 4) -------------------------------------------
+// Measured on pw_wgrad_x3_kernel with its phases switched off one at a time (672 x 112 at 504 positions x 256 clips):
+// loads alone 68 us (6 TB/s), fragment preparation + MFMAs alone > 100 us, the atomics 25 us - and the phases add up:
+// every wave of a block goes through load wait, bf16 hi / lo split, MFMAs in lock step, so the matrix pipe idles while the
+// VALUs convert and the memory pipe idles while both work.  The split itself is repeated by every wave for every fragment
+// it multiplies (a row tile of the 128 x 128 block is converted by 2 waves).  And the 128-row tiles re-read the narrow
+// operand once per row tile, missing L2 (PMC: FETCH_SIZE = the loads; the row tiles of a k-slice run on different XCDs):
+// 694 MB loaded for 404 MB of operands.  This kernel:
+//  * one block of 8 waves per CU owns a tile of up to 256 rows of the WIDE operand P (whichever of dz / x has more rows;
+//    SWAP = x) times up to 160 rows of the narrow operand Q - for every mn10 layer all of Q, so both operands are read
+//    once; the row tiles are balanced (672 rows = 3 tiles of 224, not 256 + 256 + 160);
+//  * PRODUCER / CONSUMER waves: a workgroup's waves are dealt to the SIMDs round robin, so waves 0-3 (consumers) and 4-7
+//    (producers) are one of each per SIMD.  A producer loads 1 KB pieces (8 rows x 32 positions, 16 bytes per lane: 8 full
+//    128-byte lines per instruction) into REGISTERS, three 32-position units ahead (3 x 13 pieces x 4 VGPRs: the bytes in
+//    flight live in the producers' otherwise idle register file, ~126 KB per CU, not in LDS), CONVERTS ONCE - 4 floats ->
+//    4 bf16 hi + 4 bf16 lo with the x side's transform, SE scale and the k-tail mask applied there: 12 VALU per 4 elements
+//    once instead of ~45 per fragment in each of the waves using it - and stores the fragments to one of two LDS slots.  A
+//    consumer owns 64 rows of P x all of Q (up to 4 x 10 accumulator tiles) and does nothing but ds_read_b128 + MFMA.
+//    One s_barrier per unit hands unit u + 1 to the consumers and the slot of unit u - 1 back to the producers: loads of
+//    units u + 2 ... u + 4 and the conversion of u + 1 overlap the MFMAs of u on the same SIMD.
+//  * LDS layout of a slot: row-major, 128 bytes per (row, 32 positions); the two 4-position chunks 2 kg, 2 kg + 1 of an
+//    MFMA fragment share a 32-byte block [8 hi | 8 lo] (or [8 lo | 8 hi]: rows with bit 1 set swap the halves, and the block
+//    index is XORed with bits 2-3 of the row, so that the 16 rows of a fragment read hit 16 different 16-byte bank groups).
+using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+constexpr int WIDE_PT = 4, WIDE_QT = 10;                           // 16-row tiles per consumer wave: 64 rows of P x 160 rows of Q
+constexpr int WIDE_NP = 13, WIDE_TP = 8;                            // register slots per producer wave and unit: 8 pieces of P (4 waves
+                                                                   // x 8 x 8 rows = 256) and 5 of Q (160 rows)
+constexpr int WIDE_RD = 3;                                         // units a producer holds in registers
+template <int V> struct WideInt { static constexpr int value = V; };
+// TF: the x operand is read through act(a v + b) (the project conv's input, mn_train.py); the dz-side constant of the
+// centred Gram launches is not supported here (those have dz == x and keep their own plan)
+template <int NPROD, bool SWAP, bool TF, bool SCALE>
+__global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                            const float* __restrict__ xscale, float* __restrict__ dW, int B,
+                                                            int Co, int Ci, int S, int sps, int units_per_block, WgTf tf,
+                                                            int n_slots, int p_tile_rows, int q_tile_rows, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float w_smem[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const float* __restrict__ P = SWAP ? x : dz;
+  const float* __restrict__ Q = SWAP ? dz : x;
+  const int PR = SWAP ? Ci : Co, QR = SWAP ? Co : Ci;
+  const int p0 = blockIdx.x * p_tile_rows, q0 = blockIdx.y * q_tile_rows;
+  const int pv = (PR - p0) < p_tile_rows ? (PR - p0) : p_tile_rows;   // valid rows of this block's tile
+  const int qv = (QR - q0) < q_tile_rows ? (QR - q0) : q_tile_rows;
+  const int total = B * sps;
+  const int u0 = blockIdx.z * units_per_block;
+  const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
+  if (pv <= 0 || qv <= 0 || u0 >= u1) return;                         // block-uniform, before any barrier
+  const int pt = (pv + 15) >> 4, qt = (qv + 15) >> 4;                 // 16-row tiles
+  const int GP = pt * 2, GQ = (qv + 7) >> 3;                          // 8-row pieces (P: whole 16-row tiles, so that the Q rows start
+                                                                      // on a multiple of 16: one swizzle term for all tiles)
+  const int GD = GP + GQ;
+  const int slot_f = GD * 256;                                        // floats per LDS slot
+  const int wq = wv & 3;
+
+  // (measured without effect: s_setprio 1 / 3 for the producers - the later-dispatched half -, for the consumers, and
+  //  the roles swapped: 141 - 146 us against 143 - 151 for 672 x 112)
+  if (wv >= 4) {
+    // ------------------------------------------------------------------ producer: loads, conversion, LDS stores
+    // The loads of a unit are STRAIGHT-LINE code - every producer issues WIDE_NP of them per unit whatever the tile size
+    // (slots past the last piece fetch one broadcast line), units past the block's range re-fetch the last unit, the SE scale
+    // is fetched every step for the unit converted in the next one: with loads inside conditional blocks the compiler's
+    // wait-count pass falls back to vmcnt(0) at every use, which drains the three units in flight.
+    const int lrow = lane >> 3, chunk = lane & 7;                     // this lane's 16 bytes of a piece: row lrow, positions 4 chunk ...
+    // register slot t of a producer: t < WIDE_TP -> piece wq + 4 t of P, else piece wq + 4 (t - WIDE_TP) of Q (fixed slot classes:
+    // the slots that hold x rows - transform coefficients, SE scale - are known at compile time)
+    constexpr int XS0 = SWAP ? 0 : WIDE_TP, XN = SWAP ? WIDE_TP : WIDE_NP - WIDE_TP;
+    // per slot: byte offset of this lane's 16 bytes relative to (operand + sample offset + 32 * unit)
+    unsigned roff[WIDE_NP];
+    float xa[TF ? XN : 1], xb[TF ? XN : 1];
+    int xrow[SCALE ? XN : 1];
+#pragma unroll
+    for (int t = 0; t < WIDE_NP; ++t) {
+      const bool isp = t < WIDE_TP;
+      const int g = wq + 4 * (isp ? t : t - WIDE_TP);                 // piece of P / of Q (wave-uniform)
+      const int mr = g * 8 + lrow, nv = isp ? pv : qv;
+      const int row = (isp ? p0 : q0) + (mr > nv - 1 ? nv - 1 : mr);
+      const bool valid = g < (isp ? GP : GQ);
+      roff[t] = valid ? 4u * ((unsigned)row * (unsigned)S + 4u * (unsigned)chunk) : 4u * (unsigned)(isp ? p0 : q0) * (unsigned)S;
+      if (t >= XS0 && t < XS0 + XN) {
+        const int xr = row < Ci ? row : Ci - 1;
+        if constexpr (TF) {
+          xa[t - XS0] = tf.a[xr];
+          xb[t - XS0] = tf.b[xr];
+        }
+        if constexpr (SCALE) xrow[t - XS0] = xr;
+      }
+    }
+    const bool tail = (S & 31) != 0;
+    float4 buf[WIDE_RD][WIDE_NP];
+    float xs[SCALE ? XN : 1], xs_next[SCALE ? XN : 1];
+    auto load_unit = [&](auto ktag, int bb, int stt) {
+      constexpr int K = decltype(ktag)::value;
+      const char* pb = reinterpret_cast<const char*>(P + ((size_t)bb * PR * S + (size_t)stt * 32));
+      const char* qb = reinterpret_cast<const char*>(Q + ((size_t)bb * QR * S + (size_t)stt * 32));
+      // the sample's last unit: chunks past S fetch a valid dummy (zeroed by the converter)
+      const int lim = S - 4 - stt * 32;                               // largest valid k offset inside this unit
+      const unsigned back = (tail && stt == sps - 1 && 4 * chunk > lim) ? 4u * (unsigned)(4 * chunk - lim) : 0u;
+#pragma unroll
+      for (int t = 0; t < WIDE_NP; ++t) {
+        const bool isp = t < WIDE_TP;
+        const bool valid = wq + 4 * (isp ? t : t - WIDE_TP) < (isp ? GP : GQ);
+        buf[K][t] = *reinterpret_cast<const float4*>((isp ? pb : qb) + (valid ? roff[t] - back : roff[t]));
+      }
+    };
+    auto load_scale = [&](int bb) {                                   // SE scale of the conv input, per (sample, input channel)
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int t = 0; t < XN; ++t) xs_next[t] = xscale[(size_t)bb * Ci + xrow[t]];
+      }
+    };
+    const int hb = (lrow >> 1) & 1;
+    auto convert_unit = [&](auto ktag, int slot, int stt) {
+      constexpr int K = decltype(ktag)::value;
+      const int sb = slot * slot_f;
+      const bool kz = tail && stt * 32 + 4 * chunk >= S;              // k tail (S % 4 == 0: whole chunks)
+#pragma unroll
+      for (int t = 0; t < WIDE_NP; ++t) {
+        const bool isp = t < WIDE_TP;
+        const int g = wq + 4 * (isp ? t : t - WIDE_TP);
+        if (g < (isp ? GP : GQ)) {
+          const int gi = isp ? g : GP + g;                            // piece of the LDS slot
+          float4 w = buf[K][t];
+          if constexpr (TF) {
+            if (t >= XS0 && t < XS0 + XN) {
+              const float fa = xa[t - XS0 < 0 ? 0 : t - XS0], fb = xb[t - XS0 < 0 ? 0 : t - XS0];
+              w.x = wg_tf(w.x, fa, fb, tf.act); w.y = wg_tf(w.y, fa, fb, tf.act);
+              w.z = wg_tf(w.z, fa, fb, tf.act); w.w = wg_tf(w.w, fa, fb, tf.act);
+            }
+          }
+          if constexpr (SCALE) {
+            if (t >= XS0 && t < XS0 + XN) {
+              const float sc = xs[t - XS0 < 0 ? 0 : t - XS0];
+              w.x *= sc; w.y *= sc; w.z *= sc; w.w *= sc;
+            }
+          }
+          if (kz) w = float4{0.f, 0.f, 0.f, 0.f};
+          const bf16x2_t h01 = __builtin_convertvector(f32x2_t{w.x, w.y}, bf16x2_t);
+          const bf16x2_t h23 = __builtin_convertvector(f32x2_t{w.z, w.w}, bf16x2_t);
+          const int blk = (chunk >> 1) ^ (((gi & 1) << 1) | (lrow >> 2));   // 32-byte block of the row: (c >> 1) ^ ((row >> 2) & 3)
+          const int rowf = sb + gi * 256 + lrow * 32 + 8 * blk + 2 * (chunk & 1);
+          *reinterpret_cast<u32x2_t*>(&w_smem[rowf + 4 * hb]) = u32x2_t{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+          if constexpr (NPROD == 3) {
+            const bf16x2_t l01 = __builtin_convertvector(f32x2_t{w.x - (float)h01[0], w.y - (float)h01[1]}, bf16x2_t);
+            const bf16x2_t l23 = __builtin_convertvector(f32x2_t{w.z - (float)h23[0], w.w - (float)h23[1]}, bf16x2_t);
+            *reinterpret_cast<u32x2_t*>(&w_smem[rowf + 4 * (1 - hb)]) = u32x2_t{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+          }
+        }
+      }
+    };
+    // (the lambdas take the unit's coordinates by value and the code below advances them: counters captured by reference
+    //  and modified inside a generic lambda ended up in scratch memory)
+    int bi = u0 / sps, sti = u0 - bi * sps, ui = u0;                  // next unit to load (stops at the last unit of the range)
+    int bc = bi, stc = sti, uc = u0;                                  // next unit to convert
+#define WIDE_LOAD(K_)                                                          \
+    do {                                                                       \
+      if (!(dbg & 4)) load_unit(WideInt<K_>{}, bi, sti);                       \
+      if (ui + 1 < u1) { ++ui; if (++sti == sps) { sti = 0; ++bi; } }          \
+    } while (0)
+    // conversion of unit uc; before it, the SE scale of the unit converted NEXT is requested (used one step later, when
+    // only the loads issued after it are still in flight)
+#define WIDE_CONVERT(K_, SLOT_)                                                \
+    do {                                                                       \
+      if constexpr (SCALE) {                                                   \
+        _Pragma("unroll") for (int t = 0; t < XN; ++t) xs[t] = xs_next[t];      \
+        const int bn = stc + 1 == sps ? bc + 1 : bc;                           \
+        load_scale(bn < B ? bn : B - 1);                                       \
+      }                                                                        \
+      if (uc < u1 && !(dbg & 8)) convert_unit(WideInt<K_>{}, SLOT_, stc);      \
+      if (dbg & 8) { _Pragma("unroll") for (int t = 0; t < WIDE_NP; ++t) asm volatile("" ::"v"(buf[K_][t].x)); } \
+      ++uc;                                                                    \
+      if (++stc == sps) { stc = 0; ++bc; }                                     \
+    } while (0)
+    // unit u0 + m lives in buf[m % 3] and goes to LDS slot m % 2
+    load_scale(bc);
+    WIDE_LOAD(0); WIDE_LOAD(1); WIDE_LOAD(2);
+    WIDE_CONVERT(0, 0);
+    WIDE_LOAD(0);
+    // step n (after barrier n the consumers multiply unit n): convert unit n + 1, reload its registers with unit n + 4
+    const int nsteps = u1 - u0;
+    for (int n = 0; n < nsteps; n += 3) {
+      __syncthreads();                                                // barrier n: unit n is in LDS; the slot of unit n - 1 is free
+      WIDE_CONVERT(1, (n + 1) & 1);
+      WIDE_LOAD(1);
+      if (n + 1 >= nsteps) break;
+      __syncthreads();
+      WIDE_CONVERT(2, (n + 2) & 1);
+      WIDE_LOAD(2);
+      if (n + 2 >= nsteps) break;
+      __syncthreads();
+      WIDE_CONVERT(0, (n + 3) & 1);
+      WIDE_LOAD(0);
+    }
+#undef WIDE_LOAD
+#undef WIDE_CONVERT
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer: fragments + MFMA
+  const int r = lane & 15, kg = lane >> 4;
+  const int pbase = pt >> 2, pext = pt & 3;                           // P tiles of this wave: [pm0, pm0 + pm_n)
+  const int pm_n = pbase + (wq < pext ? 1 : 0), pm0 = wq * pbase + (wq < pext ? wq : pext);
+  const unsigned out_slot = (unsigned)blockIdx.z % (unsigned)(n_slots > 0 ? n_slots : 1);
+  const size_t out_off = (size_t)out_slot * Co * Ci;
+  f32x4 acc[WIDE_PT][WIDE_QT];
+#pragma unroll
+  for (int i = 0; i < WIDE_PT; ++i)
+#pragma unroll
+    for (int j = 0; j < WIDE_QT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane LDS offsets (floats) of the fragment of row r (of any 16-row tile), k group kg: 16 bytes of hi, 16 bytes of lo
+  // inside the row's 32-byte block kg ^ ((r >> 2) & 3), halves swapped for rows with bit 1 set (see the converter)
+  const int fblk = r * 32 + 8 * (kg ^ ((r >> 2) & 3));
+  const int f_hi = fblk + 4 * ((r >> 1) & 1), f_lo = fblk + 4 * (1 - ((r >> 1) & 1));
+  const int p_off = pm0 * 512, q_off = GP * 256;
+  for (int u = u0; u < u1; ++u) {
+    __syncthreads();                                                  // unit u is in LDS slot (u - u0) & 1
+    if (pm_n > 0 && !(dbg & 2)) {
+      const int sb = ((u - u0) & 1) * slot_f;
+      // all WIDE_PT fragments of P, whatever pm_n is: a wave with 3 tiles multiplies a 4th (the next wave's rows, or Q rows,
+      // or zeros past the end of LDS) into accumulators that are never written - it would wait at the barrier for the waves
+      // with 4 tiles anyway, and the loop has no data-dependent control flow around its fragment registers
+      bf16x8_t ph[WIDE_PT], pl[WIDE_PT];
+#pragma unroll
+      for (int i = 0; i < WIDE_PT; ++i) {
+        ph[i] = *reinterpret_cast<const bf16x8_t*>(&w_smem[sb + p_off + 512 * i + f_hi]);
+        if constexpr (NPROD == 3) pl[i] = *reinterpret_cast<const bf16x8_t*>(&w_smem[sb + p_off + 512 * i + f_lo]);
+      }
+      // the Q fragment of tile j + 1 is read before the MFMAs of tile j (past the last tile it reads the other slot or zeros
+      // beyond the LDS allocation - never used)
+      bf16x8_t qh, ql;
+      qh = *reinterpret_cast<const bf16x8_t*>(&w_smem[sb + q_off + f_hi]);
+      if constexpr (NPROD == 3) ql = *reinterpret_cast<const bf16x8_t*>(&w_smem[sb + q_off + f_lo]);
+#pragma unroll
+      for (int j = 0; j < WIDE_QT; ++j) {
+        if (j < qt) {
+          bf16x8_t nh, nl;
+          if (j + 1 < WIDE_QT) {
+            nh = *reinterpret_cast<const bf16x8_t*>(&w_smem[sb + q_off + 512 * (j + 1) + f_hi]);
+            if constexpr (NPROD == 3) nl = *reinterpret_cast<const bf16x8_t*>(&w_smem[sb + q_off + 512 * (j + 1) + f_lo]);
+          }
+#pragma unroll
+          for (int i = 0; i < WIDE_PT; ++i) {
+            // D rows (kg * 4 + e) follow the first operand, D columns (lane & 15) the second: the x / Ci index goes second
+            if constexpr (SWAP) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, ph[i], acc[i][j], 0, 0, 0);
+              if constexpr (NPROD == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, pl[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql, ph[i], acc[i][j], 0, 0, 0);
+              }
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[i], qh, acc[i][j], 0, 0, 0);
+              if constexpr (NPROD == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[i], ql, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[i], qh, acc[i][j], 0, 0, 0);
+              }
+            }
+          }
+          if (j + 1 < WIDE_QT) { qh = nh; if constexpr (NPROD == 3) ql = nl; }
+        }
+      }
+    }
+  }
+  if (pm_n <= 0) return;
+  float* out = dW + out_off;
+#pragma unroll
+  for (int i = 0; i < WIDE_PT; ++i)
+#pragma unroll
+    for (int j = 0; j < WIDE_QT; ++j) {
+      if (!(i < pm_n && j < qt)) continue;                            // wave-uniform
+      const int pr0 = 16 * (pm0 + i), qr0 = 16 * j;                   // tile origins inside the block tile
+      const bool full = pr0 + 16 <= pv && qr0 + 16 <= qv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // C/D layout: row = kg * 4 + e (first MFMA operand), column = lane & 15 (second operand); rows / columns past the
+        // matrix hold products of the clamped duplicate rows and are simply not written
+        const int m = SWAP ? q0 + qr0 + kg * 4 + e : p0 + pr0 + kg * 4 + e;
+        const int n = SWAP ? p0 + pr0 + r : q0 + qr0 + r;
+        if ((dbg & 1) && acc[i][j][e] != 12345.678f) continue;
+        if (full || (m < Co && n < Ci)) global_atomic_add(out + (size_t)m * Ci + n, acc[i][j][e]);
+      }
+    }
+}
+
 // Narrow layers (one side <= 16 channels, the other <= 64: mn10 block 1 and the expand of block 2, planes of 32000
 // positions): dW is a single 64 x 64 wave tile and the gradient is a pure streaming reduction over k.  Here the direct,
 // LDS-free form wins: the 4 waves of a block split the k range, every lane loads the 8 consecutive k of its row straight
@@ -1411,13 +1694,39 @@ extern "C" int eat_dw_conv_dyn_wgrad(const float* dz, const float* x, float* dw_
 
 // Launch plan of the 1x1 weight gradient: which kernel, how the k range is cut (also exported through
 // eat_pw_wgrad_slots so that a caller can size a one-slot-per-block workspace)
-struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; int mtb, ntb, mg, ng; bool gram; int ps_spl; };
-// kind: 0 LDS-free streaming kernel (thin matrices), 1 LDS-staged x3, 2 exact fp32; mtb / ntb: row tiles per block, mg / ng groups
+struct WgPlan { int kind; int upb; unsigned nz; int sps; int bpb; int mtb, ntb, mg, ng; bool gram; int ps_spl;
+                int w_ptr = 0, w_qtr = 0, w_ptn = 0, w_qtn = 0, w_depth = 0; bool w_swap = false; };
+// kind: 0 LDS-free streaming kernel (thin matrices), 1 LDS-staged x3, 2 exact fp32, 3 wide-tile LDS ring (pw_wgrad_wide_kernel);
+// mtb / ntb: row tiles per block, mg / ng groups; w_*: tile rows, tile counts, ring depth and operand order of kind 3
 
 // (row tiles per block) pairs the streaming kernel is instantiated for
 // (the x side carries the SE scale / BatchNorm transform and costs more registers per tile: <= 3 tiles there, <= 4 on the dz side)
 static bool thin_pair(int m, int n) { return m >= 1 && m <= 4 && n >= 1 && n <= 3; }
-static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact_fp32, bool same, bool has_scale_or_tf) {
+// Tile shape of the wide-tile kernel for a (Co, Ci) matrix, and whether the plan uses it (EAT_WGRAD_WIDE: bit 0 = instead of
+// the 128 x 128-tile kernel, bit 1 = also instead of the streaming kernel where that re-reads an operand; default 3).
+// Measured (tools/bench_kernels.py wgrad): the producers' fixed cost per unit (13 load instructions, one barrier) loses on
+// tiles of fewer than ~20 pieces (160 rows of P + Q), and the on-load transform makes the producers the pole.
+struct WideShape { bool ok; bool swap; int ptr, qtr, ptn, qtn; };
+static WideShape wide_shape(int Co, int Ci, bool per_sample, bool same, bool no_wide, bool has_xscale, bool has_tf) {
+  static const int wide_on = getenv("EAT_WGRAD_WIDE") ? atoi(getenv("EAT_WGRAD_WIDE")) : 3;
+  static const int wide_min = getenv("EAT_WGRAD_WIDE_MIN") ? atoi(getenv("EAT_WGRAD_WIDE_MIN")) : 20;
+  WideShape w{false, Ci > Co, 0, 0, 0, 0};
+  if (per_sample || same || no_wide || has_tf || !(wide_on & 1) || (has_xscale && (Ci & 3) != 0)) return w;
+  const int PR = w.swap ? Ci : Co, QR = w.swap ? Co : Ci;
+  w.ptn = (PR + 255) / 256;
+  w.ptr = ((PR + w.ptn - 1) / w.ptn + 15) / 16 * 16;
+  w.qtn = (QR + 159) / 160;                                  // rows of Q per block: 4 producers x 5 pieces of 8 rows
+  w.qtr = ((QR + w.qtn - 1) / w.qtn + 15) / 16 * 16;
+  w.ok = (w.ptn - 1) * w.ptr < PR && (w.qtn - 1) * w.qtr < QR && w.ptr / 8 + w.qtr / 8 >= wide_min;
+  return w;
+}
+static bool wide_replaces_thin() {
+  static const int wide_on = getenv("EAT_WGRAD_WIDE") ? atoi(getenv("EAT_WGRAD_WIDE")) : 3;
+  return (wide_on & 3) == 3;
+}
+static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact_fp32, bool same, bool has_scale_or_tf,
+                         bool has_xscale = false, bool no_wide = false,
+                         bool has_tf = false) {
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
   const bool force_fp32 = env_fp32 || exact_fp32 == 1;      // exact_fp32: 0 = bf16x3, 1 = exact fp32, 2 = plain bf16
   static const bool dyn_x3 = !(getenv("EAT_DYN_WGRAD_X3") && atoi(getenv("EAT_DYN_WGRAD_X3")) == 0);
@@ -1462,6 +1771,8 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
         const int mg = (mtn + 3) / 4, ng = (ntn + 2) / 3;
         const int mtb = (mtn + mg - 1) / mg, ntb = (ntn + ng - 1) / ng;
         if (mg * ng <= 4 && thin_pair(mtb, ntb)) { thin = true; p.mtb = mtb; p.ntb = ntb; p.mg = mg; p.ng = ng; }
+        // more than one row group = the other operand is read once per group: the wide-tile kernel reads it once
+        if (thin && mg * ng > 1 && wide_replaces_thin() && wide_shape(Co, Ci, per_sample, same, no_wide, has_xscale, has_tf).ok) thin = false;
       }
     }
     if (thin) {
@@ -1470,6 +1781,21 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
       p.upb = (int)((total + splits - 1) / splits);
       p.nz = (unsigned)((total + p.upb - 1) / p.upb);
       return p;
+    }
+    {
+      const WideShape w = wide_shape(Co, Ci, per_sample, same, no_wide, has_xscale, has_tf);
+      if (w.ok) {
+        p.w_swap = w.swap; p.w_ptr = w.ptr; p.w_qtr = w.qtr; p.w_ptn = w.ptn; p.w_qtn = w.qtn;
+        const int wtiles = w.ptn * w.qtn;
+        static const int wtarget = getenv("EAT_WGRAD_WIDE_BLOCKS") ? atoi(getenv("EAT_WGRAD_WIDE_BLOCKS")) : 256;   // one block per CU
+        long long splits = wtiles >= wtarget ? 1 : wtarget / wtiles;
+        if (splits > total / 16) splits = total / 16;
+        if (splits < 1) splits = 1;
+        p.kind = 3;
+        p.upb = (int)((total + splits - 1) / splits);
+        p.nz = (unsigned)((total + p.upb - 1) / p.upb);
+        return p;
+      }
     }
     p.kind = 1;
     p.upb = sps;                                             // per-sample gradients: one sample per block
@@ -1507,7 +1833,8 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   // second kernel adds the copies into dW in a fixed order; n_slots >= eat_pw_wgrad_slots(...) gives every block its own
   // copy (bit-reproducible result).  The LDS-staged and exact kernels use the workspace only in that one-per-block form.
   // (a centring transform - tf.actr set - keeps the Gram plan: both operands are the same centred rows)
-  const WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr));
+  const WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
+                              x_scale != nullptr, tf.actr != nullptr, tf.a != nullptr);
   hipStream_t hs = (hipStream_t)stream;
   const bool priv = ws != nullptr && !per_sample && n_slots >= (int)p.nz;     // one copy per block
   if (p.kind == 0) {
@@ -1526,7 +1853,32 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   }
   float* target = priv ? ws : dW;
   const int slots = priv ? (int)p.nz : 0;
-  if (p.kind == 1) {
+  if (p.kind == 3) {
+    const size_t smem = (size_t)(p.w_ptr / 8 + p.w_qtr / 8) * 2 * 1024;     // two slots of converted fragments
+    dim3 grid(p.w_ptn, p.w_qtn, p.nz);
+    // EAT_WGRAD_WIDE_DBG (measurement only, results are wrong): 1 no atomics, 2 no MFMAs, 4 no loads, 8 no conversion -
+    // the phase decomposition quoted above the kernel
+    static const int wide_dbg = getenv("EAT_WGRAD_WIDE_DBG") ? atoi(getenv("EAT_WGRAD_WIDE_DBG")) : 0;
+#define EAT_WIDE(NP_, SW_, TF_, SC_)                                                                                      \
+    do {                                                                                                                  \
+      auto kern = pw_wgrad_wide_kernel<NP_, SW_, TF_, SC_>;                                                               \
+      static bool attr_set = false;                                                                                       \
+      if (!attr_set) {                                                                                                    \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+          return eat::fail(EAT_ELAUNCH, "eat_pw_conv_wgrad: hipFuncSetAttribute(160 KB of LDS) failed");                  \
+        attr_set = true;                                                                                                  \
+      }                                                                                                                   \
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, tf, slots,  \
+                         p.w_ptr, p.w_qtr, wide_dbg);                                                                     \
+    } while (0)
+#define EAT_WIDE_SC(NP_, SW_, TF_) do { if (x_scale) EAT_WIDE(NP_, SW_, TF_, true); else EAT_WIDE(NP_, SW_, TF_, false); } while (0)
+#define EAT_WIDE_SW(NP_, TF_) do { if (p.w_swap) EAT_WIDE_SC(NP_, true, TF_); else EAT_WIDE_SC(NP_, false, TF_); } while (0)
+    if (exact_fp32 == 2) { if (tf.a) EAT_WIDE_SW(1, true); else EAT_WIDE_SW(1, false); }
+    else { if (tf.a) EAT_WIDE_SW(3, true); else EAT_WIDE_SW(3, false); }
+#undef EAT_WIDE_SC
+#undef EAT_WIDE_SW
+#undef EAT_WIDE
+  } else if (p.kind == 1) {
     dim3 grid((Co + 127) / 128, (Ci + 127) / 128, p.nz);
     // EAT_WGRAD_XCD=1: XCD-aware workgroup order (see the kernel) for launches with at least 8 k-slices
     static const int xcd_on = getenv("EAT_WGRAD_XCD") ? atoi(getenv("EAT_WGRAD_XCD")) : 0;

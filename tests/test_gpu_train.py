@@ -147,6 +147,37 @@ def test_pw_wgrad_wide_and_thin_shapes(B, Co, Ci, S, mode):
         assert _rel(G, refp) < 2e-5
 
 
+@pytest.mark.parametrize("B,Co,Ci,S", [(5, 80, 240, 504), (3, 672, 112, 504), (4, 160, 672, 128), (3, 40, 120, 2000),
+                                       (2, 100, 52, 72), (3, 300, 200, 36), (2, 24, 72, 8000)])
+@pytest.mark.parametrize("opt", ["scale", "tf_relu", "tf_hswish+scale"])
+def test_pw_wgrad_wide_tile_kernel_with_input_scale_and_transform(B, Co, Ci, S, opt):
+    """The wide-tile ring kernel (csrc/train.hip: pw_wgrad_wide_kernel) with the squeeze-excitation scale of the conv input
+    (block_types.py:83,167-171: the project conv reads x * scale) and with the BatchNorm + activation transform evaluated on
+    load, both operand orders, a ring that is longer than the block's k range (S = 36), rows that are no multiple of 8."""
+    dz, x = _rand(B, Co, S, 1, seed=1), _rand(B, Ci, S, 1, seed=2)
+    sc = torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) + 0.25 if "scale" in opt else None
+    a = torch.rand(Ci, generator=torch.Generator().manual_seed(6)) + 0.5
+    b = 0.3 * torch.randn(Ci, generator=torch.Generator().manual_seed(7))
+    xe = x[..., 0].double()
+    act = ops.ACT_NONE
+    if opt.startswith("tf"):
+        act = ops.ACT_RELU if "relu" in opt else ops.ACT_HSWISH
+        u = a.double()[None, :, None] * xe + b.double()[None, :, None]
+        xe = torch.relu(u) if act == ops.ACT_RELU else F.hardswish(u)
+    if sc is not None:
+        xe = xe * sc.double()[:, :, None]
+    ref = torch.einsum("bos,bis->oi", dz[..., 0].double(), xe)
+    tf = (a.to(DEV), b.to(DEV), act) if opt.startswith("tf") else None
+    for mode in ("auto", "bf16"):
+        with ops.precision(mode):
+            got = ops.pw_conv_wgrad(dz.to(DEV), x.to(DEV), x_scale=None if sc is None else sc.to(DEV), exact=None, tf=tf)
+        if mode == "bf16":
+            refb = torch.einsum("bos,bis->oi", dz[..., 0].bfloat16().double(), xe.float().bfloat16().double())
+            assert _rel(got, refb) < 3e-5, mode
+        else:
+            assert _rel(got, ref) < 2e-5, mode
+
+
 def test_mn10_train_step_matches_oracle(golden_dir):
     g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
     sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)

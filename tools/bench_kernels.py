@@ -67,3 +67,31 @@ if "se" in what:
         h, pool = torch.relu(torch.randn(B, Cr, device=dev)), torch.randn(B, C, device=dev) * S
         W1, W2 = torch.randn(Cr, C, device=dev) * 0.1, torch.randn(C, Cr, device=dev) * 0.1
         print(f"se_mlp_bwd C={C} Cr={Cr}: %8.1f us" % timeit(lambda: ops.se_mlp_bwd(ds, sc, h, pool, W1, W2, S)))
+if "wgrad" in what:
+    # 1x1 weight gradients at the mn10 late-layer shapes (B = 256); EAT_WGRAD_WIDE=0/1/3 selects the kernel family per process
+    shapes = [(960, 160, 128), (160, 960, 128), (160, 672, 128), (672, 112, 504), (112, 672, 504), (112, 480, 504), (480, 80, 504),
+              (184, 80, 504), (200, 80, 504), (240, 40, 2000), (120, 40, 2000), (72, 24, 8000)]
+    tfs = [(80, 184, 504), (80, 240, 504), (40, 120, 2000), (40, 72, 2000), (24, 72, 8000)]
+    print("EAT_WGRAD_WIDE =", os.environ.get("EAT_WGRAD_WIDE", "(default)"), " depth", os.environ.get("EAT_WGRAD_WIDE_DEPTH", "-"))
+    with ops.precision("auto"):
+        for (Co, Ci, S) in shapes:
+            dz, x = torch.randn(B, Co, S, 1, device=dev), torch.randn(B, Ci, S, 1, device=dev)
+            with ops.zero_arena.scope("k"):
+                t = timeit(lambda: ops.pw_conv_wgrad(dz, x), n=20)
+            mb = (Co + Ci) * S * B * 4 / 1e6
+            print("wgrad %4d x %4d @ %5d  %7.1f us  %6.0f MB alg  %5.2f TB/s" % (Co, Ci, S, t, mb, mb / t))
+        for (Co, Ci, S) in [(160, 960, 128), (160, 672, 128), (112, 672, 504), (112, 480, 504), (40, 120, 2000), (40, 72, 2000)]:
+            dz, x = torch.randn(B, Co, S, 1, device=dev), torch.randn(B, Ci, S, 1, device=dev)
+            sc = torch.rand(B, Ci, device=dev)
+            with ops.zero_arena.scope("k"):
+                t = timeit(lambda: ops.pw_conv_wgrad(dz, x, x_scale=sc), n=20)
+            mb = (Co + Ci) * S * B * 4 / 1e6
+            print("wgrad_sc %4d x %4d @ %5d  %7.1f us  %6.0f MB alg  %5.2f TB/s" % (Co, Ci, S, t, mb, mb / t))
+        for (Co, Ci, S) in tfs:
+            dz, x = torch.randn(B, Co, S, 1, device=dev), torch.randn(B, Ci, S, 1, device=dev)
+            a, b = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.3
+            sc = torch.rand(B, Ci, device=dev)
+            with ops.zero_arena.scope("k"):
+                t = timeit(lambda: ops.pw_conv_wgrad(dz, x, x_scale=sc, tf=(a, b, ops.ACT_HSWISH)), n=20)
+            mb = (Co + Ci) * S * B * 4 / 1e6
+            print("wgrad_tf %4d x %4d @ %5d  %7.1f us  %6.0f MB alg  %5.2f TB/s" % (Co, Ci, S, t, mb, mb / t))
