@@ -46,6 +46,7 @@ SIGNATURES = {
     "eat_fused_expand_dw_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_mbconv_fwd": [_P] * 9 + [_I] * 11 + [_P],
     "eat_front_fwd": [_P] * 8 + [_I] * 7 + [_P],
+    "eat_block_fused_supported": [_I] * 9,
     "eat_dw_conv_fwd_tf": [_P, _P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P],
     "eat_dw_conv_wgrad_tf": [_P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_expand_dw_bf16_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeat_hip.so")
-SOURCES = ["common.cpp", "mel.hip", "conv_spatial.hip", "conv_pw.hip", "train.hip", "dymn.hip", "mbconv.hip", "front.hip", "conv_pw_bf16.hip", "conv_pw_generic.hip", "conv_pw_stream.hip", "expand_dw.hip", "irb.hip", "train_glue.hip", "dw_plane.hip", "train_fuse.hip", "stem_train.hip", "se_train.hip"]
+SOURCES = ["common.cpp", "mel.hip", "conv_spatial.hip", "conv_pw.hip", "train.hip", "dymn.hip", "conv_pw_bf16.hip", "conv_pw_generic.hip", "conv_pw_stream.hip", "expand_dw.hip", "irb.hip", "train_glue.hip", "dw_plane.hip", "train_fuse.hip", "stem_train.hip", "se_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=on", "-Wall",
          "-Wno-unused-function", "-Wno-inline-asm"]
 

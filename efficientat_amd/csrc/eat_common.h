@@ -101,11 +101,6 @@ int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const voi
 int pw_stream_try(const float* x, const void* wp, const float* bias, const float* in_scale, const float* res, float* y,
                   float* pool, int B, int Ci, int Co, int S, int act, int split, int ci_x, hipStream_t s);
 
-// irb.hip: register-resident inverted-residual block; returns 1 when the shape has no instantiation (fall back)
-int irb_try(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,
-            const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
-            int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s);
-
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B,
                  int C, int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
                  const float* in_b, int in_act, hipStream_t s, const DwEpi* epi = nullptr);
@@ -125,9 +120,6 @@ int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* 
                float* gzpart = nullptr);
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
-int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,
-              const float* wp_p, const float* bias_p, float* y, int B, int C, int F, int T, int Fo, int To, int act,
-              hipStream_t s);
 
 }  // namespace eat
 

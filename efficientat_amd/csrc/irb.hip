@@ -120,8 +120,7 @@ __device__ __forceinline__ void dw_finish(const DwAcc<NT>& a, f32x4 (&d)[NT]) {
 //   log-mel (lane (k, n): tap 4 ks + k of stem column n, zero outside the image through the buffer range check); the
 //   residual (= the stem output) is the middle row of the register window, in the accumulator layout already.
 //   F, T (a.F, a.T) are then the STEM plane, a.Fm / a.Tm the log-mel plane; ACT_E = Hardswish.
-template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false,
-          bool SWP = false>
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false>
 __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
   static_assert(!FRONT || (K == 3 && S == 1 && NKS == 3 && MTI == 1 && PROJ), "front = stem + 3x3/s1 block with project");
   constexpr int kNT = NT;
@@ -341,15 +340,8 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) v
             }
           }
       }
-      // SWP: the expand MFMAs of chunk c + 1 are issued BEFORE the depthwise arithmetic of chunk c (one chunk of software
-      // pipelining): on one SIMD a wave's VALU and MFMA instructions only overlap when they are interleaved in program
-      // order, and hipcc otherwise emits [6-12 MFMA][~60 VALU][8 MFMA] per chunk
-      f32x4 epipe[SWP ? S : 1][SWP ? TI : 1];
-      if constexpr (SWP) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < S; ++j) expand(c0 < MT ? c0 : MT - 1, xb[j], S * i - P_ + KW + j, epipe[j]);
-      }
+      // (a software-pipelined variant - the expand MFMAs of chunk c + 1 issued before the depthwise arithmetic of chunk c -
+      //  measured slower on every block and was removed in round 4)
 #pragma unroll
       for (int c = 0; c < MTI; ++c) {
         const bool c_ok = c0 + c < MT;       // a partial last group re-does chunk MT - 1 with its stores masked
@@ -358,20 +350,8 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) v
         // registers for 5 chunks) out of the row loop and spill; they are re-read per chunk instead (LDS has the bandwidth)
         asm volatile("" ::: "memory");
         f32x4 enew[S][TI];
-        if constexpr (SWP) {
 #pragma unroll
-          for (int j = 0; j < S; ++j)
-#pragma unroll
-            for (int ti = 0; ti < TI; ++ti) enew[j][ti] = epipe[j][ti];
-          if (c + 1 < MTI) {
-            const int cn = c0 + c + 1 < MT ? c0 + c + 1 : MT - 1;
-#pragma unroll
-            for (int j = 0; j < S; ++j) expand(cn, xb[j], S * i - P_ + KW + j, epipe[j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
-        }
+        for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
         if constexpr (!PF) {
           if (c == MTI - 1 && i + 1 < i1) load_rows(i + 1);   // the B operands are free: next row's loads fly from here
         }
@@ -470,7 +450,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) v
   }
 }
 
-template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, bool SWP = false>
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF>
 int launch_irb(IrbArgs a, hipStream_t s) {
   constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * NT - 2, VO = UHI - ULO + 1;
   a.MT = (a.Cexp + 15) / 16;
@@ -488,7 +468,7 @@ int launch_irb(IrbArgs a, hipStream_t s) {
   a.n_items = (int)items;
   const size_t smem = sizeof(float) * ((size_t)NKS * a.MT * 64 + (size_t)a.MT * K * K * 16 + 2 * (size_t)a.MT * 16 +
                                        (PROJ ? (size_t)a.MT * 4 * MTO * 64 + MTO * 16 : 0));
-  auto kern = irb_kernel<K, S, NKS, NT, MTI, MTO, ACT, PROJ, PF, ACT, false, SWP>;
+  auto kern = irb_kernel<K, S, NKS, NT, MTI, MTO, ACT, PROJ, PF, ACT, false>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return eat::fail(EAT_ELAUNCH, "irb: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
@@ -520,64 +500,105 @@ int launch_front(IrbArgs a, hipStream_t s) {
 
 }  // namespace
 
-namespace eat {
+namespace {
 
-// Network front (stem + first block) on the register-resident kernel; 1 = no instantiation (caller falls back).
-int front_try(const float* x, const float* w_s, const float* bias_s, const float* w_d, const float* bias_d,
-              const float* wp_p, const float* bias_p, float* y, int B, int C, int F, int T, int Fo, int To, int act,
-              hipStream_t s) {
-  static const bool off = getenv("EAT_IRB") && atoi(getenv("EAT_IRB")) == 0;
-  static const int var = getenv("EAT_IRB_FRONT") ? atoi(getenv("EAT_IRB_FRONT")) : 2;   // 1 / 2 column tiles per wave: 0.275 / 0.269 ms (round-1 kernel 0.41)
-  if (off || var == 0 || C != 16) return 1;
-  if (4LL * F * T >= (1LL << 31) || 4LL * C * Fo * To >= (1LL << 31)) return 1;
-  IrbArgs a{};
-  a.x = x; a.wpe = w_s; a.bias_e = bias_s; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = nullptr;
-  a.y = y; a.pool = nullptr;
-  a.B = B; a.Cin = 1; a.Cexp = C; a.Cout = C; a.F = Fo; a.T = To; a.Fo = Fo; a.To = To; a.Fm = F; a.Tm = T;
-  if (act == EAT_ACT_RELU)
-    return var == 2 ? launch_front<2, EAT_ACT_RELU, true>(a, s) : launch_front<1, EAT_ACT_RELU, true>(a, s);
-  return var == 2 ? launch_front<2, EAT_ACT_HSWISH, true>(a, s) : launch_front<1, EAT_ACT_HSWISH, true>(a, s);
-}
-
-// Returns 1 when the shape has no instantiation (the caller falls back to the LDS-staged kernel), 0 / <0 otherwise.
-int irb_try(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,
-            const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
-            int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s) {
-  static const bool off = getenv("EAT_IRB") && atoi(getenv("EAT_IRB")) == 0;
-  // A/B switch between tilings.  Measured on MI355X at B = 256 (blocks 2 / 3 / 4 of mn10, ms): 0 = two column tiles per
-  // wave, B operands re-requested late in the row: 0.40 / 0.31 / 0.34; 1 (default) = ONE tile per wave (half the
-  // registers: 3-4 waves per SIMD instead of 2), next row's B operands a whole row ahead, SE block marches all 5 chunks
-  // together: 0.36 / 0.28 / 0.25; 2 = two tiles + full-row prefetch: 0.40 / 0.32 / 0.36.  (LDS-staged round-1 kernel: 0.65 / 0.51 / 0.40.)
-  static const int var = getenv("EAT_IRB_V") ? atoi(getenv("EAT_IRB_V")) : 1;
-  if (off || act != EAT_ACT_RELU) return 1;
-  if (4LL * Cin * F * T >= (1LL << 31) || 4LL * (Cexp > Cout ? Cexp : Cout) * Fo * To >= (1LL << 31)) return 1;   // 32-bit byte offsets inside a sample
-  if (Cexp % 8 != 0 || (wp_p && Cout % 4 != 0)) return 1;
-  IrbArgs a{};
-  a.x = x; a.wpe = wp_e; a.bias_e = bias_e; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = res;
-  a.y = y; a.pool = pool;
-  a.B = B; a.Cin = Cin; a.Cexp = Cexp; a.Cout = Cout; a.F = F; a.T = T; a.Fo = Fo; a.To = To;
-  const bool proj = wp_p != nullptr;
-  const int MT = (Cexp + 15) / 16, MTO = (Cout + 15) / 16;
+// Shape -> instantiation of the register-resident block kernel; returns 1 when there is none (the caller's plan then uses
+// the separate 1x1 / depthwise kernels), 0 / < 0 after a launch.  dry = only answer the question.
+// Tilings measured on MI355X at B = 256 (blocks 2 / 3 / 4 of mn10, ms): one column tile per wave (half the registers: 3-4
+// waves per SIMD instead of 2), the next row's B operands a whole row ahead, SE block marching all 5 chunks together:
+// 0.36 / 0.28 / 0.25; two tiles per wave 0.40 / 0.31 / 0.34, two tiles + full-row prefetch 0.40 / 0.32 / 0.36, a
+// window-swapping variant slower still - those instantiations were removed in round 4 (round-1 LDS-staged kernel:
+// 0.65 / 0.51 / 0.40, removed with csrc/mbconv.hip).
+int irb_dispatch(IrbArgs a, int k, int stride, int act, bool dry, hipStream_t s) {
+  if (act != EAT_ACT_RELU) return 1;
+  if (4LL * a.Cin * a.F * a.T >= (1LL << 31) || 4LL * (a.Cexp > a.Cout ? a.Cexp : a.Cout) * a.Fo * a.To >= (1LL << 31)) return 1;   // 32-bit byte offsets inside a sample
+  const bool proj = a.wpp != nullptr;
+  if (a.Cexp % 8 != 0 || (proj && a.Cout % 4 != 0)) return 1;
+  const int MT = (a.Cexp + 15) / 16, MTO = (a.Cout + 15) / 16;
   constexpr int R = EAT_ACT_RELU;
+#define EAT_IRB_GO(...) return dry ? 0 : launch_irb<__VA_ARGS__>(a, s)
   if (proj) {
-    if (k == 3 && stride == 2 && Cin == 16 && MT == 4 && MTO == 2)
-      return var == 3 ? launch_irb<3, 2, 4, 1, 4, 2, R, true, true, true>(a, s)
-           : var == 1 ? launch_irb<3, 2, 4, 1, 4, 2, R, true, true>(a, s) : launch_irb<3, 2, 4, 2, 4, 2, R, true, false>(a, s);
-    if (k == 3 && stride == 1 && Cin == 24 && MT == 5 && MTO == 2)
-      return var == 3 ? launch_irb<3, 1, 6, 1, 5, 2, R, true, true, true>(a, s)
-           : var == 1 ? launch_irb<3, 1, 6, 1, 5, 2, R, true, true>(a, s)
-           : var == 2 ? launch_irb<3, 1, 6, 2, 5, 2, R, true, true>(a, s) : launch_irb<3, 1, 6, 2, 5, 2, R, true, false>(a, s);
+    if (k == 3 && stride == 2 && a.Cin == 16 && MT == 4 && MTO == 2) EAT_IRB_GO(3, 2, 4, 1, 4, 2, R, true, true);
+    if (k == 3 && stride == 1 && a.Cin == 24 && MT == 5 && MTO == 2) EAT_IRB_GO(3, 1, 6, 1, 5, 2, R, true, true);
     // (mn10 block 7 - 40 -> 240 -> 80, 3x3 / stride 2, Hardswish - as <3, 2, 10, 1, 15, 5>: the window of 15 chunks plus the
     //  project accumulators need 256 VGPRs + 64 spilled registers; not instantiated)
     return 1;
   }
-  if (k == 5 && stride == 2 && Cin == 24)
-    return (var == 3 && MT == 5) ? launch_irb<5, 2, 6, 1, 5, 1, R, false, false, true>(a, s)
-         : (var == 1 && MT == 5) ? launch_irb<5, 2, 6, 1, 5, 1, R, false, false>(a, s)
-         : var == 2 ? launch_irb<5, 2, 6, 1, 1, 1, R, false, true>(a, s) : launch_irb<5, 2, 6, 2, 1, 1, R, false, false>(a, s);
-  if (k == 3 && stride == 2 && Cin == 16) return launch_irb<3, 2, 4, 2, 1, 1, R, false, false>(a, s);
-  if (k == 3 && stride == 1 && Cin == 24) return launch_irb<3, 1, 6, 2, 1, 1, R, false, false>(a, s);
+  if (k == 5 && stride == 2 && a.Cin == 24) {
+    if (MT == 5) EAT_IRB_GO(5, 2, 6, 1, 5, 1, R, false, false);
+    EAT_IRB_GO(5, 2, 6, 2, 1, 1, R, false, false);
+  }
+  if (k == 3 && stride == 2 && a.Cin == 16) EAT_IRB_GO(3, 2, 4, 2, 1, 1, R, false, false);
+  if (k == 3 && stride == 1 && a.Cin == 24) EAT_IRB_GO(3, 1, 6, 2, 1, 1, R, false, false);
+#undef EAT_IRB_GO
   return 1;
 }
 
-}  // namespace eat
+int block_fused(const float* x, const float* wp_e, const float* bias_e, const float* w_d, const float* bias_d,
+                const float* wp_p, const float* bias_p, const float* res, float* y, float* pool, int B, int Cin, int Cexp,
+                int Cout, int F, int T, int Fo, int To, int k, int stride, int act, hipStream_t s, const char* who) {
+  if (act != EAT_ACT_RELU && act != EAT_ACT_HSWISH) return eat::fail(EAT_EINVAL, "%s: act must be relu/hswish", who);
+  const int p = (k - 1) / 2;
+  if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
+    return eat::fail(EAT_EINVAL, "%s: output %dx%d inconsistent with input %dx%d", who, Fo, To, F, T);
+  IrbArgs a{};
+  a.x = x; a.wpe = wp_e; a.bias_e = bias_e; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = res;
+  a.y = y; a.pool = pool;
+  a.B = B; a.Cin = Cin; a.Cexp = Cexp; a.Cout = Cout; a.F = F; a.T = T; a.Fo = Fo; a.To = To;
+  const int rc = irb_dispatch(a, k, stride, act, false, s);
+  if (rc == 1)
+    return eat::fail(EAT_EINVAL, "%s: no fused instantiation for Cin=%d Cexp=%d Cout=%d k=%d stride=%d act=%d (ask "
+                     "eat_block_fused_supported; use eat_pw_conv_fwd + eat_dw_conv_fwd)", who, Cin, Cexp, Cout, k, stride, act);
+  return rc;
+}
+
+}  // namespace
+
+// Host query: 1 when eat_mbconv_fwd (proj = 1) / eat_fused_expand_dw_fwd (proj = 0) has an instantiation for the block.
+extern "C" int eat_block_fused_supported(int Cin, int Cexp, int Cout, int F, int T, int k, int stride, int act, int proj) {
+  IrbArgs a{};
+  static const float dummy = 0.0f;
+  a.wpp = proj ? &dummy : nullptr;
+  const int p = (k - 1) / 2;
+  a.B = 1; a.Cin = Cin; a.Cexp = Cexp; a.Cout = Cout; a.F = F; a.T = T;
+  a.Fo = (F + 2 * p - k) / stride + 1; a.To = (T + 2 * p - k) / stride + 1;
+  return irb_dispatch(a, k, stride, act, true, nullptr) == 0 ? 1 : 0;
+}
+
+extern "C" int eat_fused_expand_dw_fwd(const float* x, const float* wp_e, const float* bias_e, const float* w_d,
+                                       const float* bias_d, float* y, float* pool, int B, int Cin, int Cexp, int F,
+                                       int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  return block_fused(x, wp_e, bias_e, w_d, bias_d, nullptr, nullptr, nullptr, y, pool, B, Cin, Cexp, 0, F, T, Fo, To, k,
+                     stride, act, (hipStream_t)stream, "eat_fused_expand_dw_fwd");
+}
+
+extern "C" int eat_mbconv_fwd(const float* x, const float* wp_e, const float* bias_e, const float* w_d,
+                              const float* bias_d, const float* wp_p, const float* bias_p, const float* res, float* y,
+                              int B, int Cin, int Cexp, int Cout, int F, int T, int Fo, int To, int k, int stride,
+                              int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!wp_p || !bias_p) return eat::fail(EAT_EINVAL, "eat_mbconv_fwd: project weights and bias are required");
+  return block_fused(x, wp_e, bias_e, w_d, bias_d, wp_p, bias_p, res, y, nullptr, B, Cin, Cexp, Cout, F, T, Fo, To, k,
+                     stride, act, (hipStream_t)stream, "eat_mbconv_fwd");
+}
+
+// Network front (stem + first block) on the register-resident kernel (FRONT mode: two column tiles per wave, 0.269 ms for
+// mn10 at B = 256; one tile 0.275, round-1 LDS-staged kernel 0.41 - removed with csrc/front.hip).
+extern "C" int eat_front_fwd(const float* x, const float* w_s, const float* bias_s, const float* w_d,
+                             const float* bias_d, const float* wp_p, const float* bias_p, float* y, int B, int C, int F,
+                             int T, int Fo, int To, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (C != 16) return eat::fail(EAT_EINVAL, "eat_front_fwd: C=%d unsupported (the fused front is built for 16 channels)", C);
+  if (Fo != (F - 1) / 2 + 1 || To != (T - 1) / 2 + 1)
+    return eat::fail(EAT_EINVAL, "eat_front_fwd: output %dx%d does not match input %dx%d", Fo, To, F, T);
+  if (act != EAT_ACT_RELU && act != EAT_ACT_HSWISH) return eat::fail(EAT_EINVAL, "eat_front_fwd: act must be relu/hswish");
+  if (4LL * F * T >= (1LL << 31) || 4LL * C * Fo * To >= (1LL << 31))
+    return eat::fail(EAT_EINVAL, "eat_front_fwd: plane too large for 32-bit byte offsets");
+  IrbArgs a{};
+  a.x = x; a.wpe = w_s; a.bias_e = bias_s; a.wd = w_d; a.bias_d = bias_d; a.wpp = wp_p; a.bias_p = bias_p; a.res = nullptr;
+  a.y = y; a.pool = nullptr;
+  a.B = B; a.Cin = 1; a.Cexp = C; a.Cout = C; a.F = Fo; a.T = To; a.Fo = Fo; a.To = To; a.Fm = F; a.Tm = T;
+  hipStream_t s = (hipStream_t)stream;
+  return act == EAT_ACT_RELU ? launch_front<2, EAT_ACT_RELU, true>(a, s) : launch_front<2, EAT_ACT_HSWISH, true>(a, s);
+}

@@ -714,26 +714,16 @@ template <int NPROD>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                              const float* __restrict__ xscale, float* __restrict__ dW,
                                                              int B, int Co, int Ci, int S, int sps, int units_per_block,
-                                                             int per_sample, WgTf tf, int n_slots, int xcd_tx, int xcd_T,
-                                                             int xcd_nz) {
+                                                             int per_sample, WgTf tf, int n_slots) {
   // stage = [A: 128 rows x 128 B][B: 128 rows x 128 B] = 32 KB; 2 stages
   __shared__ __attribute__((aligned(16))) float s_op[2][2][128 * 32];
   // wv through readfirstlane: the compiler then knows it (and the tile counts derived from it) to be wave-uniform - scalar
   // branches instead of exec-masked blocks around the loads and MFMAs of rows beyond the matrix
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 15, kg = lane >> 4;
-  // XCD-aware order (xcd_T > 0, 1-D grid): workgroup ids go round-robin over the 8 XCDs, each with its own L2, so with the
-  // plain (tile, tile, k-slice) grid the tiles that share a k-slice - i.e. read the same rows of dz and x - land on 8
-  // different L2s.  Here workgroup L works on k-slice 8 * (L / 8 / T) + L % 8: all T tiles of a slice on one XCD.
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (xcd_T > 0) {
-    const int L = blockIdx.x, slot = L >> 3;
-    bz = (slot / xcd_T) * 8 + (L & 7);
-    const int tile = slot % xcd_T;
-    bx = tile % xcd_tx;
-    by = tile / xcd_tx;
-    if (bz >= xcd_nz) return;                                      // whole block (padding of the last group of 8 slices)
-  }
+  // (an XCD-aware workgroup order - all tiles of a k-slice on one XCD, so that their shared operand rows meet in one L2 -
+  //  was measured slower in round 3 and removed in round 4; the wide-tile kernel below reads each operand once instead)
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   const int mb = bx * 128, nb = by * 128;                          // block tile origin
   const int mw = (wv & 1) * 64, nw = (wv >> 1) * 64;              // wave sub-tile inside the block tile
   const int total = B * sps;
@@ -1880,20 +1870,12 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
 #undef EAT_WIDE
   } else if (p.kind == 1) {
     dim3 grid((Co + 127) / 128, (Ci + 127) / 128, p.nz);
-    // EAT_WGRAD_XCD=1: XCD-aware workgroup order (see the kernel) for launches with at least 8 k-slices
-    static const int xcd_on = getenv("EAT_WGRAD_XCD") ? atoi(getenv("EAT_WGRAD_XCD")) : 0;
-    int xcd_tx = 0, xcd_T = 0;
-    if (xcd_on && !per_sample && p.nz >= 8) {
-      xcd_tx = (int)grid.x;
-      xcd_T = (int)(grid.x * grid.y);
-      grid = dim3((unsigned)(((p.nz + 7) / 8) * 8 * xcd_T), 1, 1);
-    }
     if (exact_fp32 == 2)
       hipLaunchKernelGGL(pw_wgrad_x3_kernel<1>, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb,
-                         per_sample, tf, slots, xcd_tx, xcd_T, (int)p.nz);
+                         per_sample, tf, slots);
     else
       hipLaunchKernelGGL(pw_wgrad_x3_kernel<3>, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb,
-                         per_sample, tf, slots, xcd_tx, xcd_T, (int)p.nz);
+                         per_sample, tf, slots);
   } else {
     dim3 grid((Co + 31) / 32, (Ci + 31) / 32, p.nz);
     hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.bpb, per_sample, tf,

@@ -373,7 +373,7 @@ class DyMN(nn.Module):
         fmaps = []
         first = 0
         if "front" in W and not return_fmaps:
-            # static first block (replace_se): stem + block in one kernel, as in MN (csrc/front.hip)
+            # static first block (replace_se): stem + block in one kernel, as in MN (csrc/irb.hip, FRONT mode)
             x = ops.front(x, *W["stem"], *W[0]["dw"], *W["front"],
                           ops.ACT_HSWISH if self.layers[0].cnf.use_hs else ops.ACT_RELU)
             first = 1

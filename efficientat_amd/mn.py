@@ -25,13 +25,13 @@ from . import ops
 from .utils import make_divisible, cnn_out_size, NAME_TO_WIDTH  # noqa: F401
 
 BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
-# Blocks whose input has at most this many channels run as one fused kernel (csrc/mbconv.hip): whole
+# Blocks whose input has at most this many channels run as one fused kernel (csrc/irb.hip): whole
 # block when it has no SE, expand + depthwise when it has.  Measured on MI355X at B=256 (fused vs separate
 # kernels): mn10 block 2 0.72 vs 1.13 ms, block 3 0.54 vs 0.65, block 4 0.40 vs 0.51; from C_in = 40 on the
 # fused kernel is VALU/MFMA-bound (blocks 5-7: 0.38 vs 0.24, 0.64 vs 0.39 ms) and the separate kernels win.
 # 0 disables (A/B switch).
 _FUSE_MAX_CIN = int(os.environ.get("EAT_FUSE_MAX_CIN", "24"))
-# stem + first block as one kernel (csrc/front.hip); 0 disables (A/B switch)
+# stem + first block as one kernel (csrc/irb.hip, FRONT mode); 0 disables (A/B switch)
 _FUSE_FRONT = int(os.environ.get("EAT_FUSE_FRONT", "1"))
 # arithmetic of the 1x1 convs in eval: fp32 | bf16x3 | bf16 | auto (see _pw_mode)
 _PW_MODE = os.environ.get("EAT_PW_MODE", "auto")
@@ -205,11 +205,18 @@ def _pw_mode(Co, Ci):
     return _PW_MODE
 
 
-def _fusable(blk):
+def _fusable(blk, proj):
+    """Blocks that run as ONE kernel in eval mode (csrc/irb.hip): the whole SE-less block (proj) or expand + depthwise of a
+    block with a channel-only SE; the library says which geometries it has instantiations for (mn10: blocks 2-4)."""
     cnf = blk.cnf
-    return (blk.i_expand is not None and cnf.input_channels <= _FUSE_MAX_CIN and cnf.input_channels % 4 == 0
-            and cnf.expanded_channels % 4 == 0 and cnf.dilation == 1
-            and (blk.i_se is None or blk.block[blk.i_se].channel_only))
+    if not (blk.i_expand is not None and cnf.input_channels <= _FUSE_MAX_CIN and cnf.dilation == 1
+            and (blk.i_se is None or blk.block[blk.i_se].channel_only)):
+        return False
+    if proj and blk.i_se is not None:
+        return False
+    act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
+    return ops.block_fused_supported(cnf.input_channels, cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride,
+                                     act, proj)
 
 
 def _concurrent_se(se_block, y, pool_c):
@@ -272,18 +279,18 @@ def fold_block(blk):
     cna = blk.block[blk.i_proj]
     s, b = _fold(cna[0], cna[1])
     d["proj"] = _pack_pw(cna[0].weight.flatten(1), s.contiguous(), b.contiguous())
-    if _fusable(blk):
-        # the block kernel (csrc/mbconv.hip) multiplies on the exact fp32 MFMA: its own fp32 packs
+    if _fusable(blk, True) or _fusable(blk, False):
+        # the block kernel (csrc/irb.hip) multiplies on the exact fp32 MFMA: its own fp32 packs
         ce = blk.block[blk.i_expand]
         se_, be_ = _fold(ce[0], ce[1])
         d["exp32"] = (ops.pw_prepack(ce[0].weight.flatten(1), se_.contiguous()), be_.contiguous())
-        if blk.i_se is None and blk.cnf.out_channels <= 80:
+        if _fusable(blk, True):
             d["proj32"] = (ops.pw_prepack(cna[0].weight.flatten(1), s.contiguous()), b.contiguous())
     return d
 
 
 def fold_front(stem, b0):
-    """Packed project layer of the first block when stem + block 0 run as one kernel (csrc/front.hip), else None."""
+    """Packed project layer of the first block when stem + block 0 run as one kernel (csrc/irb.hip, FRONT mode), else None."""
     if (_FUSE_FRONT and stem[0].out_channels == 16 and b0.i_expand is None and b0.i_se is None and b0.use_res_connect
             and b0.cnf.kernel == 3 and b0.cnf.stride == 1 and b0.cnf.dilation == 1):
         cna = b0.block[b0.i_proj]
@@ -300,7 +307,7 @@ def run_block(blk, w, x, pool=None):
     inp = x
     scale = None
     # early, bandwidth-bound blocks: the whole block (without SE) or expand + depthwise (with SE) in
-    # one kernel, the expanded tensor stays on chip (csrc/mbconv.hip); late blocks are MFMA-bound
+    # one kernel, the expanded tensor stays on chip (csrc/irb.hip); late blocks are MFMA-bound
     # and keep the separate kernels
     if "proj32" in w:
         return ops.mbconv(x, *w["exp32"], *w["dw"], *w["proj32"], cnf.expanded_channels, cnf.out_channels,
@@ -465,7 +472,7 @@ class MN(nn.Module):
 
         first = 0
         if "front" in W and not return_fmaps:
-            # stem + first block in one kernel (csrc/front.hip): the 16 x 64 x 500 stem map never leaves the CU
+            # stem + first block in one kernel (csrc/irb.hip, FRONT mode): the 16 x 64 x 500 stem map never leaves the CU
             c0 = blocks[0].cnf
             x = ops.front(x, *W["stem"], *W[0]["dw"], *W["front"], ops.ACT_HSWISH if c0.use_hs else ops.ACT_RELU)
             first = 1

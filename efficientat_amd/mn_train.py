@@ -74,19 +74,6 @@ def _pk(plan, key, w, trans=False):
     return plan.get(key) if plan is not None else ops.pw_prepack(w.flatten(1), trans=trans)
 
 
-_side_streams = {}
-
-
-def _side_stream(dev):
-    """Second HIP stream of the train step: work that is off the critical path (the Gram-matrix chain of the forward, the
-    project convs' weight gradients of the backward) runs on it next to the main chain's latency-bound small kernels.
-    Fork / join with wait_stream, so the dependencies are recorded when the step is captured into a hipGraph."""
-    key = (dev.type, dev.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev)
-    return _side_streams[key]
-
-
 class _Ones(_Zeros):
     def get(self, n, device):
         if self.buf is None or self.buf.numel() < n or self.buf.device != device:
@@ -136,401 +123,267 @@ def _pw_conv_bn(x, wp, Co, bn, dev, tf=None, in_scale=None):
     return z, _conv_bn_stats(z, bn)
 
 
-class MNTrainFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, model, x, drop_mask, *params):
-        keep = torch.is_grad_enabled() or any(p.requires_grad for p in params)
-        dev = x.device
-        x = x.contiguous().float()
-        B = x.shape[0]
-        saved = {}
-        blocks = list(model.features[1:-1])
+# (the round-2 plan - separate statistics / apply passes per BatchNorm, behind EAT_TRAIN_V=1 - was removed in round 4)
+def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
+    """Backward of MNTrainFunction2 (one pass, reverse layer order)."""
+    # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
+    # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
+    # a model that was never handed to dp.enable_data_parallel keeps its gradients local (no hidden collective)
+    g = _GradSink(getattr(model, "_grad_reducer", None) or GradReducer(local=True))
+    dev = dlogits.device
+    dlogits = dlogits.contiguous().float()
+    B = dlogits.shape[0]
+    blocks = list(model.features[1:-1])
+    nb = len(blocks)
 
-        # stem
-        stem = model.features[0]
-        C0 = stem[0].out_channels
-        z0 = ops.stem_conv(x, stem[0].weight.reshape(C0, 9), _zeros.get(C0, dev), NONE)
-        st0 = _conv_bn_stats(z0, stem[1])
-        cur = ops.bn_act_fwd(z0, st0[0], st0[1], HSWISH)
-        saved["stem"] = (x, z0, st0)
+    # the fp64 channel sums of every BatchNorm backward of the pass live in ONE zeroed buffer: dgamma / dbeta of all
+    # layers are converted to fp32 by one launch at the end (31 conversions before) and handed to the sink together
+    bn_total = 2 * sum(m.num_features for m in model.features.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    bn_buf = ops.zero_arena.zeros((bn_total,), torch.float64, dev)
+    bn_reg = []
 
-        blk_saved = []
-        for blk in blocks:
-            cnf = blk.cnf
-            act = HSWISH if cnf.use_hs else RELU
-            inp = cur
-            rec = {"inp": inp}
-            if blk.i_expand is not None:
-                cna = blk.block[blk.i_expand]
-                wp = ops.pw_prepack(cna[0].weight.flatten(1))
-                z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
-                st_e = _conv_bn_stats(z_e, cna[1])
-                rec.update(z_e=z_e, st_e=st_e)
-            cna = blk.block[blk.i_dw]
-            k = cnf.kernel
-            if blk.i_expand is not None and _FUSE_EXPAND_BN:
-                # y_e = act(BN(z_e)) is consumed only by the depthwise conv (and its weight gradient): both
-                # evaluate it on load from z_e and the BN affine - the activated tensor is never written
-                y_e = None
-                z_d = ops.dw_conv_tf(z_e, st_e[0], st_e[1], act, cna[0].weight.reshape(-1, k * k),
-                                     _zeros.get(cnf.expanded_channels, dev), k, cnf.stride)
-            else:
-                y_e = ops.bn_act_fwd(z_e, st_e[0], st_e[1], act) if blk.i_expand is not None else inp
-                z_d = ops.dw_conv(y_e, cna[0].weight.reshape(-1, k * k), _zeros.get(cnf.expanded_channels, dev), k,
-                                  cnf.stride, NONE)
-            st_d = _conv_bn_stats(z_d, cna[1])
-            S_d = z_d.shape[2] * z_d.shape[3]
-            pool = torch.empty((B, cnf.expanded_channels), device=dev) if blk.i_se is not None else None
-            y_d = ops.bn_act_fwd(z_d, st_d[0], st_d[1], act, pool=pool)
-            rec.update(y_e=y_e, z_d=z_d, st_d=st_d, y_d=y_d)
-            scale = None
-            if blk.i_se is not None:
-                se = blk.block[blk.i_se].conc_se_layers[0]
-                h = ops.linear(pool, se.fc1.weight, se.fc1.bias, RELU, 1.0 / S_d)
-                scale = ops.linear(h, se.fc2.weight, se.fc2.bias, SIGMOID)
-                rec.update(pool=pool, h=h, scale=scale, S_d=S_d)
-            cna = blk.block[blk.i_proj]
-            wp = ops.pw_prepack(cna[0].weight.flatten(1))
-            z_p = ops.pw_conv(y_d, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, in_scale=scale)
-            st_p = _conv_bn_stats(z_p, cna[1])
-            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None)
-            rec.update(z_p=z_p, st_p=st_p)
-            blk_saved.append(rec)
+    def bn_sums(C, wname, bname):
+        if bn_buf is None:
+            return None
+        off = sum(2 * r[2] for r in bn_reg)
+        bn_reg.append((wname, bname, C, off))
+        return bn_buf[off:off + 2 * C]
 
-        last = model.features[-1]
-        c_feat = last.out_channels
-        wp = ops.pw_prepack(last[0].weight.flatten(1))
-        z_l = ops.pw_conv(cur, wp, _zeros.get(c_feat, dev), c_feat, NONE)
-        st_l = _conv_bn_stats(z_l, last[1])
-        pooled = torch.empty((B, c_feat), device=dev)
-        ops.bn_act_fwd(z_l, st_l[0], st_l[1], HSWISH, pool=pooled, write=False)
-        S_l = z_l.shape[2] * z_l.shape[3]
-        feat = pooled * (1.0 / S_l)
+    def bn_grads(dgam, dbet, wname, bname):
+        if dgam is not None:
+            g[wname], g[bname] = dgam, dbet
+
+    x_l, z_l, st_l, S_l = sv["last"]
+    last = model.features[-1]
+    nm = f"features.{nb + 1}"
+    if sv["head"] is None:
+        # trunk mode: the head ran outside (torch autograd); dlogits is the gradient w.r.t. the last feature map
+        dz, dgam, dbet = ops.bn_act_bwd(dlogits.view_as(z_l), z_l, *st_l, HSWISH,
+                                        sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
+    else:
+        # ---- head (mn/model.py:186-194)
+        feat, u, h2, drop_mask = sv["head"]
         fc1, fc2 = model.classifier[2], model.classifier[5]
-        u = ops.linear(feat, fc1.weight, fc1.bias, NONE)
-        h2 = F.hardswish(u)
+        # plain library GEMMs on the transposed VIEWS (rocBLAS takes the transposition as a flag: no transposed copies)
+        # and torch's fused Hardswish backward: 9 launches where the round-2 form took 25
+        g["classifier.5.weight"] = torch.mm(dlogits.t(), h2)
+        g["classifier.5.bias"] = dlogits.sum(0)
+        dh2 = torch.mm(dlogits, fc2.weight)
         if drop_mask is not None:
-            h2 = h2 * drop_mask
-        logits = ops.linear(h2, fc2.weight, fc2.bias, NONE)
-        if keep:
-            saved.update(blocks=blk_saved, last=(cur, z_l, st_l, S_l), head=(feat, u, h2, drop_mask))
-            ctx.saved, ctx.model = saved, model
-            ctx.names = [n for n, _ in model.named_parameters()]
-        return logits, feat
+            dh2 = dh2 * drop_mask
+        du = torch.ops.aten.hardswish_backward(dh2, u)
+        g["classifier.2.weight"] = torch.mm(du.t(), feat)
+        g["classifier.2.bias"] = du.sum(0)
+        dft = torch.mm(du, fc1.weight)
+        if dfeat is not None:
+            dft = dft + dfeat
+        # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
+        zeros_bc = torch.zeros((B, z_l.shape[1]), device=dev)
+        dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l),
+                                        sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
+    bn_grads(dgam, dbet, nm + ".1.weight", nm + ".1.bias")
+    g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
+    plan = sv.get("plan")
+    if plan is not None and plan.runs != sv.get("plan_run"):
+        # another forward of the model re-packed the plan's views since this pass's forward (two forwards before one
+        # backward): the views hold the CURRENT weights - pack this backward's operands matrix by matrix instead
+        plan = None
+    wpt = _pk(plan, ("lt",), last[0].weight, trans=True)
+    dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
+    del dz, z_l
 
-    @staticmethod
-    def backward(ctx, dlogits, dfeat):
-        model, sv = ctx.model, ctx.saved
-        ctx.saved = None
-        with ops.precision(getattr(model, "train_precision", "fp32")), ops.zero_arena.scope("mn_bwd"):
-            return MNTrainFunction._backward_impl(ctx, model, sv, dlogits, dfeat)
-
-    @staticmethod
-    def _backward_impl(ctx, model, sv, dlogits, dfeat, v2=False, n_lead=3):
-        # every `g[name] = grad` hands the gradient to the data-parallel reducer, which all-reduces full
-        # buckets on RCCL's stream while the remaining layers' backward kernels run (dp.py)
-        # a model that was never handed to dp.enable_data_parallel keeps its gradients local (no hidden collective)
-        g = _GradSink(getattr(model, "_grad_reducer", None) or GradReducer(local=True))
-        dev = dlogits.device
-        dlogits = dlogits.contiguous().float()
-        B = dlogits.shape[0]
-        blocks = list(model.features[1:-1])
-        nb = len(blocks)
-
-        # the fp64 channel sums of every BatchNorm backward of the pass live in ONE zeroed buffer: dgamma / dbeta of all
-        # layers are converted to fp32 by one launch at the end (31 conversions before) and handed to the sink together
-        bn_total = 2 * sum(m.num_features for m in model.features.modules() if isinstance(m, torch.nn.BatchNorm2d))
-        bn_buf = ops.zero_arena.zeros((bn_total,), torch.float64, dev) if v2 else None
-        bn_reg = []
-
-        def bn_sums(C, wname, bname):
-            if bn_buf is None:
-                return None
-            off = sum(2 * r[2] for r in bn_reg)
-            bn_reg.append((wname, bname, C, off))
-            return bn_buf[off:off + 2 * C]
-
-        def bn_grads(dgam, dbet, wname, bname):
-            if dgam is not None:
-                g[wname], g[bname] = dgam, dbet
-
-        x_l, z_l, st_l, S_l = sv["last"]
-        last = model.features[-1]
-        nm = f"features.{nb + 1}"
-        if sv["head"] is None:
-            # trunk mode: the head ran outside (torch autograd); dlogits is the gradient w.r.t. the last feature map
-            dz, dgam, dbet = ops.bn_act_bwd(dlogits.view_as(z_l), z_l, *st_l, HSWISH,
-                                            sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
+    # ---- inverted residual blocks, last to first (mn/block_types.py:177-181)
+    dout2 = None                   # second summand of the gradient w.r.t. the stem output (see res_ok below)
+    for i in range(nb - 1, -1, -1):
+        blk, rec = blocks[i], sv["blocks"][i]
+        cnf = blk.cnf
+        act = HSWISH if cnf.use_hs else RELU
+        pre = f"features.{i + 1}.block"
+        inp = rec["inp"]
+        res_grad = dout if blk.use_res_connect else None
+        # project conv + BN (no activation); the residual branch passes dout through unchanged
+        cna = blk.block[blk.i_proj]
+        nw, nbias = f"{pre}.{blk.i_proj}.1.weight", f"{pre}.{blk.i_proj}.1.bias"
+        dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias))
+        bn_grads(dgam, dbet, nw, nbias)
+        scale = rec.get("scale")
+        if rec["y_d"] is None:     # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
+            st_d = rec["st_d"]
+            dWp = ops.pw_conv_wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act))
         else:
-            # ---- head (mn/model.py:186-194)
-            feat, u, h2, drop_mask = sv["head"]
-            fc1, fc2 = model.classifier[2], model.classifier[5]
-            if v2:
-                # plain library GEMMs on the transposed VIEWS (rocBLAS takes the transposition as a flag: no transposed copies)
-                # and torch's fused Hardswish backward: 9 launches where the round-2 form took 25
-                g["classifier.5.weight"] = torch.mm(dlogits.t(), h2)
-                g["classifier.5.bias"] = dlogits.sum(0)
-                dh2 = torch.mm(dlogits, fc2.weight)
-                if drop_mask is not None:
-                    dh2 = dh2 * drop_mask
-                du = torch.ops.aten.hardswish_backward(dh2, u)
-                g["classifier.2.weight"] = torch.mm(du.t(), feat)
-                g["classifier.2.bias"] = du.sum(0)
-                dft = torch.mm(du, fc1.weight)
-            else:
-                g["classifier.5.weight"] = _mm_nt(_t(dlogits), _t(h2))
-                g["classifier.5.bias"] = dlogits.sum(0)
-                dh2 = _mm_nt(dlogits, _t(fc2.weight))
-                if drop_mask is not None:
-                    dh2 = dh2 * drop_mask
-                du = dh2 * torch.where(u < -3, torch.zeros_like(u), torch.where(u <= 3, u / 3 + 0.5, torch.ones_like(u)))
-                g["classifier.2.weight"] = _mm_nt(_t(du), _t(feat))
-                g["classifier.2.bias"] = du.sum(0)
-                dft = _mm_nt(du, _t(fc1.weight))
-            if dfeat is not None:
-                dft = dft + dfeat
-            # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
-            zeros_bc = torch.zeros((B, z_l.shape[1]), device=dev)
-            dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l),
-                                            sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
-        bn_grads(dgam, dbet, nm + ".1.weight", nm + ".1.bias")
-        g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
-        plan = sv.get("plan")
-        if plan is not None and plan.runs != sv.get("plan_run"):
-            # another forward of the model re-packed the plan's views since this pass's forward (two forwards before one
-            # backward): the views hold the CURRENT weights - pack this backward's operands matrix by matrix instead
-            plan = None
-        wpt = _pk(plan, ("lt",), last[0].weight, trans=True)
-        dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
-        del dz, z_l
-
-        # ---- inverted residual blocks, last to first (mn/block_types.py:177-181)
-        dout2 = None                   # second summand of the gradient w.r.t. the stem output (see res_ok below)
-        for i in range(nb - 1, -1, -1):
-            blk, rec = blocks[i], sv["blocks"][i]
-            cnf = blk.cnf
-            act = HSWISH if cnf.use_hs else RELU
-            pre = f"features.{i + 1}.block"
-            inp = rec["inp"]
-            res_grad = dout if blk.use_res_connect else None
-            # project conv + BN (no activation); the residual branch passes dout through unchanged
-            cna = blk.block[blk.i_proj]
-            nw, nbias = f"{pre}.{blk.i_proj}.1.weight", f"{pre}.{blk.i_proj}.1.bias"
-            dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias))
-            bn_grads(dgam, dbet, nw, nbias)
-            scale = rec.get("scale")
-            pend = None                    # (name, gradient, stream, inputs kept alive) of a launch on the side stream
-            if v2 and _OVERLAP:
-                # the project conv's weight gradient is needed only at the end of the pass: on the side stream it fills the
-                # gaps the main chain's small kernels (gate MLP, BatchNorm sums, coefficient GEMMs) leave on the chip
-                main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
-                side_s.wait_stream(main_s)
-                torch.cuda.set_stream(side_s)
-            try:
-                if rec["y_d"] is None:     # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
-                    st_d = rec["st_d"]
-                    dWp = ops.pw_conv_wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act))
-                else:
-                    dWp = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale)
-            finally:
-                if v2 and _OVERLAP:
-                    torch.cuda.set_stream(main_s)
-            if v2 and _OVERLAP:
-                dWp.record_stream(main_s)
-                pend = (f"{pre}.{blk.i_proj}.0.weight", dWp.view_as(cna[0].weight), side_s, (dz_p, rec["z_d"], rec["y_d"], scale))
-            else:
-                g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
-
-            def join_side(pend=pend):
-                if pend is not None:
-                    torch.cuda.current_stream(dev).wait_stream(pend[2])
-                    g[pend[0]] = pend[1]
-            wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
-            dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
-            del dz_p
-            gscale = gadd = se_P = None
-            if scale is not None:     # squeeze-excitation gate (mn/block_types.py:72-83)
-                se = blk.block[blk.i_se].conc_se_layers[0]
-                sp = f"{pre}.{blk.i_se}.conc_se_layers.0"
-                h, pool, S_d = rec["h"], rec["pool"], rec["S_d"]
-                if v2 and _FUSE_SE_BWD:
-                    # one pass over (dxs, z_d) for the gate gradient AND the BatchNorm-backward plane sums
-                    st_d = rec["st_d"]
-                    se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
-                    ds = se_P[0]
-                elif rec["y_d"] is None:
-                    st_d = rec["st_d"]
-                    ds = ops.plane_dot(dxs, rec["z_d"], st_d[0], st_d[1], act)
-                else:
-                    ds = ops.plane_dot(dxs, rec["y_d"])
-                if v2 and _FUSE_SE_MLP:
-                    # the gate MLP's backward as two launches (csrc/se_train.hip) instead of ~25 KB-sized torch ops
-                    dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d)
-                    g[sp + ".fc2.weight"], g[sp + ".fc2.bias"] = dW2, db2
-                    g[sp + ".fc1.weight"], g[sp + ".fc1.bias"] = dW1, db1
-                else:
-                    dq = ds * scale * (1.0 - scale)
-                    g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
-                    g[sp + ".fc2.bias"] = dq.sum(0)
-                    dh = _mm_nt(dq, _t(se.fc2.weight)) * (h > 0).float()
-                    zmean = pool * (1.0 / S_d)
-                    g[sp + ".fc1.weight"] = _mm_nt(_t(dh), _t(zmean))
-                    g[sp + ".fc1.bias"] = dh.sum(0)
-                    gadd = _mm_nt(dh, _t(se.fc1.weight)) * (1.0 / S_d)
-                gscale = scale
-            # depthwise conv + BN + act
-            cna = blk.block[blk.i_dw]
-            k = cnf.kernel
-            y_e = rec["y_e"]
-            merged = None
-            no_expand = blk.i_expand is None
-            src_shape = tuple((y_e if y_e is not None else rec["z_e"]).shape)
-            # a block without expand conv hands its residual-branch gradient to the stem's backward kernel, which adds the
-            # two on load (the merged kernel has no residual input)
-            res_ok = not no_expand or res_grad is None or (i == 0 and sv["stem"][1] is None)
-            if (v2 and _MERGED_DW_BWD and _DW_BN_ON_LOAD and (y_e is None or no_expand) and res_ok
-                    and ops.dw_bwd_merged_ok(rec["z_d"].shape, src_shape, k, cnf.stride)):
-                # large planes: dz_d is never written - the merged backward kernel evaluates the BatchNorm + activation
-                # backward of the depthwise output on load from (dxs, z_d) and the channel sums of the reduce pass
+            dWp = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale)
+        g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
+        wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
+        dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+        del dz_p
+        gscale = gadd = se_P = None
+        if scale is not None:     # squeeze-excitation gate (mn/block_types.py:72-83)
+            se = blk.block[blk.i_se].conc_se_layers[0]
+            sp = f"{pre}.{blk.i_se}.conc_se_layers.0"
+            h, pool, S_d = rec["h"], rec["pool"], rec["S_d"]
+            if _FUSE_SE_BWD:
+                # one pass over (dxs, z_d) for the gate gradient AND the BatchNorm-backward plane sums
                 st_d = rec["st_d"]
-                nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
-                sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P,
-                                                       sums=bn_sums(cnf.expanded_channels, nw, nbias))
-                bn_grads(dgam, dbet, nw, nbias)
-                w_d = cna[0].weight.reshape(-1, k * k)
-                if no_expand:
-                    C_d = cnf.expanded_channels
-                    dout, _, dw_d = ops.dw_conv_bwd_bn_g(dxs, rec["z_d"], st_d, act, sums, w_d, y_e, _ones.get(C_d, dev),
-                                                         _zeros.get(C_d, dev), NONE, k, cnf.stride, gscale=gscale,
-                                                         gadd=gadd, want_gsum=False)
-                    dout2 = res_grad
-                    g[f"{pre}.{blk.i_dw}.0.weight"] = dw_d.view_as(cna[0].weight)
-                    del dxs
-                    join_side()
-                    sv["blocks"][i] = None
-                    continue
-                st_e = rec["st_e"]
-                merged = ops.dw_conv_bwd_bn_g(dxs, rec["z_d"], st_d, act, sums, w_d, rec["z_e"], st_e[0], st_e[1], act, k,
-                                              cnf.stride, gscale=gscale, gadd=gadd)
-                g[f"{pre}.{blk.i_dw}.0.weight"] = merged[2].view_as(cna[0].weight)
-                in_shape = src_shape
-                dz_d = None
-                del dxs
+                se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
+                ds = se_P[0]
+            elif rec["y_d"] is None:
+                st_d = rec["st_d"]
+                ds = ops.plane_dot(dxs, rec["z_d"], st_d[0], st_d[1], act)
             else:
-                nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
-                if se_P is not None:
-                    dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd,
-                                                         sums=bn_sums(cnf.expanded_channels, nw, nbias))
-                else:
-                    dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd,
-                                                      sums=bn_sums(cnf.expanded_channels, nw, nbias))
-                del dxs
-                bn_grads(dgam, dbet, nw, nbias)
-            if merged is not None:
-                pass
-            elif y_e is None and v2 and _MERGED_DW_BWD:
-                # weight gradient, data gradient and the activation-derivative epilogue from ONE pass over dz_d and z_e
-                st_e = rec["st_e"]
-                merged = ops.dw_conv_bwd_g(dz_d, cna[0].weight.reshape(-1, k * k), rec["z_e"], st_e[0], st_e[1], act, k, cnf.stride)
-                g[f"{pre}.{blk.i_dw}.0.weight"] = merged[2].view_as(cna[0].weight)
-                in_shape = tuple(rec["z_e"].shape)
-            elif y_e is None:           # fused expand-BN: the depthwise input is act(a z_e + b), evaluated on load
-                st_e = rec["st_e"]
-                g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad_tf(dz_d, rec["z_e"], st_e[0], st_e[1], act, k,
-                                                                       cnf.stride).view_as(cna[0].weight)
-                in_shape = tuple(rec["z_e"].shape)
+                ds = ops.plane_dot(dxs, rec["y_d"])
+            if _FUSE_SE_MLP:
+                # the gate MLP's backward as two launches (csrc/se_train.hip) instead of ~25 KB-sized torch ops
+                dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d)
+                g[sp + ".fc2.weight"], g[sp + ".fc2.bias"] = dW2, db2
+                g[sp + ".fc1.weight"], g[sp + ".fc1.bias"] = dW1, db1
             else:
-                g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
-                in_shape = tuple(y_e.shape)
-            if v2 and not no_expand:
-                # expand conv + BN + act without dz_e (csrc/train_fuse.hip): g = dy_e * act'(.) and sum g leave the
-                # depthwise data-gradient kernel; dW / dx follow from Gx = sum g x^T and the forward's Gram products
-                st_e = rec["st_e"]
-                cna_e = blk.block[blk.i_expand]
-                W = cna_e[0].weight.flatten(1)
-                if merged is not None:
-                    g_e, gparts = merged[0], merged[1]
-                else:
-                    g_e, gparts = ops.dw_conv_dgrad_g(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
-                                                      rec["z_e"], st_e[0], st_e[1], act)
-                del dz_d
-                frozen = getattr(st_e[2], "_eat_frozen", False)
-                n_e = inp.shape[0] * inp.shape[2] * inp.shape[3]
-                Gx = ops.pw_conv_wgrad(g_e, inp)
-                Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
-                dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
-                                                                 frozen=frozen, centered=not frozen)
-                g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
-                g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
-                S_e = inp.shape[2] * inp.shape[3]
-                if not frozen and _CAT_DGRAD and S_e % 4 == 0:
-                    # dx = [WaT | M] [g ; x] + c0 (+ residual-branch gradient): one GEMM over both tensors
-                    wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
-                    dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad)
-                else:
-                    t = res_grad
-                    if not frozen:                                                  # M x + c0 (+ residual-branch gradient)
-                        t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
-                    dout = ops.pw_conv(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
-                                       NONE, res=t)
-                del g_e
-                join_side()
+                dq = ds * scale * (1.0 - scale)
+                g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
+                g[sp + ".fc2.bias"] = dq.sum(0)
+                dh = _mm_nt(dq, _t(se.fc2.weight)) * (h > 0).float()
+                zmean = pool * (1.0 / S_d)
+                g[sp + ".fc1.weight"] = _mm_nt(_t(dh), _t(zmean))
+                g[sp + ".fc1.bias"] = dh.sum(0)
+                gadd = _mm_nt(dh, _t(se.fc1.weight)) * (1.0 / S_d)
+            gscale = scale
+        # depthwise conv + BN + act
+        cna = blk.block[blk.i_dw]
+        k = cnf.kernel
+        y_e = rec["y_e"]
+        merged = None
+        no_expand = blk.i_expand is None
+        src_shape = tuple((y_e if y_e is not None else rec["z_e"]).shape)
+        # a block without expand conv hands its residual-branch gradient to the stem's backward kernel, which adds the
+        # two on load (the merged kernel has no residual input)
+        res_ok = not no_expand or res_grad is None or (i == 0 and sv["stem"][1] is None)
+        if (_MERGED_DW_BWD and _DW_BN_ON_LOAD and (y_e is None or no_expand) and res_ok
+                and ops.dw_bwd_merged_ok(rec["z_d"].shape, src_shape, k, cnf.stride)):
+            # large planes: dz_d is never written - the merged backward kernel evaluates the BatchNorm + activation
+            # backward of the depthwise output on load from (dxs, z_d) and the channel sums of the reduce pass
+            st_d = rec["st_d"]
+            nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
+            sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P,
+                                                   sums=bn_sums(cnf.expanded_channels, nw, nbias))
+            bn_grads(dgam, dbet, nw, nbias)
+            w_d = cna[0].weight.reshape(-1, k * k)
+            if no_expand:
+                C_d = cnf.expanded_channels
+                dout, _, dw_d = ops.dw_conv_bwd_bn_g(dxs, rec["z_d"], st_d, act, sums, w_d, y_e, _ones.get(C_d, dev),
+                                                     _zeros.get(C_d, dev), NONE, k, cnf.stride, gscale=gscale,
+                                                     gadd=gadd, want_gsum=False)
+                dout2 = res_grad
+                g[f"{pre}.{blk.i_dw}.0.weight"] = dw_d.view_as(cna[0].weight)
+                del dxs
                 sv["blocks"][i] = None
                 continue
-            dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
-                                     res=res_grad if no_expand else None)
-            del dz_d
-            if no_expand:
-                dout = dy_e
-            else:
-                cna = blk.block[blk.i_expand]
-                dz_e, dgam, dbet = ops.bn_act_bwd(dy_e, rec["z_e"], *rec["st_e"], act)
-                del dy_e
-                g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
-                g[f"{pre}.{blk.i_expand}.0.weight"] = ops.pw_conv_wgrad(dz_e, inp).view_as(cna[0].weight)
-                wpt = ops.pw_prepack(cna[0].weight.flatten(1), trans=True)
-                dout = ops.pw_conv(dz_e, wpt, _zeros.get(cnf.input_channels, dev), cnf.input_channels, NONE,
-                                   res=res_grad)
-                del dz_e
-            join_side()
-            sv["blocks"][i] = None
-
-        # ---- stem
-        x, z0, st0 = sv["stem"][:3]
-        stem = model.features[0]
-        if z0 is None:
-            # one pass over the block-0 gradient: g = dout * hswish'(.) from the log-mel window, Gx = sum g p^T, sum g
-            Tm0, sp0 = sv["stem"][3:]
-            W0 = stem[0].weight.reshape(-1, 9)
-            Gx, gparts = ops.stem_bwd(dout, x, W0, st0[0], st0[1], HSWISH, dy2=dout2)
-            frozen = getattr(st0[2], "_eat_frozen", False)
-            if frozen:
-                Tm0, sp0 = Gx, _zeros.get(9, dev)                                         # not read (m1 = m2 = 0)
-            dW, dgam, dbet = ops.expand_bwd_coef(W0, Gx, Tm0, sp0, gparts, st0[0], st0[2], st0[3], dout.numel() // W0.shape[0],
-                                                 frozen=frozen, need_dx=False)[:3]
-            g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
-            g["features.0.0.weight"] = dW.view_as(stem[0].weight)
+            st_e = rec["st_e"]
+            merged = ops.dw_conv_bwd_bn_g(dxs, rec["z_d"], st_d, act, sums, w_d, rec["z_e"], st_e[0], st_e[1], act, k,
+                                          cnf.stride, gscale=gscale, gadd=gadd)
+            g[f"{pre}.{blk.i_dw}.0.weight"] = merged[2].view_as(cna[0].weight)
+            in_shape = src_shape
+            dz_d = None
+            del dxs
         else:
-            dz0, dgam, dbet = ops.bn_act_bwd(dout, z0, *st0, HSWISH)
-            g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
-            g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
-        if bn_reg:
-            sf = bn_buf.float()
-            for wname, bname, C, off in bn_reg:
-                g[wname], g[bname] = sf[off + C:off + 2 * C], sf[off:off + C]
-        grads = g.finish()
-        return (None,) * n_lead + tuple(grads.get(n) for n in ctx.names)
+            nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
+            if se_P is not None:
+                dz_d, dgam, dbet = ops.bn_act_bwd_se(dxs, rec["z_d"], *rec["st_d"], act, se_P, gscale, gadd,
+                                                     sums=bn_sums(cnf.expanded_channels, nw, nbias))
+            else:
+                dz_d, dgam, dbet = ops.bn_act_bwd(dxs, rec["z_d"], *rec["st_d"], act, gscale=gscale, gadd=gadd,
+                                                  sums=bn_sums(cnf.expanded_channels, nw, nbias))
+            del dxs
+            bn_grads(dgam, dbet, nw, nbias)
+        if merged is not None:
+            pass
+        elif y_e is None and _MERGED_DW_BWD:
+            # weight gradient, data gradient and the activation-derivative epilogue from ONE pass over dz_d and z_e
+            st_e = rec["st_e"]
+            merged = ops.dw_conv_bwd_g(dz_d, cna[0].weight.reshape(-1, k * k), rec["z_e"], st_e[0], st_e[1], act, k, cnf.stride)
+            g[f"{pre}.{blk.i_dw}.0.weight"] = merged[2].view_as(cna[0].weight)
+            in_shape = tuple(rec["z_e"].shape)
+        elif y_e is None:           # fused expand-BN: the depthwise input is act(a z_e + b), evaluated on load
+            st_e = rec["st_e"]
+            g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad_tf(dz_d, rec["z_e"], st_e[0], st_e[1], act, k,
+                                                                   cnf.stride).view_as(cna[0].weight)
+            in_shape = tuple(rec["z_e"].shape)
+        else:
+            g[f"{pre}.{blk.i_dw}.0.weight"] = ops.dw_conv_wgrad(dz_d, y_e, k, cnf.stride).view_as(cna[0].weight)
+            in_shape = tuple(y_e.shape)
+        if not no_expand:
+            # expand conv + BN + act without dz_e (csrc/train_fuse.hip): g = dy_e * act'(.) and sum g leave the
+            # depthwise data-gradient kernel; dW / dx follow from Gx = sum g x^T and the forward's Gram products
+            st_e = rec["st_e"]
+            cna_e = blk.block[blk.i_expand]
+            W = cna_e[0].weight.flatten(1)
+            if merged is not None:
+                g_e, gparts = merged[0], merged[1]
+            else:
+                g_e, gparts = ops.dw_conv_dgrad_g(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride,
+                                                  rec["z_e"], st_e[0], st_e[1], act)
+            del dz_d
+            frozen = getattr(st_e[2], "_eat_frozen", False)
+            n_e = inp.shape[0] * inp.shape[2] * inp.shape[3]
+            Gx = ops.pw_conv_wgrad(g_e, inp)
+            Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
+            dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
+                                                             frozen=frozen, centered=not frozen)
+            g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
+            g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
+            S_e = inp.shape[2] * inp.shape[3]
+            if not frozen and _CAT_DGRAD and S_e % 4 == 0:
+                # dx = [WaT | M] [g ; x] + c0 (+ residual-branch gradient): one GEMM over both tensors
+                wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
+                dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad)
+            else:
+                t = res_grad
+                if not frozen:                                                  # M x + c0 (+ residual-branch gradient)
+                    t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
+                dout = ops.pw_conv(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
+                                   NONE, res=t)
+            del g_e
+            sv["blocks"][i] = None
+            continue
+        dy_e = ops.dw_conv_dgrad(dz_d, cna[0].weight.reshape(-1, k * k), in_shape, k, cnf.stride, res=res_grad)
+        del dz_d
+        dout = dy_e                    # (only a block without expand conv gets here)
+        sv["blocks"][i] = None
+
+    # ---- stem
+    x, z0, st0 = sv["stem"][:3]
+    stem = model.features[0]
+    if z0 is None:
+        # one pass over the block-0 gradient: g = dout * hswish'(.) from the log-mel window, Gx = sum g p^T, sum g
+        Tm0, sp0 = sv["stem"][3:]
+        W0 = stem[0].weight.reshape(-1, 9)
+        Gx, gparts = ops.stem_bwd(dout, x, W0, st0[0], st0[1], HSWISH, dy2=dout2)
+        frozen = getattr(st0[2], "_eat_frozen", False)
+        if frozen:
+            Tm0, sp0 = Gx, _zeros.get(9, dev)                                         # not read (m1 = m2 = 0)
+        dW, dgam, dbet = ops.expand_bwd_coef(W0, Gx, Tm0, sp0, gparts, st0[0], st0[2], st0[3], dout.numel() // W0.shape[0],
+                                             frozen=frozen, need_dx=False)[:3]
+        g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
+        g["features.0.0.weight"] = dW.view_as(stem[0].weight)
+    else:
+        dz0, dgam, dbet = ops.bn_act_bwd(dout, z0, *st0, HSWISH)
+        g["features.0.1.weight"], g["features.0.1.bias"] = dgam, dbet
+        g["features.0.0.weight"] = ops.dw_conv_wgrad(dz0, x, 3, 2).view_as(stem[0].weight)
+    if bn_reg:
+        sf = bn_buf.float()
+        for wname, bname, C, off in bn_reg:
+            g[wname], g[bname] = sf[off + C:off + 2 * C], sf[off:off + C]
+    grads = g.finish()
+    return (None,) * n_lead + tuple(grads.get(n) for n in ctx.names)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Round 3 plan (EAT_TRAIN_V=2, default).  Same math as MNTrainFunction, fewer passes over the expanded tensors
+# The training plan (round 3).  Same math as one statistics pass + one apply pass per BatchNorm, fewer passes over the expanded tensors
 # (csrc/train_fuse.hip has the algebra):
 #   * expand conv: BatchNorm statistics from the Gram matrix of the block input (no pass over z_e); backward through
 #     BN + activation WITHOUT dz_e: the depthwise data-gradient kernel's epilogue writes g = dy_e * act'(.) and sum g,
 #     the weight gradient / data gradient are wgrad(g, x) and two 1x1 convs with corrected weights;
 #   * depthwise conv: sum / sum of squares of its output leave the conv kernel's epilogue as per-wave partials.
 # Expanded-resolution passes per block: forward 3 -> 2, backward 9 -> 5.
-_TRAIN_V = int(os.environ.get("EAT_TRAIN_V", "2"))
+_TRAIN_V = 2                         # (bench.py reports it; the round-2 plan behind EAT_TRAIN_V=1 was removed in round 4)
 _FUSE_SE_BWD = os.environ.get("EAT_FUSE_SE_BWD", "1") == "1"     # A/B: gate gradient + BN-backward sums in one pass
 # A/B: BatchNorm + activation (+ SE scale) of the depthwise output evaluated on load inside the project conv and its
 # weight gradient - the activated tensor y_d is never written (SE blocks: one read-only pass for the squeeze sums)
@@ -538,10 +391,8 @@ _FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
 # A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
 _MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
 _DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthwise BN backward evaluated on load in the merged backward kernel
-# side stream for off-critical-path launches.  OFF by default: -0.26 ms in good runs (24.9 vs 25.2 ms), but the replay time
-# of the captured step became erratic from process to process (26.8 / 114.8 / 62.9 / 38.7 ms in four consecutive runs on one
-# box; never seen in ~40 single-stream runs) - a hipGraph with ~60 fork / join edges is not worth 1 %
-_OVERLAP = os.environ.get("EAT_TRAIN_OVERLAP", "0") == "1"
+# (a side stream for off-critical-path launches was measured in round 3 - -0.26 ms in good runs, erratic replay times of the
+#  captured step in others - and removed in round 4: DESIGN 7)
 _EPI_STATS = os.environ.get("EAT_PW_EPI_STATS", "1") != "0"      # project / last conv: BatchNorm statistics in the 1x1 epilogue
 _PREPACK_PLAN = os.environ.get("EAT_PREPACK_PLAN", "1") == "1"      # A/B: all weight packs of the step from one launch
 _FUSE_SE_MLP = os.environ.get("EAT_FUSE_SE_MLP", "1") == "1"        # A/B: SE gate MLP backward as two launches (csrc/se_train.hip)
@@ -609,37 +460,21 @@ class MNTrainFunction2(torch.autograd.Function):
                 cna = blk.block[blk.i_expand]
                 W = cna[0].weight.flatten(1)
                 n_e = B * inp.shape[2] * inp.shape[3]
-                forked = False
                 if cna[1].training:
-                    if _OVERLAP:
-                        # the Gram chain (three latency-bound launches) next to the expand conv, which does not need its result
-                        main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
-                        side_s.wait_stream(main_s)
-                        forked = True
-                        torch.cuda.set_stream(side_s)
-                    try:
-                        # centred Gram matrix of the block input (reproducible; x - mean on load: the variance is not a
-                        # difference of two (mean / std)^2-times larger sums)
-                        G = ops.gram(inp, exact=exact, sx=sx)
-                        if W.shape[1] <= 192:
-                            Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e, centered=True)   # T = W Gc and the BatchNorm state, one launch
-                        else:
-                            # wide inputs (mn40: up to 640 channels): every block of the one-launch form would stream the whole
-                            # G from L2 (C_out x C_in^2 floats: 0.79 ms at 3840 x 640) - W G on the matrix cores instead
-                            Tm = ops.linear(W, G, None, NONE)
-                            st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e, centered=True)
-                    finally:
-                        if forked:
-                            torch.cuda.set_stream(main_s)
-                    if forked:
-                        for t_ in (Tm,) + tuple(st_e):
-                            t_.record_stream(main_s)
+                    # centred Gram matrix of the block input (reproducible; x - mean on load: the variance is not a
+                    # difference of two (mean / std)^2-times larger sums)
+                    G = ops.gram(inp, exact=exact, sx=sx)
+                    if W.shape[1] <= 192:
+                        Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e, centered=True)   # T = W Gc and the BatchNorm state, one launch
+                    else:
+                        # wide inputs (mn40: up to 640 channels): every block of the one-launch form would stream the whole
+                        # G from L2 (C_out x C_in^2 floats: 0.79 ms at 3840 x 640) - W G on the matrix cores instead
+                        Tm = ops.linear(W, G, None, NONE)
+                        st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e, centered=True)
                 else:
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
                 wp = _pk(plan, ("e", bi), cna[0].weight)
                 z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
-                if forked:
-                    main_s.wait_stream(side_s)
                 rec.update(z_e=z_e, st_e=st_e, Tm=Tm, sx=sx)
                 tf = (st_e[0], st_e[1], act)
             src = z_e if blk.i_expand is not None else inp
@@ -715,7 +550,7 @@ class MNTrainFunction2(torch.autograd.Function):
         ctx.saved = None
         dfeat = rest[0] if ctx.mode == 0 else None
         with ops.precision(getattr(model, "train_precision", "fp32")), ops.zero_arena.scope("mn_bwd"):
-            return MNTrainFunction._backward_impl(ctx, model, sv, dout0, dfeat, v2=True, n_lead=4)
+            return _backward_impl(ctx, model, sv, dout0, dfeat, n_lead=4)
 
 
 def forward_train(model, x, return_fmaps=False):
@@ -738,11 +573,7 @@ def forward_train(model, x, return_fmaps=False):
     model._eat_trunk_active = trunk       # dp.py: the head's gradients come from torch autograd then (their own reducer hooks)
     with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters, ops.zero_arena.scope("mn_fwd"):
         if not trunk:
-            if _TRAIN_V >= 2:
-                return MNTrainFunction2.apply(model, x, mask, 0, *params)
-            return MNTrainFunction.apply(model, x, mask, *params)
-        if _TRAIN_V < 2:
-            raise NotImplementedError("non-default heads / return_fmaps in train mode need the round-3 plan (EAT_TRAIN_V=2)")
+            return MNTrainFunction2.apply(model, x, mask, 0, *params)
         outs = MNTrainFunction2.apply(model, x, None, 1, *params)
         y_l, fmaps = outs[0], list(outs[1:])
         feat = y_l.mean(dim=(2, 3))

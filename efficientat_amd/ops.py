@@ -914,6 +914,11 @@ def bn_bwd_apply(g, z, a, b, mean, invstd, sums, inplace=True):
     return dz
 
 
+def block_fused_supported(Cin, Cexp, Cout, k, stride, act, proj, F=64, T=500):
+    """True where the register-resident block kernel (csrc/irb.hip) has an instantiation: `mbconv` (proj) / `fused_expand_dw`."""
+    return bool(_lib.lib().eat_block_fused_supported(Cin, Cexp, Cout, F, T, k, stride, act, 1 if proj else 0))
+
+
 def fused_expand_dw(x, wp_e, bias_e, w_d, bias_d, Cexp, k, stride, act, pool=None):
     """expand 1x1 + BN + act -> depthwise k x k + BN + act in one kernel (eval; early blocks)."""
     B, Cin, F, T = x.shape

@@ -509,7 +509,10 @@ int eat_dw_conv_dyn_bwd_bn_g(const float* dy, const float* z, const float* bn_a,
 /* ---- fused expand 1x1 + depthwise k x k (eval): models/mn/block_types.py:138-162 (+ :72-73) ------
  * y (B,Cexp,Fo,To) = act(dw_k,s( act(W_e x + bias_e) ) + bias_d) without materialising the expanded
  * tensor: wp_e = eat_pw_prepack of the BN-folded expand weights, w_d (Cexp,k*k) BN-folded taps;
- * pool (B,Cexp) or NULL accumulates plane sums (zeroed by the caller).  act in {relu, hswish}. */
+ * pool (B,Cexp) or NULL accumulates plane sums (zeroed by the caller).  Register-resident kernel (csrc/irb.hip) with
+ * instantiations for the early-block geometries (ReLU; C_in 16 with 3x3 / stride 2, C_in 24 with 3x3 / stride 1 and
+ * 5x5 / stride 2; Cexp % 8 == 0): ask eat_block_fused_supported, anything else returns EAT_EINVAL (use eat_pw_conv_fwd +
+ * eat_dw_conv_fwd). */
 int eat_fused_expand_dw_fwd(const float* x, const float* wp_e, const float* bias_e, const float* w_d,
                             const float* bias_d, float* y, float* pool, int B, int Cin, int Cexp, int F,
                             int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream);
@@ -541,12 +544,17 @@ int eat_front_fwd(const float* x, const float* w_s, const float* bias_s, const f
  * y (B,Cout,Fo,To) = W_p . act(dw_k,s( act(W_e x + bias_e) ) + bias_d) + bias_p [+ res]; neither the
  * expanded tensor nor the depthwise output touches HBM.  wp_e / wp_p = eat_pw_prepack of the BN-folded
  * expand (Cexp,Cin) / project (Cout,Cexp) weights, w_d (Cexp,k*k) BN-folded taps.  res (B,Cout,Fo,To)
- * or NULL is the residual input (stride 1, Cin == Cout).  Cin % 4 == 0, Cin <= 40, Cout <= 80,
- * act in {relu, hswish}. */
+ * or NULL is the residual input (stride 1, Cin == Cout).  Instantiated for mn10's blocks 2 and 3 (16 -> 64 -> 24 with
+ * 3x3 / stride 2, 24 -> 72 -> 24 with 3x3 / stride 1, ReLU); eat_block_fused_supported answers for a geometry, anything
+ * else returns EAT_EINVAL (use the separate kernels). */
 int eat_mbconv_fwd(const float* x, const float* wp_e, const float* bias_e, const float* w_d,
                    const float* bias_d, const float* wp_p, const float* bias_p, const float* res, float* y,
                    int B, int Cin, int Cexp, int Cout, int F, int T, int Fo, int To, int k, int stride,
                    int act, eat_stream_t stream);
+
+/* Host query (no launch): 1 when eat_mbconv_fwd (proj = 1) / eat_fused_expand_dw_fwd (proj = 0) has an instantiation for
+ * an InvertedResidual block (models/mn/block_types.py:138-181) of this geometry on an (F, T) input plane, else 0. */
+int eat_block_fused_supported(int Cin, int Cexp, int Cout, int F, int T, int k, int stride, int act, int proj);
 
 /* Expand 1x1 conv + BN + act -> depthwise 3x3 (stride 1) conv + BN + act [+ SE squeeze sums] in one kernel for small
  * planes (models/mn/block_types.py:138-162, :72-73): the expanded tensor stays in LDS (csrc/expand_dw.hip).

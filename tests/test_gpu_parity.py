@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():  # collected but skipped on the CPU-only build container
     pytest.skip("no GPU", allow_module_level=True)
 
-from efficientat_amd import ops  # noqa: E402
+from efficientat_amd import _lib, ops  # noqa: E402
 from efficientat_amd.mn import get_model  # noqa: E402
 from efficientat_amd.preprocess import AugmentMelSTFT  # noqa: E402
 
@@ -311,7 +311,9 @@ def test_cpu_tensor_fails_loudly():
     (3, 24, 72, 33, 71, 5, 2, 1), (2, 24, 72, 9, 30, 5, 2, 1), (3, 16, 64, 17, 63, 3, 2, 1), (2, 24, 72, 8, 31, 3, 1, 1),
     (1, 24, 40, 5, 7, 5, 2, 1), (2, 24, 72, 1, 3, 5, 2, 1)])
 def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
-    """expand 1x1 + act -> depthwise + act fused (csrc/mbconv.hip, SE variant) vs the two-step torch reference."""
+    """expand 1x1 + act -> depthwise + act fused (csrc/irb.hip, SE variant) vs the two-step torch reference; geometries
+    without an instantiation must say so (eat_block_fused_supported) and fail loudly - the model's plan then uses the
+    separate kernels."""
     x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
     be, rs = _rand(Ce, seed=3, scale=0.2), torch.rand(Ce, generator=torch.Generator().manual_seed(4)) + 0.5
     wd, bd = _rand(Ce, 1, k, k, seed=5, scale=0.3), _rand(Ce, seed=6, scale=0.1)
@@ -319,15 +321,21 @@ def test_fused_expand_dw(B, Ci, Ce, F_, T, k, s, act):
     e = f(F.conv2d(x, (we * rs[:, None]).view(Ce, Ci, 1, 1), be))
     ref = f(F.conv2d(e, wd, bd, s, (k - 1) // 2, 1, Ce))
     pool = torch.zeros(B, Ce, device=DEV)
-    got = ops.fused_expand_dw(x.to(DEV), ops.pw_prepack(we.to(DEV), rs.to(DEV)), be.to(DEV),
-                              wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), Ce, k, s, act, pool)
+    call = lambda: ops.fused_expand_dw(x.to(DEV), ops.pw_prepack(we.to(DEV), rs.to(DEV)), be.to(DEV),
+                                       wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), Ce, k, s, act, pool)
+    if not ops.block_fused_supported(Ci, Ce, 0, k, s, act, False, F_, T):
+        assert (Ci, k, s, act) not in {(16, 3, 2, 1), (24, 3, 1, 1), (24, 5, 2, 1)}
+        with pytest.raises(_lib.EatHipError):
+            call()
+        return
+    got = call()
     _close(got, ref, 5e-6, "fused expand+dw")
     _close(pool, ref.sum(dim=(2, 3)), 5e-5, "fused pool")
 
 
 @pytest.mark.parametrize("B,F_,T,act", [(2, 128, 1000, 1), (3, 128, 250, 1), (2, 37, 75, 2), (1, 128, 998, 1)])
 def test_front_stem_plus_first_block(B, F_, T, act):
-    """stem conv + hswish -> depthwise 3x3 + act -> project 1x1 + residual in one kernel (csrc/front.hip)
+    """stem conv + hswish -> depthwise 3x3 + act -> project 1x1 + residual in one kernel (csrc/irb.hip, FRONT mode)
     vs the torch composition (models/mn/model.py:124-133, block_types.py:150-181)."""
     C = 16
     x = _rand(B, 1, F_, T, seed=1)
@@ -353,7 +361,8 @@ def test_front_stem_plus_first_block(B, F_, T, act):
     (2, 24, 72, 24, 9, 30, 3, 1, 1, False), (1, 16, 64, 24, 2, 5, 3, 2, 1, False), (5, 24, 72, 24, 32, 250, 3, 1, 1, True)])
 def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
     """Whole inverted-residual block (expand + depthwise + project [+ residual]) in one kernel
-    (csrc/mbconv.hip) vs the three-step torch reference (models/mn/block_types.py:138-181)."""
+    (csrc/irb.hip) vs the three-step torch reference (models/mn/block_types.py:138-181); geometries without an
+    instantiation fail loudly."""
     x, we = _rand(B, Ci, F_, T, seed=1), _rand(Ce, Ci, seed=2, scale=Ci ** -0.5)
     be, rs = _rand(Ce, seed=3, scale=0.2), torch.rand(Ce, generator=torch.Generator().manual_seed(4)) + 0.5
     wd, bd = _rand(Ce, 1, k, k, seed=5, scale=0.3), _rand(Ce, seed=6, scale=0.1)
@@ -365,10 +374,15 @@ def test_mbconv_block(B, Ci, Ce, Co, F_, T, k, s, act, res):
     ref = F.conv2d(d, (wpj * rp[:, None]).double().view(Co, Ce, 1, 1), bp.double())
     if res:
         ref = ref + x.double()
-    got = ops.mbconv(x.to(DEV), ops.pw_prepack(we.to(DEV), rs.to(DEV)), be.to(DEV),
-                     wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), ops.pw_prepack(wpj.to(DEV), rp.to(DEV)),
-                     bp.to(DEV), Ce, Co, k, s, act, res=x.to(DEV) if res else None)
-    _close(got, ref.float(), 1e-5, "mbconv block")
+    call = lambda: ops.mbconv(x.to(DEV), ops.pw_prepack(we.to(DEV), rs.to(DEV)), be.to(DEV),
+                              wd.reshape(Ce, k * k).contiguous().to(DEV), bd.to(DEV), ops.pw_prepack(wpj.to(DEV), rp.to(DEV)),
+                              bp.to(DEV), Ce, Co, k, s, act, res=x.to(DEV) if res else None)
+    if not ops.block_fused_supported(Ci, Ce, Co, k, s, act, True, F_, T):
+        assert (Ci, Ce, Co, k, s, act) not in {(16, 64, 24, 3, 2, 1), (24, 72, 24, 3, 1, 1)}
+        with pytest.raises(_lib.EatHipError):
+            call()
+        return
+    _close(call(), ref.float(), 1e-5, "mbconv block")
 
 
 @pytest.mark.parametrize("B,Ci,Ce,F_,T,act,use_pool", [

@@ -443,3 +443,17 @@ def test_mn_backward_through_bucketed_rccl_reducer_matches_local():
         if "RCCL_REDUCER_OK" in r.stdout or r.returncode >= 0:
             break
     assert "RCCL_REDUCER_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_two_rank_data_parallel_step():
+    """Model-level data-parallel equivalence on TWO ranks (tests/dp_two_rank_case.py): after `enable_data_parallel` the
+    replicas hold rank 0's weights, and the gradient each rank finds in `.grad` is the mean over the ranks of the local
+    gradients - MN (monolithic backward), MN trunk mode (head hooks) and DyMN (hooks).  One GPU per rank over RCCL when
+    two GPUs are visible, else both ranks on cuda:0 through gloo."""
+    import subprocess
+    import sys
+    case = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_two_rank_case.py")
+    r = subprocess.run([sys.executable, case], capture_output=True, text=True, timeout=900)
+    if "DP_TWO_RANK_SKIP" in r.stdout:
+        pytest.skip("this torch build's gloo does not reduce device tensors and only one GPU is visible: " + r.stdout[-300:])
+    assert "DP_TWO_RANK_OK" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
