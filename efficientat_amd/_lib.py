@@ -64,6 +64,8 @@ SIGNATURES = {
     "eat_calib_copy": [_P, _P, ctypes.c_longlong, _I, _P],
     "eat_pw_conv_kcat_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dilated_fwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
+    "eat_dw_conv_dilated_dgrad": [_P, _P, _P] + [_I] * 9 + [_P],
+    "eat_dw_conv_dilated_wgrad": [_P, _P, _P] + [_I] * 9 + [_P],
     "eat_kd_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P],
     "eat_pw_wgrad_slots": [_I] * 6,
     "eat_pw_conv_wgrad_ws": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

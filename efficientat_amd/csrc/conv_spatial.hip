@@ -367,3 +367,81 @@ extern "C" int eat_dw_conv_dilated_fwd(const float* x, const float* w, const flo
                      Fo, To, k, stride, dilation, act);
   return eat::check_launch("eat_dw_conv_dilated_fwd");
 }
+
+// Backward of the dilated depthwise conv (training of the `dilated=True` networks; the same generic, unmeasured form):
+//   dx[b,c,fi,ti] = sum_{u,v} w[c,u,v] dz[b,c,i,j] over the outputs with i*stride - pad + u*dil = fi (same for j / ti);
+//   dw[c,u,v]     = sum_{b,i,j} dz[b,c,i,j] x[b,c,i*stride - pad + u*dil, j*stride - pad + v*dil]  (atomics, dw zeroed).
+namespace {
+__global__ __launch_bounds__(256) void dw_dilated_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                               float* __restrict__ dx, int C, int F, int T, int Fo, int To,
+                                                               int k, int stride, int dil) {
+  const int plane = blockIdx.y, c = plane % C;
+  const int pad = (k - 1) / 2 * dil;
+  const float* g = dz + (size_t)plane * Fo * To;
+  const float* wc = w + (size_t)c * k * k;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * T; e += gridDim.x * blockDim.x) {
+    const int fi = e / T, ti = e - fi * T;
+    float acc = 0.0f;
+    for (int u = 0; u < k; ++u) {
+      const int ii = fi + pad - u * dil;
+      if (ii < 0 || ii % stride != 0 || ii / stride >= Fo) continue;
+      for (int v = 0; v < k; ++v) {
+        const int jj = ti + pad - v * dil;
+        if (jj >= 0 && jj % stride == 0 && jj / stride < To)
+          acc = fmaf(wc[u * k + v], g[(size_t)(ii / stride) * To + jj / stride], acc);
+      }
+    }
+    dx[(size_t)plane * F * T + e] = acc;
+  }
+}
+
+// one block per (tap, channel): the 256 threads walk the channel's output positions of every sample
+__global__ __launch_bounds__(256) void dw_dilated_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                               float* __restrict__ dw, int B, int C, int F, int T, int Fo,
+                                                               int To, int k, int stride, int dil) {
+  __shared__ float s_red[4];
+  const int tap = blockIdx.x, c = blockIdx.y;
+  const int u = tap / k, v = tap - u * k;
+  const int pad = (k - 1) / 2 * dil;
+  float acc = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* g = dz + ((size_t)b * C + c) * Fo * To;
+    const float* xp = x + ((size_t)b * C + c) * F * T;
+    for (int e = threadIdx.x; e < Fo * To; e += 256) {
+      const int i = e / To, j = e - i * To;
+      const int fi = i * stride - pad + u * dil, ti = j * stride - pad + v * dil;
+      if (fi >= 0 && fi < F && ti >= 0 && ti < T) acc = fmaf(g[e], xp[(size_t)fi * T + ti], acc);
+    }
+  }
+  acc = eat::wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dw[(size_t)c * k * k + tap] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+}  // namespace
+
+static int dilated_geometry_ok(int F, int T, int Fo, int To, int k, int stride, int dilation) {
+  if (k < 1 || k > 7 || (k & 1) == 0 || stride < 1 || dilation < 1) return 0;
+  const int pad = (k - 1) / 2 * dilation;
+  return Fo == (F + 2 * pad - dilation * (k - 1) - 1) / stride + 1 && To == (T + 2 * pad - dilation * (k - 1) - 1) / stride + 1;
+}
+
+extern "C" int eat_dw_conv_dilated_dgrad(const float* dz, const float* w, float* dx, int B, int C, int F, int T, int Fo, int To,
+                                         int k, int stride, int dilation, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dilated_geometry_ok(F, T, Fo, To, k, stride, dilation)) return eat::fail(EAT_EINVAL, "eat_dw_conv_dilated_dgrad: bad geometry");
+  int gx = (F * T + 255) / 256;
+  gx = gx > 32 ? 32 : gx;
+  hipLaunchKernelGGL(dw_dilated_dgrad_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, dz, w, dx, C, F, T, Fo, To, k,
+                     stride, dilation);
+  return eat::check_launch("eat_dw_conv_dilated_dgrad");
+}
+
+extern "C" int eat_dw_conv_dilated_wgrad(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To,
+                                         int k, int stride, int dilation, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dilated_geometry_ok(F, T, Fo, To, k, stride, dilation)) return eat::fail(EAT_EINVAL, "eat_dw_conv_dilated_wgrad: bad geometry");
+  hipLaunchKernelGGL(dw_dilated_wgrad_kernel, dim3(k * k, C), dim3(256), 0, (hipStream_t)stream, dz, x, dw, B, C, F, T, Fo, To, k,
+                     stride, dilation);
+  return eat::check_launch("eat_dw_conv_dilated_wgrad");
+}

@@ -214,23 +214,30 @@ class PwConvB(torch.autograd.Function):
 
 
 class DwConv(torch.autograd.Function):
-    """Static depthwise k x k conv (no bias) of the SE-less blocks of a `use_dy_blocks="replace_se"` network."""
+    """Static depthwise k x k conv (no bias): the SE-less blocks of a `use_dy_blocks="replace_se"` network and the modular
+    MN train path (mn_train.forward_train_modular); dilation > 1 (models/mn/model.py:244-269) runs the generic dilated kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, k, stride):
+    def forward(ctx, x, w, k, stride, dilation=1):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
-        ctx.k, ctx.stride = k, stride
+        ctx.k, ctx.stride, ctx.dilation = k, stride, dilation
         C = x.shape[1]
+        if dilation > 1:
+            return ops.dw_conv_dilated(x, w.reshape(C, k * k), _zeros.get(C, x.device), k, stride, dilation, NONE)
         return ops.dw_conv(x, w.reshape(C, k * k), _zeros.get(C, x.device), k, stride, NONE)
 
     @staticmethod
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
         dz = dz.contiguous()
-        k, stride = ctx.k, ctx.stride
-        dx = ops.dw_conv_dgrad(dz, w.reshape(-1, k * k).contiguous(), x.shape, k, stride)
-        return dx, ops.dw_conv_wgrad(dz, x, k, stride).view_as(w), None, None
+        k, stride, dil = ctx.k, ctx.stride, ctx.dilation
+        w2 = w.reshape(-1, k * k).contiguous()
+        if dil > 1:
+            return (ops.dw_conv_dilated_dgrad(dz, w2, x.shape, k, stride, dil),
+                    ops.dw_conv_dilated_wgrad(dz, x, k, stride, dil).view_as(w), None, None, None)
+        dx = ops.dw_conv_dgrad(dz, w2, x.shape, k, stride)
+        return dx, ops.dw_conv_wgrad(dz, x, k, stride).view_as(w), None, None, None
 
 
 def _bank_grad(G, att, bank):

@@ -405,7 +405,12 @@ class MN(nn.Module):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.zeros_(m.bias)
         self._cache = _FoldCache()
-        self._monolithic_backward = True      # train-mode backward is one autograd Function (mn_train.py)
+        # dilated tails / squeeze-excitation beyond the channel axis train on per-layer autograd Functions
+        # (mn_train.forward_train_modular); everything else on ONE autograd Function that hands its gradients to the
+        # data-parallel reducer itself (mn_train.py, dp.py)
+        self._modular_train = any(b.cnf.dilation > 1 or (b.i_se is not None and not b.block[b.i_se].channel_only)
+                                  for b in self.features[1:-1])
+        self._monolithic_backward = not self._modular_train
         # arithmetic of the 1x1 forward / data-gradient GEMMs of the train step (ops.precision): "auto" =
         # exact fp32 below C_in 40, split-operand bf16x3 (fp32-class) above; "fp32"; "bf16" = BASELINE config 3
         self.train_precision = os.environ.get("EAT_TRAIN_PRECISION", "auto")
@@ -448,9 +453,9 @@ class MN(nn.Module):
         if not x.is_cuda:
             raise ops._lib.EatHipError("MN.forward needs a GPU tensor: efficientat_amd has no CPU path")
         if self.training:
-            if any(b.cnf.dilation > 1 or (b.i_se is not None and not b.block[b.i_se].channel_only) for b in self.features[1:-1]):
-                raise NotImplementedError("training on the HIP path covers se_dims='c' and dilation 1 (every head_type); "
-                                          "squeeze-excitation over t / dilated blocks are eval-only")
+            if self._modular_train:
+                from .mn_train import forward_train_modular
+                return forward_train_modular(self, x, return_fmaps)
             from .mn_train import forward_train
             return forward_train(self, x, return_fmaps)
         W = self._cache.get(self._fold_sources(), self._build_folded)

@@ -589,3 +589,71 @@ def forward_train(model, x, return_fmaps=False):
             # torch ops on the 4 x 32 map under torch autograd
             logits = model.classifier(y_l).reshape(x.shape[0], -1)
     return (logits, fmaps + [y_l]) if return_fmaps else (logits, feat)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Modular train path for the variants the monolithic plan does not cover: dilated tails (`dilated=True`,
+# models/mn/model.py:244-269) and squeeze-excitation over the time axis / several axes at once (`se_dims` beyond 'c',
+# models/mn/block_types.py:10-83).  Neither has a released checkpoint or a measured configuration: every conv / BatchNorm is
+# the library's kernel behind a per-layer autograd Function (the ones DyMN's static blocks use, dymn_train.py), the
+# concurrent SE block - a mean over two axes, two Linears on a vector of <= 960 entries, a broadcast product and the
+# max / avg / add / min of the gated copies - is torch ops under torch autograd.
+def _concurrent_se_train(se_block, y):
+    """ConcurrentSEBlock.forward (block_types.py:36-42) over SqueezeExcitation.forward (:72-83), differentiable."""
+    outs = []
+    for se in se_block.conc_se_layers:
+        d = se.gate_dim                                            # the axis that keeps its extent (1 = c, 3 = t)
+        m = y.mean(dim=[k for k in (1, 2, 3) if k != d])           # (B, extent)
+        gate = torch.sigmoid(F.linear(F.relu(F.linear(m, se.fc1.weight, se.fc1.bias)), se.fc2.weight, se.fc2.bias))
+        shape = [y.shape[0], 1, 1, 1]
+        shape[d] = gate.shape[1]
+        outs.append(gate.view(shape) * y)
+    if len(outs) == 1:
+        return outs[0]
+    st = torch.stack(outs, dim=0)
+    agg = se_block.se_agg
+    return (st.max(dim=0)[0] if agg == "max" else st.mean(dim=0) if agg == "avg" else st.sum(dim=0) if agg == "add"
+            else st.min(dim=0)[0])
+
+
+def forward_train_modular(model, x, return_fmaps=False):
+    """Train-mode `(logits, features)` / `(logits, fmaps)` of an MN with dilated blocks or SE beyond the channel axis."""
+    from .dymn_train import BnAct, DwConv, Linear, PwConv, StemConv
+    drop = model.classifier[4] if model.head_type == "mlp" else None
+    with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters, ops.zero_arena.scope("mn_fwd"):
+        x = x.contiguous().float()
+        stem = model.features[0]
+        cur = BnAct.apply(StemConv.apply(x, stem[0].weight), stem[1].weight, stem[1].bias, stem[1], HSWISH)
+        fmaps = [cur]
+        for blk in model.features[1:-1]:
+            cnf = blk.cnf
+            act = HSWISH if cnf.use_hs else RELU
+            inp = cur
+            if blk.i_expand is not None:
+                conv, bn = blk.block[blk.i_expand][0], blk.block[blk.i_expand][1]
+                cur = BnAct.apply(PwConv.apply(cur, conv.weight), bn.weight, bn.bias, bn, act)
+            conv, bn = blk.block[blk.i_dw][0], blk.block[blk.i_dw][1]
+            cur = BnAct.apply(DwConv.apply(cur, conv.weight, cnf.kernel, blk.dw_stride, cnf.dilation), bn.weight, bn.bias, bn, act)
+            if blk.i_se is not None:
+                cur = _concurrent_se_train(blk.block[blk.i_se], cur)
+            conv, bn = blk.block[blk.i_proj][0], blk.block[blk.i_proj][1]
+            cur = BnAct.apply(PwConv.apply(cur, conv.weight), bn.weight, bn.bias, bn, NONE)
+            if blk.use_res_connect:
+                cur = cur + inp
+            fmaps.append(cur)
+        last = model.features[-1]
+        y_l = BnAct.apply(PwConv.apply(cur, last[0].weight), last[1].weight, last[1].bias, last[1], HSWISH)
+        feat = y_l.mean(dim=(2, 3))
+        if model.head_type == "mlp":
+            fc1, fc2 = model.classifier[2], model.classifier[5]
+            h = F.hardswish(Linear.apply(feat, fc1.weight, fc1.bias))
+            override = getattr(model, "_drop_mask_override", None)
+            if drop is not None and drop.training:
+                if override is not None:
+                    h = h * (override.to(h.device).float() / (1.0 - drop.p))
+                elif drop.p > 0:
+                    h = F.dropout(h, drop.p, True)
+            logits = Linear.apply(h, fc2.weight, fc2.bias)
+        else:
+            logits = model.classifier(y_l).reshape(x.shape[0], -1)
+    return (logits, fmaps + [y_l]) if return_fmaps else (logits, feat)

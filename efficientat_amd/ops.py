@@ -84,6 +84,23 @@ def dw_conv_dilated(x, w, bias, k, stride, dilation, act, pool=None):
     return y
 
 
+def dw_conv_dilated_dgrad(dz, w, x_shape, k, stride, dilation):
+    """Data gradient of the dilated depthwise conv (training of `dilated=True` networks; generic kernel)."""
+    B, C, F, T = x_shape
+    dx = torch.empty((B, C, F, T), device=dz.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_dilated_dgrad", _dev(dz, "dz"), _dev(w, "w"), dx.data_ptr(), B, C, F, T, dz.shape[2], dz.shape[3],
+              k, stride, dilation, _stream())
+    return dx
+
+
+def dw_conv_dilated_wgrad(dz, x, k, stride, dilation):
+    B, C, F, T = x.shape
+    dw = torch.empty((C, k * k), device=dz.device, dtype=torch.float32)
+    _lib.call("eat_dw_conv_dilated_wgrad", _dev(dz, "dz"), _dev(x, "x"), dw.data_ptr(), B, C, F, T, dz.shape[2], dz.shape[3],
+              k, stride, dilation, _stream())
+    return dw
+
+
 def dw_conv_tf(x, in_a, in_b, in_act, w, bias, k, stride):
     """Depthwise conv of act_in(in_a[c] * x + in_b[c]) (evaluated on load), no output activation (train mode)."""
     B, C, F, T = x.shape

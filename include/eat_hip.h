@@ -79,6 +79,14 @@ int eat_dw_conv_fwd(const float* x, const float* w, const float* bias, float* y,
 int eat_dw_conv_dilated_fwd(const float* x, const float* w, const float* bias, float* y, float* pool, int B, int C,
                             int F, int T, int Fo, int To, int k, int stride, int dilation, int act, eat_stream_t stream);
 
+/* Backward of the dilated depthwise conv (training of the `dilated=True` networks, models/mn/model.py:244-269: autograd
+ * of F.conv2d(..., dilation) in block_types.py:150-162): dx (B,C,F,T) from dz (B,C,Fo,To) and the taps w (C,k*k);
+ * dw (C,k*k) = sum over batch and positions of dz times the shifted input (plain stores: one block per tap and channel). */
+int eat_dw_conv_dilated_dgrad(const float* dz, const float* w, float* dx, int B, int C, int F, int T, int Fo, int To,
+                              int k, int stride, int dilation, eat_stream_t stream);
+int eat_dw_conv_dilated_wgrad(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To,
+                              int k, int stride, int dilation, eat_stream_t stream);
+
 /* ---- pointwise 1x1 conv (GEMM): models/mn/block_types.py:138-147,167-171; mn/model.py:159-167
  * y[b] (Co,S) = act( W (Co,Ci) . (x[b] (Ci,S) * in_scale[b,:,None]) + bias[:,None] ) + res[b]
  * wp = W packed by eat_pw_prepack (BN scale folded in via row_scale), bias (Co);

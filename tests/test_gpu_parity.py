@@ -572,14 +572,11 @@ def test_mn_variants_match_reference_and_oracle(tag, golden_dir):
     assert np.abs(got.cpu().numpy() - g[f"{tag}/logits"]).max() < 1e-3 * scale
     assert np.abs(feat.cpu().numpy() - g[f"{tag}/features"]).max() < 1e-3 * max(1.0, np.abs(g[f"{tag}/features"]).max())
     model.train()
-    if tag.startswith("se_ct") or tag.startswith("se_t") or tag == "dilated_reduced":
-        with pytest.raises(NotImplementedError):
-            model(x.to(DEV))          # SE over t / dilated blocks: eval only on the HIP path, fails loudly
-        return
-    # heads (and se_dims='none'): one training step vs torch-CPU autograd over the oracle, and train-mode return_fmaps
+    # every variant - heads, se_dims='none', and (round 4: the modular train path of mn_train.py) SE over t / c + t and
+    # the dilated, reduced tail: one training step vs torch-CPU autograd over the oracle, and train-mode return_fmaps
     B = x.shape[0]
     y = (torch.rand(B, 527, generator=torch.Generator().manual_seed(8)) < 0.01).float()
-    keep = torch.ones(B, 1280)
+    keep = torch.ones(B, model.classifier[2].out_features if model.head_type == "mlp" else 1280)
     sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
     stats = {}
     logits_ref, _ = O.mn_forward(sdr, x, train=True, stats=stats, drop_mask=keep * 0.8, **VARIANTS[tag][1])

@@ -426,6 +426,23 @@ def test_mn40_bf16_train_step_tracks_fp32():
     assert float(np.median(cos)) > 0.9, float(np.median(cos))
 
 
+@pytest.mark.parametrize("B,C,F_,T,k,s,dil", [(2, 24, 8, 31, 5, 1, 2), (3, 16, 9, 20, 3, 1, 2), (2, 8, 12, 33, 3, 2, 2), (1, 12, 7, 15, 5, 1, 3)])
+def test_dilated_depthwise_conv_gradients(B, C, F_, T, k, s, dil):
+    """Dilated depthwise conv (models/mn/model.py:244-269, block_types.py:150-162 with dilation): forward, data gradient and
+    weight gradient of the generic kernels against torch autograd."""
+    x = _rand(B, C, F_, T, seed=1).requires_grad_(True)
+    w = _rand(C, 1, k, k, seed=2, scale=0.3).requires_grad_(True)
+    pad = (k - 1) // 2 * dil
+    y = F.conv2d(x, w, None, s, pad, dil, C)
+    dz = _rand(*y.shape, seed=3)
+    y.backward(dz)
+    w2 = w.detach().reshape(C, k * k).contiguous().to(DEV)
+    got = ops.dw_conv_dilated(x.detach().to(DEV), w2, torch.zeros(C, device=DEV), k, s, dil, ops.ACT_NONE)
+    assert _rel(got, y) < 1e-5
+    assert _rel(ops.dw_conv_dilated_dgrad(dz.to(DEV), w2, tuple(x.shape), k, s, dil), x.grad) < 1e-5
+    assert _rel(ops.dw_conv_dilated_wgrad(dz.to(DEV), x.detach().to(DEV), k, s, dil), w.grad.reshape(C, k * k)) < 2e-5
+
+
 # --------------------------------------------------------- data-parallel reducer on the GPU (RCCL, one rank)
 def test_mn_backward_through_bucketed_rccl_reducer_matches_local():
     """The MN monolithic backward pushes its gradients into dp.GradReducer in production order.  With ONE rank and forced
