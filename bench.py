@@ -153,35 +153,30 @@ def _alg_bytes(name, a):
         pool, w1, b1, w2, b2, out, B, C, H, N = a[:10]
         return "head_kernel", 4 * (B * C + C * H + H * N + B * N), 2 * B * H * (C + N)
     # ---- training-step entry points (symbols: the dispatch rules of csrc/train.hip / dw_plane.hip)
-    if name == "eat_pw_conv_wgrad":
-        dz, x, xs, dW, B, Co, Ci, S, mode = a[:9]
-        same = dz == x
-        nbytes = 4 * B * S * (Co if same else Co + Ci) + 4 * Co * Ci
-        if mode == 1 or S % 4:
-            sym = "pw_wgrad_kernel"
-        elif Co <= 64 and Ci <= 64 and (Co <= 16 or Ci <= 16 or (same and Co == Ci and not xs)):
-            mt, nt = (Co + 15) // 16, (Ci + 15) // 16
-            gram = same and mt == nt and not xs
-            sym = f"pw_wgrad_x3_narrow_kernel<{mt},{nt},{'true' if gram else 'false'}>"
-        else:
-            sym = f"pw_wgrad_x3_kernel<{1 if mode == 2 else 3}>"
-        return sym, nbytes, 2 * B * S * Co * Ci
-    if name in ("eat_pw_conv_wgrad_ws", "eat_pw_conv_wgrad_tf"):
-        if name == "eat_pw_conv_wgrad_ws":
+    if name in ("eat_pw_conv_wgrad", "eat_pw_conv_wgrad_ws", "eat_pw_conv_wgrad_tf"):
+        if name == "eat_pw_conv_wgrad":
+            dz, x, xs, dW, B, Co, Ci, S, mode = a[:9]
+            tf = None
+        elif name == "eat_pw_conv_wgrad_ws":
             dz, x, xs, dW, ws, nsl, B, Co, Ci, S, mode = a[:11]
             tf = None
         else:
             dz, x, tf, tfb, tfact, xs, dW, ws, nsl, B, Co, Ci, S, mode = a[:14]
         same = dz == x and tf is None
         nbytes = 4 * B * S * (Co if same else Co + Ci) + 4 * Co * Ci
-        if mode == 1 or S % 4:
+        # the library's own dispatch (csrc/train.hip: wgrad_plan), asked through its host helper
+        from efficientat_amd import _lib as _l
+        kind = int(_l.lib().eat_pw_wgrad_kernel_kind(B, Co, Ci, S, mode, 1 if dz == x else 0, 1 if xs else 0, 1 if tf else 0))
+        npr = 1 if mode == 2 else 3
+        if kind == 2:
             sym = "pw_wgrad_kernel"
-        elif Co <= 64 and Ci <= 64 and (Co <= 16 or Ci <= 16 or (same and Co == Ci and not xs)):
-            mt, nt = (Co + 15) // 16, (Ci + 15) // 16
-            gram = same and mt == nt and not xs
-            sym = f"pw_wgrad_x3_narrow_kernel<{mt},{nt},{'true' if gram else 'false'}>"
+        elif kind == 1:
+            sym = f"pw_wgrad_x3_kernel<{npr}>"
+        elif kind == 3:
+            sym = f"pw_wgrad_wide_kernel<{npr},*>"
         else:
-            sym = f"pw_wgrad_x3_kernel<{1 if mode == 2 else 3}>"
+            d = kind // 10
+            sym = f"pw_wgrad_x3_narrow_kernel<{d // 1000},{(d % 1000) // 10},{'true' if d % 10 else 'false'}>"
         return sym, nbytes, 2 * B * S * Co * Ci
     if name == "eat_pw_conv_tf_fwd":
         x, ta, tb, tact, wp, wmode, bias, sc, res, y, B, Ci, Co, S, act = a[:15]
@@ -346,7 +341,7 @@ def _alg_bytes(name, a):
 
 
 # access width of a kernel's global loads -> which calibration copy corrects its FETCH_SIZE reading
-_ACCESS_CLASS = {"pw_conv_kernel": "lds16", "pw_conv_bf16_kernel": "lds16", "pw_wgrad_x3_kernel": "lds16",
+_ACCESS_CLASS = {"pw_conv_kernel": "lds16", "pw_conv_bf16_kernel": "lds16", "pw_wgrad_x3_kernel": "lds16", "pw_wgrad_wide_kernel": "b16",
                  "dw_plane_kernel": "b8", "dw_tile_kernel": "b8", "dw_bwd_tile_kernel": "b8", "dw_conv_fwd_stats": "b8",
                  "dw_conv_kernel": "b4", "irb_kernel": "b4", "stem_conv_kernel": "b4", "dyrelu_ca_fwd_kernel": "b4",
                  "dyrelu_ca_bwd_kernel": "b4", "ctx_pool_kernel": "b4", "col_sum_kernel": "b4"}
@@ -354,7 +349,7 @@ _ACCESS_CLASS = {"pw_conv_kernel": "lds16", "pw_conv_bf16_kernel": "lds16", "pw_
 _PMC_FAMILY = {"dw_conv_fwd_stats": "dw_tile_kernel", "se_mlp_bwd_kernels": "se_mlp_bwd_kernel", "pw_wgrad_dyn": "pw_wgrad_x3_kernel"}
 
 _HAS_MFMA = ("pw_conv_kernel", "pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel", "expand_dw_kernel", "irb_kernel",
-             "pw_wgrad_kernel", "pw_wgrad_x3_kernel", "pw_wgrad_x3_narrow_kernel", "linear_kernel")
+             "pw_wgrad_kernel", "pw_wgrad_x3_kernel", "pw_wgrad_x3_narrow_kernel", "pw_wgrad_wide_kernel", "linear_kernel")
 
 
 def roofline_of(name, d, args):
@@ -399,9 +394,9 @@ def roofline_of(name, d, args):
     mfma_peak = MFMA_F32_PEAK
     if base in ("pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel"):
         mfma_peak = MFMA_BF16_PEAK / (3 if ",3," in name else 1)
-    if base in ("expand_dw_kernel", "pw_wgrad_x3_narrow_kernel") or name == "pw_wgrad_x3_kernel<3>":
+    if base in ("expand_dw_kernel", "pw_wgrad_x3_narrow_kernel") or name in ("pw_wgrad_x3_kernel<3>", "pw_wgrad_wide_kernel<3,*>"):
         mfma_peak = MFMA_BF16_PEAK / 3            # every useful product costs three bf16 MFMAs
-    if name == "pw_wgrad_x3_kernel<1>":
+    if name in ("pw_wgrad_x3_kernel<1>", "pw_wgrad_wide_kernel<1,*>"):
         mfma_peak = MFMA_BF16_PEAK
     # which roof binds: a kernel WITHOUT matrix instructions is priced against HBM only (its fp32 VALU work is reported
     # as `valu_tflops` for information); an MFMA kernel against the larger of its HBM time and its MFMA time

@@ -68,6 +68,7 @@ SIGNATURES = {
     "eat_dw_conv_dilated_wgrad": [_P, _P, _P] + [_I] * 9 + [_P],
     "eat_kd_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P],
     "eat_pw_wgrad_slots": [_I] * 6,
+    "eat_pw_wgrad_kernel_kind": [_I] * 8,
     "eat_pw_conv_wgrad_ws": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_pw_conv_tf_fwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_pw_conv_cat_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],

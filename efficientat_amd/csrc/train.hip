@@ -1888,6 +1888,16 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
 
 // Number of workspace copies that gives every block of eat_pw_conv_wgrad_ws its own (bit-reproducible result); `same`: the
 // two operands are the same tensor (Gram matrix).  Host helper.
+// Which kernel family eat_pw_conv_wgrad[_ws|_tf] launches for a shape (host helper for bench.py's byte models and the
+// profiles): 0 = pw_wgrad_x3_narrow_kernel<mtb, ntb> (returned as 1000 * mtb + 10 * ntb + gram), 1 = pw_wgrad_x3_kernel,
+// 2 = pw_wgrad_kernel (exact fp32), 3 = pw_wgrad_wide_kernel; encoded as kind + 10 * detail.
+extern "C" int eat_pw_wgrad_kernel_kind(int B, int Co, int Ci, int S, int exact_fp32, int same, int has_scale, int has_tf) {
+  const WgPlan p = wgrad_plan(B, Co, Ci, S, 0, exact_fp32, same != 0, has_scale != 0 || has_tf != 0, has_scale != 0, false,
+                              has_tf != 0);
+  if (p.kind == 0) return 10 * (1000 * p.mtb + 10 * p.ntb + (p.gram ? 1 : 0));
+  return p.kind;
+}
+
 extern "C" int eat_pw_wgrad_slots(int B, int Co, int Ci, int S, int exact_fp32, int same) {
   return (int)wgrad_plan(B, Co, Ci, S, 0, exact_fp32, same != 0, false).nz;
 }

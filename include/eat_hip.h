@@ -334,6 +334,10 @@ int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float* x_scale, 
  * run to run (the copies are added in a fixed order).  same != 0: dz and x are the same tensor (the Gram matrix of
  * eat_gram_bn_finalize, whose round-off reaches the BatchNorm statistics).  Host helper. */
 int eat_pw_wgrad_slots(int B, int Co, int Ci, int S, int exact_fp32, int same);
+/* Host helper (no launch): the kernel family eat_pw_conv_wgrad / _ws / _tf uses for a shape - 1 = 128 x 128-tile LDS-staged
+ * kernel, 2 = exact fp32 kernel, 3 = wide-tile producer / consumer kernel, 10 * (1000 * mtb + 10 * ntb + gram) = the
+ * LDS-free streaming kernel with mtb x ntb row tiles per block.  For measurement tools (bench.py's per-kernel byte models). */
+int eat_pw_wgrad_kernel_kind(int B, int Co, int Ci, int S, int exact_fp32, int same, int has_scale, int has_tf);
 
 /* Train-mode project conv, models/mn/block_types.py:167-171 fed by :150-162 (+ the SE scale of :72-83): the conv input is
  * act_in(tf_a[k] x + tf_b[k]) * in_scale[b,k] evaluated on the way to the matrix cores, i.e. BatchNorm + activation of
