@@ -915,13 +915,13 @@ constexpr int WIDE_NP = 13, WIDE_TP = 8;                            // register 
                                                                    // x 8 x 8 rows = 256) and 5 of Q (160 rows)
 constexpr int WIDE_RD = 3;                                         // units a producer holds in registers
 template <int V> struct WideInt { static constexpr int value = V; };
-// TF: the x operand is read through act(a v + b) (the project conv's input, mn_train.py); the dz-side constant of the
-// centred Gram launches is not supported here (those have dz == x and keep their own plan)
-template <int NPROD, bool SWAP, bool TF, bool SCALE>
+// (an instantiation with the x operand read through act(a v + b) - the project conv's on-load input - made the producers the
+//  pole: 40 x 120 at 2000 positions 152 us against 128 for the 128 x 128-tile kernel; those launches keep that kernel)
+template <int NPROD, bool SWAP, bool SCALE>
 __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                             const float* __restrict__ xscale, float* __restrict__ dW, int B,
-                                                            int Co, int Ci, int S, int sps, int units_per_block, WgTf tf,
-                                                            int n_slots, int p_tile_rows, int q_tile_rows, int dbg) {
+                                                            int Co, int Ci, int S, int sps, int units_per_block,
+                                                            int p_tile_rows, int q_tile_rows, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float w_smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const float* __restrict__ P = SWAP ? x : dz;
@@ -955,7 +955,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
     constexpr int XS0 = SWAP ? 0 : WIDE_TP, XN = SWAP ? WIDE_TP : WIDE_NP - WIDE_TP;
     // per slot: byte offset of this lane's 16 bytes relative to (operand + sample offset + 32 * unit)
     unsigned roff[WIDE_NP];
-    float xa[TF ? XN : 1], xb[TF ? XN : 1];
     int xrow[SCALE ? XN : 1];
 #pragma unroll
     for (int t = 0; t < WIDE_NP; ++t) {
@@ -967,10 +966,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
       roff[t] = valid ? 4u * ((unsigned)row * (unsigned)S + 4u * (unsigned)chunk) : 4u * (unsigned)(isp ? p0 : q0) * (unsigned)S;
       if (t >= XS0 && t < XS0 + XN) {
         const int xr = row < Ci ? row : Ci - 1;
-        if constexpr (TF) {
-          xa[t - XS0] = tf.a[xr];
-          xb[t - XS0] = tf.b[xr];
-        }
         if constexpr (SCALE) xrow[t - XS0] = xr;
       }
     }
@@ -1009,13 +1004,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
         if (g < (isp ? GP : GQ)) {
           const int gi = isp ? g : GP + g;                            // piece of the LDS slot
           float4 w = buf[K][t];
-          if constexpr (TF) {
-            if (t >= XS0 && t < XS0 + XN) {
-              const float fa = xa[t - XS0 < 0 ? 0 : t - XS0], fb = xb[t - XS0 < 0 ? 0 : t - XS0];
-              w.x = wg_tf(w.x, fa, fb, tf.act); w.y = wg_tf(w.y, fa, fb, tf.act);
-              w.z = wg_tf(w.z, fa, fb, tf.act); w.w = wg_tf(w.w, fa, fb, tf.act);
-            }
-          }
           if constexpr (SCALE) {
             if (t >= XS0 && t < XS0 + XN) {
               const float sc = xs[t - XS0 < 0 ? 0 : t - XS0];
@@ -1088,8 +1076,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
   const int r = lane & 15, kg = lane >> 4;
   const int pbase = pt >> 2, pext = pt & 3;                           // P tiles of this wave: [pm0, pm0 + pm_n)
   const int pm_n = pbase + (wq < pext ? 1 : 0), pm0 = wq * pbase + (wq < pext ? wq : pext);
-  const unsigned out_slot = (unsigned)blockIdx.z % (unsigned)(n_slots > 0 ? n_slots : 1);
-  const size_t out_off = (size_t)out_slot * Co * Ci;
   f32x4 acc[WIDE_PT][WIDE_QT];
 #pragma unroll
   for (int i = 0; i < WIDE_PT; ++i)
@@ -1128,18 +1114,19 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
           }
 #pragma unroll
           for (int i = 0; i < WIDE_PT; ++i) {
-            // D rows (kg * 4 + e) follow the first operand, D columns (lane & 15) the second: the x / Ci index goes second
+            // D rows (kg * 4 + e) follow the first operand, D columns (lane & 15) the second: the x / Ci index goes FIRST, so
+            // that a lane's four accumulator values are four consecutive columns of dW (one 16-byte store)
             if constexpr (SWAP) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, ph[i], acc[i][j], 0, 0, 0);
-              if constexpr (NPROD == 3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, pl[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql, ph[i], acc[i][j], 0, 0, 0);
-              }
-            } else {
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[i], qh, acc[i][j], 0, 0, 0);
               if constexpr (NPROD == 3) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[i], ql, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[i], qh, acc[i][j], 0, 0, 0);
+              }
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, ph[i], acc[i][j], 0, 0, 0);
+              if constexpr (NPROD == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, pl[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql, ph[i], acc[i][j], 0, 0, 0);
               }
             }
           }
@@ -1149,23 +1136,22 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
     }
   }
   if (pm_n <= 0) return;
-  float* out = dW + out_off;
+  // Epilogue: PLAIN 16-byte stores into this k-slice's own copy of dW (ws holds gridDim.z copies; wgrad_slot_reduce4_kernel
+  // adds them in a fixed order: bit-reproducible).  The atomic form - 160 wave-instructions of 64 fp32 atomics per consumer -
+  // cost 25 - 35 us of the 85 - 145 us launches (the same-address adds of all k-slices arrive together).
+  float* out = dW + (size_t)blockIdx.z * Co * Ci;
 #pragma unroll
   for (int i = 0; i < WIDE_PT; ++i)
 #pragma unroll
     for (int j = 0; j < WIDE_QT; ++j) {
       if (!(i < pm_n && j < qt)) continue;                            // wave-uniform
       const int pr0 = 16 * (pm0 + i), qr0 = 16 * j;                   // tile origins inside the block tile
-      const bool full = pr0 + 16 <= pv && qr0 + 16 <= qv;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // C/D layout: row = kg * 4 + e (first MFMA operand), column = lane & 15 (second operand); rows / columns past the
-        // matrix hold products of the clamped duplicate rows and are simply not written
-        const int m = SWAP ? q0 + qr0 + kg * 4 + e : p0 + pr0 + kg * 4 + e;
-        const int n = SWAP ? p0 + pr0 + r : q0 + qr0 + r;
-        if ((dbg & 1) && acc[i][j][e] != 12345.678f) continue;
-        if (full || (m < Co && n < Ci)) global_atomic_add(out + (size_t)m * Ci + n, acc[i][j][e]);
-      }
+      // C/D layout: row = kg * 4 + e (first MFMA operand = the x rows = columns n of dW), column = lane & 15 (the dz rows m);
+      // rows / columns past the matrix hold products of the clamped duplicate rows and are not written (Ci % 4 == 0)
+      const int m = SWAP ? q0 + qr0 + r : p0 + pr0 + r;
+      const int n = (SWAP ? p0 + pr0 : q0 + qr0) + kg * 4;
+      if ((dbg & 1) && acc[i][j][0] != 12345.678f) continue;
+      if (m < Co && n < Ci) *reinterpret_cast<f32x4*>(out + (size_t)m * Ci + n) = acc[i][j];
     }
 }
 
@@ -1342,6 +1328,33 @@ __global__ __launch_bounds__(256) void wgrad_slot_reduce_kernel(const float* __r
   s_part[wv][lane] = t;
   __syncthreads();
   if (wv == 0 && e < n) dW[e] += ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+}
+
+// the same for n % 4 == 0 with 16-byte loads: a block adds 256 elements of up to n_slots copies (the wide-tile kernel's
+// per-k-slice copies: 25 - 39 MB per launch on the late mn10 layers)
+__global__ __launch_bounds__(256) void wgrad_slot_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ dW, int n,
+                                                                 int n_slots) {
+  __shared__ f32x4 s_part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = blockIdx.x * 256 + 4 * lane;
+  f32x4 t{0.f, 0.f, 0.f, 0.f};
+  if (e < n) {
+    int sidx = wv;
+    for (; sidx + 28 < n_slots; sidx += 32) {
+      f32x4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 4 * q) * n + e);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += v[q];
+    }
+    for (; sidx < n_slots; sidx += 4) t += *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + e);
+  }
+  s_part[wv][lane] = t;
+  __syncthreads();
+  if (wv == 0 && e < n) {
+    f32x4* o = reinterpret_cast<f32x4*>(dW + e);
+    *o = *o + (((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]);
+  }
 }
 
 template <int MTN, int NTN>
@@ -1699,10 +1712,12 @@ static bool thin_pair(int m, int n) { return m >= 1 && m <= 4 && n >= 1 && n <= 
 struct WideShape { bool ok; bool swap; int ptr, qtr, ptn, qtn; };
 static WideShape wide_shape(int Co, int Ci, bool per_sample, bool same, bool no_wide, bool has_xscale, bool has_tf) {
   static const int wide_on = getenv("EAT_WGRAD_WIDE") ? atoi(getenv("EAT_WGRAD_WIDE")) : 3;
-  static const int wide_min = getenv("EAT_WGRAD_WIDE_MIN") ? atoi(getenv("EAT_WGRAD_WIDE_MIN")) : 20;
+  constexpr int wide_min = 20;
   WideShape w{false, Ci > Co, 0, 0, 0, 0};
   if (per_sample || same || no_wide || has_tf || !(wide_on & 1) || (has_xscale && (Ci & 3) != 0)) return w;
   const int PR = w.swap ? Ci : Co, QR = w.swap ? Co : Ci;
+  // (tile limits measured: P <= 192 / 128 rows per block instead of 256: 672 x 112 147 -> 157 / 198 us, mn10 step +0.3 ms;
+  //  384 blocks instead of one per CU: +0.3 ms; minimum of 14 / 30 pieces instead of 20: +0.1 ms)
   w.ptn = (PR + 255) / 256;
   w.ptr = ((PR + w.ptn - 1) / w.ptn + 15) / 16 * 16;
   w.qtn = (QR + 159) / 160;                                  // rows of Q per block: 4 producers x 5 pieces of 8 rows
@@ -1777,7 +1792,7 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
       if (w.ok) {
         p.w_swap = w.swap; p.w_ptr = w.ptr; p.w_qtr = w.qtr; p.w_ptn = w.ptn; p.w_qtn = w.qtn;
         const int wtiles = w.ptn * w.qtn;
-        static const int wtarget = getenv("EAT_WGRAD_WIDE_BLOCKS") ? atoi(getenv("EAT_WGRAD_WIDE_BLOCKS")) : 256;   // one block per CU
+        constexpr int wtarget = 256;                           // one block per CU
         long long splits = wtiles >= wtarget ? 1 : wtarget / wtiles;
         if (splits > total / 16) splits = total / 16;
         if (splits < 1) splits = 1;
@@ -1823,8 +1838,13 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   // second kernel adds the copies into dW in a fixed order; n_slots >= eat_pw_wgrad_slots(...) gives every block its own
   // copy (bit-reproducible result).  The LDS-staged and exact kernels use the workspace only in that one-per-block form.
   // (a centring transform - tf.actr set - keeps the Gram plan: both operands are the same centred rows)
-  const WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
-                              x_scale != nullptr, tf.actr != nullptr, tf.a != nullptr);
+  WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
+                        x_scale != nullptr, tf.actr != nullptr, tf.a != nullptr);
+  // the wide-tile kernel stores one copy of dW per k-slice: it needs the workspace (eat_pw_conv_wgrad_ws with
+  // n_slots >= eat_pw_wgrad_slots) and 16-byte aligned rows; without them the plan is the one without it
+  if (p.kind == 3 && !(ws != nullptr && n_slots >= (int)p.nz && (Ci & 3) == 0))
+    p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
+                   x_scale != nullptr, true, tf.a != nullptr);
   hipStream_t hs = (hipStream_t)stream;
   const bool priv = ws != nullptr && !per_sample && n_slots >= (int)p.nz;     // one copy per block
   if (p.kind == 0) {
@@ -1849,22 +1869,21 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
     // EAT_WGRAD_WIDE_DBG (measurement only, results are wrong): 1 no atomics, 2 no MFMAs, 4 no loads, 8 no conversion -
     // the phase decomposition quoted above the kernel
     static const int wide_dbg = getenv("EAT_WGRAD_WIDE_DBG") ? atoi(getenv("EAT_WGRAD_WIDE_DBG")) : 0;
-#define EAT_WIDE(NP_, SW_, TF_, SC_)                                                                                      \
+#define EAT_WIDE(NP_, SW_, SC_)                                                                                           \
     do {                                                                                                                  \
-      auto kern = pw_wgrad_wide_kernel<NP_, SW_, TF_, SC_>;                                                               \
+      auto kern = pw_wgrad_wide_kernel<NP_, SW_, SC_>;                                                                    \
       static bool attr_set = false;                                                                                       \
       if (!attr_set) {                                                                                                    \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
           return eat::fail(EAT_ELAUNCH, "eat_pw_conv_wgrad: hipFuncSetAttribute(160 KB of LDS) failed");                  \
         attr_set = true;                                                                                                  \
       }                                                                                                                   \
-      hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, tf, slots,  \
-                         p.w_ptr, p.w_qtr, wide_dbg);                                                                     \
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.w_ptr,    \
+                         p.w_qtr, wide_dbg);                                                                              \
     } while (0)
-#define EAT_WIDE_SC(NP_, SW_, TF_) do { if (x_scale) EAT_WIDE(NP_, SW_, TF_, true); else EAT_WIDE(NP_, SW_, TF_, false); } while (0)
-#define EAT_WIDE_SW(NP_, TF_) do { if (p.w_swap) EAT_WIDE_SC(NP_, true, TF_); else EAT_WIDE_SC(NP_, false, TF_); } while (0)
-    if (exact_fp32 == 2) { if (tf.a) EAT_WIDE_SW(1, true); else EAT_WIDE_SW(1, false); }
-    else { if (tf.a) EAT_WIDE_SW(3, true); else EAT_WIDE_SW(3, false); }
+#define EAT_WIDE_SC(NP_, SW_) do { if (x_scale) EAT_WIDE(NP_, SW_, true); else EAT_WIDE(NP_, SW_, false); } while (0)
+#define EAT_WIDE_SW(NP_) do { if (p.w_swap) EAT_WIDE_SC(NP_, true); else EAT_WIDE_SC(NP_, false); } while (0)
+    if (exact_fp32 == 2) EAT_WIDE_SW(1); else EAT_WIDE_SW(3);
 #undef EAT_WIDE_SC
 #undef EAT_WIDE_SW
 #undef EAT_WIDE
@@ -1881,19 +1900,28 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
     hipLaunchKernelGGL(pw_wgrad_kernel, grid, dim3(256), 0, hs, dz, x, x_scale, target, B, Co, Ci, S, p.bpb, per_sample, tf,
                        slots);
   }
-  if (priv)
+  if (priv && p.kind == 3)
+    hipLaunchKernelGGL(wgrad_slot_reduce4_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
+  else if (priv)
     hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, hs, ws, dW, Co * Ci, slots);
   return eat::check_launch("eat_pw_conv_wgrad");
 }
 
 // Number of workspace copies that gives every block of eat_pw_conv_wgrad_ws its own (bit-reproducible result); `same`: the
 // two operands are the same tensor (Gram matrix).  Host helper.
+static int eat_pw_wgrad_kernel_kind_nowide(int B, int Co, int Ci, int S, int exact_fp32, int same, int has_scale, int has_tf) {
+  const WgPlan p = wgrad_plan(B, Co, Ci, S, 0, exact_fp32, same != 0, has_scale != 0 || has_tf != 0, has_scale != 0, true,
+                              has_tf != 0);
+  return p.kind == 0 ? 10 * (1000 * p.mtb + 10 * p.ntb + (p.gram ? 1 : 0)) : p.kind;
+}
 // Which kernel family eat_pw_conv_wgrad[_ws|_tf] launches for a shape (host helper for bench.py's byte models and the
 // profiles): 0 = pw_wgrad_x3_narrow_kernel<mtb, ntb> (returned as 1000 * mtb + 10 * ntb + gram), 1 = pw_wgrad_x3_kernel,
 // 2 = pw_wgrad_kernel (exact fp32), 3 = pw_wgrad_wide_kernel; encoded as kind + 10 * detail.
 extern "C" int eat_pw_wgrad_kernel_kind(int B, int Co, int Ci, int S, int exact_fp32, int same, int has_scale, int has_tf) {
   const WgPlan p = wgrad_plan(B, Co, Ci, S, 0, exact_fp32, same != 0, has_scale != 0 || has_tf != 0, has_scale != 0, false,
                               has_tf != 0);
+  if (p.kind == 3 && (Ci & 3) != 0)                           // (the wide-tile kernel needs 16-byte aligned rows of dW)
+    return eat_pw_wgrad_kernel_kind_nowide(B, Co, Ci, S, exact_fp32, same, has_scale, has_tf);
   if (p.kind == 0) return 10 * (1000 * p.mtb + 10 * p.ntb + (p.gram ? 1 : 0));
   return p.kind;
 }

@@ -437,6 +437,15 @@ def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None):
         _lib.call("eat_pw_conv_wgrad_ws", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(),
                   ws.data_ptr(), 8, B, Co, Ci, S, mode, _stream())
         return dW
+    h = _lib.lib()
+    if h.eat_pw_wgrad_kernel_kind(B, Co, Ci, S, mode, 1 if dz.data_ptr() == x.data_ptr() else 0, 0 if x_scale is None else 1, 0) == 3:
+        # late-layer shapes: the wide-tile kernel stores one copy of dW per k-slice (no atomics, bit-reproducible); the copies
+        # need no zero fill
+        n = int(h.eat_pw_wgrad_slots(B, Co, Ci, S, mode, 0))
+        ws = torch.empty((n, Co, Ci), device=dz.device, dtype=torch.float32)
+        _lib.call("eat_pw_conv_wgrad_ws", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(),
+                  ws.data_ptr(), n, B, Co, Ci, S, mode, _stream())
+        return dW
     _lib.call("eat_pw_conv_wgrad", _dev(dz, "dz"), _dev(x, "x"), _opt(x_scale, "x_scale"), dW.data_ptr(), B, Co, Ci,
               S, mode, _stream())
     return dW

@@ -325,9 +325,12 @@ int eat_dw_conv_wgrad(const float* dz, const float* x, float* dw, int B, int C, 
  * zeroed by the caller.  The data gradient is eat_pw_conv_fwd with the packed W^T. */
 int eat_pw_conv_wgrad(const float* dz, const float* x, const float* x_scale, float* dW, int B, int Co,
                       int Ci, int S, int exact_fp32, eat_stream_t stream);
-/* eat_pw_conv_wgrad with a zero-filled workspace ws (n_slots * Co * Ci floats): the streaming kernel of the small
- * matrices (Co, Ci <= 64 with one side <= 16, or the Gram matrix dz == x) spreads its atomics over n_slots copies of dW
- * and a second kernel adds them into dW; other shapes ignore ws. */
+/* eat_pw_conv_wgrad with a workspace ws (n_slots * Co * Ci floats): the streaming kernel of the small matrices (Co, Ci <= 64
+ * with one side <= 16, or the Gram matrix dz == x) spreads its atomics over n_slots copies of dW (ws zero-filled) and a
+ * second kernel adds them into dW.  With n_slots >= eat_pw_wgrad_slots(...) every block has its own copy: the result is
+ * bit-reproducible, and the late-layer shapes (eat_pw_wgrad_kernel_kind == 3) run the wide-tile producer / consumer
+ * kernel, which STORES its copies (ws need not be zeroed for it) - without the workspace those shapes run the 128 x 128-tile
+ * kernel with atomics into dW. */
 int eat_pw_conv_wgrad_ws(const float* dz, const float* x, const float* x_scale, float* dW, float* ws, int n_slots, int B,
                          int Co, int Ci, int S, int exact_fp32, eat_stream_t stream);
 /* Copies of dW that give every block of eat_pw_conv_wgrad_ws its own slot: the result is then bit-reproducible from

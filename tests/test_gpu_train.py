@@ -136,8 +136,13 @@ def test_pw_wgrad_wide_and_thin_shapes(B, Co, Ci, S, mode):
         assert _rel(got, refb) < 2e-5
     else:
         assert _rel(got, ref) < 2e-5
+    from efficientat_amd import _lib
+    if _lib.lib().eat_pw_wgrad_kernel_kind(B, Co, Ci, S, 2 if mode == "bf16" else 0, 0, 0, 0) == 3:
+        # the wide-tile kernel stores one copy per k-slice and adds them in a fixed order: bit-reproducible
+        with ops.precision("bf16" if mode == "bf16" else "auto"):
+            again = ops.pw_conv_wgrad(dzd, xd, exact=None)
+        assert torch.equal(got, again)
     if mode == "x3" and Co >= 64 and Ci >= 64:
-        from efficientat_amd import _lib
         G = torch.full((B, Co * Ci), float("nan"), device=DEV)         # stores, not accumulation: poison must vanish
         if ops.dyn_wgrad_needs_zero(Co, Ci, S):
             G.zero_()
@@ -150,10 +155,11 @@ def test_pw_wgrad_wide_and_thin_shapes(B, Co, Ci, S, mode):
 @pytest.mark.parametrize("B,Co,Ci,S", [(5, 80, 240, 504), (3, 672, 112, 504), (4, 160, 672, 128), (3, 40, 120, 2000),
                                        (2, 100, 52, 72), (3, 300, 200, 36), (2, 24, 72, 8000)])
 @pytest.mark.parametrize("opt", ["scale", "tf_relu", "tf_hswish+scale"])
-def test_pw_wgrad_wide_tile_kernel_with_input_scale_and_transform(B, Co, Ci, S, opt):
-    """The wide-tile ring kernel (csrc/train.hip: pw_wgrad_wide_kernel) with the squeeze-excitation scale of the conv input
-    (block_types.py:83,167-171: the project conv reads x * scale) and with the BatchNorm + activation transform evaluated on
-    load, both operand orders, a ring that is longer than the block's k range (S = 36), rows that are no multiple of 8."""
+def test_pw_wgrad_with_input_scale_and_transform(B, Co, Ci, S, opt):
+    """1x1 weight gradients with the squeeze-excitation scale of the conv input (block_types.py:83,167-171: the project conv
+    reads x * scale; the late-layer shapes run csrc/train.hip: pw_wgrad_wide_kernel) and with the BatchNorm + activation
+    transform evaluated on load (128 x 128-tile / streaming kernels), both operand orders, a k range shorter than the
+    producers' run-ahead (S = 36), rows that are no multiple of 8."""
     dz, x = _rand(B, Co, S, 1, seed=1), _rand(B, Ci, S, 1, seed=2)
     sc = torch.rand(B, Ci, generator=torch.Generator().manual_seed(5)) + 0.25 if "scale" in opt else None
     a = torch.rand(Ci, generator=torch.Generator().manual_seed(6)) + 0.5
