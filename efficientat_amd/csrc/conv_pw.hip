@@ -264,17 +264,19 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
 
 // y (M,N) = act((x (M,K) * xs) . w (N,K)^T + bias): both operands K-contiguous; each lane loads 4
 // consecutive k as one float4 and the 4 MFMAs of a 16-k step consume a consistent k permutation.
-// Block = 4 waves on ONE 16 x 32 output tile with K split 4 ways (these GEMMs are tiny and
-// latency-bound: M = batch, K,N <= a few thousand), partial sums combined through LDS.
-__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ y,
-                                                     int M, int K, int N, float xs, int act) {
-  __shared__ float s_red[3][2][4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// Block = 4 ... 16 waves on ONE 16 x 32 output tile with K split over the waves (these GEMMs are tiny and
+// latency-bound: M = batch, K,N <= a few thousand), partial sums combined through LDS in a fixed order.
+// Round 4: up to 16 waves (one 64-k step each for K <= 1024) - with 4 waves the SE gate GEMMs (K = 960) ran four
+// dependent load -> MFMA rounds per wave: 11.5 us per launch in the captured step, 50 launches per training step.
+__global__ __launch_bounds__(1024) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int M, int K, int N, float xs, int act) {
+  __shared__ float s_red[15][2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
   const int row = lane & 15, kq = lane >> 4;
   const int mrow = m0 + row;
-  const int kslice = (((K + 3) / 4 + 15) / 16) * 16;       // per-wave K range, multiple of 16
+  const int kslice = (((K + nw - 1) / nw + 15) / 16) * 16; // per-wave K range, multiple of 16
   const int kb = wv * kslice, ke = (kb + kslice) < K ? (kb + kslice) : K;
   const bool vec = (K & 3) == 0;
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -323,7 +325,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + kq * 4 + r;
-      float v = acc[j][r] + s_red[0][j][r][lane] + s_red[1][j][r][lane] + s_red[2][j][r][lane] + bn;
+      float v = acc[j][r];
+      for (int q = 0; q + 1 < nw; ++q) v += s_red[q][j][r][lane];
+      v += bn;
       if (act == EAT_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
       else v = eat::activate_rt(v, act);
       if (n < N && m < M) y[(size_t)m * N + n] = v;
@@ -497,6 +501,8 @@ extern "C" int eat_linear_fwd(const float* x, const float* w, const float* bias,
   eat::clear_stale_error();
   if (act < 0 || act > 3) return eat::fail(EAT_EINVAL, "eat_linear_fwd: bad act %d", act);
   dim3 grid((N + 31) / 32, (B + 15) / 16);
-  hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, K, N, x_scale, act);
+  int nw = (K + 63) / 64;                                  // one 64-k step per wave where K allows
+  nw = nw < 4 ? 4 : (nw > 16 ? 16 : nw);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * nw), 0, (hipStream_t)stream, x, w, bias, y, B, K, N, x_scale, act);
   return eat::check_launch("eat_linear_fwd");
 }
