@@ -184,6 +184,40 @@ def test_pw_wgrad_with_input_scale_and_transform(B, Co, Ci, S, opt):
             assert _rel(got, ref) < 2e-5, mode
 
 
+def _wide_shapes(n=28):
+    """Deterministic random shapes that the library routes to the wide-tile weight-gradient kernel (any tile count, ragged
+    row / column tiles, k ranges shorter and longer than the producers' run-ahead, positions not a multiple of 32)."""
+    import random
+    from efficientat_amd import _lib
+    rnd, out = random.Random(1234), []
+    try:
+        h = _lib.lib()
+    except Exception:
+        return []
+    while len(out) < n:
+        Co, Ci = 4 * rnd.randint(6, 200), 4 * rnd.randint(6, 200)
+        S, B = 4 * rnd.randint(3, 160), rnd.randint(1, 6)
+        sc = rnd.random() < 0.4
+        if h.eat_pw_wgrad_kernel_kind(B, Co, Ci, S, 0, 0, 1 if sc else 0, 0) == 3:
+            out.append((B, Co, Ci, S, sc))
+    return out
+
+
+@pytest.mark.parametrize("B,Co,Ci,S,sc", _wide_shapes())
+def test_pw_wgrad_wide_tile_random_shapes(B, Co, Ci, S, sc):
+    """csrc/train.hip: pw_wgrad_wide_kernel on random geometries against fp64 (dW = sum_b dz_b (x_b * scale_b)^T,
+    models/mn/block_types.py:83,138-147,167-171 backward), twice: bit-identical."""
+    dz, x = _rand(B, Co, S, 1, seed=B + Co), _rand(B, Ci, S, 1, seed=Ci + S)
+    scale = torch.rand(B, Ci, generator=torch.Generator().manual_seed(S)) + 0.25 if sc else None
+    xe = x[..., 0].double() * (scale.double()[:, :, None] if sc else 1.0)
+    ref = torch.einsum("bos,bis->oi", dz[..., 0].double(), xe)
+    with ops.precision("auto"):
+        got = ops.pw_conv_wgrad(dz.to(DEV), x.to(DEV), x_scale=scale.to(DEV) if sc else None, exact=None)
+        again = ops.pw_conv_wgrad(dz.to(DEV), x.to(DEV), x_scale=scale.to(DEV) if sc else None, exact=None)
+    assert _rel(got, ref) < 2e-5
+    assert torch.equal(got, again)
+
+
 def test_mn10_train_step_matches_oracle(golden_dir):
     g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
     sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
