@@ -267,7 +267,10 @@ def _alg_bytes(name, a):
     if name == "eat_gram_centered":
         B, C, S = a[6:9]
         mt = (C + 15) // 16
-        sym = f"pw_wgrad_x3_narrow_kernel<{mt},{mt},true>" if C <= 64 else ("pw_wgrad_kernel" if a[9] == 1 else "pw_wgrad_x3_kernel<3>")
+        from efficientat_amd import _lib as _l
+        kind = int(_l.lib().eat_pw_wgrad_kernel_kind(B, C, C, S, a[9], 1, 0, 0))
+        sym = ("pw_wgrad_kernel" if kind == 2 else "pw_wgrad_x3_kernel<3>" if kind == 1 else "pw_wgrad_wide_kernel<3,*>" if kind == 3
+               else f"pw_wgrad_x3_narrow_kernel<{kind // 10 // 1000},{(kind // 10 % 1000) // 10},true>")
         return sym, 4 * B * S * C + 4 * C * C, 2 * B * S * C * C
     if name == "eat_expand_bwd_coef":
         Co, Ci = a[7:9]

@@ -917,16 +917,20 @@ constexpr int WIDE_RD = 3;                                         // units a pr
 template <int V> struct WideInt { static constexpr int value = V; };
 // (an instantiation with the x operand read through act(a v + b) - the project conv's on-load input - made the producers the
 //  pole: 40 x 120 at 2000 positions 152 us against 128 for the 128 x 128-tile kernel; those launches keep that kernel)
-template <int NPROD, bool SWAP, bool SCALE>
+// RADD: an additive constant per x row (radd), applied to loaded elements only - the centred Gram matrix (same = 1)
+template <int NPROD, bool SWAP, bool SCALE, bool RADD>
 __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                             const float* __restrict__ xscale, float* __restrict__ dW, int B,
                                                             int Co, int Ci, int S, int sps, int units_per_block,
-                                                            int p_tile_rows, int q_tile_rows, int dbg) {
+                                                            int p_tile_rows, int q_tile_rows, int dbg,
+                                                            const float* __restrict__ radd, int same) {
   extern __shared__ __attribute__((aligned(16))) float w_smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const float* __restrict__ P = SWAP ? x : dz;
   const float* __restrict__ Q = SWAP ? dz : x;
   const int PR = SWAP ? Ci : Co, QR = SWAP ? Co : Ci;
+  // same (Gram matrix, dz == x, one tile): the Q operand IS the P operand - no Q pieces, Q fragments read from P's rows;
+  // radd (or NULL): additive constant per x row, applied to loaded elements only (the centred Gram matrix)
   const int p0 = blockIdx.x * p_tile_rows, q0 = blockIdx.y * q_tile_rows;
   const int pv = (PR - p0) < p_tile_rows ? (PR - p0) : p_tile_rows;   // valid rows of this block's tile
   const int qv = (QR - q0) < q_tile_rows ? (QR - q0) : q_tile_rows;
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
   const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
   if (pv <= 0 || qv <= 0 || u0 >= u1) return;                         // block-uniform, before any barrier
   const int pt = (pv + 15) >> 4, qt = (qv + 15) >> 4;                 // 16-row tiles
-  const int GP = pt * 2, GQ = (qv + 7) >> 3;                          // 8-row pieces (P: whole 16-row tiles, so that the Q rows start
+  const int GP = pt * 2, GQ = same ? 0 : (qv + 7) >> 3;               // 8-row pieces (P: whole 16-row tiles, so that the Q rows start
                                                                       // on a multiple of 16: one swizzle term for all tiles)
   const int GD = GP + GQ;
   const int slot_f = GD * 256;                                        // floats per LDS slot
@@ -956,6 +960,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
     // per slot: byte offset of this lane's 16 bytes relative to (operand + sample offset + 32 * unit)
     unsigned roff[WIDE_NP];
     int xrow[SCALE ? XN : 1];
+    float ra[RADD ? XN : 1];
 #pragma unroll
     for (int t = 0; t < WIDE_NP; ++t) {
       const bool isp = t < WIDE_TP;
@@ -967,7 +972,14 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
       if (t >= XS0 && t < XS0 + XN) {
         const int xr = row < Ci ? row : Ci - 1;
         if constexpr (SCALE) xrow[t - XS0] = xr;
+        if constexpr (RADD) ra[t - XS0] = radd[xr];
       }
+    }
+    // (the loads above must be back - and known to the compiler to be back - before the loop: a wait it placed at their first
+    //  use inside the loop would be a vmcnt(0) per step; the empty asm statements read the registers)
+    if constexpr (RADD) {
+#pragma unroll
+      for (int t = 0; t < XN; ++t) asm volatile("" ::"v"(ra[t]));
     }
     const bool tail = (S & 31) != 0;
     float4 buf[WIDE_RD][WIDE_NP];
@@ -1010,6 +1022,12 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
               w.x *= sc; w.y *= sc; w.z *= sc; w.w *= sc;
             }
           }
+          if constexpr (RADD) {
+            if (t >= XS0 && t < XS0 + XN) {                           // centring constant of the row
+              const float c = ra[t - XS0 < 0 ? 0 : t - XS0];
+              w.x += c; w.y += c; w.z += c; w.w += c;
+            }
+          }
           if (kz) w = float4{0.f, 0.f, 0.f, 0.f};
           const bf16x2_t h01 = __builtin_convertvector(f32x2_t{w.x, w.y}, bf16x2_t);
           const bf16x2_t h23 = __builtin_convertvector(f32x2_t{w.z, w.w}, bf16x2_t);
@@ -1030,7 +1048,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
     int bc = bi, stc = sti, uc = u0;                                  // next unit to convert
 #define WIDE_LOAD(K_)                                                          \
     do {                                                                       \
-      if (!(dbg & 4)) load_unit(WideInt<K_>{}, bi, sti);                       \
+      load_unit(WideInt<K_>{}, bi, sti);                                       \
       if (ui + 1 < u1) { ++ui; if (++sti == sps) { sti = 0; ++bi; } }          \
     } while (0)
     // conversion of unit uc; before it, the SE scale of the unit converted NEXT is requested (used one step later, when
@@ -1042,8 +1060,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
         const int bn = stc + 1 == sps ? bc + 1 : bc;                           \
         load_scale(bn < B ? bn : B - 1);                                       \
       }                                                                        \
-      if (uc < u1 && !(dbg & 8)) convert_unit(WideInt<K_>{}, SLOT_, stc);      \
-      if (dbg & 8) { _Pragma("unroll") for (int t = 0; t < WIDE_NP; ++t) asm volatile("" ::"v"(buf[K_][t].x)); } \
+      if (uc < u1) convert_unit(WideInt<K_>{}, SLOT_, stc);                    \
       ++uc;                                                                    \
       if (++stc == sps) { stc = 0; ++bc; }                                     \
     } while (0)
@@ -1085,7 +1102,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
   // inside the row's 32-byte block kg ^ ((r >> 2) & 3), halves swapped for rows with bit 1 set (see the converter)
   const int fblk = r * 32 + 8 * (kg ^ ((r >> 2) & 3));
   const int f_hi = fblk + 4 * ((r >> 1) & 1), f_lo = fblk + 4 * (1 - ((r >> 1) & 1));
-  const int p_off = pm0 * 512, q_off = GP * 256;
+  const int p_off = pm0 * 512, q_off = same ? 0 : GP * 256;
   for (int u = u0; u < u1; ++u) {
     __syncthreads();                                                  // unit u is in LDS slot (u - u0) & 1
     if (pm_n > 0 && !(dbg & 2)) {
@@ -1714,7 +1731,18 @@ static WideShape wide_shape(int Co, int Ci, bool per_sample, bool same, bool no_
   static const int wide_on = getenv("EAT_WGRAD_WIDE") ? atoi(getenv("EAT_WGRAD_WIDE")) : 3;
   constexpr int wide_min = 20;
   WideShape w{false, Ci > Co, 0, 0, 0, 0};
-  if (per_sample || same || no_wide || has_tf || !(wide_on & 1) || (has_xscale && (Ci & 3) != 0)) return w;
+  if (per_sample || no_wide || has_tf || !(wide_on & 1) || (has_xscale && (Ci & 3) != 0)) return w;
+  if (same) {
+    // Gram matrix (dz == x, train_fuse.hip): ONE operand, loaded once - P = x, the Q fragments are read from P's rows.  Above
+    // the streaming kernel's range (C > 64) up to what one consumer quartet holds (10 column tiles); 80 x 80 at 504
+    // positions x 256 clips: 62 us on the 128 x 128-tile kernel for 41 MB of input
+    if (Co != Ci || Co <= 64 || Co > 160 || has_xscale || (wide_on & 4)) return w;
+    w.swap = true;
+    w.ptn = w.qtn = 1;
+    w.ptr = w.qtr = (Co + 15) / 16 * 16;
+    w.ok = true;
+    return w;
+  }
   const int PR = w.swap ? Ci : Co, QR = w.swap ? Co : Ci;
   // (tile limits measured: P <= 192 / 128 rows per block instead of 256: 672 x 112 147 -> 157 / 198 us, mn10 step +0.3 ms;
   //  384 blocks instead of one per CU: +0.3 ms; minimum of 14 / 30 pieces instead of 20: +0.1 ms)
@@ -1838,13 +1866,15 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   // second kernel adds the copies into dW in a fixed order; n_slots >= eat_pw_wgrad_slots(...) gives every block its own
   // copy (bit-reproducible result).  The LDS-staged and exact kernels use the workspace only in that one-per-block form.
   // (a centring transform - tf.actr set - keeps the Gram plan: both operands are the same centred rows)
+  // centring form of the Gram launches (eat_gram_centered): a = 1, b = actr = -mean, no activation - an additive row constant
+  const bool centring = dz == x && tf.actr != nullptr && tf.act == EAT_ACT_NONE;
   WgPlan p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
-                        x_scale != nullptr, tf.actr != nullptr, tf.a != nullptr);
+                        x_scale != nullptr, tf.actr != nullptr && !centring, tf.a != nullptr && !centring);
   // the wide-tile kernel stores one copy of dW per k-slice: it needs the workspace (eat_pw_conv_wgrad_ws with
   // n_slots >= eat_pw_wgrad_slots) and 16-byte aligned rows; without them the plan is the one without it
   if (p.kind == 3 && !(ws != nullptr && n_slots >= (int)p.nz && (Ci & 3) == 0))
     p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
-                   x_scale != nullptr, true, tf.a != nullptr);
+                   x_scale != nullptr, true, tf.a != nullptr && !centring);
   hipStream_t hs = (hipStream_t)stream;
   const bool priv = ws != nullptr && !per_sample && n_slots >= (int)p.nz;     // one copy per block
   if (p.kind == 0) {
@@ -1866,12 +1896,13 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   if (p.kind == 3) {
     const size_t smem = (size_t)(p.w_ptr / 8 + p.w_qtr / 8) * 2 * 1024;     // two slots of converted fragments
     dim3 grid(p.w_ptn, p.w_qtn, p.nz);
-    // EAT_WGRAD_WIDE_DBG (measurement only, results are wrong): 1 no atomics, 2 no MFMAs, 4 no loads, 8 no conversion -
-    // the phase decomposition quoted above the kernel
+    // EAT_WGRAD_WIDE_DBG (measurement only, results are wrong): 1 no epilogue stores, 2 no MFMAs.  (The producers' switches
+    // of the decomposition runs - no loads, no conversion - are not in the shipped kernel: a load inside a conditional
+    // block makes the compiler wait with vmcnt(<= 12) instead of vmcnt(26 ... 38), i.e. drains the units in flight.)
     static const int wide_dbg = getenv("EAT_WGRAD_WIDE_DBG") ? atoi(getenv("EAT_WGRAD_WIDE_DBG")) : 0;
-#define EAT_WIDE(NP_, SW_, SC_)                                                                                           \
+#define EAT_WIDE(NP_, SW_, SC_, RA_)                                                                                      \
     do {                                                                                                                  \
-      auto kern = pw_wgrad_wide_kernel<NP_, SW_, SC_>;                                                                    \
+      auto kern = pw_wgrad_wide_kernel<NP_, SW_, SC_, RA_>;                                                               \
       static bool attr_set = false;                                                                                       \
       if (!attr_set) {                                                                                                    \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
@@ -1879,10 +1910,15 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
         attr_set = true;                                                                                                  \
       }                                                                                                                   \
       hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.w_ptr,    \
-                         p.w_qtr, wide_dbg);                                                                              \
+                         p.w_qtr, wide_dbg, centring ? tf.b : (const float*)nullptr, dz == x ? 1 : 0);                    \
     } while (0)
-#define EAT_WIDE_SC(NP_, SW_) do { if (x_scale) EAT_WIDE(NP_, SW_, true); else EAT_WIDE(NP_, SW_, false); } while (0)
-#define EAT_WIDE_SW(NP_) do { if (p.w_swap) EAT_WIDE_SC(NP_, true); else EAT_WIDE_SC(NP_, false); } while (0)
+#define EAT_WIDE_SC(NP_, SW_) do { if (x_scale) EAT_WIDE(NP_, SW_, true, false); else EAT_WIDE(NP_, SW_, false, false); } while (0)
+#define EAT_WIDE_SW(NP_)                                                                                                  \
+    do {                                                                                                                  \
+      if (centring) EAT_WIDE(NP_, true, false, true);                /* Gram matrices: P = x, no SE scale */                \
+      else if (p.w_swap) EAT_WIDE_SC(NP_, true);                                                                          \
+      else EAT_WIDE_SC(NP_, false);                                                                                       \
+    } while (0)
     if (exact_fp32 == 2) EAT_WIDE_SW(1); else EAT_WIDE_SW(3);
 #undef EAT_WIDE_SC
 #undef EAT_WIDE_SW

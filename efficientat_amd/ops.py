@@ -399,16 +399,19 @@ def gram(x, exact=False, sx=None):
     B, C = x.shape[0], x.shape[1]
     S = x.numel() // (B * C)
     mode = 1 if exact else 0
+    # (64 < C <= 160: the wide-tile kernel STORES its per-slice copies - no zero fill needed for them)
+    stored = _lib.lib().eat_pw_wgrad_kernel_kind(B, C, C, S, mode, 1, 0, 0) == 3
     if sx is not None:
         slots = int(_lib.lib().eat_pw_wgrad_slots(B, C, C, S, mode, 1))
         G = zero_arena.zeros((C, C), torch.float32, x.device)
-        ws = zero_arena.zeros((2 * C + slots * C * C,), torch.float32, x.device)
+        n_ws = 2 * C + slots * C * C
+        ws = torch.empty((n_ws,), dtype=torch.float32, device=x.device) if stored else zero_arena.zeros((n_ws,), torch.float32, x.device)
         _lib.call("eat_gram_centered", _dev(x, "x"), _dev(sx, "sx"), 1.0 / (B * S), G.data_ptr(), ws.data_ptr(), slots, B, C,
                   S, mode, _stream())
         return G
     slots = int(_lib.lib().eat_pw_wgrad_slots(B, C, C, S, mode, 1))
     G = zero_arena.zeros((C, C), torch.float32, x.device)
-    ws = zero_arena.zeros((slots, C, C), torch.float32, x.device)
+    ws = torch.empty((slots, C, C), dtype=torch.float32, device=x.device) if stored else zero_arena.zeros((slots, C, C), torch.float32, x.device)
     _lib.call("eat_pw_conv_wgrad_ws", _dev(x, "x"), _dev(x, "x"), None, G.data_ptr(), ws.data_ptr(), slots, B, C, C, S, mode,
               _stream())
     return G
