@@ -90,7 +90,17 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # With a process group (data-parallel step: the bucketed RCCL all-reduces are captured too) torch's ProcessGroupNCCL
+        # watchdog THREAD polls the events of the warm-up steps' collectives with hipEventQuery.  In the default "global"
+        # capture mode any such call from ANY thread while this thread captures fails with
+        # hipErrorStreamCaptureUnsupported, the watchdog throws and the process aborts (seen in ~1 of 8 runs of
+        # tests/rccl_reducer_case.py: the poll has to land inside the ~0.3 s capture).  "thread_local" restricts only the
+        # capturing thread, which is what is wanted here; the device is drained first so that the warm-up's works are
+        # complete before the capture begins.
+        import torch.distributed as dist
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager(zero=False)
 
     def _eager(self, zero=True):

@@ -1,7 +1,8 @@
 """Body of tests/test_gpu_train.py::test_mn_backward_through_bucketed_rccl_reducer_matches_local, run as a separate
-process: `python tests/rccl_reducer_case.py` prints RCCL_REDUCER_OK when every check passed.  (RCCL's process-group
-teardown after a hipGraph capture that contains collectives has aborted the interpreter once inside a long pytest run;
-in its own process that cannot take the rest of the suite with it.)"""
+process: `python tests/rccl_reducer_case.py` prints RCCL_REDUCER_OK when every check passed.  (Its own process because a
+process-group failure aborts the interpreter: until round 4 the ProcessGroupNCCL watchdog thread's event polls could land
+inside the hipGraph capture of the step - "operation not permitted when stream is capturing" - and terminate the process;
+graphs.GraphedTrainStep captures with capture_error_mode="thread_local" now.)"""
 import contextlib
 import io
 import os
