@@ -15,6 +15,12 @@ sub-batches issued on concurrent HIP streams inside the captured graph, so that 
 sub-batch (SE / head GEMMs, kernel tails) overlap with the bandwidth-bound kernels of the other.
 """
 import torch
+import torch.distributed as dist
+
+
+def _capture_mode():
+    """"thread_local" while a process group exists (its watchdog thread polls events during our capture), else "global"."""
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
 
 
 class GraphedForward:
@@ -41,7 +47,8 @@ class GraphedForward:
             self._issue()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self._issue()
 
     def _issue(self):
@@ -97,10 +104,8 @@ class GraphedTrainStep:
         # tests/rccl_reducer_case.py: the poll has to land inside the ~0.3 s capture).  "thread_local" restricts only the
         # capturing thread, which is what is wanted here; the device is drained first so that the warm-up's works are
         # complete before the capture begins.
-        import torch.distributed as dist
-        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = self._eager(zero=False)
 
     def _eager(self, zero=True):
