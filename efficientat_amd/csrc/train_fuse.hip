@@ -159,6 +159,48 @@ __global__ __launch_bounds__(256) void se_bn_bwd_partials_kernel(const float* __
   }
 }
 
+// Small planes (S <= 512, S % 4 == 0: the 8 x 63 and 4 x 32 planes of the late SE blocks): one block per plane is a 64-thread
+// block that reads 1 - 4 KB - block scheduling, not bandwidth, set the pace (2.6 TB/s at S = 128).  Here a WAVE owns LPP-lane
+// groups, one plane per group (LPP = 32 for S <= 128: two planes per wave), walks its planes with a grid stride and
+// reduces inside the group with xor shuffles: no LDS, no barrier.
+template <int ACT, int LPP>
+__global__ __launch_bounds__(256) void se_bn_bwd_partials_small_kernel(const float* __restrict__ d, const float* __restrict__ z,
+                                                                       const float* __restrict__ a, const float* __restrict__ b,
+                                                                       const float* __restrict__ mean, float* __restrict__ P,
+                                                                       int C, int S, int n_planes) {
+  constexpr int GPW = 64 / LPP;                                      // plane groups per wave
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int grp = lane / LPP, gl = lane % LPP;
+  const int stride = gridDim.x * 4 * GPW;
+  for (int plane = (blockIdx.x * 4 + wv) * GPW + grp; plane < n_planes; plane += stride) {
+    const int c = plane % C;
+    const float av = a[c], bv = b[c], mu = mean[c];
+    const size_t base = (size_t)plane * S;
+    float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = gl * 4; i < S; i += LPP * 4) {
+      const float4 dv = *reinterpret_cast<const float4*>(d + base + i);
+      const float4 zv = *reinterpret_cast<const float4*>(z + base + i);
+      const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = fmaf(av, zz[e], bv);
+        const float da = act_deriv(u, ACT), y = eat::activate<ACT>(u), zc = zz[e] - mu;
+        p[0] = fmaf(dd[e], y, p[0]);
+        p[1] = fmaf(dd[e], da, p[1]);
+        p[2] += da;
+        p[3] = fmaf(dd[e] * da, zc, p[3]);
+        p[4] = fmaf(da, zc, p[4]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+#pragma unroll
+      for (int o = LPP / 2; o > 0; o >>= 1) p[q] += __shfl_xor(p[q], o, 64);
+    }
+    if (gl < 5) P[(size_t)gl * n_planes + plane] = gl == 0 ? p[0] : gl == 1 ? p[1] : gl == 2 ? p[2] : gl == 3 ? p[3] : p[4];
+  }
+}
+
 // sums[c] = sum_b (s P1 + gadd P2), sums[C + c] = invstd[c] * sum_b (s P3 + gadd P4)   (fp64, one block per channel)
 __global__ __launch_bounds__(64) void se_bn_bwd_combine_kernel(const float* __restrict__ P, const float* __restrict__ gs,
                                                                const float* __restrict__ ga,
@@ -394,6 +436,20 @@ extern "C" int eat_se_bn_bwd_partials(const float* d, const float* z, const floa
   eat::clear_stale_error();
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad act %d", act);
   if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad shape");
+  if (S <= 512 && (S & 3) == 0) {
+    // small planes: waves own planes (two per wave for S <= 128); ~8 planes per wave fill the chip several times over
+    const int n_planes = B * C, ppb = S <= 128 ? 8 : 4;            // planes per block per grid-stride step
+    int nb = (n_planes + ppb * 8 - 1) / (ppb * 8);
+    nb = nb < 1 ? 1 : nb;
+    if (S <= 128) {
+      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_small_kernel<ACT, 32>), dim3((unsigned)nb), dim3(256), 0,
+                                               (hipStream_t)stream, d, z, a, b, mean, P, C, S, n_planes));
+    } else {
+      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_small_kernel<ACT, 64>), dim3((unsigned)nb), dim3(256), 0,
+                                               (hipStream_t)stream, d, z, a, b, mean, P, C, S, n_planes));
+    }
+    return eat::check_launch("eat_se_bn_bwd_partials");
+  }
   const dim3 blk(S >= 1024 ? 256 : 64);
   EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_kernel<ACT>), dim3((unsigned)(B * C)), blk, 0,
                                            (hipStream_t)stream, d, z, a, b, mean, P, C, S, B * C));
