@@ -227,6 +227,35 @@ def _alg_bytes(name, a):
     if name == "eat_act_grad_sum":
         B, C, S = a[7:10]
         return "act_grad_sum_kernel", 12 * B * C * S, 4 * B * C * S
+    # ---- round 5: bf16 activation storage (BASELINE configs[2]): the wide tensor of each launch moves 2 bytes per element
+    if name == "eat_pw_conv_b16_fwd":
+        x, x16, x2, c1, wp, bias, ta, tb, tact, sc, res, y, y16, part, B, Ci, Co, S, act = a[:19]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        cw = (c1 if x2 else Ci) if x16 else 0                                      # bf16 input channels
+        nbytes = B * S * (2 * cw + 4 * (Ci - cw) + (2 if y16 else 4) * Co + (4 * Co if res else 0)) + 2 * Co * Ci
+        tag = "cat" if x2 else ("true" if ta else "*")
+        return f"pw_conv_bf16_kernel<{mtw},1,*,{tag},{'bf16' if x16 else 'f32'}->{'bf16' if y16 else 'f32'}>", nbytes, 2 * B * S * Ci * Co
+    if name == "eat_dw_conv_fwd_stats_b16":
+        x, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:17]
+        return f"dw_conv_fwd_stats<{k},{s},bf16>", 2 * B * C * (F * T + Fo * To), 2 * B * C * Fo * To * k * k
+    if name == "eat_bn_act_fwd_b16":
+        z, aa, bb, y, pool, B, C, S, act = a[:9]
+        return f"bn_act_fwd_kernel<{act},bf16>", 2 * B * C * S * (1 + (1 if y else 0)), 4 * B * C * S
+    if name == "eat_bn_act_bwd_reduce_b16":
+        B, C, S, act = a[8:12]
+        return f"bn_act_bwd_reduce_kernel<{act},bf16>", 4 * B * C * S, 8 * B * C * S
+    if name == "eat_se_bn_bwd_partials_b16":
+        B, C, S = a[6:9]
+        return "se_bn_bwd_partials_kernel<bf16>", 4 * B * C * S, 12 * B * C * S
+    if name == "eat_dw_conv_bwd_bn_g_b16":
+        B, C, F, T, Fo, To, k, s = a[-9:-1]
+        return (f"dw_bwd_tile_kernel<{k},{s},*,true,*,false,bf16>", 2 * B * C * (2 * Fo * To + 2 * F * T),
+                4 * B * C * F * T * k * k // (s * s) + 2 * B * C * Fo * To * k * k)
+    if name == "eat_pw_conv_wgrad_b16":
+        dz, d16, x, x16, ta, tb, tact, xs, dW, ws, nsl, B, Co, Ci, S = a[:15]
+        return "pw_wgrad_wide_kernel<1,*,bf16>", B * S * ((2 if d16 else 4) * Co + (2 if x16 else 4) * Ci) + 4 * Co * Ci, 2 * B * S * Co * Ci
     # ---- round 4: every entry point of the training steps has a byte model (argument order = include/eat_hip.h)
     if name in ("eat_dw_conv_bwd_bn_g", "eat_dw_conv_dyn_bwd_bn_g"):
         B, C, F, T, Fo, To, k, s = a[-9:-1]
@@ -252,6 +281,9 @@ def _alg_bytes(name, a):
     if name == "eat_se_mlp_bwd":
         B, C, Cr = a[13:16]
         return "se_mlp_bwd_kernels", 4 * (4 * B * C + 2 * B * Cr + 4 * C * Cr + C + Cr), 8 * B * C * Cr
+    if name == "eat_mlp_head_bwd":
+        B, C, H, N = a[13:17]
+        return "head_bwd_kernels", 4 * (B * (2 * N + 5 * H + 2 * C) + 2 * (H * C + N * H)), 4 * B * H * (N + C)
     if name == "eat_stem_bwd":
         B, C, F, T = a[10:14]
         Fo, To = (F - 1) // 2 + 1, (T - 1) // 2 + 1
@@ -614,6 +646,10 @@ def make_train_model(name, dev, precision=None):
         from efficientat_amd.mn import get_model as gm
         model = quiet(gm, width_mult=4.0 if name.startswith("mn40") else 1.0)
         model.train_precision = precision or ("bf16" if name.endswith("bf16") else os.environ.get("EAT_TRAIN_PRECISION", "auto"))
+        # BASELINE configs[2] "train step bf16": bf16 GEMM operands AND bf16 storage of the wide activations / gradients
+        # (EAT_ACT_STORAGE=fp32: the round-4 form, fp32 activations in HBM, for A/B)
+        if name.endswith("bf16") and model.train_precision == "bf16":
+            model.act_storage = os.environ.get("EAT_ACT_STORAGE", "bf16")
     _fan_in_init(model, head_scale=0.05 if name == "mn10" else None)
     return model.to(dev)
 
@@ -692,7 +728,8 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
            "warmup": max(2, warmup), "batch_per_gpu": bt, "n_gpus": ranks.world, "final_loss": round(float(out["loss"]), 5),
            "launch": launch, "model": name,
            "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if use_dp else "") + "fused Adam; "
-                   + ("bf16 MFMA 1x1 GEMMs, fp32 activations" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
+                   + (f"bf16 MFMA 1x1 GEMMs, wide activations / gradients stored in {getattr(model, 'act_storage', 'fp32')}, fp32 statistics / "
+                      "parameters / optimizer" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
            "roofline_e2e_frac": round(cps / ranks.world * alg / HBM_PEAK, 4) if alg else None,
            "alg_bytes_per_clip": alg}
     mel.eval()

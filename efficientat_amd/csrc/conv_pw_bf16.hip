@@ -14,6 +14,7 @@
 // fragment is one 16-byte LDS read.  The fp32 epilogue (bias, activation, residual, pooled sums) is
 // the one of conv_pw.hip.
 #include <cstdlib>
+#include <type_traits>
 #include "eat_common.h"
 #include "pw_epilogue.h"
 
@@ -23,6 +24,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int kKC = 32;
@@ -98,10 +100,15 @@ __global__ __launch_bounds__(256) void pw_prepack_multi_kernel(const PrepackDesc
 // models/mn/block_types.py:150-171 under model.train()); the SE scale (in_scale) multiplies the transformed value.
 struct PwTf { const float* a; const float* b; int act; };
 
-template <int MTW, int NPROD, int NSTG, bool TF>
+// XT / YT: storage type of x / y (act_io.h).  XT = bf16 (the wide tensors of the bf16-storage training plan): a chunk is
+// staged as 32 rows x 512 B (one LDS-DMA instruction = two rows), a lane reads its 4 columns of 8 rows as 8-byte pieces and
+// transposes them into B fragments with v_perm_b32 - no conversion, no lo part (host: NPROD = 1); x2 stays fp32 (the
+// two-source GEMM of the expand data gradient reads the wide gradient g in bf16 and the narrow block input in fp32; host:
+// c1 % 32 == 0, so a chunk is one or the other).
+template <int MTW, int NPROD, int NSTG, bool TF, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
-    const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
+    const XT* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ res, YT* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
     int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1, int tps, long long wp_bstride,
     float* __restrict__ stats) {
@@ -117,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NP2 = NPROD == 3 ? 2 : 1;
   constexpr int kABytes = MTW * NP2 * 1024;                 // A fragments of one chunk
-  constexpr int kXBytes = kKC * kTileN * 4;
+  constexpr bool XB = eat::Io<XT>::kBf;
+  const int kXBytes = kKC * kTileN * ((XB && !x2) ? 2 : 4);
   const int kStage = kABytes + kXBytes + sc_bytes;           // + the SE scales of the chunk: kKC x NS floats, 256 B pieces
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
@@ -132,8 +140,12 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   unsigned nl = n_base + 4 * lane;
   if (nl > N - 4) nl = N - 4;
   const int bl = (int)(nl / (unsigned)S), sl = (int)(nl - (unsigned)bl * (unsigned)S);
-  const float* xsrc = x + ((size_t)bl * (x2 ? c1 : ci_x)) * S + sl;
-  const float* xsrc2 = x2 ? x2 + ((size_t)bl * (Ci - c1)) * S + sl : xsrc;
+  // XB: a lane moves 8 columns (16 bytes) of row (lane >> 5) of a row pair (host: S % 8 == 0)
+  unsigned nl8 = n_base + 8 * (lane & 31);
+  if (nl8 > N - 8) nl8 = N - 8;
+  const int bl8 = (int)(nl8 / (unsigned)S), sl8 = (int)(nl8 - (unsigned)bl8 * (unsigned)S);
+  const XT* xsrc = XB ? x + ((size_t)bl8 * (x2 ? c1 : ci_x)) * S + sl8 : x + ((size_t)bl * (x2 ? c1 : ci_x)) * S + sl;
+  const float* xsrc2 = x2 ? x2 + ((size_t)bl * (Ci - c1)) * S + sl : nullptr;
   const unsigned nc = n_base + 64 * wv + 4 * (lane & 15);
   const bool col_ok = nc < N;
   const unsigned ncc = col_ok ? nc : N - 4;
@@ -147,12 +159,26 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const int klen = (Ci - k0) < kKC ? (Ci - k0) : kKC;
     const int kx0 = k0 % ci_x;                                // row of x the chunk starts at
     float* Xs = reinterpret_cast<float*>(st + kABytes);
+    bool rows16 = false;
+    if constexpr (XB) rows16 = !(x2 && k0 >= c1);             // (block-uniform) bf16 rows: two per instruction
+    if (rows16) {
 #pragma unroll
-    for (int i = 0; i < kKC / 4; ++i) {
-      const int r = wv + 4 * i;
-      const int rc = r < klen ? r : klen - 1;                // padded k: finite data x zero weight
-      const int row = kx0 + rc;
-      glds16_raw((x2 && row >= c1) ? xsrc2 + (size_t)(row - c1) * S : xsrc + (size_t)row * S, Xs + r * kTileN);
+      for (int i = 0; i < kKC / 8; ++i) {
+        const int r = 2 * (wv + 4 * i) + (lane >> 5);
+        const int rc = r < klen ? r : klen - 1;
+        glds16_raw(xsrc + (size_t)(kx0 + rc) * S, reinterpret_cast<unsigned char*>(Xs) + (wv + 4 * i) * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kKC / 4; ++i) {
+        const int r = wv + 4 * i;
+        const int rc = r < klen ? r : klen - 1;                // padded k: finite data x zero weight
+        const int row = kx0 + rc;
+        if constexpr (XB)
+          glds16_raw(xsrc2 + (size_t)(row - c1) * S, Xs + r * kTileN);
+        else
+          glds16_raw((x2 && row >= c1) ? xsrc2 + (size_t)(row - c1) * S : xsrc + (size_t)row * S, Xs + r * kTileN);
+      }
     }
 #pragma unroll
     for (int i = 0; i < (MTW * NP2 + 3) / 4; ++i) {
@@ -191,9 +217,38 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const unsigned char* st = smem_raw + (c & (n_stages - 1)) * kStage;
     const float* Xw = reinterpret_cast<const float*>(st + kABytes) + (8 * kq) * kTileN + 64 * wv + 4 * (lane & 15);
     const float* SCs = reinterpret_cast<const float*>(st + kABytes + kXBytes) + (8 * kq) * NS + (bc - b_first);
+    bf16x8 bh[4], bl_[4];
+    bool raw16 = false;                                      // the chunk's rows are bf16 and need no arithmetic: transpose only
     float4 xr[8];
+    bool rows16 = false;
+    if constexpr (XB) rows16 = !(x2 && c * kKC >= c1);       // (block-uniform)
+    if (rows16) {
+      const unsigned char* Xb = st + kABytes + (8 * kq) * (kTileN * 2) + (64 * wv + 4 * (lane & 15)) * 2;
+      u32x2 xq[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4*>(Xw + i * kTileN);
+      for (int i = 0; i < 8; ++i) xq[i] = *reinterpret_cast<const u32x2*>(Xb + i * (kTileN * 2));
+      if (!TF && !in_scale) {
+        raw16 = true;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          // column j of rows i, i + 1: the low (j even) / high (j odd) halves of dword j >> 1 of the two rows
+          const unsigned p0 = __builtin_amdgcn_perm(xq[i + 1][0], xq[i][0], 0x05040100u), p1 = __builtin_amdgcn_perm(xq[i + 1][0], xq[i][0], 0x07060302u);
+          const unsigned p2 = __builtin_amdgcn_perm(xq[i + 1][1], xq[i][1], 0x05040100u), p3 = __builtin_amdgcn_perm(xq[i + 1][1], xq[i][1], 0x07060302u);
+          const bf16x2 h0 = __builtin_bit_cast(bf16x2, p0), h1 = __builtin_bit_cast(bf16x2, p1);
+          const bf16x2 h2 = __builtin_bit_cast(bf16x2, p2), h3 = __builtin_bit_cast(bf16x2, p3);
+          bh[0][i] = h0[0]; bh[0][i + 1] = h0[1]; bh[1][i] = h1[0]; bh[1][i + 1] = h1[1];
+          bh[2][i] = h2[0]; bh[2][i + 1] = h2[1]; bh[3][i] = h3[0]; bh[3][i + 1] = h3[1];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          xr[i] = make_float4(eat::bf_lo(xq[i][0]), eat::bf_hi(xq[i][0]), eat::bf_lo(xq[i][1]), eat::bf_hi(xq[i][1]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4*>(Xw + i * kTileN);
+    }
+    if (!raw16) {
     if constexpr (TF) {
       // rows kb .. kb+7 of this lane (host: Ci % 8 == 0, so an octet is inside or outside as a whole; rows beyond Ci
       // meet zero weights: coefficient 0 keeps them finite)
@@ -218,7 +273,6 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
         xr[i].x *= s; xr[i].y *= s; xr[i].z *= s; xr[i].w *= s;
       }
     }
-    bf16x8 bh[4], bl_[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -232,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
           bl_[j][i] = l[0]; bl_[j][i + 1] = l[1];
         }
       }
+    }
     }
     const bf16x8* Af = reinterpret_cast<const bf16x8*>(st) + lane;
 #pragma unroll
@@ -255,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     }
   }
 
-  eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
+  eat::pw_epilogue<MTW, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
   if (stats) {                                             // block-uniform: train-mode statistics of the output (pw_epilogue.h)
     __syncthreads();                                       // every wave is done with the operand stages: LDS is free
     eat::pw_epilogue_stats<MTW>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, tile, mt0, kq, lane, wv, col_ok, Co);
@@ -263,10 +318,11 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 }
 
 
-template <int MTW, int NPROD>
-int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-           float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf,
+template <int MTW, int NPROD, typename XT = float, typename YT = float>
+int launch(hipStream_t s, const XT* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
+           YT* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf,
            const float* x2, int c1, bool per_sample, float* stats) {
+  constexpr bool XB = eat::Io<XT>::kBf;
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
   const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
@@ -281,13 +337,15 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   // there are not enough blocks for two per CU anyway; otherwise ONE stage, so that a second resident
   // block hides the load latency and the store phase instead (measured on MI355X, B=256: 80->480 95 vs
   // 135 us, 160->960 48 vs 83 us; the K-heavy 960->160 with 256 blocks keeps two stages: 45 vs 56 us).
-  const size_t stage = (size_t)(MTW * NP2 * 1024 + kKC * kTileN * 4 + sc_bytes);
-  static const int forced = getenv("EAT_PW_BF16_STAGES") ? atoi(getenv("EAT_PW_BF16_STAGES")) : 0;
+  const size_t stage = (size_t)(MTW * NP2 * 1024 + kKC * kTileN * ((XB && !x2) ? 2 : 4) + sc_bytes);
   const int n_blocks = ((n_tiles + 7) / 8 * 8) * MC;
-  const int n_stages = forced ? forced : ((2 * stage <= 78 * 1024 || n_blocks < 2 * 256) ? 2 : 1);
+  const int n_stages = (2 * stage <= 78 * 1024 || n_blocks < 2 * 256) ? 2 : 1;
   const size_t smem = n_stages * stage;
-  auto kern = tf.a ? (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, true> : pw_conv_bf16_kernel<MTW, NPROD, 1, true>)
-                   : (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, false> : pw_conv_bf16_kernel<MTW, NPROD, 1, false>);
+  // (the on-load transform exists for fp32 -> fp32 and bf16 -> fp32: the project conv of the training plans)
+  constexpr bool TFOK = std::is_same<YT, float>::value;
+  if (tf.a && !TFOK) return eat::fail(EAT_EINVAL, "eat_pw_conv: the on-load transform needs an fp32 output");
+  auto kern = (tf.a && TFOK) ? (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, TFOK, XT, YT> : pw_conv_bf16_kernel<MTW, NPROD, 1, TFOK, XT, YT>)
+                   : (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, false, XT, YT> : pw_conv_bf16_kernel<MTW, NPROD, 1, false, XT, YT>);
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: LDS stage too large (%zu B; planes of %d positions)", smem, S);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -299,16 +357,16 @@ int launch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, c
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
-template <int NPROD>
-int dispatch(hipStream_t s, const float* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
-             float* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0},
+template <int NPROD, typename XT = float, typename YT = float>
+int dispatch(hipStream_t s, const XT* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
+             YT* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0},
              const float* x2 = nullptr, int c1 = 0, bool per_sample = false, float* stats = nullptr) {
   const int MT = (Co + 15) / 16;
   // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
   // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample, stats);
+#define EAT_CASE(n) case n: return launch<n, NPROD, XT, YT>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample, stats);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -433,4 +491,43 @@ extern "C" int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float*
   }
   return dispatch<3>((hipStream_t)stream, x, reinterpret_cast<const __bf16*>(wp), bias, att_scale, res, y, nullptr, B,
                      nbank * Ci, Co, S, act, Ci);
+}
+
+// ---- 1x1 conv of the bf16-STORAGE training plan (act_io.h; BASELINE configs[2], the reference's 16-bit mixed precision,
+// ex_pl_audioset.py:287-293 over models/mn/block_types.py:138-147,167-181): plain bf16 operands, fp32 accumulation, and
+// the WIDE tensor of the layer - the expand conv's output, the project conv's input, the project data gradient's output,
+// the expand data gradient's input - in bf16 in HBM, the narrow one in fp32.
+//   x_b16 = 0, y_b16 = 1   z_e = W x (expand conv) / dxs = Wp^T dz_p (project data gradient): no transform, scale, residual
+//   x_b16 = 1, y_b16 = 0   project conv z_p = Wp act(tf_a x + tf_b) * in_scale with the statistics epilogue (stats_part, as
+//                          eat_pw_conv_stats_fwd), or the two-source data-gradient GEMM dx = [WaT | M] [g ; x2] + bias + res
+//                          (x2 fp32 with Ci - c1 channels, c1 % 32 == 0; as eat_pw_conv_cat_fwd)
+// wp: eat_pw_prepack_bf16(split = 0) of the (Co, Ci) matrix.  S % 8 == 0, Ci % 4 == 0 (% 8 with a transform).
+extern "C" int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const void* wp, const float* bias,
+                                   const float* tf_a, const float* tf_b, int tf_act, const float* in_scale, const float* res,
+                                   void* y, int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act,
+                                   eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !wp || !bias || !y) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: missing operand");
+  if (B < 1 || Co < 1 || Ci < 4 || Ci % 4 != 0 || S < 8 || S % 8 != 0)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: Ci=%d must be a multiple of 4 and S=%d a multiple of 8", Ci, S);
+  if (act < 0 || act > 2 || tf_act < 0 || tf_act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: bad act");
+  if ((tf_a == nullptr) != (tf_b == nullptr)) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: tf_a and tf_b go together");
+  if (tf_a && Ci % 8 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: the on-load transform needs Ci %% 8 == 0 (Ci=%d)", Ci);
+  const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
+  const PwTf tf{tf_a, tf_b, tf_act};
+  hipStream_t s = (hipStream_t)stream;
+  if (!x_b16 && y_b16) {
+    if (x2 || tf_a || in_scale || res || stats_part)
+      return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: a bf16 output takes a plain conv only");
+    return dispatch<1, float, eat::bf16_t>(s, reinterpret_cast<const float*>(x), w16, bias, nullptr, nullptr,
+                                           reinterpret_cast<eat::bf16_t*>(y), nullptr, B, Ci, Co, S, act, Ci);
+  }
+  if (x_b16 && !y_b16) {
+    if (x2 && (c1 < 32 || c1 % 32 != 0 || c1 >= Ci || tf_a || in_scale || stats_part))
+      return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: two-source form needs c1 %% 32 == 0 (c1=%d) and no transform / scale / statistics", c1);
+    return dispatch<1, eat::bf16_t, float>(s, reinterpret_cast<const eat::bf16_t*>(x), w16, bias, in_scale, res,
+                                           reinterpret_cast<float*>(y), nullptr, B, Ci, Co, S, act, Ci, tf, x2, c1, false,
+                                           stats_part);
+  }
+  return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: exactly one of x / y is the bf16 (wide) tensor");
 }

@@ -254,9 +254,8 @@ static int dw_conv_fwd_stats_impl(int per_plane_w, const float* x, const float* 
   if (!part || !h_inner || inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 0))
     return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats: partial buffer too small (inner_cap %d)", inner_cap);
   const DwDyn dyn{nullptr, nullptr, nullptr, nullptr, 0, per_plane_w, in_a, in_b, in_act};
-  static const bool fused = !(getenv("EAT_DW_STATS_FUSED") && atoi(getenv("EAT_DW_STATS_FUSED")) == 0);
   int inner = 1;
-  if (fused) {
+  {
     const eat::DwEpi epi{part, nullptr, nullptr, nullptr, 0, nullptr, &inner};
     const int rc = dispatch_dw(x, w, nullptr, y, nullptr, B, C, F, T, Fo, To, k, stride, EAT_ACT_NONE, &dyn, (hipStream_t)stream, &epi);
     if (rc != 1) { *h_inner = inner; return rc; }
@@ -272,6 +271,46 @@ extern "C" int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const fl
                                      int Fo, int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();
   return dw_conv_fwd_stats_impl(0, x, in_a, in_b, in_act, w, y, part, inner_cap, h_inner, B, C, F, T, Fo, To, k, stride, stream);
+}
+
+// The same over bf16-stored x and y (act_io.h; the bf16-storage plan of BASELINE configs[2]: the expand conv's output z_e in,
+// the depthwise output z_d out, both 16-bit in HBM; taps, transform coefficients and statistics fp32).  The partial sums are
+// those of the ROUNDED outputs - the values the BatchNorm that follows will actually read.  Register-resident kernels only
+// (csrc/dw_plane.hip): eat_dw_conv_b16_ok tells whether a geometry is covered.
+extern "C" int eat_dw_conv_fwd_stats_b16(const void* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                                         void* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T,
+                                         int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !w || !y) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: missing operand");
+  if ((in_a == nullptr) != (in_b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: in_a and in_b come together");
+  if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: bad in_act %d", in_act);
+  if (!part || !h_inner || inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 0))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: partial buffer too small (inner_cap %d)", inner_cap);
+  if ((F * T) % 2 != 0 || (Fo * To) % 2 != 0)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: planes must hold an even number of elements (%d, %d)", F * T, Fo * To);
+  int inner = 1;
+  const eat::DwEpi epi{part, nullptr, nullptr, nullptr, 0, nullptr, &inner};
+  const int rc = eat::dw_plane_try(reinterpret_cast<const float*>(x), w, nullptr, nullptr, reinterpret_cast<float*>(y), nullptr, B,
+                                   C, F, T, Fo, To, k, stride, EAT_ACT_NONE, 0, 0, in_a, in_b, in_act, (hipStream_t)stream, &epi, 1);
+  if (rc == 1)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: no register-resident kernel for F=%d T=%d k=%d stride=%d", F, T, k, stride);
+  *h_inner = inner;
+  return rc;
+}
+
+// 1 where eat_dw_conv_fwd_stats_b16 and eat_dw_conv_bwd_bn_g_b16 cover the geometry (host helper: a training plan keeps fp32
+// storage for the blocks they do not cover)
+extern "C" int eat_dw_conv_b16_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
+  if ((F * T) % 2 != 0 || (Fo * To) % 2 != 0 || (long long)B * C > 0x3fffffffLL) return 0;
+  if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return 0;
+  bool fwd = false;
+  if (T > 128 && (long long)F * T < (1 << 28)) fwd = true;                                  // tile kernels
+  else if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) fwd = true;               // plane kernels (dw_plane_try)
+  else if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128) fwd = true;
+  else if (k == 5 && stride == 2 && F == 8 && T > 32 && T <= 64) fwd = true;
+  else if (k == 3 && stride == 2 && F == 16 && T > 64 && T <= 128) fwd = true;
+  else if (k == 5 && stride == 1 && F == 4 && T <= 32) fwd = true;
+  return fwd && eat_dw_bwd_merged_ok(B, C, F, T, Fo, To, k, stride) ? 1 : 0;
 }
 
 // The same with per-(b,c) taps w_bc (B, C, k*k): DyMN's dynamic depthwise conv in train mode (models/dymn/dy_block.py:

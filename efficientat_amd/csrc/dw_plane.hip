@@ -17,6 +17,7 @@
 // `dw_plane_try` returns 1 when the geometry is not one of the instantiated ones; the caller then uses the row-ring kernel.
 #include <cstdlib>
 #include "eat_common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -63,6 +64,7 @@ struct PlaneArgs {
   InTf tf;
   eat::DwEpi epi;
   int per_plane_w;
+  int b16 = 0;           // x and y are bf16 in HBM (act_io.h): the statistics instance only
 };
 
 // d act(u) / du, PyTorch conventions (nn.ReLU / nn.Hardswish backward); `act` is wave-uniform
@@ -103,6 +105,41 @@ __device__ __forceinline__ void buf_store2(float v0, float v1, __amdgpu_buffer_r
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), r, (int)voff, (int)soff, 0);
 }
 
+// Storage-typed buffer access (act_io.h): XT = float or bf16 (the wide tensors of the bf16-storage training plan).  All
+// offsets are BYTES (Bio<XT>::kB per element).  A bf16 row of an odd width starts on a 2-byte boundary on every other row:
+// the two-column access is ONE dword at a 2-byte aligned address (gfx9 under ROCm runs with unaligned access enabled for
+// buffer / global memory).  The last lane of an odd-width row owns one column only; its load is moved back by one element
+// (`adj`) so that it never reaches past its row - i.e. never past the end of the tensor - and takes the high half.
+template <typename T> struct Bio;
+template <> struct Bio<float> {
+  static constexpr unsigned kB = 4;
+  static __device__ __forceinline__ unsigned adj(unsigned voff, bool) { return voff; }
+  static __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return buf_load(r, voff, soff); }
+  static __device__ __forceinline__ f32x2 ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool) { return buf_load2(r, voff, soff); }
+  static __device__ __forceinline__ void st1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { buf_store(v, r, voff, soff); }
+  static __device__ __forceinline__ void st2(float v0, float v1, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { buf_store2(v0, v1, r, voff, soff); }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct Bio<eat::bf16_t> {
+  static constexpr unsigned kB = 2;
+  static __device__ __forceinline__ unsigned adj(unsigned voff, bool part) { return (part && voff != kOOB) ? voff - 2u : voff; }
+  static __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return eat::bf_lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0));
+  }
+  // voff = adj(offset of the lane's first column, part): (first, second) column; a `part` lane has no second column
+  static __device__ __forceinline__ f32x2 ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool part) {
+    const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+    return f32x2{part ? eat::bf_hi(w) : eat::bf_lo(w), part ? 0.0f : eat::bf_hi(w)};
+  }
+  static __device__ __forceinline__ void st1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(eat::pack_bf2(v, 0.0f) & 0xffffu), r, (int)voff, (int)soff, 0);
+  }
+  static __device__ __forceinline__ void st2(float v0, float v1, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(eat::pack_bf2(v0, v1), r, (int)voff, (int)soff, 0);
+  }
+  static __device__ __forceinline__ float rnd(float v) { return eat::bf_round(v); }
+};
+
 // PF: keep the next plane group of the wave loading while the current one is multiplied (small planes; big planes have
 // enough bytes in flight from the waves of the CU alone and need the registers)
 // EPI: 0 plain, 1 residual add (res), 2 training data gradient: the output is multiplied by act'(ga[c] * gz + gb[c]) of
@@ -111,7 +148,8 @@ __device__ __forceinline__ void buf_store2(float v0, float v1, __amdgpu_buffer_r
 // STATS: per-plane sum / sum of squares of the output (epi.stats), the BatchNorm batch statistics of the conv output
 // PPW: taps per (b,c) plane (DyMN's dynamic depthwise conv in train mode, models/dymn/dy_block.py:103-131): wave-uniform
 // scalar loads for one plane per wave, per-lane loads (one address per half-wave) for two
-template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS, bool PPW = false>
+// XT: storage type of x AND y (Bio; bf16 = the statistics instances of the bf16-storage plan, which sum the ROUNDED outputs)
+template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS, bool PPW = false, typename XT = float>
 __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const float* __restrict__ w_,
                                                        const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2;
@@ -119,6 +157,10 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
   constexpr int NE = S == 1 ? CPL + 2 * P : K;           // extended row: input columns CPL*l - P ... as seen by lane l
   constexpr int NO = S == 1 ? CPL : 1;                   // output columns per lane
   constexpr int Fo = (F + 2 * P - K) / S + 1;
+  constexpr unsigned EB = Bio<XT>::kB;
+  static_assert(EPI == 0 || EB == 4, "residual / derivative epilogues: fp32 storage only");
+  const XT* const ax = reinterpret_cast<const XT*>(a.x);
+  XT* const ay = reinterpret_cast<XT*>(a.y);
   static_assert(S == 1 || CPL == 2, "stride 2: a lane owns input columns 2l, 2l+1 and output column l");
   const int lane = threadIdx.x & 63;
   const int l = lane & (LPP - 1);
@@ -136,12 +178,13 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
   // zeroes it; the STORE of that lane is a separate dword (vout[1]), the 8-byte store (vout[0]) skips it.
   unsigned vin, vout[NO];
   {
-    const unsigned bi = 4u * (unsigned)(half * C * (F * T) + CPL * l), bo = 4u * (unsigned)(half * C * (Fo * To) + NO * l);
+    const unsigned bi = EB * (unsigned)(half * C * (F * T) + CPL * l), bo = EB * (unsigned)(half * C * (Fo * To) + NO * l);
     vin = CPL * l < T ? bi : kOOB;
     vout[0] = NO * l + NO - 1 < To ? bo : kOOB;
     if (NO == 2) vout[NO - 1] = (NO * l < To && NO * l + 1 >= To) ? bo : kOOB;
   }
   const bool in_part = CPL == 2 && CPL * l + 1 >= T;      // second input column of this lane does not exist
+  if (CPL == 2) vin = Bio<XT>::adj(vin, in_part);
   const long long x_elems = (long long)a.B * C * (F * T), y_elems = (long long)a.B * C * (Fo * To);
 
   float raw[PF ? 2 : 1][F][CPL];
@@ -156,14 +199,14 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
   auto fetch = [&](int g, float (&r)[F][CPL]) {
     int c; bool mine;
     const int p = plane_of(g, c, mine);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * (F * T), 4 * (x_elems - (long long)p * (F * T)));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(ax + (size_t)p * (F * T), (long long)EB * (x_elems - (long long)p * (F * T)));
     const unsigned v = mine ? vin : kOOB;
 #pragma unroll
     for (int i = 0; i < F; ++i) {
       if constexpr (CPL == 1) {
-        r[i][0] = buf_load(rx, v, 4u * (unsigned)(i * T));
+        r[i][0] = Bio<XT>::ld1(rx, v, EB * (unsigned)(i * T));
       } else {
-        const f32x2 pv = buf_load2(rx, v, 4u * (unsigned)(i * T));
+        const f32x2 pv = Bio<XT>::ld2(rx, v, EB * (unsigned)(i * T), in_part);
         r[i][0] = pv[0];
         r[i][1] = in_part ? 0.0f : pv[1];
       }
@@ -197,8 +240,8 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
       for (int i = 0; i < K * K / 2; ++i) { const float t = wk[i]; wk[i] = wk[K * K - 1 - i]; wk[K * K - 1 - i] = t; }
     }
     const float b = bias_ ? bias_[c] : 0.0f;
-    const long long y_left = 4 * (y_elems - (long long)p * (Fo * To));
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)p * (Fo * To), y_left);
+    const long long y_left = (long long)EB * (y_elems - (long long)p * (Fo * To));
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(ay + (size_t)p * (Fo * To), y_left);
     constexpr bool RES = EPI == 1;
     const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.y) + (size_t)p * (Fo * To), y_left);
     const float g_a = EPI == 2 ? a.epi.ga[c] : 0.0f, g_b = EPI == 2 ? a.epi.gb[c] : 0.0f;
@@ -244,16 +287,16 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
             for (int j = 0; j < NO; ++j) acc[j] = fmaf(wk[u * K + v], ext[rr][j + v], acc[j]);
         }
       }
-      const unsigned so = 4u * (unsigned)(i * To);
+      const unsigned so = EB * (unsigned)(i * To);
       if constexpr (NO == 1) {
-        float o = eat::activate<ACT>(acc[0]);
+        float o = Bio<XT>::rnd(eat::activate<ACT>(acc[0]));
         if constexpr (RES) o += buf_load(rr_, vo[0], so);
         if constexpr (EPI == 2) o *= act_deriv(fmaf(g_a, buf_load(rr_, vo[0], so), g_b), a.epi.gact);
-        buf_store(o, ry, vo[0], so);
+        Bio<XT>::st1(o, ry, vo[0], so);
         psum += has0 ? o : 0.0f;
         if constexpr (STATS) psq += has0 ? o * o : 0.0f;
       } else {
-        float o0 = eat::activate<ACT>(acc[0]), o1 = eat::activate<ACT>(acc[1]);
+        float o0 = Bio<XT>::rnd(eat::activate<ACT>(acc[0])), o1 = Bio<XT>::rnd(eat::activate<ACT>(acc[1]));
         if constexpr (EPI != 0) {
           const f32x2 rv = buf_load2(rr_, has0 ? 4u * (unsigned)(half * C * (Fo * To) + NO * l) : kOOB, so);
           if constexpr (EPI == 1) {
@@ -263,8 +306,8 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
             o1 *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
           }
         }
-        buf_store2(o0, o1, ry, vo[0], so);
-        buf_store(o0, ry, vo[1], so);
+        Bio<XT>::st2(o0, o1, ry, vo[0], so);
+        Bio<XT>::st1(o0, ry, vo[1], so);
         psum += (has0 ? o0 : 0.0f) + (has1 ? o1 : 0.0f);
         if constexpr (STATS) psq += (has0 ? o0 * o0 : 0.0f) + (has1 ? o1 * o1 : 0.0f);
       }
@@ -315,13 +358,16 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   constexpr int NPW = 64 / LPP;
   const int n_groups = ((a.B + NPW - 1) / NPW) * a.C;
   // plane groups per wave: enough waves to fill the chip several times over, an even count for the 2-deep prefetch
-  static const int g_env = getenv("EAT_DWP_G") ? atoi(getenv("EAT_DWP_G")) : 0;
-  int G = g_env > 0 ? g_env : (PF ? 2 : 1);
-  if (PF) G = (G + 1) & ~1;
+  const int G = PF ? 2 : 1;
   a.G = G;
   const int waves = (n_groups + G - 1) / G;
   const dim3 grid((waves + 3) / 4), blk(256);
   if (a.epi.inner) *a.epi.inner = 1;
+  if (a.b16) {                                            // bf16 storage: train-mode conv + statistics (eat_dw_conv_fwd_stats_b16)
+    if (!a.epi.stats || a.per_plane_w || a.epi.gz || a.res || a.pool || a.act != EAT_ACT_NONE || a.flip) return 1;
+    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, false, eat::bf16_t>), grid, blk, 0, s, a, a.w, a.bias);
+    return eat::check_launch("eat_dw_conv_fwd_stats_b16(plane)");
+  }
   if (a.per_plane_w) {                                    // DyMN train mode: plain conv (forward / flipped data gradient) or + statistics
     if (a.epi.gz || a.res || a.act != EAT_ACT_NONE) return 1;
     if (a.epi.stats)
@@ -353,15 +399,18 @@ struct TileArgs {
   int B, C, F, T, Fo, To, n_rc, n_cs, WO, flip, per_plane_w;
   InTf tf;
   eat::DwEpi epi;
+  int b16 = 0;           // x and y are bf16 in HBM (act_io.h): the statistics instance only
 };
 
-template <int K, int S, int RO, int ACT, int EPI, bool STATS>
+template <int K, int S, int RO, int ACT, int EPI, bool STATS, typename XT = float>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const float* __restrict__ w_,
                                                       const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2, CPL = 2, LPP = 64;
   constexpr int NE = S == 1 ? CPL + 2 * P : K;
   constexpr int NO = S == 1 ? 2 : 1;
   constexpr int FI = (RO - 1) * S + K;                   // input rows under a tile
+  constexpr unsigned EB = Bio<XT>::kB;
+  static_assert(EPI == 0 || EB == 4, "residual / derivative epilogues: fp32 storage only");
   const int l = threadIdx.x & 63;
   const bool first = l == 0, last = l == 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -374,19 +423,19 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
   const int o_lo = cs * a.WO, o_hi = (o_lo + a.WO) < To ? (o_lo + a.WO) : To;   // output columns of this strip
   const int c0 = (S == 1 ? o_lo : 2 * o_lo) - 2;         // input column of lane 0 (a halo lane)
   const int col_in = c0 + 2 * l;
-  const unsigned vin = (col_in >= 0 && col_in < T) ? 4u * (unsigned)col_in : kOOB;
   const bool in_part = col_in + 1 >= T;
+  const unsigned vin = Bio<XT>::adj((col_in >= 0 && col_in < T) ? EB * (unsigned)col_in : kOOB, in_part);
   // output columns of this lane
   const int oc = S == 1 ? col_in : o_lo - 1 + l;
   const bool ok0 = oc >= o_lo && oc < o_hi, ok1 = NO == 2 && oc + 1 >= o_lo && oc + 1 < o_hi;
   unsigned vout[2];
-  vout[0] = (NO == 2 ? (ok0 && ok1) : ok0) ? 4u * (unsigned)oc : kOOB;
-  vout[1] = (NO == 2 && ok0 && !ok1) ? 4u * (unsigned)oc : kOOB;
+  vout[0] = (NO == 2 ? (ok0 && ok1) : ok0) ? EB * (unsigned)oc : kOOB;
+  vout[1] = (NO == 2 && ok0 && !ok1) ? EB * (unsigned)oc : kOOB;
   const int r0o = rc * RO, r0i = r0o * S - P;
-  const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
-  const long long y_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)p * Fo * To, y_left);
+  const long long x_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)F * T);
+  const long long y_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const XT*>(a.x) + (size_t)p * F * T, x_left);
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(reinterpret_cast<XT*>(a.y) + (size_t)p * Fo * To, y_left);
   constexpr bool RES = EPI == 1;
   const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.y) + (size_t)p * Fo * To, y_left);
   const float g_a = EPI == 2 ? a.epi.ga[c] : 0.0f, g_b = EPI == 2 ? a.epi.gb[c] : 0.0f;
@@ -396,7 +445,7 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
   for (int i = 0; i < FI; ++i) {
     const int rin = r0i + i;
     const bool rok = rin >= 0 && rin < F;                // wave-uniform: rows above / below the plane read as zero
-    const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
+    const f32x2 pv = Bio<XT>::ld2(rx, rok ? vin : kOOB, rok ? EB * (unsigned)(rin * T) : 0u, in_part);
     r[i][0] = pv[0];
     r[i][1] = in_part ? 0.0f : pv[1];
   }
@@ -452,17 +501,17 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
         for (int j = 0; j < NO; ++j) acc[j] = fmaf(wk[u * K + v], ext[i * S + u][j + v], acc[j]);
     const int ro = r0o + i;
     const bool rowok = ro < Fo;                          // wave-uniform
-    const unsigned so = rowok ? 4u * (unsigned)(ro * To) : 0u;
+    const unsigned so = rowok ? EB * (unsigned)(ro * To) : 0u;
     const unsigned v0 = rowok ? vout[0] : kOOB, v1 = rowok ? vout[1] : kOOB;
     if constexpr (NO == 1) {
-      float o = eat::activate<ACT>(acc[0]);
+      float o = Bio<XT>::rnd(eat::activate<ACT>(acc[0]));
       if constexpr (RES) o += buf_load(rr_, v0, so);
       if constexpr (EPI == 2) o *= act_deriv(fmaf(g_a, buf_load(rr_, v0, so), g_b), a.epi.gact);
-      buf_store(o, ry, v0, so);
+      Bio<XT>::st1(o, ry, v0, so);
       psum += (rowok && ok0) ? o : 0.0f;
       if constexpr (STATS) psq += (rowok && ok0) ? o * o : 0.0f;
     } else {
-      float o0 = eat::activate<ACT>(acc[0]), o1 = eat::activate<ACT>(acc[1]);
+      float o0 = Bio<XT>::rnd(eat::activate<ACT>(acc[0])), o1 = Bio<XT>::rnd(eat::activate<ACT>(acc[1]));
       if constexpr (EPI != 0) {
         const f32x2 rv = buf_load2(rr_, (rowok && ok0) ? 4u * (unsigned)oc : kOOB, so);
         if constexpr (EPI == 1) {
@@ -472,8 +521,8 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
           o1 *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
         }
       }
-      buf_store2(o0, o1, ry, v0, so);
-      buf_store(o0, ry, v1, so);
+      Bio<XT>::st2(o0, o1, ry, v0, so);
+      Bio<XT>::st1(o0, ry, v1, so);
       psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
       if constexpr (STATS) psq += ((rowok && ok0) ? o0 * o0 : 0.0f) + ((rowok && ok1) ? o1 * o1 : 0.0f);
     }
@@ -508,6 +557,11 @@ int launch_tile(TileArgs a, const float* w, const float* bias, int act, hipStrea
   if (waves > 0x7fffffffLL) return 1;
   const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
   if (a.epi.inner) *a.epi.inner = a.n_rc * a.n_cs;
+  if (a.b16) {                                            // bf16 storage: train-mode conv + statistics
+    if (!a.epi.stats || a.epi.gz || a.res || a.pool || act != EAT_ACT_NONE || a.flip) return 1;
+    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 0, true, eat::bf16_t>), grid, blk, 0, s, a, w, bias);
+    return eat::check_launch("eat_dw_conv_fwd_stats_b16(tile)");
+  }
   if (a.epi.gz) {
     hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 2, false>), grid, blk, 0, s, a, w, bias);
   } else if (a.epi.stats) {
@@ -939,6 +993,7 @@ struct DwBwdArgs {
   DzBn bn;
   const float* res;      // PPW: added to g (the gradient of a skip connection that ends at the conv input), or NULL
   float* gzpart;         // PPW: per-tile partials of sum g * x (x = the raw conv input), layout of gpart, or NULL
+  int b16 = 0;           // dz, bn.z, x and g are bf16 in HBM (act_io.h): the BatchNorm-on-load instances only
 };
 
 // LPP = 64: a wave owns one tile of one plane (column strips with halo lanes).  LPP = 32 / 16 (small planes, T <= 2 LPP): a
@@ -974,7 +1029,8 @@ __device__ __forceinline__ void tap_reduce(float (&v)[NV], int l, int& vidx) {
 // PPW: taps and weight gradient per (b,c) plane (DyMN's dynamic depthwise conv, models/dymn/dy_block.py:103-131): the taps
 // of the lane group's own plane are loaded per sample, the K*K sums are reduced over the lane group after every sample and
 // stored (one tile per plane) or added (several) to dw (B, C, K*K)
-template <int K, int S, int RO, bool BN, int LPP, bool WR, bool PPW = false>
+// XT: storage type of dz, bn.z, x AND g (Bio; bf16 = the bf16-storage plan: every wide tensor of the block)
+template <int K, int S, int RO, bool BN, int LPP, bool WR, bool PPW = false, typename XT = float>
 __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
   constexpr int P = (K - 1) / 2, KK = K * K, NPW = 64 / LPP;
   static_assert(WR || LPP == 64, "strip mode owns the whole wave");
@@ -983,6 +1039,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   constexpr int DOFF = S == 1 ? P : 1;                             // dz-array index of the tile's first dz row
   constexpr int ND = S == 1 ? 2 : 1;                               // dz columns per lane
   constexpr int NE = S == 1 ? 2 + 2 * P : K;                       // extended x row: columns under the filter
+  constexpr unsigned EB = Bio<XT>::kB;
+  static_assert(!PPW || EB == 4, "per-plane taps: fp32 storage only");
   const int lane = threadIdx.x & 63;
   const int l = lane & (LPP - 1);
   const int half = lane / LPP;                                     // which of the wave's NPW planes (samples)
@@ -1001,13 +1059,14 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   const int q = WR ? l : s_lo - 1 + l;                              // S == 2: dz column of this lane
   const int col_in = S == 1 ? (WR ? 2 * l : s_lo - 2 + 2 * l) : 2 * q;   // first of the lane's two x / dx columns
   // byte offsets inside the wave's first plane; the lane group's own plane lies `half` samples (C planes each) further on
-  const unsigned hx = 4u * (unsigned)(half * a.C * (F * T)), hz = 4u * (unsigned)(half * a.C * (Fo * To));
-  const unsigned vin_b = (col_in >= 0 && col_in < T) ? hx + 4u * (unsigned)col_in : kOOB;
+  const unsigned hx = EB * (unsigned)(half * a.C * (F * T)), hz = EB * (unsigned)(half * a.C * (Fo * To));
   const bool in_part = col_in + 1 >= T;
+  // (bf16: the one-column lane at the end of an odd-width row loads the dword that ENDS with its column - Bio::adj)
+  const unsigned vin_b = Bio<XT>::adj((col_in >= 0 && col_in < T) ? hx + EB * (unsigned)col_in : kOOB, in_part);
   // which of the lane's positions belong to the strip (produce output / contribute to the weight gradient)
   const bool ok0_b = S == 1 ? (col_in >= s_lo && col_in < s_hi) : (q >= s_lo && q < s_hi);
   const bool ok1_b = S == 1 ? (col_in + 1 >= s_lo && col_in + 1 < s_hi) : (ok0_b && 2 * q + 1 < T);
-  const unsigned vdz_b = S == 1 ? vin_b : ((q >= 0 && q < To) ? hz + 4u * (unsigned)q : kOOB);
+  const unsigned vdz_b = S == 1 ? vin_b : ((q >= 0 && q < To) ? hz + EB * (unsigned)q : kOOB);
   const int r0 = rc * RO;                                           // first dx row (S == 1) / dz row (S == 2) of the tile
   const int x0 = S == 1 ? r0 - P : 2 * r0 - P;                      // global row of x-array index 0
   const int d0 = r0 - DOFF;                                         // global row of dz-array index 0
@@ -1042,12 +1101,12 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
     const bool v0 = vin != kOOB, v1 = v0 && !in_part;
     const bool ok0 = ok0_b && mine, ok1 = ok1_b && mine;
     // dx stores: an 8-byte store when both columns exist, else a single dword for the first
-    const unsigned vo2 = (ok0 && ok1) ? hx + 4u * (unsigned)col_in : kOOB, vo1 = (ok0 && !ok1) ? hx + 4u * (unsigned)col_in : kOOB;
-    const long long x_left = 4 * ((long long)a.B * a.C - p) * ((long long)F * T);
-    const long long z_left = 4 * ((long long)a.B * a.C - p) * ((long long)Fo * To);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)p * F * T, x_left);
-    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz + (size_t)p * Fo * To, z_left);
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.g + (size_t)p * F * T, x_left);
+    const unsigned vo2 = (ok0 && ok1) ? hx + EB * (unsigned)col_in : kOOB, vo1 = (ok0 && !ok1) ? hx + EB * (unsigned)col_in : kOOB;
+    const long long x_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)F * T);
+    const long long z_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const XT*>(a.x) + (size_t)p * F * T, x_left);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(reinterpret_cast<const XT*>(a.dz) + (size_t)p * Fo * To, z_left);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(reinterpret_cast<XT*>(a.g) + (size_t)p * F * T, x_left);
     if constexpr (PPW) {
       const float* wsrc = w_ + (size_t)(mine ? p + half * a.C : p) * KK;
 #pragma unroll
@@ -1058,7 +1117,7 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
     for (int i = 0; i < FX; ++i) {
       const int rin = x0 + i;
       const bool rok = rin >= 0 && rin < F;                         // wave-uniform
-      const f32x2 pv = buf_load2(rx, rok ? vin : kOOB, rok ? 4u * (unsigned)(rin * T) : 0u);
+      const f32x2 pv = Bio<XT>::ld2(rx, rok ? vin : kOOB, rok ? EB * (unsigned)(rin * T) : 0u, in_part);
       xu[i][0] = pv[0];
       xu[i][1] = pv[1];
     }
@@ -1070,7 +1129,7 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       for (int i = 0; i < NZR; ++i) { xraw[i][0] = xu[i + P][0]; xraw[i][1] = xu[i + P][1]; }
     }
     if constexpr (BN) {
-      const __amdgpu_buffer_rsrc_t rzz = make_rsrc(a.bn.z + (size_t)p * Fo * To, z_left);
+      const __amdgpu_buffer_rsrc_t rzz = make_rsrc(reinterpret_cast<const XT*>(a.bn.z) + (size_t)p * Fo * To, z_left);
       const int pm = mine ? p + half * a.C : p;                     // this lane group's plane (per-plane SE constants)
       const float gs = a.bn.gscale ? a.bn.gscale[pm] : 1.0f, ga = a.bn.gadd ? a.bn.gadd[pm] : 0.0f;
       // validity as a 0 / 1 factor (operands are 0 outside the plane, so every term is finite): a select around dzf would
@@ -1089,16 +1148,16 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       for (int i = 0; i < FD; ++i) {
         const int rin = d0 + i;
         const bool rok = rin >= 0 && rin < Fo;                    // wave-uniform
-        const unsigned so = rok ? 4u * (unsigned)(rin * To) : 0u;
+        const unsigned so = rok ? EB * (unsigned)(rin * To) : 0u;
         if constexpr (ND == 2) {
-          const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, so);
-          const f32x2 zv = buf_load2(rzz, rok ? vdz : kOOB, so);
+          const f32x2 pv = Bio<XT>::ld2(rz, rok ? vdz : kOOB, so, in_part);
+          const f32x2 zv = Bio<XT>::ld2(rzz, rok ? vdz : kOOB, so, in_part);
           const float mr = eat::opaque(rok ? 1.0f : 0.0f);
           dd[i][0] = dzf(pv[0], zv[0], m0 * mr);
           dd[i][1] = dzf(pv[1], zv[1], m1v * mr);
         } else {
-          const float pv = buf_load(rz, rok ? vdz : kOOB, so);
-          const float zv = buf_load(rzz, rok ? vdz : kOOB, so);
+          const float pv = Bio<XT>::ld1(rz, rok ? vdz : kOOB, so);
+          const float zv = Bio<XT>::ld1(rzz, rok ? vdz : kOOB, so);
           dd[i][0] = dzf(pv, zv, m0 * eat::opaque(rok ? 1.0f : 0.0f));
         }
       }
@@ -1108,11 +1167,11 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
         const int rin = d0 + i;
         const bool rok = rin >= 0 && rin < Fo;
         if constexpr (ND == 2) {
-          const f32x2 pv = buf_load2(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+          const f32x2 pv = Bio<XT>::ld2(rz, rok ? vdz : kOOB, rok ? EB * (unsigned)(rin * To) : 0u, in_part);
           dd[i][0] = pv[0];
           dd[i][1] = in_part ? 0.0f : pv[1];
         } else {
-          dd[i][0] = buf_load(rz, rok ? vdz : kOOB, rok ? 4u * (unsigned)(rin * To) : 0u);
+          dd[i][0] = Bio<XT>::ld1(rz, rok ? vdz : kOOB, rok ? EB * (unsigned)(rin * To) : 0u);
         }
       }
     }
@@ -1197,7 +1256,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
         o1 *= act_deriv(xu[i + P][1], a.tf.act);
         const int row = r0 + i;
         const bool rowok = row < F;
-        const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
+        const unsigned so = rowok ? EB * (unsigned)(row * T) : 0u;
+        o0 = Bio<XT>::rnd(o0); o1 = Bio<XT>::rnd(o1);                 // (bf16: sum g of the values as stored)
         if constexpr (PPW) {
           psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
           pgz += ((rowok && ok0) ? o0 * xraw[i][0] : 0.0f) + ((rowok && ok1) ? o1 * xraw[i][1] : 0.0f);
@@ -1208,8 +1268,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
           buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
           buf_store(o0, rg, rowok ? vo1 : kOOB, so);
         } else {
-          buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
-          buf_store(o0, rg, rowok ? vo1 : kOOB, so);
+          Bio<XT>::st2(o0, o1, rg, rowok ? vo2 : kOOB, so);
+          Bio<XT>::st1(o0, rg, rowok ? vo1 : kOOB, so);
           psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
         }
       }
@@ -1240,11 +1300,11 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
                 sacc = fmaf(wk[u * K + v], z[i + 1 + dr][1 + dc], sacc);
               }
             }
-            o[pb] = sacc * act_deriv(xu[2 * i + pa + P][pb], a.tf.act);
+            o[pb] = Bio<XT>::rnd(sacc * act_deriv(xu[2 * i + pa + P][pb], a.tf.act));
           }
           const int row = 2 * (r0 + i) + pa;
           const bool rowok = row < F;
-          const unsigned so = rowok ? 4u * (unsigned)(row * T) : 0u;
+          const unsigned so = rowok ? EB * (unsigned)(row * T) : 0u;
           psum += ((rowok && ok0) ? o[0] : 0.0f) + ((rowok && ok1) ? o[1] : 0.0f);
           if constexpr (PPW) {
             pgz += ((rowok && ok0) ? o[0] * xraw[2 * i + pa][0] : 0.0f) + ((rowok && ok1) ? o[1] * xraw[2 * i + pa][1] : 0.0f);
@@ -1253,8 +1313,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
               o[0] += rv[0]; o[1] += rv[1];
             }
           }
-          buf_store2(o[0], o[1], rg, rowok ? vo2 : kOOB, so);
-          buf_store(o[0], rg, rowok ? vo1 : kOOB, so);
+          Bio<XT>::st2(o[0], o[1], rg, rowok ? vo2 : kOOB, so);
+          Bio<XT>::st1(o[0], rg, rowok ? vo1 : kOOB, so);
         }
       }
     }
@@ -1317,9 +1377,8 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s, bool
   const int n_cols = S == 1 ? a.T : a.To, n_rows = S == 1 ? a.F : a.Fo;
   // small planes (BN instances only): whole rows per lane group, 2 or 4 samples per wave; up to 128 columns: one plane per
   // wave without halo lanes
-  static const int wr64 = getenv("EAT_DW_BWD_WR64") ? atoi(getenv("EAT_DW_BWD_WR64")) : 1;
   const int lpp = !bn ? 64 : (a.T <= 32 ? 16 : (a.T <= 64 ? 32 : 64));
-  const bool wr = lpp < 64 || (bn && wr64 && a.T <= 128);
+  const bool wr = lpp < 64 || (bn && a.T <= 128);
   const int npw = 64 / lpp;
   a.n_cs = wr ? 1 : (n_cols + WMAX - 1) / WMAX;
   a.WO = (n_cols + a.n_cs - 1) / a.n_cs;
@@ -1340,6 +1399,15 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s, bool
     else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true, true>), grid, dim3(256), 0, s, a, w);
     return eat::check_launch("eat_dw_conv_dyn_bwd_bn_g");
   }
+  if (a.b16) {
+    using BT = eat::bf16_t;
+    if (!bn) return 1;
+    if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true, false, BT>), grid, dim3(256), 0, s, a, w);
+    else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false, false, BT>), grid, dim3(256), 0, s, a, w);
+    else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32, true, false, BT>), grid, dim3(256), 0, s, a, w);
+    else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true, false, BT>), grid, dim3(256), 0, s, a, w);
+    return eat::check_launch("eat_dw_conv_bwd_bn_g_b16");
+  }
   if (!bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false, 64, false>), grid, dim3(256), 0, s, a, w);
   else if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true>), grid, dim3(256), 0, s, a, w);
   else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false>), grid, dim3(256), 0, s, a, w);
@@ -1352,11 +1420,10 @@ template <int K, int S, int CPL, int LPP, int F>
 int launch_plane_wgrad(const PlaneWgArgs& a0, hipStream_t s) {
   PlaneWgArgs a = a0;
   constexpr int NPW = 64 / LPP;
-  static const int g_env = getenv("EAT_DWP_WG") ? atoi(getenv("EAT_DWP_WG")) : 0;
   // samples per wave: every wave should multiply several planes before its K*K-value reduction, but keep >= ~8 k waves
   int G = 1;
   if (!a.per_plane) {
-    G = g_env > 0 ? g_env : 8;
+    G = 8;
     while (G > 1 && (long long)a.C * ((a.B + NPW * G - 1) / (NPW * G)) < 8192) G >>= 1;
   }
   a.G = G;
@@ -1371,29 +1438,25 @@ namespace eat {
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B, int C,
                  int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
-                 const float* in_b, int in_act, hipStream_t s, const DwEpi* epi_) {
-  static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
-  if (off) return 1;
+                 const float* in_b, int in_act, hipStream_t s, const DwEpi* epi_, int b16) {
   const long long n_planes = (long long)B * C;
   if (n_planes > 0x3fffffffLL) return 1;                 // plane bases are 64-bit, offsets inside a plane 32-bit
   if (res && act != EAT_ACT_NONE) return 1;              // residual add: the data-gradient form only
   const DwEpi epi = epi_ ? *epi_ : DwEpi{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if ((epi.stats || epi.gz) && (res || pool || act != EAT_ACT_NONE)) return 1;   // training epilogues: plain conv only
   if (epi.gz && per_plane_w) return 1;
-  static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
-  if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {            // large planes: tiles of rows x column strips
-    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w, InTf{in_a, in_b, in_act}, epi};
+  if (T > 128 && (long long)F * T < (1 << 28)) {            // large planes: tiles of rows x column strips
+    TileArgs ta{x, res, y, pool, B, C, F, T, Fo, To, 0, 0, 0, flip, per_plane_w, InTf{in_a, in_b, in_act}, epi, b16};
     if (k == 3 && stride == 1) return launch_tile<3, 1, 16>(ta, w, bias, act, s);
     if (k == 5 && stride == 1) return launch_tile<5, 1, 16>(ta, w, bias, act, s);
     if (k == 3 && stride == 2) return launch_tile<3, 2, 8>(ta, w, bias, act, s);
     if (k == 5 && stride == 2) return launch_tile<5, 2, 8>(ta, w, bias, act, s);
   }
   if (per_plane_w && (res || pool || act != EAT_ACT_NONE)) return 1;     // per-plane taps: the plain conv (+ statistics) only
-  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}, epi, per_plane_w};
+  PlaneArgs a{x, w, bias, res, y, pool, B, C, T, To, 2, flip, act, InTf{in_a, in_b, in_act}, epi, per_plane_w, b16};
   if (k == 3 && stride == 1 && F == 8 && T > 32 && T <= 64) return launch_plane<3, 1, 1, 64, 8, true>(a, s);
-  static const int pfb = getenv("EAT_DWP_PFB") ? atoi(getenv("EAT_DWP_PFB")) : 0;
-  if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128)
-    return pfb ? launch_plane<5, 1, 2, 64, 16, true>(a, s) : launch_plane<5, 1, 2, 64, 16, false>(a, s);
+  // (no prefetch of the next plane group here: 2 x 16 rows x 2 columns of registers cost the occupancy it would buy)
+  if (k == 5 && stride == 1 && F == 16 && T > 64 && T <= 128) return launch_plane<5, 1, 2, 64, 16, false>(a, s);
   if (k == 5 && stride == 2 && F == 8 && T > 32 && T <= 64) return launch_plane<5, 2, 2, 32, 8, true>(a, s);
   if (k == 3 && stride == 2 && F == 16 && T > 64 && T <= 128) return launch_plane<3, 2, 2, 64, 16, true>(a, s);
   if (k == 5 && stride == 1 && F == 4 && T <= 32) return launch_plane<5, 1, 1, 32, 4, true>(a, s);
@@ -1403,11 +1466,8 @@ int dw_plane_try(const float* x, const float* w, const float* bias, const float*
 
 int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
                        int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s) {
-  static const int off = getenv("EAT_DWP") ? atoi(getenv("EAT_DWP")) == 0 : 0;
-  if (off) return 1;
   if ((long long)B * C > 0x3fffffffLL) return 1;
-  static const int tile_on = getenv("EAT_DWP_TILE") ? atoi(getenv("EAT_DWP_TILE")) : 1;
-  if (tile_on && T > 128 && (long long)F * T < (1 << 28)) {
+  if (T > 128 && (long long)F * T < (1 << 28)) {
     TileWgArgs ta{dz, x, dw, B, C, F, T, Fo, To, 0, 0, 0, 1, per_plane, InTf{in_a, in_b, in_act}};
     if (k == 3 && stride == 1) return launch_tile_wgrad<3, 1, 16>(ta, s);
     if (k == 3 && stride == 2) return launch_tile_wgrad<3, 2, 8>(ta, s);
@@ -1425,16 +1485,14 @@ int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C,
 
 int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
                float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
-               hipStream_t s, const DwBnBwd* bn, int per_plane_w, const float* res, float* gzpart) {
-  static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
-  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
+               hipStream_t s, const DwBnBwd* bn, int per_plane_w, const float* res, float* gzpart, int b16) {
+  if ((long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
   // Measured (MI355X, B = 256): the merged kernel wins on the LARGE planes (64x500 -> 32x250: 1.03 vs 1.47 ms, 32x250:
   // 0.35 vs 0.53 ms) and loses on the small late-layer planes, where the whole-plane kernels pack one or two planes per
   // wave with every lane busy (4x32 planes: 0.69 vs 0.35 ms; a wave of this kernel would use 18 of its 64 lanes)
-  static const int t_min = getenv("EAT_DW_BWD_TMIN") ? atoi(getenv("EAT_DW_BWD_TMIN")) : 128;
-  if (!bn && T <= t_min) return 1;                       // (with the BatchNorm backward on load the small planes gain: fewer passes)
+  if (!bn && T <= 128) return 1;                       // (with the BatchNorm backward on load the small planes gain: fewer passes)
   DwBwdArgs a{dz, x, g, dw, gpart, B, C, F, T, Fo, To, 0, 0, 0, 1, InTf{in_a, in_b, in_act},
-              DzBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0}, res, gzpart};
+              DzBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0}, res, gzpart, b16};
   const bool ppw = per_plane_w != 0;
   if (ppw && !bn) return 1;
   if (bn) a.bn = DzBn{bn->z, bn->a, bn->b, bn->mean, bn->invstd, bn->gscale, bn->gadd, bn->sums, (double)B * Fo * To, bn->act, bn->frozen};
@@ -1451,8 +1509,7 @@ int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* 
 
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi_) {
-  static const int on = getenv("EAT_DWP_DGRAD2") ? atoi(getenv("EAT_DWP_DGRAD2")) : 1;
-  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
+  if ((long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 1;
   const DwEpi epi = epi_ ? *epi_ : DwEpi{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (epi.gz && (res || per_plane_w)) return 1;
   TileDgArgs a{dz, res, dx, B, C, F, T, Fo, To, 0, 0, 0, per_plane_w, epi};

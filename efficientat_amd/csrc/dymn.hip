@@ -762,8 +762,7 @@ extern "C" int eat_dyn_bank_grad(const float* G, const float* att, const float* 
   if (K > 8) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: K=%d > 8", K);
   // LDS: the fused kernel stages 2 * B * K floats, the two-pass kernels B * K; both within 48 KB
   if ((size_t)B * K * sizeof(float) > 48 * 1024) return eat::fail(EAT_EINVAL, "eat_dyn_bank_grad: batch too large");
-  static const bool two_pass = getenv("EAT_BANK_GRAD_OLD") && atoi(getenv("EAT_BANK_GRAD_OLD")) != 0;
-  if (K == 4 && (N & 3) == 0 && !two_pass && (size_t)2 * B * K * sizeof(float) <= 48 * 1024) {            // DynamicConv's k = 4 (models/dymn/dy_block.py:68): one pass over G
+  if (K == 4 && (N & 3) == 0 && (size_t)2 * B * K * sizeof(float) <= 48 * 1024) {            // DynamicConv's k = 4 (models/dymn/dy_block.py:68): one pass over G
     const int gx = (N / 4 + 255) / 256;
     // few column tiles (N <= 64 k): slice the batch over ~512 blocks, a slice walks at least 8 samples (the atomics on
     // dbank cost more than they gain once the column tiles alone fill the chip: 301 k columns 96 vs 105 us)

@@ -103,7 +103,7 @@ int pw_stream_try(const float* x, const void* wp, const float* bias, const float
 
 int dw_plane_try(const float* x, const float* w, const float* bias, const float* res, float* y, float* pool, int B,
                  int C, int F, int T, int Fo, int To, int k, int stride, int act, int flip, int per_plane_w, const float* in_a,
-                 const float* in_b, int in_act, hipStream_t s, const DwEpi* epi = nullptr);
+                 const float* in_b, int in_act, hipStream_t s, const DwEpi* epi = nullptr, int b16 = 0);
 int dw_plane_wgrad_try(const float* dz, const float* x, float* dw, int B, int C, int F, int T, int Fo, int To, int k,
                        int stride, int per_plane, const float* in_a, const float* in_b, int in_act, hipStream_t s);
 // merged depthwise backward (dw_plane.hip): weight gradient + data gradient + activation-derivative epilogue in one pass;
@@ -117,7 +117,9 @@ struct DwBnBwd {
 int dw_bwd_try(const float* dz, const float* x, const float* in_a, const float* in_b, int in_act, const float* w, float* g,
                float* dw, float* gpart, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k, int stride,
                hipStream_t s, const DwBnBwd* bn = nullptr, int per_plane_w = 0, const float* res = nullptr,
-               float* gzpart = nullptr);
+               float* gzpart = nullptr, int b16 = 0);
+// b16 (dw_plane_try, dw_bwd_try): the wide tensors (x and y; dz, bn->z, x and g) are bf16 in HBM (act_io.h) and the pointers
+// are really bf16_t*: the statistics forward / the BatchNorm-on-load backward instances only, 1 = geometry not covered
 int dw_tile_dgrad2_try(const float* dz, const float* w, const float* res, float* dx, int B, int C, int F, int T, int Fo,
                        int To, int k, int per_plane_w, hipStream_t s, const DwEpi* epi = nullptr);
 

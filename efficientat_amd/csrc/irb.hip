@@ -456,7 +456,7 @@ int launch_irb(IrbArgs a, hipStream_t s) {
   a.MT = (a.Cexp + 15) / 16;
   a.n_strips = (a.To + VO - 1) / VO;
   // enough waves to fill the chip a few times over, but row ranges of >= 8 rows (each range re-expands K - S halo rows)
-  static const int target = getenv("EAT_IRB_ITEMS") ? atoi(getenv("EAT_IRB_ITEMS")) : 6144;
+  constexpr int target = 6144;                               // work items per launch (measured: 3072 ... 12288 within 1 %)
   const long long strips = (long long)a.B * a.n_strips;
   int parts = (int)((target + strips - 1) / strips);
   const int max_parts = a.Fo / 8 > 1 ? a.Fo / 8 : 1;
@@ -482,7 +482,7 @@ int launch_front(IrbArgs a, hipStream_t s) {
   constexpr int VO = 16 * NT - 2;
   a.MT = 1;
   a.n_strips = (a.To + VO - 1) / VO;
-  static const int target = getenv("EAT_IRB_ITEMS") ? atoi(getenv("EAT_IRB_ITEMS")) : 6144;
+  constexpr int target = 6144;
   const long long strips = (long long)a.B * a.n_strips;
   int parts = (int)((target + strips - 1) / strips);
   const int max_parts = a.Fo / 8 > 1 ? a.Fo / 8 : 1;

@@ -11,6 +11,7 @@
 // m-tile i are issued.
 #pragma once
 #include "eat_common.h"
+#include "act_io.h"
 
 namespace eat {
 
@@ -44,9 +45,10 @@ __device__ __forceinline__ void pw_stage_bias(const float* __restrict__ bias, fl
 
 // Lane layout (both kernels): lane owns rows m = (mt0+i)*16 + kq*4 + r (i < MTW, r < 4) and the 4
 // consecutive columns starting at position sc_ of sample bc; acc[i][j][r] is column j of row r.
-template <int MTW, bool LINEAR>
+// YT: storage type of y (act_io.h); the pooled variant and the residual are fp32-only (host checks)
+template <int MTW, bool LINEAR, typename YT = float>
 __device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], const float* s_bias,
-                                                const float* __restrict__ res, float* __restrict__ y,
+                                                const float* __restrict__ res, YT* __restrict__ y,
                                                 float* __restrict__ pool, int mt0, int kq, int lane, bool col_ok,
                                                 int bc, int sc_, int Co, int S, const ActCoef ac) {
   const size_t plane = (size_t)S;
@@ -62,16 +64,16 @@ __device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], 
   auto row_of = [&](int i, int r) { return (mt0 + i) * 16 + kq * 4 + r; };
   auto store_tile = [&](int i, const float4 (&v)[4]) {
     const bool full = (mt0 + i + 1) * 16 <= Co;                      // wave-uniform
-    float* yr = y + base + (size_t)row_of(i, 0) * plane;
+    YT* yr = y + base + (size_t)row_of(i, 0) * plane;
     if (full) {
       if (col_ok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(yr + (size_t)r * plane) = v[r];
+        for (int r = 0; r < 4; ++r) Io<YT>::store4(yr + (size_t)r * plane, v[r]);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (col_ok && row_of(i, r) < Co) *reinterpret_cast<float4*>(yr + (size_t)r * plane) = v[r];
+        if (col_ok && row_of(i, r) < Co) Io<YT>::store4(yr + (size_t)r * plane, v[r]);
     }
   };
 
@@ -135,7 +137,7 @@ __device__ __forceinline__ void pw_epilogue_act(const acc_f32x4 (&acc)[MTW][4], 
           const float4 q = *reinterpret_cast<const float4*>(res + off);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
-        if (y) *reinterpret_cast<float4*>(y + off) = v;
+        if (y) Io<YT>::store4(y + off, v);
       }
       float ps = v.x + v.y + v.z + v.w;
       if (group_one_sample) {
@@ -197,16 +199,16 @@ __device__ __forceinline__ void pw_epilogue_stats(const acc_f32x4 (&acc)[MTW][4]
 // `act` is wave-uniform: the project layers (no activation) take a branch without any activation math,
 // ReLU / Hardswish share the branch-free 4-op form (a third specialisation pushed the 7-8 m-tile kernels
 // over 256 VGPRs).
-template <int MTW>
+template <int MTW, typename YT = float>
 __device__ __forceinline__ void pw_epilogue(const acc_f32x4 (&acc)[MTW][4], const float* s_bias,
-                                            const float* __restrict__ res, float* __restrict__ y,
+                                            const float* __restrict__ res, YT* __restrict__ y,
                                             float* __restrict__ pool, int mt0, int kq, int lane, bool col_ok, int bc,
                                             int sc_, int Co, int S, int act) {
   const ActCoef ac = act_coef(act);
   if (act == EAT_ACT_NONE)
-    pw_epilogue_act<MTW, true>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, ac);
+    pw_epilogue_act<MTW, true, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, ac);
   else
-    pw_epilogue_act<MTW, false>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, ac);
+    pw_epilogue_act<MTW, false, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, ac);
 }
 
 }  // namespace eat

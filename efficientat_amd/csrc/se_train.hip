@@ -134,9 +134,83 @@ __global__ __launch_bounds__(256) void se_bwd_stage2_kernel(const float* __restr
   col_sum_tile(B, Cr, id * 32, [&](int b, int r) { return dh[(size_t)b * Cr + r]; }, db1);
 }
 
+// ---- the classifier head's backward on the same two-stage scheme (models/mn/model.py:186-194: Linear(C -> H), Hardswish,
+// Dropout, Linear(H -> N)); round 5: replaces four rocBLAS GEMMs + five torch ops of the timed step.
+//   stage 1: dW2 = dlogits^T h2 (N x H), db2 = sum_b dlogits, du = (dlogits W2) * mask * hardswish'(u)   (B x H)
+//   stage 2: dW1 = du^T feat (H x C),   db1 = sum_b du,      dfeat = du W1                              (B x C)
+__global__ __launch_bounds__(256) void head_bwd_stage1_kernel(const float* __restrict__ dl, const float* __restrict__ h2,
+                                                              const float* __restrict__ u, const float* __restrict__ mask,
+                                                              const float* __restrict__ W2, float* __restrict__ dW2,
+                                                              float* __restrict__ db2, float* __restrict__ du, int B, int H,
+                                                              int N) {
+  const int tA_n = cdiv(H, 32), nA = cdiv(N, 32) * tA_n;
+  const int tB_n = cdiv(H, 32), nB = cdiv(B, 32) * tB_n;
+  int id = blockIdx.x;
+  if (id < nA) {                      // dW2 (N x H): A(m = n, k = b) = dl[b, n], B(k = b, n = r) = h2[b, r]
+    gemm_tile<true>(N, H, B, (id / tA_n) * 32, (id % tA_n) * 32, [&](int m, int k) { return dl[(size_t)k * N + m]; },
+                    [&](int k, int n) { return h2[(size_t)k * H + n]; },
+                    [&](int m, int n, float v) { dW2[(size_t)m * H + n] = v; });
+    return;
+  }
+  id -= nA;
+  if (id < nB) {                      // du (B x H): A(m = b, k = n) = dl[b, n], B(k = n, n = r) = W2[n, r]
+    gemm_tile<false>(B, H, N, (id / tB_n) * 32, (id % tB_n) * 32, [&](int m, int k) { return dl[(size_t)m * N + k]; },
+                     [&](int k, int n) { return W2[(size_t)k * H + n]; },
+                     [&](int m, int n, float v) {
+                       const float uv = u[(size_t)m * H + n];
+                       // nn.Hardswish backward (PyTorch): 0 below -3, x / 3 + 1 / 2 inside [-3, 3], 1 above
+                       const float d = uv < -3.0f ? 0.0f : (uv <= 3.0f ? uv * (1.0f / 3.0f) + 0.5f : 1.0f);
+                       du[(size_t)m * H + n] = v * (mask ? mask[(size_t)m * H + n] : 1.0f) * d;
+                     });
+    return;
+  }
+  id -= nB;
+  col_sum_tile(B, N, id * 32, [&](int b, int n) { return dl[(size_t)b * N + n]; }, db2);
+}
+
+__global__ __launch_bounds__(256) void head_bwd_stage2_kernel(const float* __restrict__ du, const float* __restrict__ feat,
+                                                              const float* __restrict__ W1, float* __restrict__ dW1,
+                                                              float* __restrict__ db1, float* __restrict__ dfeat, int B,
+                                                              int C, int H) {
+  const int tC_n = cdiv(C, 32), nC = cdiv(H, 32) * tC_n;
+  const int tD_n = cdiv(C, 32), nD = cdiv(B, 32) * tD_n;
+  int id = blockIdx.x;
+  if (id < nC) {                      // dW1 (H x C): A(m = r, k = b) = du[b, r], B(k = b, n = c) = feat[b, c]
+    gemm_tile<true>(H, C, B, (id / tC_n) * 32, (id % tC_n) * 32, [&](int m, int k) { return du[(size_t)k * H + m]; },
+                    [&](int k, int n) { return feat[(size_t)k * C + n]; },
+                    [&](int m, int n, float v) { dW1[(size_t)m * C + n] = v; });
+    return;
+  }
+  id -= nC;
+  if (id < nD) {                      // dfeat (B x C): A(m = b, k = r) = du[b, r], B(k = r, n = c) = W1[r, c]
+    gemm_tile<false>(B, C, H, (id / tD_n) * 32, (id % tD_n) * 32, [&](int m, int k) { return du[(size_t)m * H + k]; },
+                     [&](int k, int n) { return W1[(size_t)k * C + n]; },
+                     [&](int m, int n, float v) { dfeat[(size_t)m * C + n] = v; });
+    return;
+  }
+  id -= nD;
+  col_sum_tile(B, H, id * 32, [&](int b, int r) { return du[(size_t)b * H + r]; }, db1);
+}
+
 }  // namespace
 
 static int cdiv_host(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int eat_mlp_head_bwd(const float* dlogits, const float* h2, const float* u, const float* drop_mask,
+                                const float* feat, const float* W1, const float* W2, float* dW1, float* db1, float* dW2,
+                                float* db2, float* du, float* dfeat, int B, int C, int H, int N, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dlogits || !h2 || !u || !feat || !W1 || !W2 || !dW1 || !db1 || !dW2 || !db2 || !du || !dfeat)
+    return eat::fail(EAT_EINVAL, "eat_mlp_head_bwd: missing operand");
+  if (B < 1 || C < 1 || H < 1 || N < 1) return eat::fail(EAT_EINVAL, "eat_mlp_head_bwd: bad shape");
+  const int n1 = cdiv_host(N, 32) * cdiv_host(H, 32) + cdiv_host(B, 32) * cdiv_host(H, 32) + cdiv_host(N, 32);
+  const int n2 = cdiv_host(H, 32) * cdiv_host(C, 32) + cdiv_host(B, 32) * cdiv_host(C, 32) + cdiv_host(H, 32);
+  hipLaunchKernelGGL(head_bwd_stage1_kernel, dim3((unsigned)n1), dim3(256), 0, (hipStream_t)stream, dlogits, h2, u, drop_mask,
+                     W2, dW2, db2, du, B, H, N);
+  hipLaunchKernelGGL(head_bwd_stage2_kernel, dim3((unsigned)n2), dim3(256), 0, (hipStream_t)stream, du, feat, W1, dW1, db1,
+                     dfeat, B, C, H);
+  return eat::check_launch("eat_mlp_head_bwd");
+}
 
 extern "C" int eat_se_mlp_bwd(const float* ds, const float* scale, const float* h, const float* pool, const float* W1,
                               const float* W2, float inv_s, float* dW1, float* db1, float* dW2, float* db2, float* dh,

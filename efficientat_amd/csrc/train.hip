@@ -9,9 +9,11 @@
 // accumulated in fp64 atomics so that sums over up to 8M elements do not lose precision).
 #include <cstdlib>
 #include "eat_common.h"
+#include "act_io.h"
 
 namespace {
 
+using eat::Io;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // Optional transform of the x operand of the 1x1 weight gradient: x' = act(a[ci] * x + b[ci]) evaluated on load (training:
@@ -128,10 +130,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
 }
 
 // ---- y = act(a_c z + b_c) [+ res]; optional per-(b,c) sums of y (SE squeeze / head pool) ----------
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
+// ZT: storage type of z and y (act_io.h; bf16 in the bf16-storage plan: the pool sums the values as STORED)
+template <int ACT, typename ZT = float>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const ZT* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
-                                                         float* __restrict__ y, float* __restrict__ pool, int C, int S) {
+                                                         ZT* __restrict__ y, float* __restrict__ pool, int C, int S) {
   __shared__ float s_red[16];
   const int plane = blockIdx.x, c = plane % C;
   const float av = a[c], bv = b[c];
@@ -140,21 +143,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   if ((S & 3) == 0) {
 #pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
-      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      const float4 v = Io<ZT>::load4(z + base + i);
       float4 o = make_float4(eat::activate<ACT>(fmaf(av, v.x, bv)), eat::activate<ACT>(fmaf(av, v.y, bv)),
                              eat::activate<ACT>(fmaf(av, v.z, bv)), eat::activate<ACT>(fmaf(av, v.w, bv)));
       if (res) {
         const float4 r = *reinterpret_cast<const float4*>(res + base + i);
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      if (y) *reinterpret_cast<float4*>(y + base + i) = o;
+      if constexpr (Io<ZT>::kBf) { o.x = eat::bf_round(o.x); o.y = eat::bf_round(o.y); o.z = eat::bf_round(o.z); o.w = eat::bf_round(o.w); }
+      if (y) Io<ZT>::store4(y + base + i, o);
       ps += (o.x + o.y) + (o.z + o.w);
     }
   } else {
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-      float o = eat::activate<ACT>(fmaf(av, z[base + i], bv));
-      if (res) o += res[base + i];
-      if (y) y[base + i] = o;
+      float o = Io<ZT>::rnd(eat::activate<ACT>(fmaf(av, Io<ZT>::load1(z + base + i), bv)) + (res ? res[base + i] : 0.0f));
+      if (y) Io<ZT>::store1(y + base + i, o);
       ps += o;
     }
   }
@@ -171,9 +174,9 @@ __device__ __forceinline__ float grad_pre(float dy, float zv, float av, float bv
 }
 
 // ---- backward pass 1: per-channel sum g and sum g*xhat -------------------------------------------------
-template <int ACT>
+template <int ACT, typename ZT = float>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
-    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ a,
+    const ZT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, int C, int S, double* __restrict__ sums) {
   __shared__ float s_red[16];
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   if ((S & 3) == 0) {
 #pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
-      const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
-      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      const float4 d = Io<ZT>::load4(dy + base + i);
+      const float4 v = Io<ZT>::load4(z + base + i);
       const float g0 = grad_pre<ACT>(d.x, v.x, av, bv, gs, ga), g1 = grad_pre<ACT>(d.y, v.y, av, bv, gs, ga);
       const float g2 = grad_pre<ACT>(d.z, v.z, av, bv, gs, ga), g3 = grad_pre<ACT>(d.w, v.w, av, bv, gs, ga);
       s1 += (g0 + g1) + (g2 + g3);
@@ -194,9 +197,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     }
   } else {
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-      const float g = grad_pre<ACT>(dy[base + i], z[base + i], av, bv, gs, ga);
+      const float zv = Io<ZT>::load1(z + base + i);
+      const float g = grad_pre<ACT>(Io<ZT>::load1(dy + base + i), zv, av, bv, gs, ga);
       s1 += g;
-      s2 += g * (z[base + i] - mu);
+      s2 += g * (zv - mu);
     }
   }
   s2 *= is;
@@ -208,9 +212,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 }
 
 // small planes: one block per (channel, PPB samples), see bn_stats_multi_kernel
-template <int ACT>
+template <int ACT, typename ZT = float>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
-    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ a,
+    const ZT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, int B, int C, int S4, int PPB,
     double* __restrict__ sums) {
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
     const int bl = e / S4, i = e - bl * S4;
     const size_t plane = (size_t)(b0 + bl) * C + c;
     const float gs = gscale ? gscale[plane] : 1.0f, ga = gadd ? gadd[plane] : 0.0f;
-    const float4 d = *reinterpret_cast<const float4*>(dy + plane * (4 * S4) + 4 * i);
-    const float4 v = *reinterpret_cast<const float4*>(z + plane * (4 * S4) + 4 * i);
+    const float4 d = Io<ZT>::load4(dy + plane * (4 * S4) + 4 * i);
+    const float4 v = Io<ZT>::load4(z + plane * (4 * S4) + 4 * i);
     const float g0 = grad_pre<ACT>(d.x, v.x, av, bv, gs, ga), g1 = grad_pre<ACT>(d.y, v.y, av, bv, gs, ga);
     const float g2 = grad_pre<ACT>(d.z, v.z, av, bv, gs, ga), g3 = grad_pre<ACT>(d.w, v.w, av, bv, gs, ga);
     s1 += (g0 + g1) + (g2 + g3);
@@ -918,12 +922,22 @@ template <int V> struct WideInt { static constexpr int value = V; };
 // (an instantiation with the x operand read through act(a v + b) - the project conv's on-load input - made the producers the
 //  pole: 40 x 120 at 2000 positions 152 us against 128 for the 128 x 128-tile kernel; those launches keep that kernel)
 // RADD: an additive constant per x row (radd), applied to loaded elements only - the centred Gram matrix (same = 1)
-template <int NPROD, bool SWAP, bool SCALE, bool RADD>
+// P16: the P operand is bf16 in HBM (act_io.h; the bf16-storage plan: P = the wide tensor - the project conv's input y_d / z_d
+// when SWAP, the expand conv's gradient g otherwise - and Q the narrow fp32 one).  A producer then moves 8 bytes per lane and
+// piece and its fragments need NO conversion; PTF (with SWAP, P16): the x rows are act(tf_a[ci] v + tf_b[ci]) evaluated on
+// load (the on-load BatchNorm of the project conv's input), times the SE scale - unpack, 4 VALU, one v_cvt_pk per pair, which
+// the fp32 instantiation could not afford next to its hi / lo split.  Host: P16 only with NPROD = 1.
+template <int NPROD, bool SWAP, bool SCALE, bool RADD, bool P16 = false, bool PTF = false>
 __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                             const float* __restrict__ xscale, float* __restrict__ dW, int B,
                                                             int Co, int Ci, int S, int sps, int units_per_block,
-                                                            int p_tile_rows, int q_tile_rows, int dbg,
-                                                            const float* __restrict__ radd, int same) {
+                                                            int p_tile_rows, int q_tile_rows,
+                                                            const float* __restrict__ radd, int same,
+                                                            const float* __restrict__ tf_a = nullptr,
+                                                            const float* __restrict__ tf_b = nullptr, int tf_act = 0) {
+  static_assert(!P16 || NPROD == 1, "bf16-stored operand: plain bf16 products");
+  static_assert(!PTF || (P16 && SWAP), "on-load transform: the bf16-stored x operand");
+  constexpr unsigned PB = P16 ? 2u : 4u;                              // bytes per element of P
   extern __shared__ __attribute__((aligned(16))) float w_smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const float* __restrict__ P = SWAP ? x : dz;
@@ -961,6 +975,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
     unsigned roff[WIDE_NP];
     int xrow[SCALE ? XN : 1];
     float ra[RADD ? XN : 1];
+    float tfa[PTF ? XN : 1], tfb[PTF ? XN : 1];
 #pragma unroll
     for (int t = 0; t < WIDE_NP; ++t) {
       const bool isp = t < WIDE_TP;
@@ -968,12 +983,18 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
       const int mr = g * 8 + lrow, nv = isp ? pv : qv;
       const int row = (isp ? p0 : q0) + (mr > nv - 1 ? nv - 1 : mr);
       const bool valid = g < (isp ? GP : GQ);
-      roff[t] = valid ? 4u * ((unsigned)row * (unsigned)S + 4u * (unsigned)chunk) : 4u * (unsigned)(isp ? p0 : q0) * (unsigned)S;
+      const unsigned eb = isp ? PB : 4u;
+      roff[t] = valid ? eb * ((unsigned)row * (unsigned)S + 4u * (unsigned)chunk) : eb * (unsigned)(isp ? p0 : q0) * (unsigned)S;
       if (t >= XS0 && t < XS0 + XN) {
         const int xr = row < Ci ? row : Ci - 1;
         if constexpr (SCALE) xrow[t - XS0] = xr;
         if constexpr (RADD) ra[t - XS0] = radd[xr];
+        if constexpr (PTF) { tfa[t - XS0] = tf_a[xr]; tfb[t - XS0] = tf_b[xr]; }
       }
+    }
+    if constexpr (PTF) {
+#pragma unroll
+      for (int t = 0; t < XN; ++t) asm volatile("" ::"v"(tfa[t]), "v"(tfb[t]));
     }
     // (the loads above must be back - and known to the compiler to be back - before the loop: a wait it placed at their first
     //  use inside the loop would be a vmcnt(0) per step; the empty asm statements read the registers)
@@ -983,19 +1004,25 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
     }
     const bool tail = (S & 31) != 0;
     float4 buf[WIDE_RD][WIDE_NP];
+    u32x2_t pbuf[WIDE_RD][P16 ? WIDE_TP : 1];                        // P16: the P slots hold 4 bf16 (not members of a float4:
+                                                                      // hipcc folded `.y` of a partly written float4 into `.x`)
     float xs[SCALE ? XN : 1], xs_next[SCALE ? XN : 1];
     auto load_unit = [&](auto ktag, int bb, int stt) {
       constexpr int K = decltype(ktag)::value;
-      const char* pb = reinterpret_cast<const char*>(P + ((size_t)bb * PR * S + (size_t)stt * 32));
+      const char* pb = reinterpret_cast<const char*>(P) + ((size_t)bb * PR * S + (size_t)stt * 32) * PB;
       const char* qb = reinterpret_cast<const char*>(Q + ((size_t)bb * QR * S + (size_t)stt * 32));
       // the sample's last unit: chunks past S fetch a valid dummy (zeroed by the converter)
       const int lim = S - 4 - stt * 32;                               // largest valid k offset inside this unit
-      const unsigned back = (tail && stt == sps - 1 && 4 * chunk > lim) ? 4u * (unsigned)(4 * chunk - lim) : 0u;
+      const unsigned back_e = (tail && stt == sps - 1 && 4 * chunk > lim) ? (unsigned)(4 * chunk - lim) : 0u;   // elements
 #pragma unroll
       for (int t = 0; t < WIDE_NP; ++t) {
         const bool isp = t < WIDE_TP;
         const bool valid = wq + 4 * (isp ? t : t - WIDE_TP) < (isp ? GP : GQ);
-        buf[K][t] = *reinterpret_cast<const float4*>((isp ? pb : qb) + (valid ? roff[t] - back : roff[t]));
+        if (isp && P16) {                                             // (compile-time per slot) 4 bf16 = 8 bytes
+          pbuf[K][t < WIDE_TP ? t : 0] = *reinterpret_cast<const u32x2_t*>(pb + (valid ? roff[t] - PB * back_e : roff[t]));
+        } else {
+          buf[K][t] = *reinterpret_cast<const float4*>((isp ? pb : qb) + (valid ? roff[t] - (isp ? PB : 4u) * back_e : roff[t]));
+        }
       }
     };
     auto load_scale = [&](int bb) {                                   // SE scale of the conv input, per (sample, input channel)
@@ -1015,7 +1042,28 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
         const int g = wq + 4 * (isp ? t : t - WIDE_TP);
         if (g < (isp ? GP : GQ)) {
           const int gi = isp ? g : GP + g;                            // piece of the LDS slot
-          float4 w = buf[K][t];
+          float4 w = (isp && P16) ? float4{0.f, 0.f, 0.f, 0.f} : buf[K][t];
+          const int blk = (chunk >> 1) ^ (((gi & 1) << 1) | (lrow >> 2));   // 32-byte block of the row: (c >> 1) ^ ((row >> 2) & 3)
+          const int rowf = sb + gi * 256 + lrow * 32 + 8 * blk + 2 * (chunk & 1);
+          if (isp && P16) {                                            // (compile-time per slot) finished bf16 pairs
+            unsigned w01 = pbuf[K][t < WIDE_TP ? t : 0][0], w23 = pbuf[K][t < WIDE_TP ? t : 0][1];
+            if constexpr (SWAP && (SCALE || PTF)) {                    // P = the x rows: transform / SE scale on load
+              float v0 = eat::bf_lo(w01), v1 = eat::bf_hi(w01), v2 = eat::bf_lo(w23), v3 = eat::bf_hi(w23);
+              if constexpr (PTF) {
+                const float fa = tfa[t < XN ? t : 0], fb = tfb[t < XN ? t : 0];
+                v0 = wg_tf(v0, fa, fb, tf_act); v1 = wg_tf(v1, fa, fb, tf_act);
+                v2 = wg_tf(v2, fa, fb, tf_act); v3 = wg_tf(v3, fa, fb, tf_act);
+              }
+              if constexpr (SCALE) {
+                const float sc = xs[t < XN ? t : 0];
+                v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc;
+              }
+              w01 = eat::pack_bf2(v0, v1); w23 = eat::pack_bf2(v2, v3);
+            }
+            if (kz) { w01 = 0u; w23 = 0u; }
+            *reinterpret_cast<u32x2_t*>(&w_smem[rowf + 4 * hb]) = u32x2_t{w01, w23};
+            continue;
+          }
           if constexpr (SCALE) {
             if (t >= XS0 && t < XS0 + XN) {
               const float sc = xs[t - XS0 < 0 ? 0 : t - XS0];
@@ -1031,8 +1079,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
           if (kz) w = float4{0.f, 0.f, 0.f, 0.f};
           const bf16x2_t h01 = __builtin_convertvector(f32x2_t{w.x, w.y}, bf16x2_t);
           const bf16x2_t h23 = __builtin_convertvector(f32x2_t{w.z, w.w}, bf16x2_t);
-          const int blk = (chunk >> 1) ^ (((gi & 1) << 1) | (lrow >> 2));   // 32-byte block of the row: (c >> 1) ^ ((row >> 2) & 3)
-          const int rowf = sb + gi * 256 + lrow * 32 + 8 * blk + 2 * (chunk & 1);
           *reinterpret_cast<u32x2_t*>(&w_smem[rowf + 4 * hb]) = u32x2_t{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
           if constexpr (NPROD == 3) {
             const bf16x2_t l01 = __builtin_convertvector(f32x2_t{w.x - (float)h01[0], w.y - (float)h01[1]}, bf16x2_t);
@@ -1105,7 +1151,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
   const int p_off = pm0 * 512, q_off = same ? 0 : GP * 256;
   for (int u = u0; u < u1; ++u) {
     __syncthreads();                                                  // unit u is in LDS slot (u - u0) & 1
-    if (pm_n > 0 && !(dbg & 2)) {
+    if (pm_n > 0) {
       const int sb = ((u - u0) & 1) * slot_f;
       // all WIDE_PT fragments of P, whatever pm_n is: a wave with 3 tiles multiplies a 4th (the next wave's rows, or Q rows,
       // or zeros past the end of LDS) into accumulators that are never written - it would wait at the barrier for the waves
@@ -1167,7 +1213,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
       // rows / columns past the matrix hold products of the clamped duplicate rows and are not written (Ci % 4 == 0)
       const int m = SWAP ? q0 + qr0 + r : p0 + pr0 + r;
       const int n = (SWAP ? p0 + pr0 : q0 + qr0) + kg * 4;
-      if ((dbg & 1) && acc[i][j][0] != 12345.678f) continue;
       if (m < Co && n < Ci) *reinterpret_cast<f32x4*>(out + (size_t)m * Ci + n) = acc[i][j];
     }
 }
@@ -1444,6 +1489,40 @@ extern "C" int eat_bn_act_bwd_reduce(const float* dy, const float* z, const floa
   return eat::check_launch("eat_bn_act_bwd_reduce");
 }
 
+// ---- the two stand-alone BatchNorm passes of the bf16-storage plan (act_io.h; BASELINE configs[2]): the depthwise output
+// z_d and the gradient arriving at it are bf16 in HBM.  Same arithmetic as the fp32 entry points; y (or NULL) is written in
+// bf16 and `pool` sums the ROUNDED values - what the project conv will read.  (S % 4 != 0: element-wise path.)
+extern "C" int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, void* y, float* pool, int B, int C, int S,
+                                  int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: bad act %d", act);
+  if (!z || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: bad shape");
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0, (hipStream_t)stream,
+                                           reinterpret_cast<const eat::bf16_t*>(z), a, b, (const float*)nullptr,
+                                           reinterpret_cast<eat::bf16_t*>(y), pool, C, S));
+  return eat::check_launch("eat_bn_act_fwd_b16");
+}
+
+extern "C" int eat_bn_act_bwd_reduce_b16(const void* dy, const void* z, const float* a, const float* b, const float* mean,
+                                         const float* invstd, const float* gscale, const float* gadd, int B, int C, int S,
+                                         int act, double* sums, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_reduce_b16: bad act %d", act);
+  if (!dy || !z || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_reduce_b16: bad shape");
+  const eat::bf16_t* d16 = reinterpret_cast<const eat::bf16_t*>(dy);
+  const eat::bf16_t* z16 = reinterpret_cast<const eat::bf16_t*>(z);
+  if (const int ppb = bn_multi_ppb(B, C, S)) {
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_multi_kernel<ACT, eat::bf16_t>), dim3(C, (B + ppb - 1) / ppb), dim3(256), 0,
+                                             (hipStream_t)stream, d16, z16, a, b, mean, invstd, gscale, gadd, B, C, S >> 2, ppb, sums));
+    return eat::check_launch("eat_bn_act_bwd_reduce_b16");
+  }
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0,
+                                           (hipStream_t)stream, d16, z16, a, b, mean, invstd, gscale, gadd, C, S, sums));
+  return eat::check_launch("eat_bn_act_bwd_reduce_b16");
+}
+
 extern "C" int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const float* b,
                                     const float* mean, const float* invstd, const float* gscale, const float* gadd,
                                     const double* sums, float* dz, int B, int C, int S, int act, eat_stream_t stream) {
@@ -1512,8 +1591,7 @@ extern "C" int eat_dw_conv_dgrad_g(const float* dz, const float* w, const float*
   if (inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 1))
     return eat::fail(EAT_EINVAL, "eat_dw_conv_dgrad_g: partial buffer too small (inner_cap %d)", inner_cap);
   hipStream_t s = (hipStream_t)stream;
-  static const bool fused = !(getenv("EAT_DW_GEPI_FUSED") && atoi(getenv("EAT_DW_GEPI_FUSED")) == 0);
-  if (fused && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+  if ((k == 3 || k == 5) && (stride == 1 || stride == 2)) {
     int inner = 1;
     const eat::DwEpi epi{nullptr, gz, ga, gb, gact, gpart, &inner};
     const int rc = stride == 1 ? eat::dw_conv_dgrad_s1(dz, w, nullptr, nullptr, g, B, C, F, T, k, 0, s, &epi)
@@ -1536,15 +1614,14 @@ static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int 
                          int k, int stride, int per_sample, eat_stream_t stream, const float* in_a = nullptr,
                          const float* in_b = nullptr, int in_act = 0) {
   if (XC != C && XC != 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad: x must have C or 1 channels");
-  static const bool old_kernel = getenv("EAT_DW_WGRAD_OLD") && atoi(getenv("EAT_DW_WGRAD_OLD")) != 0;
-  if (in_a && (XC != C || old_kernel)) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: needs the column-walking kernel");
-  if (XC == C && !old_kernel) {
+  if (in_a && XC != C) return eat::fail(EAT_EINVAL, "eat_dw_conv_wgrad_tf: needs the column-walking kernel");
+  if (XC == C) {
     // register-resident kernels (dw_plane.hip): every element loaded once; 1 = geometry not instantiated
     const int rc = eat::dw_plane_wgrad_try(dz, x, dw, B, C, F, T, Fo, To, k, stride, per_sample, in_a, in_b, in_act,
                                            (hipStream_t)stream);
     if (rc != 1) return rc;
   }
-  if (XC == C && !old_kernel && !per_sample && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+  if (XC == C && !per_sample && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
     // column-walking kernel: block = (column tile, channel, batch slice)
     const int TX = To > 32 ? 64 : 32, TY = 256 / TX;
     const int ct = (To + TX - 1) / TX;
@@ -1566,8 +1643,7 @@ static int dw_wgrad_impl(const float* dz, const float* x, float* dw, int B, int 
 #undef EAT_WGC
     return eat::check_launch("eat_dw_conv_wgrad");
   }
-  static const bool stem_new = !(getenv("EAT_STEM_WGRAD_OLD") && atoi(getenv("EAT_STEM_WGRAD_OLD")) != 0);
-  if (XC == 1 && k == 3 && stride == 2 && !per_sample && stem_new) {
+  if (XC == 1 && k == 3 && stride == 2 && !per_sample) {
     // ~2048 blocks: (row chunks) x (samples)
     int rpb = (int)(((long long)Fo * B + 2047) / 2048);
     if (rpb < 1) rpb = 1;
@@ -1637,8 +1713,7 @@ extern "C" int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* i
 // gpart may be NULL.  Only the geometries of the merged kernel:
 // eat_dw_bwd_merged_ok(...) != 0, else EAT_EINVAL.
 static int dw_bwd_bn_geometry_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
-  static const int on = getenv("EAT_DW_BWD_MERGED") ? atoi(getenv("EAT_DW_BWD_MERGED")) : 1;
-  if (!on || (long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 0;
+  if ((long long)B * C > 0x3fffffffLL || (long long)F * T >= (1 << 28)) return 0;
   if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return 0;
   if (stride == 1 && (Fo != F || To != T)) return 0;
   if ((long long)4 * C * F * T * 4 >= 0x7fffffffLL) return 0;         // lane-group offsets inside a wave's samples are 32-bit
@@ -1648,14 +1723,6 @@ static int dw_bwd_bn_geometry_ok(int B, int C, int F, int T, int Fo, int To, int
 // Host helper: 1 where eat_dw_conv_bwd_bn_g runs AND is the faster plan (EAT_DW_BN_K5=0: 5x5 convs keep the apply pass +
 // eat_dw_conv_bwd_g - their on-load instances sit at 240 registers and gain 4 % only).
 extern "C" int eat_dw_bwd_merged_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride) {
-  static const int k5 = getenv("EAT_DW_BN_K5") ? atoi(getenv("EAT_DW_BN_K5")) : 1;
-  if (k == 5 && !k5) return 0;
-  static const int t_min = getenv("EAT_DW_BN_TMIN") ? atoi(getenv("EAT_DW_BN_TMIN")) : 0;      // A/B: large planes only
-  if (T <= t_min) return 0;
-  // (A/B switch: EAT_DW_BN_K5S1=0 keeps the 5x5 / stride-1 layers of <= 128 columns on the apply pass + the two plane
-  //  kernels - they lost there until the whole-row mode: 16 x 125 planes 446 -> 268 us against 137 + 269)
-  static const int k5s1 = getenv("EAT_DW_BN_K5S1") ? atoi(getenv("EAT_DW_BN_K5S1")) : 1;
-  if (k == 5 && stride == 1 && T <= 128 && !k5s1) return 0;
   return dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride);
 }
 
@@ -1677,6 +1744,31 @@ extern "C" int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float
   const int rc = eat::dw_bwd_try(dy, x, in_a, in_b, in_act, w, g, dw, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
                                  (hipStream_t)stream, &bn);
   if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g: merged kernel unavailable");
+  return rc;
+}
+
+// The same over bf16-stored dy, z, x and g (act_io.h; the bf16-storage plan of BASELINE configs[2]): every wide tensor the
+// backward of a block touches is 16-bit in HBM; coefficients, channel sums, taps, dw and the partial sums (taken of the g
+// values as stored) are fp32 / fp64 as above.
+extern "C" int eat_dw_conv_bwd_bn_g_b16(const void* dy, const void* z, const float* bn_a, const float* bn_b,
+                                        const float* bn_mean, const float* bn_invstd, const float* gscale, const float* gadd,
+                                        const double* sums, int bn_act, int frozen, const void* x, const float* in_a,
+                                        const float* in_b, int in_act, const float* w, void* g, float* dw, float* gpart,
+                                        int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
+                                        int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dy || !z || !bn_a || !bn_b || !bn_mean || !bn_invstd || !sums || !x || !in_a || !in_b || !w || !g || !dw)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g_b16: missing operand");
+  if (in_act < 0 || in_act > 2 || bn_act < 0 || bn_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g_b16: bad act");
+  if (!dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride) || (F * T) % 2 != 0 || (Fo * To) % 2 != 0)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g_b16: geometry not covered by the merged kernel (F=%d T=%d k=%d stride=%d)", F, T, k, stride);
+  if (gpart && inner_cap < eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g_b16: partial buffer too small (inner_cap %d)", inner_cap);
+  const eat::DwBnBwd bn{reinterpret_cast<const float*>(z), bn_a, bn_b, bn_mean, bn_invstd, gscale, gadd, sums, bn_act, frozen};
+  const int rc = eat::dw_bwd_try(reinterpret_cast<const float*>(dy), reinterpret_cast<const float*>(x), in_a, in_b, in_act, w,
+                                 reinterpret_cast<float*>(g), dw, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
+                                 (hipStream_t)stream, &bn, 0, nullptr, nullptr, 1);
+  if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g_b16: merged kernel unavailable");
   return rc;
 }
 
@@ -1728,15 +1820,14 @@ static bool thin_pair(int m, int n) { return m >= 1 && m <= 4 && n >= 1 && n <= 
 // tiles of fewer than ~20 pieces (160 rows of P + Q), and the on-load transform makes the producers the pole.
 struct WideShape { bool ok; bool swap; int ptr, qtr, ptn, qtn; };
 static WideShape wide_shape(int Co, int Ci, bool per_sample, bool same, bool no_wide, bool has_xscale, bool has_tf) {
-  static const int wide_on = getenv("EAT_WGRAD_WIDE") ? atoi(getenv("EAT_WGRAD_WIDE")) : 3;
   constexpr int wide_min = 20;
   WideShape w{false, Ci > Co, 0, 0, 0, 0};
-  if (per_sample || no_wide || has_tf || !(wide_on & 1) || (has_xscale && (Ci & 3) != 0)) return w;
+  if (per_sample || no_wide || has_tf || (has_xscale && (Ci & 3) != 0)) return w;
   if (same) {
     // Gram matrix (dz == x, train_fuse.hip): ONE operand, loaded once - P = x, the Q fragments are read from P's rows.  Above
     // the streaming kernel's range (C > 64) up to what one consumer quartet holds (10 column tiles); 80 x 80 at 504
     // positions x 256 clips: 62 us on the 128 x 128-tile kernel for 41 MB of input
-    if (Co != Ci || Co <= 64 || Co > 160 || has_xscale || (wide_on & 4)) return w;
+    if (Co != Ci || Co <= 64 || Co > 160 || has_xscale) return w;
     w.swap = true;
     w.ptn = w.qtn = 1;
     w.ptr = w.qtr = (Co + 15) / 16 * 16;
@@ -1753,23 +1844,17 @@ static WideShape wide_shape(int Co, int Ci, bool per_sample, bool same, bool no_
   w.ok = (w.ptn - 1) * w.ptr < PR && (w.qtn - 1) * w.qtr < QR && w.ptr / 8 + w.qtr / 8 >= wide_min;
   return w;
 }
-static bool wide_replaces_thin() {
-  static const int wide_on = getenv("EAT_WGRAD_WIDE") ? atoi(getenv("EAT_WGRAD_WIDE")) : 3;
-  return (wide_on & 3) == 3;
-}
 static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact_fp32, bool same, bool has_scale_or_tf,
                          bool has_xscale = false, bool no_wide = false,
                          bool has_tf = false) {
   static const bool env_fp32 = getenv("EAT_WGRAD_FP32") && atoi(getenv("EAT_WGRAD_FP32")) != 0;
   const bool force_fp32 = env_fp32 || exact_fp32 == 1;      // exact_fp32: 0 = bf16x3, 1 = exact fp32, 2 = plain bf16
-  static const bool dyn_x3 = !(getenv("EAT_DYN_WGRAD_X3") && atoi(getenv("EAT_DYN_WGRAD_X3")) == 0);
-  const bool ps_x3 = per_sample && dyn_x3 && Co >= 64 && Ci >= 64;
+  const bool ps_x3 = per_sample && Co >= 64 && Ci >= 64;
   WgPlan p{2, 0, 0, (S + 31) / 32, 0, 0, 0, 1, 1, false, 0};
-  static const bool thin_on = !(getenv("EAT_WGRAD_THIN") && atoi(getenv("EAT_WGRAD_THIN")) == 0);
   if (!force_fp32 && (S & 3) == 0) {
     const int sps = p.sps;
     const int mtn = (Co + 15) / 16, ntn = (Ci + 15) / 16;
-    if (per_sample && !ps_x3 && thin_on && sps >= 32) {
+    if (per_sample && !ps_x3 && sps >= 32) {
       // per-sample gradients of the thin early-layer matrices (one side < 64 channels, planes of >= 1024 positions):
       // the same streaming kernel, a few blocks per sample adding into the sample's own matrix
       const int mg = (mtn + 3) / 4, ng = (ntn + 2) / 3;
@@ -1798,14 +1883,14 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
         thin = true; p.mtb = p.ntb = mtn; p.mg = p.ng = 1; p.gram = true;
       } else if (Co <= 64 && Ci <= 64 && (Co <= 16 || Ci <= 16)) {
         thin = true; p.mtb = mtn; p.ntb = ntn; p.mg = p.ng = 1;
-      } else if (thin_on && total * 32 >= (1 << 19)) {
+      } else if (total * 32 >= (1 << 19)) {
         // a long k axis (>= 512 k positions) over few rows: groups of <= 4 row tiles per block, at most 4 groups (the other
         // operand is re-read once per group, from L2)
         const int mg = (mtn + 3) / 4, ng = (ntn + 2) / 3;
         const int mtb = (mtn + mg - 1) / mg, ntb = (ntn + ng - 1) / ng;
         if (mg * ng <= 4 && thin_pair(mtb, ntb)) { thin = true; p.mtb = mtb; p.ntb = ntb; p.mg = mg; p.ng = ng; }
         // more than one row group = the other operand is read once per group: the wide-tile kernel reads it once
-        if (thin && mg * ng > 1 && wide_replaces_thin() && wide_shape(Co, Ci, per_sample, same, no_wide, has_xscale, has_tf).ok) thin = false;
+        if (thin && mg * ng > 1 && wide_shape(Co, Ci, per_sample, same, no_wide, has_xscale, has_tf).ok) thin = false;
       }
     }
     if (thin) {
@@ -1836,7 +1921,7 @@ static WgPlan wgrad_plan(int B, int Co, int Ci, int S, int per_sample, int exact
       // ~512 blocks, but at least 16 units (512 k) of MFMA work in front of a block's Co x Ci atomics
       // (512 = one round of two resident blocks per CU; 1024 measured 0.26 ms slower per mn10 step: the second round pays
       // prologue, tail and the Co x Ci atomics again)
-      static const int target = getenv("EAT_WGRAD_BLOCKS") ? atoi(getenv("EAT_WGRAD_BLOCKS")) : 512;
+      constexpr int target = 512;
       // never MORE than `target` blocks: 516 blocks (6 tiles x 86 slices, the 672 x 112 layers) ran as a full round of 512
       // resident blocks plus a second round of 4 (183 -> 158 us with 510)
       long long splits = tiles >= target ? 1 : target / tiles;
@@ -1896,10 +1981,8 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
   if (p.kind == 3) {
     const size_t smem = (size_t)(p.w_ptr / 8 + p.w_qtr / 8) * 2 * 1024;     // two slots of converted fragments
     dim3 grid(p.w_ptn, p.w_qtn, p.nz);
-    // EAT_WGRAD_WIDE_DBG (measurement only, results are wrong): 1 no epilogue stores, 2 no MFMAs.  (The producers' switches
-    // of the decomposition runs - no loads, no conversion - are not in the shipped kernel: a load inside a conditional
-    // block makes the compiler wait with vmcnt(<= 12) instead of vmcnt(26 ... 38), i.e. drains the units in flight.)
-    static const int wide_dbg = getenv("EAT_WGRAD_WIDE_DBG") ? atoi(getenv("EAT_WGRAD_WIDE_DBG")) : 0;
+    // (the phase-decomposition switches of the round-4 measurement builds - no epilogue stores, no MFMAs, no loads, no
+    //  conversion: DESIGN 3.15 - are not in the shipped kernel)
 #define EAT_WIDE(NP_, SW_, SC_, RA_)                                                                                      \
     do {                                                                                                                  \
       auto kern = pw_wgrad_wide_kernel<NP_, SW_, SC_, RA_>;                                                               \
@@ -1910,7 +1993,8 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
         attr_set = true;                                                                                                  \
       }                                                                                                                   \
       hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.w_ptr,    \
-                         p.w_qtr, wide_dbg, centring ? tf.b : (const float*)nullptr, dz == x ? 1 : 0);                    \
+                         p.w_qtr, centring ? tf.b : (const float*)nullptr, dz == x ? 1 : 0, (const float*)nullptr, \
+                         (const float*)nullptr, 0);                                                                      \
     } while (0)
 #define EAT_WIDE_SC(NP_, SW_) do { if (x_scale) EAT_WIDE(NP_, SW_, true, false); else EAT_WIDE(NP_, SW_, false, false); } while (0)
 #define EAT_WIDE_SW(NP_)                                                                                                  \
@@ -1990,6 +2074,80 @@ extern "C" int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float
   if (!tf_a || !tf_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_tf: tf_a and tf_b are required");
   if (tf_act < 0 || tf_act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_tf: bad act %d", tf_act);
   return pw_wgrad_impl(dz, x, x_scale, dW, B, Co, Ci, S, 0, exact_fp32, stream, ws, n_slots, WgTf{tf_a, tf_b, tf_act});
+}
+
+// ---- 1x1 weight gradient of the bf16-storage plan (act_io.h; BASELINE configs[2]): ONE of the operands - the wide tensor -
+// is bf16 in HBM: x (the project conv's input y_d, or z_d with act(tf_a x + tf_b) evaluated on load, times x_scale) or dz (the
+// expand conv's incoming gradient g).  Plain bf16 products, fp32 accumulation (what autocast does to the conv weight
+// gradient, ex_pl_audioset.py:287-293).  Always the wide-tile producer / consumer kernel with the bf16 operand as P (its
+// fragments need no conversion); ws: >= eat_pw_wgrad_b16_slots(...) * Co * Ci floats (no zero fill), dW is added to (zeroed by
+// the caller).  S % 4 == 0, Ci % 4 == 0.
+struct WgB16Plan { WideShape w; int upb; unsigned nz; int sps; };
+static WgB16Plan wgrad_b16_plan(int B, int Co, int Ci, int S, int x_b16) {
+  WgB16Plan p{};
+  p.sps = (S + 31) / 32;
+  WideShape& w = p.w;
+  w.swap = x_b16 != 0;
+  const int PR = w.swap ? Ci : Co, QR = w.swap ? Co : Ci;
+  w.ptn = (PR + 255) / 256;
+  w.ptr = ((PR + w.ptn - 1) / w.ptn + 15) / 16 * 16;
+  w.qtn = (QR + 159) / 160;
+  w.qtr = ((QR + w.qtn - 1) / w.qtn + 15) / 16 * 16;
+  w.ok = (w.ptn - 1) * w.ptr < PR && (w.qtn - 1) * w.qtr < QR;
+  const long long total = (long long)B * p.sps;
+  const int wtiles = w.ptn * w.qtn;
+  long long splits = wtiles >= 256 ? 1 : 256 / wtiles;                // one block per CU
+  if (splits > total / 16) splits = total / 16;
+  if (splits < 1) splits = 1;
+  p.upb = (int)((total + splits - 1) / splits);
+  p.nz = (unsigned)((total + p.upb - 1) / p.upb);
+  return p;
+}
+
+extern "C" int eat_pw_wgrad_b16_slots(int B, int Co, int Ci, int S, int x_b16) {
+  return (int)wgrad_b16_plan(B, Co, Ci, S, x_b16).nz;
+}
+
+extern "C" int eat_pw_conv_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, const float* tf_a,
+                                     const float* tf_b, int tf_act, const float* x_scale, float* dW, float* ws, int n_slots,
+                                     int B, int Co, int Ci, int S, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dz || !x || !dW || !ws) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: missing operand");
+  if ((dz_b16 != 0) == (x_b16 != 0)) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: exactly one of dz / x is the bf16 (wide) tensor");
+  if (B < 1 || Co < 1 || Ci < 4 || (Ci & 3) != 0 || S < 4 || (S & 3) != 0)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  if ((tf_a == nullptr) != (tf_b == nullptr) || tf_act < 0 || tf_act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: bad transform");
+  if (dz_b16 && (tf_a || x_scale)) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: transform / scale belong to a bf16 x operand");
+  const WgB16Plan p = wgrad_b16_plan(B, Co, Ci, S, x_b16);
+  if (!p.w.ok) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: internal tiling error (%d x %d)", Co, Ci);
+  if (n_slots < (int)p.nz) return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: workspace of %d copies, %u needed", n_slots, p.nz);
+  if ((long long)(x_b16 ? Ci : Co) * S * 2 > 0x7fffffffLL || (long long)(x_b16 ? Co : Ci) * S * 4 > 0x7fffffffLL)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_b16: a sample exceeds the 32-bit row offsets");
+  hipStream_t hs = (hipStream_t)stream;
+  const size_t smem = (size_t)(p.w.ptr / 8 + p.w.qtr / 8) * 2 * 1024;
+  dim3 grid(p.w.ptn, p.w.qtn, p.nz);
+  const float* fdz = reinterpret_cast<const float*>(dz);
+  const float* fx = reinterpret_cast<const float*>(x);
+#define EAT_WIDE16(SW_, SC_, TF_)                                                                                          \
+  do {                                                                                                                    \
+    auto kern = pw_wgrad_wide_kernel<1, SW_, SC_, false, true, TF_>;                                                      \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+        return eat::fail(EAT_ELAUNCH, "eat_pw_conv_wgrad_b16: hipFuncSetAttribute(160 KB of LDS) failed");                \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, fdz, fx, x_scale, ws, B, Co, Ci, S, p.sps, p.upb, p.w.ptr, p.w.qtr,    \
+                       (const float*)nullptr, 0, tf_a, tf_b, tf_act);                                                     \
+  } while (0)
+  if (!x_b16) EAT_WIDE16(false, false, false);
+  else if (tf_a && x_scale) EAT_WIDE16(true, true, true);
+  else if (tf_a) EAT_WIDE16(true, false, true);
+  else if (x_scale) EAT_WIDE16(true, true, false);
+  else EAT_WIDE16(true, false, false);
+#undef EAT_WIDE16
+  hipLaunchKernelGGL(wgrad_slot_reduce4_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, (int)p.nz);
+  return eat::check_launch("eat_pw_conv_wgrad_b16");
 }
 
 // 1 where eat_pw_conv_dyn_wgrad adds into dW_b (the caller zero-fills it), 0 where it stores.  Host helper.

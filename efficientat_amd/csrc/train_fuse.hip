@@ -15,6 +15,7 @@
 //      reduce pass, the apply pass and its re-reads.
 #include <cstdlib>
 #include "eat_common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256) void act_grad_sum_kernel(const float* __restri
 //   sum g = s * P1 + gadd * P2,   sum g (z - mu) = s * P3 + gadd * P4
 // with P0 = sum d y, P1 = sum d act', P2 = sum act', P3 = sum d act' (z - mu), P4 = sum act' (z - mu) per plane - all
 // five taken here in one pass; se_bn_bwd_combine_kernel finishes per channel once the gate gradients are known.
-template <int ACT>
-__global__ __launch_bounds__(256) void se_bn_bwd_partials_kernel(const float* __restrict__ d, const float* __restrict__ z,
+template <int ACT, typename ZT = float>
+__global__ __launch_bounds__(256) void se_bn_bwd_partials_kernel(const ZT* __restrict__ d, const ZT* __restrict__ z,
                                                                  const float* __restrict__ a, const float* __restrict__ b,
                                                                  const float* __restrict__ mean, float* __restrict__ P,
                                                                  int C, int S, int n_planes) {
@@ -138,12 +139,12 @@ __global__ __launch_bounds__(256) void se_bn_bwd_partials_kernel(const float* __
   if ((S & 3) == 0) {
 #pragma unroll 2
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
-      const float4 dv = *reinterpret_cast<const float4*>(d + base + i);
-      const float4 zv = *reinterpret_cast<const float4*>(z + base + i);
+      const float4 dv = eat::Io<ZT>::load4(d + base + i);
+      const float4 zv = eat::Io<ZT>::load4(z + base + i);
       acc1(dv.x, zv.x); acc1(dv.y, zv.y); acc1(dv.z, zv.z); acc1(dv.w, zv.w);
     }
   } else {
-    for (int i = threadIdx.x; i < S; i += blockDim.x) acc1(d[base + i], z[base + i]);
+    for (int i = threadIdx.x; i < S; i += blockDim.x) acc1(eat::Io<ZT>::load1(d + base + i), eat::Io<ZT>::load1(z + base + i));
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void se_bn_bwd_partials_kernel(const float* __
 // block that reads 1 - 4 KB - block scheduling, not bandwidth, set the pace (2.6 TB/s at S = 128).  Here a WAVE owns LPP-lane
 // groups, one plane per group (LPP = 32 for S <= 128: two planes per wave), walks its planes with a grid stride and
 // reduces inside the group with xor shuffles: no LDS, no barrier.
-template <int ACT, int LPP>
-__global__ __launch_bounds__(256) void se_bn_bwd_partials_small_kernel(const float* __restrict__ d, const float* __restrict__ z,
+template <int ACT, int LPP, typename ZT = float>
+__global__ __launch_bounds__(256) void se_bn_bwd_partials_small_kernel(const ZT* __restrict__ d, const ZT* __restrict__ z,
                                                                        const float* __restrict__ a, const float* __restrict__ b,
                                                                        const float* __restrict__ mean, float* __restrict__ P,
                                                                        int C, int S, int n_planes) {
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void se_bn_bwd_partials_small_kernel(const flo
     const size_t base = (size_t)plane * S;
     float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = gl * 4; i < S; i += LPP * 4) {
-      const float4 dv = *reinterpret_cast<const float4*>(d + base + i);
-      const float4 zv = *reinterpret_cast<const float4*>(z + base + i);
+      const float4 dv = eat::Io<ZT>::load4(d + base + i);
+      const float4 zv = eat::Io<ZT>::load4(z + base + i);
       const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -431,29 +432,45 @@ extern "C" int eat_act_grad_sum(const float* dy, const float* z, const float* a,
   return eat::act_grad_sum(dy, z, a, b, act, g, gpart, B, C, S, (hipStream_t)stream);
 }
 
-extern "C" int eat_se_bn_bwd_partials(const float* d, const float* z, const float* a, const float* b, const float* mean,
-                                      float* P, int B, int C, int S, int act, eat_stream_t stream) {
-  eat::clear_stale_error();
-  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad act %d", act);
-  if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad shape");
+template <typename ZT>
+static int se_bn_bwd_partials_impl(const ZT* d, const ZT* z, const float* a, const float* b, const float* mean, float* P, int B,
+                                   int C, int S, int act, hipStream_t stream, const char* what) {
   if (S <= 512 && (S & 3) == 0) {
     // small planes: waves own planes (two per wave for S <= 128); ~8 planes per wave fill the chip several times over
     const int n_planes = B * C, ppb = S <= 128 ? 8 : 4;            // planes per block per grid-stride step
     int nb = (n_planes + ppb * 8 - 1) / (ppb * 8);
     nb = nb < 1 ? 1 : nb;
     if (S <= 128) {
-      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_small_kernel<ACT, 32>), dim3((unsigned)nb), dim3(256), 0,
-                                               (hipStream_t)stream, d, z, a, b, mean, P, C, S, n_planes));
+      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_small_kernel<ACT, 32, ZT>), dim3((unsigned)nb), dim3(256), 0,
+                                               stream, d, z, a, b, mean, P, C, S, n_planes));
     } else {
-      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_small_kernel<ACT, 64>), dim3((unsigned)nb), dim3(256), 0,
-                                               (hipStream_t)stream, d, z, a, b, mean, P, C, S, n_planes));
+      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_small_kernel<ACT, 64, ZT>), dim3((unsigned)nb), dim3(256), 0,
+                                               stream, d, z, a, b, mean, P, C, S, n_planes));
     }
-    return eat::check_launch("eat_se_bn_bwd_partials");
+    return eat::check_launch(what);
   }
   const dim3 blk(S >= 1024 ? 256 : 64);
-  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_kernel<ACT>), dim3((unsigned)(B * C)), blk, 0,
-                                           (hipStream_t)stream, d, z, a, b, mean, P, C, S, B * C));
-  return eat::check_launch("eat_se_bn_bwd_partials");
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((se_bn_bwd_partials_kernel<ACT, ZT>), dim3((unsigned)(B * C)), blk, 0, stream, d, z, a,
+                                           b, mean, P, C, S, B * C));
+  return eat::check_launch(what);
+}
+
+extern "C" int eat_se_bn_bwd_partials(const float* d, const float* z, const float* a, const float* b, const float* mean,
+                                      float* P, int B, int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad act %d", act);
+  if (B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials: bad shape");
+  return se_bn_bwd_partials_impl<float>(d, z, a, b, mean, P, B, C, S, act, (hipStream_t)stream, "eat_se_bn_bwd_partials");
+}
+
+// the same over bf16-stored d and z (act_io.h: the bf16-storage plan of BASELINE configs[2])
+extern "C" int eat_se_bn_bwd_partials_b16(const void* d, const void* z, const float* a, const float* b, const float* mean,
+                                          float* P, int B, int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials_b16: bad act %d", act);
+  if (!d || !z || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_se_bn_bwd_partials_b16: bad shape");
+  return se_bn_bwd_partials_impl<eat::bf16_t>(reinterpret_cast<const eat::bf16_t*>(d), reinterpret_cast<const eat::bf16_t*>(z), a,
+                                              b, mean, P, B, C, S, act, (hipStream_t)stream, "eat_se_bn_bwd_partials_b16");
 }
 
 extern "C" int eat_se_bn_bwd_combine(const float* P, const float* gscale, const float* gadd, const float* invstd, int B,

@@ -414,6 +414,10 @@ class MN(nn.Module):
         # arithmetic of the 1x1 forward / data-gradient GEMMs of the train step (ops.precision): "auto" =
         # exact fp32 below C_in 40, split-operand bf16x3 (fp32-class) above; "fp32"; "bf16" = BASELINE config 3
         self.train_precision = os.environ.get("EAT_TRAIN_PRECISION", "auto")
+        # storage of the WIDE activation tensors of the train step (mn_train.py): "fp32", or "bf16" = the reference's 16-bit
+        # mixed precision (ex_pl_audioset.py:287-293; BASELINE configs[2]) - z_e, z_d, y_d and the gradients arriving at them
+        # live in bf16 in HBM; needs train_precision "bf16" (plain bf16 GEMM operands), anything else is a loud error
+        self.act_storage = os.environ.get("EAT_ACT_STORAGE", "fp32")
 
     def train(self, mode: bool = True):
         """nn.Module.train plus dropping the folded eval weights: parameters may have been updated by paths

@@ -164,17 +164,13 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         # ---- head (mn/model.py:186-194)
         feat, u, h2, drop_mask = sv["head"]
         fc1, fc2 = model.classifier[2], model.classifier[5]
-        # plain library GEMMs on the transposed VIEWS (rocBLAS takes the transposition as a flag: no transposed copies)
-        # and torch's fused Hardswish backward: 9 launches where the round-2 form took 25
-        g["classifier.5.weight"] = torch.mm(dlogits.t(), h2)
-        g["classifier.5.bias"] = dlogits.sum(0)
-        dh2 = torch.mm(dlogits, fc2.weight)
-        if drop_mask is not None:
-            dh2 = dh2 * drop_mask
-        du = torch.ops.aten.hardswish_backward(dh2, u)
-        g["classifier.2.weight"] = torch.mm(du.t(), feat)
-        g["classifier.2.bias"] = du.sum(0)
-        dft = torch.mm(du, fc1.weight)
+        # two launches of the library's stride-addressed tile GEMMs (csrc/se_train.hip: eat_mlp_head_bwd) - round 4 ran
+        # four rocBLAS GEMMs + five torch ops here
+        dW1, db1, dW2, db2, dft = ops.mlp_head_bwd(dlogits, h2.contiguous(), u.contiguous(),
+                                                  None if drop_mask is None else drop_mask.contiguous(), feat.contiguous(),
+                                                  fc1.weight, fc2.weight)
+        g["classifier.5.weight"], g["classifier.5.bias"] = dW2, db2
+        g["classifier.2.weight"], g["classifier.2.bias"] = dW1, db1
         if dfeat is not None:
             dft = dft + dfeat
         # ---- last 1x1 conv + BN + hardswish, pooled (the pool's gradient is a per-plane constant)
@@ -207,14 +203,19 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias))
         bn_grads(dgam, dbet, nw, nbias)
         scale = rec.get("scale")
+        b16 = rec.get("b16", False)                    # the block's wide tensors are bf16 in HBM (forward: rec["b16"])
+        wgrad = ops.pw_conv_wgrad_b16 if b16 else ops.pw_conv_wgrad
         if rec["y_d"] is None:     # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
             st_d = rec["st_d"]
-            dWp = ops.pw_conv_wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act))
+            dWp = wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act))
         else:
-            dWp = ops.pw_conv_wgrad(dz_p, rec["y_d"], x_scale=scale)
+            dWp = wgrad(dz_p, rec["y_d"], x_scale=scale)
         g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
         wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
-        dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+        if b16:
+            dxs = ops.pw_conv_b16(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+        else:
+            dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
         del dz_p
         gscale = gadd = se_P = None
         if scale is not None:     # squeeze-excitation gate (mn/block_types.py:72-83)
@@ -256,6 +257,8 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         # a block without expand conv hands its residual-branch gradient to the stem's backward kernel, which adds the
         # two on load (the merged kernel has no residual input)
         res_ok = not no_expand or res_grad is None or (i == 0 and sv["stem"][1] is None)
+        if b16 and not (_MERGED_DW_BWD and _DW_BN_ON_LOAD):
+            raise _lib.EatHipError("act_storage='bf16' runs the merged depthwise backward only (EAT_MERGED_DW_BWD / EAT_DW_BN_ON_LOAD = 1)")
         if (_MERGED_DW_BWD and _DW_BN_ON_LOAD and (y_e is None or no_expand) and res_ok
                 and ops.dw_bwd_merged_ok(rec["z_d"].shape, src_shape, k, cnf.stride)):
             # large planes: dz_d is never written - the merged backward kernel evaluates the BatchNorm + activation
@@ -323,14 +326,25 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             del dz_d
             frozen = getattr(st_e[2], "_eat_frozen", False)
             n_e = inp.shape[0] * inp.shape[2] * inp.shape[3]
-            Gx = ops.pw_conv_wgrad(g_e, inp)
+            Gx = wgrad(g_e, inp)
             Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
             dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
                                                              frozen=frozen, centered=not frozen)
             g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
             g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
             S_e = inp.shape[2] * inp.shape[3]
-            if not frozen and _CAT_DGRAD and S_e % 4 == 0:
+            if b16:
+                # the same GEMMs with g read from its bf16 storage; two-source form where g's channels fill whole k-chunks
+                if not frozen and _CAT_DGRAD and cnf.expanded_channels % 32 == 0:
+                    wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
+                    dout = ops.pw_conv_b16(g_e, wcat, c0, cnf.input_channels, NONE, x2=inp, res=res_grad)
+                else:
+                    t = res_grad
+                    if not frozen:
+                        t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
+                    dout = ops.pw_conv_b16(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
+                                           NONE, res=t)
+            elif not frozen and _CAT_DGRAD and S_e % 4 == 0:
                 # dx = [WaT | M] [g ; x] + c0 (+ residual-branch gradient): one GEMM over both tensors
                 wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
                 dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad)
@@ -400,6 +414,19 @@ _FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem with
 _CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
 
 
+def _act_storage_bf16(model):
+    """True when the step stores its wide activations in bf16 (model.act_storage, mn.py); checks the combination."""
+    st = getattr(model, "act_storage", "fp32")
+    if st == "fp32":
+        return False
+    if st != "bf16":
+        raise _lib.EatHipError(f"act_storage must be 'fp32' or 'bf16' (got {st!r})")
+    if ops.precision.mode != "bf16":
+        raise _lib.EatHipError("act_storage='bf16' needs train_precision='bf16' (plain bf16 GEMM operands): the split-operand "
+                               f"kernels read fp32 activations (train_precision={ops.precision.mode!r})")
+    return True
+
+
 class MNTrainFunction2(torch.autograd.Function):
     """mode 0: the whole network incl. the mlp head -> (logits, features).  mode 1 ("trunk"): up to the last feature map
     -> (y_last, fmap_0 ... fmap_15): the caller runs the head on y_last (non-default heads, `return_fmaps`); the block
@@ -414,6 +441,7 @@ class MNTrainFunction2(torch.autograd.Function):
         saved = {}
         blocks = list(model.features[1:-1])
         exact = ops.precision.mode == "fp32"
+        store16 = _act_storage_bf16(model)
         plan = _prepack_plan(model)
         if plan is not None:
             plan.run()
@@ -456,6 +484,11 @@ class MNTrainFunction2(torch.autograd.Function):
             cna_d = blk.block[blk.i_dw]
             w_d = cna_d[0].weight.reshape(-1, k * k)
             tf = None
+            # bf16 storage of this block's wide tensors (z_e, z_d, y_d; backward: dxs, g) where the kernels cover its geometry;
+            # a block without expand conv reads the fp32 block input in its depthwise conv and keeps fp32 storage
+            b16 = (store16 and blk.i_expand is not None and cna_d[1].training
+                   and ops.b16_block_ok(B, cnf.expanded_channels, inp.shape[2], inp.shape[3], k, cnf.stride))
+            rec["b16"] = b16
             if blk.i_expand is not None:
                 cna = blk.block[blk.i_expand]
                 W = cna[0].weight.flatten(1)
@@ -474,7 +507,10 @@ class MNTrainFunction2(torch.autograd.Function):
                 else:
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
                 wp = _pk(plan, ("e", bi), cna[0].weight)
-                z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+                if b16:
+                    z_e = ops.pw_conv_b16(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+                else:
+                    z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
                 rec.update(z_e=z_e, st_e=st_e, Tm=Tm, sx=sx)
                 tf = (st_e[0], st_e[1], act)
             src = z_e if blk.i_expand is not None else inp
@@ -503,7 +539,17 @@ class MNTrainFunction2(torch.autograd.Function):
                 rec.update(pool=pool, h=h, scale=scale, S_d=S_d)
             cna = blk.block[blk.i_proj]
             wp = _pk(plan, ("p", bi), cna[0].weight)
-            if on_load:
+            if b16:
+                # project conv from the bf16-stored z_d (BatchNorm + activation on load) or y_d, statistics in its epilogue
+                src_p, tf_p = (z_d, (st_d[0], st_d[1], act)) if on_load else (y_d, None)
+                if cna[1].training:
+                    z_p, parts = ops.pw_conv_b16(src_p, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, tf=tf_p,
+                                                 in_scale=scale, stats=True)
+                    st_p = ops.bn_state_from_partials(parts, cna[1], z_p.numel() // cnf.out_channels)
+                else:
+                    z_p = ops.pw_conv_b16(src_p, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, tf=tf_p, in_scale=scale)
+                    st_p = ops.bn_frozen_state(cna[1])
+            elif on_load:
                 z_p, st_p = _pw_conv_bn(z_d, wp, cnf.out_channels, cna[1], dev, tf=(st_d[0], st_d[1], act), in_scale=scale)
             else:
                 z_p, st_p = _pw_conv_bn(y_d, wp, cnf.out_channels, cna[1], dev, in_scale=scale)

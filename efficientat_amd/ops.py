@@ -33,6 +33,21 @@ def _dev(t, name):
 def _opt(t, name):
     return None if t is None else _dev(t, name)
 
+
+def _dev16(t, name):
+    """Device pointer of a contiguous bfloat16 activation tensor (the wide tensors of the bf16-storage plan)."""
+    if not t.is_cuda:
+        raise _lib.EatHipError(f"{name} must live on the GPU: efficientat_amd has no CPU path (got device {t.device})")
+    if t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise _lib.EatHipError(f"{name} must be contiguous bfloat16 (got {t.dtype}, contiguous={t.is_contiguous()})")
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.EatHipError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}")
+    return t.data_ptr()
+
+
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
 _KCAT = os.environ.get("EAT_DYN_KCAT", "1") == "1"   # K-concat form of the late dynamic 1x1 convs (A/B switch)
 
 
@@ -266,6 +281,12 @@ def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True):
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
     y = torch.empty_like(z) if write else None
+    if _is16(z):                                   # bf16 storage (BASELINE configs[2]): y in bf16, pool = sums of the stored values
+        if res is not None:
+            raise _lib.EatHipError("bn_act_fwd: no residual on a bf16-stored tensor")
+        _lib.call("eat_bn_act_fwd_b16", _dev16(z, "z"), a.data_ptr(), b.data_ptr(), None if y is None else y.data_ptr(),
+                  _opt(pool, "pool"), B, C, S, act, _stream())
+        return y
     _lib.call("eat_bn_act_fwd", _dev(z, "z"), a.data_ptr(), b.data_ptr(), _opt(res, "res"),
               None if y is None else y.data_ptr(), _opt(pool, "pool"), B, C, S, act, _stream())
     return y
@@ -299,6 +320,10 @@ def se_bn_bwd_partials(d, z, a, b, mean, act):
     with act(a z + b)), P[1..4] the plane sums `bn_act_bwd_se` combines once gadd is known (csrc/train_fuse.hip)."""
     B, C = z.shape[0], z.shape[1]
     P = torch.empty((5, B, C), device=z.device, dtype=torch.float32)
+    if _is16(z):
+        _lib.call("eat_se_bn_bwd_partials_b16", _dev16(d, "dy"), _dev16(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                  P.data_ptr(), B, C, z.numel() // (B * C), act, _stream())
+        return P
     _lib.call("eat_se_bn_bwd_partials", _dev(d, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
               P.data_ptr(), B, C, z.numel() // (B * C), act, _stream())
     return P
@@ -470,10 +495,14 @@ def dw_conv_stats(x, w, k, stride, tf=None):
     B, C, F, T = x.shape
     Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
     cap = dw_partials_inner(F, T, Fo, To, k, stride, False)
-    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=x.dtype)
     part = torch.empty((B * 2 * C * cap,), device=x.device, dtype=torch.float32)
     inner = _ct.c_int(0)
     a, b, act = tf if tf is not None else (None, None, 0)
+    if _is16(x):                                   # bf16 storage: z_e in, z_d out, statistics of the stored z_d
+        _lib.call("eat_dw_conv_fwd_stats_b16", _dev16(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w, "w"),
+                  y.data_ptr(), part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
+        return y, (part, B, inner.value)
     _lib.call("eat_dw_conv_fwd_stats", _dev(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w, "w"), y.data_ptr(),
               part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
     return y, (part, B, inner.value)
@@ -592,7 +621,9 @@ def bn_act_bwd_sums(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, se_P
     else:
         if own:
             sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
-        _lib.call("eat_bn_act_bwd_reduce", _dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+        b16 = _is16(z)
+        _lib.call("eat_bn_act_bwd_reduce_b16" if b16 else "eat_bn_act_bwd_reduce", (_dev16 if b16 else _dev)(dy, "dy"),
+                  (_dev16 if b16 else _dev)(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
                   invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), B, C, S, act, sums.data_ptr(), _stream())
     if not own:
         return sums, None, None
@@ -607,11 +638,19 @@ def dw_conv_bwd_bn_g(dy, z, st, act, sums, w, x, in_a, in_b, in_act, k, stride, 
     Fo, To = z.shape[2], z.shape[3]
     h = _lib.lib()
     cap = int(h.eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
-    g = torch.empty((B, C, F, T), device=z.device, dtype=torch.float32)
+    b16 = _is16(z)                                 # bf16 storage: dy, z, x and g are bf16 together
+    g = torch.empty((B, C, F, T), device=z.device, dtype=z.dtype)
     gpart = torch.empty((B * C * cap,), device=z.device, dtype=torch.float32) if want_gsum else None
     dw = zero_arena.zeros((C, k * k), torch.float32, z.device)
     inner = _ct.c_int(0)
     frozen = 1 if getattr(st[2], "_eat_frozen", False) else 0
+    if b16:
+        _lib.call("eat_dw_conv_bwd_bn_g_b16", _dev16(dy, "dy"), _dev16(z, "z"), st[0].data_ptr(), st[1].data_ptr(),
+                  st[2].data_ptr(), st[3].data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), sums.data_ptr(), act, frozen,
+                  _dev16(x, "x"), in_a.data_ptr(), in_b.data_ptr(), in_act, _dev(w, "w"), g.data_ptr(), dw.data_ptr(),
+                  None if gpart is None else gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride,
+                  _stream())
+        return g, ((gpart, B, inner.value) if want_gsum else None), dw
     _lib.call("eat_dw_conv_bwd_bn_g", _dev(dy, "dy"), _dev(z, "z"), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
               st[3].data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), sums.data_ptr(), act, frozen, _dev(x, "x"),
               in_a.data_ptr(), in_b.data_ptr(), in_act, _dev(w, "w"), g.data_ptr(), dw.data_ptr(),
@@ -637,6 +676,26 @@ def se_mlp_bwd(ds, scale, h, pool, W1, W2, S):
               _dev(W2, "W2"), 1.0 / S, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), dh.data_ptr(),
               gadd.data_ptr(), B, C, Cr, _stream())
     return dW1, db1, dW2, db2, gadd
+
+
+def mlp_head_bwd(dlogits, h2, u, drop_mask, feat, W1, W2):
+    """Backward of the classifier head Linear -> Hardswish -> Dropout -> Linear in two launches (csrc/se_train.hip):
+    -> (dW1, db1, dW2, db2, dfeat)."""
+    B, N = dlogits.shape
+    H, C = W1.shape
+    dev = dlogits.device
+    buf = torch.empty((H * C + H + N * H + N + B * H + B * C,), device=dev, dtype=torch.float32)
+    o = 0
+    dW1 = buf[o:o + H * C].view(H, C); o += H * C
+    db1 = buf[o:o + H]; o += H
+    dW2 = buf[o:o + N * H].view(N, H); o += N * H
+    db2 = buf[o:o + N]; o += N
+    du = buf[o:o + B * H]; o += B * H
+    dfeat = buf[o:o + B * C].view(B, C)
+    _lib.call("eat_mlp_head_bwd", _dev(dlogits, "dy"), _dev(h2, "h2"), _dev(u, "u"), _opt(drop_mask, "drop_mask"),
+              _dev(feat, "feat"), _dev(W1, "W1"), _dev(W2, "W2"), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(),
+              db2.data_ptr(), du.data_ptr(), dfeat.data_ptr(), B, C, H, N, _stream())
+    return dW1, db1, dW2, db2, dfeat
 
 
 def stem_gram(x, W):
@@ -1026,6 +1085,55 @@ def pw_conv_bf16(x, wp16, bias, Co, act, split=True, in_scale=None, res=None, po
               _opt(res, "res"), None if y is None else y.data_ptr(), _opt(pool, "pool"), B, Ci, Co, F * T, act,
               1 if split else 0, _stream())
     return y
+
+
+# ------------------------------------------------------------------ bf16 activation storage (BASELINE configs[2])
+def b16_block_ok(B, C_exp, F, T, k, stride):
+    """True where the bf16-storage kernels cover an inverted-residual block whose depthwise conv maps (F, T) planes of
+    C_exp channels (csrc/dw_plane.hip geometries, even plane sizes, 16-byte row pieces for the 1x1 kernels)."""
+    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
+    return (bool(_lib.lib().eat_dw_conv_b16_ok(B, C_exp, F, T, Fo, To, k, stride)) and (F * T) % 8 == 0
+            and (Fo * To) % 8 == 0 and C_exp % 8 == 0)
+
+
+def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None, stats=False):
+    """1x1 conv of the bf16-storage plan: exactly one of input / output is the wide bf16 tensor (`eat_pw_conv_b16_fwd`).
+    x fp32 -> y bf16 (expand conv, project data gradient); x bf16 -> y fp32 (project conv with tf = (a, b, act) / in_scale /
+    stats=True -> (y, parts); two-source data-gradient GEMM with x2 fp32 + res).  wp: plain bf16 pack (precision 'bf16')."""
+    if wp.dtype != torch.bfloat16 or getattr(wp, "_eat_split", False):
+        raise _lib.EatHipError("pw_conv_b16: needs a plain bf16 weight pack (precision('bf16'))")
+    B, C1, F, T = x.shape
+    S = F * T
+    x16 = _is16(x)
+    Ci = C1 + (x2.shape[1] if x2 is not None else 0)
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32 if x16 else torch.bfloat16)
+    part = None
+    if stats:
+        tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, S, 0))
+        part = torch.empty((tiles * 2 * Co,), device=x.device, dtype=torch.float32)
+    a, b, tact = tf if tf is not None else (None, None, 0)
+    _lib.call("eat_pw_conv_b16_fwd", _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(x2, "x2"), C1,
+              wp.data_ptr(), _dev(bias, "bias"), _opt(a, "tf_a"), _opt(b, "tf_b"), tact, _opt(in_scale, "in_scale"),
+              _opt(res, "res"), y.data_ptr(), 0 if x16 else 1, None if part is None else part.data_ptr(), B, Ci, Co, S, act,
+              _stream())
+    return (y, (part, tiles, 1)) if stats else y
+
+
+def pw_conv_wgrad_b16(dz, x, x_scale=None, tf=None):
+    """dW (Co, Ci) = sum_b dz[b] . (act(tf_a x + tf_b) * x_scale)[b]^T with exactly one bf16 (wide) operand; plain bf16
+    products, fp32 accumulation (`eat_pw_conv_wgrad_b16`)."""
+    B, Co = dz.shape[0], dz.shape[1]
+    Ci = x.shape[1]
+    S = dz.numel() // (B * Co)
+    d16, x16 = _is16(dz), _is16(x)
+    n = int(_lib.lib().eat_pw_wgrad_b16_slots(B, Co, Ci, S, 1 if x16 else 0))
+    dW = zero_arena.zeros((Co, Ci), torch.float32, dz.device)
+    ws = torch.empty((n, Co, Ci), device=dz.device, dtype=torch.float32)
+    a, b, tact = tf if tf is not None else (None, None, 0)
+    _lib.call("eat_pw_conv_wgrad_b16", _dev16(dz, "dz") if d16 else _dev(dz, "dz"), 1 if d16 else 0,
+              _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(a, "tf_a"), _opt(b, "tf_b"), tact,
+              _opt(x_scale, "x_scale"), dW.data_ptr(), ws.data_ptr(), n, B, Co, Ci, S, _stream())
+    return dW
 
 
 # ------------------------------------------------------------------ precision switch (training plans)

@@ -9,7 +9,12 @@
  *   - every pointer is a DEVICE pointer unless the name starts with h_; fp32 unless noted
  *   - tensors are contiguous NCHW = (B, C, F, T), T fastest; S = F*T is the plane size
  *   - the caller owns every buffer; the library allocates nothing and keeps no mutable
- *     global state, so calls may be issued concurrently on different streams
+ *     global state - with ONE documented exception, the process-wide kernel-variant selector
+ *     eat_pw_stream_mode() (an atomic int read once per eat_pw_conv_bf16_fwd call; it selects between
+ *     kernels with identical results) - so calls may be issued concurrently on different streams
+ *   - environment variables read by the library (each once, at first use): EAT_PW_STREAM (initial
+ *     value of that selector) and EAT_WGRAD_FP32 (=1: every 1x1 weight gradient on the exact fp32
+ *     kernel, a debugging override of the caller's `exact_fp32` argument); nothing else
  *   - work is enqueued on `stream` (a hipStream_t) asynchronously; no hidden synchronisation
  *   - return 0 on success, a negative EAT_E* code otherwise (never throws, never exits);
  *     eat_last_error_string() returns the message of the calling thread's last failure
@@ -633,6 +638,75 @@ int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out,
 int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, const float* lam, const float* teacher,
                         const long long* teacher_idx, int n_teacher, float kd_lambda, int B, int C, float* sums,
                         float* dlogits, eat_stream_t stream);
+
+/* Backward of the classifier head (models/mn/model.py:186-194: Linear(C -> H) -> Hardswish -> Dropout -> Linear(H -> N); the
+ * reference leaves it to autograd) in two launches, no transposed copies, every output element from one block (no atomics):
+ *   dW2 = dlogits^T h2, db2 = sum_b dlogits, du = (dlogits W2) * drop_mask * hardswish'(u), dW1 = du^T feat, db1 = sum_b du,
+ *   dfeat = du W1.  dlogits (B, N); h2 (B, H) the second Linear's input (after dropout); u (B, H) the first Linear's output;
+ *   drop_mask (B, H) keep / (1 - p) factors or NULL; feat (B, C); W1 (H, C); W2 (N, H); du (B, H) scratch. */
+int eat_mlp_head_bwd(const float* dlogits, const float* h2, const float* u, const float* drop_mask, const float* feat,
+                     const float* W1, const float* W2, float* dW1, float* db1, float* dW2, float* db2, float* du,
+                     float* dfeat, int B, int C, int H, int N, eat_stream_t stream);
+
+/* ==== bf16 ACTIVATION STORAGE (BASELINE configs[2]: "mn40_as train step bf16") ============================================
+ * The reference trains in 16-bit mixed precision through PyTorch-Lightning (`precision=16`, ex_pl_audioset.py:287-293;
+ * the same surface as torch.autocast around models/mn/model.py:212-231): conv outputs and the gradients flowing back
+ * through them are stored in 16 bits, BatchNorm statistics, parameters, their gradients and the optimizer state in fp32.
+ * Here that is the `_b16` family: the WIDE tensors of an inverted-residual block (models/mn/block_types.py:138-181) - the
+ * expand conv's output z_e, the depthwise output z_d, its activated form y_d, and the gradients dxs / g arriving at them -
+ * are bf16 in HBM (`const void*` = bf16 where the matching `*_b16` flag says so); the narrow block inputs / outputs and
+ * every per-channel quantity stay fp32; arithmetic is fp32 in registers, GEMM operands plain bf16 with fp32 accumulation.
+ * Stores round to nearest even; statistics are taken of the values AS STORED.  Planes must hold an even number of elements
+ * (bf16 planes then start on 4-byte boundaries).  Each entry point below is the bf16-storage twin of the fp32 one named in
+ * its comment and replaces the same reference call site. */
+
+/* Twin of eat_pw_conv_fwd / _tf_fwd / _stats_fwd / _cat_fwd (models/mn/block_types.py:138-147,167-181): exactly one of x / y is
+ * the wide bf16 tensor.
+ *   x_b16 = 0, y_b16 = 1: z_e = W x (expand conv) or dxs = Wp^T dz_p (project data gradient): plain conv, everything optional NULL;
+ *   x_b16 = 1, y_b16 = 0: z_p = Wp (act(tf_a x + tf_b) * in_scale) with the statistics epilogue (stats_part as
+ *          eat_pw_conv_stats_fwd, tiles = eat_pw_conv_stat_tiles(B, S, 0)), or the two-source data-gradient GEMM
+ *          dx = [WaT | M] [g ; x2] + bias + res with x2 (B, Ci - c1, S) fp32, c1 % 32 == 0 (as eat_pw_conv_cat_fwd).
+ * wp = eat_pw_prepack_bf16(split = 0) of the (Co, Ci) matrix, Ci = all reduction channels; S % 8 == 0, Ci % 4 == 0
+ * (% 8 with a transform). */
+int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const void* wp, const float* bias,
+                        const float* tf_a, const float* tf_b, int tf_act, const float* in_scale, const float* res, void* y,
+                        int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act, eat_stream_t stream);
+
+/* Twin of eat_dw_conv_fwd_stats (models/mn/block_types.py:150-162 under model.train()): x, y bf16; partial sums of the rounded
+ * outputs.  eat_dw_conv_b16_ok(...) != 0 where this and eat_dw_conv_bwd_bn_g_b16 cover the geometry (a plan keeps fp32
+ * storage for the other blocks). */
+int eat_dw_conv_b16_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride);
+int eat_dw_conv_fwd_stats_b16(const void* x, const float* in_a, const float* in_b, int in_act, const float* w, void* y,
+                              float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
+                              int stride, eat_stream_t stream);
+
+/* Twin of eat_bn_act_fwd (block_types.py:150-162, 72-73): z bf16 -> y bf16 (or NULL: squeeze sums only), pool (B, C) plain
+ * stores of the sums of the rounded y. */
+int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, void* y, float* pool, int B, int C, int S, int act,
+                       eat_stream_t stream);
+
+/* Twins of eat_bn_act_bwd_reduce and eat_se_bn_bwd_partials (backward of block_types.py:150-162, 72-83): dy / d and z bf16. */
+int eat_bn_act_bwd_reduce_b16(const void* dy, const void* z, const float* a, const float* b, const float* mean,
+                              const float* invstd, const float* gscale, const float* gadd, int B, int C, int S, int act,
+                              double* sums, eat_stream_t stream);
+int eat_se_bn_bwd_partials_b16(const void* d, const void* z, const float* a, const float* b, const float* mean, float* P,
+                               int B, int C, int S, int act, eat_stream_t stream);
+
+/* Twin of eat_dw_conv_bwd_bn_g (backward of block_types.py:138-162): dy, z, x and the output g are bf16. */
+int eat_dw_conv_bwd_bn_g_b16(const void* dy, const void* z, const float* bn_a, const float* bn_b, const float* bn_mean,
+                             const float* bn_invstd, const float* gscale, const float* gadd, const double* sums, int bn_act,
+                             int frozen, const void* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                             void* g, float* dw, float* gpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo,
+                             int To, int k, int stride, eat_stream_t stream);
+
+/* Twin of eat_pw_conv_wgrad_ws / _tf (backward of block_types.py:138-147,167-181): dW (Co, Ci) += sum_b dz[b] x'[b]^T with
+ * exactly one bf16 operand - x (then x' = act(tf_a x + tf_b) * x_scale, each optional) or dz.  ws: workspace of
+ * n_slots >= eat_pw_wgrad_b16_slots(B, Co, Ci, S, x_b16) copies of dW (no zero fill needed); dW is added to.
+ * S % 4 == 0, Ci % 4 == 0. */
+int eat_pw_wgrad_b16_slots(int B, int Co, int Ci, int S, int x_b16);
+int eat_pw_conv_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, const float* tf_a, const float* tf_b,
+                          int tf_act, const float* x_scale, float* dW, float* ws, int n_slots, int B, int Co, int Ci, int S,
+                          eat_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -139,31 +139,72 @@ class _PwBf16(torch.autograd.Function):
 
 
 PW_BF16 = False      # set through `emulate_bf16_pointwise()` only
+ST_BF16 = False      # ... with storage=True: the wide tensors of the blocks that have an expand conv are STORED in bf16
+
+
+class _StoreBf16(torch.autograd.Function):
+    """A tensor that lives in bf16 in memory: the forward value is rounded once (what a store + load leaves)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy
+
+
+class _GradBf16(torch.autograd.Function):
+    """A point of the graph whose incoming GRADIENT is stored in bf16 (identity in the forward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.bfloat16().float()
 
 
 class emulate_bf16_pointwise:
-    """with O.emulate_bf16_pointwise(): every 1x1 convolution of mn_forward runs as `_PwBf16`."""
+    """with O.emulate_bf16_pointwise(): every 1x1 convolution of mn_forward runs as `_PwBf16`.
+    storage=True additionally emulates `act_storage="bf16"` (efficientat_amd/mn_train.py; the reference's 16-bit mixed
+    precision, ex_pl_audioset.py:287-293): in every inverted-residual block with an expand conv the expand output z_e, the
+    depthwise output z_d and its activated form y_d are rounded to bf16 where they are stored, and so are the two wide
+    gradients of the backward - the one arriving at the project conv's input and g = dL/d(BN output of the expand conv)."""
+
+    def __init__(self, storage=False):
+        self.storage = storage
 
     def __enter__(self):
-        global PW_BF16
-        self.old, PW_BF16 = PW_BF16, True
+        global PW_BF16, ST_BF16
+        self.old, PW_BF16 = (PW_BF16, ST_BF16), True
+        ST_BF16 = self.storage
 
     def __exit__(self, *exc):
-        global PW_BF16
-        PW_BF16 = self.old
+        global PW_BF16, ST_BF16
+        PW_BF16, ST_BF16 = self.old
 
 
-def _cna(sd, prefix, x, train, stats, k, stride, groups, act, dil=1):
-    """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2*dilation) + BN + act."""
+def _cna(sd, prefix, x, train, stats, k, stride, groups, act, dil=1, store=None):
+    """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2*dilation) + BN + act.
+    store (bf16-storage emulation only): "expand" = conv output stored in bf16, gradient w.r.t. the BN output stored in
+    bf16; "depthwise" = conv output and activated output stored in bf16."""
     if PW_BF16 and k == 1 and groups == 1:
         x = _PwBf16.apply(x, sd[prefix + ".0.weight"])
     else:
         x = F.conv2d(x, sd[prefix + ".0.weight"], None, stride, (k - 1) // 2 * dil, dil, groups)
+    if store is not None:
+        x = _StoreBf16.apply(x)
     x = _bn(sd, prefix + ".1", x, train, stats)
+    if store == "expand":
+        x = _GradBf16.apply(x)
     if act == "hs":
         x = F.hardswish(x)
     elif act == "re":
         x = F.relu(x)
+    if store == "depthwise":
+        x = _StoreBf16.apply(x)
     return x
 
 
@@ -197,10 +238,12 @@ def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True, se_dims=(1,)
     inp, j = x, 0
     a = "hs" if c["hs"] else "re"
     dil = c.get("dil", 1)
+    st16 = ST_BF16 and train and c["cexp"] != c["cin"]      # (a block without expand conv keeps fp32 storage)
     if c["cexp"] != c["cin"]:
-        x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, a)
+        x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, a, store="expand" if st16 else None)
         j += 1
-    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, c["k"], 1 if dil > 1 else c["stride"], c["cexp"], a, dil)   # :150
+    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, c["k"], 1 if dil > 1 else c["stride"], c["cexp"], a, dil,
+             store="depthwise" if st16 else None)   # :150
     j += 1
     if c["se"] and use_se and se_dims is not None and tuple(se_dims) != (1,):
         x = _concurrent_se(sd, f"{prefix}.block.{j}", x, se_dims, se_agg)
@@ -208,6 +251,8 @@ def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True, se_dims=(1,)
     elif c["se"] and use_se and se_dims is not None:
         x = _se(sd, f"{prefix}.block.{j}.conc_se_layers.0", x)
         j += 1
+    if st16:
+        x = _GradBf16.apply(x)                              # the project conv's data gradient is stored in bf16
     x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, None)
     if c["stride"] == 1 and c["cin"] == c["cout"]:
         x = x + inp

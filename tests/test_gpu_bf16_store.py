@@ -1,0 +1,242 @@
+"""GPU tests of the bf16 ACTIVATION STORAGE kernels (BASELINE configs[2]; include/eat_hip.h `_b16` family, csrc/act_io.h).
+
+Each `_b16` entry point is the storage twin of an fp32 entry point that has its own test against fp64 autograd of the
+reference's op sequence (tests/test_gpu_train_fuse.py, tests/test_gpu_train.py).  The twins are therefore pinned on those:
+the same inputs, rounded to bf16 once, go through both; fp32 results must agree to accumulation-order noise, bf16 results
+must be the round-to-nearest-even of the fp32 result (up to rare ties between two bf16 neighbours: the two kernels need
+not add in the same order), and statistics must be those of the values AS STORED.  Reference call sites:
+models/mn/block_types.py:138-181 under the reference's 16-bit mixed precision (ex_pl_audioset.py:287-293)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("no GPU", allow_module_level=True)
+
+from efficientat_amd import _lib, ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+NONE, RELU, HSWISH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_HSWISH
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _rel(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = ref.detach().cpu().double().reshape(-1)
+    return float((got - ref).norm() / max(1e-30, float(ref.norm())))
+
+
+def _bf(t):
+    """fp32 tensor holding bf16-representable values (what a bf16 store + load leaves)."""
+    return t.bfloat16().float()
+
+
+def _assert_is_rounding_of(y16, y32, what=""):
+    """y16 (bf16) must be the bf16 rounding of y32 (fp32), except where y32 sits within fp32 noise of a rounding tie."""
+    assert y16.dtype == torch.bfloat16, what
+    a, r = y16.float(), y32.bfloat16().float()
+    bad = a != r
+    frac = float(bad.float().mean())
+    assert frac < 2e-3, (what, frac)
+    if bad.any():                                                     # the odd ones out are one bf16 step away, no more
+        err = (a - y32.float()).abs()[bad]
+        ulp = y32.float().abs()[bad] * 2.0 ** -7 + 1e-30
+        assert float((err / ulp).max()) < 1.01, what
+
+
+# (B, Ci, Co, F, T): every row-tile count of the kernel (MTW 1 .. 8, two row chunks), ragged Co, tiles that straddle samples
+PW = [(3, 64, 256, 8, 63), (2, 40, 120, 16, 125), (5, 160, 960, 4, 32), (2, 16, 64, 64, 500), (3, 24, 72, 32, 250),
+      (7, 80, 200, 8, 63), (3, 112, 672, 8, 63), (2, 64, 16, 8, 63), (4, 96, 100, 4, 32), (3, 320, 48, 8, 63)]
+
+
+@pytest.mark.parametrize("B,Ci,Co,F_,T", PW)
+def test_pw_conv_bf16_output(B, Ci, Co, F_, T):
+    """expand conv / project data gradient: fp32 in, bf16 out (eat_pw_conv_b16_fwd, x_b16 = 0, y_b16 = 1)."""
+    x = _rand(B, Ci, F_, T, seed=1).to(DEV)
+    w = _rand(Co, Ci, seed=2, scale=Ci ** -0.5).to(DEV)
+    zb = torch.zeros(Co, device=DEV)
+    with ops.precision("bf16"):
+        wp = ops.pw_prepack(w)
+        y32 = ops.pw_conv(x, wp, zb, Co, NONE)
+        y16 = ops.pw_conv_b16(x, wp, zb, Co, NONE)
+    _assert_is_rounding_of(y16, y32, "pw_conv f32 -> bf16")
+    # and the fp32 twin itself against fp64 on the rounded operands (plain bf16 products, fp32 accumulation)
+    ref = torch.einsum("oi,bifs->bofs", _bf(w).double().cpu(), _bf(x).double().cpu())
+    assert _rel(y32, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,Ci,Co,F_,T", PW)
+@pytest.mark.parametrize("variant", ["plain", "tf", "tf_se", "se"])
+def test_pw_conv_bf16_input_with_statistics(B, Ci, Co, F_, T, variant):
+    """project conv: bf16 in (z_d or y_d), on-load BatchNorm + activation, SE scale, statistics epilogue, fp32 out."""
+    if "tf" in variant and Ci % 8:
+        pytest.skip("on-load transform needs Ci % 8 == 0")
+    x16 = (_rand(B, Ci, F_, T, seed=1, scale=1.5) + _rand(1, Ci, 1, 1, seed=3)).to(DEV).bfloat16()
+    w = _rand(Co, Ci, seed=2, scale=Ci ** -0.5).to(DEV)
+    zb = torch.zeros(Co, device=DEV)
+    tf = None
+    if "tf" in variant:
+        tf = ((torch.rand(Ci, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV), _rand(Ci, seed=5, scale=0.3).to(DEV), HSWISH)
+    sc = (torch.rand(B, Ci, generator=torch.Generator().manual_seed(6)) + 0.25).to(DEV) if "se" in variant else None
+    with ops.precision("bf16"):
+        wp = ops.pw_prepack(w)
+        y, parts = ops.pw_conv_b16(x16, wp, zb, Co, NONE, tf=tf, in_scale=sc, stats=True)
+        y_ref, parts_ref = ops.pw_conv_stats(x16.float(), wp, Co, tf=tf, in_scale=sc)
+    assert y.dtype == torch.float32 and _rel(y, y_ref) < 2e-6, _rel(y, y_ref)
+    assert _rel(parts[0], parts_ref[0]) < 1e-5 and parts[1:] == parts_ref[1:]
+    # the partial sums are those of y
+    part = parts[0].view(parts[1], 2, Co).double().sum(0).cpu()
+    assert _rel(part[0], y.double().sum((0, 2, 3)).cpu()) < 1e-5 and _rel(part[1], (y.double() ** 2).sum((0, 2, 3)).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,F_,T", [(3, 256, 64, 64, 8, 63), (2, 288, 96, 96, 32, 250), (5, 960, 160, 160, 4, 32),
+                                              (2, 32, 16, 16, 64, 500), (3, 736, 320, 320, 8, 63)])
+def test_two_source_pointwise_conv_bf16_first_source(B, C1, C2, Co, F_, T):
+    """dx = [WaT | M] [g ; x] + c0 + res with g bf16 (C1 % 32 == 0) and x fp32: the expand conv's data gradient."""
+    g16 = _rand(B, C1, F_, T, seed=1).to(DEV).bfloat16()
+    x = _rand(B, C2, F_, T, seed=2).to(DEV)
+    w = _rand(Co, C1 + C2, seed=3, scale=(C1 + C2) ** -0.5).to(DEV)
+    c0 = _rand(Co, seed=4, scale=0.1).to(DEV)
+    res = _rand(B, Co, F_, T, seed=5).to(DEV)
+    with ops.precision("bf16"):
+        wp = ops.pw_prepack(w)
+        y = ops.pw_conv_b16(g16, wp, c0, Co, NONE, x2=x, res=res)
+        y_ref = ops.pw_conv_cat(g16.float(), x, wp, c0, Co, NONE, res=res)
+    assert _rel(y, y_ref) < 2e-6, _rel(y, y_ref)
+
+
+# (B, C, F, T, k, stride, act): every register-resident geometry (tile kernels incl. odd row widths, the five plane kernels,
+# two planes per wave, odd batches)
+DW = [(3, 64, 64, 500, 3, 2, 1), (2, 16, 64, 500, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1), (2, 24, 32, 250, 3, 1, 2),
+      (2, 8, 64, 200, 5, 1, 1), (2, 8, 34, 171, 3, 1, 2), (3, 9, 32, 171, 3, 2, 2), (5, 120, 16, 125, 5, 1, 2),
+      (3, 240, 16, 125, 3, 2, 2), (5, 200, 8, 63, 3, 1, 2), (3, 672, 8, 63, 5, 2, 2), (5, 96, 4, 32, 5, 1, 2),
+      (70, 24, 8, 63, 3, 1, 2), (1, 8, 16, 125, 5, 1, 1)]
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s,act", DW)
+def test_dw_conv_statistics_bf16_storage(B, C, F_, T, k, s, act):
+    """depthwise conv z_e (bf16) -> z_d (bf16) with the expand BatchNorm + activation on load and the statistics of the
+    STORED z_d (eat_dw_conv_fwd_stats_b16) against the fp32 twin on the same rounded input."""
+    p = (k - 1) // 2
+    assert _lib.lib().eat_dw_conv_b16_ok(B, C, F_, T, (F_ + 2 * p - k) // s + 1, (T + 2 * p - k) // s + 1, k, s)
+    x16 = (_rand(B, C, F_, T, seed=1, scale=1.5) + _rand(1, C, 1, 1, seed=2)).to(DEV).bfloat16()
+    w = _rand(C, k * k, seed=3, scale=0.3).to(DEV)
+    tf = ((torch.rand(C, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV), _rand(C, seed=5, scale=0.3).to(DEV), act)
+    for use_tf in (True, False):
+        y16, parts = ops.dw_conv_stats(x16, w, k, s, tf=tf if use_tf else None)
+        y32, _ = ops.dw_conv_stats(x16.float(), w, k, s, tf=tf if use_tf else None)
+        _assert_is_rounding_of(y16, y32, f"dw conv tf={use_tf}")
+        part, outer, inner = parts
+        st = part[:outer * 2 * C * inner].view(outer, 2, C, inner).double().sum((0, 3)).cpu()
+        yd = y16.double().cpu()
+        assert _rel(st[0], yd.sum((0, 2, 3))) < 1e-5 and _rel(st[1], (yd ** 2).sum((0, 2, 3))) < 1e-5, use_tf
+
+
+@pytest.mark.parametrize("B,C,S,act", [(3, 64, 8000, 1), (5, 672, 504, 2), (7, 960, 128, 2), (2, 16, 32000, 0), (300, 120, 2000, 2)])
+def test_bn_act_forward_and_reduce_bf16_storage(B, C, S, act):
+    """bn_act_fwd (y_d / squeeze sums), bn_act_bwd_reduce and se_bn_bwd_partials over bf16-stored tensors."""
+    z16 = (_rand(B, C, S, 1, seed=1, scale=1.5) + _rand(1, C, 1, 1, seed=2)).to(DEV).bfloat16()
+    d16 = _rand(B, C, S, 1, seed=3).to(DEV).bfloat16()
+    a = (torch.rand(C, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV)
+    b = _rand(C, seed=5, scale=0.3).to(DEV)
+    mean, invstd = _rand(C, seed=6, scale=0.2).to(DEV), (torch.rand(C, generator=torch.Generator().manual_seed(7)) + 0.5).to(DEV)
+    pool16, pool32 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    y16 = ops.bn_act_fwd(z16, a, b, act, pool=pool16)
+    y32 = ops.bn_act_fwd(z16.float(), a, b, act, pool=pool32)
+    _assert_is_rounding_of(y16, y32, "bn_act_fwd")
+    assert _rel(pool16, y16.double().sum((2, 3))) < 1e-5                        # the sums of the STORED values
+    p2 = torch.empty(B, C, device=DEV)
+    assert ops.bn_act_fwd(z16, a, b, act, pool=p2, write=False) is None and torch.equal(p2, pool16)
+    gs = (torch.rand(B, C, generator=torch.Generator().manual_seed(8)) + 0.2).to(DEV)
+    ga = _rand(B, C, seed=9, scale=0.05).to(DEV)
+    for gsc, gad in ((None, None), (gs, ga)):
+        s16, dg16, db16 = ops.bn_act_bwd_sums(d16, z16, a, b, mean, invstd, act, gscale=gsc, gadd=gad)
+        s32, dg32, db32 = ops.bn_act_bwd_sums(d16.float(), z16.float(), a, b, mean, invstd, act, gscale=gsc, gadd=gad)
+        assert _rel(s16, s32) < 1e-6 and _rel(dg16, dg32) < 1e-5 and _rel(db16, db32) < 1e-5
+    P16 = ops.se_bn_bwd_partials(d16, z16, a, b, mean, act)
+    P32 = ops.se_bn_bwd_partials(d16.float(), z16.float(), a, b, mean, act)
+    assert _rel(P16, P32) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,F_,T,k,s,act", DW)
+@pytest.mark.parametrize("variant", ["plain", "se"])
+def test_dw_conv_backward_bf16_storage(B, C, F_, T, k, s, act, variant):
+    """merged depthwise backward with the BatchNorm backward on load over bf16-stored (dy, z_d, z_e) -> g (bf16), dw, sum g."""
+    p = (k - 1) // 2
+    Fo, To = (F_ + 2 * p - k) // s + 1, (T + 2 * p - k) // s + 1
+    x16 = _rand(B, C, F_, T, seed=1, scale=2.5).to(DEV).bfloat16()
+    z16 = (_rand(B, C, Fo, To, seed=2, scale=1.5) + _rand(1, C, 1, 1, seed=3)).to(DEV).bfloat16()
+    dy16 = _rand(B, C, Fo, To, seed=4).to(DEV).bfloat16()
+    ia, ib = (torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5).to(DEV), _rand(C, seed=6, scale=0.3).to(DEV)
+    w = _rand(C, k * k, seed=7, scale=0.3).to(DEV)
+    st = ((torch.rand(C, generator=torch.Generator().manual_seed(8)) + 0.5).to(DEV), _rand(C, seed=9, scale=0.3).to(DEV),
+          _rand(C, seed=10, scale=0.2).to(DEV), (torch.rand(C, generator=torch.Generator().manual_seed(11)) + 0.5).to(DEV))
+    gs = ga = None
+    if variant == "se":
+        gs = (torch.rand(B, C, generator=torch.Generator().manual_seed(12)) + 0.2).to(DEV)
+        ga = _rand(B, C, seed=13, scale=0.05).to(DEV)
+    sums, _, _ = ops.bn_act_bwd_sums(dy16, z16, *st, act, gscale=gs, gadd=ga)
+    g16, gp16, dw16 = ops.dw_conv_bwd_bn_g(dy16, z16, st, act, sums, w, x16, ia, ib, act, k, s, gscale=gs, gadd=ga)
+    g32, gp32, dw32 = ops.dw_conv_bwd_bn_g(dy16.float(), z16.float(), st, act, sums, w, x16.float(), ia, ib, act, k, s, gscale=gs, gadd=ga)
+    _assert_is_rounding_of(g16, g32, "merged dw backward g")
+    assert _rel(dw16, dw32) < 2e-5, _rel(dw16, dw32)
+    gpart, outer, inner = gp16
+    sums_g = gpart[:B * C * inner].view(B, C, inner).double().sum(2).cpu()
+    ref_s = g16.double().sum((2, 3)).cpu()                                       # of the STORED g
+    assert float((sums_g - ref_s).abs().max()) < 2e-4 * max(1.0, float(ref_s.abs().max()))
+
+
+# (B, Co, Ci, F, T, which operand is bf16, SE scale, on-load transform)
+WG = [(8, 64, 256, 8, 63, "x", False, None), (8, 64, 256, 8, 63, "x", True, 2), (5, 160, 960, 4, 32, "x", True, None),
+      (3, 96, 288, 32, 250, "x", False, 1), (2, 64, 64, 64, 500, "x", False, 1), (8, 256, 64, 8, 63, "dz", False, None),
+      (5, 960, 160, 4, 32, "dz", False, None), (3, 288, 96, 32, 250, "dz", False, None), (6, 2688, 448, 8, 63, "dz", False, None),
+      (6, 448, 2688, 8, 63, "x", True, 2), (3, 24, 72, 16, 125, "x", False, 2), (9, 200, 80, 8, 63, "dz", False, None),
+      (37, 80, 184, 8, 63, "x", True, None)]
+
+
+@pytest.mark.parametrize("B,Co,Ci,F_,T,which,se,tf_act", WG)
+def test_weight_gradient_with_one_bf16_operand(B, Co, Ci, F_, T, which, se, tf_act):
+    """eat_pw_conv_wgrad_b16 (the wide-tile kernel with the bf16 operand as P) against the fp32-storage kernel in plain-bf16
+    arithmetic and against fp64 on the rounded operands."""
+    dz = _rand(B, Co, F_, T, seed=1).to(DEV)
+    x = (_rand(B, Ci, F_, T, seed=2, scale=1.5)).to(DEV)
+    sc = (torch.rand(B, Ci, generator=torch.Generator().manual_seed(3)) + 0.25).to(DEV) if se else None
+    tf = None
+    if tf_act is not None:
+        tf = ((torch.rand(Ci, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV), _rand(Ci, seed=5, scale=0.3).to(DEV), tf_act)
+    if which == "x":
+        x = x.bfloat16()
+    else:
+        dz = dz.bfloat16()
+    dW = ops.pw_conv_wgrad_b16(dz, x, x_scale=sc, tf=tf)
+    dW2 = ops.pw_conv_wgrad_b16(dz, x, x_scale=sc, tf=tf)
+    assert torch.equal(dW, dW2)                                                 # stored slices, fixed-order reduction
+    with ops.precision("bf16"):
+        ref32 = ops.pw_conv_wgrad(dz.float(), x.float(), x_scale=sc, tf=tf)
+    assert _rel(dW, ref32) < 2e-5, _rel(dW, ref32)
+    xe = x.float().double().cpu()
+    if tf is not None:
+        xe = [lambda t: t, F.relu, F.hardswish][tf_act](xe * tf[0].double().cpu()[None, :, None, None] + tf[1].double().cpu()[None, :, None, None])
+    if se:
+        xe = xe * sc.double().cpu()[:, :, None, None]
+    ref = torch.einsum("bofs,bifs->oi", _bf(dz.float()).double().cpu(), _bf(xe.float()).double())
+    assert _rel(dW, ref) < 3e-5, _rel(dW, ref)
+
+
+def test_b16_entry_points_fail_loudly():
+    """No silent fall-back: geometries / operand mixes the bf16-storage kernels do not cover are errors."""
+    x = _rand(2, 16, 9, 21, seed=1).to(DEV).bfloat16()                           # 9 x 21 planes: no register-resident kernel
+    w = _rand(16, 9, seed=2).to(DEV)
+    with pytest.raises(_lib.EatHipError):
+        ops.dw_conv_stats(x, w, 3, 1)
+    assert not ops.b16_block_ok(2, 16, 9, 21, 3, 1)
+    with pytest.raises(_lib.EatHipError):                                        # both operands bf16
+        ops.pw_conv_wgrad_b16(_rand(2, 16, 8, 8).to(DEV).bfloat16(), _rand(2, 16, 8, 8).to(DEV).bfloat16())
+    with ops.precision("auto"):                                                  # split pack: not the plain bf16 arithmetic
+        wp = ops.pw_prepack(_rand(64, 64).to(DEV))
+    with pytest.raises(_lib.EatHipError):
+        ops.pw_conv_b16(_rand(2, 64, 8, 8).to(DEV), wp, torch.zeros(64, device=DEV), 64, NONE)

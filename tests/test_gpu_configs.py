@@ -224,11 +224,12 @@ def mn40_case():
     return dict(sd=sd, x=x, y=y, keep=keep, loss=float(loss), logits=logits.detach(), grads=grads, stats=stats)
 
 
-def _mn40_step(d, precision):
+def _mn40_step(d, precision, act_storage="fp32"):
     model = _quiet(mn_mod.get_model, width_mult=4.0)
     model.load_state_dict(d["sd"], strict=True)
     model.to(DEV).train()
     model.train_precision = precision
+    model.act_storage = act_storage
     model._drop_mask_override = d["keep"]
     logits, _ = model(d["x"].to(DEV))
     loss = F.binary_cross_entropy_with_logits(logits, d["y"].to(DEV))
@@ -270,8 +271,12 @@ def test_mn40_train_step_auto_matches_oracle(mn40_case):
     assert float(np.median(list(rels.values()))) < 1e-2
 
 
-def test_mn40_train_step_bf16_tracks_oracle(mn40_case):
-    """BASELINE configs[2]: 1x1 GEMMs on plain bf16 operands (2^-9 relative round-off per operand), anchored on the
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_mn40_train_step_bf16_tracks_oracle(mn40_case, storage):
+    """storage = "bf16": BASELINE configs[2] as stated - bf16 ACTIVATION STORAGE (`model.act_storage`; the wide tensors z_e,
+    z_d, y_d and the gradients arriving at them live in bf16 in HBM) on top of the bf16 GEMM operands, against the oracle's
+    emulation of exactly that (`O.emulate_bf16_pointwise(storage=True)`) and against the fp32 oracle.
+    storage = "fp32": 1x1 GEMMs on plain bf16 operands (2^-9 relative round-off per operand), anchored on the
     ORACLE, not on our own fp32 path:
       (a) an oracle evaluation of the SAME arithmetic (`O.emulate_bf16_pointwise`: bf16-rounded operands, fp32
           accumulation; that the kernel computes exactly this per layer is test_pw_conv_bf16's tight check) - loss and
@@ -285,7 +290,7 @@ def test_mn40_train_step_bf16_tracks_oracle(mn40_case):
     d = mn40_case
     sdr = _grad_state(d["sd"])
     fwd = lambda sd, xm, **k: O.mn_forward(sd, xm, width_mult=4.0, **k)
-    with O.emulate_bf16_pointwise():
+    with O.emulate_bf16_pointwise(storage=storage == "bf16"):
         logits_e, _ = fwd(sdr, d["x"], train=True, stats={}, drop_mask=d["keep"])
         loss_e = F.binary_cross_entropy_with_logits(logits_e, d["y"])
         loss_e.backward()
@@ -294,7 +299,16 @@ def test_mn40_train_step_bf16_tracks_oracle(mn40_case):
     emu_vs_fp32 = {n: _rel(v.grad, d["grads"][n]) for n, v in sdr.items()
                    if getattr(v, "grad", None) is not None and float(d["grads"][n].norm()) >= 1e-5 * gmax}
 
-    model, loss, logits, hip_vs_fp32 = _mn40_step(d, "bf16")
+    model, loss, logits, hip_vs_fp32 = _mn40_step(d, "bf16", act_storage=storage)
+    if storage == "bf16":                 # every block with an expand conv really ran on bf16 storage
+        from efficientat_amd import ops
+        B, _, F0, T0 = d["x"].shape
+        f, t = (F0 - 1) // 2 + 1, (T0 - 1) // 2 + 1
+        for blk in model.features[1:-1]:
+            c = blk.cnf
+            if blk.i_expand is not None:
+                assert ops.b16_block_ok(B, c.expanded_channels, f, t, c.kernel, c.stride), (f, t, c.kernel, c.stride)
+            f, t = ops.conv_out(f, c.kernel, c.stride), ops.conv_out(t, c.kernel, c.stride)
     scale = float(d["logits"].abs().max())
     # (a) same arithmetic, oracle vs HIP
     assert abs(loss - float(loss_e)) < 2e-3 * abs(float(loss_e)), (loss, float(loss_e))

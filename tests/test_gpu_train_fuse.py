@@ -480,6 +480,31 @@ def test_se_gate_mlp_backward_in_two_launches(B, C, Cr, S):
         assert _rel(got, ref) < 2e-5, _rel(got, ref)
 
 
+@pytest.mark.parametrize("B,C,H,N,drop", [(256, 960, 1280, 527, True), (8, 3840, 5120, 527, True), (37, 96, 130, 10, False),
+                                           (3, 33, 7, 5, True)])
+def test_classifier_head_backward_in_two_launches(B, C, H, N, drop):
+    """eat_mlp_head_bwd against fp64 autograd of Linear -> Hardswish -> Dropout (replayed keep mask) -> Linear
+    (models/mn/model.py:186-194)."""
+    feat = _rand(B, C, seed=1)
+    W1, b1 = _rand(H, C, seed=2, scale=C ** -0.5), _rand(H, seed=3, scale=0.1)
+    W2, b2 = _rand(N, H, seed=4, scale=H ** -0.5), _rand(N, seed=5, scale=0.1)
+    mask = ((torch.rand(B, H, generator=torch.Generator().manual_seed(6)) < 0.8).float() / 0.8) if drop else None
+    dl = _rand(B, N, seed=7)
+    fr, W1r, b1r, W2r, b2r = (t.double().requires_grad_(True) for t in (feat, W1, b1, W2, b2))
+    u_ref = F.linear(fr, W1r, b1r)
+    near = (u_ref.detach().abs() - 3.0).abs() < 1e-4                     # Hardswish' jumps at +-3
+    h2_ref = F.hardswish(u_ref) * (mask.double() if drop else 1.0)
+    out = F.linear(h2_ref, W2r, b2r)
+    (out * dl.double()).sum().backward()
+    u = u_ref.detach().float().to(DEV)
+    h2 = h2_ref.detach().float().to(DEV)
+    dW1, db1, dW2, db2, dfeat = ops.mlp_head_bwd(dl.to(DEV), h2, u, mask.to(DEV) if drop else None, feat.to(DEV), W1.to(DEV),
+                                                 W2.to(DEV))
+    tol = 1e-3 if bool(near.any()) else 2e-5
+    assert _rel(dW2, W2r.grad) < 2e-5 and _rel(db2, b2r.grad) < 2e-5
+    assert _rel(dW1, W1r.grad) < tol and _rel(db1, b1r.grad) < tol and _rel(dfeat, fr.grad) < tol
+
+
 @pytest.mark.parametrize("mode", ["fp32", "auto", "bf16x3", "bf16"])
 def test_all_weight_packs_from_one_launch(mode):
     """eat_pw_prepack_multi: every pack bit-identical to the single-matrix entry points, normal and transposed."""

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 GPU call driver: gpurun --timeout 1200 -- 'bash tools/gpu_r4.sh <tag> <sections...>'
+# Round-5 GPU call driver: gpurun --timeout 1200 -- 'bash tools/gpu_r5.sh <tag> <sections...>'
 set -u
-TAG=${1:-r4a}; shift || true
+TAG=${1:-r5a}; shift || true
 WHAT="${*:-full}"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,6 +19,21 @@ if has dymnstats; then
 fi
 if has unit; then
   timeout 1500 python -m pytest ${UNIT:-tests/test_gpu_train_fuse.py} -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" | tail -60 > $OUT/unit.log; tail -40 $OUT/unit.log
+fi
+if has unit2; then
+  timeout 1500 python -m pytest ${UNIT2} -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" | tail -60 > $OUT/unit2.log; tail -40 $OUT/unit2.log
+fi
+if has mn40ab; then
+  for st in fp32 bf16; do
+    EAT_ACT_STORAGE=$st timeout 400 python bench.py --train-model mn40_bf16 --batch 128 --no-forward --no-profile --no-cpu-baseline --no-train-configs --steps 10 --warmup 3 > $OUT/mn40_$st.json 2> $OUT/mn40_$st.err
+    python - <<P
+import json
+try:
+    d=json.load(open("$OUT/mn40_$st.json")); print("mn40_bf16 storage=$st ->", d["value"], "clips/s", d["ms_per_step"], "ms")
+except Exception as e:
+    print("mn40 $st -> FAILED", e); print(open("$OUT/mn40_$st.err").read()[-3000:])
+P
+  done
 fi
 if has full; then
   timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" > $OUT/full.log; tail -40 $OUT/full.log
