@@ -1957,6 +1957,12 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
                         x_scale != nullptr, tf.actr != nullptr && !centring, tf.a != nullptr && !centring);
   // the wide-tile kernel stores one copy of dW per k-slice: it needs the workspace (eat_pw_conv_wgrad_ws with
   // n_slots >= eat_pw_wgrad_slots) and 16-byte aligned rows; without them the plan is the one without it
+  // A caller that DID bring a workspace sized it with eat_pw_wgrad_slots / eat_pw_wgrad_kernel_kind and - for this kernel -
+  // left it uninitialised: too few copies means the two plans diverged, and the atomic kernels of the fallback plan would
+  // add into garbage.  Fail instead of falling back.
+  if (p.kind == 3 && ws != nullptr && (Ci & 3) == 0 && n_slots < (int)p.nz)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_wgrad_ws: workspace of %d copies, the stored-slice kernel needs %u "
+                     "(eat_pw_wgrad_slots)", n_slots, p.nz);
   if (p.kind == 3 && !(ws != nullptr && n_slots >= (int)p.nz && (Ci & 3) == 0))
     p = wgrad_plan(B, Co, Ci, S, per_sample, exact_fp32, dz == x, x_scale != nullptr || (tf.a != nullptr && !tf.actr),
                    x_scale != nullptr, true, tf.a != nullptr && !centring);

@@ -67,7 +67,14 @@ class CtxPool(torch.autograd.Function):
         return dx
 
 
-_pending = set()          # hand-overs of dx a DyBlockMain.backward has filled and no CtxPoolCm.backward has collected yet
+# Hand-over of a block's input gradient from the main path's backward to the context path's (below).  RESTRICTION: it
+# needs the WHOLE graph to run backward (`loss.backward()` / `torch.autograd.grad` w.r.t. the parameters or the input): a
+# partial backward that stops between the two Functions would drop the main path's dx.  The hand-over dicts of a forward
+# live on the model (`_eat_handovers`, one list per model - no process-global state); the NEXT forward of that model finds
+# an uncollected dx and fails loudly, naming the cause.
+
+
+_handovers = []           # the current forward's list (= model._eat_handovers of the model being run)
 
 
 class CtxPoolCm(torch.autograd.Function):
@@ -84,8 +91,6 @@ class CtxPoolCm(torch.autograd.Function):
         # first - everything the context path's backward consumes comes out of it): the two contributions to dx are summed
         # inside this kernel instead of by a separate pass over the block input
         add = ctx.hand_over.pop("dx", None) if ctx.hand_over is not None else None
-        if ctx.hand_over is not None:
-            _pending.discard(id(ctx.hand_over))
         return ops.ctx_pool_cm_bwd(dseq.contiguous(), ctx.shape, add=add), None
 
 
@@ -168,7 +173,10 @@ class StemConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
-        return None, ops.dw_conv_wgrad(dz.contiguous(), x, 3, 2).view_as(w)
+        dw = ops.dw_conv_wgrad(dz.contiguous(), x, 3, 2).view_as(w)
+        # the stem is the last node of DyMN's backward: the step's zero arena (forward_train: begin) is done
+        ops.zero_arena.end("dymn_step")
+        return None, dw
 
 
 class PwConv(torch.autograd.Function):
@@ -472,8 +480,8 @@ def _block_train(blk, x):
 # ------------------------------------------------------------------ the fully dynamic block as ONE autograd Function
 import os as _os
 
-_FUSED_BLOCK = _os.environ.get("EAT_DYMN_FUSED", "1") != "0"
-_EPI_STATS = _os.environ.get("EAT_PW_EPI_STATS", "1") != "0"      # BatchNorm statistics in the dynamic 1x1 convs' epilogue
+_FUSED_BLOCK = True       # the dynamic block as one autograd Function (round 4; ablated blocks keep the per-layer Functions)
+_EPI_STATS = True         # BatchNorm statistics in the dynamic 1x1 convs' epilogue
 _FUSED_DW = _os.environ.get("EAT_DYMN_FUSED_DW", "1") != "0"      # A/B: the round-4 depthwise / DyReLU kernels of the block
 
 
@@ -662,7 +670,6 @@ class DyBlockMain(torch.autograd.Function):
                 dwe = None
         if ctx.hand_over is not None and ctx.needs_input_grad[3]:
             ctx.hand_over["dx"] = dx                  # collected (and added to the pools' gradient) by CtxPoolCm.backward
-            _pending.add(id(ctx.hand_over))
             dx = None
         return (None, None, None, dx, datt, dcoef, dgf, dgt, dwe, dbank_d.view_as(w_d), dbank_p.view_as(w_p), dge, dbe, dgd,
                 dbd, dgp, dbp)
@@ -676,6 +683,8 @@ def _block_train_fused(blk, x):
     fused = _FUSED_DW and To <= 512 and ops.dw_bwd_merged_ok((B, cexp, Fo, To), (B, cexp, Fq, T), k, stride)
     # (x needs a gradient: then the context path's backward always runs after the main path's and collects its dx)
     hand_over = {} if (fused and x.requires_grad) else None
+    if hand_over is not None:
+        _handovers.append(hand_over)
     h_c, g_cf, g_ct = _context_cm(blk, x, hand_over) if fused else _context(blk, x)
     convs = ([blk.exp_conv] if blk.has_expand else []) + [blk.depth_conv, blk.proj_conv]
     da = blk.depth_act
@@ -712,9 +721,15 @@ def forward_train(model, x, return_fmaps=False):
     """Train-mode `(logits, embedding)` - or `(logits, fmaps)`, models/dymn/model.py:157-195 - of DyMN with autograd
     support (models/dymn/model.py:185-200).  The fully-convolutional head (:119-130) runs as torch ops on the last 4 x 32
     map (its class count, 527, is not a multiple of 4, which the library's data-gradient GEMM needs)."""
-    if _pending:
-        _pending.clear()
-        raise _lib.EatHipError("DyMN backward: a block's input gradient was handed over but never collected")
+    global _handovers
+    prev = getattr(model, "_eat_handovers", None) or []
+    dropped = any("dx" in h for h in prev)
+    model._eat_handovers = _handovers = []         # the hand-over dicts of THIS forward (filled by _block_train_fused)
+    if dropped:
+        raise _lib.EatHipError("DyMN: the previous backward of this model ran only part of the graph - a dynamic block's input "
+                               "gradient was handed to its context path, whose backward never ran (torch.autograd.grad over "
+                               "a subset of the graph?).  The fused DyMN blocks need the whole backward; EAT_DYMN_FUSED_DW=0 "
+                               "selects the per-layer Functions, which have no such restriction.")
     ops.zero_arena.begin("dymn_step")          # one zero-filled arena per step (forward + the backward autograd runs later)
     with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters:
         return _forward_train(model, x, return_fmaps)

@@ -30,9 +30,9 @@ BN_EPS, BN_MOMENTUM = 0.001, 0.01  # models/mn/model.py:114-115
 # kernels): mn10 block 2 0.72 vs 1.13 ms, block 3 0.54 vs 0.65, block 4 0.40 vs 0.51; from C_in = 40 on the
 # fused kernel is VALU/MFMA-bound (blocks 5-7: 0.38 vs 0.24, 0.64 vs 0.39 ms) and the separate kernels win.
 # 0 disables (A/B switch).
-_FUSE_MAX_CIN = int(os.environ.get("EAT_FUSE_MAX_CIN", "24"))
+_FUSE_MAX_CIN = 24
 # stem + first block as one kernel (csrc/irb.hip, FRONT mode); 0 disables (A/B switch)
-_FUSE_FRONT = int(os.environ.get("EAT_FUSE_FRONT", "1"))
+_FUSE_FRONT = 1
 # arithmetic of the 1x1 convs in eval: fp32 | bf16x3 | bf16 | auto (see _pw_mode)
 _PW_MODE = os.environ.get("EAT_PW_MODE", "auto")
 model_url = "https://github.com/fschmid56/EfficientAT/releases/download/v0.0.1/"
@@ -309,10 +309,14 @@ def run_block(blk, w, x, pool=None):
     # early, bandwidth-bound blocks: the whole block (without SE) or expand + depthwise (with SE) in
     # one kernel, the expanded tensor stays on chip (csrc/irb.hip); late blocks are MFMA-bound
     # and keep the separate kernels
-    if "proj32" in w:
+    # (the library's size guard - 32-bit offsets inside a sample - depends on the REAL plane size: asked per call, so that
+    #  very long inputs fall back to the separate kernels instead of failing; fold time only knows the channel counts)
+    fused = "exp32" in w and ops.block_fused_supported(cnf.input_channels, cnf.expanded_channels, cnf.out_channels, cnf.kernel,
+                                                       cnf.stride, act, "proj32" in w, F=x.shape[2], T=x.shape[3])
+    if fused and "proj32" in w:
         return ops.mbconv(x, *w["exp32"], *w["dw"], *w["proj32"], cnf.expanded_channels, cnf.out_channels,
                           cnf.kernel, cnf.stride, act, res=inp if blk.use_res_connect else None)
-    if "exp32" in w:
+    if fused:
         x = ops.fused_expand_dw(x, *w["exp32"], *w["dw"], cnf.expanded_channels, cnf.kernel, cnf.stride, act, pool)
     elif (blk.i_expand is not None and w["exp"][2] == "bf16x3" and cnf.dilation == 1
           and ops.expand_dw_eligible(x.shape[1], x.shape[2], x.shape[3], cnf.kernel, cnf.stride)):

@@ -12,8 +12,6 @@ Tiny (B, C)-shaped glue of the SE gate and the head (ReLU/sigmoid/hardswish deri
 sums, transposes) uses torch elementwise ops; every GEMM / conv / reduction over activations runs
 in libeat_hip.so.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -21,15 +19,6 @@ from . import _lib, ops
 from .dp import GradReducer
 
 NONE, RELU, HSWISH, SIGMOID = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_HSWISH, ops.ACT_SIGMOID
-
-
-def _t(x):
-    return x.t().contiguous()
-
-
-def _mm_nt(x, w):
-    """x (M,K) @ w (N,K)^T on the MFMA linear kernel."""
-    return ops.linear(x, w, None, NONE)
 
 
 class _Zeros:
@@ -82,14 +71,6 @@ class _Ones(_Zeros):
 
 
 _ones = _Ones()
-
-
-# expand conv's BN + activation evaluated inside the depthwise conv / its weight gradient instead of a separate
-# bn_act_fwd pass (saves writing + re-reading the activated tensor: 2 of the 10 forward passes over expanded tensors).
-# Round 1 measured this SLOWER (25.8 vs 24.6 ms per mn10 step): the row-ring depthwise kernels load every element K
-# times and re-evaluated the activation for each.  The register-resident kernels (csrc/dw_plane.hip) load - and
-# transform - every element once: 35.8 vs 37.9 ms per step at B = 256, so it is ON by default now (=0: A/B).
-_FUSE_EXPAND_BN = os.environ.get("EAT_FUSE_EXPAND_BN", "1") == "1"
 
 
 class _GradSink:
@@ -222,30 +203,14 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             se = blk.block[blk.i_se].conc_se_layers[0]
             sp = f"{pre}.{blk.i_se}.conc_se_layers.0"
             h, pool, S_d = rec["h"], rec["pool"], rec["S_d"]
-            if _FUSE_SE_BWD:
-                # one pass over (dxs, z_d) for the gate gradient AND the BatchNorm-backward plane sums
-                st_d = rec["st_d"]
-                se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
-                ds = se_P[0]
-            elif rec["y_d"] is None:
-                st_d = rec["st_d"]
-                ds = ops.plane_dot(dxs, rec["z_d"], st_d[0], st_d[1], act)
-            else:
-                ds = ops.plane_dot(dxs, rec["y_d"])
-            if _FUSE_SE_MLP:
-                # the gate MLP's backward as two launches (csrc/se_train.hip) instead of ~25 KB-sized torch ops
-                dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d)
-                g[sp + ".fc2.weight"], g[sp + ".fc2.bias"] = dW2, db2
-                g[sp + ".fc1.weight"], g[sp + ".fc1.bias"] = dW1, db1
-            else:
-                dq = ds * scale * (1.0 - scale)
-                g[sp + ".fc2.weight"] = _mm_nt(_t(dq), _t(h))
-                g[sp + ".fc2.bias"] = dq.sum(0)
-                dh = _mm_nt(dq, _t(se.fc2.weight)) * (h > 0).float()
-                zmean = pool * (1.0 / S_d)
-                g[sp + ".fc1.weight"] = _mm_nt(_t(dh), _t(zmean))
-                g[sp + ".fc1.bias"] = dh.sum(0)
-                gadd = _mm_nt(dh, _t(se.fc1.weight)) * (1.0 / S_d)
+            # one pass over (dxs, z_d) for the gate gradient AND the BatchNorm-backward plane sums
+            st_d = rec["st_d"]
+            se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
+            ds = se_P[0]
+            # the gate MLP's backward as two launches (csrc/se_train.hip)
+            dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d)
+            g[sp + ".fc2.weight"], g[sp + ".fc2.bias"] = dW2, db2
+            g[sp + ".fc1.weight"], g[sp + ".fc1.bias"] = dW1, db1
             gscale = scale
         # depthwise conv + BN + act
         cna = blk.block[blk.i_dw]
@@ -398,20 +363,17 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
 #   * depthwise conv: sum / sum of squares of its output leave the conv kernel's epilogue as per-wave partials.
 # Expanded-resolution passes per block: forward 3 -> 2, backward 9 -> 5.
 _TRAIN_V = 2                         # (bench.py reports it; the round-2 plan behind EAT_TRAIN_V=1 was removed in round 4)
-_FUSE_SE_BWD = os.environ.get("EAT_FUSE_SE_BWD", "1") == "1"     # A/B: gate gradient + BN-backward sums in one pass
-# A/B: BatchNorm + activation (+ SE scale) of the depthwise output evaluated on load inside the project conv and its
-# weight gradient - the activated tensor y_d is never written (SE blocks: one read-only pass for the squeeze sums)
-_FUSE_DW_BN = os.environ.get("EAT_FUSE_DW_BN", "1") == "1"
-# A/B: depthwise weight gradient + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip: dw_bwd_tile_kernel)
-_MERGED_DW_BWD = os.environ.get("EAT_MERGED_DW_BWD", "1") == "1"
-_DW_BN_ON_LOAD = os.environ.get("EAT_DW_BN_ON_LOAD", "1") == "1"   # A/B: depthwise BN backward evaluated on load in the merged backward kernel
-# (a side stream for off-critical-path launches was measured in round 3 - -0.26 ms in good runs, erratic replay times of the
-#  captured step in others - and removed in round 4: DESIGN 7)
-_EPI_STATS = os.environ.get("EAT_PW_EPI_STATS", "1") != "0"      # project / last conv: BatchNorm statistics in the 1x1 epilogue
-_PREPACK_PLAN = os.environ.get("EAT_PREPACK_PLAN", "1") == "1"      # A/B: all weight packs of the step from one launch
-_FUSE_SE_MLP = os.environ.get("EAT_FUSE_SE_MLP", "1") == "1"        # A/B: SE gate MLP backward as two launches (csrc/se_train.hip)
-_FUSE_STEM = os.environ.get("EAT_FUSE_STEM", "1") == "1"        # A/B: stem without its pre-activation tensor (csrc/stem_train.hip)
-_CAT_DGRAD = os.environ.get("EAT_CAT_DGRAD", "1") == "1"        # A/B: expand data gradient + BN correction as one two-source GEMM
+# The pieces of the plan.  Each was an environment switch while it was being measured against the form it replaced
+# (rounds 3 / 4: DESIGN 3.12, 3.14); round 5 fixed them - the other branch of every test below is still LIVE code, taken
+# for the geometries / layer states the fused form does not cover (planes that are not a multiple of 4, frozen BatchNorm,
+# blocks without expand conv, SE blocks on small planes, a hipGraph capture before the pack plan exists).
+_FUSE_DW_BN = True        # BatchNorm + activation (+ SE scale) of the depthwise output on load in the project conv / its wgrad
+_MERGED_DW_BWD = True     # depthwise weight + data gradient (+ derivative epilogue) as one kernel (csrc/dw_plane.hip)
+_DW_BN_ON_LOAD = True     # ... with the depthwise BatchNorm's own backward evaluated on load
+_EPI_STATS = True         # project / last conv: BatchNorm statistics in the 1x1 epilogue
+_PREPACK_PLAN = True      # all weight packs of the step from one launch
+_FUSE_STEM = True         # stem without its pre-activation tensor (csrc/stem_train.hip)
+_CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
 
 
 def _act_storage_bf16(model):

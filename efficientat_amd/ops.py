@@ -48,7 +48,7 @@ def _dev16(t, name):
 def _is16(t):
     return t is not None and t.dtype == torch.bfloat16
 
-_KCAT = os.environ.get("EAT_DYN_KCAT", "1") == "1"   # K-concat form of the late dynamic 1x1 convs (A/B switch)
+_KCAT = True   # K-concat form of the late dynamic 1x1 convs (eval; `kcat_eligible`)
 
 
 def conv_out(n, k, stride):
@@ -182,6 +182,14 @@ class _ZeroArena:
         if self.name == name:
             self.need[name] = max(self.need.get(name, 0), self.req)
         self.name, self.buf, self.off, self.req = name, None, 0, 0
+
+    def end(self, name):
+        """Close a pass opened with `begin` (DyMN: called when the backward reaches the stem, and by GraphedTrainStep after
+        its capture): later un-scoped callers get their own `torch.zeros` again instead of slices of the step's buffer -
+        which a captured graph re-zeroes on every replay."""
+        if self.name == name:
+            self.need[name] = max(self.need.get(name, 0), self.req)
+            self.name, self.buf, self.off, self.req = None, None, 0, 0
 
     def zeros(self, shape, dtype, device):
         if self.name is None:
@@ -1051,7 +1059,7 @@ def pw_prepack_bf16(w2d, row_scale=None, split=True, trans=False):
     return wp
 
 
-_FUSE_EXPAND_DW = os.environ.get("EAT_FUSE_EXPAND_DW", "1") == "1"   # csrc/expand_dw.hip (A/B switch)
+_FUSE_EXPAND_DW = True   # expand + depthwise of the 8 x 63-class blocks as one kernel (csrc/expand_dw.hip)
 
 
 def expand_dw_eligible(Ci, F, T, k, stride):
