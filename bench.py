@@ -238,8 +238,8 @@ def _alg_bytes(name, a):
         tag = "cat" if x2 else ("true" if ta else "*")
         return f"pw_conv_bf16_kernel<{mtw},1,*,{tag},{'bf16' if x16 else 'f32'}->{'bf16' if y16 else 'f32'}>", nbytes, 2 * B * S * Ci * Co
     if name == "eat_dw_conv_fwd_stats_b16":
-        x, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:17]
-        return f"dw_conv_fwd_stats<{k},{s},bf16>", 2 * B * C * (F * T + Fo * To), 2 * B * C * Fo * To * k * k
+        x, x16, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:18]
+        return f"dw_conv_fwd_stats<{k},{s},bf16>", B * C * ((2 if x16 else 4) * F * T + 2 * Fo * To), 2 * B * C * Fo * To * k * k
     if name == "eat_bn_act_fwd_b16":
         z, aa, bb, y, pool, B, C, S, act = a[:9]
         return f"bn_act_fwd_kernel<{act},bf16>", 2 * B * C * S * (1 + (1 if y else 0)), 4 * B * C * S
@@ -251,7 +251,8 @@ def _alg_bytes(name, a):
         return "se_bn_bwd_partials_kernel<bf16>", 4 * B * C * S, 12 * B * C * S
     if name == "eat_dw_conv_bwd_bn_g_b16":
         B, C, F, T, Fo, To, k, s = a[-9:-1]
-        return (f"dw_bwd_tile_kernel<{k},{s},*,true,*,false,bf16>", 2 * B * C * (2 * Fo * To + 2 * F * T),
+        xb = 2 if a[12] else 4                                                    # x and g: bf16, or fp32 in the first block
+        return (f"dw_bwd_tile_kernel<{k},{s},*,true,*,false,bf16>", B * C * (2 * 2 * Fo * To + 2 * xb * F * T),
                 4 * B * C * F * T * k * k // (s * s) + 2 * B * C * Fo * To * k * k)
     if name == "eat_pw_conv_wgrad_b16":
         dz, d16, x, x16, ta, tb, tact, xs, dW, ws, nsl, B, Co, Ci, S = a[:15]

@@ -274,10 +274,11 @@ extern "C" int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const fl
 }
 
 // The same over bf16-stored x and y (act_io.h; the bf16-storage plan of BASELINE configs[2]: the expand conv's output z_e in,
-// the depthwise output z_d out, both 16-bit in HBM; taps, transform coefficients and statistics fp32).  The partial sums are
+// the depthwise output z_d out, both 16-bit in HBM - x_b16 = 0: x is fp32, the first block's depthwise conv reads the stem
+// output; taps, transform coefficients and statistics fp32).  The partial sums are
 // those of the ROUNDED outputs - the values the BatchNorm that follows will actually read.  Register-resident kernels only
 // (csrc/dw_plane.hip): eat_dw_conv_b16_ok tells whether a geometry is covered.
-extern "C" int eat_dw_conv_fwd_stats_b16(const void* x, const float* in_a, const float* in_b, int in_act, const float* w,
+extern "C" int eat_dw_conv_fwd_stats_b16(const void* x, int x_b16, const float* in_a, const float* in_b, int in_act, const float* w,
                                          void* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T,
                                          int Fo, int To, int k, int stride, eat_stream_t stream) {
   eat::clear_stale_error();
@@ -291,7 +292,8 @@ extern "C" int eat_dw_conv_fwd_stats_b16(const void* x, const float* in_a, const
   int inner = 1;
   const eat::DwEpi epi{part, nullptr, nullptr, nullptr, 0, nullptr, &inner};
   const int rc = eat::dw_plane_try(reinterpret_cast<const float*>(x), w, nullptr, nullptr, reinterpret_cast<float*>(y), nullptr, B,
-                                   C, F, T, Fo, To, k, stride, EAT_ACT_NONE, 0, 0, in_a, in_b, in_act, (hipStream_t)stream, &epi, 1);
+                                   C, F, T, Fo, To, k, stride, EAT_ACT_NONE, 0, 0, in_a, in_b, in_act, (hipStream_t)stream, &epi,
+                                   x_b16 ? 1 : 2);
   if (rc == 1)
     return eat::fail(EAT_EINVAL, "eat_dw_conv_fwd_stats_b16: no register-resident kernel for F=%d T=%d k=%d stride=%d", F, T, k, stride);
   *h_inner = inner;

@@ -64,7 +64,7 @@ struct PlaneArgs {
   InTf tf;
   eat::DwEpi epi;
   int per_plane_w;
-  int b16 = 0;           // x and y are bf16 in HBM (act_io.h): the statistics instance only
+  int b16 = 0;           // 1: x and y are bf16 in HBM (act_io.h), 2: y only (x fp32) - the statistics instance only
 };
 
 // d act(u) / du, PyTorch conventions (nn.ReLU / nn.Hardswish backward); `act` is wave-uniform
@@ -148,8 +148,10 @@ template <> struct Bio<eat::bf16_t> {
 // STATS: per-plane sum / sum of squares of the output (epi.stats), the BatchNorm batch statistics of the conv output
 // PPW: taps per (b,c) plane (DyMN's dynamic depthwise conv in train mode, models/dymn/dy_block.py:103-131): wave-uniform
 // scalar loads for one plane per wave, per-lane loads (one address per half-wave) for two
-// XT: storage type of x AND y (Bio; bf16 = the statistics instances of the bf16-storage plan, which sum the ROUNDED outputs)
-template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS, bool PPW = false, typename XT = float>
+// XT / YT: storage types of x / y (Bio; YT = bf16: the statistics instances of the bf16-storage plan, which sum the ROUNDED
+// outputs; XT = float with YT = bf16: the first block, whose depthwise conv reads the fp32 stem output)
+template <int K, int S, int CPL, int LPP, int F, bool PF, int ACT, int EPI, bool STATS, bool PPW = false, typename XT = float,
+          typename YT = XT>
 __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const float* __restrict__ w_,
                                                        const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2;
@@ -157,10 +159,10 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
   constexpr int NE = S == 1 ? CPL + 2 * P : K;           // extended row: input columns CPL*l - P ... as seen by lane l
   constexpr int NO = S == 1 ? CPL : 1;                   // output columns per lane
   constexpr int Fo = (F + 2 * P - K) / S + 1;
-  constexpr unsigned EB = Bio<XT>::kB;
-  static_assert(EPI == 0 || EB == 4, "residual / derivative epilogues: fp32 storage only");
+  constexpr unsigned EB = Bio<XT>::kB, EBY = Bio<YT>::kB;
+  static_assert(EPI == 0 || (EB == 4 && EBY == 4), "residual / derivative epilogues: fp32 storage only");
   const XT* const ax = reinterpret_cast<const XT*>(a.x);
-  XT* const ay = reinterpret_cast<XT*>(a.y);
+  YT* const ay = reinterpret_cast<YT*>(a.y);
   static_assert(S == 1 || CPL == 2, "stride 2: a lane owns input columns 2l, 2l+1 and output column l");
   const int lane = threadIdx.x & 63;
   const int l = lane & (LPP - 1);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
   // zeroes it; the STORE of that lane is a separate dword (vout[1]), the 8-byte store (vout[0]) skips it.
   unsigned vin, vout[NO];
   {
-    const unsigned bi = EB * (unsigned)(half * C * (F * T) + CPL * l), bo = EB * (unsigned)(half * C * (Fo * To) + NO * l);
+    const unsigned bi = EB * (unsigned)(half * C * (F * T) + CPL * l), bo = EBY * (unsigned)(half * C * (Fo * To) + NO * l);
     vin = CPL * l < T ? bi : kOOB;
     vout[0] = NO * l + NO - 1 < To ? bo : kOOB;
     if (NO == 2) vout[NO - 1] = (NO * l < To && NO * l + 1 >= To) ? bo : kOOB;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
       for (int i = 0; i < K * K / 2; ++i) { const float t = wk[i]; wk[i] = wk[K * K - 1 - i]; wk[K * K - 1 - i] = t; }
     }
     const float b = bias_ ? bias_[c] : 0.0f;
-    const long long y_left = (long long)EB * (y_elems - (long long)p * (Fo * To));
+    const long long y_left = (long long)EBY * (y_elems - (long long)p * (Fo * To));
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(ay + (size_t)p * (Fo * To), y_left);
     constexpr bool RES = EPI == 1;
     const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.y) + (size_t)p * (Fo * To), y_left);
@@ -287,16 +289,16 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
             for (int j = 0; j < NO; ++j) acc[j] = fmaf(wk[u * K + v], ext[rr][j + v], acc[j]);
         }
       }
-      const unsigned so = EB * (unsigned)(i * To);
+      const unsigned so = EBY * (unsigned)(i * To);
       if constexpr (NO == 1) {
-        float o = Bio<XT>::rnd(eat::activate<ACT>(acc[0]));
+        float o = Bio<YT>::rnd(eat::activate<ACT>(acc[0]));
         if constexpr (RES) o += buf_load(rr_, vo[0], so);
         if constexpr (EPI == 2) o *= act_deriv(fmaf(g_a, buf_load(rr_, vo[0], so), g_b), a.epi.gact);
-        Bio<XT>::st1(o, ry, vo[0], so);
+        Bio<YT>::st1(o, ry, vo[0], so);
         psum += has0 ? o : 0.0f;
         if constexpr (STATS) psq += has0 ? o * o : 0.0f;
       } else {
-        float o0 = Bio<XT>::rnd(eat::activate<ACT>(acc[0])), o1 = Bio<XT>::rnd(eat::activate<ACT>(acc[1]));
+        float o0 = Bio<YT>::rnd(eat::activate<ACT>(acc[0])), o1 = Bio<YT>::rnd(eat::activate<ACT>(acc[1]));
         if constexpr (EPI != 0) {
           const f32x2 rv = buf_load2(rr_, has0 ? 4u * (unsigned)(half * C * (Fo * To) + NO * l) : kOOB, so);
           if constexpr (EPI == 1) {
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(256) void dw_plane_kernel(const PlaneArgs a, const 
             o1 *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
           }
         }
-        Bio<XT>::st2(o0, o1, ry, vo[0], so);
-        Bio<XT>::st1(o0, ry, vo[1], so);
+        Bio<YT>::st2(o0, o1, ry, vo[0], so);
+        Bio<YT>::st1(o0, ry, vo[1], so);
         psum += (has0 ? o0 : 0.0f) + (has1 ? o1 : 0.0f);
         if constexpr (STATS) psq += (has0 ? o0 * o0 : 0.0f) + (has1 ? o1 * o1 : 0.0f);
       }
@@ -365,7 +367,10 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   if (a.epi.inner) *a.epi.inner = 1;
   if (a.b16) {                                            // bf16 storage: train-mode conv + statistics (eat_dw_conv_fwd_stats_b16)
     if (!a.epi.stats || a.per_plane_w || a.epi.gz || a.res || a.pool || a.act != EAT_ACT_NONE || a.flip) return 1;
-    hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, false, eat::bf16_t>), grid, blk, 0, s, a, a.w, a.bias);
+    if (a.b16 == 2)
+      hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, false, float, eat::bf16_t>), grid, blk, 0, s, a, a.w, a.bias);
+    else
+      hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, false, eat::bf16_t>), grid, blk, 0, s, a, a.w, a.bias);
     return eat::check_launch("eat_dw_conv_fwd_stats_b16(plane)");
   }
   if (a.per_plane_w) {                                    // DyMN train mode: plain conv (forward / flipped data gradient) or + statistics
@@ -402,15 +407,15 @@ struct TileArgs {
   int b16 = 0;           // x and y are bf16 in HBM (act_io.h): the statistics instance only
 };
 
-template <int K, int S, int RO, int ACT, int EPI, bool STATS, typename XT = float>
+template <int K, int S, int RO, int ACT, int EPI, bool STATS, typename XT = float, typename YT = XT>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const float* __restrict__ w_,
                                                       const float* __restrict__ bias_) {
   constexpr int P = (K - 1) / 2, CPL = 2, LPP = 64;
   constexpr int NE = S == 1 ? CPL + 2 * P : K;
   constexpr int NO = S == 1 ? 2 : 1;
   constexpr int FI = (RO - 1) * S + K;                   // input rows under a tile
-  constexpr unsigned EB = Bio<XT>::kB;
-  static_assert(EPI == 0 || EB == 4, "residual / derivative epilogues: fp32 storage only");
+  constexpr unsigned EB = Bio<XT>::kB, EBY = Bio<YT>::kB;
+  static_assert(EPI == 0 || (EB == 4 && EBY == 4), "residual / derivative epilogues: fp32 storage only");
   const int l = threadIdx.x & 63;
   const bool first = l == 0, last = l == 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -429,13 +434,13 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
   const int oc = S == 1 ? col_in : o_lo - 1 + l;
   const bool ok0 = oc >= o_lo && oc < o_hi, ok1 = NO == 2 && oc + 1 >= o_lo && oc + 1 < o_hi;
   unsigned vout[2];
-  vout[0] = (NO == 2 ? (ok0 && ok1) : ok0) ? EB * (unsigned)oc : kOOB;
-  vout[1] = (NO == 2 && ok0 && !ok1) ? EB * (unsigned)oc : kOOB;
+  vout[0] = (NO == 2 ? (ok0 && ok1) : ok0) ? EBY * (unsigned)oc : kOOB;
+  vout[1] = (NO == 2 && ok0 && !ok1) ? EBY * (unsigned)oc : kOOB;
   const int r0o = rc * RO, r0i = r0o * S - P;
   const long long x_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)F * T);
-  const long long y_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+  const long long y_left = (long long)EBY * ((long long)a.B * a.C - p) * ((long long)Fo * To);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const XT*>(a.x) + (size_t)p * F * T, x_left);
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(reinterpret_cast<XT*>(a.y) + (size_t)p * Fo * To, y_left);
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(reinterpret_cast<YT*>(a.y) + (size_t)p * Fo * To, y_left);
   constexpr bool RES = EPI == 1;
   const __amdgpu_buffer_rsrc_t rr_ = make_rsrc((EPI == 1 ? a.res : EPI == 2 ? a.epi.gz : a.y) + (size_t)p * Fo * To, y_left);
   const float g_a = EPI == 2 ? a.epi.ga[c] : 0.0f, g_b = EPI == 2 ? a.epi.gb[c] : 0.0f;
@@ -501,17 +506,17 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
         for (int j = 0; j < NO; ++j) acc[j] = fmaf(wk[u * K + v], ext[i * S + u][j + v], acc[j]);
     const int ro = r0o + i;
     const bool rowok = ro < Fo;                          // wave-uniform
-    const unsigned so = rowok ? EB * (unsigned)(ro * To) : 0u;
+    const unsigned so = rowok ? EBY * (unsigned)(ro * To) : 0u;
     const unsigned v0 = rowok ? vout[0] : kOOB, v1 = rowok ? vout[1] : kOOB;
     if constexpr (NO == 1) {
-      float o = Bio<XT>::rnd(eat::activate<ACT>(acc[0]));
+      float o = Bio<YT>::rnd(eat::activate<ACT>(acc[0]));
       if constexpr (RES) o += buf_load(rr_, v0, so);
       if constexpr (EPI == 2) o *= act_deriv(fmaf(g_a, buf_load(rr_, v0, so), g_b), a.epi.gact);
-      Bio<XT>::st1(o, ry, v0, so);
+      Bio<YT>::st1(o, ry, v0, so);
       psum += (rowok && ok0) ? o : 0.0f;
       if constexpr (STATS) psq += (rowok && ok0) ? o * o : 0.0f;
     } else {
-      float o0 = Bio<XT>::rnd(eat::activate<ACT>(acc[0])), o1 = Bio<XT>::rnd(eat::activate<ACT>(acc[1]));
+      float o0 = Bio<YT>::rnd(eat::activate<ACT>(acc[0])), o1 = Bio<YT>::rnd(eat::activate<ACT>(acc[1]));
       if constexpr (EPI != 0) {
         const f32x2 rv = buf_load2(rr_, (rowok && ok0) ? 4u * (unsigned)oc : kOOB, so);
         if constexpr (EPI == 1) {
@@ -521,8 +526,8 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const TileArgs a, const fl
           o1 *= act_deriv(fmaf(g_a, rv[1], g_b), a.epi.gact);
         }
       }
-      Bio<XT>::st2(o0, o1, ry, v0, so);
-      Bio<XT>::st1(o0, ry, v1, so);
+      Bio<YT>::st2(o0, o1, ry, v0, so);
+      Bio<YT>::st1(o0, ry, v1, so);
       psum += ((rowok && ok0) ? o0 : 0.0f) + ((rowok && ok1) ? o1 : 0.0f);
       if constexpr (STATS) psq += ((rowok && ok0) ? o0 * o0 : 0.0f) + ((rowok && ok1) ? o1 * o1 : 0.0f);
     }
@@ -559,7 +564,10 @@ int launch_tile(TileArgs a, const float* w, const float* bias, int act, hipStrea
   if (a.epi.inner) *a.epi.inner = a.n_rc * a.n_cs;
   if (a.b16) {                                            // bf16 storage: train-mode conv + statistics
     if (!a.epi.stats || a.epi.gz || a.res || a.pool || act != EAT_ACT_NONE || a.flip) return 1;
-    hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 0, true, eat::bf16_t>), grid, blk, 0, s, a, w, bias);
+    if (a.b16 == 2)
+      hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 0, true, float, eat::bf16_t>), grid, blk, 0, s, a, w, bias);
+    else
+      hipLaunchKernelGGL((dw_tile_kernel<K, S, RO, EAT_ACT_NONE, 0, true, eat::bf16_t>), grid, blk, 0, s, a, w, bias);
     return eat::check_launch("eat_dw_conv_fwd_stats_b16(tile)");
   }
   if (a.epi.gz) {
@@ -993,7 +1001,7 @@ struct DwBwdArgs {
   DzBn bn;
   const float* res;      // PPW: added to g (the gradient of a skip connection that ends at the conv input), or NULL
   float* gzpart;         // PPW: per-tile partials of sum g * x (x = the raw conv input), layout of gpart, or NULL
-  int b16 = 0;           // dz, bn.z, x and g are bf16 in HBM (act_io.h): the BatchNorm-on-load instances only
+  int b16 = 0;           // 1: dz, bn.z, x and g are bf16 in HBM (act_io.h), 2: dz and bn.z only - the BatchNorm-on-load instances
 };
 
 // LPP = 64: a wave owns one tile of one plane (column strips with halo lanes).  LPP = 32 / 16 (small planes, T <= 2 LPP): a
@@ -1029,8 +1037,9 @@ __device__ __forceinline__ void tap_reduce(float (&v)[NV], int l, int& vidx) {
 // PPW: taps and weight gradient per (b,c) plane (DyMN's dynamic depthwise conv, models/dymn/dy_block.py:103-131): the taps
 // of the lane group's own plane are loaded per sample, the K*K sums are reduced over the lane group after every sample and
 // stored (one tile per plane) or added (several) to dw (B, C, K*K)
-// XT: storage type of dz, bn.z, x AND g (Bio; bf16 = the bf16-storage plan: every wide tensor of the block)
-template <int K, int S, int RO, bool BN, int LPP, bool WR, bool PPW = false, typename XT = float>
+// XT: storage type of x and g, ZT: of dz and bn.z (Bio; bf16 = the bf16-storage plan: every wide tensor of the block; the
+// first block - no expand conv - has an fp32 conv input and hands an fp32 gradient to the stem: XT = float, ZT = bf16)
+template <int K, int S, int RO, bool BN, int LPP, bool WR, bool PPW = false, typename XT = float, typename ZT = XT>
 __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, const float* __restrict__ w_) {
   constexpr int P = (K - 1) / 2, KK = K * K, NPW = 64 / LPP;
   static_assert(WR || LPP == 64, "strip mode owns the whole wave");
@@ -1039,8 +1048,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   constexpr int DOFF = S == 1 ? P : 1;                             // dz-array index of the tile's first dz row
   constexpr int ND = S == 1 ? 2 : 1;                               // dz columns per lane
   constexpr int NE = S == 1 ? 2 + 2 * P : K;                       // extended x row: columns under the filter
-  constexpr unsigned EB = Bio<XT>::kB;
-  static_assert(!PPW || EB == 4, "per-plane taps: fp32 storage only");
+  constexpr unsigned EB = Bio<XT>::kB, EBZ = Bio<ZT>::kB;
+  static_assert(!PPW || (EB == 4 && EBZ == 4), "per-plane taps: fp32 storage only");
   const int lane = threadIdx.x & 63;
   const int l = lane & (LPP - 1);
   const int half = lane / LPP;                                     // which of the wave's NPW planes (samples)
@@ -1059,14 +1068,16 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   const int q = WR ? l : s_lo - 1 + l;                              // S == 2: dz column of this lane
   const int col_in = S == 1 ? (WR ? 2 * l : s_lo - 2 + 2 * l) : 2 * q;   // first of the lane's two x / dx columns
   // byte offsets inside the wave's first plane; the lane group's own plane lies `half` samples (C planes each) further on
-  const unsigned hx = EB * (unsigned)(half * a.C * (F * T)), hz = EB * (unsigned)(half * a.C * (Fo * To));
+  const unsigned hx = EB * (unsigned)(half * a.C * (F * T)), hz = EBZ * (unsigned)(half * a.C * (Fo * To));
   const bool in_part = col_in + 1 >= T;
   // (bf16: the one-column lane at the end of an odd-width row loads the dword that ENDS with its column - Bio::adj)
   const unsigned vin_b = Bio<XT>::adj((col_in >= 0 && col_in < T) ? hx + EB * (unsigned)col_in : kOOB, in_part);
   // which of the lane's positions belong to the strip (produce output / contribute to the weight gradient)
   const bool ok0_b = S == 1 ? (col_in >= s_lo && col_in < s_hi) : (q >= s_lo && q < s_hi);
   const bool ok1_b = S == 1 ? (col_in + 1 >= s_lo && col_in + 1 < s_hi) : (ok0_b && 2 * q + 1 < T);
-  const unsigned vdz_b = S == 1 ? vin_b : ((q >= 0 && q < To) ? hz + EB * (unsigned)q : kOOB);
+  // (stride 1: dz has the geometry of x - the same column pair, in dz's own element size)
+  const unsigned vdz_b = S == 1 ? Bio<ZT>::adj((col_in >= 0 && col_in < T) ? hz + EBZ * (unsigned)col_in : kOOB, in_part)
+                                : ((q >= 0 && q < To) ? hz + EBZ * (unsigned)q : kOOB);
   const int r0 = rc * RO;                                           // first dx row (S == 1) / dz row (S == 2) of the tile
   const int x0 = S == 1 ? r0 - P : 2 * r0 - P;                      // global row of x-array index 0
   const int d0 = r0 - DOFF;                                         // global row of dz-array index 0
@@ -1103,9 +1114,9 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
     // dx stores: an 8-byte store when both columns exist, else a single dword for the first
     const unsigned vo2 = (ok0 && ok1) ? hx + EB * (unsigned)col_in : kOOB, vo1 = (ok0 && !ok1) ? hx + EB * (unsigned)col_in : kOOB;
     const long long x_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)F * T);
-    const long long z_left = (long long)EB * ((long long)a.B * a.C - p) * ((long long)Fo * To);
+    const long long z_left = (long long)EBZ * ((long long)a.B * a.C - p) * ((long long)Fo * To);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const XT*>(a.x) + (size_t)p * F * T, x_left);
-    const __amdgpu_buffer_rsrc_t rz = make_rsrc(reinterpret_cast<const XT*>(a.dz) + (size_t)p * Fo * To, z_left);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(reinterpret_cast<const ZT*>(a.dz) + (size_t)p * Fo * To, z_left);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(reinterpret_cast<XT*>(a.g) + (size_t)p * F * T, x_left);
     if constexpr (PPW) {
       const float* wsrc = w_ + (size_t)(mine ? p + half * a.C : p) * KK;
@@ -1129,7 +1140,7 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       for (int i = 0; i < NZR; ++i) { xraw[i][0] = xu[i + P][0]; xraw[i][1] = xu[i + P][1]; }
     }
     if constexpr (BN) {
-      const __amdgpu_buffer_rsrc_t rzz = make_rsrc(reinterpret_cast<const XT*>(a.bn.z) + (size_t)p * Fo * To, z_left);
+      const __amdgpu_buffer_rsrc_t rzz = make_rsrc(reinterpret_cast<const ZT*>(a.bn.z) + (size_t)p * Fo * To, z_left);
       const int pm = mine ? p + half * a.C : p;                     // this lane group's plane (per-plane SE constants)
       const float gs = a.bn.gscale ? a.bn.gscale[pm] : 1.0f, ga = a.bn.gadd ? a.bn.gadd[pm] : 0.0f;
       // validity as a 0 / 1 factor (operands are 0 outside the plane, so every term is finite): a select around dzf would
@@ -1148,16 +1159,16 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
       for (int i = 0; i < FD; ++i) {
         const int rin = d0 + i;
         const bool rok = rin >= 0 && rin < Fo;                    // wave-uniform
-        const unsigned so = rok ? EB * (unsigned)(rin * To) : 0u;
+        const unsigned so = rok ? EBZ * (unsigned)(rin * To) : 0u;
         if constexpr (ND == 2) {
-          const f32x2 pv = Bio<XT>::ld2(rz, rok ? vdz : kOOB, so, in_part);
-          const f32x2 zv = Bio<XT>::ld2(rzz, rok ? vdz : kOOB, so, in_part);
+          const f32x2 pv = Bio<ZT>::ld2(rz, rok ? vdz : kOOB, so, in_part);
+          const f32x2 zv = Bio<ZT>::ld2(rzz, rok ? vdz : kOOB, so, in_part);
           const float mr = eat::opaque(rok ? 1.0f : 0.0f);
           dd[i][0] = dzf(pv[0], zv[0], m0 * mr);
           dd[i][1] = dzf(pv[1], zv[1], m1v * mr);
         } else {
-          const float pv = Bio<XT>::ld1(rz, rok ? vdz : kOOB, so);
-          const float zv = Bio<XT>::ld1(rzz, rok ? vdz : kOOB, so);
+          const float pv = Bio<ZT>::ld1(rz, rok ? vdz : kOOB, so);
+          const float zv = Bio<ZT>::ld1(rzz, rok ? vdz : kOOB, so);
           dd[i][0] = dzf(pv, zv, m0 * eat::opaque(rok ? 1.0f : 0.0f));
         }
       }
@@ -1167,11 +1178,11 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
         const int rin = d0 + i;
         const bool rok = rin >= 0 && rin < Fo;
         if constexpr (ND == 2) {
-          const f32x2 pv = Bio<XT>::ld2(rz, rok ? vdz : kOOB, rok ? EB * (unsigned)(rin * To) : 0u, in_part);
+          const f32x2 pv = Bio<ZT>::ld2(rz, rok ? vdz : kOOB, rok ? EBZ * (unsigned)(rin * To) : 0u, in_part);
           dd[i][0] = pv[0];
           dd[i][1] = in_part ? 0.0f : pv[1];
         } else {
-          dd[i][0] = Bio<XT>::ld1(rz, rok ? vdz : kOOB, rok ? EB * (unsigned)(rin * To) : 0u);
+          dd[i][0] = Bio<ZT>::ld1(rz, rok ? vdz : kOOB, rok ? EBZ * (unsigned)(rin * To) : 0u);
         }
       }
     }
@@ -1402,10 +1413,15 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s, bool
   if (a.b16) {
     using BT = eat::bf16_t;
     if (!bn) return 1;
-    if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true, false, BT>), grid, dim3(256), 0, s, a, w);
-    else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false, false, BT>), grid, dim3(256), 0, s, a, w);
-    else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32, true, false, BT>), grid, dim3(256), 0, s, a, w);
-    else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true, false, BT>), grid, dim3(256), 0, s, a, w);
+#define EAT_BWD16(XT_)                                                                                                          \
+    do {                                                                                                                          \
+      if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true, false, XT_, BT>), grid, dim3(256), 0, s, a, w);  \
+      else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false, false, XT_, BT>), grid, dim3(256), 0, s, a, w); \
+      else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32, true, false, XT_, BT>), grid, dim3(256), 0, s, a, w);  \
+      else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true, false, XT_, BT>), grid, dim3(256), 0, s, a, w);                \
+    } while (0)
+    if (a.b16 == 2) EAT_BWD16(float); else EAT_BWD16(BT);          // 2: x and g fp32 (a block without expand conv)
+#undef EAT_BWD16
     return eat::check_launch("eat_dw_conv_bwd_bn_g_b16");
   }
   if (!bn) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, false, 64, false>), grid, dim3(256), 0, s, a, w);

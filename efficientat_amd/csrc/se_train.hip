@@ -18,15 +18,21 @@
 namespace {
 
 // one 32 x 32 output tile: out(m, n) = sum_k A(m, k) B(k, n); A_MFAST: A is contiguous along m (else along k); B is
-// contiguous along n.  256 threads, 4 outputs per thread (rows ty, ty + 8, ty + 16, ty + 24 of column tx).  The k axis
-// goes through LDS in chunks of 128: 16 + 16 loads per thread in flight per barrier pair (chunks of 32 left the kernel
-// waiting on one memory latency per 32 k: 55 us for K = 960).
+// contiguous along n.  256 threads = 4 waves, each one 16 x 16 quadrant on the fp32 matrix cores (v_mfma_f32_16x16x4_f32:
+// fp32 products and accumulation - round 5; the round-3 form multiplied on the vector ALUs, 4 outputs per thread, which at
+// mn40's widths - 3840 x 960 gates, a 3840 -> 5120 -> 527 head - ran at 14 TFLOP/s: 2.1 + 0.65 ms of a 46 ms step).  The k
+// axis goes through LDS in chunks of 128: 16 + 16 loads per thread in flight per barrier pair (chunks of 32 left the
+// kernel waiting on one memory latency per 32 k: 55 us for K = 960).
 constexpr int kKC = 128;
 template <bool A_MFAST, class FA, class FB, class FS>
 __device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, FA a_at, FB b_at, FS store) {
   __shared__ float sA[kKC][33], sB[kKC][33];        // sA[k][m], sB[k][n]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ms = 16 * (wv >> 1), ns = 16 * (wv & 1);                 // this wave's quadrant of the tile
+  f32x4 acc{0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < K; k0 += kKC) {
     float av[16], bv[16];
 #pragma unroll
@@ -48,18 +54,18 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, F
       sB[ty + 8 * i][tx] = bv[i];
     }
     __syncthreads();
-    const int kn = (K - k0) < kKC ? (K - k0) : kKC;
-    for (int kk = 0; kk < kn; ++kk) {
-      const float b = sB[kk][tx];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = fmaf(sA[kk][ty + 8 * i], b, acc[i]);
-    }
+    // rows of the chunk beyond K were stored as zeros: whole 4-k steps
+    const int kn = (K - k0) < kKC ? ((K - k0 + 3) & ~3) : kKC;
+    // A operand: lane (m = l15, k = kq); B operand: lane (k = kq, n = l15); D: lane holds rows 4 kq + r of column l15
+#pragma unroll 4
+    for (int kk = 0; kk < kn; kk += 4)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sA[kk + kq][ms + l15], sB[kk + kq][ns + l15], acc, 0, 0, 0);
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty + 8 * i, n = n0 + tx;
-    if (m < M && n < N) store(m, n, acc[i]);
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + ms + 4 * kq + r, n = n0 + ns + l15;
+    if (m < M && n < N) store(m, n, acc[r]);
   }
 }
 

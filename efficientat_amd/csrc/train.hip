@@ -1748,11 +1748,11 @@ extern "C" int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float
 }
 
 // The same over bf16-stored dy, z, x and g (act_io.h; the bf16-storage plan of BASELINE configs[2]): every wide tensor the
-// backward of a block touches is 16-bit in HBM; coefficients, channel sums, taps, dw and the partial sums (taken of the g
-// values as stored) are fp32 / fp64 as above.
+// backward of a block touches is 16-bit in HBM (x_b16 = 0: x and g are fp32 - the first block, whose conv input is the stem
+// output); coefficients, channel sums, taps, dw and the partial sums (taken of the g values as stored) are fp32 / fp64.
 extern "C" int eat_dw_conv_bwd_bn_g_b16(const void* dy, const void* z, const float* bn_a, const float* bn_b,
                                         const float* bn_mean, const float* bn_invstd, const float* gscale, const float* gadd,
-                                        const double* sums, int bn_act, int frozen, const void* x, const float* in_a,
+                                        const double* sums, int bn_act, int frozen, const void* x, int x_b16, const float* in_a,
                                         const float* in_b, int in_act, const float* w, void* g, float* dw, float* gpart,
                                         int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
                                         int stride, eat_stream_t stream) {
@@ -1767,7 +1767,7 @@ extern "C" int eat_dw_conv_bwd_bn_g_b16(const void* dy, const void* z, const flo
   const eat::DwBnBwd bn{reinterpret_cast<const float*>(z), bn_a, bn_b, bn_mean, bn_invstd, gscale, gadd, sums, bn_act, frozen};
   const int rc = eat::dw_bwd_try(reinterpret_cast<const float*>(dy), reinterpret_cast<const float*>(x), in_a, in_b, in_act, w,
                                  reinterpret_cast<float*>(g), dw, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
-                                 (hipStream_t)stream, &bn, 0, nullptr, nullptr, 1);
+                                 (hipStream_t)stream, &bn, 0, nullptr, nullptr, x_b16 ? 1 : 2);
   if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_bwd_bn_g_b16: merged kernel unavailable");
   return rc;
 }

@@ -446,9 +446,10 @@ class MNTrainFunction2(torch.autograd.Function):
             cna_d = blk.block[blk.i_dw]
             w_d = cna_d[0].weight.reshape(-1, k * k)
             tf = None
-            # bf16 storage of this block's wide tensors (z_e, z_d, y_d; backward: dxs, g) where the kernels cover its geometry;
-            # a block without expand conv reads the fp32 block input in its depthwise conv and keeps fp32 storage
-            b16 = (store16 and blk.i_expand is not None and cna_d[1].training
+            # bf16 storage of this block's wide tensors (z_e, z_d, y_d; backward: dxs, g) where the kernels cover its geometry
+            # (a block without expand conv: its depthwise conv reads the fp32 block input and its backward hands an fp32
+            # gradient to the layer below - z_d, y_d and dxs are the bf16 tensors there)
+            b16 = (store16 and cna_d[1].training
                    and ops.b16_block_ok(B, cnf.expanded_channels, inp.shape[2], inp.shape[3], k, cnf.stride))
             rec["b16"] = b16
             if blk.i_expand is not None:
@@ -477,7 +478,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 tf = (st_e[0], st_e[1], act)
             src = z_e if blk.i_expand is not None else inp
             if cna_d[1].training:
-                z_d, parts = ops.dw_conv_stats(src, w_d, k, cnf.stride, tf=tf)
+                z_d, parts = ops.dw_conv_stats(src, w_d, k, cnf.stride, tf=tf, out_b16=b16)
                 st_d = ops.bn_state_from_partials(parts, cna_d[1], z_d.numel() // cnf.expanded_channels)
             else:
                 if tf is not None:

@@ -496,19 +496,22 @@ def dw_partials_inner(F, T, Fo, To, k, stride, dgrad):
     return int(_lib.lib().eat_dw_partials_inner(F, T, Fo, To, k, stride, 1 if dgrad else 0))
 
 
-def dw_conv_stats(x, w, k, stride, tf=None):
+def dw_conv_stats(x, w, k, stride, tf=None, out_b16=False):
     """Train-mode depthwise conv + the partial sums of its output for the BatchNorm that follows.
     tf = (in_a, in_b, in_act): the conv input is act(in_a[c] x + in_b[c]) evaluated on load.
-    -> (y, (part, outer, inner)) for `bn_state_from_partials`."""
+    -> (y, (part, outer, inner)) for `bn_state_from_partials`.  A bf16 x - or out_b16 with an fp32 x - selects the
+    bf16-storage kernels: y bf16, statistics of the stored values."""
     B, C, F, T = x.shape
     Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
     cap = dw_partials_inner(F, T, Fo, To, k, stride, False)
-    y = torch.empty((B, C, Fo, To), device=x.device, dtype=x.dtype)
+    x16 = _is16(x)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.bfloat16 if (x16 or out_b16) else torch.float32)
     part = torch.empty((B * 2 * C * cap,), device=x.device, dtype=torch.float32)
     inner = _ct.c_int(0)
     a, b, act = tf if tf is not None else (None, None, 0)
-    if _is16(x):                                   # bf16 storage: z_e in, z_d out, statistics of the stored z_d
-        _lib.call("eat_dw_conv_fwd_stats_b16", _dev16(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w, "w"),
+    if x16 or out_b16:                             # bf16 storage: z_e (or the fp32 stem output) in, z_d out, statistics of the stored z_d
+        _lib.call("eat_dw_conv_fwd_stats_b16", _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(a, "in_a"),
+                  _opt(b, "in_b"), act, _dev(w, "w"),
                   y.data_ptr(), part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
         return y, (part, B, inner.value)
     _lib.call("eat_dw_conv_fwd_stats", _dev(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w, "w"), y.data_ptr(),
@@ -646,8 +649,8 @@ def dw_conv_bwd_bn_g(dy, z, st, act, sums, w, x, in_a, in_b, in_act, k, stride, 
     Fo, To = z.shape[2], z.shape[3]
     h = _lib.lib()
     cap = int(h.eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
-    b16 = _is16(z)                                 # bf16 storage: dy, z, x and g are bf16 together
-    g = torch.empty((B, C, F, T), device=z.device, dtype=z.dtype)
+    b16 = _is16(z)                                 # bf16 storage: dy and z bf16; x and g bf16 (or both fp32: the first block)
+    g = torch.empty((B, C, F, T), device=z.device, dtype=x.dtype if b16 else torch.float32)
     gpart = torch.empty((B * C * cap,), device=z.device, dtype=torch.float32) if want_gsum else None
     dw = zero_arena.zeros((C, k * k), torch.float32, z.device)
     inner = _ct.c_int(0)
@@ -655,7 +658,8 @@ def dw_conv_bwd_bn_g(dy, z, st, act, sums, w, x, in_a, in_b, in_act, k, stride, 
     if b16:
         _lib.call("eat_dw_conv_bwd_bn_g_b16", _dev16(dy, "dy"), _dev16(z, "z"), st[0].data_ptr(), st[1].data_ptr(),
                   st[2].data_ptr(), st[3].data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), sums.data_ptr(), act, frozen,
-                  _dev16(x, "x"), in_a.data_ptr(), in_b.data_ptr(), in_act, _dev(w, "w"), g.data_ptr(), dw.data_ptr(),
+                  _dev16(x, "x") if _is16(x) else _dev(x, "x"), 1 if _is16(x) else 0, in_a.data_ptr(), in_b.data_ptr(), in_act,
+                  _dev(w, "w"), g.data_ptr(), dw.data_ptr(),
                   None if gpart is None else gpart.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride,
                   _stream())
         return g, ((gpart, B, inner.value) if want_gsum else None), dw

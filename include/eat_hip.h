@@ -672,11 +672,11 @@ int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const
                         const float* tf_a, const float* tf_b, int tf_act, const float* in_scale, const float* res, void* y,
                         int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act, eat_stream_t stream);
 
-/* Twin of eat_dw_conv_fwd_stats (models/mn/block_types.py:150-162 under model.train()): x, y bf16; partial sums of the rounded
- * outputs.  eat_dw_conv_b16_ok(...) != 0 where this and eat_dw_conv_bwd_bn_g_b16 cover the geometry (a plan keeps fp32
+/* Twin of eat_dw_conv_fwd_stats (models/mn/block_types.py:150-162 under model.train()): y bf16, x bf16 (x_b16 != 0) or fp32
+ * (the first block's depthwise conv reads the stem output); partial sums of the rounded outputs.  eat_dw_conv_b16_ok(...) != 0 where this and eat_dw_conv_bwd_bn_g_b16 cover the geometry (a plan keeps fp32
  * storage for the other blocks). */
 int eat_dw_conv_b16_ok(int B, int C, int F, int T, int Fo, int To, int k, int stride);
-int eat_dw_conv_fwd_stats_b16(const void* x, const float* in_a, const float* in_b, int in_act, const float* w, void* y,
+int eat_dw_conv_fwd_stats_b16(const void* x, int x_b16, const float* in_a, const float* in_b, int in_act, const float* w, void* y,
                               float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
                               int stride, eat_stream_t stream);
 
@@ -692,10 +692,11 @@ int eat_bn_act_bwd_reduce_b16(const void* dy, const void* z, const float* a, con
 int eat_se_bn_bwd_partials_b16(const void* d, const void* z, const float* a, const float* b, const float* mean, float* P,
                                int B, int C, int S, int act, eat_stream_t stream);
 
-/* Twin of eat_dw_conv_bwd_bn_g (backward of block_types.py:138-162): dy, z, x and the output g are bf16. */
+/* Twin of eat_dw_conv_bwd_bn_g (backward of block_types.py:138-162): dy and z are bf16; x and the output g are bf16
+ * (x_b16 != 0) or both fp32 (the first block). */
 int eat_dw_conv_bwd_bn_g_b16(const void* dy, const void* z, const float* bn_a, const float* bn_b, const float* bn_mean,
                              const float* bn_invstd, const float* gscale, const float* gadd, const double* sums, int bn_act,
-                             int frozen, const void* x, const float* in_a, const float* in_b, int in_act, const float* w,
+                             int frozen, const void* x, int x_b16, const float* in_a, const float* in_b, int in_act, const float* w,
                              void* g, float* dw, float* gpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo,
                              int To, int k, int stride, eat_stream_t stream);
 

@@ -169,9 +169,9 @@ class _GradBf16(torch.autograd.Function):
 class emulate_bf16_pointwise:
     """with O.emulate_bf16_pointwise(): every 1x1 convolution of mn_forward runs as `_PwBf16`.
     storage=True additionally emulates `act_storage="bf16"` (efficientat_amd/mn_train.py; the reference's 16-bit mixed
-    precision, ex_pl_audioset.py:287-293): in every inverted-residual block with an expand conv the expand output z_e, the
-    depthwise output z_d and its activated form y_d are rounded to bf16 where they are stored, and so are the two wide
-    gradients of the backward - the one arriving at the project conv's input and g = dL/d(BN output of the expand conv)."""
+    precision, ex_pl_audioset.py:287-293): in every inverted-residual block the expand output z_e, the depthwise output z_d
+    and its activated form y_d are rounded to bf16 where they are stored, and so are the two wide gradients of the
+    backward - the one arriving at the project conv's input and g = dL/d(BN output of the expand conv)."""
 
     def __init__(self, storage=False):
         self.storage = storage
@@ -238,7 +238,7 @@ def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True, se_dims=(1,)
     inp, j = x, 0
     a = "hs" if c["hs"] else "re"
     dil = c.get("dil", 1)
-    st16 = ST_BF16 and train and c["cexp"] != c["cin"]      # (a block without expand conv keeps fp32 storage)
+    st16 = ST_BF16 and train       # (a block without expand conv: z_d, y_d and the project conv's data gradient only)
     if c["cexp"] != c["cin"]:
         x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, a, store="expand" if st16 else None)
         j += 1

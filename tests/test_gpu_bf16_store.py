@@ -134,6 +134,14 @@ def test_dw_conv_statistics_bf16_storage(B, C, F_, T, k, s, act):
         st = part[:outer * 2 * C * inner].view(outer, 2, C, inner).double().sum((0, 3)).cpu()
         yd = y16.double().cpu()
         assert _rel(st[0], yd.sum((0, 2, 3))) < 1e-5 and _rel(st[1], (yd ** 2).sum((0, 2, 3))) < 1e-5, use_tf
+    # the first block's form: fp32 input (the stem output), bf16 output
+    xf = x16.float() + 2.0 ** -12 * _rand(B, C, F_, T, seed=9).to(DEV)           # not bf16-representable
+    y16, parts = ops.dw_conv_stats(xf, w, k, s, out_b16=True)
+    y32, _ = ops.dw_conv_stats(xf, w, k, s)
+    _assert_is_rounding_of(y16, y32, "dw conv f32 -> bf16")
+    part, outer, inner = parts
+    st = part[:outer * 2 * C * inner].view(outer, 2, C, inner).double().sum((0, 3)).cpu()
+    assert _rel(st[0], y16.double().cpu().sum((0, 2, 3))) < 1e-5
 
 
 @pytest.mark.parametrize("B,C,S,act", [(3, 64, 8000, 1), (5, 672, 504, 2), (7, 960, 128, 2), (2, 16, 32000, 0), (300, 120, 2000, 2)])
@@ -163,12 +171,15 @@ def test_bn_act_forward_and_reduce_bf16_storage(B, C, S, act):
 
 
 @pytest.mark.parametrize("B,C,F_,T,k,s,act", DW)
-@pytest.mark.parametrize("variant", ["plain", "se"])
+@pytest.mark.parametrize("variant", ["plain", "se", "first_block"])
 def test_dw_conv_backward_bf16_storage(B, C, F_, T, k, s, act, variant):
-    """merged depthwise backward with the BatchNorm backward on load over bf16-stored (dy, z_d, z_e) -> g (bf16), dw, sum g."""
+    """merged depthwise backward with the BatchNorm backward on load over bf16-stored (dy, z_d, z_e) -> g (bf16), dw, sum g;
+    first_block: the conv input x and the output g are fp32 (a block without expand conv), dy and z_d bf16."""
     p = (k - 1) // 2
     Fo, To = (F_ + 2 * p - k) // s + 1, (T + 2 * p - k) // s + 1
     x16 = _rand(B, C, F_, T, seed=1, scale=2.5).to(DEV).bfloat16()
+    if variant == "first_block":
+        x16 = x16.float() + 2.0 ** -12 * _rand(B, C, F_, T, seed=21).to(DEV)     # an fp32 tensor that is not bf16-representable
     z16 = (_rand(B, C, Fo, To, seed=2, scale=1.5) + _rand(1, C, 1, 1, seed=3)).to(DEV).bfloat16()
     dy16 = _rand(B, C, Fo, To, seed=4).to(DEV).bfloat16()
     ia, ib = (torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5).to(DEV), _rand(C, seed=6, scale=0.3).to(DEV)
@@ -182,7 +193,10 @@ def test_dw_conv_backward_bf16_storage(B, C, F_, T, k, s, act, variant):
     sums, _, _ = ops.bn_act_bwd_sums(dy16, z16, *st, act, gscale=gs, gadd=ga)
     g16, gp16, dw16 = ops.dw_conv_bwd_bn_g(dy16, z16, st, act, sums, w, x16, ia, ib, act, k, s, gscale=gs, gadd=ga)
     g32, gp32, dw32 = ops.dw_conv_bwd_bn_g(dy16.float(), z16.float(), st, act, sums, w, x16.float(), ia, ib, act, k, s, gscale=gs, gadd=ga)
-    _assert_is_rounding_of(g16, g32, "merged dw backward g")
+    if variant == "first_block":
+        assert g16.dtype == torch.float32 and _rel(g16, g32) < 2e-6, _rel(g16, g32)
+    else:
+        _assert_is_rounding_of(g16, g32, "merged dw backward g")
     assert _rel(dw16, dw32) < 2e-5, _rel(dw16, dw32)
     gpart, outer, inner = gp16
     sums_g = gpart[:B * C * inner].view(B, C, inner).double().sum(2).cpu()

@@ -300,14 +300,13 @@ def test_mn40_train_step_bf16_tracks_oracle(mn40_case, storage):
                    if getattr(v, "grad", None) is not None and float(d["grads"][n].norm()) >= 1e-5 * gmax}
 
     model, loss, logits, hip_vs_fp32 = _mn40_step(d, "bf16", act_storage=storage)
-    if storage == "bf16":                 # every block with an expand conv really ran on bf16 storage
+    if storage == "bf16":                 # every block really ran on bf16 storage
         from efficientat_amd import ops
         B, _, F0, T0 = d["x"].shape
         f, t = (F0 - 1) // 2 + 1, (T0 - 1) // 2 + 1
         for blk in model.features[1:-1]:
             c = blk.cnf
-            if blk.i_expand is not None:
-                assert ops.b16_block_ok(B, c.expanded_channels, f, t, c.kernel, c.stride), (f, t, c.kernel, c.stride)
+            assert ops.b16_block_ok(B, c.expanded_channels, f, t, c.kernel, c.stride), (f, t, c.kernel, c.stride)
             f, t = ops.conv_out(f, c.kernel, c.stride), ops.conv_out(t, c.kernel, c.stride)
     scale = float(d["logits"].abs().max())
     # (a) same arithmetic, oracle vs HIP
