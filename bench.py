@@ -235,8 +235,8 @@ def _alg_bytes(name, a):
         mtw = (mt + chunks - 1) // chunks
         cw = (c1 if x2 else Ci) if x16 else 0                                      # bf16 input channels
         nbytes = B * S * (2 * cw + 4 * (Ci - cw) + (2 if y16 else 4) * Co + (4 * Co if res else 0)) + 2 * Co * Ci
-        tag = "cat" if x2 else ("true" if ta else "*")
-        return f"pw_conv_bf16_kernel<{mtw},1,*,{tag},{'bf16' if x16 else 'f32'}->{'bf16' if y16 else 'f32'}>", nbytes, 2 * B * S * Ci * Co
+        return (f"pw_conv_bf16_kernel<{mtw},1,*,{'true' if ta else 'false'},{'bf16' if x16 else 'float'},{'bf16' if y16 else 'float'}>",
+                nbytes, 2 * B * S * Ci * Co)
     if name == "eat_dw_conv_fwd_stats_b16":
         x, x16, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:18]
         return f"dw_conv_fwd_stats<{k},{s},bf16>", B * C * ((2 if x16 else 4) * F * T + 2 * Fo * To), 2 * B * C * Fo * To * k * k
@@ -256,7 +256,7 @@ def _alg_bytes(name, a):
                 4 * B * C * F * T * k * k // (s * s) + 2 * B * C * Fo * To * k * k)
     if name == "eat_pw_conv_wgrad_b16":
         dz, d16, x, x16, ta, tb, tact, xs, dW, ws, nsl, B, Co, Ci, S = a[:15]
-        return "pw_wgrad_wide_kernel<1,*,bf16>", B * S * ((2 if d16 else 4) * Co + (2 if x16 else 4) * Ci) + 4 * Co * Ci, 2 * B * S * Co * Ci
+        return f"pw_wgrad_wide_kernel<1,{'true' if x16 else 'false'},*,true,*>", B * S * ((2 if d16 else 4) * Co + (2 if x16 else 4) * Ci) + 4 * Co * Ci, 2 * B * S * Co * Ci
     # ---- round 4: every entry point of the training steps has a byte model (argument order = include/eat_hip.h)
     if name in ("eat_dw_conv_bwd_bn_g", "eat_dw_conv_dyn_bwd_bn_g"):
         B, C, F, T, Fo, To, k, s = a[-9:-1]
@@ -382,6 +382,25 @@ _ACCESS_CLASS = {"pw_conv_kernel": "lds16", "pw_conv_bf16_kernel": "lds16", "pw_
                  "dw_conv_kernel": "b4", "irb_kernel": "b4", "stem_conv_kernel": "b4", "dyrelu_ca_fwd_kernel": "b4",
                  "dyrelu_ca_bwd_kernel": "b4", "ctx_pool_kernel": "b4", "col_sum_kernel": "b4"}
 # byte-model labels (an entry point runs one of several kernels) -> kernel family in the PMC file
+PMC_FILES = ("pmc_traffic_r5.json", "pmc_traffic_r4.json", "pmc_traffic_r3.json")
+
+
+def pmc_step_bytes(phase):
+    """Calibrated FETCH + WRITE bytes of one whole step of the committed PMC pass (every dispatch, torch's included), or None."""
+    for tfile in PMC_FILES:
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        if os.path.exists(tpath):
+            doc = json.load(open(tpath))
+            step, cal = doc.get(phase + "_step"), doc.get("calibration")
+            if step and cal:
+                ff, fw = cal["fetch_factor"]["b16"], cal["write_factor"]["b16"]
+                return {"bytes": int((ff * step["fetch_kib_total"] + fw * step["write_kib_total"]) * 1024),
+                        "source": f"profiles/{tfile}: sum over the {step['dispatches_per_step'][0]} dispatches of one step, "
+                                  f"FETCH_SIZE x {ff:.2f} + WRITE_SIZE x {fw:.2f}"}
+            return None
+    return None
+
+
 _PMC_FAMILY = {"dw_conv_fwd_stats": "dw_tile_kernel", "se_mlp_bwd_kernels": "se_mlp_bwd_kernel", "pw_wgrad_dyn": "pw_wgrad_x3_kernel"}
 
 _HAS_MFMA = ("pw_conv_kernel", "pw_conv_bf16_kernel", "pw_expand_kernel", "pw_kstream_kernel", "expand_dw_kernel", "irb_kernel",
@@ -395,11 +414,33 @@ def roofline_of(name, d, args):
     per_launch_flops = d["flops"] / d["launches"]
     per_launch_s = d["total_ms"] * 1e-3 / d["launches"]
     traffic, tsrc = None, None
-    for tfile in ("pmc_traffic_r4.json", "pmc_traffic_r3.json"):
+    for tfile in PMC_FILES:
         tpath = os.path.join(ROOT, "profiles", tfile)
         if not os.path.exists(tpath):
             continue
         doc = json.load(open(tpath))
+        step = doc.get(args.get("phase", "train") + "_step")
+        cal = doc.get("calibration")
+        if step and cal:
+            # round 5: counter sums over the launches of this family INSIDE one step of the PMC pass - the same layers and
+            # grids whose algorithmic bytes `alg_bytes_per_launch` averages (tools/pmc_traffic.py)
+            pat = name.replace(" ", "")
+            hit = {kk: v for kk, v in step["kernels"].items() if fnmatch.fnmatchcase(kk, pat)}
+            if not hit:
+                fam = _PMC_FAMILY.get(name.split("<")[0], name.split("<")[0])
+                hit = {kk: v for kk, v in step["kernels"].items() if kk.split("<")[0] == fam}
+            if hit:
+                n = sum(v["launches"] for v in hit.values())
+                fetch = sum(v["fetch_kib"] for v in hit.values()) * 1024
+                write = sum(v["write_kib"] for v in hit.values()) * 1024
+                cls = _ACCESS_CLASS.get(name.split("<")[0], "b16")
+                ff, fw = cal["fetch_factor"][cls], cal["write_factor"][cls]
+                traffic = int((ff * fetch + fw * write) / max(1, n))
+                tsrc = (f"profiles/{tfile}: rocprofv3 (FETCH_SIZE {fetch / 1e6:.1f} MB x {ff:.2f} + WRITE_SIZE {write / 1e6:.1f} MB x "
+                        f"{fw:.2f}) / {n} = the {n} launches of this family in ONE step of the PMC pass"
+                        + ("" if n == d["launches"] else f" (the timed step has {d['launches']}: the two launch sets differ)")
+                        + "; factors = known bytes / counter of eat_calib_copy in the same passes")
+                break
         ks = doc["kernels"]
         # `*` in our symbol stands for template arguments chosen inside the library (tile rows, stages)
         hit = [v for kk, v in ks.items() if fnmatch.fnmatchcase(kk, name.replace(" ", ""))]
@@ -632,7 +673,8 @@ def forward_bench(args, mel, model, wave, ranks):
                 model(mel(wave).unsqueeze(1))
     for _ in range(args.warmup):
         run()
-    el = ranks.timed(run, args.steps)
+    els = sorted(ranks.timed(run, args.steps) for _ in range(max(1, getattr(args, "reps", 1))))
+    el = els[len(els) // 2]                                   # median repetition (each: exactly args.steps steps)
     return ranks.world * wave.shape[0] * args.steps / el, el / args.steps * 1e3, launch
 
 
@@ -717,7 +759,11 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
             e.record()
             evs.append((e, time.perf_counter()))
             return inner()
-    el = ranks.timed(lambda: out.__setitem__("loss", tstep()), steps)
+    # median of `reps` repetitions; every repetition times EXACTLY `steps` steps between barrier +
+    # synchronize pairs (max over ranks) - the reported value / ms_per_step are those of the median repetition
+    reps = max(1, getattr(args, "reps", 1))
+    els = sorted(ranks.timed(lambda: out.__setitem__("loss", tstep()), steps) for _ in range(reps))
+    el = els[len(els) // 2]
     if evs:
         gaps = [round(evs[i][0].elapsed_time(evs[i + 1][0]), 2) for i in range(len(evs) - 1)]
         host = [round((evs[i + 1][1] - evs[i][1]) * 1e3, 2) for i in range(len(evs) - 1)]
@@ -727,7 +773,7 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
     alg = ALG_TRAIN.get(name)
     res = {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
            "warmup": max(2, warmup), "batch_per_gpu": bt, "n_gpus": ranks.world, "final_loss": round(float(out["loss"]), 5),
-           "launch": launch, "model": name,
+           "launch": launch, "model": name, "repetitions": reps, "rep_ms_per_step": [round(e / steps * 1e3, 3) for e in els],
            "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if use_dp else "") + "fused Adam; "
                    + (f"bf16 MFMA 1x1 GEMMs, wide activations / gradients stored in {getattr(model, 'act_storage', 'fp32')}, fp32 statistics / "
                       "parameters / optimizer" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
@@ -767,6 +813,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed region (each exactly --steps steps); the median is reported")
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches issued on concurrent HIP streams per step")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
@@ -863,7 +910,8 @@ def main():
     result = {
         "metric": "clips/sec (10 s @ 32 kHz) mn10_as fwd+bwd, 1/2/4/8 MI355X; logit max-abs-err",
         "value": head["value"], "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": head["warmup"],
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": head["ms_per_step"], "repetitions": head["repetitions"], "rep_ms_per_step": head["rep_ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{train_name}_as training step (log-mel + forward with batch-stat BatchNorm + BCE + backward + "
                                + ("bucketed RCCL all-reduce + " if world > 1 else "")
@@ -971,13 +1019,17 @@ def main():
             print(f"[bench] ERROR: launches without a byte model: {unmodelled}", file=sys.stderr)
         result["roofline_e2e"]["launches_without_byte_model"] = unmodelled
         name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])        # largest time share over ALL launches
-        result["roofline"] = roofline_of(name, d, {"step_ms": step_ms})
+        result["roofline"] = roofline_of(name, d, {"step_ms": step_ms, "phase": "train"})
         result["roofline"]["step"] = "training step, eager launches with a HIP event pair each (one stream)"
         moved = sum(v["bytes"] for v in prof.values())
         result["roofline_e2e"]["moved_bytes_per_step"] = int(moved)
         result["roofline_e2e"]["frac_moved"] = round(moved / (head["ms_per_step"] * 1e-3) / HBM_PEAK, 4)
         result["roofline_e2e"]["note_moved"] = ("moved = sum over the step's launches of each kernel's own input + output "
                                                 "bytes (what the plan reads and writes), against the same step time")
+        pm = pmc_step_bytes("train") if train_name == "mn10" else None
+        if pm:
+            result["roofline_e2e"]["pmc_bytes_per_step"] = pm["bytes"]
+            result["roofline_e2e"]["pmc_source"] = pm["source"]
         if args.kernel_table:
             print(f"[bench] training step, {sum(v['launches'] for v in prof.values())} library launches, "
                   f"{step_ms:.2f} ms of kernels", file=sys.stderr)
@@ -995,7 +1047,10 @@ def main():
             result["forward"]["roofline_moved_frac"] = round(fmoved / (result["forward"]["ms_per_step"] * 1e-3) / HBM_PEAK, 4)
             result["forward"]["single_stream_kernel_ms"] = round(fms, 3)
             fname, fd = max(fprof.items(), key=lambda kv: kv[1]["total_ms"])
-            result["forward"]["roofline"] = roofline_of(fname, fd, {"step_ms": fms})
+            result["forward"]["roofline"] = roofline_of(fname, fd, {"step_ms": fms, "phase": "forward"})
+            pmf = pmc_step_bytes("forward")
+            if pmf:
+                result["forward"]["pmc_bytes_per_step"] = pmf["bytes"]
             if args.kernel_table:
                 for k, v in sorted(fprof.items(), key=lambda kv: -kv[1]["total_ms"]):
                     print(f"[bench] {k:28s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "

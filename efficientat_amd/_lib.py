@@ -114,6 +114,8 @@ SIGNATURES = {
     "eat_dw_conv_dyn_bwd_bn_g": [_P] * 7 + [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_stem_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_mlp_head_bwd": [_P] * 13 + [_I, _I, _I, _I, _P],
+    "eat_se_mlp_dh_floats": [_I, _I, _I],
+    "eat_mlp_head_dfeat_floats": [_I, _I, _I],
     # bf16 activation storage (BASELINE configs[2])
     "eat_pw_conv_b16_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_b16_ok": [_I] * 8,

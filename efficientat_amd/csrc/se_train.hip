@@ -24,8 +24,9 @@ namespace {
 // axis goes through LDS in chunks of 128: 16 + 16 loads per thread in flight per barrier pair (chunks of 32 left the
 // kernel waiting on one memory latency per 32 k: 55 us for K = 960).
 constexpr int kKC = 128;
+// [k_lo, K): the slice of the contraction this block sums (split-K: the caller combines the slices in a fixed order)
 template <bool A_MFAST, class FA, class FB, class FS>
-__device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, FA a_at, FB b_at, FS store) {
+__device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, FA a_at, FB b_at, FS store, int k_lo = 0) {
   __shared__ float sA[kKC][33], sB[kKC][33];        // sA[k][m], sB[k][n]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -33,7 +34,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, F
   const int l15 = lane & 15, kq = lane >> 4;
   const int ms = 16 * (wv >> 1), ns = 16 * (wv & 1);                 // this wave's quadrant of the tile
   f32x4 acc{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += kKC) {
+  for (int k0 = k_lo; k0 < K; k0 += kKC) {
     float av[16], bv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -89,6 +90,23 @@ __device__ __forceinline__ void col_sum_tile(int M, int N, int n0, F f, float* _
 
 __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Split-K for the GEMMs with a long contraction and few output tiles (round 5: dh = dq W2 at mn40's widths is 120 tiles of
+// K = 3840 - 30 dependent load -> LDS -> MFMA rounds per block, 176 us; the head's dfeat = du W1 has K = 5120): a block sums
+// one slice of k, the slices are stored side by side ([slice][M][N]) and added in index order by slice_sum_kernel - no
+// atomics, bit-reproducible.  One slice (no extra launch) below 1024.
+__host__ __device__ __forceinline__ int k_slices(int K) { return K >= 1024 ? (K + 511) / 512 : 1; }
+__host__ __device__ __forceinline__ int k_slice_len(int K) { const int n = k_slices(K); return ((K + n - 1) / n + 3) & ~3; }
+
+// out[i] = (gate == NULL || gate[i] > 0) * sum over slices of part[s][i]
+__global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict__ part, const float* __restrict__ gate,
+                                                        float* __restrict__ out, int n, int n_slices) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.0f;
+  for (int s = 0; s < n_slices; ++s) t += part[(size_t)s * n + i];
+  out[i] = (gate == nullptr || gate[i] > 0.0f) ? t : 0.0f;
+}
+
 // stage 1: blocks [0, nA) -> dW2 tiles, [nA, nA + nB) -> dh tiles, then cdiv(C, 32) blocks -> db2
 __global__ __launch_bounds__(256) void se_bwd_stage1_kernel(const float* __restrict__ ds, const float* __restrict__ sc,
                                                             const float* __restrict__ h, const float* __restrict__ W2,
@@ -96,7 +114,8 @@ __global__ __launch_bounds__(256) void se_bwd_stage1_kernel(const float* __restr
                                                             float* __restrict__ dh, int B, int C, int Cr) {
   auto dq = [&](int b, int c) { const float s = sc[(size_t)b * C + c]; return ds[(size_t)b * C + c] * s * (1.0f - s); };
   const int tA_n = cdiv(Cr, 32), nA = cdiv(C, 32) * tA_n;
-  const int tB_n = cdiv(Cr, 32), nB = cdiv(B, 32) * tB_n;
+  const int ks = k_slices(C), kl = k_slice_len(C);
+  const int tB_n = cdiv(Cr, 32), nB1 = cdiv(B, 32) * tB_n, nB = nB1 * ks;
   int id = blockIdx.x;
   if (id < nA) {                      // dW2 (C x Cr): A(m = c, k = b) = dq[b, c], B(k = b, n = r) = h[b, r]
     gemm_tile<true>(C, Cr, B, (id / tA_n) * 32, (id % tA_n) * 32, [&](int m, int k) { return dq(k, m); },
@@ -106,9 +125,14 @@ __global__ __launch_bounds__(256) void se_bwd_stage1_kernel(const float* __restr
   }
   id -= nA;
   if (id < nB) {                      // dh (B x Cr): A(m = b, k = c) = dq[b, c], B(k = c, n = r) = W2[c, r]
-    gemm_tile<false>(B, Cr, C, (id / tB_n) * 32, (id % tB_n) * 32, [&](int m, int k) { return dq(m, k); },
+    const int sl = id / nB1, t = id - sl * nB1;
+    const int k_hi = (sl + 1) * kl < C ? (sl + 1) * kl : C;
+    // one slice: the finished dh; several: slice sl of dh_part (= dh's buffer, [ks][B][Cr]; ReLU mask in slice_sum_kernel)
+    float* o = dh + (size_t)sl * B * Cr;
+    gemm_tile<false>(B, Cr, k_hi, (t / tB_n) * 32, (t % tB_n) * 32, [&](int m, int k) { return dq(m, k); },
                      [&](int k, int n) { return W2[(size_t)k * Cr + n]; },
-                     [&](int m, int n, float v) { dh[(size_t)m * Cr + n] = h[(size_t)m * Cr + n] > 0.0f ? v : 0.0f; });
+                     [&](int m, int n, float v) { o[(size_t)m * Cr + n] = (ks > 1 || h[(size_t)m * Cr + n] > 0.0f) ? v : 0.0f; },
+                     sl * kl);
     return;
   }
   id -= nB;
@@ -179,7 +203,8 @@ __global__ __launch_bounds__(256) void head_bwd_stage2_kernel(const float* __res
                                                               float* __restrict__ db1, float* __restrict__ dfeat, int B,
                                                               int C, int H) {
   const int tC_n = cdiv(C, 32), nC = cdiv(H, 32) * tC_n;
-  const int tD_n = cdiv(C, 32), nD = cdiv(B, 32) * tD_n;
+  const int ks = k_slices(H), kl = k_slice_len(H);
+  const int tD_n = cdiv(C, 32), nD1 = cdiv(B, 32) * tD_n, nD = nD1 * ks;
   int id = blockIdx.x;
   if (id < nC) {                      // dW1 (H x C): A(m = r, k = b) = du[b, r], B(k = b, n = c) = feat[b, c]
     gemm_tile<true>(H, C, B, (id / tC_n) * 32, (id % tC_n) * 32, [&](int m, int k) { return du[(size_t)k * H + m]; },
@@ -189,9 +214,12 @@ __global__ __launch_bounds__(256) void head_bwd_stage2_kernel(const float* __res
   }
   id -= nC;
   if (id < nD) {                      // dfeat (B x C): A(m = b, k = r) = du[b, r], B(k = r, n = c) = W1[r, c]
-    gemm_tile<false>(B, C, H, (id / tD_n) * 32, (id % tD_n) * 32, [&](int m, int k) { return du[(size_t)m * H + k]; },
+    const int sl = id / nD1, t = id - sl * nD1;
+    const int k_hi = (sl + 1) * kl < H ? (sl + 1) * kl : H;
+    float* o = dfeat + (size_t)sl * B * C;                      // (several slices: dfeat is the [ks][B][C] scratch)
+    gemm_tile<false>(B, C, k_hi, (t / tD_n) * 32, (t % tD_n) * 32, [&](int m, int k) { return du[(size_t)m * H + k]; },
                      [&](int k, int n) { return W1[(size_t)k * C + n]; },
-                     [&](int m, int n, float v) { dfeat[(size_t)m * C + n] = v; });
+                     [&](int m, int n, float v) { o[(size_t)m * C + n] = v; }, sl * kl);
     return;
   }
   id -= nD;
@@ -202,6 +230,10 @@ __global__ __launch_bounds__(256) void head_bwd_stage2_kernel(const float* __res
 
 static int cdiv_host(int a, int b) { return (a + b - 1) / b; }
 
+// scratch sizes (floats) of the dh / dfeat buffers above: the result plus, when the contraction is split, its k slices
+extern "C" int eat_se_mlp_dh_floats(int B, int C, int Cr) { return B * Cr * (k_slices(C) > 1 ? 1 + k_slices(C) : 1); }
+extern "C" int eat_mlp_head_dfeat_floats(int B, int C, int H) { return B * C * (k_slices(H) > 1 ? 1 + k_slices(H) : 1); }
+
 extern "C" int eat_mlp_head_bwd(const float* dlogits, const float* h2, const float* u, const float* drop_mask,
                                 const float* feat, const float* W1, const float* W2, float* dW1, float* db1, float* dW2,
                                 float* db2, float* du, float* dfeat, int B, int C, int H, int N, eat_stream_t stream) {
@@ -209,12 +241,18 @@ extern "C" int eat_mlp_head_bwd(const float* dlogits, const float* h2, const flo
   if (!dlogits || !h2 || !u || !feat || !W1 || !W2 || !dW1 || !db1 || !dW2 || !db2 || !du || !dfeat)
     return eat::fail(EAT_EINVAL, "eat_mlp_head_bwd: missing operand");
   if (B < 1 || C < 1 || H < 1 || N < 1) return eat::fail(EAT_EINVAL, "eat_mlp_head_bwd: bad shape");
+  // dfeat: eat_mlp_head_dfeat_floats(B, C, H) floats - the finished dfeat first, behind it the k slices (contraction over H)
+  const int ks = k_slices(H);
+  float* df_part = ks > 1 ? dfeat + (size_t)B * C : dfeat;
   const int n1 = cdiv_host(N, 32) * cdiv_host(H, 32) + cdiv_host(B, 32) * cdiv_host(H, 32) + cdiv_host(N, 32);
-  const int n2 = cdiv_host(H, 32) * cdiv_host(C, 32) + cdiv_host(B, 32) * cdiv_host(C, 32) + cdiv_host(H, 32);
+  const int n2 = cdiv_host(H, 32) * cdiv_host(C, 32) + cdiv_host(B, 32) * cdiv_host(C, 32) * ks + cdiv_host(H, 32);
   hipLaunchKernelGGL(head_bwd_stage1_kernel, dim3((unsigned)n1), dim3(256), 0, (hipStream_t)stream, dlogits, h2, u, drop_mask,
                      W2, dW2, db2, du, B, H, N);
   hipLaunchKernelGGL(head_bwd_stage2_kernel, dim3((unsigned)n2), dim3(256), 0, (hipStream_t)stream, du, feat, W1, dW1, db1,
-                     dfeat, B, C, H);
+                     df_part, B, C, H);
+  if (ks > 1)
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, df_part,
+                       (const float*)nullptr, dfeat, B * C, ks);
   return eat::check_launch("eat_mlp_head_bwd");
 }
 
@@ -223,10 +261,17 @@ extern "C" int eat_se_mlp_bwd(const float* ds, const float* scale, const float* 
                               float* gadd, int B, int C, int Cr, eat_stream_t stream) {
   eat::clear_stale_error();
   if (B < 1 || C < 1 || Cr < 1) return eat::fail(EAT_EINVAL, "eat_se_mlp_bwd: bad shape");
-  const int n1 = cdiv_host(C, 32) * cdiv_host(Cr, 32) + cdiv_host(B, 32) * cdiv_host(Cr, 32) + cdiv_host(C, 32);
+  // dh: scratch of eat_se_mlp_dh_floats(B, C, Cr) floats - the finished dh first, behind it the k slices when the
+  // contraction over C is split (k_slices)
+  const int ks = k_slices(C);
+  float* dh_part = ks > 1 ? dh + (size_t)B * Cr : dh;
+  const int n1 = cdiv_host(C, 32) * cdiv_host(Cr, 32) + cdiv_host(B, 32) * cdiv_host(Cr, 32) * ks + cdiv_host(C, 32);
   const int n2 = cdiv_host(Cr, 32) * cdiv_host(C, 32) + cdiv_host(B, 32) * cdiv_host(C, 32) + cdiv_host(Cr, 32);
   hipLaunchKernelGGL(se_bwd_stage1_kernel, dim3((unsigned)n1), dim3(256), 0, (hipStream_t)stream, ds, scale, h, W2, dW2, db2,
-                     dh, B, C, Cr);
+                     dh_part, B, C, Cr);
+  if (ks > 1)
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((B * Cr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh_part, h, dh,
+                       B * Cr, ks);
   hipLaunchKernelGGL(se_bwd_stage2_kernel, dim3((unsigned)n2), dim3(256), 0, (hipStream_t)stream, dh, pool, W1, inv_s, dW1,
                      db1, gadd, B, C, Cr);
   return eat::check_launch("eat_se_mlp_bwd");

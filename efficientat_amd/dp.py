@@ -12,6 +12,12 @@ per-link bound, so a few MB per collective amortises the launch while still over
 bucket is all-reduced asynchronously (RCCL runs on its own stream, ordered after the kernels that
 produced the bucket) while the remaining layers' backward kernels keep the compute stream busy.
 `finish()` waits for the collectives and returns the averaged gradients.
+
+Round 5: no packed copy for the large gradients.  The backward asks the reducer for the MEMORY of a weight gradient before
+it launches the kernel that produces it (`alloc`): consecutive requests are carved out of one flat, zero-filled buffer per
+step, in production order, so a bucket is a contiguous range of that buffer and is all-reduced IN PLACE; `finish()` hands
+out views of the same memory.  Only what is produced elsewhere (BatchNorm / bias / depthwise gradients: a few hundred KB
+per step) still goes through `torch.cat`.
 """
 import torch
 import torch.distributed as dist
@@ -38,15 +44,63 @@ class GradReducer:
         self.cur, self.cur_bytes = [], 0
         self.inflight = []      # (work, flat, [(name, shape, numel)])
         self.out = {}
+        # flat gradient buffer of the pass (`alloc`): its size is learnt from the first pass (which falls back to `push`ed
+        # copies); slots = [name, offset, numel, shape, pushed] in allocation order, `done` = first slot not yet reduced
+        self.need = max(getattr(self, "need", 0), getattr(self, "req", 0))
+        self.gbuf, self.req, self.slots, self.done = None, 0, [], 0
+
+    def alloc(self, name, shape, device, dtype=torch.float32):
+        """Zero-filled memory for the gradient `name` inside the pass's flat bucket buffer, or None (not bucketed / size not
+        learnt yet / not fp32): the producer then allocates for itself and the gradient is packed by `push` as before."""
+        if not self.bucketed or dtype != torch.float32:
+            return None
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        n_al = (numel + 63) // 64 * 64                      # 256-byte aligned slots
+        off = self.req
+        self.req += n_al
+        if self.need < self.req:
+            return None
+        if self.gbuf is None:
+            self.gbuf = torch.zeros((self.need,), device=device, dtype=torch.float32)
+        if self.gbuf.device != device:
+            return None
+        self.slots.append([name, off, numel, tuple(shape), False])
+        return self.gbuf[off:off + numel].view(shape)
 
     def push(self, name, grad):
         if not self.bucketed:
             self.out[name] = grad
             return
+        if self.gbuf is not None and grad.dtype == torch.float32:
+            base = self.gbuf.data_ptr()
+            for slot in self.slots[self.done:]:
+                if slot[0] == name and grad.data_ptr() == base + 4 * slot[1] and grad.numel() == slot[2]:
+                    slot[4] = True
+                    self._flush_flat()
+                    return
         self.cur.append((name, grad))
         self.cur_bytes += grad.numel() * grad.element_size()
         if self.cur_bytes >= self.bucket_bytes:
             self._flush()
+
+    def _flush_flat(self, force=False):
+        """All-reduce, in place, the longest prefix of produced slots once it fills a bucket."""
+        end = self.done
+        while end < len(self.slots) and self.slots[end][4]:
+            end += 1
+        if end == self.done:
+            return
+        lo = self.slots[self.done][1]
+        hi = self.slots[end - 1][1] + (self.slots[end - 1][2] + 63) // 64 * 64
+        if not force and (hi - lo) * 4 < self.bucket_bytes:
+            return
+        flat = self.gbuf[lo:hi]                             # (the alignment padding between slots is zeros on every rank)
+        work = dist.all_reduce(flat, op=self._op, group=self.group, async_op=True)
+        meta = [(s[0], s[3], s[2], s[1] - lo) for s in self.slots[self.done:end]]
+        self.inflight.append((work, flat, meta))
+        self.done = end
 
     def _flush(self):
         if not self.cur:
@@ -62,6 +116,11 @@ class GradReducer:
 
     def finish(self):
         """-> {name: averaged gradient}; blocks the compute stream (not the host) on the collectives."""
+        if self.gbuf is not None:
+            if any(not s[4] for s in self.slots[self.done:]):
+                missing = [s[0] for s in self.slots if not s[4]]
+                raise RuntimeError(f"GradReducer: gradient memory was handed out but never pushed: {missing[:4]}")
+            self._flush_flat(force=True)
         self._flush()
         inv = 1.0 / self.world
         for work, flat, meta in self.inflight:
@@ -69,7 +128,11 @@ class GradReducer:
             if not self._avg:
                 flat.mul_(inv)
             off = 0
-            for name, shape, n in meta:
+            for m in meta:
+                if len(m) == 4:                              # in-place member of the flat buffer: (name, shape, numel, offset)
+                    self.out[m[0]] = flat[m[3]:m[3] + m[2]].view(m[1])
+                    continue
+                name, shape, n = m
                 self.out[name] = flat[off:off + n].view(shape)
                 off += n
         out = self.out

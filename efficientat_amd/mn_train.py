@@ -82,6 +82,11 @@ class _GradSink:
     def __setitem__(self, name, grad):
         self.reducer.push(name, grad)
 
+    def alloc(self, name, like):
+        """Memory for the gradient of parameter `like` inside the reducer's flat bucket buffer (zero-filled, shape of the 2-D
+        weight matrix), or None when the pass is not bucketed - the producer then allocates for itself (dp.GradReducer)."""
+        return self.reducer.alloc(name, (like.shape[0], like.numel() // like.shape[0]), like.device)
+
     def finish(self):
         return self.reducer.finish()
 
@@ -147,9 +152,10 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         fc1, fc2 = model.classifier[2], model.classifier[5]
         # two launches of the library's stride-addressed tile GEMMs (csrc/se_train.hip: eat_mlp_head_bwd) - round 4 ran
         # four rocBLAS GEMMs + five torch ops here
+        o2, o1 = g.alloc("classifier.5.weight", fc2.weight), g.alloc("classifier.2.weight", fc1.weight)   # (production order)
         dW1, db1, dW2, db2, dft = ops.mlp_head_bwd(dlogits, h2.contiguous(), u.contiguous(),
                                                   None if drop_mask is None else drop_mask.contiguous(), feat.contiguous(),
-                                                  fc1.weight, fc2.weight)
+                                                  fc1.weight, fc2.weight, dW1_out=o1, dW2_out=o2)
         g["classifier.5.weight"], g["classifier.5.bias"] = dW2, db2
         g["classifier.2.weight"], g["classifier.2.bias"] = dW1, db1
         if dfeat is not None:
@@ -159,7 +165,7 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         dz, dgam, dbet = ops.bn_act_bwd(z_l, z_l, *st_l, HSWISH, gscale=zeros_bc, gadd=dft * (1.0 / S_l),
                                         sums=bn_sums(z_l.shape[1], nm + ".1.weight", nm + ".1.bias"))
     bn_grads(dgam, dbet, nm + ".1.weight", nm + ".1.bias")
-    g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l).view_as(last[0].weight)
+    g[nm + ".0.weight"] = ops.pw_conv_wgrad(dz, x_l, out=g.alloc(nm + ".0.weight", last[0].weight)).view_as(last[0].weight)
     plan = sv.get("plan")
     if plan is not None and plan.runs != sv.get("plan_run"):
         # another forward of the model re-packed the plan's views since this pass's forward (two forwards before one
@@ -186,11 +192,12 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         scale = rec.get("scale")
         b16 = rec.get("b16", False)                    # the block's wide tensors are bf16 in HBM (forward: rec["b16"])
         wgrad = ops.pw_conv_wgrad_b16 if b16 else ops.pw_conv_wgrad
+        o_p = g.alloc(f"{pre}.{blk.i_proj}.0.weight", cna[0].weight)
         if rec["y_d"] is None:     # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
             st_d = rec["st_d"]
-            dWp = wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act))
+            dWp = wgrad(dz_p, rec["z_d"], x_scale=scale, tf=(st_d[0], st_d[1], act), out=o_p)
         else:
-            dWp = wgrad(dz_p, rec["y_d"], x_scale=scale)
+            dWp = wgrad(dz_p, rec["y_d"], x_scale=scale, out=o_p)
         g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
         wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
         if b16:
@@ -208,7 +215,8 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             se_P = ops.se_bn_bwd_partials(dxs, rec["z_d"], st_d[0], st_d[1], st_d[2], act)
             ds = se_P[0]
             # the gate MLP's backward as two launches (csrc/se_train.hip)
-            dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d)
+            o2, o1 = g.alloc(sp + ".fc2.weight", se.fc2.weight), g.alloc(sp + ".fc1.weight", se.fc1.weight)
+            dW1, db1, dW2, db2, gadd = ops.se_mlp_bwd(ds, scale, h, pool, se.fc1.weight, se.fc2.weight, S_d, dW1_out=o1, dW2_out=o2)
             g[sp + ".fc2.weight"], g[sp + ".fc2.bias"] = dW2, db2
             g[sp + ".fc1.weight"], g[sp + ".fc1.bias"] = dW1, db1
             gscale = scale
@@ -294,7 +302,8 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             Gx = wgrad(g_e, inp)
             Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
             dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
-                                                             frozen=frozen, centered=not frozen)
+                                                             frozen=frozen, centered=not frozen,
+                                                             dW_out=g.alloc(f"{pre}.{blk.i_expand}.0.weight", cna_e[0].weight))
             g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
             g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
             S_e = inp.shape[2] * inp.shape[3]
@@ -374,6 +383,15 @@ _EPI_STATS = True         # project / last conv: BatchNorm statistics in the 1x1
 _PREPACK_PLAN = True      # all weight packs of the step from one launch
 _FUSE_STEM = True         # stem without its pre-activation tensor (csrc/stem_train.hip)
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
+
+
+def _w_times_g(W, G):
+    """T = W G (C_out, C_in) for a symmetric G (C_in, C_in), C_in % 4 == 0."""
+    Co, Ci = W.shape
+    if Ci % 4:
+        return ops.linear(W, G, None, NONE)
+    wp3 = ops.pw_prepack_bf16(W, None, split=True)
+    return ops.pw_conv_bf16(G.view(1, Ci, Ci, 1), wp3, _zeros.get(Co, W.device), Co, NONE, split=True).view(Co, Ci)
 
 
 def _act_storage_bf16(model):
@@ -464,8 +482,11 @@ class MNTrainFunction2(torch.autograd.Function):
                         Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e, centered=True)   # T = W Gc and the BatchNorm state, one launch
                     else:
                         # wide inputs (mn40: up to 640 channels): every block of the one-launch form would stream the whole
-                        # G from L2 (C_out x C_in^2 floats: 0.79 ms at 3840 x 640) - W G on the matrix cores instead
-                        Tm = ops.linear(W, G, None, NONE)
+                        # G from L2 (C_out x C_in^2 floats: 0.79 ms at 3840 x 640) - W G on the matrix cores instead: as the
+                        # 1x1 conv of the "image" G (1, C_in, C_in, 1) with W on the split-operand bf16x3 kernel (fp32-class
+                        # products whatever the step's precision: T feeds the BatchNorm variance; round 4 ran the K-split
+                        # `linear` kernel here, 15 TFLOP/s on 3840 x 640 x 640)
+                        Tm = ops.linear(W, G, None, NONE) if exact else _w_times_g(W, G)
                         st_e = ops.gram_bn_state(Tm, W, sx, cna[1], n_e, centered=True)
                 else:
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])

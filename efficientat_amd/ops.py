@@ -450,7 +450,7 @@ def gram(x, exact=False, sx=None):
     return G
 
 
-def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None):
+def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None, out=None):
     """dW (Co, Ci) = sum_b dz[b] (Co,S) . (x[b] * x_scale[b])^T.  exact=True: fp32 MFMA kernel; False: split-operand
     bf16x3 kernel (fp32-class); None: follow the active `precision` context ('fp32' -> exact, 'bf16' -> plain bf16
     operands with fp32 accumulation, as autocast does to the conv weight gradient; otherwise bf16x3)."""
@@ -460,7 +460,8 @@ def pw_conv_wgrad(dz, x, x_scale=None, exact=None, tf=None):
     B, Co = dz.shape[0], dz.shape[1]
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
-    dW = zero_arena.zeros((Co, Ci), torch.float32, dz.device)
+    # out: ZERO-FILLED (Co, Ci) memory to accumulate into (dp.GradReducer.alloc: the gradient is produced inside its bucket)
+    dW = out if out is not None else zero_arena.zeros((Co, Ci), torch.float32, dz.device)
     if tf is not None:
         ws = zero_arena.zeros((8, Co, Ci), torch.float32, dz.device) if (Co <= 64 and Ci <= 64 and S % 4 == 0 and mode != 1) else None
         _lib.call("eat_pw_conv_wgrad_tf", _dev(dz, "dz"), _dev(x, "x"), tf[0].data_ptr(), tf[1].data_ptr(), tf[2],
@@ -671,18 +672,21 @@ def dw_conv_bwd_bn_g(dy, z, st, act, sums, w, x, in_a, in_b, in_act, k, stride, 
     return g, ((gpart, B, inner.value) if want_gsum else None), dw
 
 
-def se_mlp_bwd(ds, scale, h, pool, W1, W2, S):
+def se_mlp_bwd(ds, scale, h, pool, W1, W2, S, dW1_out=None, dW2_out=None):
     """Backward of the SE gate MLP in two launches -> (dW1, db1, dW2, db2, gadd); see csrc/se_train.hip."""
     B, C = ds.shape
     Cr = h.shape[1]
     dev = ds.device
-    buf = torch.empty((2 * C * Cr + C + Cr + B * Cr + B * C,), device=dev, dtype=torch.float32)
+    n_dh = int(_lib.lib().eat_se_mlp_dh_floats(B, C, Cr))            # dh + its k slices where the contraction is split
+    buf = torch.empty((2 * C * Cr + C + Cr + n_dh + B * C,), device=dev, dtype=torch.float32)
     o = 0
     dW1 = buf[o:o + Cr * C].view(Cr, C); o += Cr * C
     dW2 = buf[o:o + C * Cr].view(C, Cr); o += C * Cr
+    dW1 = dW1_out if dW1_out is not None else dW1            # (written, not accumulated: memory of the gradient buckets)
+    dW2 = dW2_out if dW2_out is not None else dW2
     db1 = buf[o:o + Cr]; o += Cr
     db2 = buf[o:o + C]; o += C
-    dh = buf[o:o + B * Cr]; o += B * Cr
+    dh = buf[o:o + n_dh]; o += n_dh
     gadd = buf[o:o + B * C].view(B, C)
     _lib.call("eat_se_mlp_bwd", _dev(ds, "ds"), _dev(scale, "scale"), _dev(h, "h"), _dev(pool, "pool"), _dev(W1, "W1"),
               _dev(W2, "W2"), 1.0 / S, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), dh.data_ptr(),
@@ -690,17 +694,20 @@ def se_mlp_bwd(ds, scale, h, pool, W1, W2, S):
     return dW1, db1, dW2, db2, gadd
 
 
-def mlp_head_bwd(dlogits, h2, u, drop_mask, feat, W1, W2):
+def mlp_head_bwd(dlogits, h2, u, drop_mask, feat, W1, W2, dW1_out=None, dW2_out=None):
     """Backward of the classifier head Linear -> Hardswish -> Dropout -> Linear in two launches (csrc/se_train.hip):
     -> (dW1, db1, dW2, db2, dfeat)."""
     B, N = dlogits.shape
     H, C = W1.shape
     dev = dlogits.device
-    buf = torch.empty((H * C + H + N * H + N + B * H + B * C,), device=dev, dtype=torch.float32)
+    n_df = int(_lib.lib().eat_mlp_head_dfeat_floats(B, C, H))       # dfeat + its k slices where the contraction is split
+    buf = torch.empty((H * C + H + N * H + N + B * H + n_df,), device=dev, dtype=torch.float32)
     o = 0
     dW1 = buf[o:o + H * C].view(H, C); o += H * C
     db1 = buf[o:o + H]; o += H
     dW2 = buf[o:o + N * H].view(N, H); o += N * H
+    dW1 = dW1_out if dW1_out is not None else dW1            # (written, not accumulated: memory of the gradient buckets)
+    dW2 = dW2_out if dW2_out is not None else dW2
     db2 = buf[o:o + N]; o += N
     du = buf[o:o + B * H]; o += B * H
     dfeat = buf[o:o + B * C].view(B, C)
@@ -739,12 +746,12 @@ def stem_bwd(dy, x, W, a, b, act, dy2=None):
     return gx, (s1, 1, 1)
 
 
-def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, need_dx=True, centered=False):
+def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, need_dx=True, centered=False, dW_out=None):
     """-> (dW, dgamma, dbeta, WaT (Ci,Co), M (Ci,Ci), c0 (Ci)): backward of conv1x1 -> BN(train) -> act without dz."""
     gpart, outer, inner = gparts
     Co, Ci = W.shape
     dev = W.device
-    dW = torch.empty((Co, Ci), device=dev, dtype=torch.float32)
+    dW = dW_out if dW_out is not None else torch.empty((Co, Ci), device=dev, dtype=torch.float32)   # (written, not accumulated)
     vec = torch.empty((2, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta
     tr = torch.empty((3 * Ci + 1, Co), device=dev, dtype=torch.float32)   # WaT, WT, [W2T ; e1]: M and c0 from ONE GEMM
     w2e = tr[2 * Ci:]
@@ -1131,7 +1138,7 @@ def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None,
     return (y, (part, tiles, 1)) if stats else y
 
 
-def pw_conv_wgrad_b16(dz, x, x_scale=None, tf=None):
+def pw_conv_wgrad_b16(dz, x, x_scale=None, tf=None, out=None):
     """dW (Co, Ci) = sum_b dz[b] . (act(tf_a x + tf_b) * x_scale)[b]^T with exactly one bf16 (wide) operand; plain bf16
     products, fp32 accumulation (`eat_pw_conv_wgrad_b16`)."""
     B, Co = dz.shape[0], dz.shape[1]
@@ -1139,7 +1146,7 @@ def pw_conv_wgrad_b16(dz, x, x_scale=None, tf=None):
     S = dz.numel() // (B * Co)
     d16, x16 = _is16(dz), _is16(x)
     n = int(_lib.lib().eat_pw_wgrad_b16_slots(B, Co, Ci, S, 1 if x16 else 0))
-    dW = zero_arena.zeros((Co, Ci), torch.float32, dz.device)
+    dW = out if out is not None else zero_arena.zeros((Co, Ci), torch.float32, dz.device)
     ws = torch.empty((n, Co, Ci), device=dz.device, dtype=torch.float32)
     a, b, tact = tf if tf is not None else (None, None, 0)
     _lib.call("eat_pw_conv_wgrad_b16", _dev16(dz, "dz") if d16 else _dev(dz, "dz"), 1 if d16 else 0,

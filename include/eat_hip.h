@@ -281,7 +281,9 @@ int eat_dw_conv_bwd_bn_g(const float* dy, const float* z, const float* bn_a, con
  *   in : ds (B,C) = sum_{f,t} d_out * y, scale (B,C), h (B,Cr) = relu(fc1(..)), pool (B,C) = sum_{f,t} y, W1 (Cr,C), W2 (C,Cr),
  *        inv_s = 1 / (F T)
  *   out: dW1 (Cr,C), db1 (Cr), dW2 (C,Cr), db2 (C), gadd (B,C) = the gradient w.r.t. y through the squeeze;
- *        dh (B,Cr) scratch.  Plain fp32, every output element written by one block (bit-reproducible). */
+ *        dh: scratch of eat_se_mlp_dh_floats(B, C, Cr) floats.  fp32 products and accumulation on the matrix cores, every
+ *        output element written by one block or summed from k slices in a fixed order (bit-reproducible). */
+int eat_se_mlp_dh_floats(int B, int C, int Cr);
 int eat_se_mlp_bwd(const float* ds, const float* scale, const float* h, const float* pool, const float* W1, const float* W2,
                    float inv_s, float* dW1, float* db1, float* dW2, float* db2, float* dh, float* gadd, int B, int C, int Cr,
                    eat_stream_t stream);
@@ -643,7 +645,10 @@ int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, co
  * reference leaves it to autograd) in two launches, no transposed copies, every output element from one block (no atomics):
  *   dW2 = dlogits^T h2, db2 = sum_b dlogits, du = (dlogits W2) * drop_mask * hardswish'(u), dW1 = du^T feat, db1 = sum_b du,
  *   dfeat = du W1.  dlogits (B, N); h2 (B, H) the second Linear's input (after dropout); u (B, H) the first Linear's output;
- *   drop_mask (B, H) keep / (1 - p) factors or NULL; feat (B, C); W1 (H, C); W2 (N, H); du (B, H) scratch. */
+ *   drop_mask (B, H) keep / (1 - p) factors or NULL; feat (B, C); W1 (H, C); W2 (N, H); du (B, H) scratch; dfeat:
+ *   eat_mlp_head_dfeat_floats(B, C, H) floats, the result (B, C) first (long contractions are split and summed in a fixed
+ *   order). */
+int eat_mlp_head_dfeat_floats(int B, int C, int H);
 int eat_mlp_head_bwd(const float* dlogits, const float* h2, const float* u, const float* drop_mask, const float* feat,
                      const float* W1, const float* W2, float* dW1, float* db1, float* dW2, float* db2, float* du,
                      float* dfeat, int B, int C, int H, int N, eat_stream_t stream);

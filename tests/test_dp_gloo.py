@@ -52,6 +52,63 @@ def test_grad_reducer_world2_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _flat_worker(rank, world, port, ret):
+    """Round 5: the large gradients are PRODUCED inside the reducer's flat buffer (`alloc`) and all-reduced in place; small
+    ones still go through the packed copy.  Pass 1 learns the buffer size (alloc -> None, everything packed), passes 2 and
+    3 run in place - all three must return the mean over ranks, and `finish` must hand out the very memory it gave."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        big = {"l.weight": (960, 160), "p.weight": (160, 960), "se.fc2": (33, 7), "e.weight": (960, 160)}
+        small = {"bn.weight": (160,), "bn.bias": (160,), "dw": (960, 9)}
+        order = ["l.weight", "bn.weight", "bn.bias", "p.weight", "se.fc2", "dw", "e.weight"]
+        red = GradReducer(bucket_bytes=256 << 10)
+        ok, inplace = True, []
+        for it in range(3):
+            gen = torch.Generator().manual_seed(1000 * it + rank)
+            vals = {k: torch.randn({**big, **small}[k], generator=gen) for k in order}
+            handed = {}
+            for k in order:
+                mem = red.alloc(k, big[k], torch.device("cpu")) if k in big else None
+                if mem is not None:
+                    assert float(mem.abs().max()) == 0.0            # zero-filled: the kernels accumulate into it
+                    mem.add_(vals[k])                               # "the kernel produces the gradient in its bucket"
+                    handed[k] = mem
+                    red.push(k, mem)
+                else:
+                    red.push(k, vals[k].clone())
+            out = red.finish()
+            for k in order:
+                exp = sum(torch.randn({**big, **small}[k], generator=_gen_upto(1000 * it + r, order, k, {**big, **small}))
+                          for r in range(world)) / world
+                ok = ok and torch.allclose(out[k], exp, atol=1e-6) and tuple(out[k].shape) == tuple({**big, **small}[k])
+            inplace.append(sorted(k for k in handed if out[k].data_ptr() == handed[k].data_ptr()))
+        ret[rank] = (bool(ok), inplace)
+    finally:
+        dist.destroy_process_group()
+
+
+def _gen_upto(seed, order, key, shapes):
+    """Generator positioned where `key`'s values start in the stream the worker drew (same draw order)."""
+    gen = torch.Generator().manual_seed(seed)
+    for k in order:
+        if k == key:
+            return gen
+        torch.randn(shapes[k], generator=gen)
+    raise KeyError(key)
+
+
+def test_grad_reducer_in_place_flat_buffer_world2_gloo():
+    world, port = 2, _free_port()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_flat_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, inplace = ret[r]
+        assert ok
+        assert inplace[0] == []                                                   # first pass: size unknown, packed copies
+        assert inplace[1] == inplace[2] == ["e.weight", "l.weight", "p.weight", "se.fc2"]   # then produced in place
+
+
 def _hook_worker(rank, world, port, ret):
     """install_grad_hooks(only=..., active=...): the head of an MN in trunk mode (its gradients come from torch autograd,
     not from the trunk Function) is averaged across ranks while the flag is up, and left alone while it is down."""

@@ -115,14 +115,31 @@ def test_mn10_batch256_matches_oracle_and_is_batch_invariant(mn10_b256, pw_mode,
 
 
 # ------------------------------------------------------------------ configs[3]: dymn20
-@pytest.fixture(scope="module")
-def dymn20_case():
+def _dymn20_case(temp):
     wave = synth.parity_clips(320000, seed=31)[[0, 2, 3, 4]]     # noise, two-tone, silence+chirp, AM noise+tone
     x = O.mel_forward(wave).unsqueeze(1)
-    temp = 1.0
     fwd = lambda sd, xm, **k: O.dymn_forward(sd, xm, width_mult=2.0, temperature=temp, **k)
     sd = synth.calibrate(synth.synth_state(synth.dymn_shapes(2.0), seed=0), fwd, x)
     return dict(sd=sd, x=x, fwd=fwd, temp=temp)
+
+
+@pytest.fixture(scope="module")
+def dymn20_case():
+    return _dymn20_case(1.0)
+
+
+@pytest.fixture(scope="module")
+def dymn20_case_t30():
+    """The same network at the reference's STARTING temperature (models/dymn/dy_block.py:133-139: T_max = 30): the kernel
+    attention is then close to uniform and the step well conditioned - the regime in which the tensors that need the
+    round-off-floor escape at T = 1 (below) are held to the FIXED bars."""
+    return _dymn20_case(30.0)
+
+
+# parameters whose gradient the one-ulp control itself moves by more than the fixed bar at temperature 1: the Linear that
+# produces the K = 4 kernel-attention logits of a DynamicConv (models/dymn/dy_block.py:68-71, `residuals.0`) - a softmax at
+# T = 1 over logits that differ by O(10) amplifies round-off of the context vector into percent-level changes
+_ATTENTION_HEAD = (".residuals.0.weight", ".residuals.0.bias")
 
 
 def _dymn20(sd, temp):
@@ -153,14 +170,19 @@ def test_dymn20_eval_matches_oracle(dymn20_case):
     assert e1 < 1e-3 and e2 < 1e-3, (e1, e2)
 
 
+@pytest.mark.parametrize("temp", [1.0, 30.0])
 @pytest.mark.parametrize("prec", ["fp32", "auto"])
-def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
-    """fp32: exact fp32 GEMMs - SURVEY 8c's gradient bar (rel-L2 <= 1e-2 per tensor).  auto (what bench.py times): split
+def test_dymn20_train_step_matches_oracle(dymn20_case, dymn20_case_t30, prec, temp):
+    """temp = 30 (the reference's initial temperature, a conditioned network): FIXED bars for every tensor, no round-off
+    escape.  temp = 1: the bars yield to 4x the tensor's own one-ulp floor, but ONLY for the kernel-attention heads
+    (`_ATTENTION_HEAD`) - the escape is a named list that cannot grow silently - and those very tensors are held to the
+    fixed bars by the temp = 30 run.
+    fp32: exact fp32 GEMMs - SURVEY 8c's gradient bar (rel-L2 <= 1e-2 per tensor).  auto (what bench.py times): split
     bf16 operands from C_in = 40 on, ~1e-5 relative noise per GEMM, i.e. ~100x as many activation-kink flips as fp32
     re-association: 5e-2 per tensor, 2e-2 median (see test_gpu_dymn.py::test_dymn10_train_step_matches_oracle).  Either bar
     yields to 4x the round-off floor of the tensor (`_ulp_noise`): at temperature 1 the kernel attention of this network
     turns one-ulp input noise into percent-level changes of the 4-value attention-bias gradients."""
-    d = dymn20_case
+    d = dymn20_case if temp == 1.0 else dymn20_case_t30
     y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
     keep = (torch.rand(4, 2560, generator=torch.Generator().manual_seed(6)) < 0.8).float()
     sdr = _grad_state(d["sd"])
@@ -186,7 +208,8 @@ def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
     lerr = float((logits.detach().cpu() - logits_ref.detach()).abs().max())
     assert lerr < 1e-3, lerr                                           # absolute, |logit| up to ~12
     gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
-    rels, bad = [], []
+    rels, bad, excused = [], [], []
+    bar = 1e-2 if prec == "fp32" else 5e-2
     for name, p in model.named_parameters():
         ref = sdr[name].grad
         assert p.grad is not None, name
@@ -194,13 +217,19 @@ def test_dymn20_train_step_matches_oracle(dymn20_case, prec):
             continue
         r = _rel(p.grad, ref)
         rels.append(r)
-        if r > max(1e-2 if prec == "fp32" else 5e-2, _floor(noise, name)):
+        if r <= bar:
+            continue
+        if temp == 1.0 and name.endswith(_ATTENTION_HEAD) and r <= _floor(noise, name):
+            excused.append((name, round(r, 4), round(noise[name], 4)))
+        else:
             bad.append((name, r, noise[name]))
     nmed = float(np.median(list(noise.values())))
-    print(f"dymn20 train step [{prec}]: logits max abs err {lerr:.2e}, gradient rel-L2 median {np.median(rels):.2e}, max {max(rels):.2e}"
-          f"  (one-ulp input noise on the same step: median {nmed:.2e}, max {max(noise.values()):.2e})")
+    print(f"dymn20 train step [{prec}, T = {temp}]: logits max abs err {lerr:.2e}, gradient rel-L2 median {np.median(rels):.2e}, "
+          f"max {max(rels):.2e}  (one-ulp input noise on the same step: median {nmed:.2e}, max {max(noise.values()):.2e}); "
+          f"{len(excused)} attention-head tensors above the fixed bar but inside 4x their floor: {excused[:6]}")
     assert not bad, bad[:8]
-    assert float(np.median(rels)) < max(3e-3 if prec == "fp32" else 2e-2, 4 * nmed), float(np.median(rels))
+    med_bar = 3e-3 if prec == "fp32" else 2e-2
+    assert float(np.median(rels)) < (med_bar if temp != 1.0 else max(med_bar, 4 * nmed)), float(np.median(rels))
     msd = model.state_dict()
     for k, v in stats.items():
         assert _rel(msd[k], v) < 1e-4, k
@@ -255,6 +284,12 @@ def test_mn40_train_step_fp32_matches_oracle(mn40_case):
     bad = [(n, r) for n, r in rels.items() if r > 3e-2]
     assert not bad, bad[:8]
     assert float(np.median(list(rels.values()))) < 1e-2
+    # SURVEY 8c's per-tensor bar is 1e-2; the fp32 CPU oracle itself sits 1 - 3e-2 away from its fp64 evaluation on a few
+    # tensors of this random-weight net (activation kinks: DESIGN 5).  Which tensors exceed 1e-2 is printed, and there may
+    # be only a handful of them - a systematic error moves the median, an indexing error moves everything
+    above = sorted(((round(r, 4), n) for n, r in rels.items() if r > 1e-2), reverse=True)
+    print(f"mn40 fp32 train step: {len(above)} of {len(rels)} gradient tensors above 1e-2 (max 3e-2 allowed): {above[:8]}")
+    assert len(above) <= max(3, len(rels) // 20), above
     msd = model.state_dict()
     for k, v in d["stats"].items():
         assert _rel(msd[k], v) < 1e-5, k
@@ -360,6 +395,9 @@ def _check_tiled(small, large, n, stats_small, stats_large, grad_tol=3e-2, fwd_t
     # noise: {name: rel} of a second small-batch step on one-ulp-noisy input (`_ulp_noise`) - the bars yield to 4x that
     bad = [(r, nm) for r, nm in rels if r >= max(grad_tol, _floor(noise, nm))]
     assert not bad, max(bad)
+    above = sorted(((round(r, 4), nm) for r, nm in rels if r > 1e-2), reverse=True)
+    print(f"tiled batch vs oracle-pinned batch: {len(above)} of {len(rels)} gradient tensors above 1e-2: {above[:6]}")
+    assert len(above) <= max(3, len(rels) // 10), above
     nmed = float(np.median([noise[nm] for _, nm in rels])) if noise else 0.0
     assert float(np.median([r for r, _ in rels])) < max(med_tol, 4 * nmed), (float(np.median([r for r, _ in rels])), nmed)
     for k, v in stats_small.items():                         # running statistics (unbiased factor n/(n-1) differs by ~1e-6;

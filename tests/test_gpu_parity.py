@@ -598,6 +598,12 @@ def test_mn_variants_match_reference_and_oracle(tag, golden_dir):
             continue
         rels.append(float((p.grad.cpu().double() - ref_g.double()).norm() / ref_g.double().norm()))
     assert max(rels) < 5e-2 and float(np.median(rels)) < 1.5e-2, (max(rels), float(np.median(rels)))
+    # (1e-2 per tensor.  These 3 s / 5-clip variant nets have 47 random-weight layers whose fp32 CPU oracle
+    #  differs from its own fp64 evaluation by up to a few 1e-2 on single tensors - activation kinks; the measured count
+    #  above 1e-2 is printed and bounded)
+    n_above = sum(r > 1e-2 for r in rels)
+    print(f"variant {tag}: gradient rel-L2 max {max(rels):.2e}, median {float(np.median(rels)):.2e}, {n_above} of {len(rels)} above 1e-2")
+    assert n_above <= max(3, len(rels) // 5), (tag, n_above, len(rels))
     with torch.no_grad():
         model2 = variant_state(tag, golden_dir)[0]
         model2.load_state_dict(sd, strict=True)

@@ -17,6 +17,13 @@ if has dymnstats; then
   rm -rf $OUT/stats_dymn
   head -45 $OUT/dymn20_rocprof_kernel_stats.csv; cat $OUT/rocprof_dymn.json
 fi
+if has mn40stats; then
+  (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats_mn40 -o s --output-format csv -- \
+      python $GRAFT_REPO_ROOT/bench.py --train-model mn40_bf16 --batch 128 --no-forward --no-profile --no-cpu-baseline --no-train-configs --no-fp32-exact --steps 5 --warmup 2 > $GRAFT_REPO_ROOT/$OUT/rocprof_mn40.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof_mn40.log)
+  find $OUT/stats_mn40 -name "*kernel_stats.csv" -exec cp {} $OUT/mn40_bf16_rocprof_kernel_stats.csv \;
+  rm -rf $OUT/stats_mn40
+  head -50 $OUT/mn40_bf16_rocprof_kernel_stats.csv | cut -c1-200; cat $OUT/rocprof_mn40.json | head -c 600
+fi
 if has unit; then
   timeout 1500 python -m pytest ${UNIT:-tests/test_gpu_train_fuse.py} -q --tb=short 2>&1 | grep -v "^  /usr\|Warning" | tail -60 > $OUT/unit.log; tail -40 $OUT/unit.log
 fi
@@ -73,9 +80,9 @@ if has pmc; then
         python $GRAFT_REPO_ROOT/bench.py $PROF_ARGS > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$name.log) || echo "pmc pass $name failed/timed out"
   done
   F=$(find $OUT/pmc_f -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w -name "*counter_collection.csv" | head -1)
-  python tools/pmc_traffic.py $F $W $OUT/pmc_traffic_${PMC_TAG:-r4}.json
+  python tools/pmc_traffic.py $F $W $OUT/pmc_traffic_${PMC_TAG:-r5}.json
   S=$(find $OUT/pmc_sq1 -name "*counter_collection.csv" | head -1)
-  python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r4}.json $S > $OUT/pmc_sq_${PMC_TAG:-r4}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r4}.txt
+  python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r5}.json $S > $OUT/pmc_sq_${PMC_TAG:-r5}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r5}.txt
   rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq1
 fi
 if has smoke; then
