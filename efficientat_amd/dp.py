@@ -77,7 +77,7 @@ class GradReducer:
             base = self.gbuf.data_ptr()
             for slot in self.slots[self.done:]:
                 if slot[0] == name and grad.data_ptr() == base + 4 * slot[1] and grad.numel() == slot[2]:
-                    slot[4] = True
+                    slot[3], slot[4] = tuple(grad.shape), True      # (handed out 2-D, pushed in the parameter's shape)
                     self._flush_flat()
                     return
         self.cur.append((name, grad))

@@ -74,14 +74,15 @@ def _flat_worker(rank, world, port, ret):
                     assert float(mem.abs().max()) == 0.0            # zero-filled: the kernels accumulate into it
                     mem.add_(vals[k])                               # "the kernel produces the gradient in its bucket"
                     handed[k] = mem
-                    red.push(k, mem)
+                    red.push(k, mem.view(*mem.shape, 1, 1) if k == "p.weight" else mem)   # pushed in the PARAMETER's shape
                 else:
                     red.push(k, vals[k].clone())
             out = red.finish()
             for k in order:
                 exp = sum(torch.randn({**big, **small}[k], generator=_gen_upto(1000 * it + r, order, k, {**big, **small}))
                           for r in range(world)) / world
-                ok = ok and torch.allclose(out[k], exp, atol=1e-6) and tuple(out[k].shape) == tuple({**big, **small}[k])
+                want = tuple({**big, **small}[k]) + ((1, 1) if (k == "p.weight" and k in handed) else ())
+                ok = ok and torch.allclose(out[k].reshape(exp.shape), exp, atol=1e-6) and tuple(out[k].shape) == want
             inplace.append(sorted(k for k in handed if out[k].data_ptr() == handed[k].data_ptr()))
         ret[rank] = (bool(ok), inplace)
     finally:

@@ -141,6 +141,37 @@ def test_pw_conv_with_statistics_epilogue(B, Ci, Co, F_, T, mode, per_sample, tf
     assert _rel(bn.running_var, 0.99 + 0.01 * var * (B * S) / (B * S - 1)) < 1e-5
 
 
+@pytest.mark.parametrize("shift", [10.0, 30.0])
+@pytest.mark.parametrize("B,Ci,Co,F_,T", [(64, 960, 160, 4, 32), (16, 240, 40, 16, 125), (4, 64, 16, 64, 500)])
+def test_pw_conv_statistics_epilogue_with_large_channel_means(B, Ci, Co, F_, T, shift):
+    """the epilogue sums z and z^2 of a 256-column tile in fp32 and only the tiles in fp64; with |mean| = `shift`
+    standard deviations the variance is a difference of (shift^2 + 1)-times larger sums.  Each tile's fp32 sum carries
+    ~2^-24 sqrt(256) relative round-off, independent from tile to tile, so the variance error is
+    ~1e-6 (shift^2 + 1) / sqrt(tiles) - measured here against fp64 statistics of the same z: <= 2e-4 relative on invstd at
+    30 sigma with 32 tiles, far inside what eps = 1e-3 and the 1e-3 logit budget absorb (the expand convs, whose statistics
+    come from the Gram matrix, were the case that needed centring: test_expand_conv_bn_act_via_gram_matrix)."""
+    S = F_ * T
+    W = _rand(Co, Ci, seed=3, scale=Ci ** -0.5)
+    x = _rand(B, Ci, F_, T, seed=1)
+    # per-output-channel offset of `shift` standard deviations of z = W x (std of z ~ 1): add it through one input channel
+    z0 = torch.einsum("oi,bifs->bofs", W.double(), x.double())
+    sd = z0.std((0, 2, 3))
+    bias_like = (shift * sd).float()                                  # realised as an extra input channel of ones
+    Wb = torch.cat([W, bias_like[:, None], torch.zeros(Co, 3)], dim=1)          # Ci + 4 channels (Ci % 4 stays 0)
+    xb = torch.cat([x, torch.ones(B, 1, F_, T), torch.zeros(B, 3, F_, T)], dim=1)
+    bn = torch.nn.BatchNorm2d(Co, eps=1e-3, momentum=0.01).to(DEV).train()
+    with ops.precision("auto"):
+        z, parts = ops.pw_conv_stats(xb.to(DEV), ops.pw_prepack(Wb.to(DEV)), Co)
+    st = ops.bn_state_from_partials(parts, bn, B * S)
+    zd = z.cpu().double()
+    mu, var = zd.mean((0, 2, 3)), zd.var((0, 2, 3), unbiased=False)
+    ratio = float((mu.abs() / var.sqrt()).median())
+    assert abs(ratio - shift) < 0.2 * shift, ratio                    # the construction really put the mean `shift` sigmas out
+    e_mu, e_is = _rel(st[2], mu), _rel(st[3], (var + 1e-3).rsqrt())
+    print(f"pw stats epilogue |mean|/std = {ratio:.1f}, {B * S // 256} tiles: rel err mean {e_mu:.1e}, invstd {e_is:.1e}")
+    assert e_mu < 1e-5 and e_is < 2e-4 * max(1.0, shift / 30.0), (e_mu, e_is)
+
+
 @pytest.mark.parametrize("shift", [0.5, 10.0, 30.0])
 @pytest.mark.parametrize("B,Ci,Co,F_,T,act,exact", [(3, 16, 64, 64, 500, 1, True), (3, 16, 64, 64, 500, 1, False),
                                                      (4, 40, 120, 16, 125, 1, False), (5, 112, 672, 8, 63, 2, False),

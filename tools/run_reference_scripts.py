@@ -9,6 +9,12 @@ working directory is a scratch folder with what the scripts expect relative to t
 (synthetic label names), resources/<checkpoint>.pt (a synthetic state_dict under the released file name: torch.hub then
 uses the cached file, no network), resources/<clip>.wav (44.1 kHz PCM, so the resampler runs), the KD teacher logits and
 the file-name index.  Needs a GPU: the product has no CPU path.
+
+Round 5: `--audio <wav>` runs inference.py / windowed_inference.py on a given recording (the reference's own
+resources/metro_station-paris.wav: BASELINE configs[0]'s file) instead of the synthetic clip, and the log starts with the
+commit it was asked to record (`--commit`, the GPU box has no .git) and a sha256 over the product tree it actually ran
+(`tree_sha`: every file under efficientat_amd/ except build products, dropin/, include/).  `--verify <log>` recomputes
+that hash on the tree it is run in and fails when it differs: the log of record must come from the committed state.
 """
 import argparse
 import csv
@@ -22,6 +28,22 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tree_sha():
+    """sha256 over the product sources (paths + contents, sorted): what a run of the reference scripts exercises."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for top in ("efficientat_amd", "dropin", "include"):
+        for d, _, fs in os.walk(os.path.join(ROOT, top)):
+            if "__pycache__" in d:
+                continue
+            files += [os.path.join(d, f) for f in fs if f.endswith((".py", ".hip", ".h", ".cpp"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_workdir(work, n_train=48, n_test=527):
@@ -104,17 +126,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default=os.environ.get("EAT_REFERENCE_ROOT", "/root/reference"))
     ap.add_argument("--out", default=None)
+    ap.add_argument("--audio", default=None, help="wav file for inference.py / windowed_inference.py (default: a synthetic clip)")
+    ap.add_argument("--commit", default="unknown", help="commit hash to record in the log (the GPU box has no .git)")
+    ap.add_argument("--verify", default=None, help="check that this log was produced from the tree this script runs in")
     a = ap.parse_args()
+    if a.verify:
+        m = re.search(r"tree_sha (\w+)", open(a.verify).read())
+        ok = bool(m) and m.group(1) == tree_sha()
+        print(f"{a.verify}: tree_sha {m.group(1) if m else None} vs this tree {tree_sha()}: {'MATCH' if ok else 'DIFFERENT'}")
+        sys.exit(0 if ok else 1)
     work = tempfile.mkdtemp(prefix="eat_refscripts_")
     env = build_workdir(work)
-    log = []
-    runs = [("inference.py", ["--cuda", "--audio_path", "resources/synthetic_clip.wav"]),
+    clip = "resources/synthetic_clip.wav"
+    if a.audio:
+        import shutil
+        clip = "resources/" + os.path.basename(a.audio)
+        shutil.copy(a.audio, os.path.join(work, clip))
+    log = [f"# tools/run_reference_scripts.py: commit {a.commit}, tree_sha {tree_sha()}, audio {clip}: the reference's unmodified scripts\n"]
+    runs = [("inference.py", ["--cuda", "--audio_path", clip]),
             ("ex_audioset.py", ["--cuda", "--batch_size", "31", "--num_workers", "0"]),               # evaluate(): fp16 autocast
             ("ex_audioset.py", ["--train", "--cuda", "--batch_size", "8", "--num_workers", "0", "--n_epochs", "1",
                                 "--epoch_len", "32", "--pretrained"])]
     if os.path.exists(os.path.join(a.ref, "windowed_inference.py")):
-        runs.append(("windowed_inference.py", ["--cuda", "--audio_path", "resources/synthetic_clip.wav", "--window_size", "4.0",
-                                               "--hop_length", "3.0"]))
+        runs.append(("windowed_inference.py", ["--cuda", "--audio_path", clip, "--window_size", "4.0", "--hop_length", "3.0"]))
     rc_all = 0
     for script, argv in runs:
         rc, out, err = run_script(a.ref, script, argv, work, env)
