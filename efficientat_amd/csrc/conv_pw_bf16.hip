@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   eat::pw_epilogue<MTW, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
   if (stats) {                                             // block-uniform: train-mode statistics of the output (pw_epilogue.h)
     __syncthreads();                                       // every wave is done with the operand stages: LDS is free
-    eat::pw_epilogue_stats<MTW>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, tile, mt0, kq, lane, wv, col_ok, Co);
+    eat::pw_epilogue_stats<MTW, YT>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, tile, mt0, kq, lane, wv, col_ok, Co);
   }
 }
 
@@ -341,9 +341,9 @@ int launch(hipStream_t s, const XT* x, const __bf16* wp, const float* bias, cons
   const int n_blocks = ((n_tiles + 7) / 8 * 8) * MC;
   const int n_stages = (2 * stage <= 78 * 1024 || n_blocks < 2 * 256) ? 2 : 1;
   const size_t smem = n_stages * stage;
-  // (the on-load transform exists for fp32 -> fp32 and bf16 -> fp32: the project conv of the training plans)
-  constexpr bool TFOK = std::is_same<YT, float>::value;
-  if (tf.a && !TFOK) return eat::fail(EAT_EINVAL, "eat_pw_conv: the on-load transform needs an fp32 output");
+  // (the on-load transform exists for fp32 -> fp32 and bf16 -> fp32 / bf16: the project conv of the training plans)
+  constexpr bool TFOK = std::is_same<YT, float>::value || XB;
+  if (tf.a && !TFOK) return eat::fail(EAT_EINVAL, "eat_pw_conv: the on-load transform needs an fp32 output or a bf16 input");
   auto kern = (tf.a && TFOK) ? (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, TFOK, XT, YT> : pw_conv_bf16_kernel<MTW, NPROD, 1, TFOK, XT, YT>)
                    : (n_stages == 2 ? pw_conv_bf16_kernel<MTW, NPROD, 2, false, XT, YT> : pw_conv_bf16_kernel<MTW, NPROD, 1, false, XT, YT>);
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: LDS stage too large (%zu B; planes of %d positions)", smem, S);
@@ -501,6 +501,7 @@ extern "C" int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float*
 //   x_b16 = 1, y_b16 = 0   project conv z_p = Wp act(tf_a x + tf_b) * in_scale with the statistics epilogue (stats_part, as
 //                          eat_pw_conv_stats_fwd), or the two-source data-gradient GEMM dx = [WaT | M] [g ; x2] + bias + res
 //                          (x2 fp32 with Ci - c1 channels, c1 % 32 == 0; as eat_pw_conv_cat_fwd)
+//   x_b16 = 1, y_b16 = 1   the project conv with z_p stored in bf16 as well (statistics of the stored values); no x2 / res
 // wp: eat_pw_prepack_bf16(split = 0) of the (Co, Ci) matrix.  S % 8 == 0, Ci % 4 == 0 (% 8 with a transform).
 extern "C" int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const void* wp, const float* bias,
                                    const float* tf_a, const float* tf_b, int tf_act, const float* in_scale, const float* res,
@@ -529,5 +530,11 @@ extern "C" int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, in
                                            reinterpret_cast<float*>(y), nullptr, B, Ci, Co, S, act, Ci, tf, x2, c1, false,
                                            stats_part);
   }
-  return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: exactly one of x / y is the bf16 (wide) tensor");
+  if (x_b16 && y_b16) {
+    if (x2 || res) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: bf16 -> bf16 takes no second source / residual");
+    return dispatch<1, eat::bf16_t, eat::bf16_t>(s, reinterpret_cast<const eat::bf16_t*>(x), w16, bias, in_scale, nullptr,
+                                                 reinterpret_cast<eat::bf16_t*>(y), nullptr, B, Ci, Co, S, act, Ci, tf, nullptr, 0,
+                                                 false, stats_part);
+  }
+  return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: at least one of x / y is a bf16 tensor");
 }

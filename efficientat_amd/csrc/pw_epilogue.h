@@ -165,7 +165,8 @@ __device__ __forceinline__ float row16_sum_lane15(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));   // row_shr:8
   return v;                                                // lane 15 of every 16-lane row holds the row's sum
 }
-template <int MTW>
+// YT = bf16: the output was STORED in bf16 - the sums are those of the rounded values (act_io.h)
+template <int MTW, typename YT = float>
 __device__ __forceinline__ void pw_epilogue_stats(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, float* scratch,
                                                   float* __restrict__ part, int tile, int mt0, int kq, int lane, int wv,
                                                   bool col_ok, int Co) {
@@ -175,7 +176,8 @@ __device__ __forceinline__ void pw_epilogue_stats(const acc_f32x4 (&acc)[MTW][4]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float bm = s_bias[i * 16 + kq * 4 + r];
-      const float v0 = acc[i][0][r] + bm, v1 = acc[i][1][r] + bm, v2 = acc[i][2][r] + bm, v3 = acc[i][3][r] + bm;
+      const float v0 = Io<YT>::rnd(acc[i][0][r] + bm), v1 = Io<YT>::rnd(acc[i][1][r] + bm);
+      const float v2 = Io<YT>::rnd(acc[i][2][r] + bm), v3 = Io<YT>::rnd(acc[i][3][r] + bm);
       float sm = ((v0 + v1) + (v2 + v3)) * ok;
       float sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, v3 * v3))) * ok;
       sm = row16_sum_lane15(sm);

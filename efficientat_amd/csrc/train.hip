@@ -130,11 +130,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
 }
 
 // ---- y = act(a_c z + b_c) [+ res]; optional per-(b,c) sums of y (SE squeeze / head pool) ----------
-// ZT: storage type of z and y (act_io.h; bf16 in the bf16-storage plan: the pool sums the values as STORED)
-template <int ACT, typename ZT = float>
+// ZT / YT: storage types of z / y (act_io.h; bf16 in the bf16-storage plan: the pool sums the values as STORED; ZT = bf16 with
+// YT = float: the project conv's BatchNorm - z_p is stored in bf16, the block output it produces is an fp32 tensor)
+template <int ACT, typename ZT = float, typename YT = ZT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const ZT* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
-                                                         ZT* __restrict__ y, float* __restrict__ pool, int C, int S) {
+                                                         YT* __restrict__ y, float* __restrict__ pool, int C, int S) {
   __shared__ float s_red[16];
   const int plane = blockIdx.x, c = plane % C;
   const float av = a[c], bv = b[c];
@@ -150,14 +151,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const ZT* __restrict__ 
         const float4 r = *reinterpret_cast<const float4*>(res + base + i);
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      if constexpr (Io<ZT>::kBf) { o.x = eat::bf_round(o.x); o.y = eat::bf_round(o.y); o.z = eat::bf_round(o.z); o.w = eat::bf_round(o.w); }
-      if (y) Io<ZT>::store4(y + base + i, o);
+      if constexpr (Io<YT>::kBf) { o.x = eat::bf_round(o.x); o.y = eat::bf_round(o.y); o.z = eat::bf_round(o.z); o.w = eat::bf_round(o.w); }
+      if (y) Io<YT>::store4(y + base + i, o);
       ps += (o.x + o.y) + (o.z + o.w);
     }
   } else {
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-      float o = Io<ZT>::rnd(eat::activate<ACT>(fmaf(av, Io<ZT>::load1(z + base + i), bv)) + (res ? res[base + i] : 0.0f));
-      if (y) Io<ZT>::store1(y + base + i, o);
+      float o = Io<YT>::rnd(eat::activate<ACT>(fmaf(av, Io<ZT>::load1(z + base + i), bv)) + (res ? res[base + i] : 0.0f));
+      if (y) Io<YT>::store1(y + base + i, o);
       ps += o;
     }
   }
@@ -174,9 +175,9 @@ __device__ __forceinline__ float grad_pre(float dy, float zv, float av, float bv
 }
 
 // ---- backward pass 1: per-channel sum g and sum g*xhat -------------------------------------------------
-template <int ACT, typename ZT = float>
+template <int ACT, typename ZT = float, typename DT = ZT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
-    const ZT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
+    const DT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, int C, int S, double* __restrict__ sums) {
   __shared__ float s_red[16];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   if ((S & 3) == 0) {
 #pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
-      const float4 d = Io<ZT>::load4(dy + base + i);
+      const float4 d = Io<DT>::load4(dy + base + i);
       const float4 v = Io<ZT>::load4(z + base + i);
       const float g0 = grad_pre<ACT>(d.x, v.x, av, bv, gs, ga), g1 = grad_pre<ACT>(d.y, v.y, av, bv, gs, ga);
       const float g2 = grad_pre<ACT>(d.z, v.z, av, bv, gs, ga), g3 = grad_pre<ACT>(d.w, v.w, av, bv, gs, ga);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   } else {
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
       const float zv = Io<ZT>::load1(z + base + i);
-      const float g = grad_pre<ACT>(Io<ZT>::load1(dy + base + i), zv, av, bv, gs, ga);
+      const float g = grad_pre<ACT>(Io<DT>::load1(dy + base + i), zv, av, bv, gs, ga);
       s1 += g;
       s2 += g * (zv - mu);
     }
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 }
 
 // small planes: one block per (channel, PPB samples), see bn_stats_multi_kernel
-template <int ACT, typename ZT = float>
+template <int ACT, typename ZT = float, typename DT = ZT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
-    const ZT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
+    const DT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, int B, int C, int S4, int PPB,
     double* __restrict__ sums) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
     const int bl = e / S4, i = e - bl * S4;
     const size_t plane = (size_t)(b0 + bl) * C + c;
     const float gs = gscale ? gscale[plane] : 1.0f, ga = gadd ? gadd[plane] : 0.0f;
-    const float4 d = Io<ZT>::load4(dy + plane * (4 * S4) + 4 * i);
+    const float4 d = Io<DT>::load4(dy + plane * (4 * S4) + 4 * i);
     const float4 v = Io<ZT>::load4(z + plane * (4 * S4) + 4 * i);
     const float g0 = grad_pre<ACT>(d.x, v.x, av, bv, gs, ga), g1 = grad_pre<ACT>(d.y, v.y, av, bv, gs, ga);
     const float g2 = grad_pre<ACT>(d.z, v.z, av, bv, gs, ga), g3 = grad_pre<ACT>(d.w, v.w, av, bv, gs, ga);
@@ -243,9 +244,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
 }
 
 // ---- backward pass 2: dz = a * (g - sum_g/N - xhat * sum_gx/N) ----------------------------------------------
-template <int ACT>
+template <int ACT, typename ZT = float>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ a,
+    const float* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, const double* __restrict__ sums,
     float* __restrict__ dz, int C, int S, double n) {
@@ -262,11 +263,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
 #pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
       const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
-      const float4 v = *reinterpret_cast<const float4*>(z + base + i);
+      const float4 v = Io<ZT>::load4(z + base + i);
       *reinterpret_cast<float4*>(dz + base + i) = make_float4(f(d.x, v.x), f(d.y, v.y), f(d.z, v.z), f(d.w, v.w));
     }
   } else {
-    for (int i = threadIdx.x; i < S; i += blockDim.x) dz[base + i] = f(dy[base + i], z[base + i]);
+    for (int i = threadIdx.x; i < S; i += blockDim.x) dz[base + i] = f(dy[base + i], Io<ZT>::load1(z + base + i));
   }
 }
 
@@ -1492,35 +1493,62 @@ extern "C" int eat_bn_act_bwd_reduce(const float* dy, const float* z, const floa
 // ---- the two stand-alone BatchNorm passes of the bf16-storage plan (act_io.h; BASELINE configs[2]): the depthwise output
 // z_d and the gradient arriving at it are bf16 in HBM.  Same arithmetic as the fp32 entry points; y (or NULL) is written in
 // bf16 and `pool` sums the ROUNDED values - what the project conv will read.  (S % 4 != 0: element-wise path.)
-extern "C" int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, void* y, float* pool, int B, int C, int S,
-                                  int act, eat_stream_t stream) {
+extern "C" int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, const float* res, void* y, int y_b16,
+                                  float* pool, int B, int C, int S, int act, eat_stream_t stream) {
   eat::clear_stale_error();
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: bad act %d", act);
   if (!z || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: bad shape");
+  if (res && y_b16) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: a residual is added to an fp32 output only");
   const dim3 blk(S >= 1024 ? 256 : 64);
-  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0, (hipStream_t)stream,
-                                           reinterpret_cast<const eat::bf16_t*>(z), a, b, (const float*)nullptr,
-                                           reinterpret_cast<eat::bf16_t*>(y), pool, C, S));
+  const eat::bf16_t* z16 = reinterpret_cast<const eat::bf16_t*>(z);
+  if (y_b16)
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0, (hipStream_t)stream,
+                                             z16, a, b, (const float*)nullptr, reinterpret_cast<eat::bf16_t*>(y), pool, C, S));
+  else
+    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, eat::bf16_t, float>), EAT_PLANES_GRID(B, C), blk, 0,
+                                             (hipStream_t)stream, z16, a, b, res, reinterpret_cast<float*>(y), pool, C, S));
   return eat::check_launch("eat_bn_act_fwd_b16");
 }
 
-extern "C" int eat_bn_act_bwd_reduce_b16(const void* dy, const void* z, const float* a, const float* b, const float* mean,
-                                         const float* invstd, const float* gscale, const float* gadd, int B, int C, int S,
-                                         int act, double* sums, eat_stream_t stream) {
+extern "C" int eat_bn_act_bwd_reduce_b16(const void* dy, int dy_b16, const void* z, const float* a, const float* b,
+                                         const float* mean, const float* invstd, const float* gscale, const float* gadd, int B,
+                                         int C, int S, int act, double* sums, eat_stream_t stream) {
   eat::clear_stale_error();
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_reduce_b16: bad act %d", act);
   if (!dy || !z || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_reduce_b16: bad shape");
-  const eat::bf16_t* d16 = reinterpret_cast<const eat::bf16_t*>(dy);
   const eat::bf16_t* z16 = reinterpret_cast<const eat::bf16_t*>(z);
-  if (const int ppb = bn_multi_ppb(B, C, S)) {
-    EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_multi_kernel<ACT, eat::bf16_t>), dim3(C, (B + ppb - 1) / ppb), dim3(256), 0,
-                                             (hipStream_t)stream, d16, z16, a, b, mean, invstd, gscale, gadd, B, C, S >> 2, ppb, sums));
-    return eat::check_launch("eat_bn_act_bwd_reduce_b16");
-  }
+  const int ppb = bn_multi_ppb(B, C, S);
   const dim3 blk(S >= 1024 ? 256 : 64);
-  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0,
-                                           (hipStream_t)stream, d16, z16, a, b, mean, invstd, gscale, gadd, C, S, sums));
+#define EAT_RED16(DT_, dyp)                                                                                                  \
+  do {                                                                                                                      \
+    if (ppb) {                                                                                                              \
+      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_multi_kernel<ACT, eat::bf16_t, DT_>), dim3(C, (B + ppb - 1) / ppb), \
+                                               dim3(256), 0, (hipStream_t)stream, dyp, z16, a, b, mean, invstd, gscale, gadd, B, C, \
+                                               S >> 2, ppb, sums));                                                         \
+    } else {                                                                                                                \
+      EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, eat::bf16_t, DT_>), EAT_PLANES_GRID(B, C), blk, 0,   \
+                                               (hipStream_t)stream, dyp, z16, a, b, mean, invstd, gscale, gadd, C, S, sums)); \
+    }                                                                                                                       \
+  } while (0)
+  if (dy_b16) EAT_RED16(eat::bf16_t, reinterpret_cast<const eat::bf16_t*>(dy));
+  else EAT_RED16(float, reinterpret_cast<const float*>(dy));
+#undef EAT_RED16
   return eat::check_launch("eat_bn_act_bwd_reduce_b16");
+}
+
+// apply pass over a bf16-stored z (the project conv's output z_p in the bf16-storage plan): dy and dz are fp32
+extern "C" int eat_bn_act_bwd_apply_b16(const float* dy, const void* z, const float* a, const float* b, const float* mean,
+                                        const float* invstd, const float* gscale, const float* gadd, const double* sums,
+                                        float* dz, int B, int C, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_apply_b16: bad act %d", act);
+  if (!dy || !z || !dz || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_apply_b16: bad shape");
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  const double n = (double)B * S;
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0,
+                                           (hipStream_t)stream, dy, reinterpret_cast<const eat::bf16_t*>(z), a, b, mean, invstd,
+                                           gscale, gadd, sums, dz, C, S, n));
+  return eat::check_launch("eat_bn_act_bwd_apply_b16");
 }
 
 extern "C" int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const float* b,

@@ -477,7 +477,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 if cna[1].training:
                     # centred Gram matrix of the block input (reproducible; x - mean on load: the variance is not a
                     # difference of two (mean / std)^2-times larger sums)
-                    G = ops.gram(inp, exact=exact, sx=sx)
+                    G = ops.gram(inp, exact=exact, sx=sx, plain_bf16=store16)
                     if W.shape[1] <= 192:
                         Tm, st_e = ops.gram_bn_state_g(G, W, sx, cna[1], n_e, centered=True)   # T = W Gc and the BatchNorm state, one launch
                     else:
@@ -527,8 +527,9 @@ class MNTrainFunction2(torch.autograd.Function):
                 # project conv from the bf16-stored z_d (BatchNorm + activation on load) or y_d, statistics in its epilogue
                 src_p, tf_p = (z_d, (st_d[0], st_d[1], act)) if on_load else (y_d, None)
                 if cna[1].training:
+                    # z_p too is stored in bf16 (statistics of the stored values); the block output below is fp32
                     z_p, parts = ops.pw_conv_b16(src_p, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, tf=tf_p,
-                                                 in_scale=scale, stats=True)
+                                                 in_scale=scale, stats=True, out_b16=True)
                     st_p = ops.bn_state_from_partials(parts, cna[1], z_p.numel() // cnf.out_channels)
                 else:
                     z_p = ops.pw_conv_b16(src_p, wp, _zeros.get(cnf.out_channels, dev), cnf.out_channels, NONE, tf=tf_p, in_scale=scale)
@@ -539,7 +540,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 z_p, st_p = _pw_conv_bn(y_d, wp, cnf.out_channels, cna[1], dev, in_scale=scale)
             need_sx = bi + 1 < len(blocks) and blocks[bi + 1].i_expand is not None
             pool_c = torch.empty((B, cnf.out_channels), device=dev) if need_sx else None
-            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None, pool=pool_c)
+            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None, pool=pool_c, y_f32=True)
             sx = ops.col_sum(pool_c) if need_sx else None
             rec.update(z_p=z_p, st_p=st_p)
             blk_saved.append(rec)

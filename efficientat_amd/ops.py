@@ -285,16 +285,20 @@ def bn_train_state(z, bn):
     return st
 
 
-def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True):
+def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True, y_f32=False):
+    """y = act(a[c] z + b[c]) [+ res]; pool (B, C): plane sums of y.  A bf16 z (bf16-storage plan): y is bf16 too - or, with
+    y_f32 (the project conv's BatchNorm: z_p stored in bf16, the block output fp32), fp32 with the optional fp32 residual."""
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
-    y = torch.empty_like(z) if write else None
-    if _is16(z):                                   # bf16 storage (BASELINE configs[2]): y in bf16, pool = sums of the stored values
-        if res is not None:
-            raise _lib.EatHipError("bn_act_fwd: no residual on a bf16-stored tensor")
-        _lib.call("eat_bn_act_fwd_b16", _dev16(z, "z"), a.data_ptr(), b.data_ptr(), None if y is None else y.data_ptr(),
-                  _opt(pool, "pool"), B, C, S, act, _stream())
+    if _is16(z):                                   # bf16 storage (BASELINE configs[2]): pool = sums of the values as stored
+        y16 = not y_f32
+        if res is not None and y16:
+            raise _lib.EatHipError("bn_act_fwd: a residual is added to an fp32 output only (y_f32=True)")
+        y = torch.empty(z.shape, device=z.device, dtype=torch.bfloat16 if y16 else torch.float32) if write else None
+        _lib.call("eat_bn_act_fwd_b16", _dev16(z, "z"), a.data_ptr(), b.data_ptr(), _opt(res, "res"),
+                  None if y is None else y.data_ptr(), 1 if y16 else 0, _opt(pool, "pool"), B, C, S, act, _stream())
         return y
+    y = torch.empty_like(z) if write else None
     _lib.call("eat_bn_act_fwd", _dev(z, "z"), a.data_ptr(), b.data_ptr(), _opt(res, "res"),
               None if y is None else y.data_ptr(), _opt(pool, "pool"), B, C, S, act, _stream())
     return y
@@ -311,11 +315,21 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=No
     own = sums is None            # sums: a zeroed (2C,) float64 slice of the caller's arena (one fp32 conversion per pass)
     if own:
         sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
+    asums = torch.zeros_like(sums) if frozen else sums
+    if _is16(z):                  # bf16-storage plan: the project conv's z_p is bf16, its gradient and dz are fp32 tensors
+        tail = (a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"))
+        _lib.call("eat_bn_act_bwd_reduce_b16", _dev(dy, "dy"), 0, _dev16(z, "z"), *tail, B, C, S, act, sums.data_ptr(), _stream())
+        dz = torch.empty(z.shape, device=z.device, dtype=torch.float32)
+        _lib.call("eat_bn_act_bwd_apply_b16", _dev(dy, "dy"), _dev16(z, "z"), *tail, asums.data_ptr(), dz.data_ptr(), B, C, S,
+                  act, _stream())
+        if not own:
+            return dz, None, None
+        sf = sums.float()
+        return dz, sf[C:], sf[:C]
     args = (_dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
             _opt(gscale, "gscale"), _opt(gadd, "gadd"))
     _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
     dz = torch.empty_like(z)
-    asums = torch.zeros_like(sums) if frozen else sums
     _lib.call("eat_bn_act_bwd_apply", *args, asums.data_ptr(), dz.data_ptr(), B, C, S, act, _stream())
     if not own:
         return dz, None, None
@@ -423,15 +437,17 @@ def pw_conv_cat(x1, x2, wp, bias, Co, act, res=None):
     return y
 
 
-def gram(x, exact=False, sx=None):
+def gram(x, exact=False, sx=None, plain_bf16=False):
     """G (C, C) = sum_{b,s} x x^T, bit-reproducible from run to run: every block of the weight-gradient kernel adds into
     its own zeroed copy and the copies are summed in a fixed order (the BatchNorm statistics of the expand conv follow
     from G - csrc/train_fuse.hip - so its round-off decides on which side of a ReLU / Hardswish kink activations fall).
     sx (C,) = sum_{b,s} x: the CENTRED matrix Gc = sum (x - m)(x - m)^T, m = sx / n, instead (`centered=True` in
-    `gram_bn_state*` / `expand_bwd_coef`): the variance w^T Gc w / n is then not a difference of two large sums."""
+    `gram_bn_state*` / `expand_bwd_coef`): the variance w^T Gc w / n is then not a difference of two large sums.
+    plain_bf16: single bf16 products (the bf16-storage plan: the conv output these statistics describe is itself stored
+    with 2^-9 relative rounding; the centring happens BEFORE the rounding, the accumulation stays fp32)."""
     B, C = x.shape[0], x.shape[1]
     S = x.numel() // (B * C)
-    mode = 1 if exact else 0
+    mode = 1 if exact else (2 if plain_bf16 else 0)
     # (64 < C <= 160: the wide-tile kernel STORES its per-slice copies - no zero fill needed for them)
     stored = _lib.lib().eat_pw_wgrad_kernel_kind(B, C, C, S, mode, 1, 0, 0) == 3
     if sx is not None:
@@ -634,9 +650,12 @@ def bn_act_bwd_sums(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, se_P
         if own:
             sums = zero_arena.zeros((2 * C,), torch.float64, z.device)
         b16 = _is16(z)
-        _lib.call("eat_bn_act_bwd_reduce_b16" if b16 else "eat_bn_act_bwd_reduce", (_dev16 if b16 else _dev)(dy, "dy"),
-                  (_dev16 if b16 else _dev)(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
-                  invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), B, C, S, act, sums.data_ptr(), _stream())
+        tail = (a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"), B, C, S,
+                act, sums.data_ptr(), _stream())
+        if b16:
+            _lib.call("eat_bn_act_bwd_reduce_b16", _dev16(dy, "dy"), 1, _dev16(z, "z"), *tail)
+        else:
+            _lib.call("eat_bn_act_bwd_reduce", _dev(dy, "dy"), _dev(z, "z"), *tail)
     if not own:
         return sums, None, None
     sf = sums.float()
@@ -762,7 +781,14 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, nee
               w2e[Ci].data_ptr(), 1 if centered else 0, _stream())
     if frozen or not need_dx:
         return dW, vec[0], vec[1], tr[0], None, None
-    Mc = linear(w2e, tr[1], None, ACT_NONE)                                # [W2T ; e1] . WT^T -> (Ci + 1, Ci)
+    if precision.mode != "fp32" and Ci % 4 == 0 and Co % 4 == 0 and W.is_contiguous():
+        # [W2T ; e1] . W as the 1x1 conv of the "image" W (1, Co, Ci, 1) with the (Ci + 1, Co) matrix on the split-operand
+        # bf16x3 kernel (fp32-class products; round 5: the K-split `linear` kernel ran these C_in x C_in x C_exp products at
+        # 15 TFLOP/s - 14 launches of up to 213 us in the mn40 step)
+        wp3 = pw_prepack_bf16(w2e, None, split=True)
+        Mc = pw_conv_bf16(W.view(1, Co, Ci, 1), wp3, _zero_bias(Ci + 1, dev), Ci + 1, ACT_NONE, split=True).view(Ci + 1, Ci)
+    else:
+        Mc = linear(w2e, tr[1], None, ACT_NONE)                            # [W2T ; e1] . WT^T -> (Ci + 1, Ci)
     return dW, vec[0], vec[1], tr[0], Mc[:Ci], Mc[Ci]
 
 
@@ -1115,7 +1141,7 @@ def b16_block_ok(B, C_exp, F, T, k, stride):
             and (Fo * To) % 8 == 0 and C_exp % 8 == 0)
 
 
-def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None, stats=False):
+def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None, stats=False, out_b16=False):
     """1x1 conv of the bf16-storage plan: exactly one of input / output is the wide bf16 tensor (`eat_pw_conv_b16_fwd`).
     x fp32 -> y bf16 (expand conv, project data gradient); x bf16 -> y fp32 (project conv with tf = (a, b, act) / in_scale /
     stats=True -> (y, parts); two-source data-gradient GEMM with x2 fp32 + res).  wp: plain bf16 pack (precision 'bf16')."""
@@ -1125,7 +1151,8 @@ def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None,
     S = F * T
     x16 = _is16(x)
     Ci = C1 + (x2.shape[1] if x2 is not None else 0)
-    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32 if x16 else torch.bfloat16)
+    y16 = out_b16 or not x16                       # (fp32 in: always a bf16 output; bf16 in: fp32, or bf16 for z_p)
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.bfloat16 if y16 else torch.float32)
     part = None
     if stats:
         tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, S, 0))
@@ -1133,7 +1160,7 @@ def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None,
     a, b, tact = tf if tf is not None else (None, None, 0)
     _lib.call("eat_pw_conv_b16_fwd", _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(x2, "x2"), C1,
               wp.data_ptr(), _dev(bias, "bias"), _opt(a, "tf_a"), _opt(b, "tf_b"), tact, _opt(in_scale, "in_scale"),
-              _opt(res, "res"), y.data_ptr(), 0 if x16 else 1, None if part is None else part.data_ptr(), B, Ci, Co, S, act,
+              _opt(res, "res"), y.data_ptr(), 1 if y16 else 0, None if part is None else part.data_ptr(), B, Ci, Co, S, act,
               _stream())
     return (y, (part, tiles, 1)) if stats else y
 

@@ -670,7 +670,8 @@ int eat_mlp_head_bwd(const float* dlogits, const float* h2, const float* u, cons
  *   x_b16 = 0, y_b16 = 1: z_e = W x (expand conv) or dxs = Wp^T dz_p (project data gradient): plain conv, everything optional NULL;
  *   x_b16 = 1, y_b16 = 0: z_p = Wp (act(tf_a x + tf_b) * in_scale) with the statistics epilogue (stats_part as
  *          eat_pw_conv_stats_fwd, tiles = eat_pw_conv_stat_tiles(B, S, 0)), or the two-source data-gradient GEMM
- *          dx = [WaT | M] [g ; x2] + bias + res with x2 (B, Ci - c1, S) fp32, c1 % 32 == 0 (as eat_pw_conv_cat_fwd).
+ *          dx = [WaT | M] [g ; x2] + bias + res with x2 (B, Ci - c1, S) fp32, c1 % 32 == 0 (as eat_pw_conv_cat_fwd);
+ *   x_b16 = 1, y_b16 = 1: the project conv with its output z_p stored in bf16 too (statistics of the stored values).
  * wp = eat_pw_prepack_bf16(split = 0) of the (Co, Ci) matrix, Ci = all reduction channels; S % 8 == 0, Ci % 4 == 0
  * (% 8 with a transform). */
 int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const void* wp, const float* bias,
@@ -685,15 +686,21 @@ int eat_dw_conv_fwd_stats_b16(const void* x, int x_b16, const float* in_a, const
                               float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
                               int stride, eat_stream_t stream);
 
-/* Twin of eat_bn_act_fwd (block_types.py:150-162, 72-73): z bf16 -> y bf16 (or NULL: squeeze sums only), pool (B, C) plain
- * stores of the sums of the rounded y. */
-int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, void* y, float* pool, int B, int C, int S, int act,
-                       eat_stream_t stream);
+/* Twin of eat_bn_act_fwd (block_types.py:150-162, 72-73, 167-181): z bf16 -> y bf16 (y_b16 != 0; or NULL: squeeze sums only)
+ * or -> y fp32 with the optional fp32 residual `res` (the project conv's BatchNorm: z_p stored in bf16, the block output in
+ * fp32); pool (B, C) plain stores of the sums of y as stored. */
+int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, const float* res, void* y, int y_b16, float* pool, int B,
+                       int C, int S, int act, eat_stream_t stream);
 
-/* Twins of eat_bn_act_bwd_reduce and eat_se_bn_bwd_partials (backward of block_types.py:150-162, 72-83): dy / d and z bf16. */
-int eat_bn_act_bwd_reduce_b16(const void* dy, const void* z, const float* a, const float* b, const float* mean,
+/* Twins of eat_bn_act_bwd_reduce / _apply and eat_se_bn_bwd_partials (backward of block_types.py:150-181, 72-83): z bf16; dy
+ * bf16 (dy_b16 != 0: the depthwise BatchNorm, gradient dxs) or fp32 (the project BatchNorm); the apply pass (project
+ * BatchNorm only) reads fp32 dy and writes fp32 dz. */
+int eat_bn_act_bwd_reduce_b16(const void* dy, int dy_b16, const void* z, const float* a, const float* b, const float* mean,
                               const float* invstd, const float* gscale, const float* gadd, int B, int C, int S, int act,
                               double* sums, eat_stream_t stream);
+int eat_bn_act_bwd_apply_b16(const float* dy, const void* z, const float* a, const float* b, const float* mean,
+                             const float* invstd, const float* gscale, const float* gadd, const double* sums, float* dz, int B,
+                             int C, int S, int act, eat_stream_t stream);
 int eat_se_bn_bwd_partials_b16(const void* d, const void* z, const float* a, const float* b, const float* mean, float* P,
                                int B, int C, int S, int act, eat_stream_t stream);
 

@@ -169,8 +169,8 @@ class _GradBf16(torch.autograd.Function):
 class emulate_bf16_pointwise:
     """with O.emulate_bf16_pointwise(): every 1x1 convolution of mn_forward runs as `_PwBf16`.
     storage=True additionally emulates `act_storage="bf16"` (efficientat_amd/mn_train.py; the reference's 16-bit mixed
-    precision, ex_pl_audioset.py:287-293): in every inverted-residual block the expand output z_e, the depthwise output z_d
-    and its activated form y_d are rounded to bf16 where they are stored, and so are the two wide gradients of the
+    precision, ex_pl_audioset.py:287-293): in every inverted-residual block the expand output z_e, the depthwise output z_d,
+    its activated form y_d and the project conv's output z_p are rounded to bf16 where they are stored, and so are the two wide gradients of the
     backward - the one arriving at the project conv's input and g = dL/d(BN output of the expand conv)."""
 
     def __init__(self, storage=False):
@@ -189,7 +189,7 @@ class emulate_bf16_pointwise:
 def _cna(sd, prefix, x, train, stats, k, stride, groups, act, dil=1, store=None):
     """ConvNormActivation (torchvision 0.14): conv(bias=False,pad=(k-1)//2*dilation) + BN + act.
     store (bf16-storage emulation only): "expand" = conv output stored in bf16, gradient w.r.t. the BN output stored in
-    bf16; "depthwise" = conv output and activated output stored in bf16."""
+    bf16; "depthwise" = conv output and activated output stored in bf16; "project" = conv output stored in bf16."""
     if PW_BF16 and k == 1 and groups == 1:
         x = _PwBf16.apply(x, sd[prefix + ".0.weight"])
     else:
@@ -253,7 +253,7 @@ def _inverted_residual(sd, prefix, x, c, train, stats, use_se=True, se_dims=(1,)
         j += 1
     if st16:
         x = _GradBf16.apply(x)                              # the project conv's data gradient is stored in bf16
-    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, None)
+    x = _cna(sd, f"{prefix}.block.{j}", x, train, stats, 1, 1, 1, None, store="project" if st16 else None)
     if c["stride"] == 1 and c["cin"] == c["cout"]:
         x = x + inp
     return x

@@ -93,6 +93,46 @@ def test_pw_conv_bf16_input_with_statistics(B, Ci, Co, F_, T, variant):
     assert _rel(part[0], y.double().sum((0, 2, 3)).cpu()) < 1e-5 and _rel(part[1], (y.double() ** 2).sum((0, 2, 3)).cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("B,Ci,Co,F_,T", PW)
+@pytest.mark.parametrize("variant", ["plain", "tf_se"])
+def test_pw_conv_bf16_input_and_output_with_statistics(B, Ci, Co, F_, T, variant):
+    """project conv with z_p stored in bf16 as well: bf16 in, bf16 out, the statistics of the STORED z_p."""
+    x16 = (_rand(B, Ci, F_, T, seed=1, scale=1.5) + _rand(1, Ci, 1, 1, seed=3)).to(DEV).bfloat16()
+    w = _rand(Co, Ci, seed=2, scale=Ci ** -0.5).to(DEV)
+    zb = torch.zeros(Co, device=DEV)
+    tf = sc = None
+    if variant == "tf_se":
+        tf = ((torch.rand(Ci, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV), _rand(Ci, seed=5, scale=0.3).to(DEV), RELU)
+        sc = (torch.rand(B, Ci, generator=torch.Generator().manual_seed(6)) + 0.25).to(DEV)
+    with ops.precision("bf16"):
+        wp = ops.pw_prepack(w)
+        y16, parts = ops.pw_conv_b16(x16, wp, zb, Co, NONE, tf=tf, in_scale=sc, stats=True, out_b16=True)
+        y32 = ops.pw_conv_b16(x16, wp, zb, Co, NONE, tf=tf, in_scale=sc)
+    _assert_is_rounding_of(y16, y32, "pw_conv bf16 -> bf16")
+    part = parts[0].view(parts[1], 2, Co).double().sum(0).cpu()
+    yd = y16.double().cpu()
+    assert _rel(part[0], yd.sum((0, 2, 3))) < 1e-5 and _rel(part[1], (yd ** 2).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,S,act", [(3, 64, 8000, 0), (5, 160, 504, 0), (300, 40, 2000, 0), (7, 24, 32000, 1)])
+def test_project_batchnorm_passes_over_a_bf16_stored_conv_output(B, C, S, act):
+    """z_p in bf16, everything around it fp32: y = BN(z_p) + residual (fp32 out, pool of the fp32 y) and the BatchNorm
+    backward (fp32 dy -> channel sums, fp32 dz) against the fp32-storage kernels on the same rounded z_p."""
+    z16 = (_rand(B, C, S, 1, seed=1, scale=1.5) + _rand(1, C, 1, 1, seed=2)).to(DEV).bfloat16()
+    res = _rand(B, C, S, 1, seed=3).to(DEV)
+    dy = _rand(B, C, S, 1, seed=4).to(DEV)
+    a = (torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5).to(DEV)
+    b = _rand(C, seed=6, scale=0.3).to(DEV)
+    mean, invstd = _rand(C, seed=7, scale=0.2).to(DEV), (torch.rand(C, generator=torch.Generator().manual_seed(8)) + 0.5).to(DEV)
+    p16, p32 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    y = ops.bn_act_fwd(z16, a, b, act, res=res, pool=p16, y_f32=True)
+    y_ref = ops.bn_act_fwd(z16.float(), a, b, act, res=res, pool=p32)
+    assert y.dtype == torch.float32 and torch.equal(y, y_ref) and _rel(p16, p32) < 1e-6
+    dz, dg, db = ops.bn_act_bwd(dy, z16, a, b, mean, invstd, act)
+    dz_ref, dg_ref, db_ref = ops.bn_act_bwd(dy, z16.float(), a, b, mean, invstd, act)
+    assert dz.dtype == torch.float32 and _rel(dz, dz_ref) < 1e-6 and _rel(dg, dg_ref) < 1e-5 and _rel(db, db_ref) < 1e-5
+
+
 @pytest.mark.parametrize("B,C1,C2,Co,F_,T", [(3, 256, 64, 64, 8, 63), (2, 288, 96, 96, 32, 250), (5, 960, 160, 160, 4, 32),
                                               (2, 32, 16, 16, 64, 500), (3, 736, 320, 320, 8, 63)])
 def test_two_source_pointwise_conv_bf16_first_source(B, C1, C2, Co, F_, T):
