@@ -62,6 +62,7 @@ SIGNATURES = {
     "eat_mixup_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "eat_col_sum": [_P, _P, _I, _I, _P],
     "eat_calib_copy": [_P, _P, ctypes.c_longlong, _I, _P],
+    "eat_cast_b16": [_P, _P, ctypes.c_longlong, _P],
     "eat_pw_conv_kcat_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dilated_fwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "eat_dw_conv_dilated_dgrad": [_P, _P, _P] + [_I] * 9 + [_P],

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(1024) void stem_gram_finalize_kernel(const float* _
 // 10 sums per channel; the window is loaded once per position.  The 9 taps + (a, b) of the channels sit in LDS and are
 // re-read per position as broadcast 16-byte reads (176 values do not fit the scalar registers, and per-position scalar
 // loads expose their latency: 0.87 ms; the memory clobber keeps the compiler from hoisting them into 192 VGPRs).
+// Round 5: channel groups of 4 (122 VGPRs, 4 waves per SIMD; groups of 8 took 232) and a one-deep software pipeline over
+// the (row, column-pass) iterations; same-box microbenchmark at B = 128, C = 64: 741 -> 625 us, B = 256, C = 16: 408 -> 344 us
+// (bit-identical sums: a thread adds the same values in the same order).
 template <int CG>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
                                                        const float* __restrict__ x,
@@ -151,40 +154,54 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     for (int c = 0; c < CG; ++c)
 #pragma unroll
       for (int t = 0; t < 10; ++t) acc[c][t] = 0.0f;
-    const float* gz = dy + ((size_t)b * C + c0) * Fo * To;
-    const float* gz2 = dy2 ? dy2 + ((size_t)b * C + c0) * Fo * To : nullptr;
-    for (int i = i0; i < i1; ++i) {
-      for (int j = threadIdx.x; j < To; j += 256) {
-        float xw[9];
-        load_window(xb, i, j, F, T, xw);
-        const size_t pos = (size_t)i * To + j;
-        float dv[CG];
+    // software pipeline over the block's (row, column-pass) iterations: the window and the CG gradient values of the NEXT
+    // iteration are in flight while this one is evaluated.  Range-checked buffer loads (no divergent branches): a channel
+    // past C or a column past To reads 0.
+    const int plane = Fo * To;
+    const int cg = (C - c0) < CG ? (C - c0) : CG;
+    const __amdgpu_buffer_rsrc_t gb = make_rsrc(dy + ((size_t)b * C + c0) * plane, 4LL * cg * plane);
+    const __amdgpu_buffer_rsrc_t gb2 = make_rsrc(dy2 ? dy2 + ((size_t)b * C + c0) * plane : dy, dy2 ? 4LL * cg * plane : 0LL);
+    const int KT = (To + 255) >> 8;
+    float xn[9], dn[CG], dn2[CG];
+    int ii = i0, kk = 0;
+    auto fetch = [&]() {
+      const int j = threadIdx.x + (kk << 8);
+      load_window(xb, ii, j, F, T, xn);
+      const unsigned vo = j < To ? 4u * (unsigned)(ii * To + j) : kOOB;
 #pragma unroll
-        for (int c = 0; c < CG; ++c) dv[c] = (c0 + c < C) ? gz[(size_t)c * Fo * To + pos] : 0.0f;
-        if (gz2) {                                             // uniform
+      for (int c = 0; c < CG; ++c) dn[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gb, (int)vo, 4 * c * plane, 0));
 #pragma unroll
-          for (int c = 0; c < CG; ++c) dv[c] += (c0 + c < C) ? gz2[(size_t)c * Fo * To + pos] : 0.0f;
-        }
-        asm volatile("" ::: "memory");
+      for (int c = 0; c < CG; ++c) dn2[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gb2, (int)vo, 4 * c * plane, 0));
+      if (++kk == KT) { kk = 0; ++ii; }
+    };
+    const int n_it = (i1 - i0) * KT;
+    if (n_it > 0) fetch();
+    for (int it = 0; it < n_it; ++it) {
+      float xw[9], dv[CG];
 #pragma unroll
-        for (int c = 0; c < CG; ++c) {
-          const float4 w0 = *reinterpret_cast<const float4*>(&s_w[c][0]);
-          const float4 w1 = *reinterpret_cast<const float4*>(&s_w[c][4]);
-          const float4 w2 = *reinterpret_cast<const float4*>(&s_w[c][8]);
-          float z = w0.x * xw[0];
-          z = fmaf(w0.y, xw[1], z); z = fmaf(w0.z, xw[2], z); z = fmaf(w0.w, xw[3], z);
-          z = fmaf(w1.x, xw[4], z); z = fmaf(w1.y, xw[5], z); z = fmaf(w1.z, xw[6], z); z = fmaf(w1.w, xw[7], z);
-          z = fmaf(w2.x, xw[8], z);
-          const float u = fmaf(w2.y, z, w2.z);
-          const float m_in = (u >= -3.0f && u <= 3.0f) ? 1.0f : 0.0f, m_hi = u > 3.0f ? 1.0f : 0.0f;
-          const float dhs = fmaf(fmaf(u, 1.0f / 3.0f, 0.5f), m_in, m_hi);
-          const float dre = u > 0.0f ? 1.0f : 0.0f;
-          const float d = is_hs ? dhs : (is_re ? dre : 1.0f);
-          const float g = dv[c] * d;
+      for (int t = 0; t < 9; ++t) xw[t] = xn[t];
 #pragma unroll
-          for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(g, xw[t], acc[c][t]);
-          acc[c][9] += g;
-        }
+      for (int c = 0; c < CG; ++c) dv[c] = dn[c] + dn2[c];
+      if (it + 1 < n_it) fetch();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const float4 w0 = *reinterpret_cast<const float4*>(&s_w[c][0]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&s_w[c][4]);
+        const float4 w2 = *reinterpret_cast<const float4*>(&s_w[c][8]);
+        float z = w0.x * xw[0];
+        z = fmaf(w0.y, xw[1], z); z = fmaf(w0.z, xw[2], z); z = fmaf(w0.w, xw[3], z);
+        z = fmaf(w1.x, xw[4], z); z = fmaf(w1.y, xw[5], z); z = fmaf(w1.z, xw[6], z); z = fmaf(w1.w, xw[7], z);
+        z = fmaf(w2.x, xw[8], z);
+        const float u = fmaf(w2.y, z, w2.z);
+        const float m_in = (u >= -3.0f && u <= 3.0f) ? 1.0f : 0.0f, m_hi = u > 3.0f ? 1.0f : 0.0f;
+        const float dhs = fmaf(fmaf(u, 1.0f / 3.0f, 0.5f), m_in, m_hi);
+        const float dre = u > 0.0f ? 1.0f : 0.0f;
+        const float d = is_hs ? dhs : (is_re ? dre : 1.0f);
+        const float g = dv[c] * d;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(g, xw[t], acc[c][t]);
+        acc[c][9] += g;
       }
     }
 #pragma unroll
@@ -250,7 +267,7 @@ extern "C" int eat_stem_bwd(const float* dy, const float* dy2, const float* x, c
   if (B < 1 || C < 1 || F < 1 || T < 1) return eat::fail(EAT_EINVAL, "eat_stem_bwd: bad shape");
   const int Fo = (F - 1) / 2 + 1, To = (T - 1) / 2 + 1, rpb = 8;
   const dim3 grid((unsigned)((Fo + rpb - 1) / rpb), (unsigned)B);
-  hipLaunchKernelGGL(stem_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy2, x, W, a, b, act, part, C, F, T, Fo,
+  hipLaunchKernelGGL(stem_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy2, x, W, a, b, act, part, C, F, T, Fo,
                      To, rpb);
   hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part,
                      (int)(grid.x * grid.y), C, gx, s1);

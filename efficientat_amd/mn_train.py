@@ -201,7 +201,9 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
         wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
         if b16:
-            dxs = ops.pw_conv_b16(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+            dz16 = ops.cast_b16(dz_p) if _cast_narrow(cnf, dz_p) else dz_p
+            dxs = ops.pw_conv_b16(dz16, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE, out_b16=True)
+            del dz16
         else:
             dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
         del dz_p
@@ -382,6 +384,7 @@ _DW_BN_ON_LOAD = True     # ... with the depthwise BatchNorm's own backward eval
 _EPI_STATS = True         # project / last conv: BatchNorm statistics in the 1x1 epilogue
 _PREPACK_PLAN = True      # all weight packs of the step from one launch
 _FUSE_STEM = True         # stem without its pre-activation tensor (csrc/stem_train.hip)
+_CAST_NARROW_MIN_CEXP = 1920   # bf16-storage plan: bf16 copy of the narrow operand of the expand / data-gradient conv from this width
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
 
 
@@ -392,6 +395,13 @@ def _w_times_g(W, G):
         return ops.linear(W, G, None, NONE)
     wp3 = ops.pw_prepack_bf16(W, None, split=True)
     return ops.pw_conv_bf16(G.view(1, Ci, Ci, 1), wp3, _zeros.get(Co, W.device), Co, NONE, split=True).view(Co, Ci)
+
+
+def _cast_narrow(cnf, x):
+    """bf16-storage plan: hand the expand / data-gradient 1x1 conv of the widest blocks a bf16 COPY of its narrow fp32 operand
+    (bit-identical results - the kernel rounds the operand the same way; measured on MI355X at B = 128: 320 -> 1920 at S = 504
+    209 -> 144 + 18 us, 448 -> 2688 324 -> 238 + 24 us, 640 -> 3840 at S = 128 123 -> 91 + 10 us; no gain below)."""
+    return cnf.expanded_channels >= _CAST_NARROW_MIN_CEXP and x.numel() % 8 == 0
 
 
 def _act_storage_bf16(model):
@@ -492,7 +502,10 @@ class MNTrainFunction2(torch.autograd.Function):
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
                 wp = _pk(plan, ("e", bi), cna[0].weight)
                 if b16:
-                    z_e = ops.pw_conv_b16(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+                    x16 = ops.cast_b16(inp) if _cast_narrow(cnf, inp) else inp
+                    z_e = ops.pw_conv_b16(x16, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE,
+                                          out_b16=True)
+                    del x16
                 else:
                     z_e = ops.pw_conv(inp, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
                 rec.update(z_e=z_e, st_e=st_e, Tm=Tm, sx=sx)

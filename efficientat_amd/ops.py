@@ -1165,6 +1165,13 @@ def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None,
     return (y, (part, tiles, 1)) if stats else y
 
 
+def cast_b16(x):
+    """bf16 copy of a contiguous fp32 tensor (numel % 8 == 0; `eat_cast_b16`)."""
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _lib.call("eat_cast_b16", _dev(x, "x"), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
 def pw_conv_wgrad_b16(dz, x, x_scale=None, tf=None, out=None):
     """dW (Co, Ci) = sum_b dz[b] . (act(tf_a x + tf_b) * x_scale)[b]^T with exactly one bf16 (wide) operand; plain bf16
     products, fp32 accumulation (`eat_pw_conv_wgrad_b16`)."""

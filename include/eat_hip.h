@@ -686,6 +686,11 @@ int eat_dw_conv_fwd_stats_b16(const void* x, int x_b16, const float* in_a, const
                               float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To, int k,
                               int stride, eat_stream_t stream);
 
+/* bf16 copy (round to nearest even) of n fp32 values, n % 8 == 0: the narrow operand of the widest blocks' expand /
+ * data-gradient 1x1 convs (models/mn/block_types.py:127-133), which eat_pw_conv_b16_fwd then reads with x_b16 = y_b16 = 1 -
+ * bit-identical to handing it the fp32 tensor (the kernel rounds the same way), at half the operand traffic. */
+int eat_cast_b16(const float* x, void* y, long long n, eat_stream_t stream);
+
 /* Twin of eat_bn_act_fwd (block_types.py:150-162, 72-73, 167-181): z bf16 -> y bf16 (y_b16 != 0; or NULL: squeeze sums only)
  * or -> y fp32 with the optional fp32 residual `res` (the project conv's BatchNorm: z_p stored in bf16, the block output in
  * fp32); pool (B, C) plain stores of the sums of y as stored. */

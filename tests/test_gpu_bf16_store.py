@@ -149,6 +149,26 @@ def test_two_source_pointwise_conv_bf16_first_source(B, C1, C2, Co, F_, T):
     assert _rel(y, y_ref) < 2e-6, _rel(y, y_ref)
 
 
+@pytest.mark.parametrize("B,Ci,Co,F_,T", [(3, 320, 1920, 8, 63), (2, 448, 2688, 8, 63), (5, 640, 3840, 4, 32), (2, 64, 256, 8, 40)])
+def test_bf16_copy_of_the_narrow_operand_leaves_the_conv_bit_identical(B, Ci, Co, F_, T):
+    """The widest blocks of the bf16-storage plan hand their expand / data-gradient conv a bf16 COPY of the narrow fp32
+    operand (eat_cast_b16; mn_train._cast_narrow): the copy is the round-to-nearest-even of the tensor and the conv's
+    output is bit-identical to the one computed from the fp32 tensor (the kernel rounds its operand the same way)."""
+    x = _rand(B, Ci, F_, T, seed=1, scale=3.0).to(DEV)
+    x.view(-1)[:4] = torch.tensor([1.00390625, 1.01171875, -1.00390625, 3.3895313892515355e38], device=DEV)  # ties, near-max
+    x16 = ops.cast_b16(x)
+    assert x16.dtype == torch.bfloat16 and torch.equal(x16, x.bfloat16())
+    w = _rand(Co, Ci, seed=2, scale=Ci ** -0.5).to(DEV)
+    zb = torch.zeros(Co, device=DEV)
+    with ops.precision("bf16"):
+        wp = ops.pw_prepack(w)
+        y_a = ops.pw_conv_b16(x, wp, zb, Co, NONE)
+        y_b = ops.pw_conv_b16(x16, wp, zb, Co, NONE, out_b16=True)
+    assert y_a.dtype == y_b.dtype == torch.bfloat16 and torch.equal(y_a, y_b)
+    with pytest.raises(_lib.EatHipError):
+        ops.cast_b16(torch.zeros(12, device=DEV))            # n % 8 != 0
+
+
 # (B, C, F, T, k, stride, act): every register-resident geometry (tile kernels incl. odd row widths, the five plane kernels,
 # two planes per wave, odd batches)
 DW = [(3, 64, 64, 500, 3, 2, 1), (2, 16, 64, 500, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1), (2, 24, 32, 250, 3, 1, 2),
