@@ -241,11 +241,18 @@ def _alg_bytes(name, a):
         x, x16, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:18]
         return f"dw_conv_fwd_stats<{k},{s},bf16>", B * C * ((2 if x16 else 4) * F * T + 2 * Fo * To), 2 * B * C * Fo * To * k * k
     if name == "eat_bn_act_fwd_b16":
-        z, aa, bb, y, pool, B, C, S, act = a[:9]
-        return f"bn_act_fwd_kernel<{act},bf16>", 2 * B * C * S * (1 + (1 if y else 0)), 4 * B * C * S
+        z, aa, bb, res, y, y16, yc, pool, B, C, S, act = a[:12]
+        per = 2 + (4 if res else 0) + ((2 if y16 else 4) if y else 0) + (2 if yc else 0)
+        return f"bn_act_fwd_kernel<{act},bf16,{'bf16' if y16 else 'float'}>", per * B * C * S, 4 * B * C * S
     if name == "eat_bn_act_bwd_reduce_b16":
-        B, C, S, act = a[8:12]
-        return f"bn_act_bwd_reduce_kernel<{act},bf16>", 4 * B * C * S, 8 * B * C * S
+        d16 = a[1]
+        B, C, S, act = a[9:13]
+        return f"bn_act_bwd_reduce_kernel<{act},bf16,{'bf16' if d16 else 'float'}>", ((2 if d16 else 4) + 2) * B * C * S, 8 * B * C * S
+    if name == "eat_bn_act_bwd_apply_b16":
+        B, C, S, act = a[11:15]
+        return f"bn_act_bwd_apply_kernel<{act},bf16>", (4 + 2 + 4 + (2 if a[10] else 0)) * B * C * S, 10 * B * C * S
+    if name == "eat_cast_b16":
+        return "cast_b16_kernel", 6 * a[2], 0
     if name == "eat_se_bn_bwd_partials_b16":
         B, C, S = a[6:9]
         return "se_bn_bwd_partials_kernel<bf16>", 4 * B * C * S, 12 * B * C * S

@@ -121,9 +121,9 @@ SIGNATURES = {
     "eat_pw_conv_b16_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_b16_ok": [_I] * 8,
     "eat_dw_conv_fwd_stats_b16": [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
-    "eat_bn_act_fwd_b16": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "eat_bn_act_fwd_b16": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "eat_bn_act_bwd_reduce_b16": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "eat_bn_act_bwd_apply_b16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eat_bn_act_bwd_apply_b16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_se_bn_bwd_partials_b16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_dw_conv_bwd_bn_g_b16": [_P] * 9 + [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_pw_wgrad_b16_slots": [_I] * 5,

@@ -135,7 +135,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
 template <int ACT, typename ZT = float, typename YT = ZT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const ZT* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
-                                                         YT* __restrict__ y, float* __restrict__ pool, int C, int S) {
+                                                         YT* __restrict__ y, float* __restrict__ pool, int C, int S,
+                                                         eat::bf16_t* __restrict__ y16 = nullptr) {
+  // y16: optional bf16 COPY of an fp32 y (the block output of the bf16-storage plan: the next block's expand conv reads the
+  // copy - bit-identical to reading y, the conv rounds its operand the same way - at half the operand traffic)
   __shared__ float s_red[16];
   const int plane = blockIdx.x, c = plane % C;
   const float av = a[c], bv = b[c];
@@ -153,12 +156,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const ZT* __restrict__ 
       }
       if constexpr (Io<YT>::kBf) { o.x = eat::bf_round(o.x); o.y = eat::bf_round(o.y); o.z = eat::bf_round(o.z); o.w = eat::bf_round(o.w); }
       if (y) Io<YT>::store4(y + base + i, o);
+      if (y16) Io<eat::bf16_t>::store4(y16 + base + i, o);
       ps += (o.x + o.y) + (o.z + o.w);
     }
   } else {
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
       float o = Io<YT>::rnd(eat::activate<ACT>(fmaf(av, Io<ZT>::load1(z + base + i), bv)) + (res ? res[base + i] : 0.0f));
       if (y) Io<YT>::store1(y + base + i, o);
+      if (y16) Io<eat::bf16_t>::store1(y16 + base + i, o);
       ps += o;
     }
   }
@@ -249,7 +254,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, const double* __restrict__ sums,
-    float* __restrict__ dz, int C, int S, double n) {
+    float* __restrict__ dz, int C, int S, double n, eat::bf16_t* __restrict__ dz16 = nullptr) {
+  // dz16: optional bf16 COPY of dz (what the data-gradient 1x1 conv of the bf16-storage plan reads: see bn_act_fwd_kernel)
   const int plane = blockIdx.x, c = plane % C;
   const float av = a[c], bv = b[c], mu = mean[c], is = invstd[c];
   const float m1 = (float)(sums[c] / n), m2 = (float)(sums[C + c] / n);
@@ -264,10 +270,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
       const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
       const float4 v = Io<ZT>::load4(z + base + i);
-      *reinterpret_cast<float4*>(dz + base + i) = make_float4(f(d.x, v.x), f(d.y, v.y), f(d.z, v.z), f(d.w, v.w));
+      const float4 o = make_float4(f(d.x, v.x), f(d.y, v.y), f(d.z, v.z), f(d.w, v.w));
+      *reinterpret_cast<float4*>(dz + base + i) = o;
+      if (dz16) Io<eat::bf16_t>::store4(dz16 + base + i, o);
     }
   } else {
-    for (int i = threadIdx.x; i < S; i += blockDim.x) dz[base + i] = f(dy[base + i], Io<ZT>::load1(z + base + i));
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+      const float o = f(dy[base + i], Io<ZT>::load1(z + base + i));
+      dz[base + i] = o;
+      if (dz16) Io<eat::bf16_t>::store1(dz16 + base + i, o);
+    }
   }
 }
 
@@ -1518,11 +1530,12 @@ extern "C" int eat_cast_b16(const float* x, void* y, long long n, eat_stream_t s
 // z_d and the gradient arriving at it are bf16 in HBM.  Same arithmetic as the fp32 entry points; y (or NULL) is written in
 // bf16 and `pool` sums the ROUNDED values - what the project conv will read.  (S % 4 != 0: element-wise path.)
 extern "C" int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, const float* res, void* y, int y_b16,
-                                  float* pool, int B, int C, int S, int act, eat_stream_t stream) {
+                                  void* y_copy16, float* pool, int B, int C, int S, int act, eat_stream_t stream) {
   eat::clear_stale_error();
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: bad act %d", act);
   if (!z || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: bad shape");
-  if (res && y_b16) return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: a residual is added to an fp32 output only");
+  if ((res || y_copy16) && y_b16)
+    return eat::fail(EAT_EINVAL, "eat_bn_act_fwd_b16: a residual / a bf16 copy goes with an fp32 output only");
   const dim3 blk(S >= 1024 ? 256 : 64);
   const eat::bf16_t* z16 = reinterpret_cast<const eat::bf16_t*>(z);
   if (y_b16)
@@ -1530,7 +1543,8 @@ extern "C" int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b,
                                              z16, a, b, (const float*)nullptr, reinterpret_cast<eat::bf16_t*>(y), pool, C, S));
   else
     EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, eat::bf16_t, float>), EAT_PLANES_GRID(B, C), blk, 0,
-                                             (hipStream_t)stream, z16, a, b, res, reinterpret_cast<float*>(y), pool, C, S));
+                                             (hipStream_t)stream, z16, a, b, res, reinterpret_cast<float*>(y), pool, C, S,
+                                             reinterpret_cast<eat::bf16_t*>(y_copy16)));
   return eat::check_launch("eat_bn_act_fwd_b16");
 }
 
@@ -1563,7 +1577,7 @@ extern "C" int eat_bn_act_bwd_reduce_b16(const void* dy, int dy_b16, const void*
 // apply pass over a bf16-stored z (the project conv's output z_p in the bf16-storage plan): dy and dz are fp32
 extern "C" int eat_bn_act_bwd_apply_b16(const float* dy, const void* z, const float* a, const float* b, const float* mean,
                                         const float* invstd, const float* gscale, const float* gadd, const double* sums,
-                                        float* dz, int B, int C, int S, int act, eat_stream_t stream) {
+                                        float* dz, void* dz_copy16, int B, int C, int S, int act, eat_stream_t stream) {
   eat::clear_stale_error();
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_apply_b16: bad act %d", act);
   if (!dy || !z || !dz || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_act_bwd_apply_b16: bad shape");
@@ -1571,7 +1585,7 @@ extern "C" int eat_bn_act_bwd_apply_b16(const float* dy, const void* z, const fl
   const double n = (double)B * S;
   EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0,
                                            (hipStream_t)stream, dy, reinterpret_cast<const eat::bf16_t*>(z), a, b, mean, invstd,
-                                           gscale, gadd, sums, dz, C, S, n));
+                                           gscale, gadd, sums, dz, C, S, n, reinterpret_cast<eat::bf16_t*>(dz_copy16)));
   return eat::check_launch("eat_bn_act_bwd_apply_b16");
 }
 

@@ -187,10 +187,13 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         # project conv + BN (no activation); the residual branch passes dout through unchanged
         cna = blk.block[blk.i_proj]
         nw, nbias = f"{pre}.{blk.i_proj}.1.weight", f"{pre}.{blk.i_proj}.1.bias"
-        dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias))
+        b16 = rec.get("b16", False)                    # the block's wide tensors are bf16 in HBM (forward: rec["b16"])
+        want16 = b16 and rec["z_p"].dtype == torch.bfloat16 and _cast_narrow(cnf)
+        dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias),
+                                          copy16=want16)
+        dz_p, dz16 = dz_p if want16 else (dz_p, None)
         bn_grads(dgam, dbet, nw, nbias)
         scale = rec.get("scale")
-        b16 = rec.get("b16", False)                    # the block's wide tensors are bf16 in HBM (forward: rec["b16"])
         wgrad = ops.pw_conv_wgrad_b16 if b16 else ops.pw_conv_wgrad
         o_p = g.alloc(f"{pre}.{blk.i_proj}.0.weight", cna[0].weight)
         if rec["y_d"] is None:     # y_d = act(BN(z_d)) was evaluated on load in the forward: the same here
@@ -201,7 +204,8 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
         wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
         if b16:
-            dz16 = ops.cast_b16(dz_p) if _cast_narrow(cnf, dz_p) else dz_p
+            if dz16 is None:
+                dz16 = ops.cast_b16(dz_p) if _cast_narrow(cnf, dz_p) else dz_p
             dxs = ops.pw_conv_b16(dz16, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE, out_b16=True)
             del dz16
         else:
@@ -384,7 +388,7 @@ _DW_BN_ON_LOAD = True     # ... with the depthwise BatchNorm's own backward eval
 _EPI_STATS = True         # project / last conv: BatchNorm statistics in the 1x1 epilogue
 _PREPACK_PLAN = True      # all weight packs of the step from one launch
 _FUSE_STEM = True         # stem without its pre-activation tensor (csrc/stem_train.hip)
-_CAST_NARROW_MIN_CEXP = 1920   # bf16-storage plan: bf16 copy of the narrow operand of the expand / data-gradient conv from this width
+_CAST_NARROW_MIN_CEXP = 960    # bf16-storage plan: bf16 copy of the narrow operand of the expand / data-gradient conv from this width
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
 
 
@@ -397,11 +401,14 @@ def _w_times_g(W, G):
     return ops.pw_conv_bf16(G.view(1, Ci, Ci, 1), wp3, _zeros.get(Co, W.device), Co, NONE, split=True).view(Co, Ci)
 
 
-def _cast_narrow(cnf, x):
+def _cast_narrow(cnf, x=None):
     """bf16-storage plan: hand the expand / data-gradient 1x1 conv of the widest blocks a bf16 COPY of its narrow fp32 operand
     (bit-identical results - the kernel rounds the operand the same way; measured on MI355X at B = 128: 320 -> 1920 at S = 504
-    209 -> 144 + 18 us, 448 -> 2688 324 -> 238 + 24 us, 640 -> 3840 at S = 128 123 -> 91 + 10 us; no gain below)."""
-    return cnf.expanded_channels >= _CAST_NARROW_MIN_CEXP and x.numel() % 8 == 0
+    209 -> 144 us, 448 -> 2688 324 -> 238 us, 640 -> 3840 at S = 128 123 -> 91 us, 160 -> 960 at S = 2000 275 -> 220 us; below
+    that the copy's own 2 bytes per element cost what the conv gains).  The copy leaves the pass that produces the fp32 tensor
+    (project BatchNorm forward / backward apply: `copy16`); `eat_cast_b16` (18 / 24 / 10 us on the shapes above) is the
+    fallback when that pass ran on the fp32 kernels (frozen BatchNorm)."""
+    return cnf.expanded_channels >= _CAST_NARROW_MIN_CEXP and (x is None or x.numel() % 8 == 0)
 
 
 def _act_storage_bf16(model):
@@ -465,10 +472,11 @@ class MNTrainFunction2(torch.autograd.Function):
         fmaps = [cur]
 
         blk_saved = []
+        cur16 = None                                        # bf16 copy of `cur` (bf16-storage plan, _cast_narrow)
         for bi, blk in enumerate(blocks):
             cnf = blk.cnf
             act = HSWISH if cnf.use_hs else RELU
-            inp = cur
+            inp, inp16 = cur, cur16
             rec = {"inp": inp}
             k = cnf.kernel
             cna_d = blk.block[blk.i_dw]
@@ -502,7 +510,7 @@ class MNTrainFunction2(torch.autograd.Function):
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
                 wp = _pk(plan, ("e", bi), cna[0].weight)
                 if b16:
-                    x16 = ops.cast_b16(inp) if _cast_narrow(cnf, inp) else inp
+                    x16 = inp16 if inp16 is not None else (ops.cast_b16(inp) if _cast_narrow(cnf, inp) else inp)
                     z_e = ops.pw_conv_b16(x16, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE,
                                           out_b16=True)
                     del x16
@@ -553,7 +561,12 @@ class MNTrainFunction2(torch.autograd.Function):
                 z_p, st_p = _pw_conv_bn(y_d, wp, cnf.out_channels, cna[1], dev, in_scale=scale)
             need_sx = bi + 1 < len(blocks) and blocks[bi + 1].i_expand is not None
             pool_c = torch.empty((B, cnf.out_channels), device=dev) if need_sx else None
-            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None, pool=pool_c, y_f32=True)
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            want16 = (b16 and z_p.dtype == torch.bfloat16 and nxt is not None and nxt.i_expand is not None
+                      and _cast_narrow(nxt.cnf))
+            cur = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=inp if blk.use_res_connect else None, pool=pool_c, y_f32=True,
+                                 copy16=want16)
+            cur, cur16 = cur if want16 else (cur, None)
             sx = ops.col_sum(pool_c) if need_sx else None
             rec.update(z_p=z_p, st_p=st_p)
             blk_saved.append(rec)

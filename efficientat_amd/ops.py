@@ -285,9 +285,10 @@ def bn_train_state(z, bn):
     return st
 
 
-def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True, y_f32=False):
+def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True, y_f32=False, copy16=False):
     """y = act(a[c] z + b[c]) [+ res]; pool (B, C): plane sums of y.  A bf16 z (bf16-storage plan): y is bf16 too - or, with
-    y_f32 (the project conv's BatchNorm: z_p stored in bf16, the block output fp32), fp32 with the optional fp32 residual."""
+    y_f32 (the project conv's BatchNorm: z_p stored in bf16, the block output fp32), fp32 with the optional fp32 residual;
+    copy16 (with y_f32): -> (y, bf16 rounding of y), both written by the one pass."""
     B, C = z.shape[0], z.shape[1]
     S = z.numel() // (B * C)
     if _is16(z):                                   # bf16 storage (BASELINE configs[2]): pool = sums of the values as stored
@@ -295,16 +296,18 @@ def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True, y_f32=False):
         if res is not None and y16:
             raise _lib.EatHipError("bn_act_fwd: a residual is added to an fp32 output only (y_f32=True)")
         y = torch.empty(z.shape, device=z.device, dtype=torch.bfloat16 if y16 else torch.float32) if write else None
+        yc = torch.empty(z.shape, device=z.device, dtype=torch.bfloat16) if copy16 and y_f32 and write else None
         _lib.call("eat_bn_act_fwd_b16", _dev16(z, "z"), a.data_ptr(), b.data_ptr(), _opt(res, "res"),
-                  None if y is None else y.data_ptr(), 1 if y16 else 0, _opt(pool, "pool"), B, C, S, act, _stream())
-        return y
+                  None if y is None else y.data_ptr(), 1 if y16 else 0, None if yc is None else yc.data_ptr(),
+                  _opt(pool, "pool"), B, C, S, act, _stream())
+        return (y, yc) if copy16 else y
     y = torch.empty_like(z) if write else None
     _lib.call("eat_bn_act_fwd", _dev(z, "z"), a.data_ptr(), b.data_ptr(), _opt(res, "res"),
               None if y is None else y.data_ptr(), _opt(pool, "pool"), B, C, S, act, _stream())
     return y
 
 
-def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None, sums=None):
+def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None, sums=None, copy16=False):
     """-> (dz, dgamma, dbeta) for y = act(BN_batch(z)); incoming grad = dy*gscale[b,c] + gadd[b,c].
     frozen (default: the flag `bn_train_state` left on `mean`): the layer normalised with its running statistics,
     i.e. dz = a * g without the batch-mean terms (dgamma / dbeta are the same reductions)."""
@@ -320,8 +323,11 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=No
         tail = (a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _opt(gscale, "gscale"), _opt(gadd, "gadd"))
         _lib.call("eat_bn_act_bwd_reduce_b16", _dev(dy, "dy"), 0, _dev16(z, "z"), *tail, B, C, S, act, sums.data_ptr(), _stream())
         dz = torch.empty(z.shape, device=z.device, dtype=torch.float32)
-        _lib.call("eat_bn_act_bwd_apply_b16", _dev(dy, "dy"), _dev16(z, "z"), *tail, asums.data_ptr(), dz.data_ptr(), B, C, S,
-                  act, _stream())
+        dzc = torch.empty(z.shape, device=z.device, dtype=torch.bfloat16) if copy16 else None
+        _lib.call("eat_bn_act_bwd_apply_b16", _dev(dy, "dy"), _dev16(z, "z"), *tail, asums.data_ptr(), dz.data_ptr(),
+                  None if dzc is None else dzc.data_ptr(), B, C, S, act, _stream())
+        if copy16:                 # (dz, its bf16 rounding): bf16-storage plan, z = the project conv's z_p
+            dz = (dz, dzc)
         if not own:
             return dz, None, None
         sf = sums.float()

@@ -693,19 +693,21 @@ int eat_cast_b16(const float* x, void* y, long long n, eat_stream_t stream);
 
 /* Twin of eat_bn_act_fwd (block_types.py:150-162, 72-73, 167-181): z bf16 -> y bf16 (y_b16 != 0; or NULL: squeeze sums only)
  * or -> y fp32 with the optional fp32 residual `res` (the project conv's BatchNorm: z_p stored in bf16, the block output in
- * fp32); pool (B, C) plain stores of the sums of y as stored. */
-int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, const float* res, void* y, int y_b16, float* pool, int B,
-                       int C, int S, int act, eat_stream_t stream);
+ * fp32) and, optionally, y_copy16 = the bf16 rounding of that fp32 y written by the same pass (what the next block's expand
+ * conv reads: see eat_cast_b16); pool (B, C) plain stores of the sums of y as stored. */
+int eat_bn_act_fwd_b16(const void* z, const float* a, const float* b, const float* res, void* y, int y_b16, void* y_copy16,
+                       float* pool, int B, int C, int S, int act, eat_stream_t stream);
 
 /* Twins of eat_bn_act_bwd_reduce / _apply and eat_se_bn_bwd_partials (backward of block_types.py:150-181, 72-83): z bf16; dy
  * bf16 (dy_b16 != 0: the depthwise BatchNorm, gradient dxs) or fp32 (the project BatchNorm); the apply pass (project
- * BatchNorm only) reads fp32 dy and writes fp32 dz. */
+ * BatchNorm only) reads fp32 dy and writes fp32 dz and, optionally, dz_copy16 = its bf16 rounding (what the data-gradient
+ * 1x1 conv reads). */
 int eat_bn_act_bwd_reduce_b16(const void* dy, int dy_b16, const void* z, const float* a, const float* b, const float* mean,
                               const float* invstd, const float* gscale, const float* gadd, int B, int C, int S, int act,
                               double* sums, eat_stream_t stream);
 int eat_bn_act_bwd_apply_b16(const float* dy, const void* z, const float* a, const float* b, const float* mean,
-                             const float* invstd, const float* gscale, const float* gadd, const double* sums, float* dz, int B,
-                             int C, int S, int act, eat_stream_t stream);
+                             const float* invstd, const float* gscale, const float* gadd, const double* sums, float* dz,
+                             void* dz_copy16, int B, int C, int S, int act, eat_stream_t stream);
 int eat_se_bn_bwd_partials_b16(const void* d, const void* z, const float* a, const float* b, const float* mean, float* P,
                                int B, int C, int S, int act, eat_stream_t stream);
 

@@ -131,6 +131,11 @@ def test_project_batchnorm_passes_over_a_bf16_stored_conv_output(B, C, S, act):
     dz, dg, db = ops.bn_act_bwd(dy, z16, a, b, mean, invstd, act)
     dz_ref, dg_ref, db_ref = ops.bn_act_bwd(dy, z16.float(), a, b, mean, invstd, act)
     assert dz.dtype == torch.float32 and _rel(dz, dz_ref) < 1e-6 and _rel(dg, dg_ref) < 1e-5 and _rel(db, db_ref) < 1e-5
+    # the same passes also hand out the bf16 rounding of their fp32 result (the narrow operand of the next 1x1 conv)
+    y2, yc = ops.bn_act_fwd(z16, a, b, act, res=res, y_f32=True, copy16=True)
+    assert torch.equal(y2, y) and yc.dtype == torch.bfloat16 and torch.equal(yc, y.bfloat16())
+    (dz2, dzc), _, _ = ops.bn_act_bwd(dy, z16, a, b, mean, invstd, act, copy16=True)
+    assert torch.equal(dz2, dz) and dzc.dtype == torch.bfloat16 and torch.equal(dzc, dz.bfloat16())
 
 
 @pytest.mark.parametrize("B,C1,C2,Co,F_,T", [(3, 256, 64, 64, 8, 63), (2, 288, 96, 96, 32, 250), (5, 960, 160, 160, 4, 32),
