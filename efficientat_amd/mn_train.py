@@ -388,7 +388,7 @@ _DW_BN_ON_LOAD = True     # ... with the depthwise BatchNorm's own backward eval
 _EPI_STATS = True         # project / last conv: BatchNorm statistics in the 1x1 epilogue
 _PREPACK_PLAN = True      # all weight packs of the step from one launch
 _FUSE_STEM = True         # stem without its pre-activation tensor (csrc/stem_train.hip)
-_CAST_NARROW_MIN_CEXP = 960    # bf16-storage plan: bf16 copy of the narrow operand of the expand / data-gradient conv from this width
+_CAST_NARROW_MIN_CEXP = 200    # bf16-storage plan: bf16 copy of the narrow operand of the expand / data-gradient conv from this width
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
 
 
@@ -404,8 +404,9 @@ def _w_times_g(W, G):
 def _cast_narrow(cnf, x=None):
     """bf16-storage plan: hand the expand / data-gradient 1x1 conv of the widest blocks a bf16 COPY of its narrow fp32 operand
     (bit-identical results - the kernel rounds the operand the same way; measured on MI355X at B = 128: 320 -> 1920 at S = 504
-    209 -> 144 us, 448 -> 2688 324 -> 238 us, 640 -> 3840 at S = 128 123 -> 91 us, 160 -> 960 at S = 2000 275 -> 220 us; below
-    that the copy's own 2 bytes per element cost what the conv gains).  The copy leaves the pass that produces the fp32 tensor
+    209 -> 144 us, 448 -> 2688 324 -> 238 us, 640 -> 3840 at S = 128 123 -> 91 us, 160 -> 960 at S = 2000 275 -> 220 us,
+    64 -> 256 at S = 32000 667 -> 528 us; same-box A/B of the mn40 step with copies from expanded width 960 / 700 / 400 / 200:
+    42.71 / 42.72 / 42.60 / 42.43 ms - every block with an expand conv).  The copy leaves the pass that produces the fp32 tensor
     (project BatchNorm forward / backward apply: `copy16`); `eat_cast_b16` (18 / 24 / 10 us on the shapes above) is the
     fallback when that pass ran on the fp32 kernels (frozen BatchNorm)."""
     return cnf.expanded_channels >= _CAST_NARROW_MIN_CEXP and (x is None or x.numel() % 8 == 0)
