@@ -84,6 +84,13 @@ def _flat_worker(rank, world, port, ret):
                 want = tuple({**big, **small}[k]) + ((1, 1) if (k == "p.weight" and k in handed) else ())
                 ok = ok and torch.allclose(out[k].reshape(exp.shape), exp, atol=1e-6) and tuple(out[k].shape) == want
             inplace.append(sorted(k for k in handed if out[k].data_ptr() == handed[k].data_ptr()))
+        # memory handed out but never pushed back: finish() must refuse (the bucket would be reduced without that gradient)
+        red.alloc("l.weight", big["l.weight"], torch.device("cpu"))
+        try:
+            red.finish()
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "never pushed" in str(e)
         ret[rank] = (bool(ok), inplace)
     finally:
         dist.destroy_process_group()
