@@ -79,7 +79,8 @@ SIGNATURES = {
     "eat_dw_partials_inner": [_I] * 7,
     "eat_dw_conv_fwd_stats": [_P, _P, _P, _I, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_bn_stats_partial": [_P, _I, _I, _I, _P, _P],
-    "eat_bn_finalize_partials": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P],
+    "eat_bn_finalize_partials": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P, _P],
+    "eat_bn_finalize_ws_doubles": [_I, _I, _I],
     "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _I, _P],
     "eat_gram_centered": [_P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_act_grad_sum": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],

@@ -224,8 +224,48 @@ __global__ __launch_bounds__(64) void se_bn_bwd_combine_kernel(const float* __re
 }
 
 // ---- BatchNorm finalize from partials [outer][2][C][inner]: one block per channel ------------------------------------
+// Round 5: with many partial rows (the 1x1 epilogue leaves one row of 2 C sums per 256-column tile: 32 000 rows for the
+// 16-channel first project conv at B = 256) one block per channel walks its column of the [outer][2 C inner] matrix one
+// cache line per element - 92 us for 4 MB.  bn_partials_rowgroups_kernel sums row groups with coalesced reads first (fp64,
+// fixed order: thread (lane, column) adds rows lane, lane + RL, ...; the RL lanes are added in index order) and leaves
+// [groups][2 C inner] doubles for the finalize kernel: 2 launches of ~5 us.
+constexpr int kFinGroupsMax = 64;
+__host__ __device__ __forceinline__ int fin_col_threads(int W) { int cw = 32; while (cw < W && cw < 256) cw <<= 1; return cw; }
+__host__ __device__ __forceinline__ int fin_groups(int outer, int C, int inner) {
+  if ((long long)outer * inner < 2048) return 0;                    // the direct kernel is as fast there
+  const int W = 2 * C * inner, rl = 256 / fin_col_threads(W);
+  int g = outer / (rl * 8);
+  return g < 1 ? 1 : (g > kFinGroupsMax ? kFinGroupsMax : g);
+}
+__global__ __launch_bounds__(256) void bn_partials_rowgroups_kernel(const float* __restrict__ part, int outer, int W,
+                                                                    double* __restrict__ ws) {
+  __shared__ double s_acc[256];
+  const int cw = fin_col_threads(W), rl = 256 / cw;
+  const int col = blockIdx.x * cw + (threadIdx.x % cw), lane = threadIdx.x / cw;
+  const int G = gridDim.y, per = (outer + G - 1) / G;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per) < outer ? (r0 + per) : outer;
+  double acc = 0.0;
+  if (col < W) {
+    int r = r0 + lane;
+    for (; r + 3 * rl < r1; r += 4 * rl) {
+      const float v0 = part[(size_t)r * W + col], v1 = part[(size_t)(r + rl) * W + col];
+      const float v2 = part[(size_t)(r + 2 * rl) * W + col], v3 = part[(size_t)(r + 3 * rl) * W + col];
+      acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+    }
+    for (; r < r1; r += rl) acc += (double)part[(size_t)r * W + col];
+  }
+  s_acc[threadIdx.x] = acc;
+  __syncthreads();
+  if (lane == 0 && col < W) {
+    double t = 0.0;
+    for (int l = 0; l < rl; ++l) t += s_acc[l * cw + (threadIdx.x % cw)];
+    ws[(size_t)blockIdx.y * W + col] = t;
+  }
+}
+
+template <typename PT>
 __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
-    const float* __restrict__ part, int outer, int C, int inner, const float* __restrict__ gamma,
+    const PT* __restrict__ part, int outer, int C, int inner, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
     float eps, double n, float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean,
     float* __restrict__ invstd) {
@@ -241,13 +281,13 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
   auto next = [&]() { i += id; o += od; if (i >= inner) { i -= inner; ++o; } };
   if (inner <= 256) {
     while (o < outer) {
-      float v1[4], v2[4];
+      PT v1[4], v2[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bool ok = o < outer;
-        const float* pp = part + (size_t)(ok ? o : 0) * ostride + (size_t)c * inner + i;
-        v1[q] = ok ? pp[0] : 0.0f;
-        v2[q] = ok ? pp[koff] : 0.0f;
+        const PT* pp = part + (size_t)(ok ? o : 0) * ostride + (size_t)c * inner + i;
+        v1[q] = ok ? pp[0] : (PT)0;
+        v2[q] = ok ? pp[koff] : (PT)0;
         next();
       }
 #pragma unroll
@@ -482,14 +522,30 @@ extern "C" int eat_se_bn_bwd_combine(const float* P, const float* gscale, const 
   return eat::check_launch("eat_se_bn_bwd_combine");
 }
 
+// doubles of workspace eat_bn_finalize_partials wants for this shape (0: none - few partial rows)
+extern "C" int eat_bn_finalize_ws_doubles(int outer, int C, int inner) {
+  if (outer < 1 || C < 1 || inner < 1) return 0;
+  return fin_groups(outer, C, inner) * 2 * C * inner;
+}
+
 extern "C" int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, const float* gamma,
                                         const float* beta, float* running_mean, float* running_var, float momentum,
-                                        float eps, double n, float* a, float* b, float* mean, float* invstd,
+                                        float eps, double n, float* a, float* b, float* mean, float* invstd, double* ws,
                                         eat_stream_t stream) {
   eat::clear_stale_error();
   if (outer < 1 || C < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_bn_finalize_partials: bad shape");
-  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part, outer, C,
-                     inner, gamma, beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
+  const int G = ws ? fin_groups(outer, C, inner) : 0;
+  if (G > 0) {
+    const int W = 2 * C * inner, cw = fin_col_threads(W);
+    hipLaunchKernelGGL(bn_partials_rowgroups_kernel, dim3((unsigned)((W + cw - 1) / cw), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, part, outer, W, ws);
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<double>, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)ws, G, C, inner, gamma, beta, running_mean, running_var, momentum, eps, n, a, b, mean,
+                       invstd);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<float>, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, part, outer,
+                       C, inner, gamma, beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
+  }
   return eat::check_launch("eat_bn_finalize_partials");
 }
 

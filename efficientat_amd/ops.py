@@ -562,9 +562,12 @@ def bn_state_from_partials(parts, bn, n):
     part, outer, inner = parts
     C = bn.num_features
     out = torch.empty((4, C), device=part.device, dtype=torch.float32)
+    nws = int(_lib.lib().eat_bn_finalize_ws_doubles(outer, C, inner))      # > 0: many partial rows, summed in groups first
+    ws = torch.empty((nws,), device=part.device, dtype=torch.float64) if nws else None
     _lib.call("eat_bn_finalize_partials", part.data_ptr(), outer, C, inner, _dev(bn.weight, "gamma"), _dev(bn.bias, "beta"),
               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _bn_momentum(bn), float(bn.eps), float(n),
-              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+              None if ws is None else ws.data_ptr(), _stream())
     bn_counters.bump(bn)
     return out[0], out[1], out[2], out[3]
 

@@ -186,10 +186,13 @@ int eat_dw_conv_fwd_stats(const float* x, const float* in_a, const float* in_b, 
 int eat_bn_stats_partial(const float* z, int B, int C, int S, float* part, eat_stream_t stream);
 
 /* (a, b, mean, invstd) and the running-buffer update of nn.BatchNorm2d from partials [outer][2][C][inner]
- * (n = elements per channel). Same outputs as eat_bn_finalize. */
+ * (n = elements per channel). Same outputs as eat_bn_finalize.  ws: NULL, or eat_bn_finalize_ws_doubles(outer, C, inner)
+ * doubles of scratch (> 0 when there are many partial rows: the rows are then summed in groups with coalesced reads
+ * first - two launches, fixed summation order). */
+int eat_bn_finalize_ws_doubles(int outer, int C, int inner);
 int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, double n, float* a,
-                             float* b, float* mean, float* invstd, eat_stream_t stream);
+                             float* b, float* mean, float* invstd, double* ws, eat_stream_t stream);
 
 /* Centred Gram matrix of a conv input x (B, C, S) (the statistics of the conv1x1 -> nn.BatchNorm2d pair of
  * models/mn/block_types.py:138-147 without reading the conv output): Gc = sum_{b,s} (x - m)(x - m)^T, m = sx * inv_n the

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("no GPU", allow_module_level=True)
 
-from efficientat_amd import ops  # noqa: E402
+from efficientat_amd import _lib, ops  # noqa: E402
 
 DEV = torch.device("cuda:0")
 ACTS = [lambda t: t, F.relu, F.hardswish]
@@ -139,6 +139,32 @@ def test_pw_conv_with_statistics_epilogue(B, Ci, Co, F_, T, mode, per_sample, tf
     mu, var = zd.mean((0, 2, 3)), zd.var((0, 2, 3), unbiased=False)
     assert _rel(st[2], mu) < 1e-5 and _rel(st[3], (var + 1e-3).rsqrt()) < 1e-5
     assert _rel(bn.running_var, 0.99 + 0.01 * var * (B * S) / (B * S - 1)) < 1e-5
+
+
+@pytest.mark.parametrize("outer,C,inner", [(32000, 16, 1), (8000, 24, 1), (256, 16, 16), (256, 64, 16), (5000, 130, 1),
+                                           (300, 7, 9), (2047, 1, 1), (2048, 1, 1), (100, 40, 1)])
+def test_bn_finalize_from_many_partial_rows(outer, C, inner):
+    """BatchNorm state from producer partials [outer][2][C][inner]: with many rows (one per 256-column tile of a 1x1 conv: 32 000
+    at B = 256 on the first project conv) the rows are first summed in groups with coalesced reads (round 5: 92 -> ~10 us),
+    otherwise by one block per channel; both against fp64 sums of the same partials."""
+    g = torch.Generator().manual_seed(outer + C)
+    n = 977.0 * outer * inner
+    part = torch.randn(outer, 2, C, inner, generator=g)
+    part[:, 0] = part[:, 0] * 3.0 + 40.0 * torch.randn(1, C, 1, generator=g)         # sums of z
+    part[:, 1] = part[:, 1].abs() * 50.0 + (part[:, 0] ** 2) / 977.0 * 1.5           # sums of z^2 (>= mean^2 n)
+    bn = torch.nn.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    s1, s2 = part[:, 0].double().sum((0, 2)), part[:, 1].double().sum((0, 2))
+    mu = s1 / n
+    var = (s2 / n - mu * mu).clamp_min(0.0)
+    uses_groups = int(_lib.lib().eat_bn_finalize_ws_doubles(outer, C, inner)) > 0
+    assert uses_groups == (outer * inner >= 2048)
+    a, b, mean, invstd = ops.bn_state_from_partials((part.to(DEV).reshape(-1), outer, inner), bn, n)
+    is_ref = (var + bn.eps).rsqrt()
+    assert _rel(mean, mu) < 1e-6 and _rel(invstd, is_ref) < 1e-6
+    assert _rel(a, bn.weight.detach().cpu().double() * is_ref) < 1e-6
+    assert _rel(bn.running_mean, 0.1 * mu) < 1e-5
 
 
 @pytest.mark.parametrize("shift", [10.0, 30.0])
