@@ -21,13 +21,25 @@ namespace {
 // contiguous along n.  256 threads = 4 waves, each one 16 x 16 quadrant on the fp32 matrix cores (v_mfma_f32_16x16x4_f32:
 // fp32 products and accumulation - round 5; the round-3 form multiplied on the vector ALUs, 4 outputs per thread, which at
 // mn40's widths - 3840 x 960 gates, a 3840 -> 5120 -> 527 head - ran at 14 TFLOP/s: 2.1 + 0.65 ms of a 46 ms step).  The k
-// axis goes through LDS in chunks of 128: 16 + 16 loads per thread in flight per barrier pair (chunks of 32 left the
-// kernel waiting on one memory latency per 32 k: 55 us for K = 960).
-constexpr int kKC = 128;
+// axis goes through LDS in chunks of 64 (one LDS stage of 2 x 64 x 33 floats SHARED by the tile functions of a kernel:
+// 16.9 KB per block, 8 waves per SIMD.  History, same-box microbenchmarks at mn40's head 3840 -> 5120 -> 527, B = 128:
+// chunks of 128 with one pair of arrays PER INSTANTIATION of this template - 68.6 KB, two blocks per CU - 442 us; one shared
+// stage 257 us; chunks of 64 236 us.  Chunks of 32 at two blocks per CU had left the kernel waiting on one memory latency
+// per 32 k: 55 us for K = 960.)
+constexpr int kKC = 64;
 // [k_lo, K): the slice of the contraction this block sums (split-K: the caller combines the slices in a fixed order)
+// ONE LDS stage for every instantiation of gemm_tile / col_sum_tile inside a kernel (a block runs exactly one of them): as
+// function-local statics each instantiation had its own pair of arrays - 68.6 KB per block, two blocks per CU.
+typedef float tile_lds_t[kKC][33];
+__device__ __forceinline__ tile_lds_t* tile_lds() {
+  __shared__ float s_tiles[2][kKC][33];
+  return s_tiles;
+}
 template <bool A_MFAST, class FA, class FB, class FS>
 __device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, FA a_at, FB b_at, FS store, int k_lo = 0) {
-  __shared__ float sA[kKC][33], sB[kKC][33];        // sA[k][m], sB[k][n]
+  tile_lds_t* const lds = tile_lds();
+  tile_lds_t& sA = lds[0];                           // sA[k][m]
+  tile_lds_t& sB = lds[1];                           // sB[k][n]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -35,22 +47,23 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, F
   const int ms = 16 * (wv >> 1), ns = 16 * (wv & 1);                 // this wave's quadrant of the tile
   f32x4 acc{0.f, 0.f, 0.f, 0.f};
   for (int k0 = k_lo; k0 < K; k0 += kKC) {
-    float av[16], bv[16];
+    constexpr int NI = kKC / 8, KQ = kKC / 32;          // loads per thread and operand; 32-wide k groups of a chunk
+    float av[NI], bv[NI];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      // A: fast index tx, slow index ty + 8 i over (m: 32) x (k: 128)
+    for (int i = 0; i < NI; ++i) {
+      // A: fast index tx, slow index ty + 8 i over (m: 32) x (k: kKC)
       int mm, kk;
       if (A_MFAST) { mm = tx; kk = ty + 8 * i; }
-      else { kk = tx + 32 * (i & 3); mm = ty + 8 * (i >> 2); }
+      else { kk = tx + 32 * (i % KQ); mm = ty + 8 * (i / KQ); }
       av[i] = (m0 + mm < M && k0 + kk < K) ? a_at(m0 + mm, k0 + kk) : 0.0f;
       const int kb = ty + 8 * i;
       bv[i] = (k0 + kb < K && n0 + tx < N) ? b_at(k0 + kb, n0 + tx) : 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
       int mm, kk;
       if (A_MFAST) { mm = tx; kk = ty + 8 * i; }
-      else { kk = tx + 32 * (i & 3); mm = ty + 8 * (i >> 2); }
+      else { kk = tx + 32 * (i % KQ); mm = ty + 8 * (i / KQ); }
       sA[kk][mm] = av[i];
       sB[ty + 8 * i][tx] = bv[i];
     }
@@ -73,7 +86,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, int m0, int n0, F
 // column sums out[n] = sum_m f(m, n) for 32 columns per block: 8 row groups x 32 columns, LDS reduction
 template <class F>
 __device__ __forceinline__ void col_sum_tile(int M, int N, int n0, F f, float* __restrict__ out) {
-  __shared__ float s_cs[8][33];
+  tile_lds_t& s_cs = tile_lds()[0];                  // (8 rows of it)
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   float s = 0.0f;
   if (n0 + tx < N)
@@ -93,8 +106,9 @@ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Split-K for the GEMMs with a long contraction and few output tiles (round 5: dh = dq W2 at mn40's widths is 120 tiles of
 // K = 3840 - 30 dependent load -> LDS -> MFMA rounds per block, 176 us; the head's dfeat = du W1 has K = 5120): a block sums
 // one slice of k, the slices are stored side by side ([slice][M][N]) and added in index order by slice_sum_kernel - no
-// atomics, bit-reproducible.  One slice (no extra launch) below 1024.
-__host__ __device__ __forceinline__ int k_slices(int K) { return K >= 1024 ? (K + 511) / 512 : 1; }
+// atomics, bit-reproducible.  Slices of 256 from K = 512 (same-box: slices of 512 from K = 1024 left mn10's 960 -> 240 gate at
+// 55 us, now 33 us; mn40's 3840 -> 960 gate 120 -> 112 us); one slice (no extra launch) below.
+__host__ __device__ __forceinline__ int k_slices(int K) { return K >= 512 ? (K + 255) / 256 : 1; }
 __host__ __device__ __forceinline__ int k_slice_len(int K) { const int n = k_slices(K); return ((K + n - 1) / n + 3) & ~3; }
 
 // out[i] = (gate == NULL || gate[i] > 0) * sum over slices of part[s][i]

@@ -202,8 +202,7 @@ def test_fused_expand_dw_eligibility_rule():
     """ops.expand_dw_eligible mirrors the geometry check of eat_expand_dw_bf16_fwd (csrc/expand_dw.hip): mn10's blocks
     8-12 at 10 s clips qualify, the 16x125 / 4x32-with-C_in-160 / strided / 5x5 blocks do not."""
     from efficientat_amd import ops
-    if not ops._FUSE_EXPAND_DW:
-        pytest.skip("EAT_FUSE_EXPAND_DW=0")
+    assert ops._FUSE_EXPAND_DW                                 # (a constant since round 5)
     assert ops.expand_dw_eligible(80, 8, 63, 3, 1) and ops.expand_dw_eligible(112, 8, 63, 3, 1)
     assert ops.expand_dw_eligible(40, 4, 32, 3, 1)
     assert not ops.expand_dw_eligible(40, 16, 125, 5, 1)      # plane too large, 5x5

@@ -68,11 +68,12 @@ if "se" in what:
         W1, W2 = torch.randn(Cr, C, device=dev) * 0.1, torch.randn(C, Cr, device=dev) * 0.1
         print(f"se_mlp_bwd C={C} Cr={Cr}: %8.1f us" % timeit(lambda: ops.se_mlp_bwd(ds, sc, h, pool, W1, W2, S)))
 if "wgrad" in what:
-    # 1x1 weight gradients at the mn10 late-layer shapes (B = 256); EAT_WGRAD_WIDE=0/1/3 selects the kernel family per process
+    # 1x1 weight gradients at the mn10 late-layer shapes (B = 256) on the library's shipped dispatch (the round-4 A/B switch
+    # EAT_WGRAD_WIDE is a constant since round 5; compare builds with EAT_LIB instead)
     shapes = [(960, 160, 128), (160, 960, 128), (160, 672, 128), (672, 112, 504), (112, 672, 504), (112, 480, 504), (480, 80, 504),
               (184, 80, 504), (200, 80, 504), (240, 40, 2000), (120, 40, 2000), (72, 24, 8000)]
     tfs = [(80, 184, 504), (80, 240, 504), (40, 120, 2000), (40, 72, 2000), (24, 72, 8000)]
-    print("EAT_WGRAD_WIDE =", os.environ.get("EAT_WGRAD_WIDE", "(default)"), " depth", os.environ.get("EAT_WGRAD_WIDE_DEPTH", "-"))
+    print("library:", os.environ.get("EAT_LIB", "(in-tree build)"))
     with ops.precision("auto"):
         for (Co, Ci, S) in shapes:
             dz, x = torch.randn(B, Co, S, 1, device=dev), torch.randn(B, Ci, S, 1, device=dev)
