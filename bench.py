@@ -919,11 +919,14 @@ def main():
         "value": head["value"], "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": head["warmup"],
         "ms_per_step": head["ms_per_step"], "repetitions": head["repetitions"], "rep_ms_per_step": head["rep_ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16" if train_name == "mn40_bf16" else "f32", "data": "synthetic",
         "config": {"workload": f"{train_name}_as training step (log-mel + forward with batch-stat BatchNorm + BCE + backward + "
                                + ("bucketed RCCL all-reduce + " if world > 1 else "")
-                               + f"fused Adam), batch {args.batch} synthetic 10 s @ 32 kHz clips per GPU, fp32 "
-                               "[BASELINE.json metric; per-GPU shard of configs[4]; forward-only configs[1] in `forward`]",
+                               + f"fused Adam), batch {args.batch} synthetic 10 s @ 32 kHz clips per GPU, "
+                               + ("bf16 GEMM operands and bf16 activation storage, fp32 statistics / parameters / optimizer "
+                                  "[BASELINE.json configs[2]; not the headline configuration]" if train_name == "mn40_bf16" else
+                                  "fp32 [BASELINE.json metric; per-GPU shard of configs[4]; forward-only configs[1] in `forward`]"
+                                  if train_name == "mn10" else "fp32 [BASELINE.json configs[3]; not the headline configuration]"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "arithmetic": arithmetic,
                    "launch": head["launch"], "train_plan": __import__("efficientat_amd.mn_train", fromlist=["x"])._TRAIN_V,
                    "parallelism": f"dp{world}" + (" (local BatchNorm statistics, gradients averaged by RCCL all-reduce "
@@ -931,8 +934,8 @@ def main():
         "final_loss": head["final_loss"],
         "roofline_e2e": {"bound": "hbm", "achieved": round(head["value"] / world * alg_train / 1e9, 1) if alg_train else None,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": head["roofline_e2e_frac"],
-                         "note": "whole training step: clips/s per GPU x 285.8 MB algorithmic bytes per clip (SURVEY 8d: "
-                                 "3 x forward activations + 28 B per parameter / batch + mel)"},
+                         "note": f"whole training step: clips/s per GPU x {(alg_train or 0) / 1e6:.1f} MB algorithmic bytes per clip "
+                                 "(SURVEY 8d: 3 x forward activations + 28 B per parameter / batch + mel)"},
     }
 
     # ------------------------------------------------------------------ BASELINE configs[1]: forward only
