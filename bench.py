@@ -91,6 +91,15 @@ def _alg_bytes(name, a):
         pipe = "true" if 16 * ns <= 64 else "false"
         nbytes = 4 * B * S * (Ci + (Co if y else 0) + (Co if res else 0)) + 4 * Co * Ci
         return f"pw_conv_kernel<{mtw},{pipe}>", nbytes, 2 * B * S * Ci * Co
+    if name == "eat_pw_conv_gstats_fwd":
+        x, wp, wmode, zb, y, gz, ga, gb, gact, part, B, Ci, Co, S = a[:14]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = 4 * B * S * (Ci + 2 * Co) + 4 * Co * Ci                          # x in, y out, z_d in (the epilogue)
+        return (f"pw_conv_kernel<{mtw},true>" if wmode == 0 else f"pw_conv_bf16_kernel<{mtw},3,*>"), nbytes, 2 * B * S * Ci * Co
+    if name == "eat_bn_bwd_sums_from_tiles":
+        return "bn_bwd_sums_from_tiles_kernels", 8 * a[1] * a[2] + 64, a[1] * a[2]
     if name == "eat_pw_conv_bf16_fwd":
         x, wp, bias, sc, res, y, pool, B, Ci, Co, S, act, split = a[:13]
         mt = (Co + 15) // 16
@@ -229,12 +238,13 @@ def _alg_bytes(name, a):
         return "act_grad_sum_kernel", 12 * B * C * S, 4 * B * C * S
     # ---- round 5: bf16 activation storage (BASELINE configs[2]): the wide tensor of each launch moves 2 bytes per element
     if name == "eat_pw_conv_b16_fwd":
-        x, x16, x2, c1, wp, bias, ta, tb, tact, sc, res, y, y16, part, B, Ci, Co, S, act = a[:19]
+        x, x16, x2, c1, wp, bias, ta, tb, tact, sc, res, y, y16, part, gz, ga, gb, gact, B, Ci, Co, S, act = a[:23]
         mt = (Co + 15) // 16
         chunks = (mt + 7) // 8
         mtw = (mt + chunks - 1) // chunks
         cw = (c1 if x2 else Ci) if x16 else 0                                      # bf16 input channels
-        nbytes = B * S * (2 * cw + 4 * (Ci - cw) + (2 if y16 else 4) * Co + (4 * Co if res else 0)) + 2 * Co * Ci
+        nbytes = B * S * (2 * cw + 4 * (Ci - cw) + (2 if y16 else 4) * Co + (4 * Co if res else 0)
+                          + (2 * Co if gz else 0)) + 2 * Co * Ci               # (gz: the epilogue reads the bf16 z_d tile)
         return (f"pw_conv_bf16_kernel<{mtw},1,*,{'true' if ta else 'false'},{'bf16' if x16 else 'float'},{'bf16' if y16 else 'float'}>",
                 nbytes, 2 * B * S * Ci * Co)
     if name == "eat_dw_conv_fwd_stats_b16":

@@ -81,6 +81,9 @@ SIGNATURES = {
     "eat_bn_stats_partial": [_P, _I, _I, _I, _P, _P],
     "eat_bn_finalize_partials": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P, _P],
     "eat_bn_finalize_ws_doubles": [_I, _I, _I],
+    "eat_pw_conv_gstats_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "eat_bn_bwd_sums_from_tiles": [_P, _I, _I, _P, _P, _P, _P, _P],
+    "eat_bn_bwd_sums_ws_doubles": [_I, _I],
     "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _I, _P],
     "eat_gram_centered": [_P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "eat_act_grad_sum": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
@@ -119,7 +122,7 @@ SIGNATURES = {
     "eat_se_mlp_dh_floats": [_I, _I, _I],
     "eat_mlp_head_dfeat_floats": [_I, _I, _I],
     # bf16 activation storage (BASELINE configs[2])
-    "eat_pw_conv_b16_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "eat_pw_conv_b16_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_b16_ok": [_I] * 8,
     "eat_dw_conv_fwd_stats_b16": [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_bn_act_fwd_b16": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],

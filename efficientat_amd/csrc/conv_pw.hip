@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     const float* __restrict__ in_scale, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int kc_arg,
     int n_stages, int act, int tps, long long wp_bstride, PwTf tf, const float* __restrict__ x2, int c1,
-    float* __restrict__ stats) {
+    float* __restrict__ stats, eat::PwGStat gs) {
+  // gs.z != NULL (with stats): the partials are the BatchNorm-backward sums of pw_epilogue_gstats instead
   // x2 != NULL: channels of x (c1 rows) followed by the channels of x2 (Ci - c1 rows) - see conv_pw_bf16.hip
   // stats != NULL: per-tile partial sums of the output for the BatchNorm that follows (pw_epilogue_stats)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -255,9 +256,15 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     }
   }
 
-  eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
-  if (stats) {                                             // block-uniform
+  if (stats && gs.z) {                                     // block-uniform
+    // BEFORE the stores of y: loads and stores retire through one in-order counter - a z load issued behind the tile's
+    // stores would wait for all of them (measured: the step 0.43 ms SLOWER than with the separate reduce pass)
     __syncthreads();                                       // every wave is done with the operand stages: LDS is free
+    eat::pw_epilogue_gstats<MTW>(acc, s_bias, smem, stats, gs, tile, mt0, kq, lane, wv, col_ok, bc, sc_, Co, S);
+  }
+  eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
+  if (stats && !gs.z) {
+    __syncthreads();
     eat::pw_epilogue_stats<MTW>(acc, s_bias, smem, stats, tile, mt0, kq, lane, wv, col_ok, Co);
   }
 }
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(1024) void linear_kernel(const float* __restrict__ 
 template <int MTW>
 int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias, const float* in_scale,
               const float* res, float* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act,
-              bool per_sample, PwTf tf, const float* x2, int c1, float* stats) {
+              bool per_sample, PwTf tf, const float* x2, int c1, float* stats, eat::PwGStat gs) {
   const long long N = (long long)B * S;
   const int tps = per_sample ? (S + kTileN - 1) / kTileN : 0;
   const int n_tiles = per_sample ? B * tps : (int)((N + kTileN - 1) / kTileN);
@@ -362,7 +369,7 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
     n_stages = ((Ci + kc - 1) / kc) > 1 ? 2 : 1;
     smem = (size_t)n_stages * stage_floats(MTW, kc, NS) * sizeof(float);
   }
-  if (stats && smem < (size_t)4 * MTW * 16 * 2 * sizeof(float)) smem = (size_t)4 * MTW * 16 * 2 * sizeof(float);
+  if (stats && smem < (size_t)10 * MTW * 16 * sizeof(float)) smem = (size_t)10 * MTW * 16 * sizeof(float);   // wave partials + (a, b)
   if (smem > 160 * 1024) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: LDS stage too large (%zu B)", smem);
   auto kern = tf.a ? (pipe ? pw_conv_kernel<MTW, true, true> : pw_conv_kernel<MTW, false, true>)
                    : (pipe ? pw_conv_kernel<MTW, true, false> : pw_conv_kernel<MTW, false, false>);
@@ -372,7 +379,7 @@ int launch_pw(hipStream_t s, const float* x, const float* wp, const float* bias,
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT,
-                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf, x2, c1, stats);
+                     MC, n_tiles, NS, kc, n_stages, act, tps, wp_bstride, tf, x2, c1, stats, gs);
   return eat::check_launch("eat_pw_conv_fwd");
 }
 
@@ -401,7 +408,8 @@ extern "C" int eat_pw_prepack_t(const float* w_t, const float* row_scale, float*
 
 static int pw_dispatch(const float* x, const float* wp, const float* bias, const float* in_scale, const float* res,
                        float* y, float* pool, int B, int Ci, int Co, int S, int act, bool per_sample, hipStream_t s,
-                       PwTf tf = PwTf{nullptr, nullptr, 0}, const float* x2 = nullptr, int c1 = 0, float* stats = nullptr) {
+                       PwTf tf = PwTf{nullptr, nullptr, 0}, const float* x2 = nullptr, int c1 = 0, float* stats = nullptr,
+                       eat::PwGStat gs = eat::PwGStat{nullptr, nullptr, nullptr, 0}) {
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: Ci=%d must be a multiple of 4", Ci);
   if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad act %d", act);
   if (B < 1 || Ci < 4 || Co < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_pw_conv_fwd: bad shape");
@@ -416,7 +424,7 @@ static int pw_dispatch(const float* x, const float* wp, const float* bias, const
   // the tile must be tall: up to 8 m-tiles (128 rows) per block.
   const int MC = (MT + 7) / 8;                    // row chunks
   const int mtw = (MT + MC - 1) / MC;             // balanced m-tiles per block
-#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf, x2, c1, stats);
+#define EAT_PW_CASE(n) case n: return launch_pw<n>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, per_sample, tf, x2, c1, stats, gs);
   switch (mtw) {
     EAT_PW_CASE(1) EAT_PW_CASE(2) EAT_PW_CASE(3) EAT_PW_CASE(4) EAT_PW_CASE(5)
     EAT_PW_CASE(6) EAT_PW_CASE(7) EAT_PW_CASE(8)
@@ -494,6 +502,25 @@ extern "C" int eat_pw_conv_stats_fwd(const float* x, const void* wp, int wmode, 
                        per_sample != 0, (hipStream_t)stream, PwTf{tf_a, tf_b, tf_act}, nullptr, 0, part);
   return eat::pw_conv_bf16_stats(x, wp, wmode == 2 ? 1 : 0, per_sample, tf_a, tf_b, tf_act, in_scale, zero_bias, y, part, B, Ci,
                                  Co, S, (hipStream_t)stream);
+}
+
+// Data-gradient GEMM of a project conv (y = dxs = W^T dz_p; wp = the transposed pack, wmode as above, no per-sample form)
+// with the BatchNorm + activation BACKWARD statistics of the depthwise output z_d in its epilogue (pw_epilogue_gstats): part
+// [tile][2][Co] partials of sum g and sum g z_d, g = dxs * act'(g_a z_d + g_b) - the reduce pass over (dxs, z_d) disappears;
+// eat_bn_bwd_sums_from_tiles finishes.  Returns 1 (nothing launched) for S % 4 != 0.
+extern "C" int eat_pw_conv_gstats_fwd(const float* x, const void* wp, int wmode, const float* zero_bias, float* y,
+                                      const float* gz, const float* g_a, const float* g_b, int g_act, float* part, int B,
+                                      int Ci, int Co, int S, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !wp || !y || !part || !zero_bias || !gz || !g_a || !g_b)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_gstats_fwd: missing operand");
+  if (g_act < 0 || g_act > 2 || (wmode != 0 && wmode != 2)) return eat::fail(EAT_EINVAL, "eat_pw_conv_gstats_fwd: bad act / wmode");
+  if (S % 4 != 0) return 1;
+  const eat::PwGStat gs{gz, g_a, g_b, g_act};
+  if (wmode == 0)
+    return pw_dispatch(x, reinterpret_cast<const float*>(wp), zero_bias, nullptr, nullptr, y, nullptr, B, Ci, Co, S, EAT_ACT_NONE,
+                       false, (hipStream_t)stream, PwTf{nullptr, nullptr, 0}, nullptr, 0, part, gs);
+  return eat::pw_conv_bf16_stats(x, wp, 1, 0, nullptr, nullptr, 0, nullptr, zero_bias, y, part, B, Ci, Co, S, (hipStream_t)stream, gs);
 }
 
 extern "C" int eat_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,

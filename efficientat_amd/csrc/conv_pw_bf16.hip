@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     const float* __restrict__ in_scale, const float* __restrict__ res, YT* __restrict__ y,
     float* __restrict__ pool, int B, int Ci, int Co, int S, int MT, int MC, int n_tiles, int NS, int act,
     int sc_bytes, int ci_x, PwTf tf, const float* __restrict__ x2, int c1, int tps, long long wp_bstride,
-    float* __restrict__ stats) {
+    float* __restrict__ stats, eat::PwGStat gs) {
+  // gs.z != NULL (with stats): BatchNorm-backward partials of pw_epilogue_gstats (z in y's storage type) instead
   // tps > 0: per-sample weights (DyMN dynamic conv, models/dymn/dy_block.py:111-127, on split bf16 operands): a tile lies
   //          inside one sample (tps tiles per sample) and reads that sample's packed weights (wp_bstride elements apart)
   // x2 != NULL ("two-source"): the reduction axis is the channels of x (c1 rows) followed by the channels of x2
@@ -310,9 +311,14 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
     }
   }
 
-  eat::pw_epilogue<MTW, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
-  if (stats) {                                             // block-uniform: train-mode statistics of the output (pw_epilogue.h)
+  if (stats && gs.z) {                                     // block-uniform; before the stores of y (see conv_pw.hip)
     __syncthreads();                                       // every wave is done with the operand stages: LDS is free
+    eat::pw_epilogue_gstats<MTW, YT, YT>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, gs, tile, mt0, kq, lane, wv,
+                                         col_ok, bc, sc_, Co, S);
+  }
+  eat::pw_epilogue<MTW, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
+  if (stats && !gs.z) {                                    // train-mode statistics of the output (pw_epilogue.h)
+    __syncthreads();
     eat::pw_epilogue_stats<MTW, YT>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, tile, mt0, kq, lane, wv, col_ok, Co);
   }
 }
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
 template <int MTW, int NPROD, typename XT = float, typename YT = float>
 int launch(hipStream_t s, const XT* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
            YT* y, float* pool, int B, int Ci, int Co, int S, int MT, int MC, int act, int ci_x, PwTf tf,
-           const float* x2, int c1, bool per_sample, float* stats) {
+           const float* x2, int c1, bool per_sample, float* stats, eat::PwGStat gs) {
   constexpr bool XB = eat::Io<XT>::kBf;
   const long long N = (long long)B * S;
   if (N > 0x7fff0000LL) return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: B*S = %lld exceeds the 32-bit column index", N);
@@ -353,20 +359,21 @@ int launch(hipStream_t s, const XT* x, const __bf16* wp, const float* bias, cons
   }
   const int tiles8 = (n_tiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(tiles8 * MC), dim3(256), smem, s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, MC,
-                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1, tps, wp_bstride, stats);
+                     n_tiles, NS, act, sc_bytes, ci_x, tf, x2, c1, tps, wp_bstride, stats, gs);
   return eat::check_launch("eat_pw_conv_bf16_fwd");
 }
 
 template <int NPROD, typename XT = float, typename YT = float>
 int dispatch(hipStream_t s, const XT* x, const __bf16* wp, const float* bias, const float* in_scale, const float* res,
              YT* y, float* pool, int B, int Ci, int Co, int S, int act, int ci_x, PwTf tf = PwTf{nullptr, nullptr, 0},
-             const float* x2 = nullptr, int c1 = 0, bool per_sample = false, float* stats = nullptr) {
+             const float* x2 = nullptr, int c1 = 0, bool per_sample = false, float* stats = nullptr,
+             eat::PwGStat gs = eat::PwGStat{nullptr, nullptr, nullptr, 0}) {
   const int MT = (Co + 15) / 16;
   // (K-concat launches with few output rows - 128 x 1920 -> 320 @ 4x32: 192 blocks of 240 chunks - do NOT gain from more,
   // smaller row chunks: every block re-streams its x tile once per bank through L2, 425 -> 480 us with 448 blocks)
   const int MC = (MT + 7) / 8;
   const int mtw = (MT + MC - 1) / MC;
-#define EAT_CASE(n) case n: return launch<n, NPROD, XT, YT>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample, stats);
+#define EAT_CASE(n) case n: return launch<n, NPROD, XT, YT>(s, x, wp, bias, in_scale, res, y, pool, B, Ci, Co, S, MT, (MT + n - 1) / n, act, ci_x, tf, x2, c1, per_sample, stats, gs);
   switch (mtw) {
     EAT_CASE(1) EAT_CASE(2) EAT_CASE(3) EAT_CASE(4) EAT_CASE(5) EAT_CASE(6) EAT_CASE(7) EAT_CASE(8)
     default: return eat::fail(EAT_EINVAL, "eat_pw_conv_bf16_fwd: internal tiling error");
@@ -439,13 +446,13 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
 namespace eat {
 int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample, const float* tf_a, const float* tf_b,
                        int tf_act, const float* in_scale, const float* zero_bias, float* y, float* part, int B, int Ci, int Co,
-                       int S, hipStream_t s) {
+                       int S, hipStream_t s, PwGStat gs) {
   const PwTf tf{tf_a, tf_b, tf_act};
   const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
   return split ? dispatch<3>(s, x, w16, zero_bias, in_scale, nullptr, y, nullptr, B, Ci, Co, S, EAT_ACT_NONE, Ci, tf, nullptr, 0,
-                             per_sample != 0, part)
+                             per_sample != 0, part, gs)
                : dispatch<1>(s, x, w16, zero_bias, in_scale, nullptr, y, nullptr, B, Ci, Co, S, EAT_ACT_NONE, Ci, tf, nullptr, 0,
-                             per_sample != 0, part);
+                             per_sample != 0, part, gs);
 }
 }  // namespace eat
 
@@ -505,8 +512,8 @@ extern "C" int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float*
 // wp: eat_pw_prepack_bf16(split = 0) of the (Co, Ci) matrix.  S % 8 == 0, Ci % 4 == 0 (% 8 with a transform).
 extern "C" int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const void* wp, const float* bias,
                                    const float* tf_a, const float* tf_b, int tf_act, const float* in_scale, const float* res,
-                                   void* y, int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act,
-                                   eat_stream_t stream) {
+                                   void* y, int y_b16, float* stats_part, const void* gz, const float* g_a, const float* g_b,
+                                   int g_act, int B, int Ci, int Co, int S, int act, eat_stream_t stream) {
   eat::clear_stale_error();
   if (!x || !wp || !bias || !y) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: missing operand");
   if (B < 1 || Co < 1 || Ci < 4 || Ci % 4 != 0 || S < 8 || S % 8 != 0)
@@ -530,11 +537,14 @@ extern "C" int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, in
                                            reinterpret_cast<float*>(y), nullptr, B, Ci, Co, S, act, Ci, tf, x2, c1, false,
                                            stats_part);
   }
+  if (gz && !(x_b16 && y_b16 && stats_part && g_a && g_b && g_act >= 0 && g_act <= 2 && !tf_a && !in_scale))
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: the BatchNorm-backward epilogue (gz) goes with a plain bf16 -> bf16 conv and stats_part");
   if (x_b16 && y_b16) {
     if (x2 || res) return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: bf16 -> bf16 takes no second source / residual");
+    // gz != NULL: stats_part receives the BatchNorm-backward partials of pw_epilogue_gstats (gz = the bf16 z_d) instead
     return dispatch<1, eat::bf16_t, eat::bf16_t>(s, reinterpret_cast<const eat::bf16_t*>(x), w16, bias, in_scale, nullptr,
                                                  reinterpret_cast<eat::bf16_t*>(y), nullptr, B, Ci, Co, S, act, Ci, tf, nullptr, 0,
-                                                 false, stats_part);
+                                                 false, stats_part, eat::PwGStat{gz, g_a, g_b, g_act});
   }
   return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: at least one of x / y is a bf16 tensor");
 }

@@ -89,9 +89,13 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
                     const float* in_scale, const float* res, float* y, int B, int Ci, int Co, int S, int act, int split,
                     hipStream_t s);
 
+// BatchNorm-backward statistics in a 1x1 conv's epilogue (pw_epilogue.h: pw_epilogue_gstats): z = the tensor whose
+// BatchNorm + activation backward is being reduced (layout of the conv output), a / b = that BatchNorm's folded affine
+struct PwGStat { const void* z; const float* a; const float* b; int act; };
+
 int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample, const float* tf_a, const float* tf_b,
                        int tf_act, const float* in_scale, const float* zero_bias, float* y, float* part, int B, int Ci, int Co,
-                       int S, hipStream_t s);
+                       int S, hipStream_t s, PwGStat gs = PwGStat{nullptr, nullptr, nullptr, 0});
 
 int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const void* wp, const float* bias, const float* res,
                      float* y, int B, int Co, int S, int act, int split, hipStream_t s);

@@ -198,6 +198,91 @@ __device__ __forceinline__ void pw_epilogue_stats(const acc_f32x4 (&acc)[MTW][4]
   }
 }
 
+// Backward statistics of the BatchNorm + activation that PRODUCED this conv's input-side tensor, taken in the epilogue of the
+// project conv's data-gradient GEMM (round 5): the conv output is dxs = W^T dz_p, the gradient arriving at
+// y_d = act(a z_d + b) (models/mn/block_types.py:150-162); the BatchNorm backward of the depthwise conv needs per channel
+//   sum g   and   sum g z_d,    g = dxs * act'(a z_d + b)
+// (eat_bn_act_bwd_reduce read dxs AND z_d for them: 0.71 ms per mn10 step on the three stem-resolution blocks).  Here dxs is
+// still in the accumulators: the epilogue loads the z_d tile, forms g and leaves ONE partial per (column tile, channel) in
+// the layout of pw_epilogue_stats - [tile][2][Co] - which eat_bn_bwd_sums_from_tiles reduces in fp64 (sum g z - mean sum g,
+// times invstd).  YT = bf16: g is formed from dxs AS STORED.  ZT: storage type of z_d.
+// (struct PwGStat { z, a, b, act }: eat_common.h)
+// rows of one activation kind (a template parameter: with a run-time kind the compiler evaluated the Hardswish AND the ReLU
+// derivative for every element - the epilogue's VALU work, not its loads, made the first version slower than the pass it
+// replaces)
+template <int MTW, int ACT, typename YT, typename ZT>
+__device__ __forceinline__ void pw_gstats_rows(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, const float* s_ab,
+                                               float* scratch, const ZT* zb, int mt0, int kq, int lane, int wv, float ok,
+                                               int Co, int S) {
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * 16 + kq * 4 + r;
+      int m = mt0 * 16 + row;
+      const float rok = m < Co ? ok : 0.0f;
+      if (m >= Co) m = Co - 1;
+      const float bm = s_bias[row], av = s_ab[row], bv = s_ab[MTW * 16 + row];
+      const float4 zv = Io<ZT>::load4(zb + (size_t)m * S);
+      const float v0 = Io<YT>::rnd(acc[i][0][r] + bm), v1 = Io<YT>::rnd(acc[i][1][r] + bm);
+      const float v2 = Io<YT>::rnd(acc[i][2][r] + bm), v3 = Io<YT>::rnd(acc[i][3][r] + bm);
+      float g0, g1, g2, g3;
+      if constexpr (ACT == EAT_ACT_RELU) {
+        g0 = fmaf(av, zv.x, bv) > 0.0f ? v0 : 0.0f; g1 = fmaf(av, zv.y, bv) > 0.0f ? v1 : 0.0f;
+        g2 = fmaf(av, zv.z, bv) > 0.0f ? v2 : 0.0f; g3 = fmaf(av, zv.w, bv) > 0.0f ? v3 : 0.0f;
+      } else if constexpr (ACT == EAT_ACT_HSWISH) {
+        auto dhs = [](float u) {                       // hardswish'(u) = clamp(u / 3 + 1/2 inside [-3, 3]; 0 below, 1 above)
+          const float t = fmaf(u, 1.0f / 3.0f, 0.5f);
+          return u < -3.0f ? 0.0f : (u > 3.0f ? 1.0f : t);
+        };
+        g0 = v0 * dhs(fmaf(av, zv.x, bv)); g1 = v1 * dhs(fmaf(av, zv.y, bv));
+        g2 = v2 * dhs(fmaf(av, zv.z, bv)); g3 = v3 * dhs(fmaf(av, zv.w, bv));
+      } else {
+        g0 = v0; g1 = v1; g2 = v2; g3 = v3;
+      }
+      float sm = ((g0 + g1) + (g2 + g3)) * rok;
+      float sq = fmaf(g0, zv.x, fmaf(g1, zv.y, fmaf(g2, zv.z, g3 * zv.w))) * rok;
+      sm = row16_sum_lane15(sm);
+      sq = row16_sum_lane15(sq);
+      if ((lane & 15) == 15) {
+        float* d = scratch + ((wv * MTW + i) * 16 + kq * 4 + r) * 2;
+        d[0] = sm; d[1] = sq;
+      }
+    }
+}
+
+template <int MTW, typename YT = float, typename ZT = float>
+__device__ __forceinline__ void pw_epilogue_gstats(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, float* scratch,
+                                                   float* __restrict__ part, const PwGStat gs, int tile, int mt0, int kq,
+                                                   int lane, int wv, bool col_ok, int bc, int sc_, int Co, int S) {
+  // stage a, b of the block's rows behind the wave partials: scratch[4 MTW 16 2 ...) = [2][MTW 16]
+  float* s_ab = scratch + 4 * MTW * 16 * 2;
+  for (int e = threadIdx.x; e < 2 * MTW * 16; e += 256) {
+    const int k = e / (MTW * 16), row = e - k * (MTW * 16);
+    int m = mt0 * 16 + row;
+    if (m >= Co) m = Co - 1;
+    s_ab[e] = (k == 0 ? gs.a : gs.b)[m];
+  }
+  __syncthreads();
+  const float ok = col_ok ? 1.0f : 0.0f;
+  const ZT* zb = reinterpret_cast<const ZT*>(gs.z) + (size_t)bc * Co * (size_t)S + sc_;
+  if (gs.act == EAT_ACT_RELU)                                                       // uniform
+    pw_gstats_rows<MTW, EAT_ACT_RELU, YT, ZT>(acc, s_bias, s_ab, scratch, zb, mt0, kq, lane, wv, ok, Co, S);
+  else if (gs.act == EAT_ACT_HSWISH)
+    pw_gstats_rows<MTW, EAT_ACT_HSWISH, YT, ZT>(acc, s_bias, s_ab, scratch, zb, mt0, kq, lane, wv, ok, Co, S);
+  else
+    pw_gstats_rows<MTW, EAT_ACT_NONE, YT, ZT>(acc, s_bias, s_ab, scratch, zb, mt0, kq, lane, wv, ok, Co, S);
+  __syncthreads();
+  for (int e = threadIdx.x; e < MTW * 16 * 2; e += 256) {
+    const int row = e >> 1, k = e & 1, m = mt0 * 16 + row;
+    if (m < Co) {
+      const float t = (scratch[(0 * MTW * 16 + row) * 2 + k] + scratch[(1 * MTW * 16 + row) * 2 + k]) +
+                      (scratch[(2 * MTW * 16 + row) * 2 + k] + scratch[(3 * MTW * 16 + row) * 2 + k]);
+      part[((size_t)tile * 2 + k) * Co + m] = t;
+    }
+  }
+}
+
 // `act` is wave-uniform: the project layers (no activation) take a branch without any activation math,
 // ReLU / Hardswish share the branch-free 4-op form (a third specialisation pushed the 7-8 m-tile kernels
 // over 256 VGPRs).

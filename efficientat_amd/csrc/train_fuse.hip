@@ -522,6 +522,33 @@ extern "C" int eat_se_bn_bwd_combine(const float* P, const float* gscale, const 
   return eat::check_launch("eat_se_bn_bwd_combine");
 }
 
+// ---- channel sums of a BatchNorm backward from the tile partials of pw_epilogue_gstats ([tiles][2][C]: sum g, sum g z) ----
+// sums[c] = sum g, sums[C + c] = invstd[c] (sum g z - mean[c] sum g)   (fp64; the layout eat_bn_act_bwd_apply /
+// eat_dw_conv_bwd_bn_g read).  rows: the tile partials themselves (PT = float) or their row-group sums (PT = double).
+template <typename PT>
+__global__ __launch_bounds__(256) void bn_bwd_sums_finish_kernel(const PT* __restrict__ v, int rows, int C,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, double* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  int r = 0;
+  for (; r + 3 < rows; r += 4) {                       // (loads of four rows in flight: rows <= 64 here)
+    const PT a0 = v[(size_t)r * 2 * C + c], a1 = v[(size_t)(r + 1) * 2 * C + c];
+    const PT a2 = v[(size_t)(r + 2) * 2 * C + c], a3 = v[(size_t)(r + 3) * 2 * C + c];
+    const PT b0 = v[(size_t)r * 2 * C + C + c], b1 = v[(size_t)(r + 1) * 2 * C + C + c];
+    const PT b2 = v[(size_t)(r + 2) * 2 * C + C + c], b3 = v[(size_t)(r + 3) * 2 * C + C + c];
+    s0 += (double)a0; s0 += (double)a1; s0 += (double)a2; s0 += (double)a3;
+    s1 += (double)b0; s1 += (double)b1; s1 += (double)b2; s1 += (double)b3;
+  }
+  for (; r < rows; ++r) {
+    s0 += (double)v[(size_t)r * 2 * C + c];
+    s1 += (double)v[(size_t)r * 2 * C + C + c];
+  }
+  sums[c] = s0;
+  sums[C + c] = (double)invstd[c] * (s1 - (double)mean[c] * s0);
+}
+
 // doubles of workspace eat_bn_finalize_partials wants for this shape (0: none - few partial rows)
 extern "C" int eat_bn_finalize_ws_doubles(int outer, int C, int inner) {
   if (outer < 1 || C < 1 || inner < 1) return 0;
@@ -547,6 +574,31 @@ extern "C" int eat_bn_finalize_partials(const float* part, int outer, int C, int
                        C, inner, gamma, beta, running_mean, running_var, momentum, eps, n, a, b, mean, invstd);
   }
   return eat::check_launch("eat_bn_finalize_partials");
+}
+
+// row groups of the tile partials: from 32 tiles on (one thread walking 504 rows of its channel took 200 us)
+static int bwd_tile_groups(int tiles) { return tiles < 32 ? 0 : (tiles / 8 > kFinGroupsMax ? kFinGroupsMax : tiles / 8); }
+extern "C" int eat_bn_bwd_sums_ws_doubles(int tiles, int C) { return tiles < 1 || C < 1 ? 0 : bwd_tile_groups(tiles) * 2 * C; }
+
+// part: [tiles][2][C] from eat_pw_conv_gstats_fwd; ws: eat_bn_bwd_sums_ws_doubles(tiles, C) doubles (or NULL when that is 0)
+extern "C" int eat_bn_bwd_sums_from_tiles(const float* part, int tiles, int C, const float* mean, const float* invstd,
+                                          double* ws, double* sums, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!part || !mean || !invstd || !sums || tiles < 1 || C < 1) return eat::fail(EAT_EINVAL, "eat_bn_bwd_sums_from_tiles: bad arguments");
+  const int G = bwd_tile_groups(tiles);
+  if (G > 0 && !ws) return eat::fail(EAT_EINVAL, "eat_bn_bwd_sums_from_tiles: %d tiles need the row-group workspace", tiles);
+  const dim3 grid((unsigned)((C + 255) / 256));
+  if (G > 0) {
+    const int W = 2 * C, cw = fin_col_threads(W);
+    hipLaunchKernelGGL(bn_partials_rowgroups_kernel, dim3((unsigned)((W + cw - 1) / cw), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, part, tiles, W, ws);
+    hipLaunchKernelGGL(bn_bwd_sums_finish_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)ws, G, C, mean,
+                       invstd, sums);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_sums_finish_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, part, tiles, C, mean, invstd,
+                       sums);
+  }
+  return eat::check_launch("eat_bn_bwd_sums_from_tiles");
 }
 
 extern "C" int eat_gram_bn_finalize(const float* Tm, const float* W, const float* sx, int Co, int Ci, const float* gamma,

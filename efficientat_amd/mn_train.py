@@ -135,6 +135,10 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         bn_reg.append((wname, bname, C, off))
         return bn_buf[off:off + 2 * C]
 
+    def bn_unreserve(wname):
+        if bn_reg and bn_reg[-1][0] == wname:
+            bn_reg.pop()
+
     def bn_grads(dgam, dbet, wname, bname):
         if dgam is not None:
             g[wname], g[bname] = dgam, dbet
@@ -203,13 +207,41 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             dWp = wgrad(dz_p, rec["y_d"], x_scale=scale, out=o_p)
         g[f"{pre}.{blk.i_proj}.0.weight"] = dWp.view_as(cna[0].weight)
         wpt = _pk(plan, ("pt", i), cna[0].weight, trans=True)
+        # (what the depthwise stage below will do with dxs, decided here: without an SE gate between the two, the channel sums
+        # of the depthwise BatchNorm's backward can leave the data-gradient GEMM's epilogue - ops.pw_conv_gstats)
+        k = cnf.kernel
+        y_e = rec["y_e"]
+        no_expand = blk.i_expand is None
+        src_shape = tuple((y_e if y_e is not None else rec["z_e"]).shape)
+        # a block without expand conv hands its residual-branch gradient to the stem's backward kernel, which adds the
+        # two on load (the merged kernel has no residual input)
+        res_ok = not no_expand or res_grad is None or (i == 0 and sv["stem"][1] is None)
+        use_merged = (_MERGED_DW_BWD and _DW_BN_ON_LOAD and (y_e is None or no_expand) and res_ok
+                      and ops.dw_bwd_merged_ok(rec["z_d"].shape, src_shape, k, cnf.stride))
+        sums_d = None
         if b16:
             if dz16 is None:
                 dz16 = ops.cast_b16(dz_p) if _cast_narrow(cnf, dz_p) else dz_p
-            dxs = ops.pw_conv_b16(dz16, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE, out_b16=True)
+            gst = None
+            if (_GSTATS_EPILOGUE and use_merged and scale is None and rec["z_d"].numel() >= _GSTATS_MIN_ELEMS
+                    and dz16.dtype == torch.bfloat16 and rec["z_d"].dtype == torch.bfloat16):
+                nw_d, nb_d = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
+                gst = (rec["z_d"], rec["st_d"], act, bn_sums(cnf.expanded_channels, nw_d, nb_d))
+            dxs = ops.pw_conv_b16(dz16, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE, out_b16=True,
+                                  gstat=gst)
+            if gst is not None:
+                dxs, sums_d = dxs
             del dz16
         else:
-            dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
+            dxs = None
+            if _GSTATS_EPILOGUE and use_merged and scale is None and rec["z_d"].numel() >= _GSTATS_MIN_ELEMS:
+                nw_d, nb_d = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
+                slot = bn_sums(cnf.expanded_channels, nw_d, nb_d)
+                dxs, sums_d = ops.pw_conv_gstats(dz_p, wpt, cnf.expanded_channels, rec["z_d"], rec["st_d"], act, sums=slot)
+                if dxs is None:
+                    bn_unreserve(nw_d)
+            if dxs is None:
+                dxs = ops.pw_conv(dz_p, wpt, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE)
         del dz_p
         gscale = gadd = se_P = None
         if scale is not None:     # squeeze-excitation gate (mn/block_types.py:72-83)
@@ -228,24 +260,19 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             gscale = scale
         # depthwise conv + BN + act
         cna = blk.block[blk.i_dw]
-        k = cnf.kernel
-        y_e = rec["y_e"]
         merged = None
-        no_expand = blk.i_expand is None
-        src_shape = tuple((y_e if y_e is not None else rec["z_e"]).shape)
-        # a block without expand conv hands its residual-branch gradient to the stem's backward kernel, which adds the
-        # two on load (the merged kernel has no residual input)
-        res_ok = not no_expand or res_grad is None or (i == 0 and sv["stem"][1] is None)
         if b16 and not (_MERGED_DW_BWD and _DW_BN_ON_LOAD):
             raise _lib.EatHipError("act_storage='bf16' runs the merged depthwise backward only (EAT_MERGED_DW_BWD / EAT_DW_BN_ON_LOAD = 1)")
-        if (_MERGED_DW_BWD and _DW_BN_ON_LOAD and (y_e is None or no_expand) and res_ok
-                and ops.dw_bwd_merged_ok(rec["z_d"].shape, src_shape, k, cnf.stride)):
+        if use_merged:
             # large planes: dz_d is never written - the merged backward kernel evaluates the BatchNorm + activation
             # backward of the depthwise output on load from (dxs, z_d) and the channel sums of the reduce pass
             st_d = rec["st_d"]
             nw, nbias = f"{pre}.{blk.i_dw}.1.weight", f"{pre}.{blk.i_dw}.1.bias"
-            sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P,
-                                                   sums=bn_sums(cnf.expanded_channels, nw, nbias))
+            if sums_d is not None:                     # (they left the data-gradient GEMM's epilogue above)
+                sums, dgam, dbet = sums_d, None, None
+            else:
+                sums, dgam, dbet = ops.bn_act_bwd_sums(dxs, rec["z_d"], *st_d, act, gscale=gscale, gadd=gadd, se_P=se_P,
+                                                       sums=bn_sums(cnf.expanded_channels, nw, nbias))
             bn_grads(dgam, dbet, nw, nbias)
             w_d = cna[0].weight.reshape(-1, k * k)
             if no_expand:
@@ -389,6 +416,13 @@ _EPI_STATS = True         # project / last conv: BatchNorm statistics in the 1x1
 _PREPACK_PLAN = True      # all weight packs of the step from one launch
 _FUSE_STEM = True         # stem without its pre-activation tensor (csrc/stem_train.hip)
 _CAST_NARROW_MIN_CEXP = 200    # bf16-storage plan: bf16 copy of the narrow operand of the expand / data-gradient conv from this width
+_GSTATS_EPILOGUE = True  # depthwise BatchNorm backward sums from the project data-gradient GEMM's epilogue (blocks without SE gate)
+# (same-box A/B of the mn10 step: 24.29 / 24.17 ms without, 23.97 / 23.96 ms with; mn40 bf16 storage: 42.19 vs 42.17 ms - there
+# the reduce pass reads 2-byte tensors and the epilogue saves little)
+# ... from this size of the depthwise output on (same-box microbenchmarks at B = 256, conv + reduce pass -> conv with the
+# epilogue + finish: 16 -> 16 at 64 x 500 387 -> 299 us, 24 -> 64 at 32 x 250 352 -> 280, 24 -> 72 378 -> 332; the 8 x 63 layers
+# 80 -> 240 / 200 / 184: 89 -> 110, 76 -> 87, 67 -> 65 us - their reduce pass is cheaper than the epilogue's extra phase)
+_GSTATS_MIN_ELEMS = 1 << 26
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
 
 

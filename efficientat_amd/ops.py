@@ -935,6 +935,38 @@ def pw_conv_stats(x, wp, Co, per_sample=False, tf=None, in_scale=None):
     return y, (part, tiles, 1)
 
 
+def pw_conv_gstats(x, wp, Co, z, st, act, sums=None):
+    """Project conv's data-gradient GEMM y = W^T x (wp: transposed pack, fp32 or split bf16) with the BatchNorm + activation
+    backward statistics of the depthwise output `z` (st = its (a, b, mean, invstd), act its activation) in the epilogue:
+    -> (y, sums (2C,) float64) - what `bn_act_bwd_sums(y, z, *st, act)` returns, without the pass over (y, z) - or (None, None)
+    where the epilogue does not exist (S % 4 != 0, plain-bf16 / fp32-free packs: the caller runs the separate pass)."""
+    B, Ci, F, T = x.shape
+    S = F * T
+    if wp.dtype == torch.float32:
+        wmode = 0
+    elif getattr(wp, "_eat_split", False):
+        wmode = 2
+    else:
+        return None, None
+    if S % 4 != 0 or z.dtype != torch.float32:
+        return None, None
+    a, b, mean, invstd = st
+    tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, S, 0))
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32)
+    part = torch.empty((tiles * 2 * Co,), device=x.device, dtype=torch.float32)
+    rc = _lib.call_rc("eat_pw_conv_gstats_fwd", _dev(x, "x"), wp.data_ptr(), wmode, _zero_bias(Co, x.device).data_ptr(),
+                      y.data_ptr(), _dev(z, "z"), a.data_ptr(), b.data_ptr(), act, part.data_ptr(), B, Ci, Co, S, _stream())
+    if rc == 1:
+        return None, None
+    if sums is None:
+        sums = torch.empty((2 * Co,), device=x.device, dtype=torch.float64)
+    nws = int(_lib.lib().eat_bn_bwd_sums_ws_doubles(tiles, Co))
+    ws = torch.empty((nws,), device=x.device, dtype=torch.float64) if nws else None
+    _lib.call("eat_bn_bwd_sums_from_tiles", part.data_ptr(), tiles, Co, mean.data_ptr(), invstd.data_ptr(),
+              None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
+    return y, sums
+
+
 _zb = {}
 
 
@@ -1150,7 +1182,7 @@ def b16_block_ok(B, C_exp, F, T, k, stride):
             and (Fo * To) % 8 == 0 and C_exp % 8 == 0)
 
 
-def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None, stats=False, out_b16=False):
+def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None, stats=False, out_b16=False, gstat=None):
     """1x1 conv of the bf16-storage plan: exactly one of input / output is the wide bf16 tensor (`eat_pw_conv_b16_fwd`).
     x fp32 -> y bf16 (expand conv, project data gradient); x bf16 -> y fp32 (project conv with tf = (a, b, act) / in_scale /
     stats=True -> (y, parts); two-source data-gradient GEMM with x2 fp32 + res).  wp: plain bf16 pack (precision 'bf16')."""
@@ -1163,14 +1195,25 @@ def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None,
     y16 = out_b16 or not x16                       # (fp32 in: always a bf16 output; bf16 in: fp32, or bf16 for z_p)
     y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.bfloat16 if y16 else torch.float32)
     part = None
-    if stats:
+    if stats or gstat is not None:
         tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, S, 0))
         part = torch.empty((tiles * 2 * Co,), device=x.device, dtype=torch.float32)
     a, b, tact = tf if tf is not None else (None, None, 0)
+    # gstat = (z_d bf16, (a, b, mean, invstd), act, sums or None): bf16 -> bf16 project data gradient with the depthwise
+    # BatchNorm's backward sums in the epilogue -> (y, sums (2 Co,) float64), see pw_conv_gstats
+    gz, gst, gact, gsums = gstat if gstat is not None else (None, (None, None, None, None), 0, None)
     _lib.call("eat_pw_conv_b16_fwd", _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(x2, "x2"), C1,
               wp.data_ptr(), _dev(bias, "bias"), _opt(a, "tf_a"), _opt(b, "tf_b"), tact, _opt(in_scale, "in_scale"),
-              _opt(res, "res"), y.data_ptr(), 1 if y16 else 0, None if part is None else part.data_ptr(), B, Ci, Co, S, act,
+              _opt(res, "res"), y.data_ptr(), 1 if y16 else 0, None if part is None else part.data_ptr(),
+              None if gz is None else _dev16(gz, "gz"), _opt(gst[0], "g_a"), _opt(gst[1], "g_b"), gact, B, Ci, Co, S, act,
               _stream())
+    if gstat is not None:
+        sums = gsums if gsums is not None else torch.empty((2 * Co,), device=x.device, dtype=torch.float64)
+        nws = int(_lib.lib().eat_bn_bwd_sums_ws_doubles(tiles, Co))
+        ws = torch.empty((nws,), device=x.device, dtype=torch.float64) if nws else None
+        _lib.call("eat_bn_bwd_sums_from_tiles", part.data_ptr(), tiles, Co, gst[2].data_ptr(), gst[3].data_ptr(),
+                  None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
+        return y, sums
     return (y, (part, tiles, 1)) if stats else y
 
 

@@ -194,6 +194,20 @@ int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, con
                              float* running_mean, float* running_var, float momentum, float eps, double n, float* a,
                              float* b, float* mean, float* invstd, double* ws, eat_stream_t stream);
 
+/* Data-gradient GEMM of the project conv, y = W^T dz_p (wp: eat_pw_prepack_t / eat_pw_prepack_bf16_t pack of the project
+ * weight, wmode 0 = fp32, 2 = bf16 hi / lo), with the backward statistics of the depthwise conv's BatchNorm + activation
+ * (autograd through block_types.py:150-162) in its epilogue: part [tiles][2][Co], tiles = eat_pw_conv_stat_tiles(B, S, 0),
+ * holds per 256-column tile the sums of g and of g z_d with g = y * act'(g_a z_d + g_b); gz = z_d (B, Co, S).  Replaces
+ * eat_bn_act_bwd_reduce over (y, z_d) where no SE gate sits between the two (gscale / gadd = NULL there).  Returns 1 and
+ * launches nothing when S % 4 != 0.  eat_bn_bwd_sums_from_tiles turns the partials into the sums eat_bn_act_bwd_apply /
+ * eat_dw_conv_bwd_bn_g read (ws: eat_bn_bwd_sums_ws_doubles(tiles, C) doubles, NULL when that is 0). */
+int eat_pw_conv_gstats_fwd(const float* x, const void* wp, int wmode, const float* zero_bias, float* y, const float* gz,
+                           const float* g_a, const float* g_b, int g_act, float* part, int B, int Ci, int Co, int S,
+                           eat_stream_t stream);
+int eat_bn_bwd_sums_ws_doubles(int tiles, int C);
+int eat_bn_bwd_sums_from_tiles(const float* part, int tiles, int C, const float* mean, const float* invstd, double* ws,
+                               double* sums, eat_stream_t stream);
+
 /* Centred Gram matrix of a conv input x (B, C, S) (the statistics of the conv1x1 -> nn.BatchNorm2d pair of
  * models/mn/block_types.py:138-147 without reading the conv output): Gc = sum_{b,s} (x - m)(x - m)^T, m = sx * inv_n the
  * channel means - both operands of the weight-gradient kernel are centred on load.  w^T Gc w = sum (z - w.m)^2 is n var(z)
@@ -674,12 +688,16 @@ int eat_mlp_head_bwd(const float* dlogits, const float* h2, const float* u, cons
  *   x_b16 = 1, y_b16 = 0: z_p = Wp (act(tf_a x + tf_b) * in_scale) with the statistics epilogue (stats_part as
  *          eat_pw_conv_stats_fwd, tiles = eat_pw_conv_stat_tiles(B, S, 0)), or the two-source data-gradient GEMM
  *          dx = [WaT | M] [g ; x2] + bias + res with x2 (B, Ci - c1, S) fp32, c1 % 32 == 0 (as eat_pw_conv_cat_fwd);
- *   x_b16 = 1, y_b16 = 1: the project conv with its output z_p stored in bf16 too (statistics of the stored values).
+ *   x_b16 = 1, y_b16 = 1: the project conv with its output z_p stored in bf16 too (statistics of the stored values); the
+ *          expand conv / project data gradient from a bf16 copy of the narrow operand (eat_cast_b16); with gz != NULL
+ *          (bf16 z_d, B x Co x S) the project data gradient with the depthwise BatchNorm's backward sums in its epilogue:
+ *          stats_part then holds the partials of eat_pw_conv_gstats_fwd (g formed from y AS STORED).
  * wp = eat_pw_prepack_bf16(split = 0) of the (Co, Ci) matrix, Ci = all reduction channels; S % 8 == 0, Ci % 4 == 0
  * (% 8 with a transform). */
 int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, int c1, const void* wp, const float* bias,
                         const float* tf_a, const float* tf_b, int tf_act, const float* in_scale, const float* res, void* y,
-                        int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act, eat_stream_t stream);
+                        int y_b16, float* stats_part, const void* gz, const float* g_a, const float* g_b, int g_act, int B,
+                        int Ci, int Co, int S, int act, eat_stream_t stream);
 
 /* Twin of eat_dw_conv_fwd_stats (models/mn/block_types.py:150-162 under model.train()): y bf16, x bf16 (x_b16 != 0) or fp32
  * (the first block's depthwise conv reads the stem output); partial sums of the rounded outputs.  eat_dw_conv_b16_ok(...) != 0 where this and eat_dw_conv_bwd_bn_g_b16 cover the geometry (a plan keeps fp32

@@ -174,6 +174,36 @@ def test_bf16_copy_of_the_narrow_operand_leaves_the_conv_bit_identical(B, Ci, Co
         ops.cast_b16(torch.zeros(12, device=DEV))            # n % 8 != 0
 
 
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act", [(3, 96, 256, 32, 250, 1), (2, 96, 288, 16, 125, 1), (5, 320, 960, 8, 63, 2),
+                                               (7, 64, 72, 8, 40, 0)])
+def test_project_data_gradient_with_batchnorm_backward_sums_bf16_storage(B, Ci, Co, F_, T, act):
+    """bf16 -> bf16 project data gradient with the depthwise BatchNorm's backward sums in its epilogue (gz): y is the plain
+    conv's output bit for bit, the sums are those of the separate bf16 reduce pass over (y AS STORED, z_d)."""
+    dz16 = _rand(B, Ci, F_, T, seed=1).to(DEV).bfloat16()
+    W = _rand(Ci, Co, seed=2, scale=Ci ** -0.5).to(DEV)
+    z16 = (_rand(B, Co, F_, T, seed=3) * 1.5 + _rand(1, Co, 1, 1, seed=4)).to(DEV).bfloat16()
+    a = (torch.rand(Co, generator=torch.Generator().manual_seed(5)) + 0.5).to(DEV)
+    b = _rand(Co, seed=6, scale=0.5).to(DEV)
+    mean = _rand(Co, seed=7, scale=0.3).to(DEV)
+    invstd = (torch.rand(Co, generator=torch.Generator().manual_seed(8)) + 0.5).to(DEV)
+    zb = torch.zeros(Co, device=DEV)
+    with ops.precision("bf16"):
+        wpt = ops.pw_prepack(W, trans=True)
+        y_ref = ops.pw_conv_b16(dz16, wpt, zb, Co, NONE, out_b16=True)
+        y, sums = ops.pw_conv_b16(dz16, wpt, zb, Co, NONE, out_b16=True, gstat=(z16, (a, b, mean, invstd), act, None))
+    assert y.dtype == torch.bfloat16 and torch.equal(y, y_ref)
+    ref, _, _ = ops.bn_act_bwd_sums(y_ref, z16, a, b, mean, invstd, act)
+    yd, zd = y_ref.double(), z16.double()
+    u = a.double()[None, :, None, None] * zd + b.double()[None, :, None, None]
+    d = {0: torch.ones_like(u), 1: (u > 0).double(), 2: ((u >= -3) & (u <= 3)).double() * (u / 3 + 0.5) + (u > 3).double()}[act]
+    g = yd * d
+    s0 = g.sum((0, 2, 3)).cpu()
+    s1 = (invstd.double() * (g * (zd - mean.double()[None, :, None, None])).sum((0, 2, 3))).cpu()
+    n0, n1 = float(g.abs().sum((0, 2, 3)).max()), float((g * zd).abs().sum((0, 2, 3)).max()) * float(invstd.max())
+    assert float((sums[:Co].cpu() - s0).abs().max()) < 2e-6 * n0 and float((sums[Co:].cpu() - s1).abs().max()) < 2e-6 * n1
+    assert float((ref[:Co].cpu() - s0).abs().max()) < 2e-6 * n0
+
+
 # (B, C, F, T, k, stride, act): every register-resident geometry (tile kernels incl. odd row widths, the five plane kernels,
 # two planes per wave, odd batches)
 DW = [(3, 64, 64, 500, 3, 2, 1), (2, 16, 64, 500, 3, 1, 1), (3, 72, 32, 250, 5, 2, 1), (2, 24, 32, 250, 3, 1, 2),

@@ -141,6 +141,38 @@ def test_pw_conv_with_statistics_epilogue(B, Ci, Co, F_, T, mode, per_sample, tf
     assert _rel(bn.running_var, 0.99 + 0.01 * var * (B * S) / (B * S - 1)) < 1e-5
 
 
+@pytest.mark.parametrize("B,Ci,Co,F_,T,act,mode", [(3, 16, 64, 32, 250, 1, "fp32"), (2, 24, 72, 16, 125, 1, "fp32"),
+                                                    (5, 80, 240, 8, 63, 2, "auto"), (37, 80, 184, 8, 63, 2, "auto"),
+                                                    (2, 16, 16, 64, 500, 1, "auto"), (3, 40, 120, 16, 125, 0, "auto")])
+def test_data_gradient_conv_with_batchnorm_backward_sums_in_its_epilogue(B, Ci, Co, F_, T, act, mode):
+    """eat_pw_conv_gstats_fwd: y = W^T dz_p as the plain conv gives it, and the channel sums of the depthwise BatchNorm's
+    backward over (y, z_d) as the separate reduce pass (eat_bn_act_bwd_reduce) gives them - incl. ragged channel tiles,
+    tiles that straddle samples and both arithmetic modes of the data-gradient GEMM."""
+    dz = _rand(B, Ci, F_, T, seed=1).to(DEV)
+    W = _rand(Ci, Co, seed=2, scale=Ci ** -0.5).to(DEV)                 # project weight (Ci = its out_channels)
+    z_d = (_rand(B, Co, F_, T, seed=3) * 1.5 + _rand(1, Co, 1, 1, seed=4)).to(DEV)
+    a = (torch.rand(Co, generator=torch.Generator().manual_seed(5)) + 0.5).to(DEV)
+    b = _rand(Co, seed=6, scale=0.5).to(DEV)
+    mean = _rand(Co, seed=7, scale=0.3).to(DEV)
+    invstd = (torch.rand(Co, generator=torch.Generator().manual_seed(8)) + 0.5).to(DEV)
+    with ops.precision(mode):
+        wpt = ops.pw_prepack(W, trans=True)
+        y_ref = ops.pw_conv(dz, wpt, torch.zeros(Co, device=DEV), Co, ops.ACT_NONE)
+        y, sums = ops.pw_conv_gstats(dz, wpt, Co, z_d, (a, b, mean, invstd), act)
+    assert y is not None and torch.equal(y, y_ref)
+    ref, _, _ = ops.bn_act_bwd_sums(y_ref, z_d, a, b, mean, invstd, act)
+    # fp64 reference of the same sums from the same y
+    u = a.double()[None, :, None, None] * z_d.double() + b.double()[None, :, None, None]
+    d = {0: torch.ones_like(u), 1: (u > 0).double(), 2: ((u >= -3) & (u <= 3)).double() * (u / 3 + 0.5) + (u > 3).double()}[act]
+    g = y_ref.double() * d
+    s0 = g.sum((0, 2, 3))
+    s1 = invstd.double() * (g * (z_d.double() - mean.double()[None, :, None, None])).sum((0, 2, 3))
+    scale0, scale1 = float(g.abs().sum((0, 2, 3)).max()), float((g * z_d.double()).abs().sum((0, 2, 3)).max())
+    assert float((sums[:Co].cpu() - s0.cpu()).abs().max()) < 2e-6 * scale0
+    assert float((sums[Co:].cpu() - s1.cpu()).abs().max()) < 2e-6 * scale1 * float(invstd.max())
+    assert float((ref[:Co].cpu() - s0.cpu()).abs().max()) < 2e-6 * scale0          # (the pass it replaces, same bar)
+
+
 @pytest.mark.parametrize("outer,C,inner", [(32000, 16, 1), (8000, 24, 1), (256, 16, 16), (256, 64, 16), (5000, 130, 1),
                                            (300, 7, 9), (2047, 1, 1), (2048, 1, 1), (100, 40, 1)])
 def test_bn_finalize_from_many_partial_rows(outer, C, inner):
