@@ -6,38 +6,13 @@ import csv
 import numpy as np
 import torch
 
-from efficientat_amd.utils import NAME_TO_WIDTH  # noqa: F401
+from efficientat_amd.utils import NAME_TO_WIDTH, exp_rampup, exp_warmup_linear_down, linear_rampdown  # noqa: F401
 
 with open("metadata/class_labels_indices.csv", "r") as _f:
     _rows = list(csv.reader(_f, delimiter=","))[1:]
 ids = [r[1] for r in _rows]
 labels = [r[2] for r in _rows]
 classes_num = len(labels)
-
-
-def exp_rampup(rampup_length):
-    """exp(-5 (1 - e/L)^2) for e < L (e clipped to >= 0.5), then 1."""
-    def f(epoch):
-        if epoch >= rampup_length:
-            return 1.0
-        phase = 1.0 - float(np.clip(epoch, 0.5, rampup_length)) / rampup_length
-        return float(np.exp(-5.0 * phase * phase))
-    return f
-
-
-def linear_rampdown(rampdown_length, start=0, last_value=0):
-    def f(epoch):
-        if epoch <= start:
-            return 1.0
-        if epoch - start >= rampdown_length:
-            return last_value
-        return last_value + (1.0 - last_value) * (rampdown_length - epoch + start) / rampdown_length
-    return f
-
-
-def exp_warmup_linear_down(warmup, rampdown_length, start_rampdown, last_value):
-    up, down = exp_rampup(warmup), linear_rampdown(rampdown_length, start_rampdown, last_value)
-    return lambda epoch: up(epoch) * down(epoch)
 
 
 def mixup(size, alpha):

@@ -4,6 +4,7 @@
 //   eat_kd_loss_fwd_bwd  hard-label BCE-with-logits on the mixed targets + knowledge-distillation BCE against the
 //                        (mixed) teacher probabilities, lambda-weighted, AND its gradient w.r.t. the logits, in one
 //                        pass over the (B, C) logits (ex_audioset.py:149-189)
+//   eat_wave_i16_to_f32  16-bit PCM transport of the waveforms: int16 over PCIe, fp32 for the log-mel
 #include "eat_common.h"
 
 namespace {
@@ -27,6 +28,29 @@ __global__ __launch_bounds__(256) void mixup_tail_kernel(const float* __restrict
   const size_t pa = (size_t)b * n, pb = (size_t)perm[b] * n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     out[pa + i] = x[pa + i] * l + x[pb + i] * m;
+}
+
+// 8 samples per lane and trip: one 16-byte load, two 16-byte stores
+__global__ __launch_bounds__(256) void wave_i16_kernel(const short* __restrict__ src, float* __restrict__ dst, long long n8,
+                                                       float scale) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const int4 v = reinterpret_cast<const int4*>(src)[i];
+    const int w[4] = {v.x, v.y, v.z, v.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[2 * j] = (float)(short)(w[j] & 0xffff) * scale;
+      o[2 * j + 1] = (float)(w[j] >> 16) * scale;
+    }
+    reinterpret_cast<float4*>(dst)[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+__global__ __launch_bounds__(256) void wave_i16_tail_kernel(const short* __restrict__ src, float* __restrict__ dst, long long n0,
+                                                            long long n, float scale) {
+  const long long i = n0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i] * scale;
 }
 
 // numerically stable BCE-with-logits term (torch: max(z,0) - z t + log1p(exp(-|z|)))
@@ -197,6 +221,21 @@ extern "C" int eat_mixup_fwd(const float* x, const int* perm, const float* lam, 
     hipLaunchKernelGGL(mixup_tail_kernel, dim3(gx, B), dim3(256), 0, s, x, perm, lam, out, n);
   }
   return eat::check_launch("eat_mixup_fwd");
+}
+
+extern "C" int eat_wave_i16_to_f32(const short* src, float* dst, long long n, float scale, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!src || !dst || n < 1) return eat::fail(EAT_EINVAL, "eat_wave_i16_to_f32: bad arguments");
+  if (((size_t)src & 15) || ((size_t)dst & 15)) return eat::fail(EAT_EINVAL, "eat_wave_i16_to_f32: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const long long n8 = n >> 3;
+  if (n8 > 0) {
+    long long blocks = (n8 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(wave_i16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n8, scale);
+  }
+  if (n & 7) hipLaunchKernelGGL(wave_i16_tail_kernel, dim3(1), dim3(256), 0, s, src, dst, n8 << 3, n, scale);
+  return eat::check_launch("eat_wave_i16_to_f32");
 }
 
 extern "C" int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, const float* lam,

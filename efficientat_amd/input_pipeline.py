@@ -18,11 +18,43 @@ copy is the step: a PCIe Gen5 x16 link carries ~40-45 k clips/s of fp32 waveform
     valid UNTIL THE NEXT BATCH IS REQUESTED (clone what must outlive the step);
   * non-tensor entries (file names) pass through untouched.
 
+16-bit transport (`Int16Waveform`, `DevicePrefetcher(transport="int16")`): the waveforms cross PCIe as int16 PCM (0.64 MB per
+clip instead of 1.28) and become fp32 again on the device (`ops.wave_i16_to_f32`, one streaming kernel; `GraphedKDTrainer`
+converts straight into its captured input buffer).  AudioSet's mp3 sources decode to 16-bit PCM, so for un-augmented clips
+the round trip is the quantisation the data already had; after waveform-level augmentation (gain, waveform mix-up) it adds
+2^-16 of full scale - opt-in for that reason.  The conversion to int16 belongs in the DataLoader WORKERS (`Int16Waveform`
+wraps the dataset); the prefetcher converts a float batch itself only as a fallback (one host pass over the batch).
+
 There is no CPU mode: without a GPU it raises, like the rest of the package.
 """
+import numpy as np
 import torch
 
 from ._lib import EatHipError
+
+I16_SCALE = 32767.0
+
+
+def to_int16(wave):
+    """float waveform in [-1, 1] (numpy or torch) -> int16 PCM, round to nearest, clipped."""
+    if torch.is_tensor(wave):
+        return (wave.clamp(-1.0, 1.0) * I16_SCALE).round_().to(torch.int16)
+    return np.rint(np.clip(wave, -1.0, 1.0) * I16_SCALE).astype(np.int16)
+
+
+class Int16Waveform(torch.utils.data.Dataset):
+    """Dataset wrapper: item[0] (the waveform of the reference's `(wave, name, target[, index])` tuples) as int16 PCM,
+    converted in the DataLoader worker that produced the item."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, index):
+        item = self.ds[index]
+        return (to_int16(item[0]),) + tuple(item[1:])
 
 
 class _Slot:
@@ -32,8 +64,10 @@ class _Slot:
         self.copied = torch.cuda.Event()
         self.released = None      # recorded on the consumer's stream when the batch after this one is requested
 
-    def stage(self, batch, device, stream):
+    def stage(self, batch, device, stream, transport="fp32"):
         out = list(batch)
+        if transport == "int16" and torch.is_tensor(batch[0]) and batch[0].is_floating_point():
+            batch = (to_int16(batch[0]),) + tuple(batch[1:])      # fallback: the workers did not convert
         if self.released is not None:
             stream.wait_event(self.released)                      # device buffers of this slot are free again
         for i, item in enumerate(batch):
@@ -62,12 +96,14 @@ class _Slot:
 class DevicePrefetcher:
     """for wave, names, y, idx in DevicePrefetcher(loader, device): ...   (tensors arrive resident in HBM)."""
 
-    def __init__(self, loader, device="cuda", depth=2):
+    def __init__(self, loader, device="cuda", depth=2, transport="fp32"):
         if not torch.cuda.is_available():
             raise EatHipError("DevicePrefetcher needs a GPU: efficientat_amd has no CPU path")
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        self.loader, self.device, self.depth = loader, torch.device(device), depth
+        if transport not in ("fp32", "int16"):
+            raise ValueError("transport must be 'fp32' or 'int16'")
+        self.loader, self.device, self.depth, self.transport = loader, torch.device(device), depth, transport
         self.stream = torch.cuda.Stream(device=self.device)
         # depth batches in flight + the one the consumer holds
         self.slots = [_Slot() for _ in range(depth + 1)]
@@ -91,7 +127,7 @@ class DevicePrefetcher:
                 except StopIteration:
                     return
                 s = free.pop(0)
-                queue.append((s, self.slots[s].stage(batch, self.device, self.stream)))
+                queue.append((s, self.slots[s].stage(batch, self.device, self.stream, self.transport)))
 
         fill()
         while queue:

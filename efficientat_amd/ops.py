@@ -57,12 +57,15 @@ def conv_out(n, k, stride):
     return (n + 2 * p - (k - 1) - 1) // stride + 1
 
 
-def mel_fwd(wave, window, twiddle, band_w2, band_start, band_cnt, n_fft, hop, n_mels, fmask=(0, 0), tmask=(0, 0)):
+def mel_fwd(wave, window, twiddle, band_w2, band_start, band_cnt, n_fft, hop, n_mels, fmask=(0, 0), tmask=(0, 0), out=None):
     B, L = wave.shape
     T = 1 + (L - 1) // hop
     if band_w2.shape[1:] != (n_mels, 2) or band_start.numel() != n_mels or band_cnt.numel() != n_mels:
         raise _lib.EatHipError("mel_fwd: band table must be (pairs, n_mels, 2) with n_mels starts / counts")
-    out = torch.empty((B, n_mels, T), device=wave.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, n_mels, T), device=wave.device, dtype=torch.float32)
+    elif out.numel() != B * n_mels * T or out.dtype != torch.float32 or not out.is_contiguous():
+        raise _lib.EatHipError(f"mel_fwd: out must be a contiguous fp32 buffer of {B} x {n_mels} x {T} elements")
     _lib.call("eat_mel_fwd", _dev(wave, "wave"), B, L, _dev(window, "window"), window.numel(), n_fft, hop,
               _dev(twiddle, "twiddle"), _dev(band_w2, "band_w2"), band_start.data_ptr(), band_cnt.data_ptr(), n_mels,
               band_w2.shape[0], out.data_ptr(), T, fmask[0], fmask[1], tmask[0], tmask[1], _stream())
@@ -1359,6 +1362,18 @@ def mixup_fwd(x, perm, lam):
     B = x.shape[0]
     out = torch.empty_like(x)
     _lib.call("eat_mixup_fwd", _dev(x, "x"), perm.data_ptr(), lam.data_ptr(), out.data_ptr(), B, x.numel() // B, _stream())
+    return out
+
+
+def wave_i16_to_f32(src, out=None, scale=1.0 / 32768.0):
+    """int16 PCM (any shape, contiguous, on the GPU) -> fp32 waveform `src * scale` (f2: 16-bit transport over PCIe)."""
+    if not src.is_cuda or src.dtype != torch.int16 or not src.is_contiguous():
+        raise _lib.EatHipError(f"wave_i16_to_f32: src must be a contiguous int16 GPU tensor (got {src.dtype} on {src.device})")
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    elif out.numel() != src.numel():
+        raise _lib.EatHipError("wave_i16_to_f32: out has a different number of samples")
+    _lib.call("eat_wave_i16_to_f32", src.data_ptr(), _dev(out, "out"), src.numel(), float(scale), _stream())
     return out
 
 

@@ -645,6 +645,11 @@ int eat_calib_copy(const float* src, float* dst, long long n, int mode, eat_stre
  * x, out (B, n) fp32 (n = the flattened per-sample size), perm (B) int32, lam (B) fp32.  out must not alias x. */
 int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n, eat_stream_t stream);
 
+/* 16-bit PCM transport of the waveforms (the reference moves fp32 clips with a blocking x.to(device),
+ * ex_audioset.py:140-141, 303-304 - 1.28 MB per clip, more than PCIe carries at this path's rates): dst[i] = src[i] * scale
+ * for n samples (scale = 1 / 32768 for full-scale PCM).  src int16, dst fp32, both 16-byte aligned. */
+int eat_wave_i16_to_f32(const short* src, float* dst, long long n, float scale, eat_stream_t stream);
+
 /* Loss of the KD training step and its gradient w.r.t. the logits in one pass (ex_audioset.py:149-189):
  *   label = mean_{b,c} BCEwithLogits(z, y*lam + y[perm]*(1-lam))
  *   kd    = mean_b known[b] * ( lam[b] * mean_c BCE(z, t[idx[b]]) + (1-lam[b]) * mean_c BCE(z, t[idx[perm[b]]]) )

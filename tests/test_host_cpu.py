@@ -249,3 +249,63 @@ def test_prepack_plan_builds_the_32_byte_records_the_kernel_reads():
         assert getattr(v, "_eat_split", False) == (int(r["kind"]) == 2)
     with ops.precision("fp32"):
         assert plan.stale()                                    # another arithmetic: the plan must be rebuilt
+
+
+def test_rank_shard_sampler_partitions_the_epoch():
+    """train_dp.RankShardSampler: every rank generates the same epoch list from the base sampler (seed + epoch) and takes
+    its stride - disjoint shards of equal length whose union is the list (what Lightning's DistributedSamplerWrapper does
+    with the reference's WeightedRandomSampler, ex_pl_audioset.py:265-293)."""
+    from torch.utils.data import WeightedRandomSampler
+    from efficientat_amd.train_dp import RankShardSampler
+    w = torch.rand(101, generator=torch.Generator().manual_seed(0)) + 0.01
+    world = 4
+    shards = []
+    for r in range(world):
+        s = RankShardSampler(WeightedRandomSampler(w, num_samples=50, replacement=False), r, world, seed=3)
+        s.set_epoch(2)
+        shards.append(list(s))
+        assert len(shards[-1]) == len(s) == 12
+    one = RankShardSampler(WeightedRandomSampler(w, num_samples=50, replacement=False), 0, 1, seed=3)
+    one.set_epoch(2)
+    full = list(one)
+    inter = [full[i] for i in range(48)]
+    assert [shards[i % world][i // world] for i in range(48)] == inter
+    other = RankShardSampler(WeightedRandomSampler(w, num_samples=50, replacement=False), 0, world, seed=3)
+    other.set_epoch(3)
+    assert list(other) != shards[0]
+
+
+def test_lr_schedule_matches_the_reference_formula():
+    """helpers/utils.py:35-66 (exp warm-up x linear ramp-down), the LambdaLR factor of ex_audioset.py:93-96."""
+    from efficientat_amd.utils import exp_warmup_linear_down
+    f = exp_warmup_linear_down(8, 95, 80, 0.01)
+    def ref(e):
+        up = 1.0 if e >= 8 else float(np.exp(-5.0 * (1.0 - np.clip(e, 0.5, 8) / 8) ** 2))
+        down = 1.0 if e <= 80 else (0.01 if e - 80 >= 95 else 0.01 + 0.99 * (95 - e + 80) / 95)
+        return up * down
+    for e in (0, 1, 7, 8, 50, 80, 81, 120, 174, 175, 199):
+        assert abs(f(e) - ref(e)) < 1e-12
+
+
+def test_band_table_with_fixed_pairs_is_the_same_basis():
+    """preprocess.band_table(pairs=P): the fixed-shape table a captured step takes as an input buffer holds the same
+    non-zeros as the tight one, for the corners and the widest point of the train-mode (fmin, fmax) draw space."""
+    from efficientat_amd.preprocess import AugmentMelSTFT, band_table, kaldi_mel_basis
+    with contextlib.redirect_stdout(io.StringIO()):
+        mel = AugmentMelSTFT(freqm=0, timem=0)
+    P = mel.max_band_pairs()
+    def dense(t):
+        w2, st, cnt = t
+        d = torch.zeros(128, 512)
+        for m in range(128):
+            for j in range(int(cnt[m])):
+                d[m, int(st[m]) + 2 * j: int(st[m]) + 2 * j + 2] = w2[j, m]
+        return d
+    for fmin, fmax in ((0, 15000), (0, 16000), (9, 14001), (0, 15688), (5, 15123)):
+        basis = kaldi_mel_basis(128, 1024, 32000, fmin, fmax)
+        tight, fixed = band_table(basis), band_table(basis, pairs=P)
+        assert fixed[0].shape == (P, 128, 2) and tight[0].shape[0] <= P - 1
+        assert torch.equal(dense(fixed), basis) and torch.equal(dense(tight), basis)
+        assert bool((fixed[1] + 2 * P <= 512).all()) and bool((fixed[1] % 2 == 0).all())
+    with pytest.raises(ValueError):
+        band_table(basis, pairs=3)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 GPU call driver: gpurun --timeout 1200 -- 'bash tools/gpu_r5.sh <tag> <sections...>'
+# Round-6 GPU call driver: gpurun --timeout 1200 -- 'bash tools/gpu_r6.sh <tag> <sections...>'
 set -u
-TAG=${1:-r5a}; shift || true
+TAG=${1:-r6a}; shift || true
 WHAT="${*:-full}"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -80,9 +80,9 @@ if has pmc; then
         python $GRAFT_REPO_ROOT/bench.py $PROF_ARGS > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$name.log) || echo "pmc pass $name failed/timed out"
   done
   F=$(find $OUT/pmc_f -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_w -name "*counter_collection.csv" | head -1)
-  python tools/pmc_traffic.py $F $W $OUT/pmc_traffic_${PMC_TAG:-r5}.json
+  python tools/pmc_traffic.py $F $W $OUT/pmc_traffic_${PMC_TAG:-r6}.json
   S=$(find $OUT/pmc_sq1 -name "*counter_collection.csv" | head -1)
-  python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r5}.json $S > $OUT/pmc_sq_${PMC_TAG:-r5}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r5}.txt
+  python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r6}.json $S > $OUT/pmc_sq_${PMC_TAG:-r6}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r6}.txt
   rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq1
 fi
 if has smoke; then

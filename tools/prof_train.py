@@ -17,14 +17,19 @@ def tstep():
     logits,_=model(mel(wave).unsqueeze(1)); loss=F.binary_cross_entropy_with_logits(logits,y); loss.backward(); opt.step()
 for _ in range(2): tstep()
 torch.cuda.synchronize()
-real=_lib.call; rec=[]
+real=_lib.call; real_rc=_lib.call_rc; rec=[]
 def traced(name,*a):
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
     e0.record(); real(name,*a); e1.record(); rec.append((name,a,e0,e1))
-_lib.call=traced
+def traced_rc(name,*a):
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record(); rc=real_rc(name,*a); e1.record()
+    if rc==0: rec.append((name,a,e0,e1))
+    return rc
+_lib.call=traced; _lib.call_rc=traced_rc
 import time
 t0=time.perf_counter(); tstep(); torch.cuda.synchronize(); wall=time.perf_counter()-t0
-_lib.call=real
+_lib.call=real; _lib.call_rc=real_rc
 agg=collections.defaultdict(lambda:[0,0.0])
 for n,a,e0,e1 in rec:
     agg[n][0]+=1; agg[n][1]+=e0.elapsed_time(e1)
