@@ -35,6 +35,8 @@ import subprocess
 import sys
 import time
 
+import numpy as np
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -654,6 +656,111 @@ def cpu_baseline(budget_s=7.0, batch=32):
                       f"{trn_n} passes (~{budget_s:.0f} s each); value = the training step (mel + fwd + BCE + bwd + Adam), the bench workload"}
 
 
+def cpu_baseline_reference(ref_root, budget_s=7.0, batch=32):
+    """The REFERENCE'S OWN modules (models/preprocess.py AugmentMelSTFT, models/mn/model.py get_model) timed on this host's
+    cores - `kind: "reference"` - when a reference checkout is staged at EAT_REFERENCE_ROOT (it does not exist on the
+    driver's GPU box: `cpu_baseline()` then times the oracle port).  Imported in a CHILD process with the torchaudio /
+    torchvision stand-ins of oracle/ref_shims on its path (the reference's third-party imports are not installed here), so
+    nothing of the reference enters this process.  Same legs and budget as the port."""
+    code = r"""
+import contextlib, io, json, os, sys, time
+import torch, torch.nn.functional as F
+ref, shims, batch, budget = sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
+sys.path[:0] = [shims, ref]
+os.chdir(ref)
+with contextlib.redirect_stdout(io.StringIO()):
+    from models.preprocess import AugmentMelSTFT
+    from models.mn.model import get_model
+    mel = AugmentMelSTFT(freqm=0, timem=0)
+    model = get_model(width_mult=1.0)
+g = torch.Generator().manual_seed(1234)
+x = (0.1 * torch.randn(batch, 320000, generator=g)).clamp_(-1, 1)
+y = (torch.rand(batch, 527, generator=g) < 2.7 / 527).float()
+opt = torch.optim.Adam(model.parameters(), lr=8e-4)
+def mel_leg():
+    mel.eval()
+    with torch.no_grad():
+        return mel(x)
+m = mel_leg().unsqueeze(1)
+def fwd_leg():
+    model.eval()
+    with torch.no_grad():
+        model(m)
+def train_leg():
+    model.train(); mel.train()
+    opt.zero_grad(set_to_none=True)
+    logits, _ = model(mel(x).unsqueeze(1))
+    F.binary_cross_entropy_with_logits(logits, y).backward()
+    opt.step()
+def rate(fn, max_iters=50, min_iters=3):
+    fn()
+    t0 = time.perf_counter(); n = 0
+    while True:
+        fn(); n += 1
+        dt = time.perf_counter() - t0
+        if (dt > budget and n >= min_iters) or n >= max_iters:
+            return batch * n / dt, n
+r = [rate(mel_leg), rate(fwd_leg), rate(train_leg)]
+print("REFCPU " + json.dumps({"mel": r[0], "fwd": r[1], "train": r[2], "threads": torch.get_num_threads()}))
+"""
+    shims = os.path.join(ROOT, "oracle", "ref_shims")
+    r = subprocess.run([sys.executable, "-c", code, ref_root, shims, str(batch), str(budget_s)], capture_output=True, text=True,
+                       timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("REFCPU ")]
+    if r.returncode != 0 or not line:
+        raise RuntimeError(f"reference CPU baseline failed: {r.stderr[-800:]}")
+    d = json.loads(line[0][7:])
+    (mel_r, mel_n), (fwd_r, fwd_n), (trn_r, trn_n) = d["mel"], d["fwd"], d["train"]
+    both = 1.0 / (1.0 / mel_r + 1.0 / fwd_r)
+    return {"value": round(trn_r, 2), "unit": "clips/s", "cores": d["threads"], "kind": "reference",
+            "mel_clips_s": round(mel_r, 2), "fwd_clips_s": round(fwd_r, 2), "mel_plus_fwd_clips_s": round(both, 2),
+            "train_step_clips_s": round(trn_r, 2),
+            "sample": f"the reference's own models/preprocess.py + models/mn/model.py (staged at EAT_REFERENCE_ROOT, torchaudio / "
+                      f"torchvision stand-ins of oracle/ref_shims), batch {batch}, fp32, torch CPU with {d['threads']} threads: mel {mel_n} / "
+                      f"mn10 fwd {fwd_n} / train step {trn_n} passes (~{budget_s:.0f} s each); value = the training step (mel + fwd + "
+                      "BCE + bwd + Adam), the bench workload"}
+
+
+def parity_grad_probe(dev):
+    """Gradient parity of the training step against torch-CPU autograd over the oracle (5 structured clips x 2 s, calibrated
+    synthetic weights, Dropout replaced by its expectation on both sides), for the step's default arithmetic ("auto") and
+    for exact fp32: per-tensor relative L2 error - median, maximum, and the number of tensors above SURVEY 8(c)'s 1e-2."""
+    import torch.nn.functional as F
+    from oracle import eat_oracle as O
+    from oracle import synth
+    from efficientat_amd.mn import get_model
+    wave = synth.parity_clips(64000, seed=3)
+    x_ref = O.mel_forward(wave).unsqueeze(1)
+    sd = synth.calibrate(synth.synth_state(synth.mn_shapes(1.0), seed=0), O.mn_forward, x_ref)
+    y = (torch.rand(wave.shape[0], 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
+    keep = torch.ones(wave.shape[0], 1280) * 0.8
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    logits_ref, _ = O.mn_forward(sdr, x_ref, train=True, stats={}, drop_mask=keep)
+    F.binary_cross_entropy_with_logits(logits_ref, y).backward()
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+    out = {"vs": "torch-CPU autograd over the oracle, 5 clips x 2 s, same weights; tensors with |grad| < 1e-4 of the largest "
+                 "skipped (project-BatchNorm biases: true gradient 0)"}
+    for mode in ("auto", "fp32"):
+        model = quiet(get_model, width_mult=1.0)
+        model.load_state_dict(sd)
+        model.to(dev).train()
+        model.train_precision = mode
+        model._drop_mask_override = keep.to(dev)
+        logits, _ = model(x_ref.to(dev))
+        F.binary_cross_entropy_with_logits(logits, y.to(dev)).backward()
+        rels = []
+        for name, p in model.named_parameters():
+            rg = sdr[name].grad
+            if float(rg.norm()) >= 1e-4 * gmax:
+                rels.append(float((p.grad.cpu().double() - rg.double()).norm() / rg.double().norm()))
+        rels.sort()
+        out[mode] = {"grad_rel_l2_median": float(f"{rels[len(rels) // 2]:.3e}"), "grad_rel_l2_max": float(f"{rels[-1]:.3e}"),
+                     "n_above_1e-2": sum(r > 1e-2 for r in rels), "tensors": len(rels),
+                     "train_logit_max_abs_err": float(f"{float((logits.detach().cpu() - logits_ref.detach()).abs().max()):.3e}")}
+        del model
+    return out
+
+
 def parity_probe(mel, model, dev):
     """logit max-abs-err of the HIP path vs the CPU oracle on 4 synthetic clips (same weights)."""
     from oracle import eat_oracle as O
@@ -817,12 +924,108 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
                       "parameters / optimizer" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
            "roofline_e2e_frac": round(cps / ranks.world * alg / HBM_PEAK, 4) if alg else None,
            "alg_bytes_per_clip": alg}
+    red = getattr(model, "_grad_reducer", None) or getattr(model, "_grad_hooks_reducer", None)
+    if red is not None and red.last_stats:
+        res["reducer"] = dict(red.last_stats)
     mel.eval()
     del model, opt
     if graphed:
         del gstep
     torch.cuda.empty_cache()
     return res
+
+
+def kd_bench(args, mel_unused, wave, ranks, steps=12, warmup=3):
+    """BASELINE configs[4], per-GPU shard: the reference's KD iteration (ex_audioset.py:139-199: log-mel with fmin / fmax
+    jitter -> mixup -> forward -> BCE + KD loss against gathered teacher rows -> backward -> [RCCL all-reduce] -> Adam) on
+    `train_loop.GraphedKDTrainer` / `KDTrainer`, B clips per GPU: (a) the captured step on a device-resident batch, (b) the
+    same fed from pinned host memory through DevicePrefetcher (fp32 and 16-bit transport), (c) the eager trainer."""
+    from efficientat_amd.dp import enable_data_parallel
+    from efficientat_amd.input_pipeline import DevicePrefetcher, to_int16
+    from efficientat_amd.preprocess import AugmentMelSTFT
+    from efficientat_amd.train_loop import GraphedKDTrainer, KDTrainer
+    dev = ranks.dev
+    B, L = wave.shape
+    g = torch.Generator().manual_seed(7)
+    teacher = torch.randn(4096, 527, generator=g) * 2 - 5
+    f2i = {"syn%07d" % i: i % 4096 for i in range(0, 8192, 2)}          # half of the files have a teacher row
+    names = ["syn%07d" % i for i in range(B)]
+    y = (torch.rand((B, 527), generator=g) < 2.7 / 527).float()
+    out = {"workload": f"mn10_as KD training iteration of ex_audioset.py:139-199 (train-mode log-mel with fmin / fmax jitter, "
+                       f"mixup alpha 0.3, BCE + KD loss lambda 0.1 against a 4096-row teacher table, backward, "
+                       + ("bucketed RCCL all-reduce, " if ranks.dist is not None else "") + f"fused Adam), batch {B} per GPU "
+                       "[BASELINE.json configs[4], per-GPU shard]", "batch_per_gpu": B, "n_gpus": ranks.world, "steps": steps}
+
+    def make(graphed):
+        model = make_train_model("mn10", dev)
+        if ranks.dist is not None:
+            enable_data_parallel(model, force_buckets=ranks.world == 1)
+        model.train()
+        mel = quiet(AugmentMelSTFT, freqm=0, timem=0).to(dev).train()
+        opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=graphed, fused=True)
+        kw = dict(teacher_preds=teacher, fname_to_index=f2i, kd_lambda=0.1, mixup_alpha=0.3)
+        return (GraphedKDTrainer(model, mel, opt, B, L, **kw) if graphed else KDTrainer(model, mel, opt, **kw))
+
+    def timed(run, n):
+        for _ in range(warmup):
+            run()
+        el = ranks.timed(run, n)
+        return round(ranks.world * B * n / el, 1), round(el / n * 1e3, 3)
+
+    yd = y.to(dev)
+    xd = wave.view(B, 1, L)
+    torch.manual_seed(1234 + int(os.environ.get("RANK", 0)))
+    np.random.seed(1234 + int(os.environ.get("RANK", 0)))
+    tr = make(True)
+    v, ms = timed(lambda: tr.step(xd, names, yd), steps)
+    out["graphed"] = {"value": v, "unit": "clips/s", "ms_per_step": ms,
+                      "launch": "one hipGraph replay per step (mel + mixup + forward + KD loss + backward + "
+                                + ("all-reduce + " if ranks.dist is not None else "") + "Adam); batch resident in HBM"}
+    # fed from pinned host memory: 3 page-locked batches cycled through the prefetcher (copy stream, depth 2)
+    for transport in ("fp32", "int16"):
+        host = []
+        for i in range(3):
+            hw = wave.cpu().view(B, 1, L).roll(i, 0)
+            hw = to_int16(hw) if transport == "int16" else hw
+            host.append((hw.pin_memory(), names, y.pin_memory()))
+        n_feed = steps + warmup
+
+        class _Cycle:
+            def __len__(self):
+                return n_feed
+
+            def __iter__(self):
+                return (host[i % 3] for i in range(n_feed))
+
+        def fed():
+            it = iter(DevicePrefetcher(_Cycle(), dev, depth=2))
+            for _ in range(warmup):
+                tr.step(*next(it))
+            ranks.barrier()
+            t0 = time.perf_counter()
+            n = 0
+            for b in it:
+                tr.step(*b)
+                n += 1
+            ranks.barrier()
+            return n, time.perf_counter() - t0
+        n, el = fed()
+        out[f"graphed_fed_{transport}"] = {"value": round(ranks.world * B * n / el, 1), "unit": "clips/s",
+                                           "ms_per_step": round(el / n * 1e3, 3),
+                                           "h2d_bytes_per_step": int(host[0][0].numel() * host[0][0].element_size() + y.numel() * 4),
+                                           "launch": "hipGraph replay; batches from pinned host memory through DevicePrefetcher "
+                                                     f"(copy stream, depth 2), waveforms as {transport}"}
+        del host
+    out["final_loss"] = round(float(tr.loss), 5)
+    del tr
+    torch.cuda.empty_cache()
+    tr = make(False)
+    v, ms = timed(lambda: tr.step(xd, names, yd), max(4, steps // 2))
+    out["eager"] = {"value": v, "unit": "clips/s", "ms_per_step": ms,
+                    "launch": "eager KDTrainer.step (~450 launches from one host thread); batch resident in HBM"}
+    del tr
+    torch.cuda.empty_cache()
+    return out
 
 
 # ----------------------------------------------------------------------------- launch plumbing
@@ -861,6 +1064,7 @@ def parse_args(argv=None):
     ap.add_argument("--train-model", default=None, choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20"],
                     help="only this train-step network (debug)")
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the exact-fp32 forward measurement")
+    ap.add_argument("--no-kd", action="store_true", help="skip the KD training iteration (configs[4] per-GPU shard) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event profile to stderr")
     ap.add_argument("--calibrate-traffic", action="store_true",
@@ -1007,6 +1211,13 @@ def main():
             result["train_step_fp32_exact"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
 
+    if not args.no_kd and args.train_model is None:
+        try:
+            result["kd_train_step"] = kd_bench(args, mel, wave, ranks)
+        except Exception as e:  # pragma: no cover - one failing leg must not lose the line
+            result["kd_train_step"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+
     if world == 1 and not args.no_train_configs and args.train_model is None:
         for key, name, bt, st, wu in [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2)]:
             try:
@@ -1096,11 +1307,33 @@ def main():
                 for k, v in sorted(fprof.items(), key=lambda kv: -kv[1]["total_ms"]):
                     print(f"[bench] {k:28s} launches {v['launches']:3d}  {v['total_ms']:8.3f} ms  "
                           f"{v['bytes'] / 1e9:7.3f} GB  {v['gbps']:8.1f} GB/s", file=sys.stderr)
+    if dist is not None:
+        # what a SCALE record needs to prove RCCL saw N ranks: the process group as the library reports it + the step's buckets
+        red = head.get("reducer") or {}
+        nv = None
+        try:
+            nv = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # pragma: no cover
+            pass
+        result["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": nv,
+                          "buckets": red.get("buckets"), "bytes_per_step": red.get("bytes"),
+                          "bucket_bytes": red.get("bucket_bytes"), "forced_single_rank": bool(force_dist and world == 1)}
     if rank == 0:
         err, scale = parity_probe(mel, model, dev)
         result["parity"] = {"logit_max_abs_err": err, "logit_abs_max": scale, "vs": "CPU oracle, 4 clips, same weights (eval forward)"}
+        try:
+            result["parity"]["train_grads"] = parity_grad_probe(dev)
+        except Exception as e:  # pragma: no cover
+            result["parity"]["train_grads"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+            ref_root = os.environ.get("EAT_REFERENCE_ROOT")
+            if ref_root and os.path.isfile(os.path.join(ref_root, "models", "mn", "model.py")):
+                try:
+                    result["cpu_baseline"] = cpu_baseline_reference(ref_root)
+                except Exception as e:  # pragma: no cover - fall back to the port, say why
+                    print(f"[bench] {e}; timing the oracle port instead", file=sys.stderr)
+            if "cpu_baseline" not in result:
+                result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()

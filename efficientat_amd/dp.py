@@ -31,6 +31,7 @@ class GradReducer:
         with a single rank (exercises the bucket path on one GPU; tests and EAT_BENCH_FORCE_DIST)."""
         self.group = process_group
         self.bucket_bytes = bucket_bytes
+        self.last_stats = None      # {"buckets", "bytes", "bucket_bytes"} of the last finished pass (bench.py's `rccl` object)
         self.world = 1 if local or not dist.is_initialized() else dist.get_world_size(process_group)
         self.bucketed = (self.world > 1 or force_buckets) and not local
         # gloo (CPU tests) has no AVG: SUM + one scale there
@@ -114,14 +115,27 @@ class GradReducer:
         self.inflight.append((work, flat, meta))
         self.cur, self.cur_bytes = [], 0
 
+    def begin_pass(self):
+        """Drop whatever an ABORTED pass left behind (an exception inside the backward, e.g. an out-of-memory error the
+        training loop catches and skips): without this its slots / in-flight works would leak into the next pass and
+        `finish()` would raise "never pushed" on every later step.  Called at the start of every backward."""
+        if self.slots or self.cur or self.inflight or self.out:
+            for work, _, _ in self.inflight:
+                work.wait()
+            self._reset()
+
     def finish(self):
         """-> {name: averaged gradient}; blocks the compute stream (not the host) on the collectives."""
         if self.gbuf is not None:
             if any(not s[4] for s in self.slots[self.done:]):
                 missing = [s[0] for s in self.slots if not s[4]]
+                self._reset()                                 # (the reducer stays usable: the next pass starts clean)
                 raise RuntimeError(f"GradReducer: gradient memory was handed out but never pushed: {missing[:4]}")
             self._flush_flat(force=True)
         self._flush()
+        if self.bucketed:
+            self.last_stats = {"buckets": len(self.inflight), "bytes": int(sum(f.numel() * f.element_size() for _, f, _ in self.inflight)),
+                               "bucket_bytes": self.bucket_bytes}
         inv = 1.0 / self.world
         for work, flat, meta in self.inflight:
             work.wait()

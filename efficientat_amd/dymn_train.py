@@ -174,8 +174,6 @@ class StemConv(torch.autograd.Function):
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
         dw = ops.dw_conv_wgrad(dz.contiguous(), x, 3, 2).view_as(w)
-        # the stem is the last node of DyMN's backward: the step's zero arena (forward_train: begin) is done
-        ops.zero_arena.end("dymn_step")
         return None, dw
 
 
@@ -732,7 +730,17 @@ def forward_train(model, x, return_fmaps=False):
                                "selects the per-layer Functions, which have no such restriction.")
     ops.zero_arena.begin("dymn_step")          # one zero-filled arena per step (forward + the backward autograd runs later)
     with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters:
-        return _forward_train(model, x, return_fmaps)
+        out = _forward_train(model, x, return_fmaps)
+    if out[0].requires_grad:
+        # the arena closes when THIS backward pass is over, whichever node runs last (a frozen stem never runs its backward;
+        # ADVICE r5): the first gradient to arrive queues an engine callback, which fires after the last node of the pass
+        def _arm(grad):
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: ops.zero_arena.end("dymn_step"))
+            return grad
+        out[0].register_hook(_arm)
+    else:
+        ops.zero_arena.end("dymn_step")
+    return out
 
 
 def _forward_train(model, x, return_fmaps):

@@ -107,6 +107,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = self._eager(zero=False)
+        from . import ops
+        ops.zero_arena.end("dymn_step")      # (a step arena left open by an unfinished pass must not serve later callers)
 
     def _eager(self, zero=True):
         if zero:

@@ -74,6 +74,19 @@ class _Slot:
             if not torch.is_tensor(item):
                 continue
             item = item.contiguous()
+            if item.is_pinned():
+                # already page-locked (DataLoader(pin_memory=True), a pinned ring of the caller): no staging memcpy - the
+                # slot keeps the tensor alive until its H2D has completed (`copied` is waited on before the slot is reused)
+                dv = self.device.get(i)
+                if dv is None or dv.shape != item.shape or dv.dtype != item.dtype:
+                    with torch.cuda.stream(stream):
+                        self.device[i] = torch.empty(item.shape, dtype=item.dtype, device=device)
+                self.copied.synchronize()
+                self.pinned[i] = item
+                with torch.cuda.stream(stream):
+                    self.device[i].copy_(item, non_blocking=True)
+                out[i] = self.device[i]
+                continue
             pin = self.pinned.get(i)
             if pin is None or pin.shape != item.shape or pin.dtype != item.dtype:
                 pin = torch.empty(item.shape, dtype=item.dtype, pin_memory=True)

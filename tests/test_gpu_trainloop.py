@@ -184,9 +184,9 @@ def test_device_prefetcher_delivers_the_loader_batches_in_order():
 
 # ------------------------------------------------------------------------------------------------ configs[4]: the captured KD step
 def _kd_setup(seed=3, width=0.5):
+    torch.manual_seed(seed)                      # (before the constructor: the Linear layers keep their default init)
     with contextlib.redirect_stdout(io.StringIO()):
         m = get_model(width_mult=width)
-    torch.manual_seed(seed)
     with torch.no_grad():
         for mod in m.modules():
             if isinstance(mod, nn.Conv2d):
