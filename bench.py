@@ -1109,11 +1109,22 @@ def main():
         if dist is not None:
             dist.init_process_group("gloo")
         ranks = Ranks(dist, world, dev)
-        el = ranks.timed(lambda: time.sleep(0.001 * (rank + 1)), args.steps)
+        probe = torch.ones(1024)
+
+        def dry_step():                      # the rank plumbing of a step: something to time + one collective per step
+            time.sleep(0.001 * (rank + 1))
+            if dist is not None:
+                dist.all_reduce(probe)
+                probe.fill_(1.0)
+        el = ranks.timed(dry_step, args.steps)
         if rank == 0:
-            print(json.dumps({"metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": 0.0, "unit": "clips/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
-                              "dry_run": True}), file=json_out, flush=True)
+            line = {"metric": "clips/sec (10 s @ 32 kHz) mn10_as", "value": round(world * args.batch * args.steps / el, 1),
+                    "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": round(el / args.steps * 1e3, 4), "dry_run": True}
+            if dist is not None:
+                line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": None,
+                                "buckets": 1, "bytes_per_step": 4096, "bucket_bytes": None, "forced_single_rank": False}
+            print(json.dumps(line), file=json_out, flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

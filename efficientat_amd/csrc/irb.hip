@@ -37,11 +37,6 @@ constexpr int kWaves = 4;       // waves per block (they share the LDS weights o
 struct IrbArgs {
   const float *x, *wpe, *bias_e, *wd, *bias_d, *wpp, *bias_p, *res;
   float *y, *pool;
-  // TRAIN (train-mode forward of expand + depthwise, csrc/irb.hip bottom): scale_e / bias_e = the expand BatchNorm's (a, b)
-  // from the Gram statistics, ze = optional store of the raw expand output, part = [B][2][Cexp][part_inner] partial sums
-  const float* scale_e;
-  float *ze, *part;
-  int part_inner;
   int B, Cin, Cexp, Cout, F, T, Fo, To;
   int Fm, Tm;                             // FRONT: log-mel plane (F, T are the stem plane)
   int MT;                                 // 16-channel chunks of the expanded tensor
@@ -125,18 +120,9 @@ __device__ __forceinline__ void dw_finish(const DwAcc<NT>& a, f32x4 (&d)[NT]) {
 //   log-mel (lane (k, n): tap 4 ks + k of stem column n, zero outside the image through the buffer range check); the
 //   residual (= the stem output) is the middle row of the register window, in the accumulator layout already.
 //   F, T (a.F, a.T) are then the STEM plane, a.Fm / a.Tm the log-mel plane; ACT_E = Hardswish.
-// TRAIN: the training forward (BatchNorm in batch-statistics mode; mn_train.py).  The expand BatchNorm's (a, b) are known
-//   BEFORE the conv runs (they come from the Gram matrix of the block input), so the expanded tensor is activated in
-//   registers exactly as in eval - e = act(a (W x) + b) with a, b per channel from LDS - and never has to be read back; the
-//   depthwise output leaves RAW (its BatchNorm needs the batch statistics first) together with per-wave partial sums of z and
-//   z^2 (fixed slots, plain stores: reproducible).  The raw expand output W x is stored for the backward pass when a.ze is
-//   set: every (row, column) by exactly one wave - rows of the march (the window-priming rows only in the first row range),
-//   columns of the strip's VO core lanes.
-template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false,
-          bool TRAIN = false>
-__global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
+template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false>
+__global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
   static_assert(!FRONT || (K == 3 && S == 1 && NKS == 3 && MTI == 1 && PROJ), "front = stem + 3x3/s1 block with project");
-  static_assert(!TRAIN || (!PROJ && !FRONT), "train mode = expand + depthwise");
   constexpr int kNT = NT;
   constexpr int P_ = (K - 1) / 2, KK = K * K;
   constexpr int KW = K - S;                 // expanded rows kept between output rows
@@ -152,7 +138,6 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
   float* Bd = Be + MT * 16;                  // [MT*16]             depthwise bias
   float* Ap = Bd + MT * 16;                  // [MT*4][MTO][64]     project A fragments, k order {16c + 4k + r}
   float* Bp = Ap + (PROJ ? MT * 4 * MTO * 64 : 0);   // [MTO*16]
-  float* Se = Bp + (PROJ ? MTO * 16 : 0);            // [MT*16]             TRAIN: expand BatchNorm scale
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
   // the wave index is wave-uniform, but only readfirstlane tells the compiler: with it the work-item geometry (sample,
   // strip, rows), every row address and every loop / image-border branch live in SGPRs
@@ -175,11 +160,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
   }
   for (int i = tid; i < MT * 16; i += 64 * kWaves) {
     Be[i] = i < Cexp ? a.bias_e[i] : 0.0f;
-    if constexpr (TRAIN) {
-      Se[i] = i < Cexp ? a.scale_e[i] : 0.0f;
-    } else {
-      Bd[i] = i < Cexp ? a.bias_d[i] : 0.0f;
-    }
+    Bd[i] = i < Cexp ? a.bias_d[i] : 0.0f;
   }
   if constexpr (PROJ) {
     for (int i = tid; i < MT * 4 * MTO * 64; i += 64 * kWaves) {
@@ -221,20 +202,6 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
       lb[h * kNT + t] = 4u * (unsigned)(kq * plane + (ci < 0 ? 0 : (ci >= T ? T - 1 : ci)));
     }
   }
-  unsigned zb[TRAIN ? TI : 1];               // TRAIN: byte offset of (channel 4 kq, input column) in z_e, kOOB where this lane
-  if constexpr (TRAIN) {                     //        does not own the column (halo lanes, columns outside the image)
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) {
-      const int u = 16 * t + n;
-      const int oc = o0 + u - ULO;
-      const bool core = u >= ULO && u <= UHI;
-#pragma unroll
-      for (int h = 0; h < S; ++h) {
-        const int ci = S * oc - h;
-        zb[h * kNT + t] = (a.ze && core && ci >= 0 && ci < T) ? 4u * (unsigned)(kq * 4 * plane + ci) : kOOB;
-      }
-    }
-  }
   unsigned fv[FRONT ? NKS : 1][TI];          // FRONT: byte offset of tap 4 ks + kq (row di, column 2 st - 1 + dj) or kOOB
   int fdi[FRONT ? NKS : 1];
   if constexpr (FRONT) {
@@ -254,8 +221,6 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
                                            : make_rsrc(a.x + (size_t)b * a.Cin * plane, 4u * (unsigned)(a.Cin * plane));
   const __amdgpu_buffer_rsrc_t yr_ = make_rsrc(a.y + (size_t)b * Cy * plane_o, 4u * (unsigned)(Cy * plane_o));
   const __amdgpu_buffer_rsrc_t rr_ = make_rsrc(a.res ? a.res + (size_t)b * Cy * plane_o : a.y, a.res ? 4u * (unsigned)(Cy * plane_o) : 0u);
-  const __amdgpu_buffer_rsrc_t zr_ = (TRAIN && a.ze) ? make_rsrc(a.ze + (size_t)b * Cexp * plane, 4u * (unsigned)(Cexp * plane))
-                                                     : make_rsrc(a.y, 0u);
 
   float xb[S][NKS][TI];                      // B operands of the S new input rows of this output row
   float xn[PF ? S : 1][PF ? NKS : 1][PF ? TI : 1];   // ... and of the next output row (PF)
@@ -297,8 +262,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
   };
   auto load_rows = [&](int i) { load_into(i, xb); };
   // expanded row of chunk c from B operands xr; fi = its input row (wave-uniform)
-  // (TRAIN: `keep` = this wave owns row fi of z_e - a row of its own march, or a priming row of the first row range)
-  auto expand = [&](int c, const float (&xr)[NKS][TI], int fi, f32x4 (&e)[TI], bool keep = false) {
+  auto expand = [&](int c, const float (&xr)[NKS][TI], int fi, f32x4 (&e)[TI]) {
     if (fi < 0 || fi >= F) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) e[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -306,34 +270,17 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
     }
     const f32x4 be = *reinterpret_cast<const f32x4*>(Be + c * 16 + kq * 4);
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) e[ti] = TRAIN ? f32x4{0.f, 0.f, 0.f, 0.f} : be;
+    for (int ti = 0; ti < TI; ++ti) e[ti] = be;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const float av = As[(ks * MT + c) * 64 + lane];
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) e[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xr[ks][ti], e[ti], 0, 0, 0);
     }
-    if constexpr (TRAIN) {
-      if (keep) {                                      // wave-uniform; a lane past Cexp (multiples of 8: all 4 of its channels) stores nothing
-        const bool ch_ok = c * 16 + kq * 4 < Cexp;
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-          const unsigned vo = ch_ok ? zb[ti] : kOOB;
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) buf_store(e[ti][r], zr_, vo, 4u * (unsigned)((c * 16 + r) * plane + fi * T));
-        }
-      }
-      const f32x4 se = *reinterpret_cast<const f32x4*>(Se + c * 16 + kq * 4);
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[ti][r] = eat::activate<ACT_E>(fmaf(e[ti][r], se[r], be[r])) * cmask[ti];
-    } else {
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[ti][r] = eat::activate<ACT_E>(e[ti][r]) * cmask[ti];
-    }
+      for (int r = 0; r < 4; ++r) e[ti][r] = eat::activate<ACT_E>(e[ti][r]) * cmask[ti];
   };
 
   const int n_groups = (MT + MTI - 1) / MTI;  // PROJ: 1 (all chunks marched together); otherwise MTI chunks per march
@@ -341,14 +288,10 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
     const int c0 = g * MTI;
     f32x4 win[MTI][KW][TI];
     float psum[MTI][4];
-    float psq[TRAIN ? MTI : 1][4];
 #pragma unroll
     for (int c = 0; c < MTI; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        psum[c][r] = 0.0f;
-        if constexpr (TRAIN) psq[c][r] = 0.0f;
-      }
+      for (int r = 0; r < 4; ++r) psum[c][r] = 0.0f;
 
     // ---- prime the window: input rows S i0 - P + w, w < KW (loaded through the same S-row loader)
     {
@@ -366,7 +309,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
           if (w >= 0) {
             const int fi = S * iq - P_ + KW + j;
 #pragma unroll
-            for (int c = 0; c < MTI; ++c) expand(c0 + c < MT ? c0 + c : MT - 1, xb[j], fi, win[c][w], i0 == 0 && c0 + c < MT);
+            for (int c = 0; c < MTI; ++c) expand(c0 + c < MT ? c0 + c : MT - 1, xb[j], fi, win[c][w]);
           }
         }
       }
@@ -408,12 +351,12 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
         asm volatile("" ::: "memory");
         f32x4 enew[S][TI];
 #pragma unroll
-        for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j], c_ok);
+        for (int j = 0; j < S; ++j) expand(cg, xb[j], S * i - P_ + KW + j, enew[j]);
         if constexpr (!PF) {
           if (c == MTI - 1 && i + 1 < i1) load_rows(i + 1);   // the B operands are free: next row's loads fly from here
         }
         // depthwise row: K input rows = the window (KW) + the new rows (S)
-        const f32x4 bd = TRAIN ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(Bd + cg * 16 + kq * 4);
+        const f32x4 bd = *reinterpret_cast<const f32x4*>(Bd + cg * 16 + kq * 4);
         DwAcc<NT> da;
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
@@ -432,12 +375,10 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
         }
         f32x4 d[kNT];
         dw_finish<K, S, NT>(da, d);
-        if constexpr (!TRAIN) {
 #pragma unroll
-          for (int t = 0; t < kNT; ++t)
+        for (int t = 0; t < kNT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[t][r] = eat::activate<ACT>(d[t][r]);
-        }
+          for (int r = 0; r < 4; ++r) d[t][r] = eat::activate<ACT>(d[t][r]);
         if constexpr (PROJ) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -455,9 +396,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               buf_store(d[t][r], yr_, vo, 4u * (unsigned)((cg * 16 + r) * plane_o + i * To));
-              const float dv = ok ? d[t][r] : 0.0f;
-              psum[c][r] += dv;
-              if constexpr (TRAIN) psq[c][r] = fmaf(dv, dv, psq[c][r]);
+              psum[c][r] += ok ? d[t][r] : 0.0f;
             }
           }
         }
@@ -495,24 +434,7 @@ __global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && !TRAIN) ?
         }
       }
     }
-    if constexpr (TRAIN) {                   // statistics of the raw depthwise output: slot `rem` of [b][2][Cexp][inner]
-#pragma unroll
-      for (int c = 0; c < MTI; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s1 = psum[c][r], s2 = psq[c][r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-          }
-          const int ch = (c0 + c) * 16 + kq * 4 + r;
-          if (n == 0 && c0 + c < MT && ch < Cexp) {
-            a.part[((size_t)(b * 2 + 0) * Cexp + ch) * a.part_inner + rem] = s1;
-            a.part[((size_t)(b * 2 + 1) * Cexp + ch) * a.part_inner + rem] = s2;
-          }
-        }
-    } else if constexpr (!PROJ) {
+    if constexpr (!PROJ) {
       if (a.pool) {                          // SE squeeze: plane sums of this strip's rows, one atomic per channel
 #pragma unroll
         for (int c = 0; c < MTI; ++c)
@@ -553,49 +475,6 @@ int launch_irb(IrbArgs a, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((items + kWaves - 1) / kWaves)), dim3(64 * kWaves), smem, s, a);
   return eat::check_launch("irb_kernel");
-}
-
-// Training forward (TRAIN instantiations: one column tile per wave, all chunks marched together - the input is read once).
-// The z_e store needs an owner for EVERY input column: with stride 2 the odd column T - 1 belongs to output column T / 2,
-// which may lie one past To - the strips then cover one more column.
-template <int K, int S, int NKS, int MTI>
-int launch_irb_train(IrbArgs a, hipStream_t s, bool dry, int* inner_out) {
-  constexpr int NT = 1;
-  constexpr int ULO = (K == 3 && S == 2) ? 0 : 1, UHI = 16 * NT - 2, VO = UHI - ULO + 1;
-  a.MT = (a.Cexp + 15) / 16;              // (marched in groups of MTI chunks; a partial last group re-does the last chunk, masked)
-  int n_oc = a.To;
-  if (S == 2 && a.T / 2 + 1 > n_oc && (a.T & 1) == 0) n_oc = a.T / 2 + 1;
-  a.n_strips = (n_oc + VO - 1) / VO;
-  constexpr int target = 6144;
-  const long long strips = (long long)a.B * a.n_strips;
-  int parts = (int)((target + strips - 1) / strips);
-  const int max_parts = a.Fo / 8 > 1 ? a.Fo / 8 : 1;
-  parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
-  a.rows_per_part = (a.Fo + parts - 1) / parts;
-  a.n_parts = (a.Fo + a.rows_per_part - 1) / a.rows_per_part;
-  const long long items = strips * a.n_parts;
-  if (items > 0x7fffffffLL) return 1;
-  a.n_items = (int)items;
-  if (inner_out) *inner_out = a.n_strips * a.n_parts;
-  if (dry) return 0;
-  if (a.part_inner < a.n_strips * a.n_parts)
-    return eat::fail(EAT_EINVAL, "eat_expand_dw_train_fwd: %d partial slots per plane, the launch writes %d", a.part_inner,
-                     a.n_strips * a.n_parts);
-  a.part_inner = a.n_strips * a.n_parts;
-  const size_t smem = sizeof(float) * ((size_t)NKS * a.MT * 64 + (size_t)a.MT * K * K * 16 + 3 * (size_t)a.MT * 16);
-  auto kern = irb_kernel<K, S, NKS, NT, MTI, 1, EAT_ACT_RELU, false, false, EAT_ACT_RELU, false, true>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((items + kWaves - 1) / kWaves)), dim3(64 * kWaves), smem, s, a);
-  return eat::check_launch("irb_kernel (train)");
-}
-
-// shape -> TRAIN instantiation; 1 = none (the caller runs eat_pw_conv_fwd + eat_dw_conv_fwd_stats)
-int irb_train_dispatch(IrbArgs a, int k, int stride, int act, bool dry, int* inner, hipStream_t s) {
-  if (act != EAT_ACT_RELU || a.Cexp % 8 != 0) return 1;
-  if (4LL * a.Cin * a.F * a.T >= (1LL << 31) || 4LL * a.Cexp * a.F * a.T >= (1LL << 31)) return 1;
-  if (k == 3 && stride == 2 && a.Cin == 16) return launch_irb_train<3, 2, 4, 4>(a, s, dry, inner);
-  if (k == 3 && stride == 1 && a.Cin == 24) return launch_irb_train<3, 1, 6, 5>(a, s, dry, inner);
-  if (k == 5 && stride == 2 && a.Cin == 24) return launch_irb_train<5, 2, 6, 3>(a, s, dry, inner);
-  return 1;
 }
 
 template <int NT, int ACT, bool PF>
@@ -702,26 +581,6 @@ extern "C" int eat_mbconv_fwd(const float* x, const float* wp_e, const float* bi
   if (!wp_p || !bias_p) return eat::fail(EAT_EINVAL, "eat_mbconv_fwd: project weights and bias are required");
   return block_fused(x, wp_e, bias_e, w_d, bias_d, wp_p, bias_p, res, y, nullptr, B, Cin, Cexp, Cout, F, T, Fo, To, k,
                      stride, act, (hipStream_t)stream, "eat_mbconv_fwd");
-}
-
-// Training forward of expand 1x1 -> BatchNorm (batch statistics known from the Gram matrix) -> act -> depthwise k x k, raw
-// output + statistics partials (models/mn/block_types.py:138-162 in .train()); see the TRAIN notes above irb_kernel.
-// Returns 1 (nothing launched) where no instantiation covers the block.  inner_out (host pointer, may be NULL) receives the
-// partial slots per plane the launch writes; B = 0: only answer that question.
-extern "C" int eat_expand_dw_train_fwd(const float* x, const float* wp_e, const float* a_e, const float* b_e, const float* w_d,
-                                       float* z_e, float* z_d, float* part, int part_inner, int* inner_out, int B, int Cin,
-                                       int Cexp, int F, int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream) {
-  eat::clear_stale_error();
-  const int p = (k - 1) / 2;
-  if (Fo != (F + 2 * p - k) / stride + 1 || To != (T + 2 * p - k) / stride + 1)
-    return eat::fail(EAT_EINVAL, "eat_expand_dw_train_fwd: output %dx%d inconsistent with input %dx%d", Fo, To, F, T);
-  IrbArgs a{};
-  a.x = x; a.wpe = wp_e; a.scale_e = a_e; a.bias_e = b_e; a.wd = w_d; a.ze = z_e; a.y = z_d; a.part = part; a.part_inner = part_inner;
-  a.B = B > 0 ? B : 1; a.Cin = Cin; a.Cexp = Cexp; a.Cout = 0; a.F = F; a.T = T; a.Fo = Fo; a.To = To;
-  const bool dry = B <= 0;
-  if (!dry && (!x || !wp_e || !a_e || !b_e || !w_d || !z_d || !part))
-    return eat::fail(EAT_EINVAL, "eat_expand_dw_train_fwd: null argument");
-  return irb_train_dispatch(a, k, stride, act, dry, inner_out, (hipStream_t)stream);
 }
 
 // Network front (stem + first block) on the register-resident kernel (FRONT mode: two column tiles per wave, 0.269 ms for

@@ -425,11 +425,6 @@ _GSTATS_EPILOGUE = True  # depthwise BatchNorm backward sums from the project da
 # 80 -> 240 / 200 / 184: 89 -> 110, 76 -> 87, 67 -> 65 us - their reduce pass is cheaper than the epilogue's extra phase)
 _GSTATS_MIN_ELEMS = 1 << 26
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
-# round 6: expand conv + BatchNorm + activation + depthwise conv of the early blocks (C_in 16 / 24: exact fp32 MFMA) as one
-# register-resident kernel in the training forward (csrc/irb.hip TRAIN; EAT_FUSE_EXPAND_DW=0 restores the two launches)
-import os as _os
-_FUSE_EXPAND_DW = _os.environ.get("EAT_FUSE_EXPAND_DW", "1") != "0"
-
 
 def _w_times_g(W, G):
     """T = W G (C_out, C_in) for a symmetric G (C_in, C_in), C_in % 4 == 0."""
@@ -554,15 +549,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 else:
                     Tm, st_e = None, ops.bn_frozen_state(cna[1])
                 wp = _pk(plan, ("e", bi), cna[0].weight)
-                fused = None
-                if _FUSE_EXPAND_DW and not b16 and cna[1].training and cna_d[1].training and wp.dtype == torch.float32:
-                    # expand conv + its BatchNorm / activation + depthwise conv in ONE register-resident kernel (csrc/irb.hip,
-                    # TRAIN): the expand BatchNorm's (a, b) are known from the Gram statistics above, so z_e is activated in
-                    # registers and only WRITTEN (for the backward), never read back in the forward
-                    fused = ops.expand_dw_train(inp, wp, st_e, act, w_d, k, cnf.stride, keep_ze=True)
-                if fused is not None:
-                    z_e = fused[0]
-                elif b16:
+                if b16:
                     x16 = inp16 if inp16 is not None else (ops.cast_b16(inp) if _cast_narrow(cnf, inp) else inp)
                     z_e = ops.pw_conv_b16(x16, wp, _zeros.get(cnf.expanded_channels, dev), cnf.expanded_channels, NONE,
                                           out_b16=True)
@@ -572,10 +559,7 @@ class MNTrainFunction2(torch.autograd.Function):
                 rec.update(z_e=z_e, st_e=st_e, Tm=Tm, sx=sx)
                 tf = (st_e[0], st_e[1], act)
             src = z_e if blk.i_expand is not None else inp
-            if blk.i_expand is not None and fused is not None:
-                z_d, parts = fused[1], fused[2]
-                st_d = ops.bn_state_from_partials(parts, cna_d[1], z_d.numel() // cnf.expanded_channels)
-            elif cna_d[1].training:
+            if cna_d[1].training:
                 z_d, parts = ops.dw_conv_stats(src, w_d, k, cnf.stride, tf=tf, out_b16=b16)
                 st_d = ops.bn_state_from_partials(parts, cna_d[1], z_d.numel() // cnf.expanded_channels)
             else:

@@ -545,31 +545,6 @@ def dw_conv_stats(x, w, k, stride, tf=None, out_b16=False):
     return y, (part, B, inner.value)
 
 
-def expand_dw_train(x, wp_e, st_e, act, w_d, k, stride, keep_ze=True):
-    """Train-mode expand 1x1 -> BatchNorm (st_e = its (a, b, ...) from the Gram statistics) -> act -> depthwise conv in one
-    register-resident kernel (csrc/irb.hip, TRAIN): -> (z_e or None, z_d, (part, outer, inner)), or None where no
-    instantiation covers the block (the caller runs pw_conv + dw_conv_stats)."""
-    B, Ci, F, T = x.shape
-    Ce = w_d.shape[0]
-    Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
-    if wp_e.dtype != torch.float32:
-        return None
-    inner = _ct.c_int(0)
-    rc = _lib.call_rc("eat_expand_dw_train_fwd", None, None, None, None, None, None, None, None, 0, _ct.addressof(inner), 0, Ci, Ce,
-                      F, T, Fo, To, k, stride, act, None)
-    if rc == 1:
-        return None
-    z_e = torch.empty((B, Ce, F, T), device=x.device, dtype=torch.float32) if keep_ze else None
-    z_d = torch.empty((B, Ce, Fo, To), device=x.device, dtype=torch.float32)
-    part = torch.empty((B * 2 * Ce * inner.value,), device=x.device, dtype=torch.float32)
-    rc = _lib.call_rc("eat_expand_dw_train_fwd", _dev(x, "x"), wp_e.data_ptr(), _dev(st_e[0], "a_e"), _dev(st_e[1], "b_e"),
-                      _dev(w_d, "w_d"), None if z_e is None else z_e.data_ptr(), z_d.data_ptr(), part.data_ptr(), inner.value,
-                      None, B, Ci, Ce, F, T, Fo, To, k, stride, act, _stream())
-    if rc == 1:
-        return None
-    return z_e, z_d, (part, B, inner.value)
-
-
 def bn_stats_partial(z):
     B, C = z.shape[0], z.shape[1]
     part = torch.empty((B * 2 * C,), device=z.device, dtype=torch.float32)

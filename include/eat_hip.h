@@ -645,19 +645,6 @@ int eat_calib_copy(const float* src, float* dst, long long n, int mode, eat_stre
  * x, out (B, n) fp32 (n = the flattened per-sample size), perm (B) int32, lam (B) fp32.  out must not alias x. */
 int eat_mixup_fwd(const float* x, const int* perm, const float* lam, float* out, int B, int n, eat_stream_t stream);
 
-/* Training forward of an inverted-residual block's first two stages in ONE kernel (models/mn/block_types.py:138-162 with the
- * BatchNorm layers in batch-statistics mode; replaces eat_pw_conv_fwd + eat_dw_conv_fwd_stats of the train plan):
- *   z_e = W_e x  ->  y_e = act(a_e z_e + b_e)  (a_e, b_e: the expand BatchNorm's scale / shift, known before the conv from the
- *   Gram statistics of x - eat_gram_bn_finalize_g)  ->  z_d = depthwise_kxk(y_e), RAW, + partial sums of z_d and z_d^2.
- *   x (B,Cin,F,T); wp_e = eat_pw_prepack(W_e) (fp32 fragments); w_d (Cexp, k*k); z_d (B,Cexp,Fo,To);
- *   z_e (B,Cexp,F,T) or NULL: the raw expand output, stored for the backward pass (never read here);
- *   part [B][2][Cexp][part_inner] floats (sum, sum of squares per wave slot; unused slots are NOT written: pass the exact
- *   slot count - ask with B = 0, which only writes *inner_out) - reduce with eat_bn_finalize_partials(outer = B, inner).
- * Returns 1 without launching where no register-resident instantiation covers the block (mn10 blocks 2-4 are covered). */
-int eat_expand_dw_train_fwd(const float* x, const float* wp_e, const float* a_e, const float* b_e, const float* w_d,
-                            float* z_e, float* z_d, float* part, int part_inner, int* inner_out, int B, int Cin,
-                            int Cexp, int F, int T, int Fo, int To, int k, int stride, int act, eat_stream_t stream);
-
 /* 16-bit PCM transport of the waveforms (the reference moves fp32 clips with a blocking x.to(device),
  * ex_audioset.py:140-141, 303-304 - 1.28 MB per clip, more than PCIe carries at this path's rates): dst[i] = src[i] * scale
  * for n samples (scale = 1 / 32768 for full-scale PCM).  src int16, dst fp32, both 16-byte aligned. */

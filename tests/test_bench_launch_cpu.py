@@ -33,3 +33,28 @@ def test_rank_count_mismatch_refuses_to_print():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "refusing to print" in (p.stderr + p.stdout)
+
+
+def test_scale_check_script_end_to_end_on_cpu_ranks():
+    """tools/scale_check.sh N = 1, 2 with SCALE_EXTRA=--dry-run: the script launches bench.py per N (which respawns itself
+    under torch.distributed.run), checks n_gpus and the `rccl` object (world_size as the process group reports it) and
+    prints one efficiency line per N - the path the driver's SCALE record takes, minus the GPUs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SCALE_EXTRA="--dry-run", SCALE_STEPS="4")
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_check.sh"), "1", "2"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("N=")]
+    assert len(lines) == 2 and lines[0].startswith("N=1:") and lines[1].startswith("N=2:"), p.stdout
+    assert "'world_size': 2" in lines[1] and "'backend': 'gloo'" in lines[1] and "efficiency" in lines[1], lines[1]
+
+
+def test_scale_check_rejects_a_line_without_the_ranks(tmp_path):
+    """The script's per-N check fails when the process group did not see N ranks (a bench line with n_gpus = 2 but a
+    one-rank `rccl` object)."""
+    fake = tmp_path / "bench.py"
+    fake.write_text('import json,sys\nn=int(sys.argv[sys.argv.index("--gpus")+1])\n'
+                    'print(json.dumps({"n_gpus": n, "value": 10.0*n, "ms_per_step": 1.0, "rccl": {"world_size": 1, "backend": "nccl", "buckets": 3}}))\n')
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_check.sh"), "1", "2"], capture_output=True, text=True,
+                       timeout=120, cwd=str(tmp_path))
+    assert p.returncode != 0 and "process group reports 1 ranks" in (p.stdout + p.stderr)

@@ -218,7 +218,17 @@ def test_pw_wgrad_wide_tile_random_shapes(B, Co, Ci, S, sc):
     assert torch.equal(got, again)
 
 
-def test_mn10_train_step_matches_oracle(golden_dir):
+# whole-network gradients at rel-L2 <= 1e-2 per tensor.  What stands in the way is not arithmetic but activation
+# kinks: ONE element crossing ReLU's 0 / Hardswish's +-3 between two evaluations moves every tensor upstream through the
+# BatchNorm mean terms (the reference in fp32 vs ITSELF in fp64 shows 1-2e-3 on every tensor upstream of features.12, SURVEY
+# 8c).  The tensors the exact-fp32 step leaves above 1e-2 on this pinned batch are NAMED here (measured on MI355X, round 6;
+# per-op backward tests on the oracle's saved tensors sit at 2e-5); anything else above the bar fails.
+_ABOVE_1E2_FP32 = frozenset(())
+_MAX_ABOVE_1E2_AUTO = 200          # bf16x3 split operands from C_in >= 40: more elements sit within round-off of a kink
+
+
+@pytest.mark.parametrize("precision", ["auto", "fp32"])
+def test_mn10_train_step_matches_oracle(golden_dir, precision):
     g = np.load(os.path.join(golden_dir, "mn10_ref.npz"))
     sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
     for k in g.files:
@@ -239,6 +249,7 @@ def test_mn10_train_step_matches_oracle(golden_dir):
     model = _quiet(get_model, width_mult=1.0)
     model.load_state_dict(sd)
     model.to(DEV).train()
+    model.train_precision = precision
     model._drop_mask_override = keep
     logits, feat = model(x.to(DEV))
     loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
@@ -250,8 +261,8 @@ def test_mn10_train_step_matches_oracle(golden_dir):
     gmax = max(float(v.grad.norm()) for k, v in sdr.items() if getattr(v, "grad", None) is not None)
     # Measured on MI355X (a per-tensor diagnostic): vs an fp64 evaluation the CPU fp32 oracle itself is
     # off by 0.45 % median / 1.0 % max per tensor (activation-kink flips), the HIP path by 0.65 % / 1.9 %
-    # - the same error class.  Bound: 3 % per tensor, 1 % median.
-    bad, rels = [], []
+    # - the same error class.  Hard bound: 3 % per tensor, 1 % median; SURVEY's 1e-2 with the named / counted exceedances.
+    bad, rels, above = [], [], []
     for name, p in model.named_parameters():
         ref = sdr[name].grad
         assert p.grad is not None, name
@@ -259,10 +270,19 @@ def test_mn10_train_step_matches_oracle(golden_dir):
             continue
         r = _rel(p.grad, ref)
         rels.append(r)
+        if r > 1e-2:
+            above.append((name, round(r, 5)))
         if r > 3e-2:
             bad.append((name, r))
+    print(f"mn10 train step [{precision}]: gradient rel-L2 median {np.median(rels):.2e} max {max(rels):.2e}; "
+          f"{len(above)} of {len(rels)} tensors above 1e-2: {above}")
     assert not bad, bad[:8]
     assert float(np.median(rels)) < 1e-2, float(np.median(rels))
+    if precision == "fp32":
+        unnamed = [a for a in above if a[0] not in _ABOVE_1E2_FP32]
+        assert not unnamed, unnamed
+    else:
+        assert len(above) <= _MAX_ABOVE_1E2_AUTO, above
     # reference gradient norms stored in the golden file
     for name, p in model.named_parameters():
         ref = float(g["gnorm/" + name])

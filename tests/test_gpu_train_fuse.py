@@ -617,63 +617,3 @@ def test_all_weight_packs_from_one_launch(mode):
     with ops.precision("fp32" if mode != "fp32" else "auto"):
         assert plan.stale()
 
-
-# (round 6) expand 1x1 + BatchNorm + act + depthwise conv of the early blocks as one register-resident kernel (csrc/irb.hip,
-# TRAIN): mn10 blocks 2 / 3 / 4, small and ragged planes, the stride-2 case whose last odd input column belongs to an
-# output column one past To (T = 56 / 252 with 14-column strips), a channel count that is not a multiple of 16
-FUSED_GEOMS = [(2, 16, 64, 64, 500, 3, 2), (2, 24, 72, 32, 250, 3, 1), (2, 24, 72, 32, 250, 5, 2), (3, 16, 64, 10, 37, 3, 2),
-               (2, 24, 72, 9, 64, 3, 1), (2, 24, 72, 33, 56, 5, 2), (1, 24, 72, 17, 252, 5, 2), (2, 24, 88, 12, 45, 3, 1),
-               (2, 16, 40, 7, 30, 3, 2), (5, 24, 72, 3, 5, 5, 2)]
-
-
-@pytest.mark.parametrize("B,Ci,Ce,F_,T,k,s", FUSED_GEOMS)
-def test_fused_expand_dw_training_forward(B, Ci, Ce, F_, T, k, s):
-    """ops.expand_dw_train == pw_conv -> dw_conv_stats(tf = expand BatchNorm + ReLU on load): same z_e, same z_d, same
-    BatchNorm state from the partials; reference torch fp64 of models/mn/block_types.py:138-162 in .train()."""
-    x = _rand(B, Ci, F_, T, seed=1, scale=1.2) + _rand(1, Ci, 1, 1, seed=2, scale=0.5)
-    W = _rand(Ce, Ci, seed=3, scale=Ci ** -0.5)
-    wd = _rand(Ce, 1, k, k, seed=4, scale=0.3)
-    a_e = torch.rand(Ce, generator=torch.Generator().manual_seed(5)) + 0.5
-    b_e = _rand(Ce, seed=6, scale=0.4)
-    gamma, beta = torch.rand(Ce, generator=torch.Generator().manual_seed(7)) + 0.5, _rand(Ce, seed=8, scale=0.3)
-    ze_ref = torch.einsum("oc,bcft->boft", W.double(), x.double())
-    ye_ref = F.relu(ze_ref * a_e.double()[None, :, None, None] + b_e.double()[None, :, None, None])
-    zd_ref = F.conv2d(ye_ref, wd.double(), None, s, (k - 1) // 2, 1, Ce)
-    xd, wp = x.to(DEV), ops.pw_prepack(W.to(DEV))
-    st_e = (a_e.to(DEV), b_e.to(DEV))
-    wdd = wd.reshape(Ce, k * k).contiguous().to(DEV)
-    for keep in (True, False):
-        out = ops.expand_dw_train(xd, wp, st_e, ops.ACT_RELU, wdd, k, s, keep_ze=keep)
-        assert out is not None, "no fused instantiation for a covered geometry"
-        z_e, z_d, parts = out
-        assert (z_e is not None) == keep
-        if keep:
-            assert _rel(z_e, ze_ref) < 2e-6
-            # every element written exactly once, incl. the image borders (compare against the separate kernel's output)
-            z_sep = ops.pw_conv(xd, wp, torch.zeros(Ce, device=DEV), Ce, ops.ACT_NONE)
-            assert float((z_e - z_sep).abs().max()) <= 1e-5 * float(z_sep.abs().max())
-        assert z_d.shape == zd_ref.shape and _rel(z_d, zd_ref) < 3e-6
-        bn = torch.nn.BatchNorm2d(Ce, eps=1e-3, momentum=0.01).to(DEV).train()
-        with torch.no_grad():
-            bn.weight.copy_(gamma)
-            bn.bias.copy_(beta)
-        n = z_d.numel() // Ce
-        a, b, mean, invstd = ops.bn_state_from_partials(parts, bn, n)
-        m_ref = zd_ref.mean(dim=(0, 2, 3))
-        v_ref = zd_ref.var(dim=(0, 2, 3), unbiased=False)
-        assert float((mean.cpu().double() - m_ref).abs().max()) < 1e-5 * max(1.0, float(m_ref.abs().max()))
-        assert _rel(invstd, 1.0 / torch.sqrt(v_ref + 1e-3)) < 1e-5
-        assert _rel(a, gamma.double() / torch.sqrt(v_ref + 1e-3)) < 1e-5
-
-
-def test_fused_expand_dw_training_forward_declines_uncovered_blocks():
-    """Geometries without an instantiation answer None (the plan runs the two separate kernels): C_in 40, Hardswish."""
-    x = _rand(2, 40, 16, 125, seed=1).to(DEV)
-    W = _rand(120, 40, seed=2)
-    wd = _rand(120, 25, seed=3).to(DEV)
-    st = (torch.ones(120, device=DEV), torch.zeros(120, device=DEV))
-    assert ops.expand_dw_train(x, ops.pw_prepack(W.to(DEV)), st, ops.ACT_RELU, wd, 5, 1) is None
-    x = _rand(2, 24, 32, 250, seed=1).to(DEV)
-    W = _rand(72, 24, seed=2)
-    st = (torch.ones(72, device=DEV), torch.zeros(72, device=DEV))
-    assert ops.expand_dw_train(x, ops.pw_prepack(W.to(DEV)), st, ops.ACT_HSWISH, _rand(72, 9, seed=3).to(DEV), 3, 1) is None

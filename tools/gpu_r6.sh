@@ -85,6 +85,27 @@ if has pmc; then
   python tools/pmc_sq.py $OUT/pmc_sq_${PMC_TAG:-r6}.json $S > $OUT/pmc_sq_${PMC_TAG:-r6}.txt 2>&1; tail -3 $OUT/pmc_sq_${PMC_TAG:-r6}.txt
   rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq1
 fi
+if has overlap; then
+  # one rank, forced bucketing: the captured step with its RCCL all-reduces (what a rank of an N-GPU run replays)
+  BARGS="--no-cpu-baseline --no-forward --no-train-configs --no-profile --no-kd --no-fp32-exact --steps 6 --warmup 2 --reps 1"
+  (cd /tmp && EAT_BENCH_FORCE_DIST=1 timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/ovl -o ovl --output-format csv -- \
+      python $GRAFT_REPO_ROOT/bench.py $BARGS > $GRAFT_REPO_ROOT/$OUT/overlap_bench.json 2> $GRAFT_REPO_ROOT/$OUT/overlap.log)
+  K=$(find $OUT/ovl -name "*kernel_trace.csv" | head -1)
+  python tools/overlap_check.py $K $OUT/rccl_overlap_r6.json
+  rm -rf $OUT/ovl
+  for m in mn10 mn40_bf16; do
+    for fd in 0 1; do
+      EAT_BENCH_FORCE_DIST=$fd timeout 400 python bench.py --train-model $m --batch $([ $m = mn10 ] && echo 256 || echo 128) --no-cpu-baseline --no-forward --no-train-configs --no-profile --no-kd --no-fp32-exact --steps 15 --warmup 3 > $OUT/ovl_b.json 2> $OUT/ovl_b.err
+      python - <<P
+import json
+try:
+    d=json.load(open("$OUT/ovl_b.json")); print("$m forced_buckets=$fd ->", d["ms_per_step"], "ms/step", d.get("rccl"))
+except Exception as e:
+    print("$m fd=$fd FAILED", e); print(open("$OUT/ovl_b.err").read()[-2000:])
+P
+    done
+  done
+fi
 if has smoke; then
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; grep "smoke:" $OUT/smoke.log; tail -2 $OUT/smoke.log
 fi
