@@ -556,23 +556,33 @@ def kernel_profile(step, iters=3):
         torch.cuda.synchronize()
     finally:
         _lib.call, _lib.call_rc = real_call, real_call_rc
+    # per launch: the MINIMUM over the iterations (the launch sequences are identical) - an event pair also spans whatever idle
+    # time a host-side stall (allocator, a first-use hipMalloc) puts between its two records, and one such stall of tens of
+    # milliseconds in one iteration would otherwise be booked on whichever kernel it hit
+    n = len(rec) // iters
+    seqs = [rec[i * n:(i + 1) * n] for i in range(iters)]
+    same = len(rec) == n * iters and all([r[0] for r in sq] == [r[0] for r in seqs[0]] for sq in seqs)
+    if not same:                                              # (never seen; fall back to the last iteration alone)
+        seqs = [rec[-n:]]
+    times = [min(sq[j][2].elapsed_time(sq[j][3]) for sq in seqs) for j in range(n)]
+    last = seqs[-1]
     agg = {}
-    if os.environ.get("EAT_BENCH_LAUNCHES"):      # debug: one line per launch of the last iteration
-        for name, args, e0, e1 in rec[-(len(rec) // iters):]:
+    if os.environ.get("EAT_BENCH_LAUNCHES"):      # debug: one line per launch
+        for (name, args, _, _), ms in zip(last, times):
             sym, nbytes, _ = _alg_bytes(name, args)
-            us = e0.elapsed_time(e1) * 1e3
+            us = ms * 1e3
             ints = [a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < 10 ** 7]
             print(f"[launch] {sym:24s} {us:9.1f} us {nbytes / us / 1e3:8.1f} GB/s  {ints}", file=sys.stderr)
-    for name, args, e0, e1 in rec:
+    for (name, args, _, _), ms in zip(last, times):
         sym, nbytes, flops = _alg_bytes(name, args)
         d = agg.setdefault(sym, [0, 0.0, 0, 0, 0])
         d[0] += 1
-        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[1] += ms * 1e-3
         d[2] += nbytes
         d[3] += flops
         d[4] += _read_bytes(name, args, nbytes)
-    return {k: dict(launches=v[0] // iters, total_ms=v[1] / iters * 1e3, bytes=v[2] / iters, flops=v[3] / iters,
-                    read_bytes=v[4] / iters, gbps=(v[2] / v[1] / 1e9) if v[1] > 0 else 0.0) for k, v in agg.items()}
+    return {k: dict(launches=v[0], total_ms=v[1] * 1e3, bytes=v[2], flops=v[3], read_bytes=v[4],
+                    gbps=(v[2] / v[1] / 1e9) if v[1] > 0 else 0.0) for k, v in agg.items()}
 
 
 def _read_bytes(name, a, nbytes):

