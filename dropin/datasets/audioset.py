@@ -7,7 +7,9 @@ roll / waveform mix-up) and hands the training loop tuples
 
   * REAL: `dataset_dir` (below; or the environment variable EAT_AUDIOSET_DIR) names a directory holding
     balanced_train_segments_mp3.hdf / unbalanced_train_segments_mp3.hdf / eval_segments_mp3.hdf -> the HDF5 + mp3 reader
-    (`_Hdf5AudioSet`: h5py rows `audio_name`, `mp3`, bit-packed `target`; PyAV decode; needs h5py and av);
+    of `_hdf5_reader.py` (h5py rows `audio_name`, `mp3`, bit-packed `target`; PyAV decode; needs h5py and av - QUARANTINED:
+    never executed in the images this package was built in, it announces that on import; tests/test_host_cpu.py holds a
+    round-trip test that runs wherever both libraries exist);
   * SYNTHETIC: only on the explicit opt-in EAT_SYNTH_AUDIOSET=1 (the benchmarks, the GPU tests and the staged runs of
     the reference's own scripts set it): clips of the same layout generated on the fly - deterministic per index (numpy
     PCG64 seeded with the index), band-limited noise + tones + silence so that every mel band is exercised;
@@ -51,16 +53,25 @@ else:
     }
 
 
+def _reader():
+    """The quarantined HDF5 + mp3 reader module (loaded on first use; also when this file was loaded outside its package)."""
+    global _READER
+    if _READER is None:
+        import importlib.util
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_hdf5_reader.py")
+        spec = importlib.util.spec_from_file_location("eat_dropin_hdf5_reader", path)
+        _READER = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_READER)
+        _READER.pad_or_truncate, _READER.pydub_augment = pad_or_truncate, pydub_augment
+    return _READER
+
+
+_READER = None
+
+
 def decode_mp3(mp3_arr):
-    """uint8 array holding one mp3 file -> float32 waveform (PyAV; datasets/audioset.py:32-47)."""
-    import av
-    container = av.open(io.BytesIO(mp3_arr.tobytes()))
-    stream = next(s for s in container.streams if s.type == "audio")
-    chunks = [frame.to_ndarray().reshape(-1) for packet in container.demux(stream) for frame in packet.decode()]
-    waveform = np.concatenate(chunks)
-    if waveform.dtype != np.float32:
-        raise RuntimeError("Unexpected wave type")
-    return waveform
+    """uint8 array holding one mp3 file -> float32 waveform (datasets/audioset.py:32-47; PyAV - see _hdf5_reader.py)."""
+    return _reader().decode_mp3(mp3_arr)
 
 
 def pad_or_truncate(x, audio_length):
@@ -86,63 +97,6 @@ def _synth_target(rng, classes_num, g):
     y = (rng.random(classes_num) < 2.7 / classes_num).astype(np.float32)
     y[g % classes_num] = 1.0        # every clip carries a label, and >= classes_num consecutive clips cover every class
     return y                        # (sklearn's per-class ROC / AP of `_test` need a positive and a negative per class)
-
-
-class _Hdf5AudioSet(TorchDataset):
-    """The reference's reader (datasets/audioset.py:106-177): one HDF5 file with the rows `audio_name` (bytes), `mp3`
-    (variable-length uint8) and `target` (527 labels packed into 66 bytes); the file handle is opened lazily so that
-    every DataLoader worker gets its own."""
-
-    def __init__(self, hdf5_file, sample_rate=32000, resample_rate=32000, classes_num=527, clip_length=10, in_mem=False,
-                 gain_augment=0):
-        import h5py
-        self.sample_rate, self.resample_rate = sample_rate, resample_rate
-        self.hdf5_file = hdf5_file
-        if in_mem:
-            print("\nPreloading in memory\n")
-            with open(hdf5_file, "rb") as f:
-                self.hdf5_file = io.BytesIO(f.read())
-        with h5py.File(hdf5_file, "r") as f:
-            self.length = len(f["audio_name"])
-        print(f"Dataset from {hdf5_file} with length {self.length}.")
-        self.dataset_file = None
-        self.clip_length = clip_length * sample_rate
-        self.classes_num, self.gain_augment = classes_num, gain_augment
-
-    def __len__(self):
-        return self.length
-
-    def __del__(self):
-        if getattr(self, "dataset_file", None) is not None:
-            self.dataset_file.close()
-            self.dataset_file = None
-
-    def _file(self):
-        if self.dataset_file is None:
-            import h5py
-            self.dataset_file = h5py.File(self.hdf5_file, "r")
-        return self.dataset_file
-
-    def targets(self):
-        """(length, classes_num) float32 label matrix (for the class-balancing sampler)."""
-        return np.unpackbits(self._file()["target"][:], axis=-1, count=self.classes_num).astype(np.float32)
-
-    def __getitem__(self, index):
-        f = self._file()
-        # stored names look like "Y<youtube id>.mp3": back to the official file name
-        audio_name = f["audio_name"][index].decode().replace(".mp3", "").split("Y", 1)[1]
-        waveform = pad_or_truncate(pydub_augment(decode_mp3(f["mp3"][index]), self.gain_augment), self.clip_length)
-        target = np.unpackbits(f["target"][index], axis=-1, count=self.classes_num).astype(np.float32)
-        return self.resample(waveform).reshape(1, -1), audio_name, target
-
-    def resample(self, waveform):
-        if self.resample_rate == 32000:
-            return waveform
-        if self.resample_rate == 16000:
-            return waveform[0::2]
-        if self.resample_rate == 8000:
-            return waveform[0::4]
-        raise Exception("Incorrect sample rate!")
 
 
 class _SyntheticAudioSet(TorchDataset):
@@ -190,7 +144,12 @@ class _SyntheticAudioSet(TorchDataset):
         raise Exception("Incorrect sample rate!")
 
 
-AudioSetDataset = _SyntheticAudioSet if SYNTHETIC else _Hdf5AudioSet
+if SYNTHETIC:
+    AudioSetDataset = _SyntheticAudioSet
+else:
+    # the reference's HDF5 + mp3 reader lives in its own module: it needs h5py and PyAV, neither of which exists in any image
+    # this package was built or tested in - importing it says so loudly (see its header) instead of pretending coverage
+    AudioSetDataset = _reader().Hdf5AudioSet
 
 
 class MixupDataset(TorchDataset):

@@ -136,9 +136,9 @@ class DY_Block(nn.Module):
         super().__init__()
         if not (1 <= cnf.stride <= 2):
             raise ValueError("illegal stride value")
-        if cnf.dilation != 1:
-            raise NotImplementedError("HIP path implements the dynamic block with dilation 1")
         self.cnf = cnf
+        # a dilated block runs its depthwise conv and its context pooling at stride 1 (dy_block.py:322,385-386)
+        self.dw_stride = 1 if cnf.dilation > 1 else cnf.stride
         # ablations of the block (dy_block.py:269-271): static convs / plain activation / no coordinate attention
         self.no_dyrelu, self.no_dyconv, self.no_ca = bool(no_dyrelu), bool(no_dyconv), bool(no_ca)
         self.use_res_connect = cnf.stride == 1 and cnf.input_channels == cnf.out_channels
@@ -149,10 +149,13 @@ class DY_Block(nn.Module):
         norm = partial(nn.BatchNorm2d, eps=BN_EPS, momentum=BN_MOMENTUM)
         act_layer = nn.Hardswish if cnf.use_hs else nn.ReLU
 
-        def conv(ci, co, k, stride=1, groups=1):
+        def conv(ci, co, k, stride=1, groups=1, dilation=1):
             if no_dyconv:                                            # dy_block.py:291-302,320-332,359-370
-                return DynamicWrapper(nn.Conv2d(ci, co, (k, k), (stride, stride), (k - 1) // 2, groups=groups, bias=False))
-            return DynamicConv(ci, co, H, k, stride=stride, groups=groups, k=dyconv_k, temp_schedule=temp_schedule)
+                return DynamicWrapper(nn.Conv2d(ci, co, (k, k), (stride, stride), (k - 1) // 2 * dilation,
+                                                dilation=(dilation, dilation), groups=groups, bias=False))
+            dc = DynamicConv(ci, co, H, k, stride=stride, groups=groups, k=dyconv_k, temp_schedule=temp_schedule)
+            dc.dilation, dc.padding = dilation, (k - 1) // 2 * dilation
+            return dc
 
         self.has_expand = cexp != cin
         if self.has_expand:
@@ -161,13 +164,13 @@ class DY_Block(nn.Module):
             self.exp_act = act_layer(inplace=True)
         else:
             self.exp_conv, self.exp_norm, self.exp_act = nn.Identity(), nn.Identity(), nn.Identity()
-        self.depth_conv = conv(cexp, cexp, cnf.kernel, cnf.stride, cexp)
+        self.depth_conv = conv(cexp, cexp, cnf.kernel, self.dw_stride, cexp, cnf.dilation)
         self.depth_norm = norm(cexp)
         self.depth_act = DynamicWrapper(act_layer(inplace=True)) if no_dyrelu else DyReLUB(cexp, H, M=dyrelu_k)
         self.ca = DynamicWrapper(nn.Identity()) if no_ca else CoordAtt()
         self.proj_conv = conv(cexp, cout, 1)
         self.proj_norm = norm(cout)
-        self.context_gen = ContextGen(H, cin, cexp, stride=cnf.stride)
+        self.context_gen = ContextGen(H, cin, cexp, stride=self.dw_stride)
 
 
 def _pool3(t, stride):
@@ -288,7 +291,8 @@ class DyMN(nn.Module):
     def _block_forward(self, blk, w, x):
         cnf = blk.cnf
         B, cin, Fq, T = x.shape
-        H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
+        H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, blk.dw_stride
+        dil = cnf.dilation
         act = ops.ACT_HSWISH if cnf.use_hs else ops.ACT_RELU
         inp = x
         # ---- context generator (dy_block.py:235-254); the ablated blocks (`no_dyconv`, `no_dyrelu`, `no_ca`) only
@@ -316,18 +320,29 @@ class DyMN(nn.Module):
                 x = self._dyn_pw(blk.exp_conv, w, "exp", x, _attention(blk.exp_conv, h_c), cexp, cin, act)
         # ---- depthwise (dynamic taps) + BN + DyReLU-B + CoordAtt
         if blk.no_dyconv and blk.no_dyrelu and blk.no_ca:
-            x = ops.dw_conv(x, w["depth_taps"], w["depth"][1], k, stride, act)     # nothing dynamic left: the static kernel
+            # nothing dynamic left: the static kernels
+            x = (ops.dw_conv(x, w["depth_taps"], w["depth"][1], k, stride, act) if dil == 1 else
+                 ops.dw_conv_dilated(x, w["depth_taps"], w["depth"][1], k, stride, dil, act))
+        elif dil > 1:
+            # dilated dynamic block (models/dymn/model.py:212-218,246-250; dy_block.py:322-348): the per-sample taps make the
+            # depthwise conv a conv over B * cexp independent planes - the batch folded into the channel axis of the
+            # generic dilated depthwise kernel - followed by the stand-alone BatchNorm + DyReLU-B + CoordAtt kernel
+            if blk.no_dyconv:
+                taps = (blk.depth_conv.module.weight.flatten(1)).unsqueeze(0).expand(B, -1, -1).reshape(B * cexp, k * k).contiguous()
+            else:
+                att = _attention(blk.depth_conv, h_c)
+                taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att).view(B * cexp, k * k)
+            z = ops.dw_conv_dilated(x.reshape(1, B * cexp, Fq, T), taps, torch.zeros(B * cexp, device=x.device), k, stride, dil,
+                                    ops.ACT_NONE).view(B, cexp, *ops.dilated_out(Fq, T, k, stride, dil))
+            x = ops.dyrelu_ca(z, w["depth"][0], w["depth"][1], act if blk.no_dyrelu else None,
+                              None if blk.no_dyrelu else self._dyrelu_coef(blk, h_c, B, cexp), g_cf, g_ct)
         else:
             if blk.no_dyconv:
                 taps = w["depth_taps"].unsqueeze(0).expand(B, -1, -1).reshape(B, -1).contiguous()
             else:
                 att = _attention(blk.depth_conv, h_c)
                 taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att, w["depth"][0], k * k)
-            coef = None
-            if not blk.no_dyrelu:
-                da = blk.depth_act
-                theta = 2.0 * torch.sigmoid(ops.linear(h_c, da.coef_net[0].weight, da.coef_net[0].bias, ops.ACT_NONE)) - 1.0
-                coef = (theta.view(B, cexp, 4) * da.lambdas + da.init_v).contiguous()
+            coef = None if blk.no_dyrelu else self._dyrelu_coef(blk, h_c, B, cexp)
             if coef is not None and g_cf is not None:
                 x = ops.dw_conv_dyn(x, taps, w["depth"][1], coef, g_cf, g_ct, k, stride)
             else:
@@ -338,6 +353,13 @@ class DyMN(nn.Module):
         if blk.no_dyconv:
             return ops.pw_conv(x, w["proj_w"], w["proj"][1], cout, ops.ACT_NONE, res=res)
         return self._dyn_pw(blk.proj_conv, w, "proj", x, _attention(blk.proj_conv, h_c), cout, cexp, ops.ACT_NONE, res=res)
+
+    @staticmethod
+    def _dyrelu_coef(blk, h_c, B, cexp):
+        """DyReLU-B coefficients (dy_block.py:176-181): (2 sigmoid(coef_net(h_c)) - 1) * lambdas + init_v, (B, cexp, 4)."""
+        da = blk.depth_act
+        theta = 2.0 * torch.sigmoid(ops.linear(h_c, da.coef_net[0].weight, da.coef_net[0].bias, ops.ACT_NONE)) - 1.0
+        return (theta.view(B, cexp, 4) * da.lambdas + da.init_v).contiguous()
 
     @staticmethod
     def _dyn_pw(conv, w, name, x, att, Co, Ci, act, res=None):

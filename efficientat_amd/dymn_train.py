@@ -335,13 +335,19 @@ class DynDwConv(torch.autograd.Function):
     """Depthwise DynamicConv: per-(b,c) taps = sum_k att[b,k] w_k[c]."""
 
     @staticmethod
-    def forward(ctx, x, weight, att, k, stride):
+    def forward(ctx, x, weight, att, k, stride, dilation=1):
         x, att = x.contiguous(), att.contiguous()
         B, C, Fq, T = x.shape
         K = weight.shape[2]
         taps = ops.dyn_aggregate(weight.view(K, C * k * k), att)
         ctx.save_for_backward(x, weight, att, taps)
-        ctx.k, ctx.stride = k, stride
+        ctx.k, ctx.stride, ctx.dilation = k, stride, dilation
+        if dilation > 1:
+            # dilated dynamic block (models/dymn/model.py:212-218; dy_block.py:322-348): per-sample taps = a depthwise conv over
+            # B * C independent planes - the batch folded into the channel axis of the generic dilated kernels
+            y = ops.dw_conv_dilated(x.view(1, B * C, Fq, T), taps.view(B * C, k * k), _zeros.get(B * C, x.device), k, stride,
+                                    dilation, NONE)
+            return y.view(B, C, y.shape[2], y.shape[3])
         Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
         y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
         _lib.call("eat_dw_conv_dyn_fwd", x.data_ptr(), taps.data_ptr(), _zeros.get(C, x.device).data_ptr(), None, None,
@@ -355,13 +361,19 @@ class DynDwConv(torch.autograd.Function):
         B, C, Fq, T = x.shape
         k, stride, K = ctx.k, ctx.stride, weight.shape[2]
         Fo, To = dz.shape[2], dz.shape[3]
+        if ctx.dilation > 1:
+            dzf, xf = dz.view(1, B * C, Fo, To), x.view(1, B * C, Fq, T)
+            dx = ops.dw_conv_dilated_dgrad(dzf, taps.view(B * C, k * k), xf.shape, k, stride, ctx.dilation).view(B, C, Fq, T)
+            G = ops.dw_conv_dilated_wgrad(dzf, xf, k, stride, ctx.dilation).view(B, C * k * k)
+            dbank, datt = _bank_grad(G, att, weight.view(K, C * k * k))
+            return dx, dbank.view_as(weight), datt, None, None, None
         dx = torch.empty_like(x)
         _lib.call("eat_dw_conv_dyn_dgrad", dz.data_ptr(), taps.data_ptr(), None, dx.data_ptr(), B, C, Fq, T, Fo, To, k,
                   stride, _s())
         G = torch.zeros((B, C * k * k), device=x.device, dtype=torch.float32)
         _lib.call("eat_dw_conv_dyn_wgrad", dz.data_ptr(), x.data_ptr(), G.data_ptr(), B, C, Fq, T, Fo, To, k, stride, _s())
         dbank, datt = _bank_grad(G, att, weight.view(K, C * k * k))
-        return dx, dbank.view_as(weight), datt, None, None
+        return dx, dbank.view_as(weight), datt, None, None, None
 
 
 class DyReluCoordAtt(torch.autograd.Function):
@@ -399,7 +411,7 @@ def _context(blk, x):
     """ContextGen (models/dymn/dy_block.py:235-254) in train mode -> (h_c (B,H), g_cf (B,Fo,cexp), g_ct (B,To,cexp))."""
     cnf = blk.cnf
     B, cin, Fq, T = x.shape
-    H, cexp, stride = blk.context_dim, cnf.expanded_channels, cnf.stride
+    H, cexp, stride = blk.context_dim, cnf.expanded_channels, blk.dw_stride
     cg = blk.context_gen
     L = Fq + T
     seq = CtxPool.apply(x)                                                            # (B, L, cin)
@@ -439,11 +451,14 @@ def _context_cm(blk, x, hand_over=None):
 
 
 def _block_train(blk, x):
-    if not (blk.no_dyconv or blk.no_dyrelu or blk.no_ca) and _FUSED_BLOCK:
+    # (a dilated block - models/dymn/model.py:212-218 - takes the per-layer Functions: its depthwise conv runs on the generic
+    #  dilated kernels with the batch folded into the channel axis, DynDwConv / DwConv)
+    if not (blk.no_dyconv or blk.no_dyrelu or blk.no_ca) and _FUSED_BLOCK and blk.cnf.dilation == 1:
         return _block_train_fused(blk, x)
     cnf = blk.cnf
     B, cin, Fq, T = x.shape
-    H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, cnf.stride
+    H, cexp, cout, k, stride = blk.context_dim, cnf.expanded_channels, cnf.out_channels, cnf.kernel, blk.dw_stride
+    dil = cnf.dilation
     act = HSWISH if cnf.use_hs else RELU
     inp = x
     h_c, g_cf, g_ct = _context(blk, x)
@@ -456,8 +471,8 @@ def _block_train(blk, x):
         z = PwConv.apply(x, blk.exp_conv.module.weight) if no_dyconv else \
             DynPwConv.apply(x, blk.exp_conv.weight, _attention(blk.exp_conv, h_c), cexp)
         x = BnAct.apply(z, blk.exp_norm.weight, blk.exp_norm.bias, blk.exp_norm, act)
-    z = DwConv.apply(x, blk.depth_conv.module.weight, k, stride) if no_dyconv else \
-        DynDwConv.apply(x, blk.depth_conv.weight, _attention(blk.depth_conv, h_c), k, stride)
+    z = DwConv.apply(x, blk.depth_conv.module.weight, k, stride, dil) if no_dyconv else \
+        DynDwConv.apply(x, blk.depth_conv.weight, _attention(blk.depth_conv, h_c), k, stride, dil)
     v = BnAct.apply(z, blk.depth_norm.weight, blk.depth_norm.bias, blk.depth_norm, act if no_dyrelu else NONE)
     if no_dyrelu and no_ca:
         x = v
@@ -702,14 +717,13 @@ def _static_block_train(blk, x):
     """SE-less InvertedResidual in train mode (models/mn/block_types.py:138-181 with se_cnf None)."""
     cnf = blk.cnf
     act = HSWISH if cnf.use_hs else RELU
-    if cnf.dilation > 1:
-        raise NotImplementedError("training a dilated block is not on the HIP path")
+    dw_stride = 1 if cnf.dilation > 1 else cnf.stride          # models/mn/block_types.py:150
     inp = x
     if blk.i_expand is not None:
         conv, bn = blk.block[blk.i_expand][0], blk.block[blk.i_expand][1]
         x = BnAct.apply(PwConv.apply(x, conv.weight), bn.weight, bn.bias, bn, act)
     conv, bn = blk.block[blk.i_dw][0], blk.block[blk.i_dw][1]
-    x = BnAct.apply(DwConv.apply(x, conv.weight, cnf.kernel, cnf.stride), bn.weight, bn.bias, bn, act)
+    x = BnAct.apply(DwConv.apply(x, conv.weight, cnf.kernel, dw_stride, cnf.dilation), bn.weight, bn.bias, bn, act)
     conv, bn = blk.block[blk.i_proj][0], blk.block[blk.i_proj][1]
     x = BnAct.apply(PwConv.apply(x, conv.weight), bn.weight, bn.bias, bn, NONE)
     return x + inp if blk.use_res_connect else x

@@ -102,6 +102,33 @@ def dw_conv_dilated(x, w, bias, k, stride, dilation, act, pool=None):
     return y
 
 
+def dilated_out(F, T, k, stride, dilation):
+    pad = (k - 1) // 2 * dilation
+    return (F + 2 * pad - dilation * (k - 1) - 1) // stride + 1, (T + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+
+
+def dyrelu_ca(z, a, b, act, coef, gate_f, gate_t):
+    """BatchNorm affine (a, b per channel) + DyReLU-B (coef (B, C, 4); None: the plain activation `act`) + CoordAtt (position-
+    major PRE-sigmoid gates (B*Fo, C) / (B*To, C); None: no attention) of a (B, C, Fo, To) tensor - the stand-alone kernel
+    of the dilated dynamic block (eat_dyrelu_ca_fwd; the ablations are expressed through constant operands: a1 = a2 = 1 is
+    the identity, gates of +40 a sigmoid of exactly 1 in fp32)."""
+    B, C, Fo, To = z.shape
+    if coef is None:
+        # plain activation in DyReLU's place: BatchNorm + act through the generic pass, attention (if any) on its output
+        y = bn_act_fwd(z, a, b, act)
+        if gate_f is None:
+            return y
+        z, a, b = y, None, None
+        coef = torch.tensor([1.0, 1.0, 0.0, 0.0], device=z.device).expand(B, C, 4).contiguous()
+    if gate_f is None:
+        gate_f = torch.full((B * Fo, C), 40.0, device=z.device)
+        gate_t = torch.full((B * To, C), 40.0, device=z.device)
+    out = torch.empty_like(z)
+    _lib.call("eat_dyrelu_ca_fwd", _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef.contiguous(), "coef"),
+              _dev(gate_f.contiguous(), "gate_f"), _dev(gate_t.contiguous(), "gate_t"), out.data_ptr(), B, C, Fo, To, _stream())
+    return out
+
+
 def dw_conv_dilated_dgrad(dz, w, x_shape, k, stride, dilation):
     """Data gradient of the dilated depthwise conv (training of `dilated=True` networks; generic kernel)."""
     B, C, F, T = x_shape

@@ -319,14 +319,15 @@ def context_dim(cexp, width_mult, ratio=4, lo=32, hi=128):
     return int(min(max(v, make_divisible(lo * width_mult, 8)), make_divisible(hi * width_mult, 8)))
 
 
-def _dyconv(sd, prefix, x, h_c, cin, cout, k, stride, groups, temperature):
-    """DynamicConv (dy_block.py:103-131): per-sample kernel = softmax-weighted sum of K=4."""
+def _dyconv(sd, prefix, x, h_c, cin, cout, k, stride, groups, temperature, dilation=1):
+    """DynamicConv (dy_block.py:103-131): per-sample kernel = softmax-weighted sum of K=4; `dilation` with padding
+    (k - 1) // 2 * dilation as DY_Block builds the depthwise DynamicConv of a dilated block (dy_block.py:322-348)."""
     b = x.shape[0]
     a = F.softmax(F.linear(h_c, sd[prefix + ".residuals.0.weight"], sd[prefix + ".residuals.0.bias"])
                   / temperature, dim=-1)                                    # (B,K)
     bank = sd[prefix + ".weight"][0, 0]                                      # (K, N)
     w = (a @ bank).reshape(b * cout, cin // groups, k, k)
-    y = F.conv2d(x.reshape(1, b * cin, *x.shape[2:]), w, None, stride, (k - 1) // 2, 1, groups * b)
+    y = F.conv2d(x.reshape(1, b * cin, *x.shape[2:]), w, None, stride, (k - 1) // 2 * dilation, dilation, groups * b)
     return y.reshape(b, cout, *y.shape[2:])
 
 
@@ -343,23 +344,27 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, n
     g = F.hardswish(_bn(sd, prefix + ".context_gen.joint_norm", g, train, stats))
     h_cf, h_ct = g[:, :, :Fq], g[:, :, Fq:].permute(0, 1, 3, 2)
     h_c = g.mean(dim=2).reshape(B, H)
-    if c["stride"] > 1:
-        h_cf = F.avg_pool2d(h_cf, (3, 1), (c["stride"], 1), (1, 0))
-        h_ct = F.avg_pool2d(h_ct, (1, 3), (1, c["stride"]), (0, 1))
+    # a dilated block runs its depthwise conv AND its context pooling at stride 1 (dy_block.py:322,385-386); the residual
+    # test below still reads the configured stride (dy_block.py:278 `use_res_connect`)
+    dil = c.get("dil", 1)
+    dw_stride = 1 if dil > 1 else c["stride"]
+    if dw_stride > 1:
+        h_cf = F.avg_pool2d(h_cf, (3, 1), (dw_stride, 1), (1, 0))
+        h_ct = F.avg_pool2d(h_ct, (1, 3), (1, dw_stride), (0, 1))
     g_cf = F.conv2d(h_cf, sd[prefix + ".context_gen.conv_f.weight"], sd[prefix + ".context_gen.conv_f.bias"])
     g_ct = F.conv2d(h_ct, sd[prefix + ".context_gen.conv_t.weight"], sd[prefix + ".context_gen.conv_t.bias"])
 
-    def conv(name, x, cin, cout, k, stride, groups):
+    def conv(name, x, cin, cout, k, stride, groups, dilation=1):
         if no_dyconv:
-            return F.conv2d(x, sd[f"{prefix}.{name}.module.weight"], None, stride, (k - 1) // 2, 1, groups)
-        return _dyconv(sd, f"{prefix}.{name}", x, h_c, cin, cout, k, stride, groups, temperature)
+            return F.conv2d(x, sd[f"{prefix}.{name}.module.weight"], None, stride, (k - 1) // 2 * dilation, dilation, groups)
+        return _dyconv(sd, f"{prefix}.{name}", x, h_c, cin, cout, k, stride, groups, temperature, dilation)
 
     # expand
     if c["cexp"] != c["cin"]:
         x = conv("exp_conv", x, c["cin"], c["cexp"], 1, 1, 1)
         x = _act(_bn(sd, prefix + ".exp_norm", x, train, stats), c["hs"])
     # depthwise + DyReLU-B (dy_block.py:172-188) + CoordAtt (195-201)
-    x = conv("depth_conv", x, c["cexp"], c["cexp"], c["k"], c["stride"], c["cexp"])
+    x = conv("depth_conv", x, c["cexp"], c["cexp"], c["k"], dw_stride, c["cexp"], dil)
     x = _bn(sd, prefix + ".depth_norm", x, train, stats)
     if no_dyrelu:
         x = _act(x, c["hs"])
@@ -383,10 +388,11 @@ REPLACE_SE_DY = (False, False, False, True, True, True, False, False, False, Fal
 
 def dymn_forward(sd, x, width_mult=1.0, strides=(2, 2, 2, 2), temperature=1.0, train=False,
                  stats=None, drop_mask=None, return_fmaps=False, use_dy_blocks="all", no_dyrelu=False, no_dyconv=False,
-                 no_ca=False, head_type="mlp"):
+                 no_ca=False, head_type="mlp", dilated=False, reduced_tail=False):
     """DyMN (dymn/model.py:157-200); use_dy_blocks "all" or "replace_se" (dymn/model.py:225-231: dynamic blocks only
-    where MobileNetV3 has SE, plain SE-less inverted residuals elsewhere, dymn/model.py:102-103)."""
-    blocks, _ = block_table(width_mult, strides)
+    where MobileNetV3 has SE, plain SE-less inverted residuals elsewhere, dymn/model.py:102-103); `dilated` / `reduced_tail`:
+    the last three blocks with dilation 2 / half the channels (_dymn_conf, dymn/model.py:212-250)."""
+    blocks, _ = block_table(width_mult, strides, reduced_tail, dilated)
     dy = (True,) * 15 if use_dy_blocks == "all" else REPLACE_SE_DY
     fmaps = []
     x = _cna(sd, "in_c", x, train, stats, 3, 2, 1, "hs")

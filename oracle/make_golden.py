@@ -214,6 +214,8 @@ DYMN_VARIANTS = {   # models/dymn/model.py:225-231; ablations of the dynamic blo
     # the fully-convolutional head of models/dymn/model.py:119-130 is reachable through the `dymn` factory only
     # (get_model has no head_type argument)
     "fc_head": dict(head_type="fully_convolutional"),
+    # dilation 2 in the last three blocks (models/dymn/model.py:212-218,246-250): through the `dymn` factory as well
+    "dilated": dict(dilated=True),
 }
 
 
@@ -225,7 +227,8 @@ def golden_dymn_variants(mel):
         x_cal = mel(synth.calibration_clips(96000)).unsqueeze(1)
         x = mel(synth.parity_clips(96000, seed=43)).unsqueeze(1)
     for tag, kw in DYMN_VARIANTS.items():
-        model = quiet(dymn_factory, width_mult=1.0, **kw) if "head_type" in kw else quiet(get_dymn, width_mult=1.0, **kw)
+        model = (quiet(dymn_factory, width_mult=1.0, **kw) if ("head_type" in kw or "dilated" in kw)
+                 else quiet(get_dymn, width_mult=1.0, **kw))
         sd = synth.synth_state(synth.shapes_of(model), seed=4)
         model.load_state_dict(sd, strict=True)
 

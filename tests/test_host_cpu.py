@@ -178,7 +178,7 @@ def test_audioset_dropin_never_falls_back_to_synthetic_silently(tmp_path, monkey
     for f in ("balanced_train_segments_mp3.hdf", "unbalanced_train_segments_mp3.hdf", "eval_segments_mp3.hdf"):
         (tmp_path / f).write_bytes(b"")
     mod = load()                                                        # real back-end selected (h5py is needed to open it)
-    assert mod.SYNTHETIC is False and mod.AudioSetDataset is mod._Hdf5AudioSet
+    assert mod.SYNTHETIC is False and mod.AudioSetDataset.__name__ == "Hdf5AudioSet"        # (dropin/datasets/_hdf5_reader.py)
     assert mod.dataset_config["eval_hdf5"].endswith("eval_segments_mp3.hdf")
 
 
@@ -309,3 +309,51 @@ def test_band_table_with_fixed_pairs_is_the_same_basis():
         assert bool((fixed[1] + 2 * P <= 512).all()) and bool((fixed[1] % 2 == 0).all())
     with pytest.raises(ValueError):
         band_table(basis, pairs=3)
+
+
+def test_hdf5_reader_round_trip(tmp_path, monkeypatch):
+    """dropin/datasets/_hdf5_reader.py (QUARANTINED: datasets/audioset.py:32-47,106-177 restated, never run where this
+    package was built): a 3-clip HDF5 + mp3 file written here and read back through the public `datasets.audioset` API.
+    Needs h5py and PyAV - skipped where they are missing, so a pass anywhere is the first execution of that file."""
+    h5py = pytest.importorskip("h5py")
+    av = pytest.importorskip("av")
+    import importlib.util
+    sr, n = 32000, 3
+    rng = np.random.default_rng(0)
+    names, blobs, targets = [], [], []
+    for i in range(n):
+        wave = (0.3 * np.sin(2 * np.pi * (300.0 + 200 * i) * np.arange(2 * sr) / sr)).astype(np.float32)
+        buf = io.BytesIO()
+        with av.open(buf, mode="w", format="mp3") as c:
+            st = c.add_stream("mp3", rate=sr)
+            frame = av.AudioFrame.from_ndarray(wave.reshape(1, -1), format="fltp", layout="mono")
+            frame.sample_rate = sr
+            for pkt in st.encode(frame):
+                c.mux(pkt)
+            for pkt in st.encode(None):
+                c.mux(pkt)
+        blobs.append(np.frombuffer(buf.getvalue(), dtype=np.uint8))
+        names.append(("Yclip%d.mp3" % i).encode())
+        y = (rng.random(527) < 0.01)
+        y[i] = True
+        targets.append(np.packbits(y))
+    for fn in ("balanced_train_segments_mp3.hdf", "unbalanced_train_segments_mp3.hdf", "eval_segments_mp3.hdf"):
+        with h5py.File(tmp_path / fn, "w") as f:
+            f.create_dataset("audio_name", data=np.array(names))
+            dt = h5py.vlen_dtype(np.dtype("uint8"))
+            d = f.create_dataset("mp3", (n,), dtype=dt)
+            for i, b in enumerate(blobs):
+                d[i] = b
+            f.create_dataset("target", data=np.stack(targets))
+    monkeypatch.delenv("EAT_SYNTH_AUDIOSET", raising=False)
+    monkeypatch.setenv("EAT_AUDIOSET_DIR", str(tmp_path))
+    spec = importlib.util.spec_from_file_location("eat_audioset_real", os.path.join(ROOT, "dropin", "datasets", "audioset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = mod.get_test_set()
+    assert len(ds) == n
+    x, name, y = ds[1]
+    assert x.shape == (1, 10 * sr) and x.dtype == np.float32 and name == "clip1" and y.shape == (527,) and y[1] == 1.0
+    assert 0.1 < np.abs(x[0, :2 * sr]).max() < 0.5 and np.abs(x[0, 3 * sr:]).max() == 0.0        # decoded tone, zero padding
+    assert ds.targets().shape == (n, 527)

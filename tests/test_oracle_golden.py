@@ -192,7 +192,9 @@ DYMN_VARIANTS = {"replace_se": (dict(use_dy_blocks="replace_se"), dict(use_dy_bl
                  "static": (dict(no_dyrelu=True, no_dyconv=True, no_ca=True),
                             dict(no_dyrelu=True, no_dyconv=True, no_ca=True)),
                  # fully-convolutional head (models/dymn/model.py:119-130): through the `dymn` factory, as in the reference
-                 "fc_head": (dict(head_type="fully_convolutional"), dict(head_type="fully_convolutional"))}
+                 "fc_head": (dict(head_type="fully_convolutional"), dict(head_type="fully_convolutional")),
+                 # dilation 2 in the last three (dynamic) blocks, models/dymn/model.py:212-218,246-250; dy_block.py:322-348
+                 "dilated": (dict(dilated=True), dict(dilated=True))}
 
 
 def dymn_variant_state(tag, golden_dir):
@@ -202,7 +204,7 @@ def dymn_variant_state(tag, golden_dir):
     g = np.load(os.path.join(golden_dir, "dymn_variants_ref.npz"))
     kw = DYMN_VARIANTS[tag][0]
     with contextlib.redirect_stdout(io.StringIO()):
-        model = dymn(width_mult=1.0, **kw) if "head_type" in kw else get_model(width_mult=1.0, **kw)
+        model = dymn(width_mult=1.0, **kw) if ("head_type" in kw or "dilated" in kw) else get_model(width_mult=1.0, **kw)
     shapes = synth.shapes_of(model)
     keys = [str(k) for k in g[f"{tag}/keys"]]                   # the reference's state_dict order (seeded draws follow it)
     assert sorted(keys) == sorted(shapes) and len(keys) == int(g[f"{tag}/n_state"])   # same state_dict layout

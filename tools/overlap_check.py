@@ -14,6 +14,13 @@ import json
 import sys
 
 
+def is_coll(name):
+    """RCCL device kernels: ncclDevKernel* on N > 1 ranks; with ONE rank (forced bucketing) RCCL short-circuits the ring and
+    runs its `oneRankReduce` copy / pre-multiply kernel on the communicator's stream instead."""
+    n = name.lower()
+    return "nccl" in n or "onerankreduce" in n or "rccl" in n
+
+
 def main(path, out):
     rows = []
     with open(path, newline="") as f:
@@ -24,18 +31,18 @@ def main(path, out):
     rows.sort()
     # a step starts at a mel_fwd_kernel dispatch (tools/pmc_traffic.py uses the same marker)
     starts = [i for i, r in enumerate(rows) if "mel_fwd_kernel" in r[2]]
-    nccl_idx = [i for i, r in enumerate(rows) if "nccl" in r[2].lower()]
+    nccl_idx = [i for i, r in enumerate(rows) if is_coll(r[2])]
     if not nccl_idx:
-        json.dump({"error": "no ncclDevKernel dispatch in the trace"}, open(out, "w"))
-        print("no ncclDevKernel dispatch in the trace")
+        json.dump({"error": "no RCCL kernel dispatch in the trace"}, open(out, "w"))
+        print("no RCCL kernel dispatch in the trace")
         return 1
     # last step that contains collectives
     last = max(i for i in starts if i < nccl_idx[-1])
     nxt = [i for i in starts if i > last]
     step = rows[last:(nxt[0] if nxt else len(rows))]
     t0 = step[0][0]
-    comp = [(s, e, n) for s, e, n in step if "nccl" not in n.lower()]
-    coll = [(s, e, n) for s, e, n in step if "nccl" in n.lower()]
+    comp = [(s, e, n) for s, e, n in step if not is_coll(n)]
+    coll = [(s, e, n) for s, e, n in step if is_coll(n)]
     res = []
     tot_c, tot_o = 0, 0
     for s, e, n in coll:
