@@ -85,7 +85,7 @@ SIGNATURES = {
     "eat_bn_finalize_partials": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _P, _P],
     "eat_bn_finalize_ws_doubles": [_I, _I, _I],
     "eat_pw_conv_gstats_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
-    "eat_bn_bwd_sums_from_tiles": [_P, _I, _I, _P, _P, _P, _P, _P],
+    "eat_bn_bwd_sums_from_tiles": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "eat_bn_bwd_sums_ws_doubles": [_I, _I],
     "eat_gram_bn_finalize": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _F, _D, _P, _P, _P, _P, _I, _P],
     "eat_gram_centered": [_P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -92,6 +92,10 @@ int pw_conv_bf16_tf(const float* x, const float* tf_a, const float* tf_b, int tf
 // BatchNorm-backward statistics in a 1x1 conv's epilogue (pw_epilogue.h: pw_epilogue_gstats): z = the tensor whose
 // BatchNorm + activation backward is being reduced (layout of the conv output), a / b = that BatchNorm's folded affine
 struct PwGStat { const void* z; const float* a; const float* b; int act; };
+// centring constant of the BatchNorm-backward partials of pw_epilogue_gstats (pw_epilogue.h) and of bn_bwd_sums_finish_kernel
+// (train_fuse.hip), from the BatchNorm's (a, b): the zero of the pre-activation.  ONE expression, so that the epilogue subtracts
+// and the finish adds back the same fp32 number.
+__host__ __device__ __forceinline__ float gstat_center(float a, float b) { return a != 0.0f ? -b / a : 0.0f; }
 
 int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample, const float* tf_a, const float* tf_b,
                        int tf_act, const float* in_scale, const float* zero_bias, float* y, float* part, int B, int Ci, int Co,

@@ -222,7 +222,7 @@ __device__ __forceinline__ void pw_gstats_rows(const acc_f32x4 (&acc)[MTW][4], c
       int m = mt0 * 16 + row;
       const float rok = m < Co ? ok : 0.0f;
       if (m >= Co) m = Co - 1;
-      const float bm = s_bias[row], av = s_ab[row], bv = s_ab[MTW * 16 + row];
+      const float bm = s_bias[row], av = s_ab[row], bv = s_ab[MTW * 16 + row], cv = s_ab[2 * MTW * 16 + row];
       const float4 zv = Io<ZT>::load4(zb + (size_t)m * S);
       const float v0 = Io<YT>::rnd(acc[i][0][r] + bm), v1 = Io<YT>::rnd(acc[i][1][r] + bm);
       const float v2 = Io<YT>::rnd(acc[i][2][r] + bm), v3 = Io<YT>::rnd(acc[i][3][r] + bm);
@@ -241,7 +241,10 @@ __device__ __forceinline__ void pw_gstats_rows(const acc_f32x4 (&acc)[MTW][4], c
         g0 = v0; g1 = v1; g2 = v2; g3 = v3;
       }
       float sm = ((g0 + g1) + (g2 + g3)) * rok;
-      float sq = fmaf(g0, zv.x, fmaf(g1, zv.y, fmaf(g2, zv.z, g3 * zv.w))) * rok;
+      // sum g (z - c) with c = -b / a, the zero of the pre-activation (within a few sigma of the channel mean): a channel whose
+      // |mean| >> sigma would otherwise lose in the fp32 tile partial of sum g z the digits the fp64 finish subtracts
+      // (eat_bn_bwd_sums_from_tiles adds (c - mean) sum g back)
+      float sq = fmaf(g0, zv.x - cv, fmaf(g1, zv.y - cv, fmaf(g2, zv.z - cv, g3 * (zv.w - cv)))) * rok;
       sm = row16_sum_lane15(sm);
       sq = row16_sum_lane15(sq);
       if ((lane & 15) == 15) {
@@ -255,13 +258,13 @@ template <int MTW, typename YT = float, typename ZT = float>
 __device__ __forceinline__ void pw_epilogue_gstats(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, float* scratch,
                                                    float* __restrict__ part, const PwGStat gs, int tile, int mt0, int kq,
                                                    int lane, int wv, bool col_ok, int bc, int sc_, int Co, int S) {
-  // stage a, b of the block's rows behind the wave partials: scratch[4 MTW 16 2 ...) = [2][MTW 16]
+  // stage a, b and the centring constant c of the block's rows behind the wave partials: scratch[4 MTW 16 2 ...) = [3][MTW 16]
   float* s_ab = scratch + 4 * MTW * 16 * 2;
-  for (int e = threadIdx.x; e < 2 * MTW * 16; e += 256) {
+  for (int e = threadIdx.x; e < 3 * MTW * 16; e += 256) {
     const int k = e / (MTW * 16), row = e - k * (MTW * 16);
     int m = mt0 * 16 + row;
     if (m >= Co) m = Co - 1;
-    s_ab[e] = (k == 0 ? gs.a : gs.b)[m];
+    s_ab[e] = k == 0 ? gs.a[m] : (k == 1 ? gs.b[m] : gstat_center(gs.a[m], gs.b[m]));
   }
   __syncthreads();
   const float ok = col_ok ? 1.0f : 0.0f;

@@ -528,7 +528,8 @@ extern "C" int eat_se_bn_bwd_combine(const float* P, const float* gscale, const 
 template <typename PT>
 __global__ __launch_bounds__(256) void bn_bwd_sums_finish_kernel(const PT* __restrict__ v, int rows, int C,
                                                                  const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, double* __restrict__ sums) {
+                                                                 const float* __restrict__ invstd, double* __restrict__ sums,
+                                                                 const float* __restrict__ ga, const float* __restrict__ gb) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double s0 = 0.0, s1 = 0.0;
@@ -546,7 +547,9 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_finish_kernel(const PT* __res
     s1 += (double)v[(size_t)r * 2 * C + C + c];
   }
   sums[c] = s0;
-  sums[C + c] = (double)invstd[c] * (s1 - (double)mean[c] * s0);
+  // ga / gb (the BatchNorm's a, b): the partials hold sum g (z - c), c = -b / a (pw_epilogue.h: gstat_center) - otherwise sum g z
+  const double ctr = ga ? (double)eat::gstat_center(ga[c], gb[c]) : 0.0;
+  sums[C + c] = (double)invstd[c] * (s1 + (ctr - (double)mean[c]) * s0);
 }
 
 // doubles of workspace eat_bn_finalize_partials wants for this shape (0: none - few partial rows)
@@ -582,9 +585,10 @@ extern "C" int eat_bn_bwd_sums_ws_doubles(int tiles, int C) { return tiles < 1 |
 
 // part: [tiles][2][C] from eat_pw_conv_gstats_fwd; ws: eat_bn_bwd_sums_ws_doubles(tiles, C) doubles (or NULL when that is 0)
 extern "C" int eat_bn_bwd_sums_from_tiles(const float* part, int tiles, int C, const float* mean, const float* invstd,
-                                          double* ws, double* sums, eat_stream_t stream) {
+                                          const float* g_a, const float* g_b, double* ws, double* sums, eat_stream_t stream) {
   eat::clear_stale_error();
-  if (!part || !mean || !invstd || !sums || tiles < 1 || C < 1) return eat::fail(EAT_EINVAL, "eat_bn_bwd_sums_from_tiles: bad arguments");
+  if (!part || !mean || !invstd || !sums || tiles < 1 || C < 1 || ((g_a == nullptr) != (g_b == nullptr)))
+    return eat::fail(EAT_EINVAL, "eat_bn_bwd_sums_from_tiles: bad arguments");
   const int G = bwd_tile_groups(tiles);
   if (G > 0 && !ws) return eat::fail(EAT_EINVAL, "eat_bn_bwd_sums_from_tiles: %d tiles need the row-group workspace", tiles);
   const dim3 grid((unsigned)((C + 255) / 256));
@@ -593,10 +597,10 @@ extern "C" int eat_bn_bwd_sums_from_tiles(const float* part, int tiles, int C, c
     hipLaunchKernelGGL(bn_partials_rowgroups_kernel, dim3((unsigned)((W + cw - 1) / cw), (unsigned)G), dim3(256), 0,
                        (hipStream_t)stream, part, tiles, W, ws);
     hipLaunchKernelGGL(bn_bwd_sums_finish_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)ws, G, C, mean,
-                       invstd, sums);
+                       invstd, sums, g_a, g_b);
   } else {
     hipLaunchKernelGGL(bn_bwd_sums_finish_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, part, tiles, C, mean, invstd,
-                       sums);
+                       sums, g_a, g_b);
   }
   return eat::check_launch("eat_bn_bwd_sums_from_tiles");
 }

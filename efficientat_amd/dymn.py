@@ -331,9 +331,8 @@ class DyMN(nn.Module):
                 taps = (blk.depth_conv.module.weight.flatten(1)).unsqueeze(0).expand(B, -1, -1).reshape(B * cexp, k * k).contiguous()
             else:
                 att = _attention(blk.depth_conv, h_c)
-                taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att).view(B * cexp, k * k)
-            z = ops.dw_conv_dilated(x.reshape(1, B * cexp, Fq, T), taps, torch.zeros(B * cexp, device=x.device), k, stride, dil,
-                                    ops.ACT_NONE).view(B, cexp, *ops.dilated_out(Fq, T, k, stride, dil))
+                taps = ops.dyn_aggregate(blk.depth_conv.weight.view(blk.depth_conv.k, -1), att)
+            z = ops.dw_conv_dyn_dilated(x.contiguous(), taps.view(B, cexp * k * k), k, stride, dil)
             x = ops.dyrelu_ca(z, w["depth"][0], w["depth"][1], act if blk.no_dyrelu else None,
                               None if blk.no_dyrelu else self._dyrelu_coef(blk, h_c, B, cexp), g_cf, g_ct)
         else:

@@ -345,9 +345,7 @@ class DynDwConv(torch.autograd.Function):
         if dilation > 1:
             # dilated dynamic block (models/dymn/model.py:212-218; dy_block.py:322-348): per-sample taps = a depthwise conv over
             # B * C independent planes - the batch folded into the channel axis of the generic dilated kernels
-            y = ops.dw_conv_dilated(x.view(1, B * C, Fq, T), taps.view(B * C, k * k), _zeros.get(B * C, x.device), k, stride,
-                                    dilation, NONE)
-            return y.view(B, C, y.shape[2], y.shape[3])
+            return ops.dw_conv_dyn_dilated(x, taps, k, stride, dilation)
         Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
         y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
         _lib.call("eat_dw_conv_dyn_fwd", x.data_ptr(), taps.data_ptr(), _zeros.get(C, x.device).data_ptr(), None, None,
@@ -362,9 +360,7 @@ class DynDwConv(torch.autograd.Function):
         k, stride, K = ctx.k, ctx.stride, weight.shape[2]
         Fo, To = dz.shape[2], dz.shape[3]
         if ctx.dilation > 1:
-            dzf, xf = dz.view(1, B * C, Fo, To), x.view(1, B * C, Fq, T)
-            dx = ops.dw_conv_dilated_dgrad(dzf, taps.view(B * C, k * k), xf.shape, k, stride, ctx.dilation).view(B, C, Fq, T)
-            G = ops.dw_conv_dilated_wgrad(dzf, xf, k, stride, ctx.dilation).view(B, C * k * k)
+            dx, G = ops.dw_conv_dyn_dilated_bwd(dz, x, taps, k, stride, ctx.dilation)
             dbank, datt = _bank_grad(G, att, weight.view(K, C * k * k))
             return dx, dbank.view_as(weight), datt, None, None, None
         dx = torch.empty_like(x)

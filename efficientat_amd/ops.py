@@ -107,6 +107,43 @@ def dilated_out(F, T, k, stride, dilation):
     return (F + 2 * pad - dilation * (k - 1) - 1) // stride + 1, (T + 2 * pad - dilation * (k - 1) - 1) // stride + 1
 
 
+def _plane_chunks(B, C):
+    """Batch ranges whose (samples x channels) planes fit the y dimension of a launch grid (65535)."""
+    step = max(1, 65535 // C)
+    return [(i, min(B, i + step)) for i in range(0, B, step)]
+
+
+def dw_conv_dyn_dilated(x, taps, k, stride, dilation):
+    """Dilated depthwise conv with PER-SAMPLE taps (B, C*k*k) - the depthwise DynamicConv of a dilated DY_Block
+    (models/dymn/dy_block.py:103-131,322-348): a depthwise conv over B * C independent planes, i.e. the generic dilated
+    kernels with the batch folded into the channel axis (in chunks of <= 65535 planes)."""
+    B, C, F, T = x.shape
+    Fo, To = dilated_out(F, T, k, stride, dilation)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    zb = _zero_bias(min(B, 65535 // C + 1) * C, x.device)
+    for b0, b1 in _plane_chunks(B, C):
+        n = (b1 - b0) * C
+        _lib.call("eat_dw_conv_dilated_fwd", _dev(x, "x") + 4 * b0 * C * F * T, _dev(taps, "taps") + 4 * b0 * C * k * k,
+                  zb.data_ptr(), y.data_ptr() + 4 * b0 * C * Fo * To, None, 1, n, F, T, Fo, To, k, stride, dilation, ACT_NONE,
+                  _stream())
+    return y
+
+
+def dw_conv_dyn_dilated_bwd(dz, x, taps, k, stride, dilation):
+    """-> (dx, G (B, C*k*k) per-plane tap gradients) of `dw_conv_dyn_dilated`."""
+    B, C, F, T = x.shape
+    Fo, To = dz.shape[2], dz.shape[3]
+    dx = torch.empty_like(x)
+    G = torch.empty((B, C * k * k), device=x.device, dtype=torch.float32)
+    for b0, b1 in _plane_chunks(B, C):
+        n = (b1 - b0) * C
+        _lib.call("eat_dw_conv_dilated_dgrad", _dev(dz, "dz") + 4 * b0 * C * Fo * To, _dev(taps, "taps") + 4 * b0 * C * k * k,
+                  dx.data_ptr() + 4 * b0 * C * F * T, 1, n, F, T, Fo, To, k, stride, dilation, _stream())
+        _lib.call("eat_dw_conv_dilated_wgrad", _dev(dz, "dz") + 4 * b0 * C * Fo * To, _dev(x, "x") + 4 * b0 * C * F * T,
+                  G.data_ptr() + 4 * b0 * C * k * k, 1, n, F, T, Fo, To, k, stride, dilation, _stream())
+    return dx, G
+
+
 def dyrelu_ca(z, a, b, act, coef, gate_f, gate_t):
     """BatchNorm affine (a, b per channel) + DyReLU-B (coef (B, C, 4); None: the plain activation `act`) + CoordAtt (position-
     major PRE-sigmoid gates (B*Fo, C) / (B*To, C); None: no attention) of a (B, C, Fo, To) tensor - the stand-alone kernel
@@ -992,8 +1029,8 @@ def pw_conv_gstats(x, wp, Co, z, st, act, sums=None):
         sums = torch.empty((2 * Co,), device=x.device, dtype=torch.float64)
     nws = int(_lib.lib().eat_bn_bwd_sums_ws_doubles(tiles, Co))
     ws = torch.empty((nws,), device=x.device, dtype=torch.float64) if nws else None
-    _lib.call("eat_bn_bwd_sums_from_tiles", part.data_ptr(), tiles, Co, mean.data_ptr(), invstd.data_ptr(),
-              None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
+    _lib.call("eat_bn_bwd_sums_from_tiles", part.data_ptr(), tiles, Co, mean.data_ptr(), invstd.data_ptr(), a.data_ptr(),
+              b.data_ptr(), None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
     return y, sums
 
 
@@ -1242,7 +1279,7 @@ def pw_conv_b16(x, wp, bias, Co, act, tf=None, in_scale=None, res=None, x2=None,
         nws = int(_lib.lib().eat_bn_bwd_sums_ws_doubles(tiles, Co))
         ws = torch.empty((nws,), device=x.device, dtype=torch.float64) if nws else None
         _lib.call("eat_bn_bwd_sums_from_tiles", part.data_ptr(), tiles, Co, gst[2].data_ptr(), gst[3].data_ptr(),
-                  None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
+                  gst[0].data_ptr(), gst[1].data_ptr(), None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
         return y, sums
     return (y, (part, tiles, 1)) if stats else y
 

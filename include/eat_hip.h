@@ -197,7 +197,7 @@ int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, con
 /* Data-gradient GEMM of the project conv, y = W^T dz_p (wp: eat_pw_prepack_t / eat_pw_prepack_bf16_t pack of the project
  * weight, wmode 0 = fp32, 2 = bf16 hi / lo), with the backward statistics of the depthwise conv's BatchNorm + activation
  * (autograd through block_types.py:150-162) in its epilogue: part [tiles][2][Co], tiles = eat_pw_conv_stat_tiles(B, S, 0),
- * holds per 256-column tile the sums of g and of g z_d with g = y * act'(g_a z_d + g_b); gz = z_d (B, Co, S).  Replaces
+ * holds per 256-column tile the sums of g and of g (z_d - c), c = -g_b / g_a, with g = y * act'(g_a z_d + g_b); gz = z_d (B, Co, S).  Replaces
  * eat_bn_act_bwd_reduce over (y, z_d) where no SE gate sits between the two (gscale / gadd = NULL there).  Returns 1 and
  * launches nothing when S % 4 != 0.  eat_bn_bwd_sums_from_tiles turns the partials into the sums eat_bn_act_bwd_apply /
  * eat_dw_conv_bwd_bn_g read (ws: eat_bn_bwd_sums_ws_doubles(tiles, C) doubles, NULL when that is 0). */
@@ -205,8 +205,11 @@ int eat_pw_conv_gstats_fwd(const float* x, const void* wp, int wmode, const floa
                            const float* g_a, const float* g_b, int g_act, float* part, int B, int Ci, int Co, int S,
                            eat_stream_t stream);
 int eat_bn_bwd_sums_ws_doubles(int tiles, int C);
-int eat_bn_bwd_sums_from_tiles(const float* part, int tiles, int C, const float* mean, const float* invstd, double* ws,
-                               double* sums, eat_stream_t stream);
+/* g_a / g_b: the BatchNorm's (a, b) the partials were taken with - the epilogue accumulates sum g (z_d - c), c = -g_b / g_a (the
+ * zero of the pre-activation: no cancellation against a large channel mean in the fp32 tile partials), and this call adds
+ * (c - mean) sum g back in fp64; both NULL: partials of the uncentred sum g z_d. */
+int eat_bn_bwd_sums_from_tiles(const float* part, int tiles, int C, const float* mean, const float* invstd, const float* g_a,
+                               const float* g_b, double* ws, double* sums, eat_stream_t stream);
 
 /* Centred Gram matrix of a conv input x (B, C, S) (the statistics of the conv1x1 -> nn.BatchNorm2d pair of
  * models/mn/block_types.py:138-147 without reading the conv output): Gc = sum_{b,s} (x - m)(x - m)^T, m = sx * inv_n the

@@ -173,6 +173,36 @@ def test_data_gradient_conv_with_batchnorm_backward_sums_in_its_epilogue(B, Ci, 
     assert float((ref[:Co].cpu() - s0.cpu()).abs().max()) < 2e-6 * scale0          # (the pass it replaces, same bar)
 
 
+@pytest.mark.parametrize("shift", [10.0, 300.0])
+def test_batchnorm_backward_sums_epilogue_with_large_channel_means(shift):
+    """the epilogue's fp32 tile partials hold sum g (z_d - c), c = -b / a (the zero of the BatchNorm's
+    pre-activation, within a few sigma of the channel mean), not sum g z_d - a channel with |mean| = 300 sigma keeps its
+    digits: the centred sum is held to 1e-5 of sum |g (z_d - mean)| (the uncentred form is off by ~|mean| / sigma x fp32 eps)."""
+    B, Ci, Co, F_, T = 4, 24, 72, 16, 125
+    dz = _rand(B, Ci, F_, T, seed=1).to(DEV)
+    W = _rand(Ci, Co, seed=2, scale=Ci ** -0.5).to(DEV)
+    sigma = (torch.rand(Co, generator=torch.Generator().manual_seed(3)) + 0.5)
+    mu = _rand(Co, seed=4) * shift * sigma
+    z_d = (_rand(B, Co, F_, T, seed=5) * sigma[None, :, None, None] + mu[None, :, None, None]).to(DEV)
+    mean = z_d.double().mean((0, 2, 3)).float()
+    invstd = (z_d.double().var((0, 2, 3), unbiased=False) + 1e-3).rsqrt().float()
+    gamma = (torch.rand(Co, generator=torch.Generator().manual_seed(6)) + 0.5).to(DEV)
+    beta = _rand(Co, seed=7, scale=0.3).to(DEV)
+    a = gamma * invstd
+    b = beta - mean * a
+    with ops.precision("fp32"):
+        wpt = ops.pw_prepack(W, trans=True)
+        y, sums = ops.pw_conv_gstats(dz, wpt, Co, z_d, (a, b, mean, invstd), ops.ACT_RELU)
+    u = a.double()[None, :, None, None] * z_d.double() + b.double()[None, :, None, None]
+    g = y.double() * (u > 0).double()
+    zc = z_d.double() - mean.double()[None, :, None, None]
+    s1 = invstd.double() * (g * zc).sum((0, 2, 3))
+    scale = invstd.double() * (g * zc).abs().sum((0, 2, 3))
+    err = float(((sums[Co:] - s1).abs() / scale.clamp_min(1e-30)).max())
+    assert err < 1e-5, err
+    assert float((sums[:Co] - g.sum((0, 2, 3))).abs().max()) < 2e-6 * float(g.abs().sum((0, 2, 3)).max())
+
+
 @pytest.mark.parametrize("outer,C,inner", [(32000, 16, 1), (8000, 24, 1), (256, 16, 16), (256, 64, 16), (5000, 130, 1),
                                            (300, 7, 9), (2047, 1, 1), (2048, 1, 1), (100, 40, 1)])
 def test_bn_finalize_from_many_partial_rows(outer, C, inner):

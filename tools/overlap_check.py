@@ -60,7 +60,7 @@ def main(path, out):
         if cur_b is not None:
             cov += cur_b - cur_a
         names = sorted({cn.split("(")[0][:60] for _, _, cn in inter})
-        res.append({"kernel": n.split("(")[0][:80], "start_us": round((s - t0) / 1e3, 1), "end_us": round((e - t0) / 1e3, 1),
+        res.append({"kernel": n.replace("void ", "").split("(")[0][:80], "start_us": round((s - t0) / 1e3, 1), "end_us": round((e - t0) / 1e3, 1),
                     "duration_us": round((e - s) / 1e3, 1), "compute_kernels_running_during_it": len(inter),
                     "fraction_overlapped_by_compute": round(cov / max(1, e - s), 3), "examples": names[:4]})
         tot_c += e - s
