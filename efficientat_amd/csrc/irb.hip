@@ -121,7 +121,7 @@ __device__ __forceinline__ void dw_finish(const DwAcc<NT>& a, f32x4 (&d)[NT]) {
 //   residual (= the stem output) is the middle row of the register window, in the accumulator layout already.
 //   F, T (a.F, a.T) are then the STEM plane, a.Fm / a.Tm the log-mel plane; ACT_E = Hardswish.
 template <int K, int S, int NKS, int NT, int MTI, int MTO, int ACT, bool PROJ, bool PF, int ACT_E = ACT, bool FRONT = false>
-__global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
+__global__ __launch_bounds__(64 * kWaves, ((NT == 1 && MTI * K < 25 && K != 5) ? 3 : 2)) void irb_kernel(const IrbArgs a) {
   static_assert(!FRONT || (K == 3 && S == 1 && NKS == 3 && MTI == 1 && PROJ), "front = stem + 3x3/s1 block with project");
   constexpr int kNT = NT;
   constexpr int P_ = (K - 1) / 2, KK = K * K;
@@ -525,7 +525,7 @@ int irb_dispatch(IrbArgs a, int k, int stride, int act, bool dry, hipStream_t s)
     return 1;
   }
   if (k == 5 && stride == 2 && a.Cin == 24) {
-    if (MT == 5) EAT_IRB_GO(5, 2, 6, 1, 5, 1, R, false, false);
+    if (MT == 5) EAT_IRB_GO(5, 2, 6, 1, 3, 1, R, false, false);
     EAT_IRB_GO(5, 2, 6, 2, 1, 1, R, false, false);
   }
   if (k == 3 && stride == 2 && a.Cin == 16) EAT_IRB_GO(3, 2, 4, 2, 1, 1, R, false, false);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
     const float* __restrict__ sx, const float* __restrict__ gpart, int outer, int inner, int Co, int Ci,
     const float* __restrict__ a, const float* __restrict__ mean, const float* __restrict__ invstd, double n, int frozen,
     float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ WaT,
-    float* __restrict__ WT, float* __restrict__ W2T, float* __restrict__ e1, int centered) {
+    float* __restrict__ WT, float* __restrict__ W2T, float* __restrict__ e1, int centered, float* __restrict__ e2_out) {
   // centered: Tm = W Gc with the centred Gram matrix Gc = sum (x - m)(x - m)^T (eat_gram_centered): T - mu sx^T IS W Gc -
   // the difference is taken term by term at accumulation time instead of between two (mu/sigma)^2-times larger sums.
   // (Gx - m1 sx^T and w.Gx - mu S1 lose only one factor mu/sigma, in fp64 here: Gx stays the plain sum g x^T.)
@@ -431,15 +431,116 @@ __global__ __launch_bounds__(256) void expand_bwd_coef_kernel(
     e1[c] = (float)(av * (m2 * is * mu - m1));
   }
   const double e2 = av * m2 * is;
+  if (threadIdx.x == 0 && e2_out) e2_out[c] = (float)e2;
   for (int k = threadIdx.x; k < Ci; k += blockDim.x) {
     const size_t idx = (size_t)c * Ci + k;
     const double sxk = (double)sx[k], w = (double)W[idx];
     const double tc = centered ? (double)Tm[idx] : (double)Tm[idx] - mu * sxk;
     dW[idx] = (float)(av * ((double)Gx[idx] - m1 * sxk - m2 * is * tc));
-    const size_t tdx = (size_t)k * Co + c;
-    WaT[tdx] = (float)(av * w);
-    WT[tdx] = (float)w;
-    W2T[tdx] = (float)(-e2 * w);
+    if (WaT) {                                   // (NULL: the caller takes the packed form of eat_expand_bwd_wcat instead)
+      const size_t tdx = (size_t)k * Co + c;
+      WaT[tdx] = (float)(av * w);
+      WT[tdx] = (float)w;
+      W2T[tdx] = (float)(-e2 * w);
+    }
+  }
+}
+
+// ---- (3b) the operands of dx = [WaT | M] [g ; x] + c0 straight in MFMA-fragment order (round 6) -----------------------------
+// Before: eat_expand_bwd_coef wrote three Ci x Co transposes, a prepack launch packed [W2T ; e1], a 1x1-conv launch formed
+// [M ; c0] = [W2T ; e1] W, torch.cat glued [WaT | M] and another prepack launch packed it - five latency-bound launches per
+// block per step (mn10: 14 blocks, ~0.67 ms + their boundaries).  Here ONE launch writes the pack of
+//   Wcat (Ci x (Co + Ci)):  Wcat[i][k] = a[k] W[k][i]                       for k <  Co   (WaT)
+//                           Wcat[i][Co + j] = -sum_c e2[c] W[c][i] W[c][j]  (M, exact fp32 MFMA over c)
+// and c0[i] = sum_c e1[c] W[c][i].  Every pack element has exactly one owner (address = pure function of (i, k)), rows
+// beyond Ci and the k padding are written as zeros.  kind: 0 fp32 fragments (eat_pw_prepack), 1 bf16, 2 bf16 hi + lo
+// (eat_pw_prepack_bf16) - bit-identical layouts.
+template <int KIND>
+__device__ __forceinline__ void wcat_store(void* __restrict__ wp, int MT, int i, int k, float v) {
+  const int mt = i >> 4;
+  if constexpr (KIND == 0) {
+    reinterpret_cast<float*>(wp)[((size_t)(k >> 2) * MT + mt) * 64 + (i & 15) + 16 * (k & 3)] = v;
+  } else {
+    constexpr int NP2 = KIND == 2 ? 2 : 1;
+    const int r = k & 31;
+    const size_t base = ((size_t)((k >> 5) * MT + mt) * NP2) * 512 + ((i & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+    __bf16* w16 = reinterpret_cast<__bf16*>(wp);
+    const __bf16 hi = (__bf16)v;
+    w16[base] = hi;
+    if constexpr (KIND == 2) w16[base + 512] = (__bf16)(v - (float)hi);
+  }
+}
+
+using wc_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void expand_bwd_wcat_kernel(const float* __restrict__ W, const float* __restrict__ a,
+                                                              const float* __restrict__ e2, const float* __restrict__ e1,
+                                                              int Co, int Ci, int MT, int Kpad, void* __restrict__ wp,
+                                                              float* __restrict__ c0) {
+  __shared__ float s_acc[3][4][64];
+  __shared__ float s_c0[16][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n_tiles = MT * MT;
+  if ((int)blockIdx.x >= n_tiles) {
+    // ---- elementwise part: WaT and the zero padding of the k axis
+    const int I16 = MT * 16;
+    const long long e = (long long)(blockIdx.x - n_tiles) * 256 + tid;
+    const int kidx = (int)(e / I16), i = (int)(e - (long long)kidx * I16);
+    const int n_k = Co + (Kpad - Co - Ci);
+    if (kidx >= n_k) return;
+    const int k = kidx < Co ? kidx : Ci + kidx;                       // (padding columns sit behind the M part)
+    const float v = (kidx < Co && i < Ci) ? a[k] * W[(size_t)k * Ci + i] : 0.0f;
+    wcat_store<KIND>(wp, MT, i, k, v);
+    return;
+  }
+  // ---- one 16 x 16 tile of M: four waves split the reduction over the Co channels
+  const int it = blockIdx.x / MT, jt = blockIdx.x - it * MT;
+  const int i = it * 16 + (lane & 15), j = jt * 16 + (lane & 15), kq = lane >> 4;
+  const bool iv = i < Ci, jv = j < Ci;
+  const int steps = (Co + 3) / 4, per = (steps + 3) / 4;
+  const int s0 = wv * per, s1 = (s0 + per) < steps ? (s0 + per) : steps;
+  wc_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int sb = s0; sb < s1; sb += 8) {                                   // 8 k-steps of loads in flight per round
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = (sb + u) * 4 + kq;
+      const bool ok = (sb + u) < s1 && c < Co;
+      const int cc = ok ? c : 0;
+      const float wi = W[(size_t)cc * Ci + (iv ? i : 0)], wj = W[(size_t)cc * Ci + (jv ? j : 0)];
+      av[u] = (ok && iv) ? e2[cc] * wi : 0.0f;
+      bv[u] = (ok && jv) ? wj : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_acc[wv - 1][r][lane] = acc[r];
+  }
+  // c0 of this row tile (first column tile only): 16 row groups x 16 columns
+  float pc = 0.0f;
+  if (jt == 0) {
+    const int ci = it * 16 + (tid & 15), rg = tid >> 4;
+    if (ci < Ci)
+      for (int c = rg; c < Co; c += 16) pc = fmaf(e1[c], W[(size_t)c * Ci + ci], pc);
+    s_c0[rg][tid & 15] = pc;
+  }
+  __syncthreads();
+  if (jt == 0 && tid < 16) {
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += s_c0[r][tid];
+    if (it * 16 + tid < Ci) c0[it * 16 + tid] = t;
+  }
+  if (wv != 0) return;
+  // C / D layout of the MFMA: lane (kq, n) holds rows 4 kq + r of column n
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = acc[r] + s_acc[0][r][lane] + s_acc[1][r][lane] + s_acc[2][r][lane];
+    const int mi = it * 16 + kq * 4 + r, mj = jt * 16 + (lane & 15);
+    if (mj < Ci) wcat_store<KIND>(wp, MT, mi, Co + mj, (mi < Ci) ? -v : 0.0f);
   }
 }
 
@@ -631,10 +732,37 @@ extern "C" int eat_gram_bn_finalize_g(const float* G, const float* W, const floa
 extern "C" int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart,
                                    int outer, int inner, int Co, int Ci, const float* a, const float* mean,
                                    const float* invstd, double n, int frozen, float* dW, float* dgamma, float* dbeta,
-                                   float* WaT, float* WT, float* W2T, float* e1, int centered, eat_stream_t stream) {
+                                   float* WaT, float* WT, float* W2T, float* e1, int centered, float* e2, eat_stream_t stream) {
   eat::clear_stale_error();
   if (Co < 1 || Ci < 1 || outer < 1 || inner < 1) return eat::fail(EAT_EINVAL, "eat_expand_bwd_coef: bad shape");
+  if ((WaT == nullptr) != (WT == nullptr) || (WaT == nullptr) != (W2T == nullptr))
+    return eat::fail(EAT_EINVAL, "eat_expand_bwd_coef: the three transposes come together (or none)");
   hipLaunchKernelGGL(expand_bwd_coef_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, W, Gx, Tm, sx, gpart,
-                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, WT, W2T, e1, centered);
+                     outer, inner, Co, Ci, a, mean, invstd, n, frozen, dW, dgamma, dbeta, WaT, WT, W2T, e1, centered, e2);
   return eat::check_launch("eat_expand_bwd_coef");
+}
+
+// floats (kind 0) / bf16 elements (kinds 1, 2) of the pack eat_expand_bwd_wcat writes
+extern "C" int eat_expand_bwd_wcat_elems(int Co, int Ci, int kind) {
+  if (Co < 1 || Ci < 1 || kind < 0 || kind > 2) return 0;
+  const long long MT = (Ci + 15) / 16, K = (long long)Co + Ci;
+  const long long n = kind == 0 ? (K / 4) * MT * 64 : ((K + 31) / 32) * MT * (kind == 2 ? 2 : 1) * 512;
+  return n > 0x7fffffffLL ? 0 : (int)n;
+}
+
+extern "C" int eat_expand_bwd_wcat(const float* W, const float* a, const float* e2, const float* e1, int Co, int Ci, int kind,
+                                   void* wp, float* c0, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!W || !a || !e2 || !e1 || !wp || !c0 || Co < 1 || Ci < 1 || kind < 0 || kind > 2)
+    return eat::fail(EAT_EINVAL, "eat_expand_bwd_wcat: bad arguments");
+  if (((Co + Ci) & 3) != 0) return eat::fail(EAT_EINVAL, "eat_expand_bwd_wcat: Co + Ci = %d must be a multiple of 4", Co + Ci);
+  const int MT = (Ci + 15) / 16;
+  const int Kpad = kind == 0 ? Co + Ci : ((Co + Ci + 31) / 32) * 32;
+  const long long ew = (long long)MT * 16 * (Co + (Kpad - Co - Ci));
+  const unsigned grid = (unsigned)(MT * MT + (ew + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 0) hipLaunchKernelGGL(expand_bwd_wcat_kernel<0>, dim3(grid), dim3(256), 0, s, W, a, e2, e1, Co, Ci, MT, Kpad, wp, c0);
+  else if (kind == 1) hipLaunchKernelGGL(expand_bwd_wcat_kernel<1>, dim3(grid), dim3(256), 0, s, W, a, e2, e1, Co, Ci, MT, Kpad, wp, c0);
+  else hipLaunchKernelGGL(expand_bwd_wcat_kernel<2>, dim3(grid), dim3(256), 0, s, W, a, e2, e1, Co, Ci, MT, Kpad, wp, c0);
+  return eat::check_launch("eat_expand_bwd_wcat");
 }

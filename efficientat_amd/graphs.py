@@ -120,8 +120,11 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, x, y):
-        self.x.copy_(x)
-        self.y.copy_(y)
+        # (a producer that wrote straight into the captured input buffers - e.g. `mel(wave, out=step.x)` - passes them back)
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x)
+        if y.data_ptr() != self.y.data_ptr():
+            self.y.copy_(y)
         self.graph.replay()
         cache = getattr(self.model, "_cache", None)
         if cache is not None:            # a replay updates the weights without bumping their version counters

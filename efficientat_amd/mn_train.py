@@ -335,26 +335,30 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
             n_e = inp.shape[0] * inp.shape[2] * inp.shape[3]
             Gx = wgrad(g_e, inp)
             Tm, sx = (Gx, st_e[2]) if frozen else (rec["Tm"], rec["sx"])      # frozen: not read (m1 = m2 = 0)
-            dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
-                                                             frozen=frozen, centered=not frozen,
-                                                             dW_out=g.alloc(f"{pre}.{blk.i_expand}.0.weight", cna_e[0].weight))
+            S_e = inp.shape[2] * inp.shape[3]
+            o_e = g.alloc(f"{pre}.{blk.i_expand}.0.weight", cna_e[0].weight)
+            cat_b16 = b16 and not frozen and _CAT_DGRAD and cnf.expanded_channels % 32 == 0
+            cat_f32 = not b16 and not frozen and _CAT_DGRAD and S_e % 4 == 0
+            if cat_b16 or cat_f32:
+                # dx = [WaT | M] [g ; x] + c0 (+ residual-branch gradient): one GEMM over both tensors, its weight pack and
+                # bias from ONE launch after the coefficient kernel (round 6: was transposes + pack + M GEMM + cat + pack)
+                dW, dgam, dbet, wcat, c0 = ops.expand_bwd_coef_cat(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
+                                                                   centered=True, dW_out=o_e)
+            else:
+                dW, dgam, dbet, WaT, M, c0 = ops.expand_bwd_coef(W, Gx, Tm, sx, gparts, st_e[0], st_e[2], st_e[3], n_e,
+                                                                 frozen=frozen, centered=not frozen, dW_out=o_e)
             g[f"{pre}.{blk.i_expand}.1.weight"], g[f"{pre}.{blk.i_expand}.1.bias"] = dgam, dbet
             g[f"{pre}.{blk.i_expand}.0.weight"] = dW.view_as(cna_e[0].weight)
-            S_e = inp.shape[2] * inp.shape[3]
-            if b16:
-                # the same GEMMs with g read from its bf16 storage; two-source form where g's channels fill whole k-chunks
-                if not frozen and _CAT_DGRAD and cnf.expanded_channels % 32 == 0:
-                    wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
-                    dout = ops.pw_conv_b16(g_e, wcat, c0, cnf.input_channels, NONE, x2=inp, res=res_grad)
-                else:
-                    t = res_grad
-                    if not frozen:
-                        t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
-                    dout = ops.pw_conv_b16(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
-                                           NONE, res=t)
-            elif not frozen and _CAT_DGRAD and S_e % 4 == 0:
-                # dx = [WaT | M] [g ; x] + c0 (+ residual-branch gradient): one GEMM over both tensors
-                wcat = ops.pw_prepack(torch.cat([WaT, M], dim=1))
+            if cat_b16:
+                # the same GEMM with g read from its bf16 storage (g's channels fill whole k-chunks)
+                dout = ops.pw_conv_b16(g_e, wcat, c0, cnf.input_channels, NONE, x2=inp, res=res_grad)
+            elif b16:
+                t = res_grad
+                if not frozen:
+                    t = ops.pw_conv(inp, ops.pw_prepack(M), c0, cnf.input_channels, NONE, res=res_grad)
+                dout = ops.pw_conv_b16(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
+                                       NONE, res=t)
+            elif cat_f32:
                 dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad)
             else:
                 t = res_grad

@@ -854,7 +854,7 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, nee
     _lib.call("eat_expand_bwd_coef", _dev(W, "W"), _dev(Gx, "Gx"), _dev(Tm, "Tm"), _dev(sx, "sx"), gpart.data_ptr(),
               outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 1 if frozen else 0,
               dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), tr[0].data_ptr(), tr[1].data_ptr(), tr[2].data_ptr(),
-              w2e[Ci].data_ptr(), 1 if centered else 0, _stream())
+              w2e[Ci].data_ptr(), 1 if centered else 0, None, _stream())
     if frozen or not need_dx:
         return dW, vec[0], vec[1], tr[0], None, None
     if precision.mode != "fp32" and Ci % 4 == 0 and Co % 4 == 0 and W.is_contiguous():
@@ -866,6 +866,41 @@ def expand_bwd_coef(W, Gx, Tm, sx, gparts, a, mean, invstd, n, frozen=False, nee
     else:
         Mc = linear(w2e, tr[1], None, ACT_NONE)                            # [W2T ; e1] . WT^T -> (Ci + 1, Ci)
     return dW, vec[0], vec[1], tr[0], Mc[:Ci], Mc[Ci]
+
+
+def cat_pack_kind(K):
+    """The pack `pw_prepack` would choose for a matrix with K reduction channels under the active precision
+    (0 fp32 fragments, 1 bf16, 2 bf16 hi + lo)."""
+    m = precision.mode
+    if m == "bf16":
+        return 1
+    if m == "bf16x3" or (m == "auto" and K >= 40 and K % 4 == 0):
+        return 2
+    return 0
+
+
+def expand_bwd_coef_cat(W, Gx, Tm, sx, gparts, a, mean, invstd, n, centered=False, dW_out=None):
+    """`expand_bwd_coef` for the two-source data-gradient GEMM: -> (dW, dgamma, dbeta, wcat, c0) with wcat = the weight pack
+    of [WaT | M] (Ci x (Co + Ci)) and c0 (Ci) written by ONE launch (csrc/train_fuse.hip: eat_expand_bwd_wcat) - no
+    transposes, no separate M GEMM, no torch.cat, no prepack launches.  Training BatchNorm (not frozen) only."""
+    gpart, outer, inner = gparts
+    Co, Ci = W.shape
+    dev = W.device
+    dW = dW_out if dW_out is not None else torch.empty((Co, Ci), device=dev, dtype=torch.float32)
+    vec = torch.empty((4, Co), device=dev, dtype=torch.float32)           # dgamma, dbeta, e1, e2
+    _lib.call("eat_expand_bwd_coef", _dev(W, "W"), _dev(Gx, "Gx"), _dev(Tm, "Tm"), _dev(sx, "sx"), gpart.data_ptr(),
+              outer, inner, Co, Ci, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(n), 0,
+              dW.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), None, None, None, vec[2].data_ptr(),
+              1 if centered else 0, vec[3].data_ptr(), _stream())
+    kind = cat_pack_kind(Co + Ci)
+    nel = int(_lib.lib().eat_expand_bwd_wcat_elems(Co, Ci, kind))
+    wcat = torch.empty((nel,), device=dev, dtype=torch.float32 if kind == 0 else torch.bfloat16)
+    if kind == 2:
+        wcat._eat_split = True
+    c0 = torch.empty((Ci,), device=dev, dtype=torch.float32)
+    _lib.call("eat_expand_bwd_wcat", _dev(W, "W"), a.data_ptr(), vec[3].data_ptr(), vec[2].data_ptr(), Co, Ci, kind,
+              wcat.data_ptr(), c0.data_ptr(), _stream())
+    return dW, vec[0], vec[1], wcat, c0
 
 
 # ------------------------------------------------------------------------- DyMN launchers

@@ -278,11 +278,22 @@ int eat_dw_conv_bwd_g(const float* dz, const float* x, const float* in_a, const 
  * and the operands of dx = WaT g + M x + c0 (two eat_pw_conv_fwd launches), all Ci x Co transposes so that
  * eat_linear_fwd (which contracts over the contiguous axis) forms M = W2T . WT^T (Ci x Ci) and c0 = e1 . WT^T (Ci):
  *   WaT = (diag(a) W)^T,  WT = W^T,  W2T = -(diag(a m2 invstd) W)^T,  e1 = a (m2 invstd mean - m1) (Co).
- * centered != 0: Tm = W Gc (eat_gram_centered), i.e. "Tm - mean sx^T" is already inside the operand. */
+ * centered != 0: Tm = W Gc (eat_gram_centered), i.e. "Tm - mean sx^T" is already inside the operand.
+ * WaT / WT / W2T may be NULL together (round 6): the caller then takes e2 = a m2 invstd (Co; may be NULL otherwise) and
+ * forms the operands with eat_expand_bwd_wcat. */
 int eat_expand_bwd_coef(const float* W, const float* Gx, const float* Tm, const float* sx, const float* gpart, int outer,
                         int inner, int Co, int Ci, const float* a, const float* mean, const float* invstd, double n,
                         int frozen, float* dW, float* dgamma, float* dbeta, float* WaT, float* WT, float* W2T, float* e1,
-                        int centered, eat_stream_t stream);
+                        int centered, float* e2, eat_stream_t stream);
+
+/* The operands of dx = [WaT | M] [g ; x] + c0 (previous comment) written straight as the weight pack of the two-source
+ * data-gradient GEMM (eat_pw_conv_cat_fwd / eat_pw_conv_b16_fwd with x2) - one launch instead of transposes + pack + GEMM +
+ * concatenation + pack:  Wcat (Ci x (Co + Ci)) = [ (diag(a) W)^T | -W^T diag(e2) W ],  c0 = W^T e1 (Ci).
+ * kind 0: fp32 fragments (the layout of eat_pw_prepack), 1: bf16, 2: bf16 hi + lo (eat_pw_prepack_bf16); wp holds
+ * eat_expand_bwd_wcat_elems(Co, Ci, kind) elements; M is accumulated on the exact fp32 MFMA whatever the kind. */
+int eat_expand_bwd_wcat_elems(int Co, int Ci, int kind);
+int eat_expand_bwd_wcat(const float* W, const float* a, const float* e2, const float* e1, int Co, int Ci, int kind, void* wp,
+                        float* c0, eat_stream_t stream);
 
 /* eat_dw_conv_bwd_g with the BatchNorm + activation backward of the depthwise conv's OWN output evaluated on load
  * (autograd through models/mn/block_types.py:150-162 -> :72-83): dy (B,C,Fo,To) is the gradient w.r.t. act(BN(z)) - for a

@@ -647,3 +647,43 @@ def test_all_weight_packs_from_one_launch(mode):
     with ops.precision("fp32" if mode != "fp32" else "auto"):
         assert plan.stale()
 
+
+
+# (round 6) operands of the expand data gradient dx = [WaT | M] [g ; x] + c0 written straight as the GEMM's weight pack
+@pytest.mark.parametrize("Co,Ci", [(64, 16), (72, 24), (120, 40), (240, 40), (184, 80), (672, 112), (960, 160), (40, 24), (88, 24)])
+@pytest.mark.parametrize("mode", ["fp32", "auto", "bf16"])
+def test_expand_backward_operand_pack_from_one_launch(Co, Ci, mode):
+    """eat_expand_bwd_wcat: Wcat = [(diag(a) W)^T | -W^T diag(e2) W] in MFMA-fragment order + c0 = W^T e1, against fp64 through
+    the two-source GEMM that consumes the pack (every pack kind; ragged row tiles Ci = 24 / 40, k padding; every element of the
+    pack written - it starts as NaN)."""
+    B, F_, T = 2, 8, 24
+    W = _rand(Co, Ci, seed=1, scale=Ci ** -0.5).to(DEV)
+    a = (torch.rand(Co, generator=torch.Generator().manual_seed(2)) + 0.5).to(DEV)
+    e2 = _rand(Co, seed=3, scale=0.3).to(DEV)
+    e1 = _rand(Co, seed=4, scale=0.3).to(DEV)
+    g = _rand(B, Co, F_, T, seed=5).to(DEV)
+    x = _rand(B, Ci, F_, T, seed=6).to(DEV)
+    with ops.precision(mode):
+        kind = ops.cat_pack_kind(Co + Ci)
+        assert kind == {"fp32": 0, "bf16": 1}.get(mode, 2 if Co + Ci >= 40 else 0)
+        nel = int(_lib.lib().eat_expand_bwd_wcat_elems(Co, Ci, kind))
+        wcat = torch.full((nel,), float("nan"), device=DEV, dtype=torch.float32 if kind == 0 else torch.bfloat16)
+        if kind == 2:
+            wcat._eat_split = True
+        c0 = torch.full((Ci,), float("nan"), device=DEV)
+        _lib.call("eat_expand_bwd_wcat", W.data_ptr(), a.data_ptr(), e2.data_ptr(), e1.data_ptr(), Co, Ci, kind,
+                  wcat.data_ptr(), c0.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert not bool(torch.isnan(wcat.float()).any()) and not bool(torch.isnan(c0).any())
+        y = ops.pw_conv_cat(g, x, wcat, c0, Ci, ops.ACT_NONE)
+        # the pack the previous five-launch path produced from the same operands (M in fp32 by torch): same layout, same values
+        Wd = W.double()
+        M = -(Wd.t() * e2.double()[None, :]) @ Wd
+        ref_pack = ops.pw_prepack(torch.cat([(a.double()[:, None] * Wd).t(), M], dim=1).float().contiguous())
+    assert ref_pack.shape == wcat.shape and ref_pack.dtype == wcat.dtype
+    tol_pack = {0: 2e-6, 1: 1.6e-2, 2: 1.6e-2}[kind]                    # (kinds 1, 2: per bf16 element; hi + lo checked via y)
+    assert float((wcat.float() - ref_pack.float()).abs().max()) <= tol_pack * float(ref_pack.float().abs().max())
+    c0_ref = Wd.t() @ e1.double()
+    assert _rel(c0, c0_ref) < 2e-6
+    y_ref = (torch.einsum("ic,bcft->bift", (a.double()[:, None] * Wd).t(), g.double()) + torch.einsum("ij,bjft->bift", M, x.double())
+             + c0_ref[None, :, None, None])
+    assert _rel(y, y_ref) < {0: 5e-6, 1: 1.5e-2, 2: 3e-5}[kind]

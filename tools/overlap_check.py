@@ -11,6 +11,7 @@ collective's duration during which at least one compute kernel was running - plu
 summary is tracked under profiles/."""
 import csv
 import json
+import re
 import sys
 
 
@@ -40,6 +41,10 @@ def main(path, out):
     last = max(i for i in starts if i < nccl_idx[-1])
     nxt = [i for i in starts if i > last]
     step = rows[last:(nxt[0] if nxt else len(rows))]
+    # the captured step ends with the fused Adam kernel; what follows in the trace (parity probe, teardown) is not the step
+    adam = [i for i, r in enumerate(step) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower()]
+    if adam:
+        step = step[:adam[-1] + 1]
     t0 = step[0][0]
     comp = [(s, e, n) for s, e, n in step if not is_coll(n)]
     coll = [(s, e, n) for s, e, n in step if is_coll(n)]
@@ -60,7 +65,8 @@ def main(path, out):
         if cur_b is not None:
             cov += cur_b - cur_a
         names = sorted({cn.split("(")[0][:60] for _, _, cn in inter})
-        res.append({"kernel": n.replace("void ", "").split("(")[0][:80], "start_us": round((s - t0) / 1e3, 1), "end_us": round((e - t0) / 1e3, 1),
+        m = re.search(r"(ncclDevKernel\w*|oneRankReduce<[^>]*>+|oneRankReduce)", n)
+        res.append({"kernel": (m.group(1) if m else n)[:80], "start_us": round((s - t0) / 1e3, 1), "end_us": round((e - t0) / 1e3, 1),
                     "duration_us": round((e - s) / 1e3, 1), "compute_kernels_running_during_it": len(inter),
                     "fraction_overlapped_by_compute": round(cov / max(1, e - s), 3), "examples": names[:4]})
         tot_c += e - s
