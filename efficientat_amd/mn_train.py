@@ -429,6 +429,8 @@ _GSTATS_EPILOGUE = True  # depthwise BatchNorm backward sums from the project da
 # 80 -> 240 / 200 / 184: 89 -> 110, 76 -> 87, 67 -> 65 us - their reduce pass is cheaper than the epilogue's extra phase)
 _GSTATS_MIN_ELEMS = 1 << 26
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
+# (round 6: the pack of [WaT | M] and c0 come from ONE launch after the coefficient kernel - eat_expand_bwd_wcat; same-box
+#  A/B against the five-launch form: mn10 24.23 -> 24.06 ms, mn40 bf16 42.59 -> 41.89 ms)
 
 def _w_times_g(W, G):
     """T = W G (C_out, C_in) for a symmetric G (C_in, C_in), C_in % 4 == 0."""
