@@ -416,7 +416,7 @@ _ACCESS_CLASS = {"pw_conv_kernel": "lds16", "pw_conv_bf16_kernel": "lds16", "pw_
                  "dw_conv_kernel": "b4", "irb_kernel": "b4", "stem_conv_kernel": "b4", "dyrelu_ca_fwd_kernel": "b4",
                  "dyrelu_ca_bwd_kernel": "b4", "ctx_pool_kernel": "b4", "col_sum_kernel": "b4"}
 # byte-model labels (an entry point runs one of several kernels) -> kernel family in the PMC file
-PMC_FILES = ("pmc_traffic_r5.json", "pmc_traffic_r4.json", "pmc_traffic_r3.json")
+PMC_FILES = ("pmc_traffic_r6.json", "pmc_traffic_r5.json", "pmc_traffic_r4.json")
 
 
 def pmc_step_bytes(phase):

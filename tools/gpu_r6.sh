@@ -67,13 +67,13 @@ if has prof; then
 fi
 if has rocprof; then
   (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats -o s --output-format csv -- \
-      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.log)
+      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-exact --no-train-configs --no-kd > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.log)
   find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats.csv \;
   rm -rf $OUT/stats
   head -30 $OUT/rocprof_kernel_stats.csv
 fi
 if has pmc; then
-  PROF_ARGS="--calibrate-traffic --no-cpu-baseline --no-fp32-exact --no-train-configs --no-profile --steps 2 --warmup 1 --no-graph ${PMC_EXTRA:-}"
+  PROF_ARGS="--calibrate-traffic --no-cpu-baseline --no-fp32-exact --no-train-configs --no-profile --no-kd --steps 2 --warmup 1 --no-graph ${PMC_EXTRA:-}"
   for pass in "f FETCH_SIZE" "w WRITE_SIZE" "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     set -- $pass; name=$1; shift
     (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc $* -d $GRAFT_REPO_ROOT/$OUT/pmc_$name -o $name --output-format csv -- \
