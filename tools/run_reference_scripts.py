@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--audio", default=None, help="wav file for inference.py / windowed_inference.py (default: a synthetic clip)")
     ap.add_argument("--commit", default="unknown", help="commit hash to record in the log (the GPU box has no .git)")
     ap.add_argument("--verify", default=None, help="check that this log was produced from the tree this script runs in")
+    ap.add_argument("--throughput", action="store_true",
+                    help="also run the unmodified `ex_audioset.py --train --batch_size 120` for one epoch of 20 steps on the synthetic "
+                         "AudioSet stand-in and record tqdm's steps/s (the eager loop a user of the reference's script gets)")
     a = ap.parse_args()
     if a.verify:
         m = re.search(r"tree_sha (\w+)", open(a.verify).read())
@@ -136,7 +139,7 @@ def main():
         print(f"{a.verify}: tree_sha {m.group(1) if m else None} vs this tree {tree_sha()}: {'MATCH' if ok else 'DIFFERENT'}")
         sys.exit(0 if ok else 1)
     work = tempfile.mkdtemp(prefix="eat_refscripts_")
-    env = build_workdir(work)
+    env = build_workdir(work, n_train=600 if a.throughput else 48)
     clip = "resources/synthetic_clip.wav"
     if a.audio:
         import shutil
@@ -149,10 +152,19 @@ def main():
                                 "--epoch_len", "32", "--pretrained"])]
     if os.path.exists(os.path.join(a.ref, "windowed_inference.py")):
         runs.append(("windowed_inference.py", ["--cuda", "--audio_path", clip, "--window_size", "4.0", "--hop_length", "3.0"]))
+    if a.throughput:
+        runs.append(("ex_audioset.py", ["--train", "--cuda", "--batch_size", "120", "--num_workers", "8", "--n_epochs", "1",
+                                        "--epoch_len", "2400", "--pretrained"]))
     rc_all = 0
     for script, argv in runs:
+        import time
+        t0 = time.perf_counter()
         rc, out, err = run_script(a.ref, script, argv, work, env)
+        el = time.perf_counter() - t0
         tail = "\n".join(err.strip().splitlines()[-6:])
+        rates = re.findall(r"(\d+)/\1 \[[^\]]*?([\d.]+)(it/s|s/it)\]", err)              # tqdm's closing lines
+        if rates:
+            tail += f"\n[whole script {el:.1f} s; tqdm at completion: " + ", ".join(f"{n} steps at {v} {u}" for n, v, u in rates) + "]"
         log.append(f"$ python {script} {' '.join(argv)}   [unmodified reference script, dropin/ modules]\nrc={rc}\n{_drop_repr(out.strip())}\n--- stderr tail ---\n{tail}\n")
         rc_all |= rc
     wl = os.path.join(work, "wandb_run", "wandb_log.jsonl")
