@@ -96,7 +96,6 @@ SIGNATURES = {
     "eat_se_bn_bwd_partials": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "eat_se_bn_bwd_combine": [_P, _P, _P, _P, _I, _I, _P, _P],
     "eat_expand_bwd_coef": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _D, _I] + [_P] * 7 + [_I, _P, _P],
-    "eat_pw_conv_cat_gstats_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "eat_expand_bwd_wcat": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "eat_expand_bwd_wcat_elems": [_I, _I, _I],
     "eat_stem_gram_blocks": [_I, _I],

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(
     // BEFORE the stores of y: loads and stores retire through one in-order counter - a z load issued behind the tile's
     // stores would wait for all of them (measured: the step 0.43 ms SLOWER than with the separate reduce pass)
     __syncthreads();                                       // every wave is done with the operand stages: LDS is free
-    eat::pw_epilogue_gstats<MTW>(acc, s_bias, smem, stats, gs, tile, mt0, kq, lane, wv, col_ok, bc, sc_, Co, S, res);
+    eat::pw_epilogue_gstats<MTW>(acc, s_bias, smem, stats, gs, tile, mt0, kq, lane, wv, col_ok, bc, sc_, Co, S);
   }
   eat::pw_epilogue<MTW>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
   if (stats && !gs.z) {
@@ -472,25 +472,6 @@ extern "C" int eat_pw_conv_cat_fwd(const float* x1, int C1, const float* x2, int
     return pw_dispatch(x1, reinterpret_cast<const float*>(wp), bias, nullptr, res, y, nullptr, B, C1 + C2, Co, S, act, false,
                        (hipStream_t)stream, PwTf{nullptr, nullptr, 0}, x2, C1);
   return eat::pw_conv_bf16_cat(x1, C1, x2, C2, wp, bias, res, y, B, Co, S, act, wmode == 2 ? 1 : 0, (hipStream_t)stream);
-}
-
-// The two-source GEMM above with the backward statistics of the BatchNorm (no activation) that produced z = gz in its epilogue
-// (round 6): y = W [x1 ; x2] + bias + res is the gradient arriving at the PREVIOUS block's project BatchNorm output, so the
-// channel sums of that BatchNorm's backward - sum y and sum y (gz - c), c = -g_b / g_a - leave this launch as per-tile partials
-// [tile][2][Co] (eat_bn_bwd_sums_from_tiles finishes) and the reduce pass over (y, gz) (eat_bn_act_bwd_reduce) is not run.
-extern "C" int eat_pw_conv_cat_gstats_fwd(const float* x1, int C1, const float* x2, int C2, const void* wp, int wmode,
-                                          const float* bias, const float* res, float* y, const float* gz, const float* g_a,
-                                          const float* g_b, float* part, int B, int Co, int S, eat_stream_t stream) {
-  eat::clear_stale_error();
-  if (!x1 || !x2 || C1 < 4 || C2 < 4 || C1 % 4 || C2 % 4 || S % 4)
-    return eat::fail(EAT_EINVAL, "eat_pw_conv_cat_gstats_fwd: needs C1, C2, S multiples of 4 (C1=%d, C2=%d, S=%d)", C1, C2, S);
-  if (!wp || !bias || !y || !gz || !g_a || !g_b || !part || B < 1 || Co < 1 || (wmode != 0 && wmode != 2))
-    return eat::fail(EAT_EINVAL, "eat_pw_conv_cat_gstats_fwd: bad arguments (wmode 0 = fp32 pack, 2 = bf16 hi / lo)");
-  const eat::PwGStat gs{gz, g_a, g_b, EAT_ACT_NONE};
-  if (wmode == 0)
-    return pw_dispatch(x1, reinterpret_cast<const float*>(wp), bias, nullptr, res, y, nullptr, B, C1 + C2, Co, S, EAT_ACT_NONE,
-                       false, (hipStream_t)stream, PwTf{nullptr, nullptr, 0}, x2, C1, part, gs);
-  return eat::pw_conv_bf16_cat(x1, C1, x2, C2, wp, bias, res, y, B, Co, S, EAT_ACT_NONE, 1, (hipStream_t)stream, part, gs);
 }
 
 extern "C" int eat_pw_conv_dyn_fwd(const float* x, const float* wp_b, const float* bias, const float* res, float* y,

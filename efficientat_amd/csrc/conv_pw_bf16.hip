@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_bf16_kernel(
   if (stats && gs.z) {                                     // block-uniform; before the stores of y (see conv_pw.hip)
     __syncthreads();                                       // every wave is done with the operand stages: LDS is free
     eat::pw_epilogue_gstats<MTW, YT, YT>(acc, s_bias, reinterpret_cast<float*>(smem_raw), stats, gs, tile, mt0, kq, lane, wv,
-                                         col_ok, bc, sc_, Co, S, res);
+                                         col_ok, bc, sc_, Co, S);
   }
   eat::pw_epilogue<MTW, YT>(acc, s_bias, res, y, pool, mt0, kq, lane, col_ok, bc, sc_, Co, S, act);
   if (stats && !gs.z) {                                    // train-mode statistics of the output (pw_epilogue.h)
@@ -459,13 +459,11 @@ int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample
 // 1x1 conv over the concatenated channels of two tensors (see the kernel's x2 / c1)
 namespace eat {
 int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const void* wp, const float* bias, const float* res,
-                     float* y, int B, int Co, int S, int act, int split, hipStream_t s, float* stats, PwGStat gs) {
+                     float* y, int B, int Co, int S, int act, int split, hipStream_t s) {
   const __bf16* w16 = reinterpret_cast<const __bf16*>(wp);
   const PwTf none{nullptr, nullptr, 0};
-  return split ? dispatch<3>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1, false,
-                             stats, gs)
-               : dispatch<1>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1, false,
-                             stats, gs);
+  return split ? dispatch<3>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1)
+               : dispatch<1>(s, x1, w16, bias, nullptr, res, y, nullptr, B, c1 + c2, Co, S, act, c1 + c2, none, x2, c1);
 }
 }  // namespace eat
 

@@ -102,8 +102,7 @@ int pw_conv_bf16_stats(const float* x, const void* wp, int split, int per_sample
                        int S, hipStream_t s, PwGStat gs = PwGStat{nullptr, nullptr, nullptr, 0});
 
 int pw_conv_bf16_cat(const float* x1, int c1, const float* x2, int c2, const void* wp, const float* bias, const float* res,
-                     float* y, int B, int Co, int S, int act, int split, hipStream_t s, float* stats = nullptr,
-                     PwGStat gs = PwGStat{nullptr, nullptr, nullptr, 0});
+                     float* y, int B, int Co, int S, int act, int split, hipStream_t s);
 
 // conv_pw_stream.hip: barrier-free bf16 1x1 kernels (x or the output tile resident in registers); returns 1 when the
 // shape / the EAT_PW_STREAM switch leaves the layer to conv_pw_bf16.hip

@@ -212,8 +212,8 @@ __device__ __forceinline__ void pw_epilogue_stats(const acc_f32x4 (&acc)[MTW][4]
 // replaces)
 template <int MTW, int ACT, typename YT, typename ZT>
 __device__ __forceinline__ void pw_gstats_rows(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, const float* s_ab,
-                                               float* scratch, const ZT* zb, const float* resb, int mt0, int kq, int lane,
-                                               int wv, float ok, int Co, int S) {
+                                               float* scratch, const ZT* zb, int mt0, int kq, int lane, int wv, float ok,
+                                               int Co, int S) {
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -224,12 +224,8 @@ __device__ __forceinline__ void pw_gstats_rows(const acc_f32x4 (&acc)[MTW][4], c
       if (m >= Co) m = Co - 1;
       const float bm = s_bias[row], av = s_ab[row], bv = s_ab[MTW * 16 + row], cv = s_ab[2 * MTW * 16 + row];
       const float4 zv = Io<ZT>::load4(zb + (size_t)m * S);
-      float v0 = Io<YT>::rnd(acc[i][0][r] + bm), v1 = Io<YT>::rnd(acc[i][1][r] + bm);
-      float v2 = Io<YT>::rnd(acc[i][2][r] + bm), v3 = Io<YT>::rnd(acc[i][3][r] + bm);
-      if (resb) {                                    // (uniform) the conv's residual input is part of its output y
-        const float4 rv = *reinterpret_cast<const float4*>(resb + (size_t)m * S);
-        v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-      }
+      const float v0 = Io<YT>::rnd(acc[i][0][r] + bm), v1 = Io<YT>::rnd(acc[i][1][r] + bm);
+      const float v2 = Io<YT>::rnd(acc[i][2][r] + bm), v3 = Io<YT>::rnd(acc[i][3][r] + bm);
       float g0, g1, g2, g3;
       if constexpr (ACT == EAT_ACT_RELU) {
         g0 = fmaf(av, zv.x, bv) > 0.0f ? v0 : 0.0f; g1 = fmaf(av, zv.y, bv) > 0.0f ? v1 : 0.0f;
@@ -261,8 +257,7 @@ __device__ __forceinline__ void pw_gstats_rows(const acc_f32x4 (&acc)[MTW][4], c
 template <int MTW, typename YT = float, typename ZT = float>
 __device__ __forceinline__ void pw_epilogue_gstats(const acc_f32x4 (&acc)[MTW][4], const float* s_bias, float* scratch,
                                                    float* __restrict__ part, const PwGStat gs, int tile, int mt0, int kq,
-                                                   int lane, int wv, bool col_ok, int bc, int sc_, int Co, int S,
-                                                   const float* __restrict__ res = nullptr) {
+                                                   int lane, int wv, bool col_ok, int bc, int sc_, int Co, int S) {
   // stage a, b and the centring constant c of the block's rows behind the wave partials: scratch[4 MTW 16 2 ...) = [3][MTW 16]
   float* s_ab = scratch + 4 * MTW * 16 * 2;
   for (int e = threadIdx.x; e < 3 * MTW * 16; e += 256) {
@@ -274,14 +269,12 @@ __device__ __forceinline__ void pw_epilogue_gstats(const acc_f32x4 (&acc)[MTW][4
   __syncthreads();
   const float ok = col_ok ? 1.0f : 0.0f;
   const ZT* zb = reinterpret_cast<const ZT*>(gs.z) + (size_t)bc * Co * (size_t)S + sc_;
-  // (a column tile outside the tensor clamps its loads to the tile's first column like the z loads do: rok = 0 there)
-  const float* resb = res ? res + (size_t)bc * Co * (size_t)S + sc_ : nullptr;
   if (gs.act == EAT_ACT_RELU)                                                       // uniform
-    pw_gstats_rows<MTW, EAT_ACT_RELU, YT, ZT>(acc, s_bias, s_ab, scratch, zb, resb, mt0, kq, lane, wv, ok, Co, S);
+    pw_gstats_rows<MTW, EAT_ACT_RELU, YT, ZT>(acc, s_bias, s_ab, scratch, zb, mt0, kq, lane, wv, ok, Co, S);
   else if (gs.act == EAT_ACT_HSWISH)
-    pw_gstats_rows<MTW, EAT_ACT_HSWISH, YT, ZT>(acc, s_bias, s_ab, scratch, zb, resb, mt0, kq, lane, wv, ok, Co, S);
+    pw_gstats_rows<MTW, EAT_ACT_HSWISH, YT, ZT>(acc, s_bias, s_ab, scratch, zb, mt0, kq, lane, wv, ok, Co, S);
   else
-    pw_gstats_rows<MTW, EAT_ACT_NONE, YT, ZT>(acc, s_bias, s_ab, scratch, zb, resb, mt0, kq, lane, wv, ok, Co, S);
+    pw_gstats_rows<MTW, EAT_ACT_NONE, YT, ZT>(acc, s_bias, s_ab, scratch, zb, mt0, kq, lane, wv, ok, Co, S);
   __syncthreads();
   for (int e = threadIdx.x; e < MTW * 16 * 2; e += 256) {
     const int row = e >> 1, k = e & 1, m = mt0 * 16 + row;

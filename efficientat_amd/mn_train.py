@@ -109,25 +109,6 @@ def _pw_conv_bn(x, wp, Co, bn, dev, tf=None, in_scale=None):
     return z, _conv_bn_stats(z, bn)
 
 
-_PROJ_GSTAT_MIN_ELEMS = 1 << 23   # project-BN backward sums from the producing GEMM's epilogue from this tensor size on
-
-
-def _proj_gstat(recs, j, blocks, bn_sums):
-    """(z_p, st_p, sums slot, BN weight name) of block j when the GEMM that produces the gradient arriving at its output may take
-    its project BatchNorm's backward sums in its epilogue: training BatchNorm, fp32 z_p, plane a multiple of 4, large enough
-    for the reduce pass it replaces to cost more than the epilogue + the finish launch."""
-    if j < 0 or not _PROJ_GSTATS:
-        return None
-    rec, blk = recs[j], blocks[j]
-    z_p, st_p = rec["z_p"], rec["st_p"]
-    if z_p.dtype != torch.float32 or getattr(st_p[2], "_eat_frozen", False) or (z_p.shape[2] * z_p.shape[3]) % 4:
-        return None
-    if z_p.numel() < _PROJ_GSTAT_MIN_ELEMS:
-        return None
-    pre = f"features.{j + 1}.block.{blk.i_proj}.1"
-    return z_p, st_p, bn_sums(blk.cnf.out_channels, pre + ".weight", pre + ".bias"), pre + ".weight"
-
-
 # (the round-2 plan - separate statistics / apply passes per BatchNorm, behind EAT_TRAIN_V=1 - was removed in round 4)
 def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
     """Backward of MNTrainFunction2 (one pass, reverse layer order)."""
@@ -196,17 +177,7 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         # backward): the views hold the CURRENT weights - pack this backward's operands matrix by matrix instead
         plan = None
     wpt = _pk(plan, ("lt",), last[0].weight, trans=True)
-    # `pend`: the channel sums of the project BatchNorm's backward of the block whose output gradient `dout` is, when the GEMM
-    # that produced dout took them in its epilogue (round 6: _proj_gstat) - that block's reduce pass is then skipped
-    pend = None
-    gs = _proj_gstat(sv["blocks"], nb - 1, blocks, bn_sums)
-    if gs is not None:
-        dout, ok = ops.pw_conv_gstats(dz, wpt, x_l.shape[1], gs[0], gs[1], NONE, sums=gs[2])
-        pend = gs[2] if dout is not None else None
-        if dout is None:
-            bn_unreserve(gs[3])
-    if pend is None:
-        dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
+    dout = ops.pw_conv(dz, wpt, _zeros.get(x_l.shape[1], dev), x_l.shape[1], NONE)
     del dz, z_l
 
     # ---- inverted residual blocks, last to first (mn/block_types.py:177-181)
@@ -223,12 +194,8 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
         nw, nbias = f"{pre}.{blk.i_proj}.1.weight", f"{pre}.{blk.i_proj}.1.bias"
         b16 = rec.get("b16", False)                    # the block's wide tensors are bf16 in HBM (forward: rec["b16"])
         want16 = b16 and rec["z_p"].dtype == torch.bfloat16 and _cast_narrow(cnf)
-        if pend is not None:       # (the sums left the epilogue of the GEMM that produced dout: no reduce pass)
-            dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=pend, copy16=want16, have_sums=True)
-            pend = None
-        else:
-            dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias),
-                                              copy16=want16)
+        dz_p, dgam, dbet = ops.bn_act_bwd(dout, rec["z_p"], *rec["st_p"], NONE, sums=bn_sums(cnf.out_channels, nw, nbias),
+                                          copy16=want16)
         dz_p, dz16 = dz_p if want16 else (dz_p, None)
         bn_grads(dgam, dbet, nw, nbias)
         scale = rec.get("scale")
@@ -392,10 +359,7 @@ def _backward_impl(ctx, model, sv, dlogits, dfeat, n_lead):
                 dout = ops.pw_conv_b16(g_e, ops.pw_prepack(WaT), _zeros.get(cnf.input_channels, dev), cnf.input_channels,
                                        NONE, res=t)
             elif cat_f32:
-                gs = _proj_gstat(sv["blocks"], i - 1, blocks, bn_sums) if wcat.dtype == torch.float32 or getattr(wcat, "_eat_split", False) else None
-                dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad,
-                                       gstat=None if gs is None else gs[:3])
-                pend = None if gs is None else gs[2]
+                dout = ops.pw_conv_cat(g_e, inp, wcat, c0, cnf.input_channels, NONE, res=res_grad)
             else:
                 t = res_grad
                 if not frozen:                                                  # M x + c0 (+ residual-branch gradient)
@@ -465,8 +429,6 @@ _GSTATS_EPILOGUE = True  # depthwise BatchNorm backward sums from the project da
 # 80 -> 240 / 200 / 184: 89 -> 110, 76 -> 87, 67 -> 65 us - their reduce pass is cheaper than the epilogue's extra phase)
 _GSTATS_MIN_ELEMS = 1 << 26
 _CAT_DGRAD = True         # expand data gradient + BatchNorm correction as one two-source GEMM
-import os as _os
-_PROJ_GSTATS = _os.environ.get("EAT_PROJ_GSTATS", "1") != "0"   # (temporary A/B switch, round 6)
 # (round 6: the pack of [WaT | M] and c0 come from ONE launch after the coefficient kernel - eat_expand_bwd_wcat; same-box
 #  A/B against the five-launch form: mn10 24.23 -> 24.06 ms, mn40 bf16 42.59 -> 41.89 ms)
 

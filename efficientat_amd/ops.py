@@ -374,12 +374,10 @@ def bn_act_fwd(z, a, b, act, res=None, pool=None, write=True, y_f32=False, copy1
     return y
 
 
-def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None, sums=None, copy16=False, have_sums=False):
+def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=None, sums=None, copy16=False):
     """-> (dz, dgamma, dbeta) for y = act(BN_batch(z)); incoming grad = dy*gscale[b,c] + gadd[b,c].
     frozen (default: the flag `bn_train_state` left on `mean`): the layer normalised with its running statistics,
-    i.e. dz = a * g without the batch-mean terms (dgamma / dbeta are the same reductions).
-    have_sums: `sums` already holds the channel sums (the producer of dy took them in its epilogue: pw_conv_cat / pw_conv_gstats
-    with gstat) - the reduce pass is skipped."""
+    i.e. dz = a * g without the batch-mean terms (dgamma / dbeta are the same reductions)."""
     if frozen is None:
         frozen = getattr(mean, "_eat_frozen", False)
     B, C = z.shape[0], z.shape[1]
@@ -403,8 +401,7 @@ def bn_act_bwd(dy, z, a, b, mean, invstd, act, gscale=None, gadd=None, frozen=No
         return dz, sf[C:], sf[:C]
     args = (_dev(dy, "dy"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
             _opt(gscale, "gscale"), _opt(gadd, "gadd"))
-    if not have_sums:
-        _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
+    _lib.call("eat_bn_act_bwd_reduce", *args, B, C, S, act, sums.data_ptr(), _stream())
     dz = torch.empty_like(z)
     _lib.call("eat_bn_act_bwd_apply", *args, asums.data_ptr(), dz.data_ptr(), B, C, S, act, _stream())
     if not own:
@@ -501,30 +498,13 @@ def pw_conv_tf(x, tf, wp, bias, Co, act, in_scale=None, res=None):
     return y
 
 
-def pw_conv_cat(x1, x2, wp, bias, Co, act, res=None, gstat=None):
+def pw_conv_cat(x1, x2, wp, bias, Co, act, res=None):
     """1x1 conv over the concatenated channels of x1 (B,C1,F,T) and x2 (B,C2,F,T) without materialising the concatenation;
-    wp = pw_prepack of the (Co, C1 + C2) matrix.
-    gstat = (z, (a, b, mean, invstd), sums): the output y is the gradient arriving at the BatchNorm (no activation) that
-    produced z (B, Co, F, T): the channel sums of that BatchNorm's backward over (y, z) are taken in this GEMM's epilogue and
-    written to `sums` (2 Co float64: what `bn_act_bwd`'s reduce pass leaves there) -> y; act must be NONE."""
+    wp = pw_prepack of the (Co, C1 + C2) matrix."""
     B, C1, F, T = x1.shape
     C2 = x2.shape[1]
     wmode = 0 if wp.dtype == torch.float32 else (2 if getattr(wp, "_eat_split", False) else 1)
     y = torch.empty((B, Co, F, T), device=x1.device, dtype=torch.float32)
-    if gstat is not None:
-        z, st, sums = gstat
-        if act != ACT_NONE or wmode == 1 or z.dtype != torch.float32:
-            raise _lib.EatHipError("pw_conv_cat(gstat=...): plain output, fp32 z and an fp32 / split-bf16 pack only")
-        tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, F * T, 0))
-        part = torch.empty((tiles * 2 * Co,), device=x1.device, dtype=torch.float32)
-        _lib.call("eat_pw_conv_cat_gstats_fwd", _dev(x1, "x"), C1, _dev(x2, "x2"), C2, wp.data_ptr(), wmode, _dev(bias, "bias"),
-                  _opt(res, "res"), y.data_ptr(), _dev(z, "z"), st[0].data_ptr(), st[1].data_ptr(), part.data_ptr(), B, Co,
-                  F * T, _stream())
-        nws = int(_lib.lib().eat_bn_bwd_sums_ws_doubles(tiles, Co))
-        ws = torch.empty((nws,), device=x1.device, dtype=torch.float64) if nws else None
-        _lib.call("eat_bn_bwd_sums_from_tiles", part.data_ptr(), tiles, Co, st[2].data_ptr(), st[3].data_ptr(), st[0].data_ptr(),
-                  st[1].data_ptr(), None if ws is None else ws.data_ptr(), sums.data_ptr(), _stream())
-        return y
     _lib.call("eat_pw_conv_cat_fwd", _dev(x1, "x"), C1, _dev(x2, "x2"), C2, wp.data_ptr(), wmode, _dev(bias, "bias"),
               _opt(res, "res"), y.data_ptr(), B, Co, F * T, act, _stream())
     return y

@@ -204,14 +204,6 @@ int eat_bn_finalize_partials(const float* part, int outer, int C, int inner, con
 int eat_pw_conv_gstats_fwd(const float* x, const void* wp, int wmode, const float* zero_bias, float* y, const float* gz,
                            const float* g_a, const float* g_b, int g_act, float* part, int B, int Ci, int Co, int S,
                            eat_stream_t stream);
-/* The two-source data-gradient GEMM y = W [x1 ; x2] + bias + res (eat_pw_conv_cat_fwd: the expand conv's dx of block i, which
- * IS the gradient arriving at block i-1's output) with the backward statistics of block i-1's project BatchNorm (no
- * activation; autograd through block_types.py:167-171,177-181) in its epilogue: gz = that block's raw project output z_p
- * (B, Co, S), g_a / g_b its BatchNorm (a, b); part as eat_pw_conv_gstats_fwd.  Replaces eat_bn_act_bwd_reduce over (y, z_p).
- * wmode 0 = fp32 pack, 2 = bf16 hi / lo. */
-int eat_pw_conv_cat_gstats_fwd(const float* x1, int C1, const float* x2, int C2, const void* wp, int wmode, const float* bias,
-                               const float* res, float* y, const float* gz, const float* g_a, const float* g_b, float* part,
-                               int B, int Co, int S, eat_stream_t stream);
 int eat_bn_bwd_sums_ws_doubles(int tiles, int C);
 /* g_a / g_b: the BatchNorm's (a, b) the partials were taken with - the epilogue accumulates sum g (z_d - c), c = -g_b / g_a (the
  * zero of the pre-activation: no cancellation against a large channel mean in the fp32 tile partials), and this call adds

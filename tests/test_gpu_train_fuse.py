@@ -687,43 +687,3 @@ def test_expand_backward_operand_pack_from_one_launch(Co, Ci, mode):
     y_ref = (torch.einsum("ic,bcft->bift", (a.double()[:, None] * Wd).t(), g.double()) + torch.einsum("ij,bjft->bift", M, x.double())
              + c0_ref[None, :, None, None])
     assert _rel(y, y_ref) < {0: 5e-6, 1: 1.5e-2, 2: 3e-5}[kind]
-
-
-@pytest.mark.parametrize("B,C1,C2,Co,F_,T,mode,res", [(3, 64, 16, 16, 32, 250, "fp32", True), (2, 72, 24, 24, 16, 125, "fp32", False),
-                                                      (5, 240, 40, 40, 8, 63, "auto", True), (3, 120, 40, 40, 16, 125, "auto", True),
-                                                      (37, 184, 80, 80, 8, 63, "auto", False), (2, 64, 16, 16, 9, 44, "auto", True)])
-def test_two_source_gemm_with_project_batchnorm_backward_sums(B, C1, C2, Co, F_, T, mode, res):
-    """eat_pw_conv_cat_gstats_fwd (round 6): y = W [x1 ; x2] + bias (+ res) exactly as the plain two-source GEMM, and the channel
-    sums of the backward of the BatchNorm (no activation) that produced z over (y, z) - sum y, invstd sum y (z - mean) - as
-    the reduce pass gives them and as fp64 does; the residual is part of y; a channel mean of 100 sigma is in the set."""
-    x1, x2 = _rand(B, C1, F_, T, seed=1).to(DEV), _rand(B, C2, F_, T, seed=2).to(DEV)
-    W = _rand(Co, C1 + C2, seed=3, scale=(C1 + C2) ** -0.5).to(DEV)
-    bias = _rand(Co, seed=4, scale=0.2).to(DEV)
-    r = _rand(B, Co, F_, T, seed=5).to(DEV) if res else None
-    sigma = torch.rand(Co, generator=torch.Generator().manual_seed(6)) + 0.5
-    mu = _rand(Co, seed=7) * sigma * 3
-    mu[0] = 100.0 * sigma[0]
-    z = (_rand(B, Co, F_, T, seed=8) * sigma[None, :, None, None] + mu[None, :, None, None]).to(DEV)
-    mean = z.double().mean((0, 2, 3)).float()
-    invstd = (z.double().var((0, 2, 3), unbiased=False) + 1e-3).rsqrt().float()
-    gamma = (torch.rand(Co, generator=torch.Generator().manual_seed(9)) + 0.5).to(DEV)
-    a = gamma * invstd
-    b = _rand(Co, seed=10, scale=0.3).to(DEV) - mean * a
-    with ops.precision(mode):
-        wp = ops.pw_prepack(W)
-        y_ref = ops.pw_conv_cat(x1, x2, wp, bias, Co, ops.ACT_NONE, res=r)
-        sums = torch.full((2 * Co,), float("nan"), device=DEV, dtype=torch.float64)
-        y = ops.pw_conv_cat(x1, x2, wp, bias, Co, ops.ACT_NONE, res=r, gstat=(z, (a, b, mean, invstd), sums))
-    assert torch.equal(y, y_ref)
-    g = y_ref.double()
-    s0 = g.sum((0, 2, 3))
-    zc = z.double() - mean.double()[None, :, None, None]
-    s1 = invstd.double() * (g * zc).sum((0, 2, 3))
-    assert float((sums[:Co] - s0).abs().max()) < 2e-6 * float(g.abs().sum((0, 2, 3)).max())
-    scale = invstd.double() * (g * zc).abs().sum((0, 2, 3))
-    assert float(((sums[Co:] - s1).abs() / scale.clamp_min(1e-30)).max()) < 1e-5
-    # the pass it replaces leaves the same numbers (its own fp32 / fp64 accumulation order: same bar)
-    ref = torch.zeros((2 * Co,), device=DEV, dtype=torch.float64)
-    _lib.call("eat_bn_act_bwd_reduce", y_ref.data_ptr(), z.data_ptr(), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-              None, None, B, Co, F_ * T, ops.ACT_NONE, ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert float(((ref[Co:] - s1).abs() / scale.clamp_min(1e-30)).max()) < 1e-4
