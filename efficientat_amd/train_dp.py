@@ -93,6 +93,9 @@ def parse_args(argv=None):
     p.add_argument("--precision", default=None, help="model.train_precision (auto / fp32 / bf16)")
     p.add_argument("--out", default=None, help="directory for rank 0's per-epoch state dicts")
     p.add_argument("--json", action="store_true", help="rank 0 prints one JSON line with the run's throughput at the end")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="process-group backend: nccl = RCCL, one GPU per rank (production); gloo = several ranks may share a GPU "
+                        "(tests on a one-GPU box: collectives on device tensors through the host, eager trainer only)")
     return p.parse_args(argv)
 
 
@@ -122,12 +125,19 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("efficientat_amd.train_dp needs a GPU per rank: the package has no CPU path")
+    if args.backend == "gloo":
+        local %= torch.cuda.device_count()                                    # ranks share the visible GPUs
+        if not args.no_graph and world > 1:
+            raise SystemExit("--backend gloo cannot be captured into a hipGraph (host-side collectives): add --no_graph")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")        # required to capture collectives in a graph
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(here, "dropin"))                          # datasets.audioset (reference module path)
     from datasets import audioset
@@ -214,8 +224,16 @@ def main(argv=None):
         t = torch.tensor([t_train], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_train = float(t.item())
+    digest = float(torch.cat([p.detach().double().reshape(-1) for p in model.parameters()]).abs().sum())
+    if world > 1:                                                             # replicas must end identical (DDP semantics)
+        dg = torch.tensor([digest, -digest], device=dev, dtype=torch.float64)
+        dist.all_reduce(dg, op=dist.ReduceOp.MAX)
+        spread = float(dg[0] + dg[1])                                         # max - min over the ranks
+    else:
+        spread = 0.0
     if rank == 0 and args.json:
         print(json.dumps({"what": "efficientat_amd.train_dp", "model": args.model_name, "n_gpus": world, "steps": steps_total,
+                          "param_abs_sum": digest, "param_abs_sum_spread_over_ranks": spread, "backend": args.backend if world > 1 else None,
                           "batch_per_gpu": args.batch_size, "clips_per_s": round(clips_total * world / max(t_train, 1e-9), 1),
                           "launch": "hipGraph replay" if graphed else "eager", "transport": args.transport,
                           "final": stats}), flush=True)

@@ -349,3 +349,34 @@ def test_b16_entry_points_fail_loudly():
         wp = ops.pw_prepack(_rand(64, 64).to(DEV))
     with pytest.raises(_lib.EatHipError):
         ops.pw_conv_b16(_rand(2, 64, 8, 8).to(DEV), wp, torch.zeros(64, device=DEV), 64, NONE)
+
+
+@pytest.mark.parametrize("B,Ci,Ce,F_,T", [(8, 448, 2688, 8, 63), (8, 640, 3840, 4, 32), (8, 320, 1920, 8, 63), (4, 160, 960, 16, 125)])
+def test_expand_batchnorm_statistics_describe_the_stored_tensor(B, Ci, Ce, F_, T):
+    """ADVICE r5 / DESIGN 3.4: in the bf16-storage plan the expand BatchNorm's statistics come from a plain-bf16 Gram matrix
+    of the block input (with the fp32 W), while z_e itself is a bf16 GEMM of bf16-rounded operands, rounded again on store - the
+    statistics describe a tensor that differs from the stored one by O(2^-8).  This bounds that mismatch on the widest mn40
+    blocks: per channel, |mean_gram - mean(stored z_e)| <= 0.02 sigma and var_gram / var(stored z_e) within 1 +- 0.02 (the
+    BatchNorm output then has mean 0 +- 0.02 and variance 1 +- 0.02: far inside what bf16 activations resolve)."""
+    from efficientat_amd.mn_train import _w_times_g
+    x = (_rand(B, Ci, F_, T, seed=1) * (torch.rand(1, Ci, 1, 1, generator=torch.Generator().manual_seed(2)) + 0.5)
+         + _rand(1, Ci, 1, 1, seed=3, scale=0.5)).to(DEV)
+    W = _rand(Ce, Ci, seed=4, scale=Ci ** -0.5).to(DEV)
+    n = B * F_ * T
+    bn = torch.nn.BatchNorm2d(Ce, eps=1e-3, momentum=0.01).to(DEV).train()
+    with ops.precision("bf16"):
+        sx = x.sum((0, 2, 3))
+        G = ops.gram(x, exact=False, sx=sx, plain_bf16=True)
+        Tm = _w_times_g(W, G)
+        a, b, mean, invstd = ops.gram_bn_state(Tm, W, sx, bn, n, centered=True)
+        wp = ops.pw_prepack(W)
+        z_e = ops.pw_conv_b16(ops.cast_b16(x), wp, torch.zeros(Ce, device=DEV), Ce, NONE, out_b16=True)
+    assert z_e.dtype == torch.bfloat16
+    zs = z_e.double()
+    m_st, v_st = zs.mean((0, 2, 3)), zs.var((0, 2, 3), unbiased=False)
+    sd = v_st.sqrt()
+    dm = float(((mean.double() - m_st).abs() / sd).max())
+    var_gram = 1.0 / invstd.double() ** 2 - 1e-3
+    dv = float((var_gram / v_st - 1.0).abs().max())
+    print(f"{Ci}->{Ce} @ {F_}x{T}: max |mean_gram - mean_stored| / sigma = {dm:.2e}, max |var_gram / var_stored - 1| = {dv:.2e}")
+    assert dm < 0.02 and dv < 0.02, (dm, dv)

@@ -323,3 +323,70 @@ def test_train_dp_program_runs_on_one_gpu(tmp_path):
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["steps"] == 4 and np.isfinite(line["final"]["train_loss"]) and line["final"]["distillation_loss"] > 0, line
+
+
+def test_train_dp_program_two_ranks_end_to_end(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 -m efficientat_amd.train_dp` on the one GPU (both ranks on cuda:0, gloo
+    collectives on device tensors, eager trainer): the per-rank sampler shards, the broadcast of rank 0's weights, the bucketed
+    gradient exchange and Adam keep the two replicas IDENTICAL over a few KD steps (the spread of a parameter digest over the
+    ranks is exactly 0) - BASELINE configs[4]'s loop with N > 1, minus RCCL (which needs one GPU per rank)."""
+    import json
+    import os
+    import pickle
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = torch.Generator().manual_seed(1)
+    np.save(tmp_path / "teacher.npy", (torch.randn(64, 527, generator=g) * 2 - 5).numpy())
+    with open(tmp_path / "f2i.pkl", "wb") as f:
+        pickle.dump({"syn%07d" % i: i % 64 for i in range(0, 4096, 2)}, f)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EAT_SYNTH_AUDIOSET="1", EAT_SYNTH_AUDIOSET_TRAIN="64", PYTHONPATH=root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "efficientat_amd.train_dp", "--backend", "gloo", "--no_graph",
+                        "--batch_size", "6", "--num_workers", "1", "--n_epochs", "1", "--epoch_len", "64", "--max_steps", "3",
+                        "--model_width", "0.5", "--teacher_preds", str(tmp_path / "teacher.npy"),
+                        "--fname_to_index", str(tmp_path / "f2i.pkl"), "--json"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    if r.returncode != 0 and "gloo" in r.stderr and "not supported" in r.stderr.lower():
+        pytest.skip("this torch build's gloo does not reduce device tensors: " + r.stderr[-300:])
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and np.isfinite(line["final"]["train_loss"]), line
+    assert line["param_abs_sum_spread_over_ranks"] == 0.0, line          # the replicas took the same averaged step
+
+
+def test_graphed_kd_trainer_with_dymn_and_recapture():
+    """DyMN under the captured KD step: the DynamicConv temperatures are launch constants, so the step is re-captured after
+    `update_params(epoch)` (ex_audioset.py:131-133) - the losses of the re-captured trainer follow an eager trainer that saw
+    the same schedule."""
+    from efficientat_amd.dymn import get_model as get_dymn
+    from efficientat_amd.train_loop import GraphedKDTrainer
+    B, L = 4, 32000
+    res = {}
+    for tag in ("eager", "graph"):
+        torch.manual_seed(2)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = get_dymn(width_mult=0.4).to(DEV).train()
+            mel = AugmentMelSTFT(freqm=0, timem=0).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, nn.Dropout):
+                mod.p = 0.0
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
+        tr = KDTrainer(m, mel, opt, mixup_alpha=0.3) if tag == "eager" else GraphedKDTrainer(m, mel, opt, B, L, mixup_alpha=0.3)
+        torch.manual_seed(11); np.random.seed(11)
+        losses = []
+        for epoch in range(2):
+            with contextlib.redirect_stdout(io.StringIO()):
+                m.update_params(epoch * 10)                         # T = 30, then 20
+            if tag == "graph":
+                tr.recapture()
+            losses += [float(tr.step(*_kd_batch(2 * epoch + s, B, L))) for s in range(2)]
+        res[tag] = losses
+    print(res)
+    assert all(abs(a - b) < 1e-4 * max(1.0, abs(a)) for a, b in zip(res["eager"], res["graph"])), res
