@@ -356,8 +356,9 @@ def test_expand_batchnorm_statistics_describe_the_stored_tensor(B, Ci, Ce, F_, T
     """ADVICE r5 / DESIGN 3.4: in the bf16-storage plan the expand BatchNorm's statistics come from a plain-bf16 Gram matrix
     of the block input (with the fp32 W), while z_e itself is a bf16 GEMM of bf16-rounded operands, rounded again on store - the
     statistics describe a tensor that differs from the stored one by O(2^-8).  This bounds that mismatch on the widest mn40
-    blocks: per channel, |mean_gram - mean(stored z_e)| <= 0.02 sigma and var_gram / var(stored z_e) within 1 +- 0.02 (the
-    BatchNorm output then has mean 0 +- 0.02 and variance 1 +- 0.02: far inside what bf16 activations resolve)."""
+    blocks: per channel, |mean_gram - mean(stored z_e)| <= 0.01 sigma and var_gram / var(stored z_e) within 1 +- 0.01 (measured
+    on MI355X: 3.2e-3 sigma / 1.9e-3) - the BatchNorm output then has mean 0 +- 0.01 and variance 1 +- 0.01, inside what a
+    bf16 activation (2^-9 relative) resolves."""
     from efficientat_amd.mn_train import _w_times_g
     x = (_rand(B, Ci, F_, T, seed=1) * (torch.rand(1, Ci, 1, 1, generator=torch.Generator().manual_seed(2)) + 0.5)
          + _rand(1, Ci, 1, 1, seed=3, scale=0.5)).to(DEV)
@@ -379,4 +380,4 @@ def test_expand_batchnorm_statistics_describe_the_stored_tensor(B, Ci, Ce, F_, T
     var_gram = 1.0 / invstd.double() ** 2 - 1e-3
     dv = float((var_gram / v_st - 1.0).abs().max())
     print(f"{Ci}->{Ce} @ {F_}x{T}: max |mean_gram - mean_stored| / sigma = {dm:.2e}, max |var_gram / var_stored - 1| = {dv:.2e}")
-    assert dm < 0.02 and dv < 0.02, (dm, dv)
+    assert dm < 0.01 and dv < 0.01, (dm, dv)

@@ -363,30 +363,38 @@ def test_train_dp_program_two_ranks_end_to_end(tmp_path):
 
 def test_graphed_kd_trainer_with_dymn_and_recapture():
     """DyMN under the captured KD step: the DynamicConv temperatures are launch constants, so the step is re-captured after
-    `update_params(epoch)` (ex_audioset.py:131-133) - the losses of the re-captured trainer follow an eager trainer that saw
-    the same schedule."""
+    `update_params(epoch)` (ex_audioset.py:131-133; here T = 30 -> 1) - the losses of the re-captured trainer follow an eager
+    trainer that saw the same schedule, and a trainer that is NOT re-captured keeps computing with the old temperature.
+    (DyMN's bank-gradient kernels accumulate with atomics: run-to-run noise of ~1e-6 per step, which Adam's normalisation
+    amplifies - hence lr = 1e-4 and a 3e-4 bar where the MN test holds 2e-5.)"""
     from efficientat_amd.dymn import get_model as get_dymn
     from efficientat_amd.train_loop import GraphedKDTrainer
     B, L = 4, 32000
     res = {}
-    for tag in ("eager", "graph"):
+    for tag in ("eager", "graph", "stale"):
         torch.manual_seed(2)
         with contextlib.redirect_stdout(io.StringIO()):
             m = get_dymn(width_mult=0.4).to(DEV).train()
             mel = AugmentMelSTFT(freqm=0, timem=0).to(DEV).train()
+        with torch.no_grad():                                      # attention logits of O(1): the temperature matters
+            for n_, p_ in m.named_parameters():
+                if ".residuals.0.weight" in n_:
+                    p_.normal_(0, 0.5)
         for mod in m.modules():
             if isinstance(mod, nn.Dropout):
                 mod.p = 0.0
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, capturable=True, fused=True)
         tr = KDTrainer(m, mel, opt, mixup_alpha=0.3) if tag == "eager" else GraphedKDTrainer(m, mel, opt, B, L, mixup_alpha=0.3)
         torch.manual_seed(11); np.random.seed(11)
         losses = []
-        for epoch in range(2):
+        for i, epoch in enumerate((0, 40)):
             with contextlib.redirect_stdout(io.StringIO()):
-                m.update_params(epoch * 10)                         # T = 30, then 20
+                m.update_params(epoch)                              # T = 30, then T = 1 (dy_block.py:133-139)
             if tag == "graph":
                 tr.recapture()
-            losses += [float(tr.step(*_kd_batch(2 * epoch + s, B, L))) for s in range(2)]
+            losses += [float(tr.step(*_kd_batch(2 * i + s, B, L))) for s in range(2)]
         res[tag] = losses
     print(res)
-    assert all(abs(a - b) < 1e-4 * max(1.0, abs(a)) for a, b in zip(res["eager"], res["graph"])), res
+    assert all(abs(a - b) < 3e-4 * max(1.0, abs(a)) for a, b in zip(res["eager"], res["graph"])), res
+    assert all(abs(a - b) < 3e-4 * max(1.0, abs(a)) for a, b in zip(res["eager"][:2], res["stale"][:2])), res
+    assert abs(res["stale"][2] - res["eager"][2]) > 10 * abs(res["graph"][2] - res["eager"][2]) + 1e-5, res   # old temperature
