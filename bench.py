@@ -998,6 +998,16 @@ def kd_bench(args, mel_unused, wave, ranks, steps=12, warmup=3):
     out["graphed"] = {"value": v, "unit": "clips/s", "ms_per_step": ms,
                       "launch": "one hipGraph replay per step (mel + mixup + forward + KD loss + backward + "
                                 + ("all-reduce + " if ranks.dist is not None else "") + "Adam); batch resident in HBM"}
+    if ranks.world > 1:
+        # N > 1: the captured KD step with the RCCL all-reduce inside is the configs[4] number; the host-fed and eager legs are
+        # one-GPU diagnostics (and a rank-asymmetric failure in a diagnostic leg must not be able to stall the headline line)
+        out["final_loss"] = round(float(tr.loss), 5)
+        red = getattr(tr.model, "_grad_reducer", None)
+        if red is not None and red.last_stats:
+            out["reducer"] = dict(red.last_stats)
+        del tr
+        torch.cuda.empty_cache()
+        return out
     # fed from pinned host memory: 3 page-locked batches cycled through the prefetcher (copy stream, depth 2)
     for transport in ("fp32", "int16"):
         host = []
