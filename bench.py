@@ -48,7 +48,10 @@ MFMA_BF16_PEAK = 2.5e15                 # FLOP/s, dense bf16 MFMA (no sparsity),
 MFMA_F32_PEAK = 157.3e12               # FLOP/s, dense fp32-input MFMA (= fp32 vector peak), same guide
 CLIP_SAMPLES = 320000                  # 10 s @ 32 kHz
 ALG_BYTES_PER_CLIP = 96.37e6           # mn10 fwd 94.50 MB + weights/B + mel 1.79 MB
-ALG_TRAIN = {"mn10": 285.8e6, "mn40": 581.5e6, "mn40_bf16": 581.5e6, "dymn20": 324.6e6, "dymn10": None}
+ALG_TRAIN = {"mn10": 285.8e6, "mn40": 581.5e6, "mn40_bf16": 581.5e6, "dymn20": 324.6e6, "dymn20_bf16": 324.6e6, "dymn10": None}
+# SURVEY 8(d) quotes the dymn20 contract for bf16 activations (3 x 104.70 + 8.7 + 1.79 MB); the same model with fp32 activations
+# moves 3 x 209.39 + 8.7 + 1.79 MB per clip by the same per-layer rule - reported beside the fp32-activation leg
+ALG_TRAIN_FP32_ACT = {"dymn20": 638.7e6}
 
 
 def quiet(fn, *a, **k):
@@ -842,9 +845,14 @@ def make_train_model(name, dev, precision=None):
     torch.manual_seed(0)
     if name.startswith("dymn"):
         from efficientat_amd.dymn import get_model as gm
-        model = quiet(gm, width_mult=2.0 if name == "dymn20" else 1.0)
+        model = quiet(gm, width_mult=2.0 if name.startswith("dymn20") else 1.0)
         if precision:
             model.train_precision = precision
+        elif name.endswith("bf16"):
+            # BASELINE configs[3] on the byte contract SURVEY 8(d) quotes for it: bf16 GEMM operands + bf16 storage of the wide
+            # tensors of every dynamic block (EAT_ACT_STORAGE=fp32: fp32 activations in HBM, for A/B)
+            model.train_precision = "bf16"
+            model.act_storage = os.environ.get("EAT_ACT_STORAGE", "bf16")
     else:
         from efficientat_amd.mn import get_model as gm
         model = quiet(gm, width_mult=4.0 if name.startswith("mn40") else 1.0)
@@ -941,6 +949,9 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
                       "parameters / optimizer" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
            "roofline_e2e_frac": round(cps / ranks.world * alg / HBM_PEAK, 4) if alg else None,
            "alg_bytes_per_clip": alg}
+    if name in ALG_TRAIN_FP32_ACT and getattr(model, "act_storage", "fp32") == "fp32":
+        res["alg_bytes_per_clip_fp32_activations"] = ALG_TRAIN_FP32_ACT[name]
+        res["roofline_e2e_frac_fp32_activations"] = round(cps / ranks.world * ALG_TRAIN_FP32_ACT[name] / HBM_PEAK, 4)
     red = getattr(model, "_grad_reducer", None) or getattr(model, "_grad_hooks_reducer", None)
     if red is not None and red.last_stats:
         res["reducer"] = dict(red.last_stats)
@@ -1088,7 +1099,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (configs[1]) measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event profiles (roofline objects)")
     ap.add_argument("--no-train-configs", action="store_true", help="skip the mn40_bf16 / dymn20 train steps (configs 2/3)")
-    ap.add_argument("--train-model", default=None, choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20"],
+    ap.add_argument("--train-model", default=None, choices=["mn10", "mn40", "mn40_bf16", "dymn10", "dymn20", "dymn20_bf16"],
                     help="only this train-step network (debug)")
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the exact-fp32 forward measurement")
     ap.add_argument("--no-kd", action="store_true", help="skip the KD training iteration (configs[4] per-GPU shard) measurement")
@@ -1192,12 +1203,13 @@ def main():
         "value": head["value"], "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": head["warmup"],
         "ms_per_step": head["ms_per_step"], "repetitions": head["repetitions"], "rep_ms_per_step": head["rep_ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if train_name == "mn40_bf16" else "f32", "data": "synthetic",
+        "dtype": "bf16" if train_name.endswith("bf16") else "f32", "data": "synthetic",
         "config": {"workload": f"{train_name}_as training step (log-mel + forward with batch-stat BatchNorm + BCE + backward + "
                                + ("bucketed RCCL all-reduce + " if world > 1 else "")
                                + f"fused Adam), batch {args.batch} synthetic 10 s @ 32 kHz clips per GPU, "
                                + ("bf16 GEMM operands and bf16 activation storage, fp32 statistics / parameters / optimizer "
-                                  "[BASELINE.json configs[2]; not the headline configuration]" if train_name == "mn40_bf16" else
+                                  f"[BASELINE.json configs[{2 if train_name == 'mn40_bf16' else 3}]; not the headline configuration]"
+                                  if train_name.endswith("bf16") else
                                   "fp32 [BASELINE.json metric; per-GPU shard of configs[4]; forward-only configs[1] in `forward`]"
                                   if train_name == "mn10" else "fp32 [BASELINE.json configs[3]; not the headline configuration]"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "arithmetic": arithmetic,
@@ -1257,7 +1269,8 @@ def main():
             torch.cuda.empty_cache()
 
     if world == 1 and not args.no_train_configs and args.train_model is None:
-        for key, name, bt, st, wu in [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2)]:
+        for key, name, bt, st, wu in [("train_step_mn40_bf16", "mn40_bf16", 128, 10, 2), ("train_step_dymn20", "dymn20", 128, 10, 2),
+                                      ("train_step_dymn20_bf16", "dymn20_bf16", 128, 10, 2)]:
             try:
                 result[key] = train_bench(name, bt, st, wu, args, mel, wave, ranks)
             except Exception as e:  # pragma: no cover - one failing leg must not lose the line

@@ -137,6 +137,15 @@ SIGNATURES = {
     "eat_dw_conv_bwd_bn_g_b16": [_P] * 9 + [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_pw_wgrad_b16_slots": [_I] * 5,
     "eat_pw_conv_wgrad_b16": [_P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    # bf16 activation storage of the DyMN blocks (BASELINE configs[3] on the SURVEY 8(d) byte contract)
+    "eat_dyn_pw_pack_b16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eat_pw_conv_dyn_b16_fwd": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "eat_dw_conv_dyn_fwd_stats_b16": [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
+    "eat_dyrelu_ca_fwd2_b16": [_P] * 7 + [_I, _I, _I, _I, _P],
+    "eat_dyrelu_ca_bwd2_b16": [_P] * 12 + [_I, _I, _I, _I, _P],
+    "eat_dw_conv_dyn_bwd_bn_g_b16": [_P] * 7 + [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
+    "eat_bn_bwd_apply_b16": [_P] * 8 + [_I, _I, _I, _I, _P],
+    "eat_pw_conv_dyn_wgrad_b16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
 }
 
 _lib = None

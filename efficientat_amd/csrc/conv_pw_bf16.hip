@@ -548,3 +548,32 @@ extern "C" int eat_pw_conv_b16_fwd(const void* x, int x_b16, const float* x2, in
   }
   return eat::fail(EAT_EINVAL, "eat_pw_conv_b16_fwd: at least one of x / y is a bf16 tensor");
 }
+
+// ---- per-sample-weight 1x1 conv of the bf16-STORAGE plan for DyMN (models/dymn/dy_block.py:103-131 with a 1x1 kernel, under the
+// reference's 16-bit mixed precision, ex_pl_audioset.py:287-293): plain bf16 operands, fp32 accumulation, the WIDE tensor of the
+// layer in bf16 in HBM.  wp_b: eat_dyn_pw_pack_b16 (one plain-bf16 pack per sample; tiles lie inside samples).
+//   x_b16 = 0, y_b16 = 1   dynamic expand conv z_e = W_b x (stats_part != NULL: batch statistics of the STORED z_e in the epilogue,
+//                          tiles = eat_pw_conv_stat_tiles(B, S, 1)), or the project data gradient dx2 = W_b^T dz_p
+//   x_b16 = 1, y_b16 = 0   dynamic project conv z_p = W_b x2 (+ statistics), or the expand data gradient dx = W_b^T dz_e + res
+// S % 8 == 0, Ci % 4 == 0.
+extern "C" int eat_pw_conv_dyn_b16_fwd(const void* x, int x_b16, const void* wp_b, const float* bias, const float* res, void* y,
+                                       int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !wp_b || !bias || !y) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_b16_fwd: missing operand");
+  if (B < 1 || Co < 1 || Ci < 4 || Ci % 4 != 0 || S < 8 || S % 8 != 0)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_b16_fwd: Ci=%d must be a multiple of 4 and S=%d a multiple of 8", Ci, S);
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_b16_fwd: bad act %d", act);
+  if ((x_b16 != 0) == (y_b16 != 0)) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_b16_fwd: exactly one of x / y is the bf16 (wide) tensor");
+  const __bf16* w16 = reinterpret_cast<const __bf16*>(wp_b);
+  const PwTf none{nullptr, nullptr, 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (y_b16) {
+    if (res) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_b16_fwd: a bf16 output takes no residual");
+    return dispatch<1, float, eat::bf16_t>(s, reinterpret_cast<const float*>(x), w16, bias, nullptr, nullptr,
+                                           reinterpret_cast<eat::bf16_t*>(y), nullptr, B, Ci, Co, S, act, Ci, none, nullptr, 0, true,
+                                           stats_part);
+  }
+  return dispatch<1, eat::bf16_t, float>(s, reinterpret_cast<const eat::bf16_t*>(x), w16, bias, nullptr, res,
+                                         reinterpret_cast<float*>(y), nullptr, B, Ci, Co, S, act, Ci, none, nullptr, 0, true,
+                                         stats_part);
+}

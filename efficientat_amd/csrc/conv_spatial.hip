@@ -326,6 +326,30 @@ extern "C" int eat_dw_conv_dyn_fwd_stats(const float* x, const float* in_a, cons
                                 stream);
 }
 
+// ... over bf16-stored x and y (the DyMN blocks of the bf16-storage plan; x_b16 = 0: the block without expand conv reads the
+// fp32 block input - tile geometries only): eat_dw_conv_fwd_stats_b16 with per-(b,c) taps.
+extern "C" int eat_dw_conv_dyn_fwd_stats_b16(const void* x, int x_b16, const float* in_a, const float* in_b, int in_act,
+                                             const float* w_bc, void* y, float* part, int inner_cap, int* h_inner, int B, int C,
+                                             int F, int T, int Fo, int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!x || !w_bc || !y) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_fwd_stats_b16: missing operand");
+  if ((in_a == nullptr) != (in_b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_fwd_stats_b16: in_a and in_b come together");
+  if (in_act < 0 || in_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_fwd_stats_b16: bad in_act %d", in_act);
+  if (!part || !h_inner || inner_cap < eat_dw_partials_inner(F, T, Fo, To, k, stride, 0))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_fwd_stats_b16: partial buffer too small (inner_cap %d)", inner_cap);
+  if ((F * T) % 2 != 0 || (Fo * To) % 2 != 0)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_fwd_stats_b16: planes must hold an even number of elements (%d, %d)", F * T, Fo * To);
+  int inner = 1;
+  const eat::DwEpi epi{part, nullptr, nullptr, nullptr, 0, nullptr, &inner};
+  const int rc = eat::dw_plane_try(reinterpret_cast<const float*>(x), w_bc, nullptr, nullptr, reinterpret_cast<float*>(y), nullptr, B,
+                                   C, F, T, Fo, To, k, stride, EAT_ACT_NONE, 0, 1, in_a, in_b, in_act, (hipStream_t)stream, &epi,
+                                   x_b16 ? 1 : 2);
+  if (rc == 1)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_fwd_stats_b16: no register-resident kernel for F=%d T=%d k=%d stride=%d x_b16=%d", F, T, k, stride, x_b16);
+  *h_inner = inner;
+  return rc;
+}
+
 // stride-1 depthwise data gradient = the same sliding-window kernel with the taps read reversed
 namespace eat {
 int dw_conv_dgrad_s1(const float* dz, const float* w, const float* zero_bias, const float* res, float* dx, int B, int C,

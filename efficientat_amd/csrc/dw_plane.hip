@@ -366,7 +366,12 @@ int launch_plane(const PlaneArgs& a0, hipStream_t s) {
   const dim3 grid((waves + 3) / 4), blk(256);
   if (a.epi.inner) *a.epi.inner = 1;
   if (a.b16) {                                            // bf16 storage: train-mode conv + statistics (eat_dw_conv_fwd_stats_b16)
-    if (!a.epi.stats || a.per_plane_w || a.epi.gz || a.res || a.pool || a.act != EAT_ACT_NONE || a.flip) return 1;
+    if (!a.epi.stats || a.epi.gz || a.res || a.pool || a.act != EAT_ACT_NONE || a.flip) return 1;
+    if (a.per_plane_w) {                                  // ... with per-plane taps (DyMN, eat_dw_conv_dyn_fwd_stats_b16): bf16 -> bf16
+      if (a.b16 == 2) return 1;
+      hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, true, eat::bf16_t>), grid, blk, 0, s, a, a.w, a.bias);
+      return eat::check_launch("eat_dw_conv_dyn_fwd_stats_b16(plane)");
+    }
     if (a.b16 == 2)
       hipLaunchKernelGGL((dw_plane_kernel<K, S, CPL, LPP, F, PF, EAT_ACT_NONE, 0, true, false, float, eat::bf16_t>), grid, blk, 0, s, a, a.w, a.bias);
     else
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
   constexpr int ND = S == 1 ? 2 : 1;                               // dz columns per lane
   constexpr int NE = S == 1 ? 2 + 2 * P : K;                       // extended x row: columns under the filter
   constexpr unsigned EB = Bio<XT>::kB, EBZ = Bio<ZT>::kB;
-  static_assert(!PPW || (EB == 4 && EBZ == 4), "per-plane taps: fp32 storage only");
+  // (PPW with bf16 storage: the DyMN blocks of the bf16-storage plan; a.res - fp32 - only with XT = float, host-checked)
   const int lane = threadIdx.x & 63;
   const int l = lane & (LPP - 1);
   const int half = lane / LPP;                                     // which of the wave's NPW planes (samples)
@@ -1276,8 +1281,8 @@ __global__ __launch_bounds__(256) void dw_bwd_tile_kernel(const DwBwdArgs a, con
             const f32x2 rv = buf_load2(rres, (rowok && ok0) ? hx + 4u * (unsigned)col_in : kOOB, so);
             o0 += rv[0]; o1 += rv[1];
           }
-          buf_store2(o0, o1, rg, rowok ? vo2 : kOOB, so);
-          buf_store(o0, rg, rowok ? vo1 : kOOB, so);
+          Bio<XT>::st2(o0, o1, rg, rowok ? vo2 : kOOB, so);
+          Bio<XT>::st1(o0, rg, rowok ? vo1 : kOOB, so);
         } else {
           Bio<XT>::st2(o0, o1, rg, rowok ? vo2 : kOOB, so);
           Bio<XT>::st1(o0, rg, rowok ? vo1 : kOOB, so);
@@ -1402,6 +1407,25 @@ int launch_dw_bwd(DwBwdArgs a, const float* w, int* h_inner, hipStream_t s, bool
   if (waves > 0x7fffffffLL) return 1;
   if (h_inner) *h_inner = a.n_rc * a.n_cs;
   const dim3 grid((unsigned)((waves + 3) / 4));
+  if (ppw && a.b16) {                                    // per-plane taps with bf16 storage (eat_dw_conv_dyn_bwd_bn_g_b16)
+    using BT = eat::bf16_t;
+    if (!bn) return 1;
+    if (a.b16 == 2) {                                     // x and g fp32 (the block without expand conv: 3x3 / stride 1 on the stem planes)
+      if constexpr (K == 3 && S == 1 && RO == 8) {
+        if (lpp == 64 && !wr) {
+          hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false, true, float, BT>), grid, dim3(256), 0, s, a, w);
+          return eat::check_launch("eat_dw_conv_dyn_bwd_bn_g_b16");
+        }
+      }
+      return 1;
+    }
+    if (a.res) return 1;                                  // (the fp32 skip gradient goes with an fp32 g)
+    if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true, true, BT, BT>), grid, dim3(256), 0, s, a, w);
+    else if (lpp == 64) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, false, true, BT, BT>), grid, dim3(256), 0, s, a, w);
+    else if (lpp == 32) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 32, true, true, BT, BT>), grid, dim3(256), 0, s, a, w);
+    else hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 16, true, true, BT, BT>), grid, dim3(256), 0, s, a, w);
+    return eat::check_launch("eat_dw_conv_dyn_bwd_bn_g_b16");
+  }
   if (ppw) {                                             // per-plane taps (DyMN): the BatchNorm-on-load instances only
     if (!bn) return 1;
     if (lpp == 64 && wr) hipLaunchKernelGGL((dw_bwd_tile_kernel<K, S, RO, true, 64, true, true>), grid, dim3(256), 0, s, a, w);

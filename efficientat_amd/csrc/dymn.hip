@@ -10,6 +10,7 @@
 // MFMA / sliding-window kernel as the static network, reading per-sample weights.
 #include <cstdlib>
 #include "eat_common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -125,14 +126,15 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restric
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 __global__ __launch_bounds__(256) void dyn_pw_pack_bf16_kernel(const float* __restrict__ bank, const float* __restrict__ att,
                                                                __bf16* __restrict__ wp, int K, int Co, int Ci, int MT, int KK,
-                                                               int trans) {
+                                                               int trans, int np2) {
+  // np2 = 2: hi / lo fragments (bf16x3); np2 = 1: the hi part only (plain bf16 operands, the bf16-storage plan)
   __shared__ float s_w[16 * (kPackCols + 1)];
   const int mt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int m0 = mt * 16;
   const int rows = (Co - m0) < 16 ? (Co - m0) : 16;
   const float* a = att + (size_t)b * K;
   const size_t N = (size_t)Co * Ci;
-  __bf16* out = wp + (size_t)b * KK * MT * 1024;
+  __bf16* out = wp + (size_t)b * KK * MT * 512 * np2;
   const int lane = tid & 63, wv = tid >> 6;
   const int m = lane & 15, kq = lane >> 4;
   for (int c0 = 0; c0 < Ci; c0 += kPackCols) {
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_bf16_kernel(const float* __re
     }
     __syncthreads();
     const int nkk = (cols + 31) >> 5;
-    for (int j = wv; j < nkk * 2; j += 4) {                        // (32-column chunk, hi / lo) fragments of this piece
-      const int kl = j >> 1, h = j & 1;
+    for (int j = wv; j < nkk * np2; j += 4) {                      // (32-column chunk, hi / lo) fragments of this piece
+      const int kl = np2 == 2 ? j >> 1 : j, h = np2 == 2 ? j & 1 : 0;
       bf16x8_t o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_bf16_kernel(const float* __re
         const __bf16 hi = (__bf16)v;
         o[i] = h ? (__bf16)(v - (float)hi) : hi;
       }
-      *reinterpret_cast<bf16x8_t*>(out + (((size_t)((c0 >> 5) + kl) * MT + mt) * 2 + h) * 512 + lane * 8) = o;
+      *reinterpret_cast<bf16x8_t*>(out + (((size_t)((c0 >> 5) + kl) * MT + mt) * np2 + h) * 512 + lane * 8) = o;
     }
     __syncthreads();
   }
@@ -471,11 +473,12 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // LPP lanes per plane (64 / LPP planes of consecutive channels per wave), NC columns per lane (To <= LPP * NC)
-template <int LPP, int NC>
-__global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __restrict__ z, const float* __restrict__ a,
+// ST: storage type of the feature maps z / out (act_io.h; bf16 in the bf16-storage plan - the output is rounded on store)
+template <int LPP, int NC, typename ST = float>
+__global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const ST* __restrict__ z, const float* __restrict__ a,
                                                              const float* __restrict__ b, const float* __restrict__ coef,
                                                              const float* __restrict__ gf, const float* __restrict__ gt,
-                                                             float* __restrict__ out, int n_planes, int C, int Fo, int To) {
+                                                             ST* __restrict__ out, int n_planes, int C, int Fo, int To) {
   constexpr int NPW = 64 / LPP;
   const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -489,8 +492,8 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
   const size_t grow = (size_t)c * Bn + plane / C;                  // gate row of plane (b, c) in the (C, B, .) tables
   const float* gfp = gf + grow * Fo;
   const float* gtp = gt + grow * To;
-  const float* zp = z + (size_t)plane * Fo * To;
-  float* op = out + (size_t)plane * Fo * To;
+  const ST* zp = z + (size_t)plane * Fo * To;
+  ST* op = out + (size_t)plane * Fo * To;
   float at[NC];
   bool ok[NC];
 #pragma unroll
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int t = l + LPP * j;
-        v[r][j] = zp[(size_t)f * To + (t < To ? t : 0)];
+        v[r][j] = eat::Io<ST>::load1(zp + (size_t)f * To + (t < To ? t : 0));
       }
     }
 #pragma unroll
@@ -519,17 +522,18 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const float* __rest
       for (int j = 0; j < NC; ++j) {
         const float u = fmaf(av, v[r][j], bv);
         const float o = fmaxf(fmaf(cf.x, u, cf.z), fmaf(cf.y, u, cf.w)) * (af[r] * at[j]);
-        if (ok[j]) op[(size_t)(f0 + r) * To + l + LPP * j] = o;
+        if (ok[j]) eat::Io<ST>::store1(op + (size_t)(f0 + r) * To + l + LPP * j, o);
       }
     }
   }
 }
 
-template <int LPP, int NC>
-__global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+// ST: storage type of dout / z / dv; the BatchNorm-backward partials are those of dv AS STORED
+template <int LPP, int NC, typename ST = float>
+__global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const ST* __restrict__ dout, const ST* __restrict__ z,
                                                              const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ coef, const float* __restrict__ gf,
-                                                             const float* __restrict__ gt, float* __restrict__ dv,
+                                                             const float* __restrict__ gt, ST* __restrict__ dv,
                                                              float* __restrict__ dcoef, float* __restrict__ dgf,
                                                              float* __restrict__ dgt, float* __restrict__ bnpart,
                                                              int n_planes, int C, int Fo, int To) {
@@ -570,8 +574,8 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __rest
       for (int j = 0; j < NC; ++j) {
         const int t = l + LPP * j;
         const size_t e = base + (size_t)f * To + (t < To ? t : 0);
-        zv[r][j] = z[e];
-        dd[r][j] = dout[e];
+        zv[r][j] = eat::Io<ST>::load1(z + e);
+        dd[r][j] = eat::Io<ST>::load1(dout + e);
       }
     }
 #pragma unroll
@@ -587,8 +591,8 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const float* __rest
         const float m = sel ? l1 : l2;
         const float d = ok[j] ? dd[r][j] : 0.0f;
         const float dm = d * (af[r] * at[j]);
-        const float g = dm * (sel ? cf.x : cf.y);
-        if (ok[j] && mine) dv[base + (size_t)(f0 + r) * To + l + LPP * j] = g;
+        const float g = eat::Io<ST>::rnd(dm * (sel ? cf.x : cf.y));
+        if (ok[j] && mine) eat::Io<ST>::store1(dv + base + (size_t)(f0 + r) * To + l + LPP * j, g);
         const float dmv = dm * u;
         da1 += sel ? dmv : 0.0f; db1 += sel ? dm : 0.0f;
         da2 += sel ? 0.0f : dmv; db2 += sel ? 0.0f : dm;
@@ -701,14 +705,14 @@ extern "C" int eat_dyn_pw_pack_t(const float* bank_t, const float* att, const fl
 }
 
 static int dyn_pw_pack_bf16_impl(const float* bank, const float* att, void* wp, int B, int K, int Co, int Ci, int trans,
-                                 eat_stream_t stream) {
+                                 eat_stream_t stream, int np2 = 2) {
   eat::clear_stale_error();
   if (Ci % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16: Ci=%d must be a multiple of 4", Ci);
   if (trans && Co % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16_t: Co=%d must be a multiple of 4", Co);
   if (B < 1 || K < 1 || Co < 1) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16: bad shape");
   const int MT = (Co + 15) / 16, KK = (Ci + 31) / 32;
   hipLaunchKernelGGL(dyn_pw_pack_bf16_kernel, dim3(MT, B), dim3(256), 0, (hipStream_t)stream, bank, att,
-                     reinterpret_cast<__bf16*>(wp), K, Co, Ci, MT, KK, trans);
+                     reinterpret_cast<__bf16*>(wp), K, Co, Ci, MT, KK, trans, np2);
   return eat::check_launch("eat_dyn_pw_pack_bf16");
 }
 
@@ -720,6 +724,13 @@ extern "C" int eat_dyn_pw_pack_bf16(const float* bank, const float* att, void* w
 extern "C" int eat_dyn_pw_pack_bf16_t(const float* bank_t, const float* att, void* wp, int B, int K, int Co, int Ci,
                                       eat_stream_t stream) {
   return dyn_pw_pack_bf16_impl(bank_t, att, wp, B, K, Co, Ci, 1, stream);
+}
+
+// plain bf16 packs (one fragment per (k-chunk, m-tile), eat_pw_prepack_bf16's layout with split = 0) for the per-sample convs of
+// the bf16-storage plan (eat_pw_conv_dyn_b16_fwd); trans != 0: from the bank of the transposed matrices (the data gradient)
+extern "C" int eat_dyn_pw_pack_b16(const float* bank, const float* att, void* wp, int B, int K, int Co, int Ci, int trans,
+                                   eat_stream_t stream) {
+  return dyn_pw_pack_bf16_impl(bank, att, wp, B, K, Co, Ci, trans ? 1 : 0, stream, 1);
 }
 
 extern "C" int eat_ctx_pool_bwd(const float* dseq, const float* add, float* dx, int B, int C, int F, int T,
@@ -809,17 +820,17 @@ extern "C" int eat_ctx_split_bwd(const float* dhcf, const float* dhct, const flo
   return eat::check_launch("eat_ctx_split_bwd");
 }
 
-#define EAT_DYRELU2_DISPATCH(KERNEL, ...)                                                                             \
+#define EAT_DYRELU2_DISPATCH(KERNEL, ST, ...)                                                                         \
   do {                                                                                                                \
     const int n_planes = B * C;                                                                                       \
     if (To <= 32) {                                                                                                   \
-      hipLaunchKernelGGL((KERNEL<32, 1>), dim3((n_planes / 2 + 1 + 3) / 4), dim3(256), 0, hs, __VA_ARGS__);            \
+      hipLaunchKernelGGL((KERNEL<32, 1, ST>), dim3((n_planes / 2 + 1 + 3) / 4), dim3(256), 0, hs, __VA_ARGS__);        \
     } else {                                                                                                          \
       const dim3 grid((n_planes + 3) / 4);                                                                            \
-      if (To <= 64) hipLaunchKernelGGL((KERNEL<64, 1>), grid, dim3(256), 0, hs, __VA_ARGS__);                          \
-      else if (To <= 128) hipLaunchKernelGGL((KERNEL<64, 2>), grid, dim3(256), 0, hs, __VA_ARGS__);                    \
-      else if (To <= 256) hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(256), 0, hs, __VA_ARGS__);                    \
-      else hipLaunchKernelGGL((KERNEL<64, 8>), grid, dim3(256), 0, hs, __VA_ARGS__);                                   \
+      if (To <= 64) hipLaunchKernelGGL((KERNEL<64, 1, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                      \
+      else if (To <= 128) hipLaunchKernelGGL((KERNEL<64, 2, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                \
+      else if (To <= 256) hipLaunchKernelGGL((KERNEL<64, 4, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                \
+      else hipLaunchKernelGGL((KERNEL<64, 8, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                               \
     }                                                                                                                 \
   } while (0)
 
@@ -831,8 +842,21 @@ extern "C" int eat_dyrelu_ca_fwd2(const float* z, const float* a, const float* b
   if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2: bad shape (To <= 512)");
   if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2: a and b come together");
   hipStream_t hs = (hipStream_t)stream;
-  EAT_DYRELU2_DISPATCH(dyrelu_ca_fwd2_kernel, z, a, b, coef, gate_f, gate_t, out, n_planes, C, Fo, To);
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_fwd2_kernel, float, z, a, b, coef, gate_f, gate_t, out, n_planes, C, Fo, To);
   return eat::check_launch("eat_dyrelu_ca_fwd2");
+}
+
+// bf16-storage twin (act_io.h): z and out are bf16 in HBM
+extern "C" int eat_dyrelu_ca_fwd2_b16(const void* z, const float* a, const float* b, const float* coef, const float* gate_f,
+                                      const float* gate_t, void* out, int B, int C, int Fo, int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2_b16: bad shape (To <= 512)");
+  if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_fwd2_b16: a and b come together");
+  hipStream_t hs = (hipStream_t)stream;
+  const eat::bf16_t* z16 = reinterpret_cast<const eat::bf16_t*>(z);
+  eat::bf16_t* o16 = reinterpret_cast<eat::bf16_t*>(out);
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_fwd2_kernel, eat::bf16_t, z16, a, b, coef, gate_f, gate_t, o16, n_planes, C, Fo, To);
+  return eat::check_launch("eat_dyrelu_ca_fwd2_b16");
 }
 
 // backward: dv (w.r.t. v), dcoef (B,C,4), dgate_f / dgate_t (pre-sigmoid, layouts of the gates), bnpart (B,C,2) = per-plane
@@ -844,8 +868,23 @@ extern "C" int eat_dyrelu_ca_bwd2(const float* dout, const float* z, const float
   if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2: bad shape (To <= 512)");
   if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2: a and b come together");
   hipStream_t hs = (hipStream_t)stream;
-  EAT_DYRELU2_DISPATCH(dyrelu_ca_bwd2_kernel, dout, z, a, b, coef, gate_f, gate_t, dv, dcoef, dgate_f, dgate_t, bnpart, n_planes, C, Fo, To);
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_bwd2_kernel, float, dout, z, a, b, coef, gate_f, gate_t, dv, dcoef, dgate_f, dgate_t, bnpart, n_planes, C, Fo, To);
   return eat::check_launch("eat_dyrelu_ca_bwd2");
+}
+
+// bf16-storage twin: dout, z and dv are bf16 in HBM (bnpart: sums of dv as stored)
+extern "C" int eat_dyrelu_ca_bwd2_b16(const void* dout, const void* z, const float* a, const float* b, const float* coef,
+                                      const float* gate_f, const float* gate_t, void* dv, float* dcoef, float* dgate_f,
+                                      float* dgate_t, float* bnpart, int B, int C, int Fo, int To, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (B < 1 || C < 1 || Fo < 1 || To < 1 || To > 512) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2_b16: bad shape (To <= 512)");
+  if ((a == nullptr) != (b == nullptr)) return eat::fail(EAT_EINVAL, "eat_dyrelu_ca_bwd2_b16: a and b come together");
+  hipStream_t hs = (hipStream_t)stream;
+  const eat::bf16_t* d16 = reinterpret_cast<const eat::bf16_t*>(dout);
+  const eat::bf16_t* z16 = reinterpret_cast<const eat::bf16_t*>(z);
+  eat::bf16_t* dv16 = reinterpret_cast<eat::bf16_t*>(dv);
+  EAT_DYRELU2_DISPATCH(dyrelu_ca_bwd2_kernel, eat::bf16_t, d16, z16, a, b, coef, gate_f, gate_t, dv16, dcoef, dgate_f, dgate_t, bnpart, n_planes, C, Fo, To);
+  return eat::check_launch("eat_dyrelu_ca_bwd2_b16");
 }
 #undef EAT_DYRELU2_DISPATCH
 

@@ -249,12 +249,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_multi_kernel(
 }
 
 // ---- backward pass 2: dz = a * (g - sum_g/N - xhat * sum_gx/N) ----------------------------------------------
-template <int ACT, typename ZT = float>
+// DT: storage type of dy AND dz (fp32; bf16: the expand BatchNorm of a DyMN block under the bf16-storage plan, g_e -> dz_e in place)
+template <int ACT, typename ZT = float, typename DT = float>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const float* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
+    const DT* __restrict__ dy, const ZT* __restrict__ z, const float* __restrict__ a,
     const float* __restrict__ b, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gscale, const float* __restrict__ gadd, const double* __restrict__ sums,
-    float* __restrict__ dz, int C, int S, double n, eat::bf16_t* __restrict__ dz16 = nullptr) {
+    DT* __restrict__ dz, int C, int S, double n, eat::bf16_t* __restrict__ dz16 = nullptr) {
   // dz16: optional bf16 COPY of dz (what the data-gradient 1x1 conv of the bf16-storage plan reads: see bn_act_fwd_kernel)
   const int plane = blockIdx.x, c = plane % C;
   const float av = a[c], bv = b[c], mu = mean[c], is = invstd[c];
@@ -268,16 +269,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   if ((S & 3) == 0) {
 #pragma unroll 4
     for (int i = threadIdx.x * 4; i < S; i += blockDim.x * 4) {
-      const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+      const float4 d = Io<DT>::load4(dy + base + i);
       const float4 v = Io<ZT>::load4(z + base + i);
       const float4 o = make_float4(f(d.x, v.x), f(d.y, v.y), f(d.z, v.z), f(d.w, v.w));
-      *reinterpret_cast<float4*>(dz + base + i) = o;
+      Io<DT>::store4(dz + base + i, o);
       if (dz16) Io<eat::bf16_t>::store4(dz16 + base + i, o);
     }
   } else {
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-      const float o = f(dy[base + i], Io<ZT>::load1(z + base + i));
-      dz[base + i] = o;
+      const float o = f(Io<DT>::load1(dy + base + i), Io<ZT>::load1(z + base + i));
+      Io<DT>::store1(dz + base + i, o);
       if (dz16) Io<eat::bf16_t>::store1(dz16 + base + i, o);
     }
   }
@@ -1589,6 +1590,24 @@ extern "C" int eat_bn_act_bwd_apply_b16(const float* dy, const void* z, const fl
   return eat::check_launch("eat_bn_act_bwd_apply_b16");
 }
 
+// ... with dy AND dz in bf16 too (dz may alias dy): the expand BatchNorm of a DyMN block under the bf16-storage plan - g_e, z_e
+// and dz_e are all wide tensors (models/dymn/dy_block.py:313-318 backward)
+extern "C" int eat_bn_bwd_apply_b16(const void* dy, const void* z, const float* a, const float* b, const float* mean,
+                                    const float* invstd, const double* sums, void* dz, int B, int C, int S, int act,
+                                    eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (act < 0 || act > 2) return eat::fail(EAT_EINVAL, "eat_bn_bwd_apply_b16: bad act %d", act);
+  if (!dy || !z || !dz || !sums || B < 1 || C < 1 || S < 1) return eat::fail(EAT_EINVAL, "eat_bn_bwd_apply_b16: bad arguments");
+  const dim3 blk(S >= 1024 ? 256 : 64);
+  const double n = (double)B * S;
+  EAT_DISPATCH_ACT(act, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, eat::bf16_t, eat::bf16_t>), EAT_PLANES_GRID(B, C), blk, 0,
+                                           (hipStream_t)stream, reinterpret_cast<const eat::bf16_t*>(dy),
+                                           reinterpret_cast<const eat::bf16_t*>(z), a, b, mean, invstd, (const float*)nullptr,
+                                           (const float*)nullptr, sums, reinterpret_cast<eat::bf16_t*>(dz), C, S, n,
+                                           (eat::bf16_t*)nullptr));
+  return eat::check_launch("eat_bn_bwd_apply_b16");
+}
+
 extern "C" int eat_bn_act_bwd_apply(const float* dy, const float* z, const float* a, const float* b,
                                     const float* mean, const float* invstd, const float* gscale, const float* gadd,
                                     const double* sums, float* dz, int B, int C, int S, int act, eat_stream_t stream) {
@@ -1861,6 +1880,31 @@ extern "C" int eat_dw_conv_dyn_bwd_bn_g(const float* dy, const float* z, const f
   const int rc = eat::dw_bwd_try(dy, x, in_a, in_b, in_act, w_bc, g, dw_bc, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
                                  (hipStream_t)stream, &bn, 1, res, gzpart);
   if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g: merged kernel unavailable");
+  return rc;
+}
+
+// ... over bf16-stored dy, z (and x, g when x_b16 != 0; x_b16 = 0: the block without expand conv - x is the fp32 block input, g
+// the fp32 input gradient, res its skip gradient): the DyMN blocks of the bf16-storage plan.  res needs x_b16 = 0.
+extern "C" int eat_dw_conv_dyn_bwd_bn_g_b16(const void* dy, const void* z, const float* bn_a, const float* bn_b,
+                                            const float* bn_mean, const float* bn_invstd, const double* sums, int bn_act,
+                                            int frozen, const void* x, int x_b16, const float* in_a, const float* in_b, int in_act,
+                                            const float* w_bc, const float* res, void* g, float* dw_bc, float* gpart,
+                                            float* gzpart, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo,
+                                            int To, int k, int stride, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dy || !z || !bn_a || !bn_b || !bn_mean || !bn_invstd || !sums || !x || !in_a || !in_b || !w_bc || !g || !dw_bc)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g_b16: missing operand");
+  if (in_act < 0 || in_act > 2 || bn_act < 0 || bn_act > 2) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g_b16: bad act");
+  if (res && x_b16) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g_b16: the skip gradient goes with an fp32 g (x_b16 = 0)");
+  if (!dw_bwd_bn_geometry_ok(B, C, F, T, Fo, To, k, stride) || (F * T) % 2 != 0 || (Fo * To) % 2 != 0)
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g_b16: geometry not covered by the merged kernel (F=%d T=%d k=%d stride=%d)", F, T, k, stride);
+  if ((gpart || gzpart) && inner_cap < eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
+    return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g_b16: partial buffer too small (inner_cap %d)", inner_cap);
+  const eat::DwBnBwd bn{reinterpret_cast<const float*>(z), bn_a, bn_b, bn_mean, bn_invstd, nullptr, nullptr, sums, bn_act, frozen};
+  const int rc = eat::dw_bwd_try(reinterpret_cast<const float*>(dy), reinterpret_cast<const float*>(x), in_a, in_b, in_act, w_bc,
+                                 reinterpret_cast<float*>(g), dw_bc, gpart, h_inner, B, C, F, T, Fo, To, k, stride,
+                                 (hipStream_t)stream, &bn, 1, res, gzpart, x_b16 ? 1 : 2);
+  if (rc == 1) return eat::fail(EAT_EINVAL, "eat_dw_conv_dyn_bwd_bn_g_b16: no instance for F=%d T=%d k=%d stride=%d x_b16=%d", F, T, k, stride, x_b16);
   return rc;
 }
 
@@ -2220,6 +2264,45 @@ extern "C" int eat_pw_conv_wgrad_b16(const void* dz, int dz_b16, const void* x, 
 #undef EAT_WIDE16
   hipLaunchKernelGGL(wgrad_slot_reduce4_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, hs, ws, dW, Co * Ci, (int)p.nz);
   return eat::check_launch("eat_pw_conv_wgrad_b16");
+}
+
+// Per-sample weight gradients of a dynamic 1x1 conv under the bf16-storage plan (autograd of the grouped F.conv2d of
+// models/dymn/dy_block.py:120-127): dW_b (B, Co, Ci) = dz[b] x[b]^T with exactly one bf16 operand (the wide tensor), plain bf16
+// products, fp32 accumulation.  The wide-tile kernel of eat_pw_conv_wgrad_b16 with one k-slice per SAMPLE: slice b is stored as
+// dW_b[b] - every element of dW_b is written, no zero fill, no reduction.  S % 4 == 0, Ci % 4 == 0.
+extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int B, int Co,
+                                         int Ci, int S, eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!dz || !x || !dW_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: missing operand");
+  if ((dz_b16 != 0) == (x_b16 != 0)) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: exactly one of dz / x is the bf16 (wide) tensor");
+  if (B < 1 || Co < 1 || Ci < 4 || (Ci & 3) != 0 || S < 4 || (S & 3) != 0)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: Ci=%d and S=%d must be multiples of 4", Ci, S);
+  WgB16Plan p = wgrad_b16_plan(B, Co, Ci, S, x_b16);
+  if (!p.w.ok) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: internal tiling error (%d x %d)", Co, Ci);
+  if ((long long)(x_b16 ? Ci : Co) * S * 2 > 0x7fffffffLL || (long long)(x_b16 ? Co : Ci) * S * 4 > 0x7fffffffLL)
+    return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: a sample exceeds the 32-bit row offsets");
+  p.upb = p.sps;                                                       // one k-slice = one sample
+  p.nz = (unsigned)B;
+  hipStream_t hs = (hipStream_t)stream;
+  const size_t smem = (size_t)(p.w.ptr / 8 + p.w.qtr / 8) * 2 * 1024;
+  dim3 grid(p.w.ptn, p.w.qtn, p.nz);
+  const float* fdz = reinterpret_cast<const float*>(dz);
+  const float* fx = reinterpret_cast<const float*>(x);
+#define EAT_WIDE16D(SW_)                                                                                                  \
+  do {                                                                                                                    \
+    auto kern = pw_wgrad_wide_kernel<1, SW_, false, false, true, false>;                                                  \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+        return eat::fail(EAT_ELAUNCH, "eat_pw_conv_dyn_wgrad_b16: hipFuncSetAttribute(160 KB of LDS) failed");            \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, fdz, fx, (const float*)nullptr, dW_b, B, Co, Ci, S, p.sps, p.upb,  \
+                       p.w.ptr, p.w.qtr, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0);      \
+  } while (0)
+  if (!x_b16) EAT_WIDE16D(false); else EAT_WIDE16D(true);
+#undef EAT_WIDE16D
+  return eat::check_launch("eat_pw_conv_dyn_wgrad_b16");
 }
 
 // 1 where eat_pw_conv_dyn_wgrad adds into dW_b (the caller zero-fills it), 0 where it stores.  Host helper.

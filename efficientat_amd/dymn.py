@@ -241,6 +241,10 @@ class DyMN(nn.Module):
         self._cache = _FoldCache()
         # arithmetic of the 1x1 convs of a train-mode pass (ops.precision; same switch and default as MN)
         self.train_precision = os.environ.get("EAT_TRAIN_PRECISION", "auto")
+        # storage of the wide activations of a train-mode pass (same switch as MN): "bf16" = z_e, z_d, the DyReLU * CoordAtt
+        # output and the gradients arriving at them live in bf16 in HBM in every fully dynamic block the kernels cover
+        # (dymn_train.DyBlockMain; the reference's `precision=16`, ex_pl_audioset.py:287-293); needs train_precision "bf16"
+        self.act_storage = os.environ.get("EAT_ACT_STORAGE", "fp32")
 
     # ----------------------------------------------------------------------- folded BN (eval)
     def _fold_sources(self):

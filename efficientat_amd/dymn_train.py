@@ -293,11 +293,29 @@ def _dyn_pw(x, bank, att, transposed, res=None, stats_bn=None):
     return ops.pw_conv_dyn(x, ops.dyn_pw_pack(bank2, att, Co, Ci, trans=tr), zero, Co, NONE, res=res)
 
 
+def _dyn_pw_b16(x, bank, att, transposed, res=None, stats_bn=None):
+    """`_dyn_pw` of the bf16-storage plan: exactly one of x / z is the wide bf16 tensor (x fp32 -> z bf16: expand conv, project
+    data gradient; x bf16 -> z fp32 (+ res): project conv, expand data gradient), per-sample weights as plain bf16 fragments,
+    the batch statistics of z AS STORED from the conv's epilogue (stats_bn)."""
+    K, Co, Ci = bank.shape
+    if transposed:
+        Co, Ci = Ci, Co
+    wp = ops.dyn_pw_pack_b16(bank.reshape(K, Co * Ci), att, Co, Ci, trans=transposed)
+    if stats_bn is None:
+        return ops.pw_conv_dyn_b16(x, wp, Co, NONE, res=res)
+    if stats_bn.training:
+        z, parts = ops.pw_conv_dyn_b16(x, wp, Co, NONE, stats=True)
+        return z, ops.bn_state_from_partials(parts, stats_bn, z.numel() // Co)
+    return ops.pw_conv_dyn_b16(x, wp, Co, NONE), ops.bn_frozen_state(stats_bn)
+
+
 def _dyn_pw_wgrad(dz, x, bank, att, datt=None):
     """-> (dbank (K, Co*Ci), datt (B, K)): per-sample weight gradients G_b = dz_b x_b^T, then dbank = att^T G,
     datt = G bank^T."""
     K, Co, Ci = bank.shape
     B, S = x.shape[0], x.shape[2] * x.shape[3]
+    if dz.dtype == torch.bfloat16 or x.dtype == torch.bfloat16:            # bf16-storage plan: one wide operand
+        return _bank_grad(ops.pw_conv_dyn_wgrad_b16(dz, x), att, bank.reshape(K, Co * Ci), datt)
     if ops.dyn_wgrad_needs_zero(Co, Ci, S):
         G = ops.zero_arena.zeros((B, Co * Ci), torch.float32, x.device)
     else:                                       # bf16x3 kernel in per-sample mode: plain stores
@@ -494,6 +512,7 @@ import os as _os
 _FUSED_BLOCK = True       # the dynamic block as one autograd Function (round 4; ablated blocks keep the per-layer Functions)
 _EPI_STATS = True         # BatchNorm statistics in the dynamic 1x1 convs' epilogue
 _FUSED_DW = _os.environ.get("EAT_DYMN_FUSED_DW", "1") != "0"      # A/B: the round-4 depthwise / DyReLU kernels of the block
+_STORE16 = False          # set by forward_train for the pass: model.act_storage == "bf16" (the bf16-storage plan of the blocks)
 
 
 class _Ones:
@@ -579,15 +598,22 @@ class DyBlockMain(torch.autograd.Function):
         Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
         # fused: round-4 kernels (per-plane taps in the register-resident depthwise kernels, one-wave-per-plane DyReLU on
         # channel-major gates); otherwise the separate passes on position-major gates
-        sv = {"fused": fused}
+        # fused == 2: the bf16-storage plan (model.act_storage = "bf16"): z_e, z_d, x2 (and dx2, dv, g_e, dz_e in the backward)
+        # are bf16 in HBM, plain bf16 GEMM operands, statistics of the values as stored (include/eat_hip.h, "bf16 activation
+        # storage for the DyMN blocks"); block input / output, context path and per-sample weight gradients stay fp32
+        b16 = fused == 2
+        sv = {"fused": fused, "b16": b16}
         taps = ops.dyn_aggregate(w_d.view(K, cexp * k * k), att_d)
-        if has_e:
+        if has_e and b16:
+            z_e, st_e = _dyn_pw_b16(x, w_e.view(K, cexp, cin), att_e, False, stats_bn=blk.exp_norm)
+            sv.update(z_e=z_e, st_e=st_e)
+        elif has_e:
             z_e, st_e = _dyn_pw(x, w_e.view(K, cexp, cin), att_e, False, stats_bn=blk.exp_norm)
             sv.update(z_e=z_e, st_e=st_e)
         if fused:
             # expand BatchNorm + activation on load, depth_norm's statistics in the epilogue: y_e is never written
             z_d, parts = ops.dw_conv_dyn_stats(z_e if has_e else x, taps, k, stride,
-                                               tf=(st_e[0], st_e[1], act) if has_e else None)
+                                               tf=(st_e[0], st_e[1], act) if has_e else None, out_b16=b16)
             st_d = ops.bn_state_from_partials(parts, blk.depth_norm, B * Fo * To) if blk.depth_norm.training else \
                 ops.bn_frozen_state(blk.depth_norm)
             x2 = ops.dyrelu_ca_fwd2(z_d, st_d[0], st_d[1], coef, g_cf, g_ct)
@@ -601,7 +627,7 @@ class DyBlockMain(torch.autograd.Function):
             _lib.call("eat_dyrelu_ca_fwd", z_d.data_ptr(), st_d[0].data_ptr(), st_d[1].data_ptr(), coef.data_ptr(),
                       g_cf.data_ptr(), g_ct.data_ptr(), x2.data_ptr(), B, cexp, Fo, To, _s())
             sv.update(y_e=y_e if has_e else None)
-        z_p, st_p = _dyn_pw(x2, w_p.view(K, cout, cexp), att_p, False, stats_bn=blk.proj_norm)
+        z_p, st_p = (_dyn_pw_b16 if b16 else _dyn_pw)(x2, w_p.view(K, cout, cexp), att_p, False, stats_bn=blk.proj_norm)
         out = ops.bn_act_fwd(z_p, st_p[0], st_p[1], NONE, res=x if blk.use_res_connect else None)
         sv.update(x=x, taps=taps, z_d=z_d, st_d=st_d, x2=x2, z_p=z_p, st_p=st_p, att=att, coef=coef, g_cf=g_cf, g_ct=g_ct,
                   w_e=w_e, w_d=w_d, w_p=w_p)
@@ -630,7 +656,8 @@ class DyBlockMain(torch.autograd.Function):
             # project: BN backward, data gradient, per-sample weight gradients
             dz_p, dgp, dbp = ops.bn_act_bwd(dout, sv["z_p"], *sv["st_p"], NONE)
             bank_p = w_p.view(K, cout, cexp)
-            dx2 = _dyn_pw(dz_p, bank_p, att_p, True)
+            dyn_pw = _dyn_pw_b16 if sv["b16"] else _dyn_pw
+            dx2 = dyn_pw(dz_p, bank_p, att_p, True)
             # the attention gradients of the block's dynamic convs accumulate into ONE zeroed (n_att, B, K) tensor (was: three
             # tensors + torch.stack)
             datt = ops.zero_arena.zeros(tuple(att.shape), torch.float32, att.device)
@@ -672,7 +699,7 @@ class DyBlockMain(torch.autograd.Function):
             dbank_d, _ = _bank_grad(G, att_d, w_d.view(K, cexp * k * k), datt[-2])
             if has_e:
                 bank_e = w_e.view(K, cexp, cin)
-                dx = _dyn_pw(dz_e, bank_e, att_e, True, res=res)
+                dx = dyn_pw(dz_e, bank_e, att_e, True, res=res)
                 dbank_e, _ = _dyn_pw_wgrad(dz_e, x, bank_e, att_e, datt[0])
                 dwe = dbank_e.view_as(w_e)
             else:
@@ -690,6 +717,9 @@ def _block_train_fused(blk, x):
     k, stride, cexp = cnf.kernel, cnf.stride, cnf.expanded_channels
     Fo, To = ops.conv_out(Fq, k, stride), ops.conv_out(T, k, stride)
     fused = _FUSED_DW and To <= 512 and ops.dw_bwd_merged_ok((B, cexp, Fo, To), (B, cexp, Fq, T), k, stride)
+    if fused and _STORE16 and blk.depth_norm.training and ops.dyn_b16_block_ok(B, x.shape[1], cexp, cnf.out_channels, Fq, T, k, stride) \
+            and (blk.has_expand or (T > 128 and k == 3 and stride == 1)):
+        fused = 2                  # bf16 storage of this block's wide tensors (DyBlockMain); other blocks keep fp32 storage
     # (x needs a gradient: then the context path's backward always runs after the main path's and collects its dx)
     hand_over = {} if (fused and x.requires_grad) else None
     if hand_over is not None:
@@ -738,9 +768,21 @@ def forward_train(model, x, return_fmaps=False):
                                "gradient was handed to its context path, whose backward never ran (torch.autograd.grad over "
                                "a subset of the graph?).  The fused DyMN blocks need the whole backward; EAT_DYMN_FUSED_DW=0 "
                                "selects the per-layer Functions, which have no such restriction.")
+    global _STORE16
+    prec = getattr(model, "train_precision", "fp32")
+    st = getattr(model, "act_storage", "fp32")
+    if st not in ("fp32", "bf16"):
+        raise _lib.EatHipError(f"act_storage must be 'fp32' or 'bf16' (got {st!r})")
+    if st == "bf16" and prec != "bf16":
+        raise _lib.EatHipError("act_storage='bf16' needs train_precision='bf16' (plain bf16 GEMM operands): the split-operand "
+                               "modes keep fp32-class products, which a bf16-stored operand cannot feed")
     ops.zero_arena.begin("dymn_step")          # one zero-filled arena per step (forward + the backward autograd runs later)
-    with ops.precision(getattr(model, "train_precision", "fp32")), ops.bn_counters:
-        out = _forward_train(model, x, return_fmaps)
+    _STORE16 = st == "bf16"
+    try:
+        with ops.precision(prec), ops.bn_counters:
+            out = _forward_train(model, x, return_fmaps)
+    finally:
+        _STORE16 = False
     if out[0].requires_grad:
         # the arena closes when THIS backward pass is over, whichever node runs last (a frozen stem never runs its backward;
         # ADVICE r5): the first gradient to arrive queues an engine callback, which fires after the last node of the pass

@@ -1080,15 +1080,22 @@ def _zero_bias(n, device):
 
 
 # ---- round 4: fused training passes of the dynamic block (csrc/dymn.hip, csrc/dw_plane.hip)
-def dw_conv_dyn_stats(x, w_bc, k, stride, tf=None):
-    """`dw_conv_stats` with per-(b,c) taps w_bc (B, C*k*k): -> (y, (part, outer, inner))."""
+def dw_conv_dyn_stats(x, w_bc, k, stride, tf=None, out_b16=False):
+    """`dw_conv_stats` with per-(b,c) taps w_bc (B, C*k*k): -> (y, (part, outer, inner)).  A bf16 x - or out_b16 with an fp32 x
+    (the block without expand conv) - selects the bf16-storage kernels: y bf16, statistics of the stored values."""
     B, C, F, T = x.shape
     Fo, To = conv_out(F, k, stride), conv_out(T, k, stride)
     cap = dw_partials_inner(F, T, Fo, To, k, stride, False)
-    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.float32)
+    x16 = _is16(x)
+    y = torch.empty((B, C, Fo, To), device=x.device, dtype=torch.bfloat16 if (x16 or out_b16) else torch.float32)
     part = torch.empty((B * 2 * C * cap,), device=x.device, dtype=torch.float32)
     inner = _ct.c_int(0)
     a, b, act = tf if tf is not None else (None, None, 0)
+    if x16 or out_b16:
+        _lib.call("eat_dw_conv_dyn_fwd_stats_b16", _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(a, "in_a"),
+                  _opt(b, "in_b"), act, _dev(w_bc, "w_bc"), y.data_ptr(), part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T,
+                  Fo, To, k, stride, _stream())
+        return y, (part, B, inner.value)
     _lib.call("eat_dw_conv_dyn_fwd_stats", _dev(x, "x"), _opt(a, "in_a"), _opt(b, "in_b"), act, _dev(w_bc, "w_bc"),
               y.data_ptr(), part.data_ptr(), cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
     return y, (part, B, inner.value)
@@ -1131,8 +1138,10 @@ def dyrelu_ca_fwd2(z, a, b, coef, gate_f, gate_t):
     """gate_f (C, B, Fo) / gate_t (C, B, To): channel-major pre-sigmoid gates (any shape with that memory layout)."""
     B, C, Fo, To = z.shape
     out = torch.empty_like(z)
-    _lib.call("eat_dyrelu_ca_fwd2", _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"), _dev(gate_f, "gate_f"),
-              _dev(gate_t, "gate_t"), out.data_ptr(), B, C, Fo, To, _stream())
+    z16 = _is16(z)                                  # bf16 storage: z and out (rounded on store) are bf16
+    _lib.call("eat_dyrelu_ca_fwd2_b16" if z16 else "eat_dyrelu_ca_fwd2", _dev16(z, "z") if z16 else _dev(z, "z"), _opt(a, "a"),
+              _opt(b, "b"), _dev(coef, "coef"), _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), out.data_ptr(), B, C, Fo, To,
+              _stream())
     return out
 
 
@@ -1144,7 +1153,11 @@ def dyrelu_ca_bwd2(dout, z, a, b, coef, gate_f, gate_t, want_bn=True):
     dcoef = buf[:B * C * 4].view(B, C, 4)
     bnpart = buf[B * C * 4:].view(B, C, 2) if want_bn else None
     dgf, dgt = torch.empty_like(gate_f), torch.empty_like(gate_t)
-    _lib.call("eat_dyrelu_ca_bwd2", _dev(dout, "dout"), _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"),
+    z16 = _is16(z)                                  # bf16 storage: dout, z and dv are bf16 (bnpart: sums of dv as stored)
+    if z16 != _is16(dout):
+        raise _lib.EatHipError("dyrelu_ca_bwd2: dout and z share one storage type")
+    _lib.call("eat_dyrelu_ca_bwd2_b16" if z16 else "eat_dyrelu_ca_bwd2", _dev16(dout, "dout") if z16 else _dev(dout, "dout"),
+              _dev16(z, "z") if z16 else _dev(z, "z"), _opt(a, "a"), _opt(b, "b"), _dev(coef, "coef"),
               _dev(gate_f, "gate_f"), _dev(gate_t, "gate_t"), dv.data_ptr(), dcoef.data_ptr(), dgf.data_ptr(), dgt.data_ptr(),
               None if bnpart is None else bnpart.data_ptr(), B, C, Fo, To, _stream())
     return dv, dcoef, dgf, dgt, bnpart
@@ -1165,11 +1178,19 @@ def dw_conv_dyn_bwd_bn_g(dy, z, st, bn_act, sums, w_bc, x, in_a, in_b, in_act, k
     B, C, F, T = x.shape
     Fo, To = z.shape[2], z.shape[3]
     cap = int(_lib.lib().eat_dw_bwd_partials_inner(F, T, Fo, To, k, stride))
-    g = torch.empty((B, C, F, T), device=z.device, dtype=torch.float32)
+    g = torch.empty((B, C, F, T), device=z.device, dtype=x.dtype)
     parts = torch.empty((2, B * C * cap), device=z.device, dtype=torch.float32) if want_sums else None
     dw = zero_arena.zeros((B, C * k * k), torch.float32, z.device)
     inner = _ct.c_int(0)
     frozen = 1 if getattr(st[2], "_eat_frozen", False) else 0
+    if _is16(z):                                    # bf16 storage: dy, z bf16; x and g bf16, or fp32 (block without expand conv)
+        x16 = _is16(x)
+        _lib.call("eat_dw_conv_dyn_bwd_bn_g_b16", _dev16(dy, "dy"), _dev16(z, "z"), st[0].data_ptr(), st[1].data_ptr(),
+                  st[2].data_ptr(), st[3].data_ptr(), sums.data_ptr(), bn_act, frozen, _dev16(x, "x") if x16 else _dev(x, "x"),
+                  1 if x16 else 0, in_a.data_ptr(), in_b.data_ptr(), in_act, _dev(w_bc, "w_bc"), _opt(res, "res"), g.data_ptr(),
+                  dw.data_ptr(), None if parts is None else parts[0].data_ptr(), None if parts is None else parts[1].data_ptr(),
+                  cap, _ct.addressof(inner), B, C, F, T, Fo, To, k, stride, _stream())
+        return g, dw, ((parts[0], parts[1], inner.value) if want_sums else None)
     _lib.call("eat_dw_conv_dyn_bwd_bn_g", _dev(dy, "dy"), _dev(z, "z"), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
               st[3].data_ptr(), sums.data_ptr(), bn_act, frozen, _dev(x, "x"), in_a.data_ptr(), in_b.data_ptr(), in_act,
               _dev(w_bc, "w_bc"), _opt(res, "res"), g.data_ptr(), dw.data_ptr(),
@@ -1185,6 +1206,10 @@ def bn_bwd_apply(g, z, a, b, mean, invstd, sums, inplace=True):
     S = z.numel() // (B * C)
     dz = g if inplace else torch.empty_like(g)
     asums = torch.zeros_like(sums) if getattr(mean, "_eat_frozen", False) else sums
+    if _is16(g):                                    # bf16 storage: g_e, z_e and dz_e are all wide tensors
+        _lib.call("eat_bn_bwd_apply_b16", _dev16(g, "g"), _dev16(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                  invstd.data_ptr(), asums.data_ptr(), dz.data_ptr(), B, C, S, ACT_NONE, _stream())
+        return dz
     _lib.call("eat_bn_act_bwd_apply", _dev(g, "g"), _dev(z, "z"), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
               invstd.data_ptr(), None, None, asums.data_ptr(), dz.data_ptr(), B, C, S, ACT_NONE, _stream())
     return dz
@@ -1341,6 +1366,54 @@ def pw_conv_wgrad_b16(dz, x, x_scale=None, tf=None, out=None):
               _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, _opt(a, "tf_a"), _opt(b, "tf_b"), tact,
               _opt(x_scale, "x_scale"), dW.data_ptr(), ws.data_ptr(), n, B, Co, Ci, S, _stream())
     return dW
+
+
+# ---- bf16 activation storage of the DyMN blocks (dymn_train.py; include/eat_hip.h "bf16 activation storage for the DyMN blocks")
+def dyn_b16_block_ok(B, cin, cexp, cout, F, T, k, stride):
+    """True where the bf16-storage kernels cover a fully dynamic DY_Block: depthwise geometry (`b16_block_ok`), 16-byte row
+    pieces and whole 4-channel groups for the per-sample 1x1 kernels."""
+    return b16_block_ok(B, cexp, F, T, k, stride) and cin % 4 == 0 and cout % 4 == 0 and cexp % 8 == 0
+
+
+def dyn_pw_pack_b16(bank, att, Co, Ci, trans=False):
+    """Aggregated per-sample weights sum_k att[b,k] bank[k] as PLAIN bf16 MFMA fragments (`eat_dyn_pw_pack_b16`) ->
+    (B, KK*MT*512) bfloat16.  trans: `bank` (K, Ci*Co) holds the transposed matrices (the data-gradient pack)."""
+    K, B = bank.shape[0], att.shape[0]
+    n = ((Ci + 31) // 32) * ((Co + 15) // 16) * 512
+    wp = torch.empty((B, n), device=bank.device, dtype=torch.bfloat16)
+    _lib.call("eat_dyn_pw_pack_b16", _dev(bank, "bank"), _dev(att, "att"), wp.data_ptr(), B, K, Co, Ci, 1 if trans else 0,
+              _stream())
+    return wp
+
+
+def pw_conv_dyn_b16(x, wp_b, Co, act, res=None, stats=False):
+    """Per-sample-weight 1x1 conv of the bf16-storage plan (`eat_pw_conv_dyn_b16_fwd`): x fp32 -> y bf16, or x bf16 -> y fp32
+    (+ res).  stats: -> (y, (part, tiles, 1)) with the batch statistics of y as stored."""
+    B, Ci, F, T = x.shape
+    S = F * T
+    x16 = _is16(x)
+    y = torch.empty((B, Co, F, T), device=x.device, dtype=torch.float32 if x16 else torch.bfloat16)
+    part = None
+    if stats:
+        tiles = int(_lib.lib().eat_pw_conv_stat_tiles(B, S, 1))
+        part = torch.empty((tiles * 2 * Co,), device=x.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_dyn_b16_fwd", _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, wp_b.data_ptr(),
+              _zero_bias(Co, x.device).data_ptr(), _opt(res, "res"), y.data_ptr(), 0 if x16 else 1,
+              None if part is None else part.data_ptr(), B, Ci, Co, S, act, _stream())
+    return (y, (part, tiles, 1)) if stats else y
+
+
+def pw_conv_dyn_wgrad_b16(dz, x):
+    """Per-sample weight gradients G (B, Co*Ci) = dz[b] x[b]^T with exactly one bf16 (wide) operand (`eat_pw_conv_dyn_wgrad_b16`);
+    every element is stored."""
+    B, Co = dz.shape[0], dz.shape[1]
+    Ci = x.shape[1]
+    S = dz.numel() // (B * Co)
+    d16, x16 = _is16(dz), _is16(x)
+    G = torch.empty((B, Co * Ci), device=dz.device, dtype=torch.float32)
+    _lib.call("eat_pw_conv_dyn_wgrad_b16", _dev16(dz, "dz") if d16 else _dev(dz, "dz"), 1 if d16 else 0,
+              _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, G.data_ptr(), B, Co, Ci, S, _stream())
+    return G
 
 
 # ------------------------------------------------------------------ precision switch (training plans)

@@ -781,6 +781,64 @@ int eat_pw_conv_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, 
                           int tf_act, const float* x_scale, float* dW, float* ws, int n_slots, int B, int Co, int Ci, int S,
                           eat_stream_t stream);
 
+/* ---- bf16 activation storage for the DyMN blocks (BASELINE configs[3] on the SURVEY 8(d) byte contract, which is quoted for
+ * bf16 activations; the reference's 16-bit surface is the same Lightning `precision=16`, ex_pl_audioset.py:287-293, over
+ * models/dymn/dy_block.py:390-409).  The wide tensors of a DY_Block - the dynamic expand conv's output z_e, the dynamic
+ * depthwise output z_d, the DyReLU-B * CoordAtt output, and the gradients arriving at them - are bf16 in HBM; block inputs /
+ * outputs, the context path, coefficients, gates, per-sample weights' gradients and every statistic stay fp32.  GEMM operands
+ * are plain bf16 with fp32 accumulation.  Each entry point is the bf16-storage twin of the fp32 one named in its comment. */
+
+/* Twin of eat_dyn_pw_pack_bf16 / _t (models/dymn/dy_block.py:111-119): the aggregated per-sample weights as PLAIN bf16
+ * fragments (eat_pw_prepack_bf16's layout with split = 0): ceil(Ci/32)*ceil(Co/16)*512 bf16 per sample.  trans != 0: `bank`
+ * holds the transposed matrices (K, Ci*Co) - the data-gradient pack; then Co % 4 == 0.  Ci % 4 == 0. */
+int eat_dyn_pw_pack_b16(const float* bank, const float* att, void* wp, int B, int K, int Co, int Ci, int trans,
+                        eat_stream_t stream);
+
+/* Twin of eat_pw_conv_dyn_bf16_fwd / eat_pw_conv_stats_fwd(per_sample = 1) (dy_block.py:120-127 for kernel_size 1, forward and
+ * data gradient): exactly one of x / y is the wide bf16 tensor.
+ *   x_b16 = 0, y_b16 = 1: z_e = W_b x (dynamic expand conv) or dx2 = W_b^T dz_p (project data gradient); no residual;
+ *   x_b16 = 1, y_b16 = 0: z_p = W_b x2 (dynamic project conv) or dx = W_b^T dz_e + res (expand data gradient).
+ * stats_part != NULL: the batch statistics of y AS STORED in the epilogue ([tiles][2][Co], tiles =
+ * eat_pw_conv_stat_tiles(B, S, 1); finish with eat_bn_finalize_partials).  wp_b: eat_dyn_pw_pack_b16; bias (Co) - zeros for a
+ * conv without bias.  S % 8 == 0, Ci % 4 == 0. */
+int eat_pw_conv_dyn_b16_fwd(const void* x, int x_b16, const void* wp_b, const float* bias, const float* res, void* y,
+                            int y_b16, float* stats_part, int B, int Ci, int Co, int S, int act, eat_stream_t stream);
+
+/* Twin of eat_dw_conv_dyn_fwd_stats (dy_block.py:103-131 with groups = channels, under model.train()): y bf16; x bf16, or fp32
+ * with x_b16 = 0 (the block without expand conv; tile geometries, T > 128, only).  Planes hold an even number of elements;
+ * geometries: eat_dw_conv_b16_ok. */
+int eat_dw_conv_dyn_fwd_stats_b16(const void* x, int x_b16, const float* in_a, const float* in_b, int in_act, const float* w_bc,
+                                  void* y, float* part, int inner_cap, int* h_inner, int B, int C, int F, int T, int Fo, int To,
+                                  int k, int stride, eat_stream_t stream);
+
+/* Twins of eat_dyrelu_ca_fwd2 / _bwd2 (dy_block.py:172-188, 195-201; order :399-403): z, out, dout and dv are bf16; the outputs
+ * are rounded on store and bnpart holds the sums of dv as stored. */
+int eat_dyrelu_ca_fwd2_b16(const void* z, const float* a, const float* b, const float* coef, const float* gate_f,
+                           const float* gate_t, void* out, int B, int C, int Fo, int To, eat_stream_t stream);
+int eat_dyrelu_ca_bwd2_b16(const void* dout, const void* z, const float* a, const float* b, const float* coef,
+                           const float* gate_f, const float* gate_t, void* dv, float* dcoef, float* dgate_f, float* dgate_t,
+                           float* bnpart, int B, int C, int Fo, int To, eat_stream_t stream);
+
+/* Twin of eat_dw_conv_dyn_bwd_bn_g (backward of dy_block.py:320-348): dy and z are bf16; x and g are bf16 (x_b16 != 0), or
+ * both fp32 with the optional fp32 skip gradient res (x_b16 = 0: the block without expand conv, 3x3 / stride 1 on planes wider
+ * than 128 columns only). */
+int eat_dw_conv_dyn_bwd_bn_g_b16(const void* dy, const void* z, const float* bn_a, const float* bn_b, const float* bn_mean,
+                                 const float* bn_invstd, const double* sums, int bn_act, int frozen, const void* x, int x_b16,
+                                 const float* in_a, const float* in_b, int in_act, const float* w_bc, const float* res, void* g,
+                                 float* dw_bc, float* gpart, float* gzpart, int inner_cap, int* h_inner, int B, int C, int F,
+                                 int T, int Fo, int To, int k, int stride, eat_stream_t stream);
+
+/* Twin of eat_bn_act_bwd_apply for the expand BatchNorm of a DY_Block (backward of dy_block.py:313-318): dy (= g_e, which
+ * already carries the activation derivative: act = 0), z (= z_e) and dz (= dz_e; may alias dy) are all bf16. */
+int eat_bn_bwd_apply_b16(const void* dy, const void* z, const float* a, const float* b, const float* mean, const float* invstd,
+                         const double* sums, void* dz, int B, int C, int S, int act, eat_stream_t stream);
+
+/* Twin of eat_pw_conv_dyn_wgrad (autograd of the grouped F.conv2d of dy_block.py:120-127): per-sample weight gradients
+ * dW_b (B, Co, Ci) = dz[b] x[b]^T with exactly one bf16 operand; every element of dW_b is stored (no zero fill).
+ * S % 4 == 0, Ci % 4 == 0. */
+int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int B, int Co, int Ci, int S,
+                              eat_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

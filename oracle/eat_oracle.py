@@ -174,6 +174,7 @@ class emulate_bf16_pointwise:
     backward - the one arriving at the project conv's input and g = dL/d(BN output of the expand conv)."""
 
     def __init__(self, storage=False):
+        # storage: False, True (every block), or - DyMN - the collection of block indices that run on bf16 storage
         self.storage = storage
 
     def __enter__(self):
@@ -319,13 +320,41 @@ def context_dim(cexp, width_mult, ratio=4, lo=32, hi=128):
     return int(min(max(v, make_divisible(lo * width_mult, 8)), make_divisible(hi * width_mult, 8)))
 
 
-def _dyconv(sd, prefix, x, h_c, cin, cout, k, stride, groups, temperature, dilation=1):
+class _DynPwBf16(torch.autograd.Function):
+    """Per-sample 1x1 conv y_b = W_b x_b on bf16-rounded operands with fp32 accumulation: the arithmetic of the dynamic 1x1
+    convs under `train_precision="bf16"` with the bf16-storage plan (efficientat_amd/dymn_train.py `_dyn_pw_b16`): the
+    aggregated per-sample weights are rounded once (the plain bf16 pack), the data gradient rounds dz, the per-sample weight
+    gradient rounds dz and x - the `_PwBf16` rule for weights that differ per sample."""
+
+    @staticmethod
+    def forward(ctx, x, w):                       # x (B, Ci, F, T), w (B, Co, Ci)
+        ctx.save_for_backward(x, w)
+        return torch.einsum("boi,bihw->bohw", w.bfloat16().float(), x.bfloat16().float())
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        d16 = dz.bfloat16().float()
+        return (torch.einsum("boi,bohw->bihw", w.bfloat16().float(), d16),
+                torch.einsum("bohw,bihw->boi", d16, x.bfloat16().float()))
+
+
+def _st16(i):
+    """bf16-storage emulation of dynamic block i: ST_BF16 is True (every block) or the collection of the block indices that
+    run on bf16 storage (the HIP plan keeps fp32 storage for geometries its kernels do not cover)."""
+    return ST_BF16 is True or (ST_BF16 is not False and ST_BF16 is not None and i in ST_BF16)
+
+
+def _dyconv(sd, prefix, x, h_c, cin, cout, k, stride, groups, temperature, dilation=1, pw16=False):
     """DynamicConv (dy_block.py:103-131): per-sample kernel = softmax-weighted sum of K=4; `dilation` with padding
-    (k - 1) // 2 * dilation as DY_Block builds the depthwise DynamicConv of a dilated block (dy_block.py:322-348)."""
+    (k - 1) // 2 * dilation as DY_Block builds the depthwise DynamicConv of a dilated block (dy_block.py:322-348).
+    pw16 (emulation only): the 1x1 conv on bf16-rounded operands (`_DynPwBf16`)."""
     b = x.shape[0]
     a = F.softmax(F.linear(h_c, sd[prefix + ".residuals.0.weight"], sd[prefix + ".residuals.0.bias"])
                   / temperature, dim=-1)                                    # (B,K)
     bank = sd[prefix + ".weight"][0, 0]                                      # (K, N)
+    if pw16 and k == 1 and groups == 1:
+        return _DynPwBf16.apply(x, (a @ bank).reshape(b, cout, cin))
     w = (a @ bank).reshape(b * cout, cin // groups, k, k)
     y = F.conv2d(x.reshape(1, b * cin, *x.shape[2:]), w, None, stride, (k - 1) // 2 * dilation, dilation, groups * b)
     return y.reshape(b, cout, *y.shape[2:])
@@ -338,9 +367,21 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, n
     coordinate attention.  The context generator runs in every case (dy_block.py:394)."""
     inp = x
     B, C, Fq, T = x.shape
+    # bf16 emulation (tests only, `emulate_bf16_pointwise`): pw16 = the 1x1 convs of the block on bf16-rounded operands (the
+    # context generator's static convs as `_PwBf16`, the dynamic ones as `_DynPwBf16`); st16 = this block's wide tensors are
+    # STORED in bf16 (efficientat_amd/dymn_train.py DyBlockMain with fused == 2): forward z_e, z_d and the DyReLU * CoordAtt
+    # output, backward dz_e, g_e = dL/d(exp_norm output), dL/d(depth_norm output) and dL/d(project conv input)
+    pw16 = PW_BF16 and train and not (no_dyconv or no_dyrelu or no_ca)     # (ablated blocks run the per-layer fp32-storage plan)
+    try:
+        st16 = pw16 and _st16(int(prefix.rsplit(".", 1)[1]))
+    except ValueError:
+        st16 = False
+    pwc = (lambda t, w: _PwBf16.apply(t, w)) if (PW_BF16 and train) else (lambda t, w: F.conv2d(t, w))
+    rnd = (lambda t: _StoreBf16.apply(t)) if st16 else (lambda t: t)
+    grnd = (lambda t: _GradBf16.apply(t)) if st16 else (lambda t: t)
     # ContextGen (dy_block.py:235-254)
     cf, ct = x.mean(dim=3, keepdim=True), x.mean(dim=2, keepdim=True).permute(0, 1, 3, 2)
-    g = F.conv2d(torch.cat([cf, ct], dim=2), sd[prefix + ".context_gen.joint_conv.weight"])
+    g = pwc(torch.cat([cf, ct], dim=2), sd[prefix + ".context_gen.joint_conv.weight"])
     g = F.hardswish(_bn(sd, prefix + ".context_gen.joint_norm", g, train, stats))
     h_cf, h_ct = g[:, :, :Fq], g[:, :, Fq:].permute(0, 1, 3, 2)
     h_c = g.mean(dim=2).reshape(B, H)
@@ -351,21 +392,21 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, n
     if dw_stride > 1:
         h_cf = F.avg_pool2d(h_cf, (3, 1), (dw_stride, 1), (1, 0))
         h_ct = F.avg_pool2d(h_ct, (1, 3), (1, dw_stride), (0, 1))
-    g_cf = F.conv2d(h_cf, sd[prefix + ".context_gen.conv_f.weight"], sd[prefix + ".context_gen.conv_f.bias"])
-    g_ct = F.conv2d(h_ct, sd[prefix + ".context_gen.conv_t.weight"], sd[prefix + ".context_gen.conv_t.bias"])
+    g_cf = pwc(h_cf, sd[prefix + ".context_gen.conv_f.weight"]) + sd[prefix + ".context_gen.conv_f.bias"].view(1, -1, 1, 1)
+    g_ct = pwc(h_ct, sd[prefix + ".context_gen.conv_t.weight"]) + sd[prefix + ".context_gen.conv_t.bias"].view(1, -1, 1, 1)
 
     def conv(name, x, cin, cout, k, stride, groups, dilation=1):
         if no_dyconv:
             return F.conv2d(x, sd[f"{prefix}.{name}.module.weight"], None, stride, (k - 1) // 2 * dilation, dilation, groups)
-        return _dyconv(sd, f"{prefix}.{name}", x, h_c, cin, cout, k, stride, groups, temperature, dilation)
+        return _dyconv(sd, f"{prefix}.{name}", x, h_c, cin, cout, k, stride, groups, temperature, dilation, pw16=st16)
 
     # expand
     if c["cexp"] != c["cin"]:
-        x = conv("exp_conv", x, c["cin"], c["cexp"], 1, 1, 1)
-        x = _act(_bn(sd, prefix + ".exp_norm", x, train, stats), c["hs"])
+        x = grnd(rnd(conv("exp_conv", x, c["cin"], c["cexp"], 1, 1, 1)))
+        x = _act(grnd(_bn(sd, prefix + ".exp_norm", x, train, stats)), c["hs"])
     # depthwise + DyReLU-B (dy_block.py:172-188) + CoordAtt (195-201)
-    x = conv("depth_conv", x, c["cexp"], c["cexp"], c["k"], dw_stride, c["cexp"], dil)
-    x = _bn(sd, prefix + ".depth_norm", x, train, stats)
+    x = rnd(conv("depth_conv", x, c["cexp"], c["cexp"], c["k"], dw_stride, c["cexp"], dil))
+    x = grnd(_bn(sd, prefix + ".depth_norm", x, train, stats))
     if no_dyrelu:
         x = _act(x, c["hs"])
     else:
@@ -375,6 +416,7 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, n
         x = torch.maximum(x * co[..., 0] + co[..., 2], x * co[..., 1] + co[..., 3])
     if not no_ca:
         x = x * torch.sigmoid(g_cf) * torch.sigmoid(g_ct)
+    x = grnd(rnd(x))
     # project
     x = conv("proj_conv", x, c["cexp"], c["cout"], 1, 1, 1)
     x = _bn(sd, prefix + ".proj_norm", x, train, stats)

@@ -647,3 +647,75 @@ def test_baseline_width_models_match_reference_goldens(tag, golden_dir):
     for k in g.files:
         if k.startswith(f"{tag}/bn_after/"):
             assert _rel(msd[k[len(tag) + 10:]], torch.from_numpy(g[k])) < 1e-4, k
+
+
+# ------------------------------------------------------------------ configs[3] on bf16 activation storage
+def test_dymn20_train_step_bf16_storage_tracks_oracle(dymn20_case_t30):
+    """dymn20 under train_precision = 'bf16' + act_storage = 'bf16' (the byte contract SURVEY 8(d) quotes for configs[3]; the
+    reference's 16-bit surface is Lightning `precision=16`, ex_pl_audioset.py:287-293): bf16 GEMM operands and the wide tensors
+    of every dynamic block (z_e, z_d, the DyReLU * CoordAtt output, and the gradients arriving at them) stored in bf16, against
+      (a) the oracle's emulation of exactly those roundings (`O.emulate_bf16_pointwise(storage=...)` over `O.dymn_forward`):
+          loss / logits agree at the bf16-rounding-boundary level, gradients closer to the emulation than the emulation is to
+          the fp32 oracle;
+      (b) the fp32 oracle: not further away than the emulated oracle itself is (x1.25 + 1 %) - the criterion of
+          test_mn40_train_step_bf16_tracks_oracle.  Temperature 30 (the reference's starting temperature): at T = 1 the
+          kernel-attention softmax of this synthetic network turns bf16 noise into O(1) changes of the attention (see
+          _ATTENTION_HEAD above), which says nothing about the kernels."""
+    from efficientat_amd import ops
+    d = dymn20_case_t30
+    y = (torch.rand(4, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float()
+    keep = (torch.rand(4, 2560, generator=torch.Generator().manual_seed(6)) < 0.8).float()
+    # fp32 oracle
+    sdf = _grad_state(d["sd"])
+    logits_f, _ = d["fwd"](sdf, d["x"], train=True, stats={}, drop_mask=keep)
+    loss_f = F.binary_cross_entropy_with_logits(logits_f, y)
+    loss_f.backward()
+    # which blocks the plan stores in bf16 (the emulation follows the same list)
+    blocks, _ = O.block_table(2.0)
+    B, _, F0, T0 = d["x"].shape
+    f, t = (F0 - 1) // 2 + 1, (T0 - 1) // 2 + 1
+    st16 = []
+    for i, c in enumerate(blocks):
+        ok = ops.dyn_b16_block_ok(B, c["cin"], c["cexp"], c["cout"], f, t, c["k"], c["stride"]) and \
+            (c["cexp"] != c["cin"] or (t > 128 and c["k"] == 3 and c["stride"] == 1))
+        if ok:
+            st16.append(i)
+        f, t = ops.conv_out(f, c["k"], c["stride"]), ops.conv_out(t, c["k"], c["stride"])
+    assert len(st16) == 15, st16                     # the whole network runs on bf16 storage at the bench geometry
+    sde = _grad_state(d["sd"])
+    with O.emulate_bf16_pointwise(storage=set(st16)):
+        logits_e, _ = d["fwd"](sde, d["x"], train=True, stats={}, drop_mask=keep)
+        loss_e = F.binary_cross_entropy_with_logits(logits_e, y)
+        loss_e.backward()
+    logits_e, logits_f = logits_e.detach(), logits_f.detach()
+
+    model = _dymn20(d["sd"], d["temp"]).train()
+    model.train_precision = "bf16"
+    model.act_storage = "bf16"
+    model._drop_mask_override = keep
+    logits, _ = model(d["x"].to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, y.to(DEV))
+    loss.backward()
+    logits = logits.detach().cpu()
+    gmax = max(float(v.grad.norm()) for v in sdf.values() if getattr(v, "grad", None) is not None)
+    names = [n for n, p in model.named_parameters() if float(sdf[n].grad.norm()) >= 1e-4 * gmax]
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    gp = dict(model.named_parameters())
+    emu_vs_f = np.array([_rel(sde[n].grad, sdf[n].grad) for n in names])
+    hip_vs_e = np.array([_rel(gp[n].grad, sde[n].grad) for n in names])
+    hip_vs_f = np.array([_rel(gp[n].grad, sdf[n].grad) for n in names])
+    scale = float(logits_f.abs().max())
+    e_he, e_hf, e_ef = (float((logits - logits_e).abs().max()), float((logits - logits_f).abs().max()),
+                        float((logits_e - logits_f).abs().max()))
+    print(f"dymn20 bf16 storage: loss hip {loss.item():.6f} / emulated {float(loss_e):.6f} / fp32 {float(loss_f):.6f}; logits max abs "
+          f"hip-emu {e_he:.2e}, hip-fp32 {e_hf:.2e}, emu-fp32 {e_ef:.2e} on |logit| <= {scale:.1f}; gradient rel-L2 medians: hip-emu "
+          f"{np.median(hip_vs_e):.3f}, hip-fp32 {np.median(hip_vs_f):.3f}, emu-fp32 {np.median(emu_vs_f):.3f}")
+    # (a) the same arithmetic
+    assert abs(loss.item() - float(loss_e)) < 2e-3 * abs(float(loss_e)), (loss.item(), float(loss_e))
+    assert e_he < 2e-2 * scale, (e_he, scale)
+    assert float(np.median(hip_vs_e)) < float(np.median(emu_vs_f)), (float(np.median(hip_vs_e)), float(np.median(emu_vs_f)))
+    # (b) bf16 noise against the fp32 oracle: not larger than the emulated oracle's own
+    assert abs(loss.item() - float(loss_f)) < 2e-2 * abs(float(loss_f))
+    assert float(np.median(hip_vs_f)) < 1.25 * float(np.median(emu_vs_f)) + 1e-2
+    assert e_hf < 1.5 * e_ef + 1e-2 * scale, (e_hf, e_ef)
