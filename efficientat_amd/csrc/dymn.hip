@@ -124,65 +124,92 @@ __global__ __launch_bounds__(256) void dyn_pw_pack_kernel(const float* __restric
 // Block = (16-row m-tile, sample); 16 x 256 aggregated weights through LDS as above, then every lane writes its 8
 // consecutive k of one (kk, h) fragment as ONE 16-byte store (a wave = one 1 KiB fragment).
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+// Round 6: a block packs SB consecutive SAMPLES of its m-tile.  With K == KT (= 4, every DynamicConv of the reference) the K bank
+// tiles of a 256-column piece are loaded ONCE into registers and mixed with each sample's attention in turn - before, every
+// (m-tile, sample) block re-read the K x 16 x 256 floats through L2 (8 x the bytes it wrote: 1.0 - 1.8 TB/s of packed output).
+// KT == 0: any K, the bank values are fetched per sample as before.
+template <int KT>
 __global__ __launch_bounds__(256) void dyn_pw_pack_bf16_kernel(const float* __restrict__ bank, const float* __restrict__ att,
                                                                __bf16* __restrict__ wp, int K, int Co, int Ci, int MT, int KK,
-                                                               int trans, int np2) {
+                                                               int trans, int np2, int B, int SB) {
   // np2 = 2: hi / lo fragments (bf16x3); np2 = 1: the hi part only (plain bf16 operands, the bf16-storage plan)
   __shared__ float s_w[16 * (kPackCols + 1)];
-  const int mt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int mt = blockIdx.x, tid = threadIdx.x;
+  const int b0 = blockIdx.y * SB;
+  const int nb = (B - b0) < SB ? (B - b0) : SB;
   const int m0 = mt * 16;
   const int rows = (Co - m0) < 16 ? (Co - m0) : 16;
-  const float* a = att + (size_t)b * K;
   const size_t N = (size_t)Co * Ci;
-  __bf16* out = wp + (size_t)b * KK * MT * 512 * np2;
   const int lane = tid & 63, wv = tid >> 6;
   const int m = lane & 15, kq = lane >> 4;
-  for (int c0 = 0; c0 < Ci; c0 += kPackCols) {
+  constexpr int KR = KT > 0 ? KT : 1;
+  {
+    const int c0 = blockIdx.z * kPackCols;                             // the block's 256-column piece
     const int cols = (Ci - c0) < kPackCols ? (Ci - c0) : kPackCols;     // multiple of 4
-    if (trans) {
-      for (int e = tid; e < 4 * kPackCols; e += 256) {
+    // the thread's 4 float4 positions of the piece: offset into a bank (or -1: outside the matrix -> zeros) and LDS slot
+    long long noff[4];
+    int slot[4];
+    float4 wreg[4][KR];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 256 * it;
+      if (trans) {                                                     // 4 * kPackCols = 1024 (col, 4-row group) positions
         const int col = e >> 2, q = e & 3;
+        noff[it] = (4 * q < rows && col < cols) ? (long long)((size_t)(c0 + col) * Co + m0 + 4 * q) : -1;
+        slot[it] = (4 * q) * (kPackCols + 1) + col;
+      } else {                                                         // 16 * (kPackCols / 4) = 1024 (row, 4-col group) positions
+        const int r = e / (kPackCols >> 2), q = e - r * (kPackCols >> 2);
+        noff[it] = (r < rows && 4 * q < cols) ? (long long)((size_t)(m0 + r) * Ci + c0 + 4 * q) : -1;
+        slot[it] = r * (kPackCols + 1) + 4 * q;
+      }
+      if constexpr (KT > 0) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          wreg[it][k] = noff[it] >= 0 ? *reinterpret_cast<const float4*>(bank + (size_t)k * N + noff[it]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    for (int sb = 0; sb < nb; ++sb) {
+      const float* a = att + (size_t)(b0 + sb) * K;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (4 * q < rows && col < cols) {
-          const size_t n = (size_t)(c0 + col) * Co + m0 + 4 * q;
+        if constexpr (KT > 0) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            const float ak = a[k];
+            const float4 w4 = wreg[it][k];
+            v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
+          }
+        } else if (noff[it] >= 0) {
           for (int k = 0; k < K; ++k) {
-            const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + n);
+            const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + noff[it]);
             const float ak = a[k];
             v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
           }
         }
-        s_w[(4 * q + 0) * (kPackCols + 1) + col] = v.x; s_w[(4 * q + 1) * (kPackCols + 1) + col] = v.y;
-        s_w[(4 * q + 2) * (kPackCols + 1) + col] = v.z; s_w[(4 * q + 3) * (kPackCols + 1) + col] = v.w;
-      }
-    } else
-    for (int e = tid; e < 16 * (kPackCols >> 2); e += 256) {
-      const int r = e / (kPackCols >> 2), q = e - r * (kPackCols >> 2);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows && 4 * q < cols) {
-        const size_t n = (size_t)(m0 + r) * Ci + c0 + 4 * q;
-        for (int k = 0; k < K; ++k) {
-          const float4 w4 = *reinterpret_cast<const float4*>(bank + (size_t)k * N + n);
-          const float ak = a[k];
-          v.x = fmaf(ak, w4.x, v.x); v.y = fmaf(ak, w4.y, v.y); v.z = fmaf(ak, w4.z, v.z); v.w = fmaf(ak, w4.w, v.w);
+        float* d = s_w + slot[it];
+        if (trans) {                                                   // the float4 runs down 4 ROWS of one column
+          d[0] = v.x; d[kPackCols + 1] = v.y; d[2 * (kPackCols + 1)] = v.z; d[3 * (kPackCols + 1)] = v.w;
+        } else {                                                       // ... along 4 columns of one row (zeros beyond Ci / Co)
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
       }
-      float* d = s_w + r * (kPackCols + 1) + 4 * q;               // columns beyond Ci / rows beyond Co: zeros
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-    const int nkk = (cols + 31) >> 5;
-    for (int j = wv; j < nkk * np2; j += 4) {                      // (32-column chunk, hi / lo) fragments of this piece
-      const int kl = np2 == 2 ? j >> 1 : j, h = np2 == 2 ? j & 1 : 0;
-      bf16x8_t o;
+      __syncthreads();
+      __bf16* out = wp + (size_t)(b0 + sb) * KK * MT * 512 * np2;
+      const int nkk = (cols + 31) >> 5;
+      for (int j = wv; j < nkk * np2; j += 4) {                      // (32-column chunk, hi / lo) fragments of this piece
+        const int kl = np2 == 2 ? j >> 1 : j, h = np2 == 2 ? j & 1 : 0;
+        bf16x8_t o;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = s_w[m * (kPackCols + 1) + kl * 32 + 8 * kq + i];
-        const __bf16 hi = (__bf16)v;
-        o[i] = h ? (__bf16)(v - (float)hi) : hi;
+        for (int i = 0; i < 8; ++i) {
+          const float v = s_w[m * (kPackCols + 1) + kl * 32 + 8 * kq + i];
+          const __bf16 hi = (__bf16)v;
+          o[i] = h ? (__bf16)(v - (float)hi) : hi;
+        }
+        *reinterpret_cast<bf16x8_t*>(out + (((size_t)((c0 >> 5) + kl) * MT + mt) * np2 + h) * 512 + lane * 8) = o;
       }
-      *reinterpret_cast<bf16x8_t*>(out + (((size_t)((c0 >> 5) + kl) * MT + mt) * np2 + h) * 512 + lane * 8) = o;
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -472,14 +499,40 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-// LPP lanes per plane (64 / LPP planes of consecutive channels per wave), NC columns per lane (To <= LPP * NC)
+// LPP lanes per plane (64 / LPP planes of consecutive channels per wave), NC column slots per lane; a slot is CW columns wide:
+// one for fp32 storage, TWO ADJACENT columns for bf16 storage (one 4-byte access per slot: 2-byte accesses ran the bf16 kernels
+// at the instruction count of the fp32 ones, i.e. at half their bandwidth).  To <= LPP * NC * CW.
+// A bf16 row of odd width starts on a 2-byte boundary on every other row: the slot access is ONE dword at a 2-byte aligned
+// address (gfx9 global memory handles it); the last slot of an odd-width row owns one column only - its load is moved back by
+// one element and takes the high half (so that it never reaches past the tensor), its store is a 2-byte store.
+template <typename ST> struct DyIo;
+template <> struct DyIo<float> {
+  static constexpr int CW = 1;
+  static __device__ __forceinline__ void ld(const float* p, bool, float (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void st(float* p, bool, bool ok0, const float (&v)[1]) { if (ok0) *p = v[0]; }
+};
+template <> struct DyIo<eat::bf16_t> {
+  static constexpr int CW = 2;
+  // p: address of the slot's first column; part: the second column does not exist
+  static __device__ __forceinline__ void ld(const eat::bf16_t* p, bool part, float (&v)[2]) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(part ? p - 1 : p);
+    v[0] = part ? eat::bf_hi(w) : eat::bf_lo(w);
+    v[1] = part ? 0.0f : eat::bf_hi(w);
+  }
+  static __device__ __forceinline__ void st(eat::bf16_t* p, bool part, bool ok0, const float (&v)[2]) {
+    if (!ok0) return;
+    if (part) *p = (eat::bf16_t)v[0];
+    else *reinterpret_cast<unsigned*>(p) = eat::pack_bf2(v[0], v[1]);
+  }
+};
+
 // ST: storage type of the feature maps z / out (act_io.h; bf16 in the bf16-storage plan - the output is rounded on store)
 template <int LPP, int NC, typename ST = float>
 __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const ST* __restrict__ z, const float* __restrict__ a,
                                                              const float* __restrict__ b, const float* __restrict__ coef,
                                                              const float* __restrict__ gf, const float* __restrict__ gt,
                                                              ST* __restrict__ out, int n_planes, int C, int Fo, int To) {
-  constexpr int NPW = 64 / LPP;
+  constexpr int NPW = 64 / LPP, CW = DyIo<ST>::CW;
   const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   int plane = wave * NPW + lane / LPP;
@@ -494,35 +547,40 @@ __global__ __launch_bounds__(256) void dyrelu_ca_fwd2_kernel(const ST* __restric
   const float* gtp = gt + grow * To;
   const ST* zp = z + (size_t)plane * Fo * To;
   ST* op = out + (size_t)plane * Fo * To;
-  float at[NC];
-  bool ok[NC];
+  float at[NC][CW];
+  bool ok[NC], part[NC];
+  int tc[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    const int t = l + LPP * j;
+    const int t = CW * (l + LPP * j);
     ok[j] = mine && t < To;
-    at[j] = sigm(gtp[t < To ? t : 0]);
+    part[j] = CW == 2 && t + 1 >= To;
+    tc[j] = t < To ? t : 0;
+#pragma unroll
+    for (int q = 0; q < CW; ++q) at[j][q] = sigm(gtp[t + q < To ? t + q : 0]);
   }
-  constexpr int RU = NC >= 4 ? 2 : 4;                              // rows in flight
+  constexpr int RU = NC * CW >= 4 ? 2 : 4;                         // rows in flight
   for (int f0 = 0; f0 < Fo; f0 += RU) {
-    float v[RU][NC], af[RU];
+    float v[RU][NC][CW], af[RU];
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       const int f = f0 + r < Fo ? f0 + r : Fo - 1;
       af[r] = sigm(gfp[f]);
 #pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        const int t = l + LPP * j;
-        v[r][j] = eat::Io<ST>::load1(zp + (size_t)f * To + (t < To ? t : 0));
-      }
+      for (int j = 0; j < NC; ++j) DyIo<ST>::ld(zp + (size_t)f * To + tc[j], part[j] && CW * (l + LPP * j) < To, v[r][j]);
     }
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       if (f0 + r >= Fo) break;                                      // wave-uniform
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
-        const float u = fmaf(av, v[r][j], bv);
-        const float o = fmaxf(fmaf(cf.x, u, cf.z), fmaf(cf.y, u, cf.w)) * (af[r] * at[j]);
-        if (ok[j]) eat::Io<ST>::store1(op + (size_t)(f0 + r) * To + l + LPP * j, o);
+        float o[CW];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const float u = fmaf(av, v[r][j][q], bv);
+          o[q] = fmaxf(fmaf(cf.x, u, cf.z), fmaf(cf.y, u, cf.w)) * (af[r] * at[j][q]);
+        }
+        DyIo<ST>::st(op + (size_t)(f0 + r) * To + tc[j], part[j], ok[j], o);
       }
     }
   }
@@ -537,7 +595,7 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const ST* __restric
                                                              float* __restrict__ dcoef, float* __restrict__ dgf,
                                                              float* __restrict__ dgt, float* __restrict__ bnpart,
                                                              int n_planes, int C, int Fo, int To) {
-  constexpr int NPW = 64 / LPP;
+  constexpr int NPW = 64 / LPP, CW = DyIo<ST>::CW;
   const int lane = threadIdx.x & 63, l = lane & (LPP - 1);
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   int plane = wave * NPW + lane / LPP;
@@ -553,29 +611,35 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const ST* __restric
   float* dgfp = dgf + grow * Fo;
   float* dgtp = dgt + grow * To;
   const size_t base = (size_t)plane * Fo * To;
-  float at[NC], cs[NC];
-  bool ok[NC];
+  float at[NC][CW], cs[NC][CW];
+  bool ok[NC][CW], part[NC];
+  int tc[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    const int t = l + LPP * j;
-    ok[j] = t < To;
-    at[j] = sigm(gtp[t < To ? t : 0]);
-    cs[j] = 0.0f;
+    const int t = CW * (l + LPP * j);
+    part[j] = CW == 2 && t + 1 >= To;
+    tc[j] = t < To ? t : 0;
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+      ok[j][q] = t + q < To;
+      at[j][q] = sigm(gtp[t + q < To ? t + q : 0]);
+      cs[j][q] = 0.0f;
+    }
   }
   float da1 = 0.f, da2 = 0.f, db1 = 0.f, db2 = 0.f, s1 = 0.f, s2 = 0.f;
-  constexpr int RU = NC >= 4 ? 2 : 4;
+  constexpr int RU = NC * CW >= 4 ? 2 : 4;
   for (int f0 = 0; f0 < Fo; f0 += RU) {
-    float zv[RU][NC], dd[RU][NC], af[RU];
+    float zv[RU][NC][CW], dd[RU][NC][CW], af[RU];
 #pragma unroll
     for (int r = 0; r < RU; ++r) {
       const int f = f0 + r < Fo ? f0 + r : Fo - 1;
       af[r] = sigm(gfp[f]);
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
-        const int t = l + LPP * j;
-        const size_t e = base + (size_t)f * To + (t < To ? t : 0);
-        zv[r][j] = eat::Io<ST>::load1(z + e);
-        dd[r][j] = eat::Io<ST>::load1(dout + e);
+        const size_t e = base + (size_t)f * To + tc[j];
+        const bool pt = part[j] && ok[j][0];
+        DyIo<ST>::ld(z + e, pt, zv[r][j]);
+        DyIo<ST>::ld(dout + e, pt, dd[r][j]);
       }
     }
 #pragma unroll
@@ -584,23 +648,27 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const ST* __restric
       float rs = 0.0f;
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
-        const float zr = zv[r][j];
-        const float u = fmaf(av, zr, bv);
-        const float l1 = fmaf(cf.x, u, cf.z), l2 = fmaf(cf.y, u, cf.w);
-        const bool sel = l1 >= l2;
-        const float m = sel ? l1 : l2;
-        const float d = ok[j] ? dd[r][j] : 0.0f;
-        const float dm = d * (af[r] * at[j]);
-        const float g = eat::Io<ST>::rnd(dm * (sel ? cf.x : cf.y));
-        if (ok[j] && mine) eat::Io<ST>::store1(dv + base + (size_t)(f0 + r) * To + l + LPP * j, g);
-        const float dmv = dm * u;
-        da1 += sel ? dmv : 0.0f; db1 += sel ? dm : 0.0f;
-        da2 += sel ? 0.0f : dmv; db2 += sel ? 0.0f : dm;
-        s1 += g;
-        s2 = fmaf(g, zr, s2);
-        const float dmm = d * m;
-        rs = fmaf(dmm, at[j], rs);
-        cs[j] = fmaf(dmm, af[r], cs[j]);
+        float g[CW];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const float zr = zv[r][j][q];
+          const float u = fmaf(av, zr, bv);
+          const float l1 = fmaf(cf.x, u, cf.z), l2 = fmaf(cf.y, u, cf.w);
+          const bool sel = l1 >= l2;
+          const float m = sel ? l1 : l2;
+          const float d = ok[j][q] ? dd[r][j][q] : 0.0f;
+          const float dm = d * (af[r] * at[j][q]);
+          g[q] = eat::Io<ST>::rnd(dm * (sel ? cf.x : cf.y));
+          const float dmv = dm * u;
+          da1 += sel ? dmv : 0.0f; db1 += sel ? dm : 0.0f;
+          da2 += sel ? 0.0f : dmv; db2 += sel ? 0.0f : dm;
+          s1 += g[q];
+          s2 = fmaf(g[q], zr, s2);
+          const float dmm = d * m;
+          rs = fmaf(dmm, at[j][q], rs);
+          cs[j][q] = fmaf(dmm, af[r], cs[j][q]);
+        }
+        DyIo<ST>::st(dv + base + (size_t)(f0 + r) * To + tc[j], part[j], ok[j][0] && mine, g);
       }
       rs = group_sum<LPP>(rs);
       if (l == 0 && mine) dgfp[f0 + r] = rs * af[r] * (1.0f - af[r]);       // gradient w.r.t. the PRE-sigmoid gate
@@ -608,7 +676,10 @@ __global__ __launch_bounds__(256) void dyrelu_ca_bwd2_kernel(const ST* __restric
   }
   if (mine) {
 #pragma unroll
-    for (int j = 0; j < NC; ++j) if (ok[j]) dgtp[l + LPP * j] = cs[j] * at[j] * (1.0f - at[j]);
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+      for (int q = 0; q < CW; ++q)
+        if (ok[j][q]) dgtp[CW * (l + LPP * j) + q] = cs[j][q] * at[j][q] * (1.0f - at[j][q]);
   }
   da1 = group_sum<LPP>(da1); da2 = group_sum<LPP>(da2); db1 = group_sum<LPP>(db1); db2 = group_sum<LPP>(db2);
   s1 = group_sum<LPP>(s1); s2 = group_sum<LPP>(s2);
@@ -711,8 +782,17 @@ static int dyn_pw_pack_bf16_impl(const float* bank, const float* att, void* wp, 
   if (trans && Co % 4 != 0) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16_t: Co=%d must be a multiple of 4", Co);
   if (B < 1 || K < 1 || Co < 1) return eat::fail(EAT_EINVAL, "eat_dyn_pw_pack_bf16: bad shape");
   const int MT = (Co + 15) / 16, KK = (Ci + 31) / 32;
-  hipLaunchKernelGGL(dyn_pw_pack_bf16_kernel, dim3(MT, B), dim3(256), 0, (hipStream_t)stream, bank, att,
-                     reinterpret_cast<__bf16*>(wp), K, Co, Ci, MT, KK, trans, np2);
+  // a block = (m-tile, SB samples, 256-column piece); SB: as many samples as keep >= ~2048 blocks (8 per CU) in the launch, at most 8
+  const int pieces = (Ci + kPackCols - 1) / kPackCols;
+  int SB = 8;
+  while (SB > 1 && (long long)MT * pieces * ((B + SB - 1) / SB) < 2048) SB >>= 1;
+  const dim3 grid(MT, (B + SB - 1) / SB, pieces);
+  if (K == 4)
+    hipLaunchKernelGGL(dyn_pw_pack_bf16_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, bank, att,
+                       reinterpret_cast<__bf16*>(wp), K, Co, Ci, MT, KK, trans, np2, B, SB);
+  else
+    hipLaunchKernelGGL(dyn_pw_pack_bf16_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, bank, att,
+                       reinterpret_cast<__bf16*>(wp), K, Co, Ci, MT, KK, trans, np2, B, SB);
   return eat::check_launch("eat_dyn_pw_pack_bf16");
 }
 
@@ -820,18 +900,19 @@ extern "C" int eat_ctx_split_bwd(const float* dhcf, const float* dhct, const flo
   return eat::check_launch("eat_ctx_split_bwd");
 }
 
+// (To <= LPP * NC * CW columns per lane group: CW = 1 for fp32 storage, 2 for bf16 - see DyIo)
+#define EAT_DYRELU2_LAUNCH(KERNEL, ST, LPP_, NC_, ...)                                                                 \
+  hipLaunchKernelGGL((KERNEL<LPP_, NC_, ST>), dim3(((n_planes + (64 / LPP_) - 1) / (64 / LPP_) + 3) / 4), dim3(256), 0, hs, __VA_ARGS__)
 #define EAT_DYRELU2_DISPATCH(KERNEL, ST, ...)                                                                         \
   do {                                                                                                                \
     const int n_planes = B * C;                                                                                       \
-    if (To <= 32) {                                                                                                   \
-      hipLaunchKernelGGL((KERNEL<32, 1, ST>), dim3((n_planes / 2 + 1 + 3) / 4), dim3(256), 0, hs, __VA_ARGS__);        \
-    } else {                                                                                                          \
-      const dim3 grid((n_planes + 3) / 4);                                                                            \
-      if (To <= 64) hipLaunchKernelGGL((KERNEL<64, 1, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                      \
-      else if (To <= 128) hipLaunchKernelGGL((KERNEL<64, 2, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                \
-      else if (To <= 256) hipLaunchKernelGGL((KERNEL<64, 4, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                \
-      else hipLaunchKernelGGL((KERNEL<64, 8, ST>), grid, dim3(256), 0, hs, __VA_ARGS__);                               \
-    }                                                                                                                 \
+    const int tw = (To + DyIo<ST>::CW - 1) / DyIo<ST>::CW;               /* slots per row */                           \
+    if (tw <= 16) EAT_DYRELU2_LAUNCH(KERNEL, ST, 16, 1, __VA_ARGS__);                                                  \
+    else if (tw <= 32) EAT_DYRELU2_LAUNCH(KERNEL, ST, 32, 1, __VA_ARGS__);                                             \
+    else if (tw <= 64) EAT_DYRELU2_LAUNCH(KERNEL, ST, 64, 1, __VA_ARGS__);                                             \
+    else if (tw <= 128) EAT_DYRELU2_LAUNCH(KERNEL, ST, 64, 2, __VA_ARGS__);                                            \
+    else if (tw <= 256) EAT_DYRELU2_LAUNCH(KERNEL, ST, 64, 4, __VA_ARGS__);                                            \
+    else EAT_DYRELU2_LAUNCH(KERNEL, ST, 64, 8, __VA_ARGS__);                                                           \
   } while (0)
 
 // out = max(a1 v + b1, a2 v + b2) * sigmoid(gate_f[c,b,f]) * sigmoid(gate_t[c,b,t]), v = a_c z + b_c (a, b NULL: v = z);
@@ -887,6 +968,7 @@ extern "C" int eat_dyrelu_ca_bwd2_b16(const void* dout, const void* z, const flo
   return eat::check_launch("eat_dyrelu_ca_bwd2_b16");
 }
 #undef EAT_DYRELU2_DISPATCH
+#undef EAT_DYRELU2_LAUNCH
 
 // Channel sums of a BatchNorm backward from per-plane partials (see dyn_bn_bwd_combine_kernel): p0 / p1 point at the first
 // element of the two partial arrays, element (b, c, i) lies stride_e * ((b*C + c)*inner + i) floats further on.

@@ -948,7 +948,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
                                                             int p_tile_rows, int q_tile_rows,
                                                             const float* __restrict__ radd, int same,
                                                             const float* __restrict__ tf_a = nullptr,
-                                                            const float* __restrict__ tf_b = nullptr, int tf_act = 0) {
+                                                            const float* __restrict__ tf_b = nullptr, int tf_act = 0,
+                                                            int ps_ns = 0) {
+  // ps_ns > 0 (per-sample gradients, eat_pw_conv_dyn_wgrad_b16): gridDim.z = B * ps_ns, block z multiplies slice z % ps_ns
+  // (units_per_block units, clipped to the sample) of sample z / ps_ns and stores it as copy (slice * B + sample) of dW: copy
+  // 0 of every sample forms the (B, Co, Ci) result, to which the caller adds the other slices
   static_assert(!P16 || NPROD == 1, "bf16-stored operand: plain bf16 products");
   static_assert(!PTF || (P16 && SWAP), "on-load transform: the bf16-stored x operand");
   constexpr unsigned PB = P16 ? 2u : 4u;                              // bytes per element of P
@@ -963,8 +967,15 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
   const int pv = (PR - p0) < p_tile_rows ? (PR - p0) : p_tile_rows;   // valid rows of this block's tile
   const int qv = (QR - q0) < q_tile_rows ? (QR - q0) : q_tile_rows;
   const int total = B * sps;
-  const int u0 = blockIdx.z * units_per_block;
-  const int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
+  int u0 = blockIdx.z * units_per_block;
+  int u1 = (u0 + units_per_block) < total ? (u0 + units_per_block) : total;
+  unsigned out_slot = blockIdx.z;
+  if (ps_ns > 0) {
+    const int sb = (int)blockIdx.z / ps_ns, sj = (int)blockIdx.z - sb * ps_ns;
+    u0 = sb * sps + sj * units_per_block;
+    u1 = (u0 + units_per_block) < (sb + 1) * sps ? (u0 + units_per_block) : (sb + 1) * sps;
+    out_slot = (unsigned)(sj * B + sb);
+  }
   if (pv <= 0 || qv <= 0 || u0 >= u1) return;                         // block-uniform, before any barrier
   const int pt = (pv + 15) >> 4, qt = (qv + 15) >> 4;                 // 16-row tiles
   const int GP = pt * 2, GQ = same ? 0 : (qv + 7) >> 3;               // 8-row pieces (P: whole 16-row tiles, so that the Q rows start
@@ -1216,7 +1227,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_wide_kernel(const float* __restr
   // Epilogue: PLAIN 16-byte stores into this k-slice's own copy of dW (ws holds gridDim.z copies; wgrad_slot_reduce4_kernel
   // adds them in a fixed order: bit-reproducible).  The atomic form - 160 wave-instructions of 64 fp32 atomics per consumer -
   // cost 25 - 35 us of the 85 - 145 us launches (the same-address adds of all k-slices arrive together).
-  float* out = dW + (size_t)blockIdx.z * Co * Ci;
+  float* out = dW + (size_t)out_slot * Co * Ci;
 #pragma unroll
   for (int i = 0; i < WIDE_PT; ++i)
 #pragma unroll
@@ -2110,7 +2121,7 @@ static int pw_wgrad_impl(const float* dz, const float* x, const float* x_scale, 
       }                                                                                                                   \
       hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, dz, x, x_scale, target, B, Co, Ci, S, p.sps, p.upb, p.w_ptr,    \
                          p.w_qtr, centring ? tf.b : (const float*)nullptr, dz == x ? 1 : 0, (const float*)nullptr, \
-                         (const float*)nullptr, 0);                                                                      \
+                         (const float*)nullptr, 0, 0);                                                                   \
     } while (0)
 #define EAT_WIDE_SC(NP_, SW_) do { if (x_scale) EAT_WIDE(NP_, SW_, true, false); else EAT_WIDE(NP_, SW_, false, false); } while (0)
 #define EAT_WIDE_SW(NP_)                                                                                                  \
@@ -2254,7 +2265,7 @@ extern "C" int eat_pw_conv_wgrad_b16(const void* dz, int dz_b16, const void* x, 
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, fdz, fx, x_scale, ws, B, Co, Ci, S, p.sps, p.upb, p.w.ptr, p.w.qtr,    \
-                       (const float*)nullptr, 0, tf_a, tf_b, tf_act);                                                     \
+                       (const float*)nullptr, 0, tf_a, tf_b, tf_act, 0);                                                  \
   } while (0)
   if (!x_b16) EAT_WIDE16(false, false, false);
   else if (tf_a && x_scale) EAT_WIDE16(true, true, true);
@@ -2270,8 +2281,22 @@ extern "C" int eat_pw_conv_wgrad_b16(const void* dz, int dz_b16, const void* x, 
 // models/dymn/dy_block.py:120-127): dW_b (B, Co, Ci) = dz[b] x[b]^T with exactly one bf16 operand (the wide tensor), plain bf16
 // products, fp32 accumulation.  The wide-tile kernel of eat_pw_conv_wgrad_b16 with one k-slice per SAMPLE: slice b is stored as
 // dW_b[b] - every element of dW_b is written, no zero fill, no reduction.  S % 4 == 0, Ci % 4 == 0.
-extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int B, int Co,
-                                         int Ci, int S, eat_stream_t stream) {
+// k-slices per sample: a sample's reduction is cut into several blocks where B x (tiles of dW) alone would leave CUs idle - the
+// early layers (thin matrices, planes of thousands of positions: 128 one-tile blocks walking 1000 units each ran at 1.9 TB/s)
+static int dyn_wgrad_b16_slices(const WgB16Plan& p, int B) {
+  const long long blocks = (long long)p.w.ptn * p.w.qtn * B;
+  int ns = 1;
+  while (ns < 8 && blocks * ns < 1024 && p.sps / (2 * ns) >= 8) ns *= 2;
+  while (ns > 1 && (ns - 1) * ((p.sps + ns - 1) / ns) >= p.sps) --ns;    // every slice must own at least one unit
+  return ns;
+}
+
+extern "C" int eat_pw_dyn_wgrad_b16_slices(int B, int Co, int Ci, int S, int x_b16) {
+  return dyn_wgrad_b16_slices(wgrad_b16_plan(B, Co, Ci, S, x_b16), B);
+}
+
+extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int n_slices, int B,
+                                         int Co, int Ci, int S, eat_stream_t stream) {
   eat::clear_stale_error();
   if (!dz || !x || !dW_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: missing operand");
   if ((dz_b16 != 0) == (x_b16 != 0)) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: exactly one of dz / x is the bf16 (wide) tensor");
@@ -2281,8 +2306,10 @@ extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void*
   if (!p.w.ok) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: internal tiling error (%d x %d)", Co, Ci);
   if ((long long)(x_b16 ? Ci : Co) * S * 2 > 0x7fffffffLL || (long long)(x_b16 ? Co : Ci) * S * 4 > 0x7fffffffLL)
     return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: a sample exceeds the 32-bit row offsets");
-  p.upb = p.sps;                                                       // one k-slice = one sample
-  p.nz = (unsigned)B;
+  const int ns = dyn_wgrad_b16_slices(p, B);
+  if (n_slices < ns) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: dW_b holds %d copies, %d needed (eat_pw_dyn_wgrad_b16_slices)", n_slices, ns);
+  p.upb = (p.sps + ns - 1) / ns;                                       // ns k-slices per sample
+  p.nz = (unsigned)(B * ns);
   hipStream_t hs = (hipStream_t)stream;
   const size_t smem = (size_t)(p.w.ptr / 8 + p.w.qtr / 8) * 2 * 1024;
   dim3 grid(p.w.ptn, p.w.qtn, p.nz);
@@ -2298,10 +2325,15 @@ extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void*
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, fdz, fx, (const float*)nullptr, dW_b, B, Co, Ci, S, p.sps, p.upb,  \
-                       p.w.ptr, p.w.qtr, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0);      \
+                       p.w.ptr, p.w.qtr, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0, ns);  \
   } while (0)
   if (!x_b16) EAT_WIDE16D(false); else EAT_WIDE16D(true);
 #undef EAT_WIDE16D
+  if (ns > 1) {                                                        // copy 0 (B, Co, Ci) += copies 1 .. ns - 1, fixed order
+    const long long n = (long long)B * Co * Ci;
+    if (n > 0x7fffffffLL) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: B*Co*Ci exceeds the 32-bit index of the slice reduction");
+    hipLaunchKernelGGL(wgrad_slot_reduce4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, dW_b + n, dW_b, (int)n, ns - 1);
+  }
   return eat::check_launch("eat_pw_conv_dyn_wgrad_b16");
 }
 

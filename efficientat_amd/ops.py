@@ -1410,10 +1410,11 @@ def pw_conv_dyn_wgrad_b16(dz, x):
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
     d16, x16 = _is16(dz), _is16(x)
-    G = torch.empty((B, Co * Ci), device=dz.device, dtype=torch.float32)
+    ns = int(_lib.lib().eat_pw_dyn_wgrad_b16_slices(B, Co, Ci, S, 1 if x16 else 0))
+    buf = torch.empty((ns, B, Co * Ci), device=dz.device, dtype=torch.float32)     # copy 0 = the result, the rest k-slice workspace
     _lib.call("eat_pw_conv_dyn_wgrad_b16", _dev16(dz, "dz") if d16 else _dev(dz, "dz"), 1 if d16 else 0,
-              _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, G.data_ptr(), B, Co, Ci, S, _stream())
-    return G
+              _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, buf.data_ptr(), ns, B, Co, Ci, S, _stream())
+    return buf[0]
 
 
 # ------------------------------------------------------------------ precision switch (training plans)

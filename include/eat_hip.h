@@ -834,10 +834,13 @@ int eat_bn_bwd_apply_b16(const void* dy, const void* z, const float* a, const fl
                          const double* sums, void* dz, int B, int C, int S, int act, eat_stream_t stream);
 
 /* Twin of eat_pw_conv_dyn_wgrad (autograd of the grouped F.conv2d of dy_block.py:120-127): per-sample weight gradients
- * dW_b (B, Co, Ci) = dz[b] x[b]^T with exactly one bf16 operand; every element of dW_b is stored (no zero fill).
- * S % 4 == 0, Ci % 4 == 0. */
-int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int B, int Co, int Ci, int S,
-                              eat_stream_t stream);
+ * dW_b (B, Co, Ci) = dz[b] x[b]^T with exactly one bf16 operand; every element is stored (no zero fill).  dW_b holds
+ * n_slices >= eat_pw_dyn_wgrad_b16_slices(...) copies of (B, Co, Ci) floats: the result is the FIRST copy, the others are
+ * workspace (the reduction of a sample is cut into k-slices where B x tiles alone would not fill the chip; the slices are
+ * added in a fixed order).  S % 4 == 0, Ci % 4 == 0. */
+int eat_pw_dyn_wgrad_b16_slices(int B, int Co, int Ci, int S, int x_b16);
+int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int n_slices, int B, int Co,
+                              int Ci, int S, eat_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus
