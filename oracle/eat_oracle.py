@@ -376,7 +376,10 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, n
         st16 = pw16 and _st16(int(prefix.rsplit(".", 1)[1]))
     except ValueError:
         st16 = False
-    pwc = (lambda t, w: _PwBf16.apply(t, w)) if (PW_BF16 and train) else (lambda t, w: F.conv2d(t, w))
+    if PW_BF16 and train:
+        pwc = lambda t, w, b=None: _PwBf16.apply(t, w) if b is None else _PwBf16.apply(t, w) + b.view(1, -1, 1, 1)
+    else:                                       # (the reference's own call, bias inside the conv: bit-for-bit the pinned oracle)
+        pwc = lambda t, w, b=None: F.conv2d(t, w, b)
     rnd = (lambda t: _StoreBf16.apply(t)) if st16 else (lambda t: t)
     grnd = (lambda t: _GradBf16.apply(t)) if st16 else (lambda t: t)
     # ContextGen (dy_block.py:235-254)
@@ -392,8 +395,8 @@ def _dy_block(sd, prefix, x, c, H, train, stats, temperature, no_dyrelu=False, n
     if dw_stride > 1:
         h_cf = F.avg_pool2d(h_cf, (3, 1), (dw_stride, 1), (1, 0))
         h_ct = F.avg_pool2d(h_ct, (1, 3), (1, dw_stride), (0, 1))
-    g_cf = pwc(h_cf, sd[prefix + ".context_gen.conv_f.weight"]) + sd[prefix + ".context_gen.conv_f.bias"].view(1, -1, 1, 1)
-    g_ct = pwc(h_ct, sd[prefix + ".context_gen.conv_t.weight"]) + sd[prefix + ".context_gen.conv_t.bias"].view(1, -1, 1, 1)
+    g_cf = pwc(h_cf, sd[prefix + ".context_gen.conv_f.weight"], sd[prefix + ".context_gen.conv_f.bias"])
+    g_ct = pwc(h_ct, sd[prefix + ".context_gen.conv_t.weight"], sd[prefix + ".context_gen.conv_t.bias"])
 
     def conv(name, x, cin, cout, k, stride, groups, dilation=1):
         if no_dyconv:
