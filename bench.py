@@ -410,7 +410,46 @@ def _alg_bytes(name, a):
     if name in ("eat_mixup_fwd", "eat_kd_loss_fwd_bwd", "eat_calib_copy"):
         n = a[4] * a[5] if name == "eat_mixup_fwd" else (a[8] * a[9] if name == "eat_kd_loss_fwd_bwd" else a[2])
         return name.replace("eat_", "") + "_kernel", 12 * n, 4 * n
+    # ---- round 6: bf16 activation storage of the DyMN blocks (argument order = include/eat_hip.h)
+    if name == "eat_dyn_pw_pack_b16":
+        B, K, Co, Ci = a[3:7]
+        return "dyn_pw_pack_bf16_kernel<plain>", 4 * K * Co * Ci + 2 * B * Co * Ci, 2 * B * K * Co * Ci
+    if name == "eat_pw_conv_dyn_b16_fwd":
+        x, x16, wp, bias, res, y, y16, part, B, Ci, Co, S, act = a[:13]
+        mt = (Co + 15) // 16
+        chunks = (mt + 7) // 8
+        mtw = (mt + chunks - 1) // chunks
+        nbytes = B * S * ((2 if x16 else 4) * Ci + (2 if y16 else 4) * Co + (4 * Co if res else 0)) + 2 * B * Co * Ci
+        return f"pw_conv_bf16_kernel<{mtw},1,*,dyn,{'bf16' if x16 else 'float'},{'bf16' if y16 else 'float'}>", nbytes, 2 * B * S * Ci * Co
+    if name == "eat_dw_conv_dyn_fwd_stats_b16":
+        x, x16, ia, ib, iact, w, y, part, cap, hin, B, C, F, T, Fo, To, k, s = a[:18]
+        return f"dw_conv_fwd_stats<{k},{s},dyn,bf16>", B * C * ((2 if x16 else 4) * F * T + 2 * Fo * To + 4 * k * k), 2 * B * C * Fo * To * k * k
+    if name == "eat_dw_conv_dyn_bwd_bn_g_b16":
+        B, C, F, T, Fo, To, k, s = a[-9:-1]
+        xb = 2 if a[10] else 4
+        has_res = a[15] is not None
+        nbytes = B * C * (2 * 2 * Fo * To + (2 * xb + (4 if has_res else 0)) * F * T + 4 * k * k)
+        return f"dw_bwd_tile_kernel<{k},{s},*,true,*,true,bf16>", nbytes, 4 * B * C * F * T * k * k // (s * s) + 2 * B * C * Fo * To * k * k
+    if name == "eat_dyrelu_ca_fwd2_b16":
+        B, C, Fo, To = a[-5:-1]
+        return "dyrelu_ca_fwd_kernel<bf16>", B * C * (2 * 2 * Fo * To + 4 * (Fo + To + 4)), 10 * B * C * Fo * To
+    if name == "eat_dyrelu_ca_bwd2_b16":
+        B, C, Fo, To = a[-5:-1]
+        return "dyrelu_ca_bwd_kernel<bf16>", B * C * (3 * 2 * Fo * To + 4 * (2 * (Fo + To) + 10)), 24 * B * C * Fo * To
+    if name == "eat_bn_bwd_apply_b16":
+        B, C, S, act = a[8:12]
+        return f"bn_act_bwd_apply_kernel<{act},bf16,bf16>", 6 * B * C * S, 10 * B * C * S
+    if name == "eat_pw_conv_dyn_wgrad_b16":
+        dz, d16, x, x16, dW, nsl, B, Co, Ci, S = a[:10]
+        return (f"pw_wgrad_wide_kernel<1,{'true' if x16 else 'false'},*,per-sample>",
+                B * S * ((2 if d16 else 4) * Co + (2 if x16 else 4) * Ci) + 4 * B * Co * Ci, 2 * B * S * Co * Ci)
+    if name == "eat_adam_multi":          # reads p, g, m, v, writes p, m, v (the element count: `_adam` below)
+        n = _ADAM_ELEMS["n"] or a[1] * 4096
+        return "adam_multi_kernel", 28 * n, 12 * n
     return name, 0, 0
+
+
+_ADAM_ELEMS = {"n": 0}
 
 
 # access width of a kernel's global loads -> which calibration copy corrects its FETCH_SIZE reading
@@ -865,6 +904,17 @@ def make_train_model(name, dev, precision=None):
     return model.to(dev)
 
 
+def _adam(params, capturable):
+    """The optimizer of the timed steps (ex_audioset.py:86-91: Adam, lr 8e-4): the library's one-launch multi-tensor Adam
+    (`efficientat_amd.optim.FusedAdam`, eat_adam_multi) - EAT_ADAM=torch selects torch.optim.Adam(fused=True) for A/B."""
+    params = list(params)
+    if os.environ.get("EAT_ADAM", "eat") == "torch":
+        return torch.optim.Adam(params, lr=8e-4, capturable=capturable, fused=True)
+    from efficientat_amd.optim import FusedAdam
+    _ADAM_ELEMS["n"] = sum(p.numel() for p in params)
+    return FusedAdam(params, lr=8e-4, capturable=capturable)
+
+
 def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=None):
     """Full training step per GPU: log-mel (train mode) -> forward (batch-stat BN) -> BCE-with-logits ->
     hand-written backward -> [bucketed RCCL all-reduce of the gradient, overlapped with backward] -> fused Adam.
@@ -892,7 +942,7 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
         # path spends ~350 tiny launches per step on the per-parameter bias-correction scalars)
         try:
             from efficientat_amd.graphs import GraphedTrainStep
-            opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=True, fused=True)
+            opt = _adam(model.parameters(), capturable=True)
             gstep = GraphedTrainStep(model, opt, F.binary_cross_entropy_with_logits, mel(w).unsqueeze(1), y)
             gstep.y.copy_(y)
             launch = "hipGraph replay (mel eager" + (", RCCL all-reduce captured)" if use_dp else ")")
@@ -904,7 +954,7 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
                 enable_data_parallel(model, force_buckets=ranks.world == 1)
             model.train()
     if not graphed:
-        opt = torch.optim.Adam(model.parameters(), lr=8e-4, fused=True)
+        opt = _adam(model.parameters(), capturable=False)
 
     def tstep():
         if graphed:
@@ -944,7 +994,7 @@ def train_bench(name, batch, steps, warmup, args, mel, wave, ranks, precision=No
     res = {"value": round(cps, 1), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
            "warmup": max(2, warmup), "batch_per_gpu": bt, "n_gpus": ranks.world, "final_loss": round(float(out["loss"]), 5),
            "launch": launch, "model": name, "repetitions": reps, "rep_ms_per_step": [round(e / steps * 1e3, 3) for e in els],
-           "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if use_dp else "") + "fused Adam; "
+           "what": "mel + fwd(train BN) + BCE + bwd (HIP) + " + ("RCCL all-reduce + " if use_dp else "") + ("torch fused Adam; " if os.environ.get("EAT_ADAM", "eat") == "torch" else "multi-tensor Adam (eat_adam_multi); ")
                    + (f"bf16 MFMA 1x1 GEMMs, wide activations / gradients stored in {getattr(model, 'act_storage', 'fp32')}, fp32 statistics / "
                       "parameters / optimizer" if name.endswith("bf16") else "fp32 activations, 1x1 GEMMs per EAT_TRAIN_PRECISION"),
            "roofline_e2e_frac": round(cps / ranks.world * alg / HBM_PEAK, 4) if alg else None,
@@ -990,7 +1040,7 @@ def kd_bench(args, mel_unused, wave, ranks, steps=12, warmup=3):
             enable_data_parallel(model, force_buckets=ranks.world == 1)
         model.train()
         mel = quiet(AugmentMelSTFT, freqm=0, timem=0).to(dev).train()
-        opt = torch.optim.Adam(model.parameters(), lr=8e-4, capturable=graphed, fused=True)
+        opt = _adam(model.parameters(), capturable=graphed)
         kw = dict(teacher_preds=teacher, fname_to_index=f2i, kd_lambda=0.1, mixup_alpha=0.3)
         return (GraphedKDTrainer(model, mel, opt, B, L, **kw) if graphed else KDTrainer(model, mel, opt, **kw))
 
@@ -1302,7 +1352,7 @@ def main():
         bt = min(args.batch, wave.shape[0])
         gy = torch.Generator(device=dev).manual_seed(99)
         y = (torch.rand((bt, 527), device=dev, generator=gy) < 2.7 / 527).float()
-        opt = torch.optim.Adam(tm.parameters(), lr=8e-4, fused=True)
+        opt = _adam(tm.parameters(), capturable=False)
 
         def tstep():
             opt.zero_grad(set_to_none=True)

@@ -145,6 +145,7 @@ SIGNATURES = {
     "eat_dyrelu_ca_bwd2_b16": [_P] * 12 + [_I, _I, _I, _I, _P],
     "eat_dw_conv_dyn_bwd_bn_g_b16": [_P] * 7 + [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P] + [_I] * 8 + [_P],
     "eat_bn_bwd_apply_b16": [_P] * 8 + [_I, _I, _I, _I, _P],
+    "eat_adam_multi": [_P, _I, _P, _D, _P, _F, _D, _D, _D, _D, _I, _D, _P],
     "eat_pw_dyn_wgrad_b16_slices": [_I] * 5,
     "eat_pw_conv_dyn_wgrad_b16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],
 }

@@ -267,3 +267,70 @@ extern "C" int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_
                      rows_pb);
   return eat::check_launch("eat_col_sum");
 }
+
+// ---- multi-tensor Adam / AdamW: the optimizer step of ex_audioset.py:86-91,197-199 (torch.optim.Adam / AdamW over all
+// parameters) as ONE launch over a device-resident chunk table - every block owns one chunk (<= 4096
+// consecutive elements of one parameter), so small BatchNorm vectors and multi-MB weight matrices share a launch without idle
+// blocks.  The step counter and, optionally, the learning rate live on the device (hipGraph replays / LR schedulers that write a
+// tensor): the kernel reads them, a one-thread kernel advances the counter afterwards.
+//   g' = g * grad_scale (+ wd * p, Adam's L2 form);  AdamW: p *= 1 - lr * wd
+//   m = m + (1 - b1) (g' - m);  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// - the order of operations of torch's fused kernel (aten/src/ATen/native/cuda/fused_adam_utils.cuh), bias corrections in fp64.
+namespace {
+struct AdamChunk { float* p; const float* g; float* m; float* v; int n; int pad; };
+static_assert(sizeof(AdamChunk) == 40, "host side builds the table as 40-byte records");
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk* __restrict__ table, const float* __restrict__ lr_ptr,
+                                                         double lr_val, const float* __restrict__ step_ptr, float step_val,
+                                                         double b1, double b2, double eps, double wd, int decoupled,
+                                                         double grad_scale) {
+  const AdamChunk c = table[blockIdx.x];
+  const double t = (double)(step_ptr ? *step_ptr : step_val) + 1.0;
+  const double lr = lr_ptr ? (double)*lr_ptr : lr_val;
+  const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+  const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
+  const float w1 = (float)(1.0 - b1), gsc = (float)grad_scale;
+  const double decay = 1.0 - lr * wd, omb2 = 1.0 - b2;
+  // the expression types of torch's fused kernel: the first moment is a float lerp, every line that multiplies by a double
+  // hyper-parameter (second moment, denominator, update) is evaluated in fp64 and rounded on assignment
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    g *= gsc;
+    if (decoupled) p = (float)((double)p * decay); else if (wd != 0.0) g = (float)((double)g + wd * (double)p);
+    m = fmaf(w1, g - m, m);
+    v = (float)(b2 * (double)v + omb2 * (double)g * (double)g);
+    const double denom = (double)sqrtf(v) / bc2_sqrt + eps;
+    p = (float)((double)p - step_size * (double)m / denom);
+  };
+  const bool vec = ((c.n & 3) == 0) && (((size_t)c.p | (size_t)c.g | (size_t)c.m | (size_t)c.v) & 15) == 0;
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < c.n; i += 1024) {
+      float4 p = *reinterpret_cast<float4*>(c.p + i), m = *reinterpret_cast<float4*>(c.m + i), v = *reinterpret_cast<float4*>(c.v + i);
+      const float4 g = *reinterpret_cast<const float4*>(c.g + i);
+      upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+      *reinterpret_cast<float4*>(c.p + i) = p; *reinterpret_cast<float4*>(c.m + i) = m; *reinterpret_cast<float4*>(c.v + i) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < c.n; i += 256) {
+      float p = c.p[i], m = c.m[i], v = c.v[i];
+      upd(p, c.g[i], m, v);
+      c.p[i] = p; c.m[i] = m; c.v[i] = v;
+    }
+  }
+}
+
+__global__ void adam_step_inc_kernel(float* __restrict__ step) { *step += 1.0f; }
+}  // namespace
+
+extern "C" int eat_adam_multi(const void* table, int n_chunks, const float* lr_ptr, double lr, float* step_ptr, float step,
+                              double beta1, double beta2, double eps, double weight_decay, int decoupled, double grad_scale,
+                              eat_stream_t stream) {
+  eat::clear_stale_error();
+  if (!table || n_chunks < 1) return eat::fail(EAT_EINVAL, "eat_adam_multi: empty chunk table");
+  if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
+    return eat::fail(EAT_EINVAL, "eat_adam_multi: bad hyper-parameters (beta1=%g beta2=%g eps=%g)", beta1, beta2, eps);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const AdamChunk*>(table), lr_ptr, lr, (const float*)step_ptr, step, beta1, beta2, eps,
+                     weight_decay, decoupled, grad_scale);
+  if (step_ptr) hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
+  return eat::check_launch("eat_adam_multi");
+}

@@ -90,7 +90,12 @@ def parse_args(argv=None):
     p.add_argument("--no_graph", action="store_true", help="eager KDTrainer instead of the captured step")
     p.add_argument("--transport", choices=["fp32", "int16"], default="fp32", help="waveform format over PCIe")
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many steps (benchmarks / tests); 0 = whole epochs")
+    p.add_argument("--optimizer", default="eat", choices=["eat", "torch"],
+                   help="eat: efficientat_amd.optim.FusedAdam (one launch per step); torch: torch.optim.Adam / AdamW (fused=True)")
     p.add_argument("--precision", default=None, help="model.train_precision (auto / fp32 / bf16)")
+    p.add_argument("--act_storage", default=None, choices=["fp32", "bf16"],
+                   help="model.act_storage; bf16 (with --precision bf16) = the 16-bit surface of ex_pl_audioset.py:287-293 "
+                        "(precision=16): wide activations / gradients of every block in bf16 in HBM")
     p.add_argument("--out", default=None, help="directory for rank 0's per-epoch state dicts")
     p.add_argument("--json", action="store_true", help="rank 0 prints one JSON line with the run's throughput at the end")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -114,6 +119,8 @@ def build(args, dev):
     model = _quiet(get_model, width_mult=width).to(dev)
     if args.precision:
         model.train_precision = args.precision
+    if args.act_storage:
+        model.act_storage = args.act_storage
     mel = _quiet(AugmentMelSTFT, freqm=args.freqm, timem=args.timem, fmin=args.fmin, fmax=args.fmax,
                  fmin_aug_range=args.fmin_aug_range, fmax_aug_range=args.fmax_aug_range).to(dev)
     return model, mel
@@ -165,8 +172,12 @@ def main(argv=None):
 
     graphed = not args.no_graph
     lr = torch.tensor(args.max_lr, device=dev) if graphed else args.max_lr     # tensor lr: the schedule needs no re-capture
-    opt_cls = torch.optim.AdamW if args.adamw else torch.optim.Adam
-    opt = opt_cls(model.parameters(), lr=lr, weight_decay=args.weight_decay, fused=True, capturable=graphed)
+    if args.optimizer == "torch":
+        opt_cls = torch.optim.AdamW if args.adamw else torch.optim.Adam
+        opt = opt_cls(model.parameters(), lr=lr, weight_decay=args.weight_decay, fused=True, capturable=graphed)
+    else:                        # the same update as one launch over every parameter (optim.py, eat_adam_multi)
+        from .optim import FusedAdam
+        opt = FusedAdam(model.parameters(), lr=lr, weight_decay=args.weight_decay, decoupled=args.adamw, capturable=graphed)
     sched = torch.optim.lr_scheduler.LambdaLR(
         opt, exp_warmup_linear_down(args.warm_up_len, args.ramp_down_len, args.ramp_down_start, args.last_lr_value))
 

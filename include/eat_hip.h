@@ -690,6 +690,19 @@ int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const int* perm, co
                         const long long* teacher_idx, int n_teacher, float kd_lambda, int B, int C, float* sums,
                         float* dlogits, eat_stream_t stream);
 
+/* The optimizer step of the training loop (ex_audioset.py:86-91 `torch.optim.Adam` / `AdamW` over all parameters, :197-199
+ * `optimizer.step()`) as ONE launch over every parameter: table = n_chunks records of 40 bytes
+ * { float* p; const float* g; float* m; float* v; int n; int pad; } - a chunk is <= 4096 consecutive elements of one parameter
+ * with its gradient and the two moment buffers (fp32, updated in place).
+ *   g' = g * grad_scale (+ weight_decay * p when decoupled == 0: Adam's L2 form);  decoupled != 0 (AdamW): p *= 1 - lr * weight_decay;
+ *   m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * with t = step + 1.  lr_ptr / step_ptr != NULL: the learning rate / step counter are read from the device (hipGraph replays,
+ * schedulers that write a tensor) and *step_ptr is advanced by one after the update; NULL: the by-value arguments are used.
+ * Hyper-parameters are doubles and the second-moment / update expressions are evaluated in fp64 where torch's fused kernel
+ * evaluates them in fp64 (aten/src/ATen/native/cuda/fused_adam_utils.cuh: double hyper-parameters promote those lines). */
+int eat_adam_multi(const void* table, int n_chunks, const float* lr_ptr, double lr, float* step_ptr, float step, double beta1,
+                   double beta2, double eps, double weight_decay, int decoupled, double grad_scale, eat_stream_t stream);
+
 /* Backward of the classifier head (models/mn/model.py:186-194: Linear(C -> H) -> Hardswish -> Dropout -> Linear(H -> N); the
  * reference leaves it to autograd) in two launches, no transposed copies, every output element from one block (no atomics):
  *   dW2 = dlogits^T h2, db2 = sum_b dlogits, du = (dlogits W2) * drop_mask * hardswish'(u), dW1 = du^T feat, db1 = sum_b du,

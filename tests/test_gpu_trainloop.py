@@ -315,9 +315,12 @@ def test_train_dp_program_runs_on_one_gpu(tmp_path):
     with open(tmp_path / "f2i.pkl", "wb") as f:
         pickle.dump({"syn%07d" % i: i % 64 for i in range(0, 4096, 2)}, f)
     env = dict(os.environ, EAT_SYNTH_AUDIOSET="1", EAT_SYNTH_AUDIOSET_TRAIN="64", PYTHONPATH=root)
-    for extra in (["--transport", "int16"], ["--no_graph"]):
+    # (third run: a dynamic network on the 16-bit surface - bf16 GEMM operands + bf16 storage of the blocks' wide tensors - in
+    #  the captured KD step: `--precision bf16 --act_storage bf16`, ex_pl_audioset.py:287-293)
+    for extra in (["--model_width", "0.5", "--transport", "int16"], ["--model_width", "0.5", "--no_graph"],
+                  ["--model_name", "dymn10_as", "--precision", "bf16", "--act_storage", "bf16", "--transport", "int16"]):
         r = subprocess.run([sys.executable, "-m", "efficientat_amd.train_dp", "--batch_size", "8", "--num_workers", "2",
-                            "--n_epochs", "1", "--epoch_len", "64", "--max_steps", "4", "--model_width", "0.5",
+                            "--n_epochs", "1", "--epoch_len", "64", "--max_steps", "4",
                             "--teacher_preds", str(tmp_path / "teacher.npy"), "--fname_to_index", str(tmp_path / "f2i.pkl"),
                             "--json"] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
