@@ -411,6 +411,10 @@ def _alg_bytes(name, a):
         n = a[4] * a[5] if name == "eat_mixup_fwd" else (a[8] * a[9] if name == "eat_kd_loss_fwd_bwd" else a[2])
         return name.replace("eat_", "") + "_kernel", 12 * n, 4 * n
     # ---- round 6: bf16 activation storage of the DyMN blocks (argument order = include/eat_hip.h)
+    if name in ("eat_dyn_heads_fwd", "eat_dyn_heads_bwd"):
+        B, n_att, K, cexp = (a[1:5] if name.endswith("fwd") else a[5:9])
+        n = B * (n_att * K + 4 * cexp)
+        return name.replace("eat_", "") + "_kernel", 12 * n, 8 * n
     if name == "eat_dyn_pw_pack_b16":
         B, K, Co, Ci = a[3:7]
         return "dyn_pw_pack_bf16_kernel<plain>", 4 * K * Co * Ci + 2 * B * Co * Ci, 2 * B * K * Co * Ci

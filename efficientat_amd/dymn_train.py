@@ -14,6 +14,8 @@ activation volume; every pass over a feature map and every GEMM runs in the libr
 Reference semantics: models/dymn/dy_block.py:390-409 (DY_Block.forward), :235-254 (ContextGen),
 :103-131 (DynamicConv), :172-188 (DyReLU-B), :195-201 (CoordAtt).
 """
+import os as _os
+
 import torch
 import torch.nn.functional as F
 
@@ -177,6 +179,43 @@ class StemConv(torch.autograd.Function):
         return None, dw
 
 
+# All weight packs of the network's STATIC 1x1 convs (the context generators' joint_conv / conv_f / conv_t, out_c, the convs of
+# SE-less static blocks) - forward and data-gradient forms - from ONE launch per step (ops.PrepackPlan, as the MN plan does):
+# before, every PwConv packed its matrix when it ran, 92 launches of ~7 us per dymn20 step.  `_PLAN` = (plan, run id) of the
+# pass being built; a Function keeps it in its ctx and its backward uses the plan's views only while no later forward has
+# re-packed them (two forwards before one backward).
+_PLAN = (None, 0)
+
+
+def _static_prepack_plan(model):
+    plan = getattr(model, "_eat_prepack_plan", None)
+    if plan is not None and not plan.stale():
+        return plan
+    if torch.cuda.is_current_stream_capturing() or _os.environ.get("EAT_DYMN_PLAN", "1") == "0":
+        return None
+    entries, seen = [], set()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.groups == 1 and m.weight.is_cuda \
+                and m.weight.dtype == torch.float32 and m.weight.data_ptr() not in seen:
+            seen.add(m.weight.data_ptr())
+            entries += [((m.weight.data_ptr(), False), m.weight, False), ((m.weight.data_ptr(), True), m.weight, True)]
+    try:
+        plan = ops.PrepackPlan(entries) if entries else None
+    except _lib.EatHipError:                              # channel counts the one-launch pack does not take: per-matrix packs
+        plan = None
+    model._eat_prepack_plan = plan
+    return plan
+
+
+def _pack(plan_run, w, trans):
+    plan, run = plan_run
+    if plan is not None and plan.runs == run:
+        v = plan.views.get((w.data_ptr(), trans))
+        if v is not None:
+            return v
+    return ops.pw_prepack(w.flatten(1), trans=trans)
+
+
 class PwConv(torch.autograd.Function):
     """Static 1x1 conv (no bias): forward and data gradient are the same MFMA GEMM."""
 
@@ -184,8 +223,9 @@ class PwConv(torch.autograd.Function):
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
         ctx.prec = ops.precision.mode
+        ctx.plan = _PLAN
         Co = w.shape[0]
-        return ops.pw_conv(x.contiguous(), ops.pw_prepack(w.flatten(1)), _zeros.get(Co, x.device), Co, NONE)
+        return ops.pw_conv(x.contiguous(), _pack(_PLAN, w, False), _zeros.get(Co, x.device), Co, NONE)
 
     @staticmethod
     def backward(ctx, dz):
@@ -193,7 +233,7 @@ class PwConv(torch.autograd.Function):
         dz = dz.contiguous()
         Ci = x.shape[1]
         with _in_precision(ctx):
-            dx = ops.pw_conv(dz, ops.pw_prepack(w.flatten(1), trans=True), _zeros.get(Ci, x.device), Ci, NONE)
+            dx = ops.pw_conv(dz, _pack(ctx.plan, w, True), _zeros.get(Ci, x.device), Ci, NONE)
             return dx, ops.pw_conv_wgrad(dz, x, exact=None).view_as(w)
 
 
@@ -204,8 +244,9 @@ class PwConvB(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.prec = ops.precision.mode
+        ctx.plan = _PLAN
         Co = w.shape[0]
-        return ops.pw_conv(x.contiguous(), ops.pw_prepack(w.flatten(1)), b, Co, NONE)
+        return ops.pw_conv(x.contiguous(), _pack(_PLAN, w, False), b, Co, NONE)
 
     @staticmethod
     def backward(ctx, dz):
@@ -213,7 +254,7 @@ class PwConvB(torch.autograd.Function):
         dz = dz.contiguous()
         Ci, Co = x.shape[1], w.shape[0]
         with _in_precision(ctx):
-            dx = ops.pw_conv(dz, ops.pw_prepack(w.flatten(1), trans=True), _zeros.get(Ci, x.device), Ci, NONE)
+            dx = ops.pw_conv(dz, _pack(ctx.plan, w, True), _zeros.get(Ci, x.device), Ci, NONE)
             dw = ops.pw_conv_wgrad(dz, x, exact=None).view_as(w)
         db = ops.bn_stats(dz)[:Co].float()                   # per-channel sums over (batch, positions), fp64 accumulation
         return dx, dw, db
@@ -777,12 +818,18 @@ def forward_train(model, x, return_fmaps=False):
         raise _lib.EatHipError("act_storage='bf16' needs train_precision='bf16' (plain bf16 GEMM operands): the split-operand "
                                "modes keep fp32-class products, which a bf16-stored operand cannot feed")
     ops.zero_arena.begin("dymn_step")          # one zero-filled arena per step (forward + the backward autograd runs later)
+    global _PLAN
     _STORE16 = st == "bf16"
     try:
         with ops.precision(prec), ops.bn_counters:
+            plan = _static_prepack_plan(model)
+            if plan is not None:
+                plan.run()
+                _PLAN = (plan, plan.runs)
             out = _forward_train(model, x, return_fmaps)
     finally:
         _STORE16 = False
+        _PLAN = (None, 0)
     if out[0].requires_grad:
         # the arena closes when THIS backward pass is over, whichever node runs last (a frozen stem never runs its backward;
         # ADVICE r5): the first gradient to arrive queues an engine callback, which fires after the last node of the pass

@@ -23,6 +23,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._tables = {}
         self._spare = {}
         self._counters = {}
+        self._captured = []
 
     def _state(self, p, capturable):
         st = self.state[p]
@@ -69,7 +70,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._spare[gi] = None
             host.copy_(raw)
             dev_tab.copy_(host, non_blocking=True)
-            self._tables[gi] = (key, dev_tab, len(recs), host)
+            self._tables[gi] = (key, dev_tab, len(recs))
+            self._captured.append((host, dev_tab))      # the graph's copy node re-reads them on every replay: never freed
         else:
             dev_tab = raw.to(ps[0].device)
             self._tables[gi] = (key, dev_tab, len(recs))
