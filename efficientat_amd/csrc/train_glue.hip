@@ -251,6 +251,13 @@ extern "C" int eat_kd_loss_fwd_bwd(const float* logits, const float* y, const in
   return eat::check_launch("eat_kd_loss_fwd_bwd");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void col_zero_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.0f;
+}
+}  // namespace
+
 extern "C" int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_t stream) {
   eat::clear_stale_error();
   if (R < 1 || C < 1 || C > 8192) return eat::fail(EAT_EINVAL, "eat_col_sum: bad shape (%d x %d)", R, C);
@@ -259,7 +266,8 @@ extern "C" int eat_col_sum(const float* m, float* out, int R, int C, eat_stream_
     hipLaunchKernelGGL(col_sum_det_kernel, dim3((C + 31) / 32), dim3(256), 0, s, m, out, R, C);
     return eat::check_launch("eat_col_sum");
   }
-  if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) return eat::fail(EAT_ELAUNCH, "eat_col_sum: memset failed");
+  // (a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph were not ordered reliably - see eat_dyn_bank_grad)
+  hipLaunchKernelGGL(col_zero_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, out, C);
   const int cb = (C + 63) / 64;
   int rows_pb = (int)(((long long)R * cb + 1023) / 1024);             // ~1024 blocks, at least 64 rows each
   if (rows_pb < 64) rows_pb = 64;

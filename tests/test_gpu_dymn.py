@@ -484,3 +484,51 @@ def test_pw_conv_kcat(B, Ci, Co, Fq, T, act, res, stream):
     finally:
         ops.pw_stream_mode(prev)
     assert _rel(got, ref) < 3e-5
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_dymn_captured_step_reproduces_its_gradients_on_every_replay(storage):
+    """A captured training step (graphs.GraphedTrainStep) of a dynamic network must produce, on EVERY replay, the gradients of the
+    eager step on the same parameters and input (learning rate 0: nothing moves between replays).  Guards the zero-initialised
+    accumulators of the step inside a hipGraph: with `hipMemsetAsync` nodes (ROCm 7.0) the batch-sliced bank gradients of the small
+    DynamicConv layers and the column sums were not re-zeroed reliably from the second replay on - silent accumulation of the
+    previous replay's values, and a NaN loss in ~1 of 20 fresh processes of the dymn20 bench leg; they are kernels now."""
+    from efficientat_amd.graphs import GraphedTrainStep
+    sd = synth.synth_state(synth.dymn_shapes(1.0), seed=0)
+    B = 16
+    x = O.mel_forward(synth.parity_clips(320000, seed=31)[[0, 2, 3, 4]]).unsqueeze(1).repeat(4, 1, 1, 1)
+    x = (x * (1.0 + 0.01 * _rand(B, 1, 1, 1, seed=3))).to(DEV)
+    y = (torch.rand(B, 527, generator=torch.Generator().manual_seed(5)) < 0.01).float().to(DEV)
+    keep = (torch.rand(B, 1280, generator=torch.Generator().manual_seed(6)) < 0.8).float()
+
+    def build():
+        m = _quiet(get_model, width_mult=1.0)
+        m.load_state_dict(sd)
+        for mod in m.modules():
+            if hasattr(mod, "temperature"):
+                mod.temperature = 30.0
+        m.to(DEV).train()
+        m._drop_mask_override = keep.to(DEV)           # (on the device: a host-to-device copy is not capturable)
+        if storage == "bf16":
+            m.train_precision, m.act_storage = "bf16", "bf16"
+        return m
+    ref = build()
+    logits, _ = ref(x)
+    F.binary_cross_entropy_with_logits(logits, y).backward()
+    ref_g = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+    gmax = max(float(g.norm()) for g in ref_g.values())
+    model = build()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    step = GraphedTrainStep(model, opt, F.binary_cross_entropy_with_logits, x, y)
+    tol = 2e-3 if storage == "fp32" else 3e-2          # atomics order (fp32) / rounding-boundary flips between two bf16 evaluations
+    for r in range(4):
+        step(step.x, step.y)
+        torch.cuda.synchronize()
+        worst = (0.0, None)
+        for n, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (r, n)
+            if float(ref_g[n].norm()) < 1e-3 * gmax:
+                continue
+            e = _rel(p.grad, ref_g[n].cpu())
+            worst = max(worst, (e, n))
+        assert worst[0] < tol, (r, worst)
