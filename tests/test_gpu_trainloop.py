@@ -401,3 +401,51 @@ def test_graphed_kd_trainer_with_dymn_and_recapture():
     assert all(abs(a - b) < 3e-4 * max(1.0, abs(a)) for a, b in zip(res["eager"], res["graph"])), res
     assert all(abs(a - b) < 3e-4 * max(1.0, abs(a)) for a, b in zip(res["eager"][:2], res["stale"][:2])), res
     assert abs(res["stale"][2] - res["eager"][2]) > 10 * abs(res["graph"][2] - res["eager"][2]) + 1e-5, res   # old temperature
+
+
+@pytest.mark.parametrize("prec,storage", [("auto", "fp32"), ("bf16", "bf16")])
+def test_mn_captured_step_reproduces_its_gradients_on_every_replay(prec, storage):
+    """graphs.GraphedTrainStep on mn10 at learning rate 0: every replay must reproduce the gradients of the eager step on the same
+    parameters and input - the zero-initialised accumulators (weight-gradient workspaces, fp64 BatchNorm sums, SE / head pools)
+    and the copy / fill nodes of the captured step must behave on replay 2, 3, ... exactly as on replay 1 (see
+    test_gpu_dymn.py::test_dymn_captured_step_reproduces_its_gradients_on_every_replay for the defect this guards against)."""
+    import contextlib
+    import io
+    from efficientat_amd.graphs import GraphedTrainStep
+    from efficientat_amd.mn import get_model
+    from oracle import synth
+    B = 16
+    sd = synth.synth_state(synth.mn_shapes(1.0), seed=0)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, 1, 128, 1000, generator=g) * 3.0 - 4.0).to(DEV)
+    y = (torch.rand(B, 527, generator=g) < 0.01).float().to(DEV)
+    keep = (torch.rand(B, 1280, generator=g) < 0.8).float().to(DEV)
+
+    def build():
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = get_model(width_mult=1.0)
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        m.train_precision, m.act_storage = prec, storage
+        m._drop_mask_override = keep
+        return m
+    ref = build()
+    logits, _ = ref(x)
+    F.binary_cross_entropy_with_logits(logits, y).backward()
+    ref_g = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+    gmax = max(float(v.norm()) for v in ref_g.values())
+    model = build()
+    step = GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), F.binary_cross_entropy_with_logits, x, y)
+    tol = 2e-3 if storage == "fp32" else 5e-2
+    for r in range(4):
+        step(step.x, step.y)
+        torch.cuda.synchronize()
+        worst = (0.0, None)
+        for n, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (r, n)
+            if float(ref_g[n].norm()) < 1e-3 * gmax:
+                continue
+            e = float((p.grad - ref_g[n]).norm() / ref_g[n].norm())
+            if e > worst[0]:
+                worst = (e, n)
+        assert worst[0] < tol, (r, worst)
