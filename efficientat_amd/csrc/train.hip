@@ -2211,10 +2211,12 @@ extern "C" int eat_pw_conv_wgrad_tf(const float* dz, const float* x, const float
 // the caller).  S % 4 == 0, Ci % 4 == 0.
 struct WgB16Plan { WideShape w; int upb; unsigned nz; int sps; };
 static WgB16Plan wgrad_b16_plan(int B, int Co, int Ci, int S, int x_b16) {
+  // x_b16: 1 = x is the bf16 (wide) operand, 0 = dz is; 2 = BOTH operands fp32 (the per-sample gradients of the fp32-storage
+  // DyMN plan on the same kernel, split-operand products): P = the operand with more rows
   WgB16Plan p{};
   p.sps = (S + 31) / 32;
   WideShape& w = p.w;
-  w.swap = x_b16 != 0;
+  w.swap = x_b16 == 2 ? Ci > Co : x_b16 != 0;
   const int PR = w.swap ? Ci : Co, QR = w.swap ? Co : Ci;
   w.ptn = (PR + 255) / 256;
   w.ptr = ((PR + w.ptn - 1) / w.ptn + 15) / 16 * 16;
@@ -2292,19 +2294,22 @@ static int dyn_wgrad_b16_slices(const WgB16Plan& p, int B) {
 }
 
 extern "C" int eat_pw_dyn_wgrad_b16_slices(int B, int Co, int Ci, int S, int x_b16) {
-  return dyn_wgrad_b16_slices(wgrad_b16_plan(B, Co, Ci, S, x_b16), B);
+  const WgB16Plan p = wgrad_b16_plan(B, Co, Ci, S, x_b16);
+  if (!p.w.ok || (S & 3) != 0 || (Ci & 3) != 0) return 0;               // (0: this shape does not run on the wide-tile kernel)
+  return dyn_wgrad_b16_slices(p, B);
 }
 
 extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void* x, int x_b16, float* dW_b, int n_slices, int B,
                                          int Co, int Ci, int S, eat_stream_t stream) {
   eat::clear_stale_error();
   if (!dz || !x || !dW_b) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: missing operand");
-  if ((dz_b16 != 0) == (x_b16 != 0)) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: exactly one of dz / x is the bf16 (wide) tensor");
+  if (dz_b16 && x_b16) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: at most one of dz / x is a bf16 tensor");
   if (B < 1 || Co < 1 || Ci < 4 || (Ci & 3) != 0 || S < 4 || (S & 3) != 0)
     return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: Ci=%d and S=%d must be multiples of 4", Ci, S);
-  WgB16Plan p = wgrad_b16_plan(B, Co, Ci, S, x_b16);
+  const bool f32 = !dz_b16 && !x_b16;                                  // both fp32: split-operand (bf16x3) products
+  WgB16Plan p = wgrad_b16_plan(B, Co, Ci, S, f32 ? 2 : x_b16);
   if (!p.w.ok) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: internal tiling error (%d x %d)", Co, Ci);
-  if ((long long)(x_b16 ? Ci : Co) * S * 2 > 0x7fffffffLL || (long long)(x_b16 ? Co : Ci) * S * 4 > 0x7fffffffLL)
+  if ((long long)(Ci > Co ? Ci : Co) * S * 4 > 0x7fffffffLL)
     return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: a sample exceeds the 32-bit row offsets");
   const int ns = dyn_wgrad_b16_slices(p, B);
   if (n_slices < ns) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: dW_b holds %d copies, %d needed (eat_pw_dyn_wgrad_b16_slices)", n_slices, ns);
@@ -2327,8 +2332,22 @@ extern "C" int eat_pw_conv_dyn_wgrad_b16(const void* dz, int dz_b16, const void*
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, fdz, fx, (const float*)nullptr, dW_b, B, Co, Ci, S, p.sps, p.upb,  \
                        p.w.ptr, p.w.qtr, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0, ns);  \
   } while (0)
-  if (!x_b16) EAT_WIDE16D(false); else EAT_WIDE16D(true);
+#define EAT_WIDE32D(SW_)                                                                                                  \
+  do {                                                                                                                    \
+    auto kern = pw_wgrad_wide_kernel<3, SW_, false, false>;                                                               \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+        return eat::fail(EAT_ELAUNCH, "eat_pw_conv_dyn_wgrad_b16: hipFuncSetAttribute(160 KB of LDS) failed");            \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, hs, fdz, fx, (const float*)nullptr, dW_b, B, Co, Ci, S, p.sps, p.upb,  \
+                       p.w.ptr, p.w.qtr, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0, ns);  \
+  } while (0)
+  if (f32) { if (p.w.swap) EAT_WIDE32D(true); else EAT_WIDE32D(false); }
+  else if (!x_b16) EAT_WIDE16D(false); else EAT_WIDE16D(true);
 #undef EAT_WIDE16D
+#undef EAT_WIDE32D
   if (ns > 1) {                                                        // copy 0 (B, Co, Ci) += copies 1 .. ns - 1, fixed order
     const long long n = (long long)B * Co * Ci;
     if (n > 0x7fffffffLL) return eat::fail(EAT_EINVAL, "eat_pw_conv_dyn_wgrad_b16: B*Co*Ci exceeds the 32-bit index of the slice reduction");

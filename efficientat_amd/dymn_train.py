@@ -357,6 +357,12 @@ def _dyn_pw_wgrad(dz, x, bank, att, datt=None):
     B, S = x.shape[0], x.shape[2] * x.shape[3]
     if dz.dtype == torch.bfloat16 or x.dtype == torch.bfloat16:            # bf16-storage plan: one wide operand
         return _bank_grad(ops.pw_conv_dyn_wgrad_b16(dz, x), att, bank.reshape(K, Co * Ci), datt)
+    if _WIDE_PS_WGRAD and S % 4 == 0 and Ci % 4 == 0:
+        # fp32 storage: the same wide-tile producer / consumer kernel with one k-slice (or a few) per sample, split-operand
+        # products - measured against the per-(tile, sample) kernels below (us): 1344 x 224 @ 504 298 -> 186-class, 960 x 160 195 -> 74-class
+        G = ops.pw_conv_dyn_wgrad_b16(dz, x)
+        if G is not None:
+            return _bank_grad(G, att, bank.reshape(K, Co * Ci), datt)
     if ops.dyn_wgrad_needs_zero(Co, Ci, S):
         G = ops.zero_arena.zeros((B, Co * Ci), torch.float32, x.device)
     else:                                       # bf16x3 kernel in per-sample mode: plain stores
@@ -553,6 +559,7 @@ import os as _os
 _FUSED_BLOCK = True       # the dynamic block as one autograd Function (round 4; ablated blocks keep the per-layer Functions)
 _EPI_STATS = True         # BatchNorm statistics in the dynamic 1x1 convs' epilogue
 _FUSED_DW = _os.environ.get("EAT_DYMN_FUSED_DW", "1") != "0"      # A/B: the round-4 depthwise / DyReLU kernels of the block
+_WIDE_PS_WGRAD = _os.environ.get("EAT_DYMN_WIDE_WGRAD", "1") != "0"     # A/B: fp32 per-sample weight gradients on the wide-tile kernel
 _STORE16 = False          # set by forward_train for the pass: model.act_storage == "bf16" (the bf16-storage plan of the blocks)
 
 

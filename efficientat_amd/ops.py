@@ -1404,13 +1404,16 @@ def pw_conv_dyn_b16(x, wp_b, Co, act, res=None, stats=False):
 
 
 def pw_conv_dyn_wgrad_b16(dz, x):
-    """Per-sample weight gradients G (B, Co*Ci) = dz[b] x[b]^T with exactly one bf16 (wide) operand (`eat_pw_conv_dyn_wgrad_b16`);
-    every element is stored."""
+    """Per-sample weight gradients G (B, Co*Ci) = dz[b] x[b]^T on the wide-tile kernel (`eat_pw_conv_dyn_wgrad_b16`): one bf16
+    (wide) operand - plain bf16 products - or both fp32 - split-operand bf16x3 products; every element is stored.  None where
+    the kernel does not take an all-fp32 shape."""
     B, Co = dz.shape[0], dz.shape[1]
     Ci = x.shape[1]
     S = dz.numel() // (B * Co)
     d16, x16 = _is16(dz), _is16(x)
-    ns = int(_lib.lib().eat_pw_dyn_wgrad_b16_slices(B, Co, Ci, S, 1 if x16 else 0))
+    ns = int(_lib.lib().eat_pw_dyn_wgrad_b16_slices(B, Co, Ci, S, 1 if x16 else (0 if d16 else 2)))
+    if ns < 1:
+        return None                                 # (both fp32 and a shape the wide-tile kernel does not take: the caller's fallback)
     buf = torch.empty((ns, B, Co * Ci), device=dz.device, dtype=torch.float32)     # copy 0 = the result, the rest k-slice workspace
     _lib.call("eat_pw_conv_dyn_wgrad_b16", _dev16(dz, "dz") if d16 else _dev(dz, "dz"), 1 if d16 else 0,
               _dev16(x, "x") if x16 else _dev(x, "x"), 1 if x16 else 0, buf.data_ptr(), ns, B, Co, Ci, S, _stream())
