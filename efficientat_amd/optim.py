@@ -24,6 +24,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._spare = {}
         self._counters = {}
         self._captured = []
+        self._layouts = {}
 
     def _state(self, p, capturable):
         st = self.state[p]
@@ -45,21 +46,37 @@ class FusedAdam(torch.optim.Optimizer):
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached[1], cached[2]
-        recs = []
+        # the chunk layout depends on the parameters only: offsets / lengths / parameter and moment addresses are built once per
+        # parameter set, a rebuild (gradients at new addresses: an eager data-parallel step hands out a fresh bucket buffer
+        # every pass) only adds the gradients' base addresses - vectorised, no Python loop over ~1500 chunks
+        lay = self._layouts.get(gi)
+        pkey = tuple(k[0] for k in key)
+        if lay is None or lay[0] != pkey:
+            idx, offs, lens = [], [], []
+            for i, p in enumerate(ps):
+                st = self.state[p]
+                if p.dtype != torch.float32 or not p.is_cuda:
+                    raise _lib.EatHipError("FusedAdam: fp32 CUDA parameters and gradients only")
+                if not p.is_contiguous():
+                    raise _lib.EatHipError("FusedAdam: parameters and gradients must be contiguous")
+                n = p.numel()
+                o = np.arange(0, n, _CHUNK, dtype=np.int64)
+                idx.append(np.full(o.shape, i, dtype=np.int64))
+                offs.append(o)
+                lens.append(np.minimum(_CHUNK, n - o))
+            idx, offs, lens = np.concatenate(idx), np.concatenate(offs), np.concatenate(lens).astype(np.int32)
+            pb = np.array([p.data_ptr() for p in ps], dtype=np.uint64)[idx] + (4 * offs).astype(np.uint64)
+            mb = np.array([self.state[p]["exp_avg"].data_ptr() for p in ps], dtype=np.uint64)[idx] + (4 * offs).astype(np.uint64)
+            vb = np.array([self.state[p]["exp_avg_sq"].data_ptr() for p in ps], dtype=np.uint64)[idx] + (4 * offs).astype(np.uint64)
+            lay = self._layouts[gi] = (pkey, idx, (4 * offs).astype(np.uint64), lens, pb, mb, vb)
+        _, idx, boffs, lens, pb, mb, vb = lay
         for p in ps:
-            st = self.state[p]
-            g = p.grad
-            if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_cuda:
-                raise _lib.EatHipError("FusedAdam: fp32 CUDA parameters and gradients only")
-            if not (p.is_contiguous() and g.is_contiguous()):
-                raise _lib.EatHipError("FusedAdam: parameters and gradients must be contiguous")
-            n = p.numel()
-            for o in range(0, n, _CHUNK):
-                recs.append((p.data_ptr() + 4 * o, g.data_ptr() + 4 * o, st["exp_avg"].data_ptr() + 4 * o,
-                             st["exp_avg_sq"].data_ptr() + 4 * o, min(_CHUNK, n - o), 0))
-        tab = np.zeros((len(recs),), dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i4"), ("pad", "<i4")])
-        for i, r in enumerate(recs):
-            tab[i] = r
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise _lib.EatHipError("FusedAdam: fp32 contiguous gradients only")
+        gb = np.array([k[1] for k in key], dtype=np.uint64)[idx] + boffs
+        tab = np.zeros((lens.shape[0],), dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i4"), ("pad", "<i4")])
+        tab["p"], tab["g"], tab["m"], tab["v"], tab["n"] = pb, gb, mb, vb, lens
+        recs = tab
         raw = torch.from_numpy(tab.view(np.uint8).copy())
         if torch.cuda.is_current_stream_capturing():
             spare = self._spare.get(gi)
