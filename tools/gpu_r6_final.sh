@@ -15,6 +15,6 @@ head -5 $OUT/r6_rocprof_kernel_stats.csv | cut -c1-160
 find $OUT/stats2 -name "*kernel_stats.csv" -exec cp {} $OUT/r6_dymn20_bf16_rocprof_kernel_stats.csv \; ; rm -rf $OUT/stats2
 head -4 $OUT/r6_dymn20_bf16_rocprof_kernel_stats.csv | cut -c1-160
 # 4. the reference's unmodified scripts on the HIP path (n1)
-timeout -k 10 900 python tools/run_reference_scripts.py --ref $REF --commit 24b44eb --audio $REF/resources/metro_station-paris.wav --throughput --out $OUT/r6_reference_scripts.log > $OUT/refscripts.out 2>&1; tail -5 $OUT/refscripts.out; grep -c "^rc=0" $OUT/r6_reference_scripts.log
+timeout -k 10 900 python tools/run_reference_scripts.py --ref $REF --commit b2e26da --audio $REF/resources/metro_station-paris.wav --throughput --out $OUT/r6_reference_scripts.log > $OUT/refscripts.out 2>&1; tail -5 $OUT/refscripts.out; grep -c "^rc=0" $OUT/r6_reference_scripts.log
 # 5. entry-point profile of the dymn20 bf16 step
 MODEL=dymn20_bf16 EAT_PROF_ALL=eat_pw_conv_dyn_wgrad_b16,eat_dyn_pw_pack_b16,eat_dyn_bank_grad timeout -k 10 400 python tools/prof_dymn.py 128 2>&1 | grep -v amdgpu.ids > $OUT/r6_dymn20_bf16_train_step_entry_points.log; head -8 $OUT/r6_dymn20_bf16_train_step_entry_points.log
