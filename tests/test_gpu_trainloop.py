@@ -449,3 +449,27 @@ def test_mn_captured_step_reproduces_its_gradients_on_every_replay(prec, storage
             if e > worst[0]:
                 worst = (e, n)
         assert worst[0] < tol, (r, worst)
+
+
+@pytest.mark.parametrize("name", ["mn10", "mn40_bf16", "dymn20_bf16"])
+def test_training_steps_read_no_uninitialised_memory(name):
+    """tools/uninit_hunt.py in a child process: every `torch.empty` filled with NaN (torch.utils.deterministic.
+    fill_uninitialized_memory), three eager training steps and six replays of the captured step (graphs.GraphedTrainStep, the
+    fills are captured too: every replay re-poisons) - loss, gradients and parameters must stay finite.  A kernel that reads
+    what neither it nor its producer wrote - or an accumulator that is not re-zeroed on replay - turns this red on EVERY run
+    instead of in one fresh process out of twenty."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "uninit_hunt.py"), name, "8"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("step ", "graph step "))]
+    assert len(lines) == 9, r.stdout[-2000:]
+    for ln in lines:
+        assert "loss nan" not in ln and "loss inf" not in ln, ln
+        if ln.startswith("step "):                      # eager: "... non-finite grads 0 []; params 0 []"
+            assert "non-finite grads 0 []; params 0 []" in ln, ln
+        else:                                           # captured: "... non-finite params 0 []; grads []"
+            assert "non-finite params 0 []; grads []" in ln, ln
