@@ -719,3 +719,38 @@ def test_dymn20_train_step_bf16_storage_tracks_oracle(dymn20_case_t30):
     assert abs(loss.item() - float(loss_f)) < 2e-2 * abs(float(loss_f))
     assert float(np.median(hip_vs_f)) < 1.25 * float(np.median(emu_vs_f)) + 1e-2
     assert e_hf < 1.5 * e_ef + 1e-2 * scale, (e_hf, e_ef)
+
+
+# ------------------------------------------------------------------ configs[1] as bench.py times it: the captured forward
+@pytest.mark.parametrize("streams", [1, 2])
+def test_graphed_forward_reproduces_the_eager_forward_on_every_replay(mn10_b256, streams):
+    """`graphs.GraphedForward` (what bench.py's `forward` leg replays: log-mel + mn10 eval forward in one hipGraph, the batch cut
+    into `streams` sub-batches on concurrent HIP streams) against the eager forward of the same batch and against the oracle on
+    the parity clips - on the first replay, on later replays, and after the input buffer was rewritten (replays must not
+    depend on what a previous replay left behind)."""
+    from efficientat_amd.graphs import GraphedForward
+    d = mn10_b256
+    model = _quiet(mn_mod.get_model, width_mult=1.0)
+    model.load_state_dict(d["sd"], strict=True)
+    model.to(DEV).eval()
+    mel = _quiet(AugmentMelSTFT, freqm=0, timem=0).to(DEV).eval()
+    wave = d["wave"][:64].clone()
+    for i, s in enumerate([0, 1, 31, 32, 63]):
+        wave[s] = d["clips"][i]
+    wave = wave.to(DEV)
+    with torch.no_grad():
+        ref_l, ref_f = model(mel(wave).unsqueeze(1))
+    fwd = GraphedForward(model, mel, wave, streams=streams)
+    for r in range(3):
+        lg, ft = fwd()
+        torch.cuda.synchronize()
+        assert float((lg - ref_l).abs().max()) < 5e-5 and float((ft - ref_f).abs().max()) < 5e-5, (r, float((lg - ref_l).abs().max()))
+        assert float((lg[[0, 1, 31, 32, 63]].cpu() - d["ref"]).abs().max()) < 1e-3
+    # another batch through the same graph, then the first one again
+    w2 = torch.roll(wave, 7, dims=0)
+    with torch.no_grad():
+        ref2, _ = model(mel(w2).unsqueeze(1))
+    lg2, _ = fwd(w2)
+    assert float((lg2 - ref2).abs().max()) < 5e-5
+    lg3, _ = fwd(wave)
+    assert float((lg3 - ref_l).abs().max()) < 5e-5
